@@ -1,0 +1,128 @@
+/*
+ * mobgs_hip.h -- C ABI of libmobgs_hip.so, the MI355X (gfx950) Gaussian-splatting hot path for MoBGS.
+ *
+ * Boundary (level B3).  Each entry point replaces one stage of the third-party
+ * gsplat==1.4.0 operator pipeline that the reference drives from
+ *   /root/reference/gaussian_renderer/__init__.py:143-156   rasterization(...)        (and :163,201,236,255,274,
+ *                                                                                       379,437,456,473,538)
+ *   /root/reference/gaussian_renderer/__init__.py:190-199   fully_fused_projection(...) (and :411,422,513,524)
+ * plus the reference's own per-Gaussian / per-pixel torch glue on the same path:
+ *   /root/reference/gaussian_renderer/__init__.py:23-56     interpolate_cubic_hermite
+ *   /root/reference/gaussian_renderer/__init__.py:93-125    time offset, rotation, colour feature build
+ *   /root/reference/helper_model.py:19-28                   Sandwich colour decoder
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns every buffer (outputs and scratch); the library never allocates device memory and
+ *     keeps no mutable global state apart from the thread-local last-error string;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises;
+ *   - return value: 0 on success, negative MOBGS_E_* on failure (mobgs_last_error() gives the text);
+ *   - tensors are row-major contiguous float32 / int32 exactly as gsplat lays them out
+ *     (means [N,3], quats [N,4] wxyz, scales [N,3], viewmats [C,4,4] world->camera, Ks [C,3,3],
+ *      radii [C,N], means2d [C,N,2], depths [C,N], conics [C,N,3], colors [C,N,D] or [N,D],
+ *      images [C,H,W,D], alphas [C,H,W]);
+ *   - "tile" is a 16x16 pixel square (tile_size is fixed to 16 in this build, as every reference call site
+ *     uses gsplat's default); tiles are numbered cam*tile_h*tile_w + ty*tile_w + tx.
+ */
+#ifndef MOBGS_HIP_H
+#define MOBGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOBGS_OK 0
+#define MOBGS_E_INVALID (-1)   /* bad argument (size, channel count, null pointer)            */
+#define MOBGS_E_LAUNCH (-2)    /* hipLaunchKernel / hipMemsetAsync reported an error           */
+#define MOBGS_E_UNSUPPORTED (-3)
+
+#define MOBGS_TILE 16
+#define MOBGS_MAX_CHANNELS 32
+
+/* Library identification.  Returns e.g. "mobgs_hip 0.1 gfx950". */
+const char* mobgs_version(void);
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* mobgs_last_error(void);
+
+/* Number of floats in one packed splat record / gradient slot for `channels` colour channels:
+ * {x, y, conic_a, conic_b, conic_c, opacity, colour[channels]} rounded up to a multiple of 4. */
+int mobgs_record_stride(int channels);
+
+/* ---- K1: projection forward (replaces gsplat fully_fused_projection fwd) -------------------------------
+ * Also emits tiles_per_gauss[C,N] (number of 16x16 tiles the 3-sigma box touches; 0 when culled), which
+ * gsplat computes in isect_tiles' first pass.  Culled entries get radii=0 and zeros in the other outputs. */
+int mobgs_project_fwd(int C, int N, const float* means, const float* quats, const float* scales,
+                      const float* viewmats, const float* Ks, int width, int height, float eps2d,
+                      float near_plane, float far_plane, float radius_clip, int32_t* radii,
+                      float* means2d, float* depths, float* conics, int32_t* tiles_per_gauss,
+                      void* stream);
+
+/* ---- K2: projection backward (replaces gsplat fully_fused_projection bwd, incl. v_viewmats) ------------
+ * v_viewmats_partial: scratch [ceil(C*N/256), 16] floats; v_viewmats [C,4,4] is fully written.
+ * v_means/v_quats/v_scales are [N,3]/[N,4]/[N,3], summed over cameras, fully written by the call.
+ * Any of v_means2d / v_depths / v_conics may be NULL (treated as zeros). */
+size_t mobgs_project_bwd_scratch_floats(int C, int N);
+int mobgs_project_bwd(int C, int N, const float* means, const float* quats, const float* scales,
+                      const float* viewmats, const float* Ks, int width, int height, float eps2d,
+                      const int32_t* radii, const float* conics, const float* v_means2d,
+                      const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
+                      float* v_scales, float* v_viewmats, float* v_viewmats_partial, void* stream);
+
+/* ---- K3a: intersection offsets (replaces isect_tiles pass 1 + cumsum + isect_offset_encode) ------------
+ * in : tiles_per_gauss [C*N], means2d, radii
+ * out: cum_tiles [C*N+1] exclusive prefix sum (cum_tiles[C*N] = total intersections I)
+ *      tile_offsets [C*n_tiles+1] exclusive prefix sum of per-tile list lengths
+ *      stats[0] = I, stats[1] = longest per-tile list (int64 each) -- the caller reads these back to size
+ *      the intersection buffers (the one host sync of the pipeline, as in gsplat).
+ * scratch: mobgs_isect_scratch_bytes(C*N, C*n_tiles) bytes. */
+size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles);
+int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, const int32_t* tiles_per_gauss,
+                        const float* means2d, const int32_t* radii, int32_t* cum_tiles,
+                        int32_t* tile_offsets, int64_t* stats, void* scratch, void* stream);
+
+/* ---- K3b/K4: emit + per-tile depth sort (replaces isect_tiles pass 2 + CUB DeviceRadixSort) ------------
+ * Writes, per tile, its Gaussians ordered by (float depth bits ascending, flat id ascending) -- the order a
+ * stable LSD radix sort on gsplat's 64-bit key produces.
+ * out: flatten_ids [I] (cam*N+gaussian), isect_ids [I] (gsplat's u64 key; may be NULL)
+ * scratch: tile_cursor [C*n_tiles] int32 (zeroed by this call); sort_keys [I] u64.
+ * max_tile_len is stats[1] from mobgs_isect_offsets (selects the LDS sort variant). */
+int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int64_t n_isects, int64_t max_tile_len,
+                          const float* means2d, const int32_t* radii, const float* depths,
+                          const int32_t* cum_tiles, const int32_t* tile_offsets, int32_t* tile_cursor,
+                          uint64_t* sort_keys, int32_t* flatten_ids, uint64_t* isect_ids, void* stream);
+
+/* ---- K6: rasterise forward (replaces gsplat rasterize_to_pixels fwd) -----------------------------------
+ * colors   : [C,N,channels] (colors_per_camera=1) or [N,channels] (0)
+ * opacities: [C,N] (opac_per_camera=1) or [N] (0)
+ * extra    : optional [C,N] channel appended after `channels` (gsplat's "+D"/"+ED" depth channel), or NULL
+ * backgrounds: [C, channels(+1 if extra)] or NULL
+ * records  : scratch/out [C*N, mobgs_record_stride(D)] packed splat records (kept for backward), D = total
+ * out: render [C,H,W,D], alphas [C,H,W], last_ids [C,H,W] (index into flatten_ids of the last blended splat) */
+int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const float* means2d,
+                     const float* conics, const float* colors, int colors_per_camera,
+                     const float* opacities, int opac_per_camera, const float* extra,
+                     const float* backgrounds, const int32_t* radii, const int32_t* tile_offsets,
+                     const int32_t* flatten_ids, float* records, float* render, float* alphas,
+                     int32_t* last_ids, void* stream);
+
+/* ---- K7: rasterise backward (replaces gsplat rasterize_to_pixels bwd) ----------------------------------
+ * Deterministic two-stage gradient reduction: stage 1 writes one gradient record per (tile, splat)
+ * intersection into grad_slots [I, stride] (slot = cum_tiles[flat id] + position of the tile inside the
+ * splat's tile rectangle; the buffer must be zero-filled by the caller), stage 2 sums each splat's
+ * contiguous slots.  No floating-point atomics.
+ * out (fully written): v_means2d [C,N,2], v_conics [C,N,3], v_opacities [C,N], v_colors [C,N,channels],
+ *                      v_extra [C,N] (or NULL when extra was NULL). */
+int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int height,
+                     const float* records, const float* backgrounds, const int32_t* radii,
+                     const float* means2d, const int32_t* cum_tiles, const int32_t* tile_offsets,
+                     const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
+                     const float* v_render, const float* v_alphas, float* grad_slots, float* v_means2d,
+                     float* v_conics, float* v_opacities, float* v_colors, float* v_extra, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOBGS_HIP_H */

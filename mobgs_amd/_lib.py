@@ -1,0 +1,102 @@
+"""ctypes binding of libmobgs_hip.so (the C ABI declared in include/mobgs_hip.h).
+
+The product path has NO CPU fallback: if the library cannot be loaded, or a tensor is not on a HIP device,
+the call raises.  PyTorch is used only for device memory and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+import torch
+
+from .build import LIB_PATH, build_extension, is_stale
+
+_lib: Optional[ctypes.CDLL] = None
+
+P = c_void_p
+_SIGS = {
+    "mobgs_version": (c_char_p, []),
+    "mobgs_last_error": (c_char_p, []),
+    "mobgs_record_stride": (c_int, [c_int]),
+    "mobgs_raster_channels_supported": (c_int, [c_int]),
+    "mobgs_project_fwd": (c_int, [c_int, c_int, P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float,
+                                  P, P, P, P, P, P]),
+    "mobgs_project_bwd_scratch_floats": (c_size_t, [c_int, c_int]),
+    "mobgs_project_bwd": (c_int, [c_int, c_int, P, P, P, P, P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P,
+                                  P, P]),
+    "mobgs_isect_scratch_bytes": (c_size_t, [c_int, c_int]),
+    "mobgs_isect_offsets": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "mobgs_isect_emit_sort": (c_int, [c_int, c_int, c_int, c_int, c_int64, c_int64, P, P, P, P, P, P, P, P, P,
+                                      P]),
+    "mobgs_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, P,
+                                 P, P, P, P]),
+    "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
+                                 P, P, P, P, P, P]),
+}
+# entry points added by later translation units (bound if present in the header AND the library)
+_OPTIONAL_SIGS = {}
+
+
+def register_optional(name: str, restype, argtypes) -> None:
+    _OPTIONAL_SIGS[name] = (restype, argtypes)
+    if _lib is not None:
+        _bind(_lib, name, restype, argtypes)
+
+
+def _bind(lib, name, restype, argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+
+
+def load(build_if_missing: bool = True) -> ctypes.CDLL:
+    """Load (building first if the .so is missing or older than its sources and hipcc is available)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing and is_stale():
+        try:
+            build_extension()
+        except Exception as exc:  # noqa: BLE001
+            if not LIB_PATH.exists():
+                raise RuntimeError(
+                    f"libmobgs_hip.so is missing and could not be built ({exc}); the mobgs_amd product path "
+                    "has no CPU fallback") from exc
+    if not LIB_PATH.exists():
+        raise RuntimeError(f"{LIB_PATH} not found; run `python -m mobgs_amd.build`")
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (restype, argtypes) in {**_SIGS, **_OPTIONAL_SIGS}.items():
+        if name in _SIGS or hasattr(lib, name):
+            _bind(lib, name, restype, argtypes)
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().mobgs_last_error().decode()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a contiguous HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("mobgs_amd: tensors must live on a HIP device (device='cuda'); there is no CPU path")
+    if not t.is_contiguous():
+        raise RuntimeError("mobgs_amd: internal error, non-contiguous tensor passed to the C ABI")
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    """float32 + contiguous (no copy when already so)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

@@ -1,0 +1,70 @@
+"""Build libmobgs_hip.so (gfx950) in-tree with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the resulting .so is
+git-ignored but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = CSRC / "libmobgs_hip.so"
+SOURCES = ["project.hip", "isect.hip", "raster.hip", "prep.hip", "decoder.hip", "deform.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libmobgs_hip.so")
+
+
+def sources() -> list[Path]:
+    return [CSRC / s for s in SOURCES if (CSRC / s).exists()]
+
+
+def is_stale() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    deps = sources() + [CSRC / "common.h", CSRC.parent.parent / "include" / "mobgs_hip.h"]
+    return any(d.exists() and d.stat().st_mtime > t for d in deps)
+
+
+def build_extension(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not is_stale():
+        return LIB_PATH
+    objs = []
+    hipcc = _hipcc()
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+    procs = []
+    for src in sources():
+        obj = src.with_suffix(".o")
+        objs.append(obj)
+        if not force and obj.exists() and obj.stat().st_mtime > max(
+                src.stat().st_mtime, (CSRC / "common.h").stat().st_mtime,
+                (CSRC.parent.parent / "include" / "mobgs_hip.h").stat().st_mtime):
+            continue
+        cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB_PATH)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_extension(force="--force" in os.sys.argv, verbose=True))

@@ -1,0 +1,336 @@
+// K3-K5: tile intersection lists for gfx950 -- count, offsets, emit, per-tile depth sort.
+//
+// Replaces gsplat v1.4.0 isect_tiles (two passes) + CUB DeviceRadixSort::SortPairs + isect_offset_encode
+// [upstream, SURVEY.md Appendix A.2], which run inside every rasterization() call of the reference
+// (/root/reference/gaussian_renderer/__init__.py:143, :163, :201, :236, :255, :274, ...).
+//
+// MI355X design: instead of one global 64-bit radix sort over all I intersections (6-8 passes x 24 B x I
+// of HBM traffic), intersections are binned straight into tile-contiguous segments (one histogram pass,
+// one scatter pass, both load-balanced one-thread-per-intersection) and each tile's segment is sorted
+// inside LDS by a bitonic network on the 64-bit key (depth bits << 32 | flat splat id).  The key is
+// unique, so the unstable network reproduces exactly the order of upstream's stable radix sort:
+// ascending depth bits, ties by ascending splat index.
+#include "common.h"
+
+namespace mobgs {
+
+// ---------------------------------------------------------------------------------------------------
+// exclusive scan of int32 (3 launches: block sums, scan of sums, local scan + add)
+// ---------------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;  // 2048 ints per workgroup
+
+__device__ inline int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int n = __shfl_up(v, off, 64);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+
+// inclusive scan across the 256-thread workgroup; returns this thread's inclusive value, *total = block sum
+__device__ inline int block_incl_scan(int v, int* total) {
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int inc = wave_incl_scan(v, lane);
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) base += (k < wv) ? wsum[k] : 0;
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return inc + base;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_block_sums_kernel(int n, const int32_t* __restrict__ in,
+                                                                         int32_t* __restrict__ block_sums) {
+    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) s += (base + k < n) ? in[base + k] : 0;
+    int total;
+    block_incl_scan(s, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single workgroup: in-place exclusive scan of block_sums[nb]; writes the grand total to out_total[0]
+__global__ void __launch_bounds__(SCAN_THREADS) scan_sums_kernel(int nb, int32_t* __restrict__ block_sums,
+                                                                   int32_t* __restrict__ out_last,
+                                                                   int64_t* __restrict__ stats0) {
+    int carry = 0;
+    for (int start = 0; start < nb; start += SCAN_THREADS) {
+        const int i = start + threadIdx.x;
+        const int v = (i < nb) ? block_sums[i] : 0;
+        int total;
+        const int inc = block_incl_scan(v, &total);
+        if (i < nb) block_sums[i] = carry + inc - v;
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        *out_last = carry;
+        if (stats0) *stats0 = (int64_t)carry;
+    }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(int n, const int32_t* __restrict__ in,
+                                                                    const int32_t* __restrict__ block_sums,
+                                                                    int32_t* __restrict__ out) {
+    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    int total;
+    const int inc = block_incl_scan(s, &total);
+    int run = block_sums[blockIdx.x] + inc - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one thread per intersection: owner lookup (binary search in cum_tiles) + tile id
+// ---------------------------------------------------------------------------------------------------
+__device__ inline int owner_of(const int32_t* __restrict__ cum, int n, int j) {
+    // largest g in [0,n) with cum[g] <= j   (cum is non-decreasing, cum[n] = I > j)
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cum[mid] <= j)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__device__ inline int tile_of(int j, int g, int N, int tile_w, int tile_h, const int32_t* __restrict__ cum,
+                              const float* __restrict__ means2d, const int32_t* __restrict__ radii) {
+    const float2 m = reinterpret_cast<const float2*>(means2d)[g];
+    const TileRect tr = tile_rect(m.x, m.y, radii[g], tile_w, tile_h);
+    const int k = j - cum[g];
+    const int w = tr.x1 - tr.x0;
+    const int ty = tr.y0 + k / w, tx = tr.x0 + k % w;
+    const int cam = g / N;
+    return (cam * tile_h + ty) * tile_w + tx;
+}
+
+__global__ void __launch_bounds__(256) tile_hist_kernel(int n_gauss, int N, int tile_w, int tile_h,
+                                                          const int32_t* __restrict__ cum,
+                                                          const float* __restrict__ means2d,
+                                                          const int32_t* __restrict__ radii,
+                                                          int32_t* __restrict__ tile_count) {
+    const int I = cum[n_gauss];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < I; j += gridDim.x * blockDim.x) {
+        const int g = owner_of(cum, n_gauss, j);
+        const int t = tile_of(j, g, N, tile_w, tile_h, cum, means2d, radii);
+        atomicAdd(&tile_count[t], 1);
+    }
+}
+
+// single workgroup: exclusive scan of tile_count[nt] -> tile_offsets[nt+1]; stats[1] = max count
+__global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(int nt, const int32_t* __restrict__ tile_count,
+                                                                   int32_t* __restrict__ tile_offsets,
+                                                                   int64_t* __restrict__ stats) {
+    __shared__ int smax[SCAN_THREADS];
+    int carry = 0, mx = 0;
+    for (int start = 0; start < nt; start += SCAN_THREADS) {
+        const int i = start + threadIdx.x;
+        const int v = (i < nt) ? tile_count[i] : 0;
+        mx = max(mx, v);
+        int total;
+        const int inc = block_incl_scan(v, &total);
+        if (i < nt) tile_offsets[i] = carry + inc - v;
+        carry += total;
+    }
+    smax[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = SCAN_THREADS / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) smax[threadIdx.x] = max(smax[threadIdx.x], smax[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tile_offsets[nt] = carry;
+        stats[1] = (int64_t)smax[0];
+    }
+}
+
+__global__ void __launch_bounds__(256) emit_kernel(int n_gauss, int N, int tile_w, int tile_h,
+                                                     const int32_t* __restrict__ cum,
+                                                     const float* __restrict__ means2d,
+                                                     const int32_t* __restrict__ radii,
+                                                     const float* __restrict__ depths,
+                                                     const int32_t* __restrict__ tile_offsets,
+                                                     int32_t* __restrict__ tile_cursor,
+                                                     uint64_t* __restrict__ sort_keys) {
+    const int I = cum[n_gauss];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < I; j += gridDim.x * blockDim.x) {
+        const int g = owner_of(cum, n_gauss, j);
+        const int t = tile_of(j, g, N, tile_w, tile_h, cum, means2d, radii);
+        const int r = atomicAdd(&tile_cursor[t], 1);
+        const uint32_t db = __float_as_uint(depths[g]);
+        sort_keys[(size_t)tile_offsets[t] + r] = ((uint64_t)db << 32) | (uint32_t)g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-tile bitonic sort ("mirror" formulation: every compare-exchange is ascending, so elements past the
+// end behave as +inf without being stored and any n works)
+// ---------------------------------------------------------------------------------------------------
+template <typename PTR>
+__device__ inline void bitonic_sort(PTR a, int n, int nthreads) {
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    const int half = n2 >> 1;
+    for (int k = 2; k <= n2; k <<= 1) {
+        // mirror step
+        const int hk = k >> 1;
+        for (int i = threadIdx.x; i < half; i += nthreads) {
+            const int blk = i / hk, l = i - blk * hk;
+            const int lo = blk * k + l, hi = blk * k + (k - 1 - l);
+            if (hi < n) {
+                const uint64_t x = a[lo], y = a[hi];
+                if (x > y) {
+                    a[lo] = y;
+                    a[hi] = x;
+                }
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j >= 1; j >>= 1) {
+            for (int i = threadIdx.x; i < half; i += nthreads) {
+                const int blk = i / j, l = i - blk * j;
+                const int lo = blk * 2 * j + l, hi = lo + j;
+                if (hi < n) {
+                    const uint64_t x = a[lo], y = a[hi];
+                    if (x > y) {
+                        a[lo] = y;
+                        a[hi] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) tile_sort_kernel(int n_tiles_total, int lds_cap, int tile_bits,
+                                                              const int32_t* __restrict__ tile_offsets,
+                                                              uint64_t* __restrict__ sort_keys,
+                                                              int32_t* __restrict__ flatten_ids,
+                                                              uint64_t* __restrict__ isect_ids, int tiles_per_cam) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_keys[];
+    const int t = blockIdx.x;
+    if (t >= n_tiles_total) return;
+    const int s = tile_offsets[t], e = tile_offsets[t + 1];
+    const int n = e - s;
+    if (n <= 0) return;
+    uint64_t* seg = sort_keys + s;
+    const int cam = t / tiles_per_cam, tl = t - cam * tiles_per_cam;
+    const uint64_t hi_bits = (((uint64_t)cam << tile_bits) | (uint64_t)tl) << 32;
+    if (n <= lds_cap) {
+        for (int i = threadIdx.x; i < n; i += THREADS) lds_keys[i] = seg[i];
+        __syncthreads();
+        if (n > 1) bitonic_sort(lds_keys, n, THREADS);
+        for (int i = threadIdx.x; i < n; i += THREADS) {
+            const uint64_t k = lds_keys[i];
+            flatten_ids[s + i] = (int32_t)(uint32_t)k;
+            if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+        }
+    } else {
+        // pathological tile: sort in place in global memory (same workgroup, barrier-ordered)
+        bitonic_sort(seg, n, THREADS);
+        for (int i = threadIdx.x; i < n; i += THREADS) {
+            const uint64_t k = seg[i];
+            flatten_ids[s + i] = (int32_t)(uint32_t)k;
+            if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+        }
+    }
+}
+
+}  // namespace mobgs
+
+using namespace mobgs;
+
+extern "C" {
+
+size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles) {
+    const size_t nb = (size_t)(n_gauss + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
+    return sizeof(int32_t) * (nb + (size_t)n_tiles + 16);
+}
+
+int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, const int32_t* tiles_per_gauss,
+                        const float* means2d, const int32_t* radii, int32_t* cum_tiles, int32_t* tile_offsets,
+                        int64_t* stats, void* scratch, void* stream) {
+    const long long ng = (long long)C * N;
+    const long long nt = (long long)C * tile_w * tile_h;
+    if (C <= 0 || N < 0 || ng >= (1ll << 31) - 1 || nt >= (1ll << 31) - 1) {
+        set_error("mobgs_isect_offsets: bad sizes C=%d N=%d tiles=%dx%d", C, N, tile_w, tile_h);
+        return MOBGS_E_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int n = (int)ng;
+    const int nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    int32_t* block_sums = (int32_t*)scratch;
+    int32_t* tile_count = block_sums + nb + 1;
+    hipMemsetAsync(tile_count, 0, sizeof(int32_t) * nt, st);
+    if (n == 0) {
+        hipMemsetAsync(cum_tiles, 0, sizeof(int32_t), st);
+        hipMemsetAsync(stats, 0, 2 * sizeof(int64_t), st);
+        hipMemsetAsync(tile_offsets, 0, sizeof(int32_t) * (nt + 1), st);
+        return check_launch("isect_offsets(empty)");
+    }
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, n, tiles_per_gauss, block_sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, nb, block_sums, cum_tiles + n, stats);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, n, tiles_per_gauss, block_sums,
+                       cum_tiles);
+    hipLaunchKernelGGL(tile_hist_kernel, dim3(2048), dim3(256), 0, st, n, N, tile_w, tile_h, cum_tiles, means2d,
+                       radii, tile_count);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, (int)nt, tile_count, tile_offsets,
+                       stats);
+    return check_launch("isect_offsets");
+}
+
+int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int64_t n_isects, int64_t max_tile_len,
+                          const float* means2d, const int32_t* radii, const float* depths,
+                          const int32_t* cum_tiles, const int32_t* tile_offsets, int32_t* tile_cursor,
+                          uint64_t* sort_keys, int32_t* flatten_ids, uint64_t* isect_ids, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles_per_cam = tile_w * tile_h;
+    const int nt = C * tiles_per_cam;
+    if (n_isects < 0 || n_isects >= (1ll << 31) - 1 || max_tile_len < 0) {
+        set_error("mobgs_isect_emit_sort: n_isects=%lld out of range", (long long)n_isects);
+        return MOBGS_E_INVALID;
+    }
+    if (n_isects == 0) return MOBGS_OK;
+    hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * nt, st);
+    const int n = C * N;
+    int grid = (int)((n_isects + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(256), 0, st, n, N, tile_w, tile_h, cum_tiles, means2d, radii,
+                       depths, tile_offsets, tile_cursor, sort_keys);
+    // gsplat: tile_n_bits = floor(log2(n_tiles)) + 1
+    int tile_bits = 0;
+    while ((1ll << tile_bits) <= (long long)tiles_per_cam) ++tile_bits;
+    if (max_tile_len <= 4096) {
+        const int cap = 4096;
+        hipLaunchKernelGGL(tile_sort_kernel<256>, dim3(nt), dim3(256), cap * sizeof(uint64_t), st, nt, cap, tile_bits,
+                           tile_offsets, sort_keys, flatten_ids, isect_ids, tiles_per_cam);
+    } else {
+        const int cap = 16384;  // 128 KiB of the 160 KiB LDS; longer lists fall back to global memory
+        hipLaunchKernelGGL(tile_sort_kernel<1024>, dim3(nt), dim3(1024), cap * sizeof(uint64_t), st, nt, cap,
+                           tile_bits, tile_offsets, sort_keys, flatten_ids, isect_ids, tiles_per_cam);
+    }
+    return check_launch("isect_emit_sort");
+}
+
+}  // extern "C"

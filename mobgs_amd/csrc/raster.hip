@@ -1,0 +1,504 @@
+// K6 / K7: front-to-back alpha compositing of depth-sorted splats, forward and backward, for gfx950.
+//
+// Semantics follow gsplat v1.4.0 rasterize_to_pixels_{fwd,bwd}.cu [upstream, SURVEY.md Appendix A.3/A.4],
+// reached from the reference through rasterization() at
+// /root/reference/gaussian_renderer/__init__.py:143,163,201,236,255,274,379,437,456,473,538.
+//
+// MI355X mapping (not upstream's 256-thread block per tile):
+//   * one 64-lane wavefront owns one 16x16 tile; every lane carries 4 pixels (rows r, r+4, r+8, r+12 of
+//     column lane&15), so per-splat uniform work (record fetch, loop control, early-out votes) is amortised
+//     over 256 pixel evaluations and no workgroup barrier exists anywhere in the kernels;
+//   * splats are staged 64 at a time (lane = splat) as packed 16-float records
+//     {x, y, conic a b c, opacity, colour[..]} into a per-wave LDS slab and re-read as broadcasts;
+//   * backward reduces the 6+D per-splat gradient components across the wave with a halving butterfly
+//     (log-depth, D+6 -> 1 value per lane) and writes ONE 64-byte gradient record per (tile, splat) into a
+//     slot owned by that intersection; a second streaming kernel sums each splat's contiguous slots.
+//     No floating-point atomics => bit-reproducible gradients.
+#include <type_traits>
+
+#include "common.h"
+
+namespace mobgs {
+
+constexpr float ALPHA_MIN = 1.f / 255.f;
+constexpr float ALPHA_MAX = 0.999f;
+constexpr float T_STOP = 1e-4f;
+constexpr int PPL = 4;            // pixels per lane
+constexpr int TILES_PER_WG = 4;   // waves per workgroup, each on its own tile
+
+__device__ inline void wave_lds_fence() {
+    // LDS operations of one wave execute in issue order; only the compiler has to be told
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sigma / visibility / alpha of one splat at one pixel; the same instruction sequence in fwd and bwd
+struct Eval {
+    float dx, dy, vis, alpha;
+    bool pass;
+};
+__device__ __forceinline__ Eval eval_splat(float gx, float gy, float ca, float cb, float cc, float op, float px,
+                                           float py) {
+    Eval e;
+    e.dx = gx - px;
+    e.dy = gy - py;
+    const float sigma = __fmaf_rn(0.5f, __fmaf_rn(ca * e.dx, e.dx, cc * e.dy * e.dy), cb * e.dx * e.dy);
+    e.vis = __expf(-sigma);
+    e.alpha = fminf(ALPHA_MAX, op * e.vis);
+    e.pass = !(sigma < 0.f || e.alpha < ALPHA_MIN);
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pack: gather the per-splat inputs of the compositor into one aligned record
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+pack_records_kernel(int N, int channels, int stride, const float* __restrict__ means2d,
+                    const float* __restrict__ conics, const float* __restrict__ colors, int colors_per_camera,
+                    const float* __restrict__ opacities, int opac_per_camera, const float* __restrict__ extra,
+                    const int32_t* __restrict__ radii, float* __restrict__ records) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (i >= N) return;
+    const size_t o = (size_t)c * N + i;
+    if (radii[o] <= 0) return;  // culled splats are never referenced by a tile list
+    float* r = records + o * stride;
+    const float2 m = reinterpret_cast<const float2*>(means2d)[o];
+    const float op = opacities[opac_per_camera ? o : (size_t)i];
+    reinterpret_cast<float4*>(r)[0] = make_float4(m.x, m.y, conics[3 * o], conics[3 * o + 1]);
+    const float* col = colors + (colors_per_camera ? o : (size_t)i) * channels;
+    const int D = channels + (extra ? 1 : 0);
+    float buf[4] = {conics[3 * o + 2], op, 0.f, 0.f};
+    int fill = 2;
+    int q = 1;
+    for (int k = 0; k < D; ++k) {
+        buf[fill++] = (k < channels) ? col[k] : extra[o];
+        if (fill == 4) {
+            reinterpret_cast<float4*>(r)[q++] = make_float4(buf[0], buf[1], buf[2], buf[3]);
+            fill = 0;
+            buf[0] = buf[1] = buf[2] = buf[3] = 0.f;
+        }
+    }
+    if (fill > 0) reinterpret_cast<float4*>(r)[q++] = make_float4(buf[0], buf[1], buf[2], buf[3]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+template <int CD>
+__global__ void __launch_bounds__(64 * TILES_PER_WG)
+raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
+                  const float* __restrict__ records, const float* __restrict__ backgrounds,
+                  const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+                  float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids) {
+    constexpr int RS = (6 + CD + 3) & ~3;
+    constexpr int RQ = RS / 4;
+    __shared__ float4 slab[TILES_PER_WG][64][RQ];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int group = xcd_chunked(blockIdx.x, n_groups);
+    if (group >= n_groups) return;
+    const int tile = group * TILES_PER_WG + wv;
+    if (tile >= n_tiles_total) return;
+    const int tiles_per_cam = tile_w * tile_h;
+    const int cam = tile / tiles_per_cam;
+    const int tl = tile - cam * tiles_per_cam;
+    const int ty = tl / tile_w, tx = tl - ty * tile_w;
+    const int pxi = tx * MOBGS_TILE + (lane & 15);
+    const int pyi0 = ty * MOBGS_TILE + (lane >> 4);
+    const float px = (float)pxi + 0.5f;
+    float py[PPL];
+    unsigned done = 0;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+        py[k] = (float)(pyi0 + 4 * k) + 0.5f;
+        if (!(pxi < width && (pyi0 + 4 * k) < height)) done |= 1u << k;
+    }
+    const unsigned outside = done;
+
+    const int s = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
+    const int e = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
+
+    float T[PPL];
+    float acc[PPL][CD];
+    int last[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+        T[k] = 1.f;
+        last[k] = 0;
+#pragma unroll
+        for (int c = 0; c < CD; ++c) acc[k][c] = 0.f;
+    }
+
+    // software pipeline: the records of batch b+1 are fetched into registers while batch b is blended
+    float4 pre[RQ];
+    auto fetch = [&](int b) {
+        const int idx = b + lane;
+        if (idx < e) {
+            const int g = flatten_ids[idx];
+            const float4* r = reinterpret_cast<const float4*>(records + (size_t)g * RS);
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) pre[q] = r[q];
+        }
+    };
+    if (s < e) fetch(s);
+    bool all_done = false;
+    for (int b = s; b < e && !all_done; b += 64) {
+        const int n = min(64, e - b);
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) slab[wv][lane][q] = pre[q];
+        wave_lds_fence();
+        if (b + 64 < e) fetch(b + 64);
+        for (int j = 0; j < n; ++j) {
+            float rec[RS];
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const float4 v = slab[wv][j][q];
+                rec[4 * q] = v.x;
+                rec[4 * q + 1] = v.y;
+                rec[4 * q + 2] = v.z;
+                rec[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                const Eval ev = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px, py[k]);
+                if (ev.pass && !((done >> k) & 1u)) {
+                    const float nT = T[k] * (1.f - ev.alpha);
+                    if (nT <= T_STOP) {
+                        done |= 1u << k;
+                    } else {
+                        const float w = ev.alpha * T[k];
+#pragma unroll
+                        for (int c = 0; c < CD; ++c) acc[k][c] = __fmaf_rn(rec[6 + c], w, acc[k][c]);
+                        last[k] = b + j;
+                        T[k] = nT;
+                    }
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(done != 0xFu) == 0ull) {
+                all_done = true;
+                break;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+        if ((outside >> k) & 1u) continue;
+        const size_t pix = ((size_t)cam * height + (pyi0 + 4 * k)) * width + pxi;
+        alphas[pix] = 1.f - T[k];
+        last_ids[pix] = last[k];
+        float* out = render + pix * CD;
+#pragma unroll
+        for (int c = 0; c < CD; ++c) {
+            float v = acc[k][c];
+            if (backgrounds) v = __fmaf_rn(T[k], backgrounds[cam * CD + c], v);
+            out[c] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward, stage 1: per-(tile, splat) gradient records
+// ---------------------------------------------------------------------------------------------------
+template <int NVP>
+__device__ __forceinline__ float butterfly_reduce(float (&v)[NVP], int lane) {
+    // after the halving steps lane l holds component (l & (NVP-1)) summed over its NVP-lane group
+#pragma unroll
+    for (int m = NVP / 2; m >= 1; m >>= 1) {
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+            const float keep = up ? v[m + i] : v[i];
+            const float send = up ? v[i] : v[m + i];
+            v[i] = keep + __shfl_xor(send, m, 64);
+        }
+    }
+    float r = v[0];
+#pragma unroll
+    for (int b = NVP; b < 64; b <<= 1) r += __shfl_xor(r, b, 64);
+    return r;
+}
+
+template <int CD>
+__global__ void __launch_bounds__(64 * TILES_PER_WG)
+raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
+                  const float* __restrict__ records, const float* __restrict__ backgrounds,
+                  const int32_t* __restrict__ radii, const int32_t* __restrict__ cum_tiles,
+                  const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+                  const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
+                  const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+                  float* __restrict__ grad_slots) {
+    constexpr int RS = (6 + CD + 3) & ~3;
+    constexpr int RQ = RS / 4;
+    constexpr int NV = 6 + CD;
+    constexpr int NVP = NV <= 8 ? 8 : (NV <= 16 ? 16 : (NV <= 32 ? 32 : 64));
+    __shared__ float4 slab[TILES_PER_WG][64][RQ];
+    __shared__ int slot_of[TILES_PER_WG][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int group = xcd_chunked(blockIdx.x, n_groups);
+    if (group >= n_groups) return;
+    const int tile = group * TILES_PER_WG + wv;
+    if (tile >= n_tiles_total) return;
+    const int tiles_per_cam = tile_w * tile_h;
+    const int cam = tile / tiles_per_cam;
+    const int tl = tile - cam * tiles_per_cam;
+    const int ty = tl / tile_w, tx = tl - ty * tile_w;
+    const int pxi = tx * MOBGS_TILE + (lane & 15);
+    const int pyi0 = ty * MOBGS_TILE + (lane >> 4);
+    const float px = (float)pxi + 0.5f;
+
+    const int s = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
+    const int e = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
+    if (e <= s) return;
+
+    float py[PPL], T[PPL], Tf[PPL], va[PPL], bgdot[PPL];
+    float vo[PPL][CD], buf[PPL][CD];
+    int binf[PPL];
+    int top = -1;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+        const int pyi = pyi0 + 4 * k;
+        py[k] = (float)pyi + 0.5f;
+        const bool inside = pxi < width && pyi < height;
+        binf[k] = -1;  // pixels outside the image never become valid
+        Tf[k] = 1.f;
+        va[k] = 0.f;
+        bgdot[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CD; ++c) {
+            vo[k][c] = 0.f;
+            buf[k][c] = 0.f;
+        }
+        if (inside) {
+            const size_t pix = ((size_t)cam * height + pyi) * width + pxi;
+            binf[k] = last_ids[pix];
+            Tf[k] = 1.f - render_alphas[pix];
+            va[k] = v_alphas ? v_alphas[pix] : 0.f;
+            const float* vr = v_render + pix * CD;
+#pragma unroll
+            for (int c = 0; c < CD; ++c) vo[k][c] = vr[c];
+            if (backgrounds) {
+#pragma unroll
+                for (int c = 0; c < CD; ++c) bgdot[k] = __fmaf_rn(backgrounds[cam * CD + c], vo[k][c], bgdot[k]);
+            }
+            top = max(top, binf[k]);
+        }
+        T[k] = Tf[k];
+    }
+    // highest list index any pixel of the tile blended
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
+    top = min(top, e - 1);
+
+    for (int hi = top; hi >= s; hi -= 64) {
+        const int n = min(64, hi - s + 1);
+        wave_lds_fence();
+        if (lane < n) {
+            const int g = flatten_ids[hi - lane];
+            const float4* r = reinterpret_cast<const float4*>(records + (size_t)g * RS);
+            float4 r0 = r[0];
+            slab[wv][lane][0] = r0;
+#pragma unroll
+            for (int q = 1; q < RQ; ++q) slab[wv][lane][q] = r[q];
+            const TileRect tr = tile_rect(r0.x, r0.y, radii[g], tile_w, tile_h);
+            slot_of[wv][lane] = cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0);
+        }
+        wave_lds_fence();
+        for (int j = 0; j < n; ++j) {
+            const int idx = hi - j;
+            float rec[RS];
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const float4 v = slab[wv][j][q];
+                rec[4 * q] = v.x;
+                rec[4 * q + 1] = v.y;
+                rec[4 * q + 2] = v.z;
+                rec[4 * q + 3] = v.w;
+            }
+            Eval ev[PPL];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                ev[k] = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px, py[k]);
+                ev[k].pass = ev[k].pass && (idx <= binf[k]);
+                any = any || ev[k].pass;
+            }
+            if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
+            float g[NVP];
+#pragma unroll
+            for (int i = 0; i < NVP; ++i) g[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                if (!ev[k].pass) continue;
+                const float alpha = ev[k].alpha;
+                const float ra = 1.f / (1.f - alpha);
+                T[k] *= ra;
+                const float fac = alpha * T[k];
+                float v_alpha = 0.f;
+#pragma unroll
+                for (int c = 0; c < CD; ++c) {
+                    g[6 + c] = __fmaf_rn(fac, vo[k][c], g[6 + c]);
+                    v_alpha = __fmaf_rn(rec[6 + c] * T[k] - buf[k][c] * ra, vo[k][c], v_alpha);
+                }
+                v_alpha += Tf[k] * ra * va[k];
+                if (backgrounds) v_alpha -= Tf[k] * ra * bgdot[k];
+                const float ov = rec[5] * ev[k].vis;
+                if (ov <= ALPHA_MAX) {
+                    const float v_sigma = -ov * v_alpha;
+                    const float dx = ev[k].dx, dy = ev[k].dy;
+                    g[0] = __fmaf_rn(v_sigma, rec[2] * dx + rec[3] * dy, g[0]);
+                    g[1] = __fmaf_rn(v_sigma, rec[3] * dx + rec[4] * dy, g[1]);
+                    g[2] = __fmaf_rn(0.5f * v_sigma * dx, dx, g[2]);
+                    g[3] = __fmaf_rn(v_sigma * dx, dy, g[3]);
+                    g[4] = __fmaf_rn(0.5f * v_sigma * dy, dy, g[4]);
+                    g[5] = __fmaf_rn(ev[k].vis, v_alpha, g[5]);
+                }
+#pragma unroll
+                for (int c = 0; c < CD; ++c) buf[k][c] = __fmaf_rn(rec[6 + c], fac, buf[k][c]);
+            }
+            const float r = butterfly_reduce<NVP>(g, lane);
+            if (lane < RS) grad_slots[(size_t)slot_of[wv][j] * RS + lane] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward, stage 2: per-splat sum of its slots -> dense gradient tensors
+// ---------------------------------------------------------------------------------------------------
+template <int LPG>  // lanes per splat, >= record stride
+__global__ void __launch_bounds__(256)
+slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, const int32_t* __restrict__ cum_tiles,
+                   const float* __restrict__ grad_slots, float* __restrict__ v_means2d,
+                   float* __restrict__ v_conics, float* __restrict__ v_opacities, float* __restrict__ v_colors,
+                   float* __restrict__ v_extra) {
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPG;
+    const int comp = threadIdx.x % LPG;
+    if (gid >= n_gauss) return;
+    const int a = cum_tiles[gid], b = cum_tiles[gid + 1];
+    float acc = 0.f;
+    if (comp < stride) {
+        const float* p = grad_slots + (size_t)a * stride + comp;
+        for (int k = a; k < b; ++k, p += stride) acc += *p;
+    }
+    const size_t g = (size_t)gid;
+    if (comp < 2)
+        v_means2d[2 * g + comp] = acc;
+    else if (comp < 5)
+        v_conics[3 * g + (comp - 2)] = acc;
+    else if (comp == 5)
+        v_opacities[g] = acc;
+    else if (comp - 6 < channels)
+        v_colors[g * channels + (comp - 6)] = acc;
+    else if (has_extra && comp - 6 == channels)
+        v_extra[g] = acc;
+}
+
+// supported total channel counts (compile-time accumulators); other counts are zero-padded by the host wrapper
+template <typename F>
+inline int dispatch_channels(int D, F&& f) {
+    switch (D) {
+        case 1: f(std::integral_constant<int, 1>{}); return MOBGS_OK;
+        case 2: f(std::integral_constant<int, 2>{}); return MOBGS_OK;
+        case 3: f(std::integral_constant<int, 3>{}); return MOBGS_OK;
+        case 4: f(std::integral_constant<int, 4>{}); return MOBGS_OK;
+        case 9: f(std::integral_constant<int, 9>{}); return MOBGS_OK;
+        case 10: f(std::integral_constant<int, 10>{}); return MOBGS_OK;
+        case 16: f(std::integral_constant<int, 16>{}); return MOBGS_OK;
+        case 26: f(std::integral_constant<int, 26>{}); return MOBGS_OK;
+        default: return MOBGS_E_UNSUPPORTED;
+    }
+}
+
+}  // namespace mobgs
+
+using namespace mobgs;
+
+extern "C" {
+
+int mobgs_raster_channels_supported(int D) {
+    return D == 1 || D == 2 || D == 3 || D == 4 || D == 9 || D == 10 || D == 16 || D == 26;
+}
+
+int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const float* means2d,
+                     const float* conics, const float* colors, int colors_per_camera, const float* opacities,
+                     int opac_per_camera, const float* extra, const float* backgrounds, const int32_t* radii,
+                     const int32_t* tile_offsets, const int32_t* flatten_ids, float* records, float* render,
+                     float* alphas, int32_t* last_ids, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int D = channels + (extra ? 1 : 0);
+    if (C <= 0 || N < 0 || channels < 0 || D < 1 || width <= 0 || height <= 0) {
+        set_error("mobgs_raster_fwd: bad sizes C=%d N=%d channels=%d W=%d H=%d", C, N, channels, width, height);
+        return MOBGS_E_INVALID;
+    }
+    const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
+    const int nt = C * tile_w * tile_h;
+    const int stride = record_stride(D);
+    if (N > 0) {
+        hipLaunchKernelGGL(pack_records_kernel, dim3((N + 255) / 256, C), dim3(256), 0, st, N, channels, stride,
+                           means2d, conics, colors, colors_per_camera, opacities, opac_per_camera, extra, radii,
+                           records);
+    }
+    const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
+    const int grid = ((n_groups + 7) / 8) * 8;
+    const int rc = dispatch_channels(D, [&](auto cd) {
+        constexpr int CD = decltype(cd)::value;
+        hipLaunchKernelGGL(raster_fwd_kernel<CD>, dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups, tile_w,
+                           tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render, alphas,
+                           last_ids);
+    });
+    if (rc != MOBGS_OK) {
+        set_error("mobgs_raster_fwd: %d total channels not compiled in (pad to a supported count)", D);
+        return rc;
+    }
+    return check_launch("raster_fwd_kernel");
+}
+
+int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int height, const float* records,
+                     const float* backgrounds, const int32_t* radii, const float* means2d,
+                     const int32_t* cum_tiles, const int32_t* tile_offsets, const int32_t* flatten_ids,
+                     const float* render_alphas, const int32_t* last_ids, const float* v_render,
+                     const float* v_alphas, float* grad_slots, float* v_means2d, float* v_conics,
+                     float* v_opacities, float* v_colors, float* v_extra, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    (void)means2d;
+    const int D = channels + (has_extra ? 1 : 0);
+    if (C <= 0 || N < 0 || D < 1) {
+        set_error("mobgs_raster_bwd: bad sizes C=%d N=%d channels=%d", C, N, channels);
+        return MOBGS_E_INVALID;
+    }
+    const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
+    const int nt = C * tile_w * tile_h;
+    const int stride = record_stride(D);
+    const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
+    const int grid = ((n_groups + 7) / 8) * 8;
+    const int rc = dispatch_channels(D, [&](auto cd) {
+        constexpr int CD = decltype(cd)::value;
+        hipLaunchKernelGGL(raster_bwd_kernel<CD>, dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups, tile_w,
+                           tile_h, width, height, records, backgrounds, radii, cum_tiles, tile_offsets, flatten_ids,
+                           render_alphas, last_ids, v_render, v_alphas, grad_slots);
+    });
+    if (rc != MOBGS_OK) {
+        set_error("mobgs_raster_bwd: %d total channels not compiled in", D);
+        return rc;
+    }
+    const int n = C * N;
+    if (n > 0) {
+        if (stride <= 8) {
+            hipLaunchKernelGGL(slot_reduce_kernel<8>, dim3((n * 8 + 255) / 256), dim3(256), 0, st, n, channels,
+                               has_extra, stride, cum_tiles, grad_slots, v_means2d, v_conics, v_opacities, v_colors,
+                               v_extra);
+        } else if (stride <= 16) {
+            hipLaunchKernelGGL(slot_reduce_kernel<16>, dim3((int)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, n,
+                               channels, has_extra, stride, cum_tiles, grad_slots, v_means2d, v_conics, v_opacities,
+                               v_colors, v_extra);
+        } else {
+            hipLaunchKernelGGL(slot_reduce_kernel<32>, dim3((int)(((size_t)n * 32 + 255) / 256)), dim3(256), 0, st, n,
+                               channels, has_extra, stride, cum_tiles, grad_slots, v_means2d, v_conics, v_opacities,
+                               v_colors, v_extra);
+        }
+    }
+    return check_launch("raster_bwd_kernel");
+}
+
+}  // extern "C"

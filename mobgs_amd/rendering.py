@@ -1,0 +1,327 @@
+"""Operator API (boundary B2): drop-in for `gsplat.rendering` as MoBGS uses it.
+
+    from mobgs_amd.rendering import rasterization, fully_fused_projection
+
+replaces `from gsplat.rendering import rasterization, fully_fused_projection`
+(/root/reference/gaussian_renderer/__init__.py:15).  Keyword names, return tuple and `meta` keys follow
+gsplat v1.4.0; every stage runs in libmobgs_hip.so (hand-written gfx950 kernels) through the C ABI of
+include/mobgs_hip.h.  Options the reference never uses raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import check, f32c, ptr, stream
+
+TILE = 16
+
+
+def _lib_():
+    return _lib.load()
+
+
+# --------------------------------------------------------------------------------------------------
+# projection
+# --------------------------------------------------------------------------------------------------
+class _Project(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip):
+        lib = _lib_()
+        means, quats, scales, viewmats, Ks = map(f32c, (means, quats, scales, viewmats, Ks))
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        radii = torch.empty(C, N, dtype=torch.int32, device=dev)
+        means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(C, N, dtype=torch.float32, device=dev)
+        conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
+        check(lib.mobgs_project_fwd(C, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
+                                    eps2d, near_plane, far_plane, radius_clip, ptr(radii), ptr(means2d), ptr(depths),
+                                    ptr(conics), ptr(tiles_per_gauss), stream()), "mobgs_project_fwd")
+        ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics)
+        ctx.dims = (width, height, eps2d)
+        ctx.mark_non_differentiable(radii, tiles_per_gauss)
+        return radii, means2d, depths, conics, tiles_per_gauss
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tpg):
+        lib = _lib_()
+        means, quats, scales, viewmats, Ks, radii, conics = ctx.saved_tensors
+        width, height, eps2d = ctx.dims
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        v_means = torch.empty_like(means)
+        v_quats = torch.empty_like(quats)
+        v_scales = torch.empty_like(scales)
+        v_viewmats = torch.empty_like(viewmats)
+        partial = torch.empty(lib.mobgs_project_bwd_scratch_floats(C, N), dtype=torch.float32, device=dev)
+        g2 = f32c(v_means2d) if v_means2d is not None else None
+        gd = f32c(v_depths) if v_depths is not None else None
+        gc = f32c(v_conics) if v_conics is not None else None
+        check(lib.mobgs_project_bwd(C, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
+                                    eps2d, ptr(radii), ptr(conics), ptr(g2), ptr(gd), ptr(gc), ptr(v_means),
+                                    ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(partial), stream()),
+              "mobgs_project_bwd")
+        return v_means, v_quats, v_scales, v_viewmats, None, None, None, None, None, None, None
+
+
+def fully_fused_projection(
+    means: Tensor,
+    covars: Optional[Tensor],
+    quats: Optional[Tensor],
+    scales: Optional[Tensor],
+    viewmats: Tensor,
+    Ks: Tensor,
+    width: int,
+    height: int,
+    eps2d: float = 0.3,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    packed: bool = False,
+    sparse_grad: bool = False,
+    calc_compensations: bool = False,
+    camera_model: str = "pinhole",
+) -> Tuple[Tensor, Tensor, Tensor, Tensor, Optional[Tensor]]:
+    """gsplat.fully_fused_projection (unpacked, pinhole, quats+scales).  Returns
+    (radii i32[C,N], means2d [C,N,2], depths [C,N], conics [C,N,3], compensations=None)."""
+    if covars is not None or quats is None or scales is None:
+        raise NotImplementedError("mobgs_amd: only the quats+scales parameterisation is supported")
+    if packed or sparse_grad or calc_compensations or camera_model != "pinhole":
+        raise NotImplementedError("mobgs_amd: packed / sparse_grad / compensations / non-pinhole are not supported")
+    radii, means2d, depths, conics, _ = _Project.apply(means, quats, scales, viewmats, Ks, int(width), int(height),
+                                                       float(eps2d), float(near_plane), float(far_plane),
+                                                       float(radius_clip))
+    return radii, means2d, depths, conics, None
+
+
+# --------------------------------------------------------------------------------------------------
+# tile intersection lists (no autograd)
+# --------------------------------------------------------------------------------------------------
+class TileLists:
+    """Per-tile depth-ordered splat lists of one rasterization call."""
+
+    __slots__ = ("C", "N", "tile_w", "tile_h", "n_isects", "max_tile_len", "cum_tiles", "tile_offsets",
+                 "flatten_ids", "isect_ids")
+
+
+@torch.no_grad()
+def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, tiles_per_gauss: Tensor, width: int,
+                     height: int, want_isect_ids: bool = True) -> TileLists:
+    lib = _lib_()
+    C, N = radii.shape
+    dev = radii.device
+    tile_w, tile_h = math.ceil(width / TILE), math.ceil(height / TILE)
+    nt = C * tile_w * tile_h
+    tl = TileLists()
+    tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
+    tl.cum_tiles = torch.empty(C * N + 1, dtype=torch.int32, device=dev)
+    tl.tile_offsets = torch.empty(nt + 1, dtype=torch.int32, device=dev)
+    stats = torch.empty(2, dtype=torch.int64, device=dev)
+    scratch = torch.empty(lib.mobgs_isect_scratch_bytes(C * N, nt), dtype=torch.uint8, device=dev)
+    check(lib.mobgs_isect_offsets(C, N, tile_w, tile_h, ptr(tiles_per_gauss), ptr(means2d), ptr(radii),
+                                  ptr(tl.cum_tiles), ptr(tl.tile_offsets), ptr(stats), ptr(scratch), stream()),
+          "mobgs_isect_offsets")
+    n_isects, max_len = (int(v) for v in stats.tolist())  # the pipeline's one host sync (as in gsplat)
+    tl.n_isects, tl.max_tile_len = n_isects, max_len
+    tl.flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
+    tl.isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev) if want_isect_ids else None
+    if n_isects > 0:
+        cursor = torch.empty(nt, dtype=torch.int32, device=dev)
+        keys = torch.empty(n_isects, dtype=torch.int64, device=dev)
+        check(lib.mobgs_isect_emit_sort(C, N, tile_w, tile_h, n_isects, max_len, ptr(means2d), ptr(radii),
+                                        ptr(depths), ptr(tl.cum_tiles), ptr(tl.tile_offsets), ptr(cursor),
+                                        ptr(keys), ptr(tl.flatten_ids), ptr(tl.isect_ids), stream()),
+              "mobgs_isect_emit_sort")
+    return tl
+
+
+# --------------------------------------------------------------------------------------------------
+# compositing
+# --------------------------------------------------------------------------------------------------
+_SUPPORTED = (1, 2, 3, 4, 9, 10, 16, 26)
+
+
+def _pad_channels(D: int) -> int:
+    for s in _SUPPORTED:
+        if s >= D:
+            return s
+    raise NotImplementedError(f"mobgs_amd: {D} colour channels exceed the compiled maximum ({_SUPPORTED[-1]})")
+
+
+class _Rasterize(torch.autograd.Function):
+    """rasterize_to_pixels: (means2d, conics, colors, opacities[, extra channel], backgrounds) -> image, alpha."""
+
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, extra, backgrounds, radii, tl: TileLists, width, height):
+        lib = _lib_()
+        C, N = radii.shape
+        dev = means2d.device
+        means2d, conics, colors, opacities = map(f32c, (means2d, conics, colors, opacities))
+        extra = f32c(extra) if extra is not None else None
+        channels = colors.shape[-1]
+        D = channels + (1 if extra is not None else 0)
+        colors_per_camera = 1 if colors.dim() == 3 else 0
+        opac_per_camera = 1 if opacities.dim() == 2 else 0
+        bg = f32c(backgrounds) if backgrounds is not None else None
+        stride = lib.mobgs_record_stride(D)
+        records = torch.empty(C * N, stride, dtype=torch.float32, device=dev)
+        render = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
+        alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
+        last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+        check(lib.mobgs_raster_fwd(C, N, channels, width, height, ptr(means2d), ptr(conics), ptr(colors),
+                                   colors_per_camera, ptr(opacities), opac_per_camera, ptr(extra), ptr(bg),
+                                   ptr(radii), ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(records), ptr(render),
+                                   ptr(alphas), ptr(last_ids), stream()), "mobgs_raster_fwd")
+        ctx.save_for_backward(records, bg, radii, means2d, alphas, last_ids)
+        ctx.tl = tl
+        ctx.meta = (C, N, channels, extra is not None, width, height, colors_per_camera, opac_per_camera)
+        ctx.bg_needs_grad = backgrounds is not None and backgrounds.requires_grad
+        return render, alphas.unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas):
+        lib = _lib_()
+        records, bg, radii, means2d, alphas, last_ids = ctx.saved_tensors
+        tl = ctx.tl
+        C, N, channels, has_extra, width, height, colors_per_camera, opac_per_camera = ctx.meta
+        dev = records.device
+        D = channels + (1 if has_extra else 0)
+        stride = records.shape[1]
+        v_render = f32c(v_render)
+        v_alphas = f32c(v_alphas) if v_alphas is not None else None
+        slots = torch.zeros(max(tl.n_isects, 1), stride, dtype=torch.float32, device=dev)
+        v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
+        v_colors = torch.empty(C, N, channels, dtype=torch.float32, device=dev)
+        v_extra = torch.empty(C, N, dtype=torch.float32, device=dev) if has_extra else None
+        check(lib.mobgs_raster_bwd(C, N, channels, int(has_extra), width, height, ptr(records), ptr(bg), ptr(radii),
+                                   ptr(means2d), ptr(tl.cum_tiles), ptr(tl.tile_offsets), ptr(tl.flatten_ids),
+                                   ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(slots),
+                                   ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra),
+                                   stream()), "mobgs_raster_bwd")
+        if not colors_per_camera:
+            v_colors = v_colors.sum(0) if C > 1 else v_colors[0]
+        if not opac_per_camera:
+            v_opac = v_opac.sum(0) if C > 1 else v_opac[0]
+        v_bg = None
+        if ctx.bg_needs_grad:
+            v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
+        return v_means2d, v_conics, v_colors, v_opac, v_extra, v_bg, None, None, None, None
+
+
+def rasterize_to_pixels(means2d, conics, colors, opacities, radii, tl: TileLists, width, height, backgrounds=None,
+                        extra=None):
+    """Composite; channel counts without a compiled variant are zero-padded up to the next one."""
+    C = radii.shape[0]
+    channels = colors.shape[-1]
+    D = channels + (1 if extra is not None else 0)
+    Dp = _pad_channels(D)
+    if Dp == D:
+        return _Rasterize.apply(means2d, conics, colors, opacities, extra, backgrounds, radii, tl, width, height)
+    parts = [colors if colors.dim() == 3 else colors.unsqueeze(0).expand(C, *colors.shape)]
+    if extra is not None:
+        parts.append(extra.unsqueeze(-1))
+    parts.append(parts[0].new_zeros(*parts[0].shape[:-1], Dp - D))
+    colors_p = torch.cat(parts, dim=-1)
+    bg_p = None
+    if backgrounds is not None:
+        bg_p = torch.cat([backgrounds, backgrounds.new_zeros(C, Dp - D)], dim=-1)
+    render, alphas = _Rasterize.apply(means2d, conics, colors_p, opacities, None, bg_p, radii, tl, width, height)
+    return render[..., :D], alphas
+
+
+# --------------------------------------------------------------------------------------------------
+# rasterization()
+# --------------------------------------------------------------------------------------------------
+def rasterization(
+    means: Tensor,
+    quats: Tensor,
+    scales: Tensor,
+    opacities: Tensor,
+    colors: Tensor,
+    viewmats: Tensor,
+    Ks: Tensor,
+    width: int,
+    height: int,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    sh_degree: Optional[int] = None,
+    packed: bool = True,
+    tile_size: int = 16,
+    backgrounds: Optional[Tensor] = None,
+    render_mode: str = "RGB",
+    sparse_grad: bool = False,
+    absgrad: bool = False,
+    rasterize_mode: str = "classic",
+    channel_chunk: int = 32,
+    distributed: bool = False,
+    camera_model: str = "pinhole",
+    covars: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor, Dict]:
+    """gsplat.rendering.rasterization for the options MoBGS uses (packed=False, classic, pinhole,
+    render_mode in RGB / D / ED / RGB+D / RGB+ED, tile_size 16).  Returns (colors [C,H,W,X], alphas [C,H,W,1], meta)."""
+    if packed:
+        raise NotImplementedError("mobgs_amd.rasterization: packed=True is not supported (MoBGS passes packed=False)")
+    if sh_degree is not None or covars is not None or absgrad or sparse_grad or distributed:
+        raise NotImplementedError("mobgs_amd.rasterization: sh_degree / covars / absgrad / sparse_grad / distributed")
+    if rasterize_mode != "classic" or camera_model != "pinhole" or tile_size != TILE:
+        raise NotImplementedError("mobgs_amd.rasterization: only classic / pinhole / tile_size=16")
+    if render_mode not in ("RGB", "D", "ED", "RGB+D", "RGB+ED"):
+        raise ValueError(f"unknown render_mode {render_mode}")
+    width, height = int(width), int(height)
+    C, N = viewmats.shape[0], means.shape[0]
+    if backgrounds is not None and backgrounds.shape[0] != C:
+        raise ValueError("backgrounds must be [C, D]")
+
+    radii, means2d, depths, conics, tiles_per_gauss = _Project.apply(
+        means, quats, scales, viewmats, Ks, width, height, float(eps2d), float(near_plane), float(far_plane),
+        float(radius_clip))
+    tl = build_tile_lists(means2d.detach(), radii, depths.detach(), tiles_per_gauss, width, height)
+
+    extra = None
+    bg = backgrounds
+    if render_mode in ("RGB+D", "RGB+ED"):
+        extra = depths
+        if bg is not None:
+            bg = torch.cat([bg, bg.new_zeros(C, 1)], dim=-1)
+        cols = colors
+    elif render_mode in ("D", "ED"):
+        cols = depths.unsqueeze(-1)
+        if bg is not None:
+            bg = bg.new_zeros(C, 1)
+    else:
+        cols = colors
+    render_colors, render_alphas = rasterize_to_pixels(means2d, conics, cols, opacities, radii, tl, width, height,
+                                                       backgrounds=bg, extra=extra)
+    if render_mode in ("ED", "RGB+ED"):
+        render_colors = torch.cat(
+            [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
+    meta = {
+        "camera_ids": None,
+        "gaussian_ids": None,
+        "radii": radii,
+        "means2d": means2d,
+        "depths": depths,
+        "conics": conics,
+        "opacities": opacities[None].expand(C, N) if opacities.dim() == 1 else opacities,
+        "tile_width": tl.tile_w,
+        "tile_height": tl.tile_h,
+        "tiles_per_gauss": tiles_per_gauss,
+        "isect_ids": tl.isect_ids,
+        "flatten_ids": tl.flatten_ids,
+        "isect_offsets": tl.tile_offsets[:-1].reshape(C, tl.tile_h, tl.tile_w),
+        "width": width,
+        "height": height,
+        "tile_size": tile_size,
+        "n_cameras": C,
+    }
+    return render_colors, render_alphas, meta
