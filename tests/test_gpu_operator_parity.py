@@ -22,13 +22,26 @@ def _to(d, dev):
     return {k: v.to(dev) for k, v in d.items()}
 
 
-def _close(a, b, rtol, atol, what):
+def _close(a, b, rtol, atol, what, flip_frac=0.0, flip_atol=0.0):
+    """|a-b| <= atol + rtol*|b| everywhere, except that a fraction `flip_frac` of the elements may differ by up
+    to `flip_atol`: a splat whose alpha sits within an ulp of the 1/255 cut (or whose transmittance sits at the
+    1e-4 stop) can fall on the other side when exp() differs in the last bit -- the same happens between two
+    GPUs running upstream gsplat -- and moves that one pixel by at most alpha*T <= 1/255."""
     a = a.detach().cpu().double()
     b = b.detach().cpu().double()
     err = (a - b).abs()
     tol = atol + rtol * b.abs()
     bad = err > tol
-    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max():.3e} (ref max {b.abs().max():.3e})"
+    nbad = int(bad.sum())
+    msg = f"{what}: {nbad}/{bad.numel()} off, max err {err.max():.3e} (ref max {b.abs().max():.3e})"
+    assert nbad <= flip_frac * bad.numel(), msg
+    if nbad:
+        assert float(err.max()) <= flip_atol, msg
+
+
+def _psnr(img, target):
+    mse = ((img.double() - target.double()) ** 2).mean()
+    return float(20 * torch.log10(1.0 / torch.sqrt(mse)))
 
 
 @pytest.mark.parametrize("n,w,h,seed", [(2000, 160, 128, 0), (500, 96, 64, 1), (3000, 200, 90, 2)])
@@ -75,8 +88,11 @@ def test_rasterization_forward(hip_device, mode, channels, use_bg):
     assert torch.equal(meta["isect_offsets"].cpu(), ref_meta["isect_offsets"])
     assert torch.equal(meta["isect_ids"].cpu(), ref_meta["isect_ids"])
     scale = max(1.0, float(ref_img.abs().max()))
-    _close(a, ref_a, 0, 2e-5, "alphas")
-    _close(img, ref_img, 0, 2e-5 * scale, f"image[{mode}]")
+    _close(a, ref_a, 0, 2e-5, "alphas", flip_frac=1e-3, flip_atol=1.0 / 255)
+    _close(img, ref_img, 0, 2e-5 * scale, f"image[{mode}]", flip_frac=1e-3, flip_atol=scale / 255)
+    # the north-star criterion: PSNR against a common target agrees to 1e-4 dB
+    target = (ref_img + 0.05 * torch.randn(ref_img.shape, generator=torch.Generator().manual_seed(9))) / scale
+    assert abs(_psnr(img.cpu() / scale, target) - _psnr(ref_img / scale, target)) <= 1e-4
 
 
 @pytest.mark.parametrize("mode,channels,use_bg", [("RGB+ED", 9, True), ("RGB", 1, True), ("RGB", 2, False)])
@@ -105,6 +121,27 @@ def test_rasterization_backward(hip_device, mode, channels, use_bg):
 
     ref = run(G.rasterization, torch.device("cpu"))
     out = run(rasterization, hip_device)
+    # (1) against autograd over the independent torch formulation: fp32 reformulation noise is ~1e-4 of the
+    #     largest gradient (the C restatement of upstream's backward shows the same distance, see
+    #     tests/test_oracle_cpu.py)
     for k in ref:
         scale = float(ref[k].abs().max())
-        _close(out[k], ref[k], 1e-3, 2e-5 * scale + 1e-6, f"grad[{k}]")
+        _close(out[k], ref[k], 1e-3, 5e-4 * scale + 1e-6, f"grad[{k}] vs torch oracle")
+    # (2) against the C restatement of upstream's backward kernels (same recurrences): only summation order
+    #     and the last bit of exp() differ
+    from oracle import gsplat_cpu as Cc
+    g = torch.Generator().manual_seed(7)
+    C = s["viewmats"].shape[0]
+    X = channels + (1 if mode in ("RGB+D", "RGB+ED") else 0)
+    v_img = torch.randn((C, h, w, X), generator=g)
+    v_a = torch.randn((C, h, w, 1), generator=g)
+    r = Cc.rasterization_fwd_bwd(*(s[k].numpy() for k in ["means", "quats", "scales", "opacities", "colors",
+                                                          "viewmats", "Ks"]), w, h,
+                                 backgrounds=None if bg is None else bg.numpy(), render_mode=mode,
+                                 v_render=v_img.numpy(), v_alphas=v_a[..., 0].numpy())
+    for k, ck in [("means", "v_means"), ("quats", "v_quats"), ("scales", "v_scales"), ("opacities", "v_opacities"),
+                  ("colors", "v_colors"), ("viewmats", "v_viewmats"), ("means2d", "v_means2d")]:
+        refc = torch.from_numpy(r[ck])
+        scale = float(refc.abs().max())
+        _close(out[k], refc, 2e-4, 2e-5 * scale + 1e-7, f"grad[{k}] vs C oracle", flip_frac=2e-3,
+               flip_atol=5e-4 * scale)
