@@ -1,0 +1,82 @@
+"""Read-side Gaussian container.
+
+`GaussianParams` exposes the attributes/properties of the reference's `GaussianModel` that render()/get_flow()
+read (/root/reference/scene/gaussian_model.py:91-106 activations, :209-254 accessors; parameter shapes from
+create_from_pcd* :406-582).  Optimiser surgery, densification and PLY I/O stay with the caller (out of scope).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .helper_model import Sandwich
+
+
+class GaussianParams:
+    def __init__(self, params: Dict[str, torch.Tensor], dynamic: Optional[Dict[str, torch.Tensor]] = None,
+                 decoder: Optional[torch.nn.Module] = None, device="cpu", requires_grad: bool = False):
+        def P(t, grad=True):
+            t = t.detach().clone().to(device)
+            if grad and requires_grad and t.is_floating_point():
+                t.requires_grad_(True)
+            return t
+
+        self._xyz = P(params["xyz"])
+        self._scaling = P(params["scaling"])
+        self._rotation = P(params["rotation"])
+        self._opacity = P(params["opacity"])
+        self._features_dc = P(params["features_dc"])
+        self._features_t = P(params["features_t"])
+        n = self._xyz.shape[0]
+        dyn = dynamic or {}
+        self._omega = P(dyn.get("omega", torch.zeros(n, 4)))
+        self._trbf_center = P(dyn.get("trbf_center", torch.zeros(n, 1)))
+        self.control_xyz = P(dyn.get("control_xyz", (params["xyz"] * 100.0)[:, None, :].repeat(1, 12, 1)))
+        self.current_control_num = P(dyn.get("current_control_num", torch.full((n, 1), 12, dtype=torch.int64)),
+                                     grad=False)
+        self.rgbdecoder = decoder if decoder is not None else Sandwich(9, 3).to(device)
+        self.scaling_activation = torch.exp
+        self.opacity_activation = torch.sigmoid
+        self.rotation_activation = F.normalize
+
+    # --- accessors with the reference's names -------------------------------------------------------
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+    @property
+    def get_rotation_stat(self):
+        return F.normalize(self._rotation)
+
+    def get_rotation_dy(self, rotation, delta_t):
+        return rotation + delta_t * self._omega
+
+    @property
+    def get_control_xyz(self):
+        return self.control_xyz
+
+    @property
+    def get_trbfcenter(self):
+        return self._trbf_center
+
+    def get_features(self, deltat):
+        return torch.cat((self._features_dc, deltat * self._features_t), dim=1)
+
+    @property
+    def get_features_static(self):
+        return torch.cat((self._features_dc, 0.0 * self._features_t), dim=1)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    def leaf_tensors(self, dynamic: bool) -> Dict[str, torch.Tensor]:
+        names = ["_scaling", "_rotation", "_opacity", "_features_dc", "_features_t"]
+        names += ["control_xyz", "_omega"] if dynamic else ["_xyz"]
+        return {k: getattr(self, k) for k in names}

@@ -155,7 +155,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     tile_id = tyi * tile_width + txi
     n_tiles = tile_width * tile_height
     tile_bits = max(1, int(math.floor(math.log2(n_tiles))) + 1)
-    depth_bits = depths.reshape(-1)[owner].contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    depth_bits = depths.reshape(-1)[owner].to(torch.float32).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
     keys = (cam << (32 + tile_bits)) | (tile_id << 32) | depth_bits
     keys_sorted, perm = torch.sort(keys, stable=True)
     flatten_ids = owner[perm].to(torch.int32)

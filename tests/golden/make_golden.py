@@ -1,0 +1,216 @@
+"""Generate the golden fixtures under tests/golden/*.npz by RUNNING THE REFERENCE'S OWN CODE in this container.
+
+    python tests/golden/make_golden.py
+
+Needs /root/reference (read-only, never copied) -- see ref_harness.py for how it is made importable on CPU.
+The rasterizer under the reference's render()/get_flow() is the CPU oracle oracle/gsplat_torch.py (real gsplat
+is absent), so these fixtures PIN the reference's own glue (Hermite spline, rotation/colour build, call order,
+decoder, output dict) and only carry the oracle's rasterizer arithmetic along.
+Fixtures hold inputs, outputs and autograd gradients only -- data, no reference source.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_harness as RH  # noqa: E402
+
+from mobgs_amd.camera import PinholeCamera  # noqa: E402
+from mobgs_amd.synth import SynthCamera, dynamic_extras, gaussian_cloud  # noqa: E402
+
+STAT_KEYS = ["xyz", "scaling", "rotation", "opacity", "features_dc", "features_t"]
+DYN_KEYS = ["omega", "trbf_center", "control_xyz", "current_control_num"]
+
+
+def small_w2c():
+    a, b = 0.04, -0.03
+    Ry = torch.tensor([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=torch.float32)
+    Rx = torch.tensor([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]], dtype=torch.float32)
+    w2c = torch.eye(4)
+    w2c[:3, :3] = Ry @ Rx
+    w2c[:3, 3] = torch.tensor([0.03, -0.02, 0.05])
+    return w2c
+
+
+def scene_params(ns, nd, cam, seed):
+    stat = gaussian_cloud(ns, cam, seed)
+    dyn = gaussian_cloud(nd, cam, seed + 1)
+    dyn.update(dynamic_extras(dyn["xyz"], seed))
+    return stat, dyn
+
+
+def ref_models(stat, dyn, seed):
+    """The reference's own GaussianModel objects filled with the synthetic parameters."""
+    gm = RH.ref_import("scene.gaussian_model")
+    with RH.CudaToCpu():
+        torch.manual_seed(seed)
+        spc = gm.GaussianModel(0, RH.Args())
+        dpc = gm.GaussianModel(0, RH.Args())
+
+    def fill(pc, p, dynamic):
+        pc._xyz = p["xyz"].clone().requires_grad_(True)
+        pc._scaling = p["scaling"].clone().requires_grad_(True)
+        pc._rotation = p["rotation"].clone().requires_grad_(True)
+        pc._opacity = p["opacity"].clone().requires_grad_(True)
+        pc._features_dc = p["features_dc"].clone().requires_grad_(True)
+        pc._features_t = p["features_t"].clone().requires_grad_(True)
+        if dynamic:
+            pc._omega = p["omega"].clone().requires_grad_(True)
+            pc._trbf_center = p["trbf_center"].clone().requires_grad_(True)
+            pc.control_xyz = p["control_xyz"].clone().requires_grad_(True)
+            pc.current_control_num = p["current_control_num"].clone()
+
+    fill(spc, stat, False)
+    fill(dpc, dyn, True)
+    return spc, dpc
+
+
+def leafs(spc, dpc):
+    d = {"s_" + k: getattr(spc, k) for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc",
+                                              "_features_t")}
+    d.update({"d_" + k: getattr(dpc, k) for k in ("_scaling", "_rotation", "_opacity", "_features_dc",
+                                                  "_features_t", "_omega", "control_xyz")})
+    d["w1"] = dpc.rgbdecoder.mlp1.weight
+    d["w2"] = dpc.rgbdecoder.mlp2.weight
+    return d
+
+
+def np_(t):
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def save(name, **arrays):
+    arrays = {k: v for k, v in arrays.items() if v is not None}
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB, {len(arrays)} arrays)")
+
+
+def inputs_dict(stat, dyn, cam, w2c, spc, dpc, bg):
+    d = {"in_s_" + k: np_(stat[k]) for k in STAT_KEYS}
+    d.update({"in_d_" + k: np_(dyn[k]) for k in STAT_KEYS + DYN_KEYS})
+    d.update({"in_w1": np_(dpc.rgbdecoder.mlp1.weight), "in_w2": np_(dpc.rgbdecoder.mlp2.weight),
+              "in_w2c": np_(w2c), "in_K": np_(cam.K), "in_bg": np_(bg),
+              "in_cam": np.array([cam.image_width, cam.image_height, cam.time, cam.max_time], dtype=np.float64)})
+    return d
+
+
+def gen_render(name, ns, nd, W, H, seed, get_static, get_dynamic, delta, get_flow, use_w2c_arg):
+    gr = RH.ref_import("gaussian_renderer")
+    scam = SynthCamera().scaled(W, H)
+    w2c = small_w2c()
+    cam = PinholeCamera(W, H, scam.K, w2c, time=scam.time, max_time=scam.max_time)
+    stat, dyn = scene_params(ns, nd, scam, seed)
+    spc, dpc = ref_models(stat, dyn, seed)
+    bg = torch.tensor([0.1, 0.2, 0.3, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+    w2c_leaf = w2c.clone().requires_grad_(True) if use_w2c_arg else None
+    delta_t = None if delta is None else torch.tensor(delta)
+    with RH.CudaToCpu():
+        out = gr.render(cam, spc, dpc, None, bg, get_static=get_static, get_dynamic=get_dynamic, w2c=w2c_leaf,
+                        delta_exposure=delta_t, get_flow=get_flow)
+    g = torch.Generator().manual_seed(seed + 100)
+    v_render = torch.randn(out["render"].shape, generator=g)
+    v_depth = torch.randn(out["depth"].shape, generator=g)
+    loss = (out["render"] * v_render).sum() + (out["depth"] * v_depth).sum()
+    if get_static:
+        loss = loss + (out["s_render"] * v_render).sum() * 0.5 + (out["s_alpha"] * v_depth).sum() * 0.25
+    if get_dynamic:
+        loss = loss + (out["d_render"] * v_render).sum() * 0.5 + (out["d_alpha"] * v_depth).sum() * 0.25 \
+            + (out["d_depth"] * v_depth).sum() * 0.125
+    loss.backward()
+    arrays = inputs_dict(stat, dyn, cam, w2c, spc, dpc, bg)
+    arrays["opt"] = np.array([int(get_static), int(get_dynamic), 0 if delta is None else 1,
+                              0.0 if delta is None else delta, int(get_flow), int(use_w2c_arg)], dtype=np.float64)
+    for k, v in out.items():
+        if isinstance(v, torch.Tensor):
+            arrays["out_" + k] = np_(v)
+    arrays["cot_v_render"] = np_(v_render)
+    arrays["cot_v_depth"] = np_(v_depth)
+    for k, v in leafs(spc, dpc).items():
+        arrays["grad_" + k] = np_(v.grad) if v.grad is not None else None
+    if use_w2c_arg:
+        arrays["grad_w2c"] = np_(w2c_leaf.grad)
+    arrays["grad_viewspace_points"] = np_(out["viewspace_points"].grad)
+    save(name, **arrays)
+
+
+def gen_get_flow(name, ns, nd, W, H, seed, delta):
+    gr = RH.ref_import("gaussian_renderer")
+    scam = SynthCamera().scaled(W, H)
+    w2c = small_w2c()
+    cam = PinholeCamera(W, H, scam.K, w2c, time=scam.time, max_time=scam.max_time)
+    stat, dyn = scene_params(ns, nd, scam, seed)
+    spc, dpc = ref_models(stat, dyn, seed)
+    bg = torch.zeros(9)
+    with RH.CudaToCpu(), torch.no_grad():
+        e2m, m2e, img, alpha = gr.get_flow(cam, spc, dpc, None, bg, delta_exposure=torch.tensor(delta))
+        # get_flow_static: source / target / splat cameras differ by a small pose change
+        w2c_b = w2c.clone()
+        w2c_b[:3, 3] += torch.tensor([0.02, 0.01, -0.01])
+        cam_b = PinholeCamera(W, H, scam.K, w2c_b, time=scam.time, max_time=scam.max_time)
+        flow_2d, flow_img = gr.get_flow_static(cam, cam_b, cam, spc, dpc, None, bg)
+    arrays = inputs_dict(stat, dyn, cam, w2c, spc, dpc, bg)
+    arrays.update({"opt": np.array([delta]), "in_w2c_b": np_(w2c_b), "out_exp2mid": np_(e2m), "out_mid2exp": np_(m2e),
+                   "out_latent_img": np_(img), "out_latent_alpha": np_(alpha), "out_static_flow_2d": np_(flow_2d),
+                   "out_static_flow_img": np_(flow_img)})
+    save(name, **arrays)
+
+
+def gen_hermite(name):
+    gr = RH.ref_import("gaussian_renderer")
+    g = torch.Generator().manual_seed(11)
+    n = 400
+    ctrl = torch.randn(n, 12, 3, generator=g).requires_grad_(True)
+    ncp = torch.randint(4, 13, (n, 1), generator=g, dtype=torch.int64)
+    ts = [0.0, 1.0, 0.5, 11.0 / 23.0, 0.999999, 1e-7, 1.0 / 3.0, 0.25]
+    outs, grads = [], []
+    for t in ts:
+        with RH.CudaToCpu():
+            o = gr.interpolate_cubic_hermite(ctrl.permute(0, 2, 1), torch.tensor(t)[None, None].expand(n, 3, 1), N=ncp)
+        v = torch.randn(o.shape, generator=torch.Generator().manual_seed(3))
+        gr_, = torch.autograd.grad((o * v).sum(), ctrl)
+        outs.append(np_(o))
+        grads.append(np_(gr_))
+    save(name, control=np_(ctrl), ncp=np_(ncp), ts=np.array(ts, dtype=np.float64), out=np.stack(outs),
+         grad=np.stack(grads), cot=np_(torch.randn(n, 3, generator=torch.Generator().manual_seed(3))))
+
+
+def gen_sandwich(name):
+    hm = RH.ref_import("helper_model")
+    torch.manual_seed(5)
+    dec = hm.Sandwich(9, 3)
+    g = torch.Generator().manual_seed(6)
+    feat = torch.randn(1, 9, 20, 24, generator=g).requires_grad_(True)
+    rays = torch.randn(1, 6, 20, 24, generator=g).requires_grad_(True)
+    out = dec(feat, rays)
+    v = torch.randn(out.shape, generator=g)
+    (out * v).sum().backward()
+    save(name, feat=np_(feat), rays=np_(rays), w1=np_(dec.mlp1.weight), w2=np_(dec.mlp2.weight), out=np_(out),
+         cot=np_(v), grad_feat=np_(feat.grad), grad_rays=np_(rays.grad), grad_w1=np_(dec.mlp1.weight.grad),
+         grad_w2=np_(dec.mlp2.weight.grad))
+
+
+def main():
+    RH.install()
+    gen_hermite("hermite")
+    gen_sandwich("sandwich")
+    gen_render("render_lean", 1200, 600, 96, 64, 0, False, False, None, False, True)
+    gen_render("render_train_delta_flow", 900, 500, 80, 48, 1, True, True, 0.3, True, False)
+    gen_render("render_train", 700, 400, 64, 48, 2, True, True, None, False, False)
+    gen_get_flow("get_flow", 900, 500, 80, 48, 3, -0.4)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,244 @@
+"""CPU tests of the ORACLE (-m "not gpu"): the restatements agree with each other, with known answers, and with
+the golden fixtures the reference's own code produced (tests/golden/make_golden.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import close, leaf_map, load, render_loss, scene_from_fixture
+from mobgs_amd.synth import SynthCamera, splat_inputs
+from oracle import gsplat_cpu as Cc
+from oracle import gsplat_torch as G
+from oracle import render_torch as R
+
+
+# ------------------------------------------------------------------------------------------------------
+# rasterizer restatements: C (upstream's kernels incl. hand backward) vs torch (independent, autograd)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,channels,use_bg", [("RGB+ED", 9, True), ("RGB", 1, True), ("RGB", 2, False)])
+def test_c_oracle_matches_torch_oracle(mode, channels, use_bg):
+    n, w, h = 1200, 104, 72
+    s = splat_inputs(n, SynthCamera().scaled(w, h), 4, channels)
+    s["viewmats"] = s["viewmats"].clone()
+    s["viewmats"][0, :3, 3] = torch.tensor([0.02, -0.01, 0.05])
+    bg = torch.rand(1, channels, generator=torch.Generator().manual_seed(1)) if use_bg else None
+    names = ["means", "quats", "scales", "opacities", "colors", "viewmats"]
+    t = {k: v.clone().requires_grad_(k in names) for k, v in s.items()}
+    img, a, meta = G.rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], t["viewmats"],
+                                   t["Ks"], w, h, packed=False, backgrounds=bg, render_mode=mode)
+    meta["means2d"].retain_grad()
+    g = torch.Generator().manual_seed(7)
+    v_img = torch.randn(img.shape, generator=g)
+    v_a = torch.randn(a.shape, generator=g)
+    ((img * v_img).sum() + (a * v_a).sum()).backward()
+    r = Cc.rasterization_fwd_bwd(*(s[k].numpy() for k in ["means", "quats", "scales", "opacities", "colors",
+                                                          "viewmats", "Ks"]), w, h,
+                                 backgrounds=None if bg is None else bg.numpy(), render_mode=mode,
+                                 v_render=v_img.numpy(), v_alphas=v_a[..., 0].numpy())
+    assert np.array_equal(r["radii"], meta["radii"].numpy())
+    assert np.array_equal(r["tiles_per_gauss"], meta["tiles_per_gauss"].numpy())
+    assert np.array_equal(r["flatten_ids"], meta["flatten_ids"].numpy())
+    assert np.array_equal(r["isect_ids"], meta["isect_ids"].numpy())
+    assert np.array_equal(r["isect_offsets"], meta["isect_offsets"].numpy())
+    scale = max(1.0, float(img.detach().abs().max()))
+    close(r["render"], img, 0, 2e-5 * scale, "image", flip_frac=1e-3, flip_atol=scale / 255)
+    close(r["alphas"], a[..., 0], 0, 2e-5, "alpha", flip_frac=1e-3, flip_atol=1 / 255)
+    for k, ck in [("means", "v_means"), ("quats", "v_quats"), ("scales", "v_scales"), ("opacities", "v_opacities"),
+                  ("colors", "v_colors"), ("viewmats", "v_viewmats")]:
+        ref = t[k].grad
+        close(r[ck], ref, 1e-3, 5e-4 * float(ref.abs().max()) + 1e-6, f"grad[{k}]")
+    ref = meta["means2d"].grad
+    close(r["v_means2d"], ref, 1e-3, 5e-4 * float(ref.abs().max()), "grad[means2d]")
+
+
+# ------------------------------------------------------------------------------------------------------
+# known answers (the reference has no tests of its own; SURVEY.md section 8c list)
+# ------------------------------------------------------------------------------------------------------
+def _one(means, scales, opac, W=64, H=48, f=50.0, quat=(1.0, 0, 0, 0), colors=None, bg=None):
+    n = means.shape[0]
+    K = torch.tensor([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1.0]])[None]
+    q = torch.tensor([quat] * n, dtype=torch.float32)
+    cols = torch.ones(n, 1) if colors is None else colors
+    return G.rasterization(means, q, scales, opac, cols, torch.eye(4)[None], K, W, H, packed=False, backgrounds=bg)
+
+
+def test_single_isotropic_gaussian_analytic():
+    W, H, f, z, s, o = 64, 48, 50.0, 2.0, 0.1, 0.8
+    img, a, meta = _one(torch.tensor([[0.0, 0.0, z]]), torch.full((1, 3), s), torch.tensor([o]), W, H, f)
+    var = (f * s / z) ** 2 + 0.3
+    assert int(meta["radii"][0, 0]) == math.ceil(3 * math.sqrt(var + math.sqrt(0.01)))  # b + sqrt(max(0.01, 0))
+    assert torch.allclose(meta["means2d"][0, 0], torch.tensor([W / 2, H / 2]))
+    assert torch.allclose(meta["conics"][0, 0], torch.tensor([1 / var, 0.0, 1 / var]), rtol=1e-6)
+    # pixel (33, 24): centre at (33.5, 24.5) -> d = (-1.5, -0.5) from the mean (32, 24)
+    d2 = 1.5 ** 2 + 0.5 ** 2
+    exp_alpha = o * math.exp(-0.5 * d2 / var)
+    assert abs(float(a[0, 24, 33, 0]) - exp_alpha) < 1e-6
+    r = int(meta["radii"][0, 0])
+    tiles = (math.ceil((32 + r) / 16) - math.floor((32 - r) / 16)) * (math.ceil((24 + r) / 16) - math.floor((24 - r) / 16))
+    assert int(meta["tiles_per_gauss"][0, 0]) == tiles
+
+
+def test_equal_depth_ties_resolve_by_index():
+    means = torch.tensor([[0.0, 0.0, 2.0], [0.0, 0.0, 2.0]])
+    cols = torch.tensor([[1.0, 0.0], [0.0, 1.0]])
+    img, a, meta = _one(means, torch.full((2, 3), 0.2), torch.tensor([0.9, 0.9]), colors=cols)
+    ids = meta["flatten_ids"].reshape(-1, 2)
+    assert (ids[:, 0] == 0).all() and (ids[:, 1] == 1).all()
+    # the first splat is composited in front: its channel dominates at the centre
+    assert img[0, 24, 32, 0] > img[0, 24, 32, 1]
+
+
+def test_culling_near_plane_and_image_border():
+    means = torch.tensor([[0.0, 0.0, 0.005], [0.0, 0.0, -1.0], [50.0, 0.0, 2.0], [0.0, 0.0, 2.0]])
+    img, a, meta = _one(means, torch.full((4, 3), 0.05), torch.full((4,), 0.5))
+    assert meta["radii"][0].tolist()[:3] == [0, 0, 0] and int(meta["radii"][0, 3]) > 0
+
+
+def test_opacity_one_is_clamped_to_0_999():
+    img, a, _ = _one(torch.tensor([[0.0, 0.0, 2.0]]), torch.full((1, 3), 5.0), torch.tensor([1.0]))
+    assert abs(float(a[0, 24, 32, 0]) - 0.999) < 1e-6  # o*exp(-sigma) = 0.99998 > 0.999 at the centre pixel
+
+
+def test_long_list_early_stop_and_background():
+    n = 400  # > 256 splats in one tile; opaque ones in front stop the pixel at T <= 1e-4
+    g = torch.Generator().manual_seed(0)
+    means = torch.cat([0.02 * torch.randn(n, 2, generator=g), 2.0 + torch.rand(n, 1, generator=g)], dim=1)
+    cols = torch.rand(n, 3, generator=g)
+    bg = torch.tensor([[0.3, 0.6, 0.9]])
+    img, a, meta = _one(means, torch.full((n, 3), 0.1), torch.full((n,), 0.9), colors=cols, bg=bg)
+    r = Cc.rasterization_fwd_bwd(means.numpy(), np.tile([1.0, 0, 0, 0], (n, 1)), np.full((n, 3), 0.1), np.full(n, 0.9),
+                                 cols.numpy(), np.eye(4)[None], np.array([[[50.0, 0, 32], [0, 50.0, 24], [0, 0, 1]]]),
+                                 64, 48, backgrounds=bg.numpy())
+    close(r["render"], img, 0, 2e-5, "image", flip_frac=2e-3, flip_atol=1 / 255)
+    centre_T = 1 - float(a[0, 24, 32, 0])
+    assert centre_T <= 1e-3  # stopped: transmittance left just above the 1e-4 cut
+    assert int(r["last_ids"][0, 24, 32]) < meta["flatten_ids"].numel() - 1
+
+
+def test_backgrounds_none_leaves_uncovered_pixels_zero():
+    img, a, _ = _one(torch.tensor([[0.0, 0.0, 2.0]]), torch.full((1, 3), 0.02), torch.tensor([0.9]))
+    assert float(img[0, 0, 0, 0]) == 0.0 and float(a[0, 0, 0, 0]) == 0.0
+
+
+def test_viewmat_gradient_finite_difference():
+    n, w, h = 50, 48, 32
+    s = splat_inputs(n, SynthCamera().scaled(w, h), 9, 3)
+    vm = s["viewmats"].double().clone().requires_grad_(True)
+
+    def f(v):
+        img, a, _ = G.rasterization(s["means"].double(), s["quats"].double(), s["scales"].double(),
+                                    s["opacities"].double(), s["colors"].double(), v, s["Ks"].double(), w, h,
+                                    packed=False)
+        return (img * img).sum()
+
+    f(vm).backward()
+    eps = 1e-6
+    for (r, c) in [(0, 3), (1, 3), (2, 3), (0, 1), (2, 0)]:
+        d = torch.zeros_like(vm)
+        d[0, r, c] = eps
+        fd = (f(vm.detach() + d) - f(vm.detach() - d)) / (2 * eps)
+        assert abs(float(fd) - float(vm.grad[0, r, c])) <= 1e-3 * abs(float(fd)) + 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------
+# the reference's own glue, pinned by fixtures it generated
+# ------------------------------------------------------------------------------------------------------
+def test_hermite_matches_reference_fixture():
+    fx = load("hermite")
+    ctrl = torch.from_numpy(fx["control"]).requires_grad_(True)
+    ncp = torch.from_numpy(fx["ncp"])
+    cot = torch.from_numpy(fx["cot"])
+    for i, t in enumerate(fx["ts"]):
+        out = R.hermite(ctrl, torch.tensor(float(t), dtype=torch.float32), ncp)
+        close(out, fx["out"][i], 1e-6, 1e-6, f"hermite(t={t})")
+        g, = torch.autograd.grad((out * cot).sum(), ctrl)
+        close(g, fx["grad"][i], 1e-6, 1e-6, f"hermite grad(t={t})")
+
+
+def test_sandwich_matches_reference_fixture():
+    fx = load("sandwich")
+    T = lambda k: torch.from_numpy(fx[k]).requires_grad_(True)  # noqa: E731
+    feat, rays, w1, w2 = T("feat"), T("rays"), T("w1"), T("w2")
+    out = R.sandwich(w1, w2, feat, rays)
+    close(out, fx["out"], 1e-6, 1e-6, "sandwich")
+    (out * torch.from_numpy(fx["cot"])).sum().backward()
+    for k, t in (("feat", feat), ("rays", rays), ("w1", w1), ("w2", w2)):
+        close(t.grad, fx["grad_" + k], 1e-5, 1e-6, f"sandwich grad {k}")
+
+
+@pytest.mark.parametrize("name", ["render_lean", "render_train", "render_train_delta_flow"])
+def test_render_restatement_matches_reference_fixture(name):
+    fx = load(name)
+    cam, stat, dyn, bg, w2c = scene_from_fixture(fx)
+    get_static, get_dynamic, has_delta, delta, get_flow, use_w2c = fx["opt"]
+    w2c_leaf = w2c.clone().requires_grad_(True) if use_w2c else None
+    out = R.render(cam, stat, dyn, bg, get_static=bool(get_static), get_dynamic=bool(get_dynamic), w2c=w2c_leaf,
+                   delta_exposure=torch.tensor(float(delta)) if has_delta else None, get_flow=bool(get_flow))
+    for k in [k[4:] for k in fx if k.startswith("out_")]:
+        ref = fx["out_" + k]
+        if ref.dtype == np.bool_ or ref.dtype == np.int32:
+            assert np.array_equal(out[k].numpy(), ref), k
+        else:
+            close(out[k], ref, 1e-5, 1e-5 * max(1.0, float(np.abs(ref).max())), f"out[{k}]")
+    # keys the reference returns as None stay None
+    for k in ("blending_factor", "world_coordinates", "splat_center", "labels", "centroids"):
+        assert out[k] is None
+    render_loss(out, fx).backward()
+    for k, leaf in leaf_map(stat, dyn).items():
+        if "grad_" + k in fx:
+            ref = fx["grad_" + k]
+            close(leaf.grad, ref, 1e-4, 1e-5 * float(np.abs(ref).max()) + 1e-7, f"grad[{k}]")
+    if use_w2c:
+        close(w2c_leaf.grad, fx["grad_w2c"], 1e-4, 1e-5 * float(np.abs(fx["grad_w2c"]).max()), "grad[w2c]")
+    close(out["viewspace_points"].grad, fx["grad_viewspace_points"], 1e-4, 1e-6, "viewspace_points.grad")
+
+
+def test_get_flow_restatement_matches_reference_fixture():
+    fx = load("get_flow")
+    cam, stat, dyn, bg, w2c = scene_from_fixture(fx, requires_grad=False)
+    with torch.no_grad():
+        e2m, m2e, img, alpha = R.get_flow(cam, stat, dyn, bg, torch.tensor(float(fx["opt"][0])))
+    close(e2m, fx["out_exp2mid"], 1e-5, 1e-4, "exp2mid")
+    close(m2e, fx["out_mid2exp"], 1e-5, 1e-4, "mid2exp")
+    close(img, fx["out_latent_img"], 1e-5, 1e-5, "latent_img")
+    close(alpha, fx["out_latent_alpha"], 1e-5, 1e-5, "latent_alpha")
+    from mobgs_amd.camera import PinholeCamera
+    cam_b = PinholeCamera(cam.image_width, cam.image_height, cam.K, torch.from_numpy(fx["in_w2c_b"]), cam.time,
+                          cam.max_time)
+    with torch.no_grad():
+        f2d, fimg = R.get_flow_static(cam, cam_b, cam, stat)
+    close(f2d, fx["out_static_flow_2d"], 1e-5, 1e-4, "static flow_2d")
+    close(fimg, fx["out_static_flow_img"], 1e-5, 1e-4, "static flow image")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/gaussian_renderer"), reason="reference tree not present")
+def test_render_restatement_matches_reference_live():
+    """When /root/reference is present (build container), run its render() directly on a fresh scene."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import ref_harness as RH
+    from make_golden import ref_models, scene_params, small_w2c
+    from mobgs_amd.camera import PinholeCamera
+    gr = RH.ref_import("gaussian_renderer")
+    W, H = 72, 56
+    scam = SynthCamera().scaled(W, H)
+    cam = PinholeCamera(W, H, scam.K, small_w2c(), time=0.3, max_time=scam.max_time)
+    stat_p, dyn_p = scene_params(500, 300, scam, 21)
+    spc, dpc = ref_models(stat_p, dyn_p, 21)
+    bg = torch.zeros(9)
+    with RH.CudaToCpu(), torch.no_grad():
+        ref = gr.render(cam, spc, dpc, None, bg, get_static=True, get_dynamic=True,
+                        delta_exposure=torch.tensor(-0.2), get_flow=True)
+        mine = R.render(cam, spc, dpc, bg, get_static=True, get_dynamic=True, delta_exposure=torch.tensor(-0.2),
+                        get_flow=True)
+    assert set(ref.keys()) == set(mine.keys())
+    for k, v in ref.items():
+        if isinstance(v, torch.Tensor):
+            if v.dtype in (torch.bool, torch.int32):
+                assert torch.equal(v, mine[k]), k
+            else:
+                close(mine[k], v, 1e-5, 1e-5 * max(1.0, float(v.abs().max())), k)
+        else:
+            assert mine[k] is None, k
