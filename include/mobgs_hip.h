@@ -122,6 +122,48 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
                      const float* v_render, const float* v_alphas, float* grad_slots, float* v_means2d,
                      float* v_conics, float* v_opacities, float* v_colors, float* v_extra, void* stream);
 
+/* 1 if raster kernels are compiled for `total_channels` (colour channels + optional extra channel). */
+int mobgs_raster_channels_supported(int total_channels);
+
+/* ---- K8: per-splat state build (replaces the reference's per-Gaussian torch glue) -----------------------
+ * /root/reference/gaussian_renderer/__init__.py:23-56 (interpolate_cubic_hermite), :93-125 (time offset,
+ * rotation, colour features), :181-185 (cat static|dynamic); scene/gaussian_model.py:209-254 (activations).
+ * Rows [0,Ns) of every output are the static splats, [Ns,Ns+Nd) the dynamic ones.
+ * times (device, 2 floats): {t_feat = time + delta/max_time, t_curve = clamp(t_feat,0,1)}.
+ * static leaves : xyz [Ns,3], scaling [Ns,3] (log), rotation [Ns,4], opacity [Ns] (logit), f_dc [Ns,6], f_t [Ns,3]
+ * dynamic leaves: control [Nd,12,3] (x100 units), ncp [Nd] int64 active knots (4..12), scaling, rotation,
+ *                 omega [Nd,4], opacity, f_dc, f_t, trbf [Nd]
+ * out: means [N,3], quats [N,4] (un-normalised; the projection normalises), scales [N,3], opacities [N],
+ *      colors [N,9]. */
+int mobgs_prep_fwd(int Ns, int Nd, const float* times, const float* s_xyz, const float* s_scaling,
+                   const float* s_rotation, const float* s_opacity, const float* s_fdc, const float* s_ft,
+                   const float* d_control, const int64_t* d_ncp, const float* d_scaling,
+                   const float* d_rotation, const float* d_omega, const float* d_opacity, const float* d_fdc,
+                   const float* d_ft, const float* d_trbf, float* means, float* quats, float* scales,
+                   float* opacities, float* colors, void* stream);
+/* Backward of mobgs_prep_fwd.  Cotangent pointers may be NULL (zeros).  Every gradient buffer is fully
+ * written.  trbf and the times get no gradient (the reference detaches the time offset, :102). */
+int mobgs_prep_bwd(int Ns, int Nd, const float* times, const int64_t* d_ncp, const float* d_trbf,
+                   const float* scales, const float* opacities, const float* v_means, const float* v_quats,
+                   const float* v_scales, const float* v_opacities, const float* v_colors, float* g_s_xyz,
+                   float* g_s_scaling, float* g_s_rotation, float* g_s_opacity, float* g_s_fdc, float* g_s_ft,
+                   float* g_d_control, float* g_d_scaling, float* g_d_rotation, float* g_d_omega,
+                   float* g_d_opacity, float* g_d_fdc, float* g_d_ft, void* stream);
+
+/* ---- K9: colour decoder + expected-depth normalisation (replaces Sandwich.forward + gsplat's "ED" step) ---
+ * /root/reference/helper_model.py:19-28; /root/reference/gaussian_renderer/__init__.py:216-227.
+ * feat_hw [P,CF] channels-last compositor output (CF >= 9; channel 9 = accumulated depth when has_depth),
+ * alphas [P], rays [6,P] planar (cam_ray), w1 [6,12], w2 [3,6]  ->  rgb [3,P] planar, depth [P]. */
+int mobgs_decoder_fwd(int P, int CF, int has_depth, const float* feat_hw, const float* alphas,
+                      const float* rays, const float* w1, const float* w2, float* rgb, float* depth,
+                      void* stream);
+/* w_partial: scratch [mobgs_decoder_bwd_blocks(P), 90] floats.  v_depth / v_rays may be NULL. */
+int mobgs_decoder_bwd_blocks(int P);
+int mobgs_decoder_bwd(int P, int CF, int has_depth, const float* feat_hw, const float* alphas,
+                      const float* rays, const float* w1, const float* w2, const float* v_rgb,
+                      const float* v_depth, float* v_feat_hw, float* v_alphas, float* v_rays, float* w_partial,
+                      float* g_w1, float* g_w2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

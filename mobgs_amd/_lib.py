@@ -34,6 +34,11 @@ _SIGS = {
                                  P, P, P, P]),
     "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
                                  P, P, P, P, P, P]),
+    "mobgs_prep_fwd": (c_int, [c_int, c_int] + [P] * 21 + [P]),
+    "mobgs_prep_bwd": (c_int, [c_int, c_int] + [P] * 23 + [P]),
+    "mobgs_decoder_fwd": (c_int, [c_int, c_int, c_int] + [P] * 7 + [P]),
+    "mobgs_decoder_bwd_blocks": (c_int, [c_int]),
+    "mobgs_decoder_bwd": (c_int, [c_int, c_int, c_int] + [P] * 13 + [P]),
 }
 # entry points added by later translation units (bound if present in the header AND the library)
 _OPTIONAL_SIGS = {}

@@ -1,0 +1,221 @@
+// Per-pixel colour decoder + expected-depth normalisation, forward and backward, for gfx950.
+//
+// Restates for the GPU:
+//   /root/reference/helper_model.py:19-28                 Sandwich.forward: albedo|spec|timefeat = chunk(feat, 3);
+//                                                         rgb = sigmoid(albedo + W2 relu(W1 [spec|timefeat|rays]))
+//   gsplat rendering.py "ED" post-process [upstream]      depth = acc_depth / clamp(alpha, 1e-10)
+//   /root/reference/gaussian_renderer/__init__.py:216-227 depth = img[..., -1]; feat = img[..., :-1].permute(0,3,1,2)
+//
+// One thread per pixel; the 90 weights live in SGPRs (wave-uniform, scalar loads).  Reads the compositor's
+// channels-last image [H,W,10] (one 40-byte row per lane), the planar ray map [6,H,W] and writes planar rgb
+// [3,H,W] + depth [H,W]: every access is a unit-stride stream.  HBM-bound: 68 B read + 16 B written per pixel.
+#include "common.h"
+
+namespace mobgs {
+
+constexpr int DEC_THREADS = 256;
+
+struct Weights {
+    float w1[72];  // [6][12]
+    float w2[18];  // [3][6]
+};
+
+__device__ inline Weights load_weights(const float* __restrict__ w1, const float* __restrict__ w2) {
+    Weights W;
+#pragma unroll
+    for (int k = 0; k < 72; ++k) W.w1[k] = w1[k];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) W.w2[k] = w2[k];
+    return W;
+}
+
+// feat_hw: [P, CF] channels-last with CF >= 9 (+1 accumulated depth when has_depth)
+__global__ void __launch_bounds__(DEC_THREADS)
+decoder_fwd_kernel(int P, int CF, int has_depth, const float* __restrict__ feat_hw,
+                   const float* __restrict__ alphas, const float* __restrict__ rays, const float* __restrict__ w1,
+                   const float* __restrict__ w2, float* __restrict__ rgb, float* __restrict__ depth) {
+    const Weights W = load_weights(w1, w2);
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const float* f = feat_hw + (size_t)p * CF;
+        float x[12];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x[k] = f[3 + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x[6 + k] = rays[(size_t)k * P + p];
+        float h[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) s = __fmaf_rn(W.w1[12 * j + c], x[c], s);
+            h[j] = fmaxf(s, 0.f);
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float y = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) y = __fmaf_rn(W.w2[6 * o + j], h[j], y);
+            const float z = f[o] + y;
+            rgb[(size_t)o * P + p] = 1.f / (1.f + __expf(-z));
+        }
+        if (has_depth) depth[p] = f[9] / fmaxf(alphas[p], 1e-10f);
+    }
+}
+
+__device__ inline float wave_sum_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// v_feat_hw [P, CF] is fully written (channels >= 10 get 0); v_alphas [P] written when has_depth;
+// v_rays [6,P] written when non-null; weight gradients go to w_partial [gridDim.x, 90] (summed by the next kernel)
+__global__ void __launch_bounds__(DEC_THREADS)
+decoder_bwd_kernel(int P, int CF, int has_depth, const float* __restrict__ feat_hw,
+                   const float* __restrict__ alphas, const float* __restrict__ rays, const float* __restrict__ w1,
+                   const float* __restrict__ w2, const float* __restrict__ v_rgb, const float* __restrict__ v_depth,
+                   float* __restrict__ v_feat_hw, float* __restrict__ v_alphas, float* __restrict__ v_rays,
+                   float* __restrict__ w_partial) {
+    const Weights W = load_weights(w1, w2);
+    float gw[90];
+#pragma unroll
+    for (int k = 0; k < 90; ++k) gw[k] = 0.f;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const float* f = feat_hw + (size_t)p * CF;
+        float x[12];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x[k] = f[3 + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x[6 + k] = rays[(size_t)k * P + p];
+        float h[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) s = __fmaf_rn(W.w1[12 * j + c], x[c], s);
+            h[j] = fmaxf(s, 0.f);
+        }
+        float vy[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float y = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) y = __fmaf_rn(W.w2[6 * o + j], h[j], y);
+            const float sg = 1.f / (1.f + __expf(-(f[o] + y)));
+            vy[o] = v_rgb[(size_t)o * P + p] * sg * (1.f - sg);
+        }
+        float vh[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                s = __fmaf_rn(W.w2[6 * o + j], vy[o], s);
+                gw[72 + 6 * o + j] = __fmaf_rn(vy[o], h[j], gw[72 + 6 * o + j]);
+            }
+            vh[j] = h[j] > 0.f ? s : 0.f;
+        }
+        float vx[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                s = __fmaf_rn(W.w1[12 * j + c], vh[j], s);
+                gw[12 * j + c] = __fmaf_rn(vh[j], x[c], gw[12 * j + c]);
+            }
+            vx[c] = s;
+        }
+        float* vf = v_feat_hw + (size_t)p * CF;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) vf[o] = vy[o];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vf[3 + k] = vx[k];
+        if (has_depth) {
+            const float a = alphas[p];
+            const float ac = fmaxf(a, 1e-10f);
+            const float g = v_depth ? v_depth[p] : 0.f;
+            vf[9] = g / ac;
+            v_alphas[p] = a > 1e-10f ? -g * f[9] / (ac * ac) : 0.f;
+        }
+        for (int k = 9 + (has_depth ? 1 : 0); k < CF; ++k) vf[k] = 0.f;
+        if (v_rays) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v_rays[(size_t)k * P + p] = vx[6 + k];
+        }
+    }
+    // 90 weight-gradient components: wave reduce -> LDS -> one row per workgroup
+    __shared__ float red[DEC_THREADS / 64][90];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 90; ++k) {
+        const float s = wave_sum_f(gw[k]);
+        if (lane == 0) red[wv][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 90) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < DEC_THREADS / 64; ++w) s += red[w][threadIdx.x];
+        w_partial[(size_t)blockIdx.x * 90 + threadIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(128) decoder_wgrad_reduce_kernel(int nblocks, const float* __restrict__ w_partial,
+                                                                     float* __restrict__ g_w1,
+                                                                     float* __restrict__ g_w2) {
+    const int k = threadIdx.x;
+    if (k >= 90) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += w_partial[(size_t)b * 90 + k];
+    if (k < 72)
+        g_w1[k] = s;
+    else
+        g_w2[k - 72] = s;
+}
+
+}  // namespace mobgs
+
+using namespace mobgs;
+
+extern "C" {
+
+static int decoder_grid(int P) {
+    int g = (P + DEC_THREADS * 8 - 1) / (DEC_THREADS * 8);  // ~8 pixels per thread
+    if (g < 1) g = 1;
+    if (g > 1024) g = 1024;
+    return g;
+}
+
+int mobgs_decoder_bwd_blocks(int P) { return decoder_grid(P); }
+
+int mobgs_decoder_fwd(int P, int CF, int has_depth, const float* feat_hw, const float* alphas, const float* rays,
+                      const float* w1, const float* w2, float* rgb, float* depth, void* stream) {
+    if (P < 0 || CF < 9 + (has_depth ? 1 : 0)) {
+        set_error("mobgs_decoder_fwd: bad sizes P=%d CF=%d", P, CF);
+        return MOBGS_E_INVALID;
+    }
+    if (P == 0) return MOBGS_OK;
+    int g = (P + DEC_THREADS - 1) / DEC_THREADS;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(decoder_fwd_kernel, dim3(g), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth,
+                       feat_hw, alphas, rays, w1, w2, rgb, depth);
+    return check_launch("decoder_fwd_kernel");
+}
+
+int mobgs_decoder_bwd(int P, int CF, int has_depth, const float* feat_hw, const float* alphas, const float* rays,
+                      const float* w1, const float* w2, const float* v_rgb, const float* v_depth, float* v_feat_hw,
+                      float* v_alphas, float* v_rays, float* w_partial, float* g_w1, float* g_w2, void* stream) {
+    if (P <= 0 || CF < 9 + (has_depth ? 1 : 0)) {
+        set_error("mobgs_decoder_bwd: bad sizes P=%d CF=%d", P, CF);
+        return MOBGS_E_INVALID;
+    }
+    const int g = decoder_grid(P);
+    hipLaunchKernelGGL(decoder_bwd_kernel, dim3(g), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth,
+                       feat_hw, alphas, rays, w1, w2, v_rgb, v_depth, v_feat_hw, v_alphas, v_rays, w_partial);
+    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, g, w_partial, g_w1,
+                       g_w2);
+    return check_launch("decoder_bwd_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,245 @@
+// Per-splat state build for MoBGS's render(): one streaming kernel instead of ~60 tiny torch launches.
+//
+// Restates, for gfx950, the per-Gaussian glue of the reference's render()/get_flow():
+//   /root/reference/gaussian_renderer/__init__.py:23-56    interpolate_cubic_hermite (per-splat knot count)
+//   /root/reference/gaussian_renderer/__init__.py:93-125   time offset, rotation = _rotation + tfp*_omega,
+//                                                          scales = exp, colours = [f_dc | tfp * f_t]
+//   /root/reference/scene/gaussian_model.py:209-254        get_scaling / get_opacity / get_features(_static)
+//   /root/reference/gaussian_renderer/__init__.py:181-185  cat(static, dynamic)
+//
+// Output rows [0,Ns) are the static splats, [Ns,Ns+Nd) the dynamic ones -- already concatenated, in the
+// operator-level layout (means [N,3], quats [N,4] wxyz, scales [N,3], opacities [N], colours [N,9]).
+// Quaternions are emitted UN-normalised: the projection kernel normalises (as upstream gsplat does), and
+// normalise(normalise(q)) == normalise(q) including its Jacobian, so the reference's extra F.normalize is a no-op.
+//
+// times[0] = t_feat  = time + delta/max_time (unclamped; drives tfp = t_feat - trbf_center)
+// times[1] = t_curve = clamp(t_feat, 0, 1)    (drives the Hermite spline)
+// They are read from DEVICE memory so a BLCE exposure offset living on the GPU never forces a host sync.
+#include "common.h"
+
+namespace mobgs {
+
+struct Hermite {
+    int i0, i1, i2, i3;  // left, index, right, right-right knots
+    float h00, h10, h01, h11;
+    bool left_edge, right_edge;
+};
+
+__device__ inline Hermite hermite_setup(float t, int n) {
+    Hermite H;
+    const float ts = t * (float)(n - 1);
+    int idx = (int)floorf(ts);
+    idx = min(max(idx, 0), n - 2);
+    H.i1 = idx;
+    H.i0 = min(max(idx - 1, 0), n - 1);
+    H.i2 = min(max(idx + 1, 0), n - 1);
+    H.i3 = min(max(idx + 2, 0), n - 1);
+    const float u = ts - (float)idx;
+    const float omu = 1.f - u;
+    H.h00 = (1.f + 2.f * u) * (omu * omu);
+    H.h10 = u * (omu * omu);
+    H.h01 = (u * u) * (3.f - 2.f * u);
+    H.h11 = (u * u) * (u - 1.f);
+    H.left_edge = (H.i0 == H.i1);
+    H.right_edge = (H.i3 == H.i2);
+    return H;
+}
+
+__global__ void __launch_bounds__(256)
+prep_fwd_kernel(int Ns, int Nd, const float* __restrict__ times,
+                // static
+                const float* __restrict__ s_xyz, const float* __restrict__ s_scaling,
+                const float* __restrict__ s_rotation, const float* __restrict__ s_opacity,
+                const float* __restrict__ s_fdc, const float* __restrict__ s_ft,
+                // dynamic
+                const float* __restrict__ d_control, const long long* __restrict__ d_ncp,
+                const float* __restrict__ d_scaling, const float* __restrict__ d_rotation,
+                const float* __restrict__ d_omega, const float* __restrict__ d_opacity,
+                const float* __restrict__ d_fdc, const float* __restrict__ d_ft, const float* __restrict__ d_trbf,
+                // out
+                float* __restrict__ means, float* __restrict__ quats, float* __restrict__ scales,
+                float* __restrict__ opac, float* __restrict__ colors) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = Ns + Nd;
+    if (i >= N) return;
+    float m[3], q[4], s[3], o, col[9];
+    if (i < Ns) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            m[k] = s_xyz[3 * i + k];
+            s[k] = __expf(s_scaling[3 * i + k]);
+            col[6 + k] = 0.0f * s_ft[3 * i + k];
+        }
+        // the reference normalises static rotations (get_rotation_stat); emit them raw, see header
+        const float4 r = reinterpret_cast<const float4*>(s_rotation)[i];
+        q[0] = r.x; q[1] = r.y; q[2] = r.z; q[3] = r.w;
+        o = 1.f / (1.f + __expf(-s_opacity[i]));
+#pragma unroll
+        for (int k = 0; k < 6; ++k) col[k] = s_fdc[6 * i + k];
+    } else {
+        const int j = i - Ns;
+        const float t_feat = times[0], t_curve = times[1];
+        const float tfp = t_feat - d_trbf[j];
+        const int n = (int)d_ncp[j];
+        const Hermite H = hermite_setup(t_curve, n);
+        const float* cp = d_control + (size_t)j * 36;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float p0 = cp[3 * H.i0 + k], p1 = cp[3 * H.i1 + k], p2 = cp[3 * H.i2 + k], p3 = cp[3 * H.i3 + k];
+            const float m0 = H.left_edge ? (p2 - p1) : (p2 - p0) * 0.5f;
+            const float m1 = H.right_edge ? (p2 - p1) : (p3 - p1) * 0.5f;
+            m[k] = (H.h00 * p1 + H.h10 * m0 + H.h01 * p2 + H.h11 * m1) * 1e-2f;
+            s[k] = __expf(d_scaling[3 * j + k]);
+            col[6 + k] = tfp * d_ft[3 * j + k];
+        }
+        const float4 r = reinterpret_cast<const float4*>(d_rotation)[j];
+        const float4 w = reinterpret_cast<const float4*>(d_omega)[j];
+        q[0] = r.x + tfp * w.x; q[1] = r.y + tfp * w.y; q[2] = r.z + tfp * w.z; q[3] = r.w + tfp * w.w;
+        o = 1.f / (1.f + __expf(-d_opacity[j]));
+#pragma unroll
+        for (int k = 0; k < 6; ++k) col[k] = d_fdc[6 * j + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        means[3 * i + k] = m[k];
+        scales[3 * i + k] = s[k];
+    }
+    reinterpret_cast<float4*>(quats)[i] = make_float4(q[0], q[1], q[2], q[3]);
+    opac[i] = o;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) colors[9 * i + k] = col[k];
+}
+
+__global__ void __launch_bounds__(256)
+prep_bwd_kernel(int Ns, int Nd, const float* __restrict__ times, const long long* __restrict__ d_ncp,
+                const float* __restrict__ d_trbf,
+                // forward outputs needed for the activation derivatives
+                const float* __restrict__ scales, const float* __restrict__ opac,
+                // cotangents of the forward outputs (any may be NULL)
+                const float* __restrict__ v_means, const float* __restrict__ v_quats,
+                const float* __restrict__ v_scales, const float* __restrict__ v_opac,
+                const float* __restrict__ v_colors,
+                // gradients of the leaves (static)
+                float* __restrict__ g_s_xyz, float* __restrict__ g_s_scaling, float* __restrict__ g_s_rotation,
+                float* __restrict__ g_s_opacity, float* __restrict__ g_s_fdc, float* __restrict__ g_s_ft,
+                // gradients of the leaves (dynamic)
+                float* __restrict__ g_d_control, float* __restrict__ g_d_scaling, float* __restrict__ g_d_rotation,
+                float* __restrict__ g_d_omega, float* __restrict__ g_d_opacity, float* __restrict__ g_d_fdc,
+                float* __restrict__ g_d_ft) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = Ns + Nd;
+    if (i >= N) return;
+    float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vo = 0.f, vc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) vc[k] = v_colors ? v_colors[9 * i + k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (v_means) vm[k] = v_means[3 * i + k];
+        if (v_scales) vs[k] = v_scales[3 * i + k] * scales[3 * i + k];  // d exp = exp
+    }
+    if (v_quats) {
+        const float4 r = reinterpret_cast<const float4*>(v_quats)[i];
+        vq[0] = r.x; vq[1] = r.y; vq[2] = r.z; vq[3] = r.w;
+    }
+    if (v_opac) {
+        const float o = opac[i];
+        vo = v_opac[i] * o * (1.f - o);
+    }
+    if (i < Ns) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            g_s_xyz[3 * i + k] = vm[k];
+            g_s_scaling[3 * i + k] = vs[k];
+            g_s_ft[3 * i + k] = 0.0f * vc[6 + k];
+        }
+        reinterpret_cast<float4*>(g_s_rotation)[i] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+        g_s_opacity[i] = vo;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g_s_fdc[6 * i + k] = vc[k];
+    } else {
+        const int j = i - Ns;
+        const float tfp = times[0] - d_trbf[j];
+        const int n = (int)d_ncp[j];
+        const Hermite H = hermite_setup(times[1], n);
+        float* gc = g_d_control + (size_t)j * 36;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) gc[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = vm[k] * 1e-2f;
+            float a0 = 0.f, a1 = H.h00 * v, a2 = H.h01 * v, a3 = 0.f;
+            const float vm0 = H.h10 * v, vm1 = H.h11 * v;
+            if (H.left_edge) {
+                a2 += vm0;
+                a1 -= vm0;
+            } else {
+                a2 += 0.5f * vm0;
+                a0 -= 0.5f * vm0;
+            }
+            if (H.right_edge) {
+                a2 += vm1;
+                a1 -= vm1;
+            } else {
+                a3 += 0.5f * vm1;
+                a1 -= 0.5f * vm1;
+            }
+            // knots may coincide at the curve ends: sequential read-modify-write by the owning thread
+            gc[3 * H.i0 + k] += a0;
+            gc[3 * H.i1 + k] += a1;
+            gc[3 * H.i2 + k] += a2;
+            gc[3 * H.i3 + k] += a3;
+            g_d_scaling[3 * j + k] = vs[k];
+            g_d_ft[3 * j + k] = tfp * vc[6 + k];
+        }
+        reinterpret_cast<float4*>(g_d_rotation)[j] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+        reinterpret_cast<float4*>(g_d_omega)[j] = make_float4(tfp * vq[0], tfp * vq[1], tfp * vq[2], tfp * vq[3]);
+        g_d_opacity[j] = vo;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g_d_fdc[6 * j + k] = vc[k];
+    }
+}
+
+}  // namespace mobgs
+
+using namespace mobgs;
+
+extern "C" {
+
+int mobgs_prep_fwd(int Ns, int Nd, const float* times, const float* s_xyz, const float* s_scaling,
+                   const float* s_rotation, const float* s_opacity, const float* s_fdc, const float* s_ft,
+                   const float* d_control, const int64_t* d_ncp, const float* d_scaling, const float* d_rotation,
+                   const float* d_omega, const float* d_opacity, const float* d_fdc, const float* d_ft,
+                   const float* d_trbf, float* means, float* quats, float* scales, float* opacities, float* colors,
+                   void* stream) {
+    if (Ns < 0 || Nd < 0) {
+        set_error("mobgs_prep_fwd: bad sizes Ns=%d Nd=%d", Ns, Nd);
+        return MOBGS_E_INVALID;
+    }
+    const int N = Ns + Nd;
+    if (N == 0) return MOBGS_OK;
+    hipLaunchKernelGGL(prep_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, Ns, Nd, times, s_xyz,
+                       s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_control, (const long long*)d_ncp, d_scaling,
+                       d_rotation, d_omega, d_opacity, d_fdc, d_ft, d_trbf, means, quats, scales, opacities, colors);
+    return check_launch("prep_fwd_kernel");
+}
+
+int mobgs_prep_bwd(int Ns, int Nd, const float* times, const int64_t* d_ncp, const float* d_trbf,
+                   const float* scales, const float* opacities, const float* v_means, const float* v_quats,
+                   const float* v_scales, const float* v_opacities, const float* v_colors, float* g_s_xyz,
+                   float* g_s_scaling, float* g_s_rotation, float* g_s_opacity, float* g_s_fdc, float* g_s_ft,
+                   float* g_d_control, float* g_d_scaling, float* g_d_rotation, float* g_d_omega, float* g_d_opacity,
+                   float* g_d_fdc, float* g_d_ft, void* stream) {
+    if (Ns < 0 || Nd < 0) {
+        set_error("mobgs_prep_bwd: bad sizes Ns=%d Nd=%d", Ns, Nd);
+        return MOBGS_E_INVALID;
+    }
+    const int N = Ns + Nd;
+    if (N == 0) return MOBGS_OK;
+    hipLaunchKernelGGL(prep_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, Ns, Nd, times,
+                       (const long long*)d_ncp, d_trbf, scales, opacities, v_means, v_quats, v_scales, v_opacities,
+                       v_colors, g_s_xyz, g_s_scaling, g_s_rotation, g_s_opacity, g_s_fdc, g_s_ft, g_d_control,
+                       g_d_scaling, g_d_rotation, g_d_omega, g_d_opacity, g_d_fdc, g_d_ft);
+    return check_launch("prep_bwd_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+"""autograd wrappers of the fused per-splat and per-pixel kernels (prep.hip, decoder.hip)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import check, f32c, ptr, stream
+
+
+class PrepSplats(torch.autograd.Function):
+    """Leaves of the static + dynamic Gaussian sets -> concatenated operator-level inputs at one time instant.
+
+    Replaces /root/reference/gaussian_renderer/__init__.py:69-125,181-185 (see csrc/prep.hip)."""
+
+    @staticmethod
+    def forward(ctx, times, s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_control, d_ncp, d_scaling,
+                d_rotation, d_omega, d_opacity, d_fdc, d_ft, d_trbf):
+        lib = _lib.load()
+        (times, s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_control, d_scaling, d_rotation, d_omega,
+         d_opacity, d_fdc, d_ft, d_trbf) = map(f32c, (times, s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_ft,
+                                                       d_control, d_scaling, d_rotation, d_omega, d_opacity, d_fdc,
+                                                       d_ft, d_trbf))
+        d_ncp = d_ncp.to(torch.int64).contiguous()
+        Ns, Nd = s_xyz.shape[0], d_control.shape[0]
+        N = Ns + Nd
+        dev = times.device
+        means = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        quats = torch.empty(N, 4, dtype=torch.float32, device=dev)
+        scales = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        opac = torch.empty(N, dtype=torch.float32, device=dev)
+        colors = torch.empty(N, 9, dtype=torch.float32, device=dev)
+        check(lib.mobgs_prep_fwd(Ns, Nd, ptr(times), ptr(s_xyz), ptr(s_scaling), ptr(s_rotation), ptr(s_opacity),
+                                 ptr(s_fdc), ptr(s_ft), ptr(d_control), ptr(d_ncp), ptr(d_scaling), ptr(d_rotation),
+                                 ptr(d_omega), ptr(d_opacity), ptr(d_fdc), ptr(d_ft), ptr(d_trbf), ptr(means),
+                                 ptr(quats), ptr(scales), ptr(opac), ptr(colors), stream()), "mobgs_prep_fwd")
+        ctx.save_for_backward(times, d_ncp, d_trbf, scales, opac)
+        ctx.sizes = (Ns, Nd)
+        return means, quats, scales, opac, colors
+
+    @staticmethod
+    def backward(ctx, v_means, v_quats, v_scales, v_opac, v_colors):
+        lib = _lib.load()
+        times, d_ncp, d_trbf, scales, opac = ctx.saved_tensors
+        Ns, Nd = ctx.sizes
+        dev = times.device
+
+        def E(*shape):
+            return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+        g = {"s_xyz": E(Ns, 3), "s_scaling": E(Ns, 3), "s_rotation": E(Ns, 4), "s_opacity": E(Ns, 1),
+             "s_fdc": E(Ns, 6), "s_ft": E(Ns, 3), "d_control": E(Nd, 12, 3), "d_scaling": E(Nd, 3),
+             "d_rotation": E(Nd, 4), "d_omega": E(Nd, 4), "d_opacity": E(Nd, 1), "d_fdc": E(Nd, 6), "d_ft": E(Nd, 3)}
+        c = [f32c(v) if v is not None else None for v in (v_means, v_quats, v_scales, v_opac, v_colors)]
+        check(lib.mobgs_prep_bwd(Ns, Nd, ptr(times), ptr(d_ncp), ptr(d_trbf), ptr(scales), ptr(opac), ptr(c[0]),
+                                 ptr(c[1]), ptr(c[2]), ptr(c[3]), ptr(c[4]), ptr(g["s_xyz"]), ptr(g["s_scaling"]),
+                                 ptr(g["s_rotation"]), ptr(g["s_opacity"]), ptr(g["s_fdc"]), ptr(g["s_ft"]),
+                                 ptr(g["d_control"]), ptr(g["d_scaling"]), ptr(g["d_rotation"]), ptr(g["d_omega"]),
+                                 ptr(g["d_opacity"]), ptr(g["d_fdc"]), ptr(g["d_ft"]), stream()), "mobgs_prep_bwd")
+        return (None, g["s_xyz"], g["s_scaling"], g["s_rotation"], g["s_opacity"], g["s_fdc"], g["s_ft"],
+                g["d_control"], None, g["d_scaling"], g["d_rotation"], g["d_omega"], g["d_opacity"], g["d_fdc"],
+                g["d_ft"], None)
+
+
+class Decode(torch.autograd.Function):
+    """Channels-last compositor image (+alpha) -> planar rgb [3,H,W] (+ expected depth [H,W])."""
+
+    @staticmethod
+    def forward(ctx, feat_hw, alphas, rays, w1, w2, has_depth: bool):
+        lib = _lib.load()
+        feat_hw, rays, w1, w2 = map(f32c, (feat_hw, rays, w1, w2))
+        H, W, CF = feat_hw.shape[-3:]
+        P = H * W
+        dev = feat_hw.device
+        alphas_c = f32c(alphas) if alphas is not None else None
+        rgb = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(H, W, dtype=torch.float32, device=dev) if has_depth else None
+        check(lib.mobgs_decoder_fwd(P, CF, int(has_depth), ptr(feat_hw), ptr(alphas_c), ptr(rays), ptr(w1), ptr(w2),
+                                    ptr(rgb), ptr(depth), stream()), "mobgs_decoder_fwd")
+        ctx.save_for_backward(feat_hw, alphas_c, rays, w1, w2)
+        ctx.has_depth = has_depth
+        ctx.rays_need_grad = ctx.needs_input_grad[2]
+        ctx.feat_shape = feat_hw.shape
+        if has_depth:
+            return rgb, depth
+        return rgb, rgb.new_empty(0)
+
+    @staticmethod
+    def backward(ctx, v_rgb, v_depth):
+        lib = _lib.load()
+        feat_hw, alphas, rays, w1, w2 = ctx.saved_tensors
+        H, W, CF = feat_hw.shape[-3:]
+        P = H * W
+        dev = feat_hw.device
+        has_depth = ctx.has_depth
+        v_rgb = f32c(v_rgb) if v_rgb is not None else torch.zeros(3, H, W, dtype=torch.float32, device=dev)
+        v_depth = f32c(v_depth) if (has_depth and v_depth is not None) else None
+        v_feat = torch.empty(ctx.feat_shape, dtype=torch.float32, device=dev)
+        v_alphas = torch.empty(alphas.shape, dtype=torch.float32, device=dev) if has_depth else None
+        v_rays = torch.empty_like(rays) if ctx.rays_need_grad else None
+        nb = lib.mobgs_decoder_bwd_blocks(P)
+        partial = torch.empty(nb, 90, dtype=torch.float32, device=dev)
+        g_w1 = torch.empty_like(w1)
+        g_w2 = torch.empty_like(w2)
+        check(lib.mobgs_decoder_bwd(P, CF, int(has_depth), ptr(feat_hw), ptr(alphas), ptr(rays), ptr(w1), ptr(w2),
+                                    ptr(v_rgb), ptr(v_depth), ptr(v_feat), ptr(v_alphas), ptr(v_rays), ptr(partial),
+                                    ptr(g_w1), ptr(g_w2), stream()), "mobgs_decoder_bwd")
+        return v_feat, v_alphas, v_rays, g_w1, g_w2, None
+
+
+def decode(feat_hw: Tensor, alphas: Optional[Tensor], rays: Tensor, w1: Tensor, w2: Tensor, has_depth: bool):
+    """feat_hw [..,H,W,CF>=9(+1)], alphas [..,H,W] or [..,H,W,1], rays [1,6,H,W] -> rgb [3,H,W], depth [H,W]|None."""
+    H, W = feat_hw.shape[-3], feat_hw.shape[-2]
+    if alphas is not None:
+        alphas = alphas.reshape(H, W)
+    rgb, depth = Decode.apply(feat_hw.reshape(H, W, feat_hw.shape[-1]), alphas, rays.reshape(6, H, W), w1, w2,
+                              bool(has_depth))
+    return rgb, (depth if has_depth else None)
+
+
+def decode_nchw(feat: Tensor, rays: Tensor, w1: Tensor, w2: Tensor) -> Tensor:
+    """Sandwich.forward signature: feat [1,9,H,W], rays [1,6,H,W] -> [1,3,H,W]."""
+    if feat.shape[0] != 1:
+        raise NotImplementedError("decoder batch size must be 1 (as in every reference call)")
+    rgb, _ = decode(feat[0].permute(1, 2, 0), None, rays, w1, w2, False)
+    return rgb.unsqueeze(0)

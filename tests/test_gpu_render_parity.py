@@ -1,0 +1,108 @@
+"""GPU parity of the render API (B1) against the golden fixtures produced by the reference's own
+render()/get_flow()/interpolate_cubic_hermite()/Sandwich (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import close, leaf_map, load, psnr, render_loss, scene_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+IMG_KEYS = ("render", "s_render", "d_render", "d_alpha", "s_alpha", "depth", "d_depth", "s_depth", "ori_flow",
+            "ori_coord_map")
+
+
+@pytest.mark.parametrize("name", ["render_lean", "render_train", "render_train_delta_flow"])
+def test_render_matches_reference_fixture(hip_device, name):
+    from mobgs_amd.gaussian_renderer import render
+    fx = load(name)
+    cam, stat, dyn, bg, w2c = scene_from_fixture(fx, device=hip_device)
+    get_static, get_dynamic, has_delta, delta, get_flow, use_w2c = fx["opt"]
+    w2c_leaf = w2c.clone().requires_grad_(True) if use_w2c else None
+    out = render(cam, stat, dyn, None, bg, get_static=bool(get_static), get_dynamic=bool(get_dynamic), w2c=w2c_leaf,
+                 delta_exposure=torch.tensor(float(delta), device=hip_device) if has_delta else None,
+                 get_flow=bool(get_flow))
+    ref_keys = {k[4:] for k in fx if k.startswith("out_")}
+    assert {k for k, v in out.items() if isinstance(v, torch.Tensor)} == ref_keys
+    assert len(out) == 22
+    for k in sorted(ref_keys):
+        ref = fx["out_" + k]
+        got = out[k].detach().cpu()
+        assert tuple(got.shape) == ref.shape, f"{k}: {tuple(got.shape)} vs {ref.shape}"
+        if ref.dtype in (np.bool_, np.int32):
+            assert np.array_equal(got.numpy(), ref), k
+        elif k in IMG_KEYS:
+            scale = max(1.0, float(np.abs(ref).max()))
+            close(got, ref, 0, 3e-5 * scale, f"out[{k}]", flip_frac=2e-3, flip_atol=scale / 100)
+        else:
+            close(got, ref, 2e-5, 1e-5 * max(1.0, float(np.abs(ref).max())), f"out[{k}]")
+    # north-star criterion: PSNR of the decoded image against a common target within 1e-4 dB
+    ref_img = torch.from_numpy(fx["out_render"])
+    target = (ref_img + 0.05 * torch.randn(ref_img.shape, generator=torch.Generator().manual_seed(2))).clamp(0, 1)
+    assert abs(psnr(out["render"].detach().cpu(), target) - psnr(ref_img, target)) <= 1e-4
+
+    render_loss(out, fx, hip_device).backward()
+    for k, leaf in leaf_map(stat, dyn).items():
+        if "grad_" + k not in fx:
+            continue
+        ref = fx["grad_" + k]
+        scale = float(np.abs(ref).max())
+        close(leaf.grad, ref, 1e-3, 5e-4 * scale + 1e-7, f"grad[{k}]")
+    if use_w2c:
+        ref = fx["grad_w2c"]
+        close(w2c_leaf.grad, ref, 1e-3, 5e-4 * float(np.abs(ref).max()), "grad[w2c]")
+    ref = fx["grad_viewspace_points"]
+    close(out["viewspace_points"].grad, ref, 1e-3, 5e-4 * float(np.abs(ref).max()), "viewspace_points.grad")
+
+
+def test_get_flow_matches_reference_fixture(hip_device):
+    from mobgs_amd.camera import PinholeCamera
+    from mobgs_amd.gaussian_renderer import get_flow, get_flow_static
+    fx = load("get_flow")
+    cam, stat, dyn, bg, w2c = scene_from_fixture(fx, device=hip_device, requires_grad=False)
+    with torch.no_grad():
+        e2m, m2e, img, alpha = get_flow(cam, stat, dyn, None, bg,
+                                        delta_exposure=torch.tensor(float(fx["opt"][0]), device=hip_device))
+    for got, key, atol in ((e2m, "out_exp2mid", 2e-4), (m2e, "out_mid2exp", 2e-4), (img, "out_latent_img", 3e-5),
+                           (alpha, "out_latent_alpha", 3e-5)):
+        assert tuple(got.shape) == fx[key].shape
+        close(got, fx[key], 1e-5, atol, key, flip_frac=2e-3, flip_atol=1.0)
+    cam_b = PinholeCamera(cam.image_width, cam.image_height, cam.K, torch.from_numpy(fx["in_w2c_b"]), cam.time,
+                          cam.max_time, device=hip_device)
+    with torch.no_grad():
+        f2d, fimg = get_flow_static(cam, cam_b, cam, stat, dyn, None, bg)
+    close(f2d, fx["out_static_flow_2d"], 1e-5, 2e-4, "static flow_2d")
+    close(fimg, fx["out_static_flow_img"], 1e-5, 2e-4, "static flow image", flip_frac=2e-3, flip_atol=1.0)
+
+
+def test_hermite_wrapper_matches_reference_fixture(hip_device):
+    from mobgs_amd.gaussian_renderer import interpolate_cubic_hermite
+    fx = load("hermite")
+    ncp = torch.from_numpy(fx["ncp"]).to(hip_device)
+    cot = torch.from_numpy(fx["cot"]).to(hip_device)
+    for i, t in enumerate(fx["ts"]):
+        ctrl = torch.from_numpy(fx["control"]).to(hip_device).requires_grad_(True)
+        n = ctrl.shape[0]
+        tt = torch.tensor(float(t), dtype=torch.float32, device=hip_device)[None, None].expand(n, 3, 1)
+        out = interpolate_cubic_hermite(ctrl.permute(0, 2, 1), tt, ncp)
+        close(out, fx["out"][i], 2e-5, 2e-5, f"hermite(t={t})")
+        (out * cot).sum().backward()
+        close(ctrl.grad, fx["grad"][i], 2e-5, 2e-5, f"hermite grad(t={t})")
+
+
+def test_sandwich_module_matches_reference_fixture(hip_device):
+    from mobgs_amd.helper_model import Sandwich
+    fx = load("sandwich")
+    dec = Sandwich(9, 3).to(hip_device)
+    with torch.no_grad():
+        dec.mlp1.weight.copy_(torch.from_numpy(fx["w1"]))
+        dec.mlp2.weight.copy_(torch.from_numpy(fx["w2"]))
+    feat = torch.from_numpy(fx["feat"]).to(hip_device).requires_grad_(True)
+    rays = torch.from_numpy(fx["rays"]).to(hip_device).requires_grad_(True)
+    out = dec(feat, rays)
+    close(out, fx["out"], 1e-5, 1e-6, "sandwich")
+    (out * torch.from_numpy(fx["cot"]).to(hip_device)).sum().backward()
+    close(feat.grad, fx["grad_feat"], 1e-4, 1e-6, "grad feat")
+    close(rays.grad, fx["grad_rays"], 1e-4, 1e-6, "grad rays")
+    close(dec.mlp1.weight.grad, fx["grad_w1"], 1e-4, 1e-5, "grad w1")
+    close(dec.mlp2.weight.grad, fx["grad_w2"], 1e-4, 1e-5, "grad w2")
