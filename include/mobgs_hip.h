@@ -109,18 +109,22 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
                      int32_t* last_ids, void* stream);
 
 /* ---- K7: rasterise backward (replaces gsplat rasterize_to_pixels bwd) ----------------------------------
- * Deterministic two-stage gradient reduction: stage 1 writes one gradient record per (tile, splat)
- * intersection into grad_slots [I, stride] (slot = cum_tiles[flat id] + position of the tile inside the
- * splat's tile rectangle; the buffer must be zero-filled by the caller), stage 2 sums each splat's
- * contiguous slots.  No floating-point atomics.
- * out (fully written): v_means2d [C,N,2], v_conics [C,N,3], v_opacities [C,N], v_colors [C,N,channels],
- *                      v_extra [C,N] (or NULL when extra was NULL). */
+ * Deterministic two-stage gradient reduction, no floating-point atomics:
+ *   stage 1 (mobgs_raster_bwd) walks every tile back to front and writes ONE gradient record
+ *     {v_x, v_y, v_conic a b c, v_opacity, v_colour[..]} per (tile, splat) intersection into
+ *     grad_slots [I, stride]; slot = cum_tiles[flat id] + position of the tile inside the splat's tile
+ *     rectangle.  grad_slots must be zero-filled by the caller (intersections that no pixel blended stay 0).
+ *   stage 2 (mobgs_raster_bwd_reduce) sums each splat's contiguous slots into the dense gradients
+ *     v_means2d [C,N,2], v_conics [C,N,3], v_opacities [C,N], v_colors [C,N,channels], v_extra [C,N] (NULL when
+ *     there was no extra channel); all fully written. */
 int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int height,
                      const float* records, const float* backgrounds, const int32_t* radii,
                      const float* means2d, const int32_t* cum_tiles, const int32_t* tile_offsets,
                      const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
-                     const float* v_render, const float* v_alphas, float* grad_slots, float* v_means2d,
-                     float* v_conics, float* v_opacities, float* v_colors, float* v_extra, void* stream);
+                     const float* v_render, const float* v_alphas, float* grad_slots, void* stream);
+int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int32_t* cum_tiles,
+                            const float* grad_slots, float* v_means2d, float* v_conics, float* v_opacities,
+                            float* v_colors, float* v_extra, void* stream);
 
 /* 1 if raster kernels are compiled for `total_channels` (colour channels + optional extra channel). */
 int mobgs_raster_channels_supported(int total_channels);

@@ -32,8 +32,8 @@ _SIGS = {
                                       P]),
     "mobgs_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, P,
                                  P, P, P, P]),
-    "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P,
-                                 P, P, P, P, P, P]),
+    "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int] + [P] * 12 + [P]),
+    "mobgs_raster_bwd_reduce": (c_int, [c_int, c_int, c_int, c_int] + [P] * 7 + [P]),
     "mobgs_prep_fwd": (c_int, [c_int, c_int] + [P] * 21 + [P]),
     "mobgs_prep_bwd": (c_int, [c_int, c_int] + [P] * 23 + [P]),
     "mobgs_decoder_fwd": (c_int, [c_int, c_int, c_int] + [P] * 7 + [P]),

@@ -458,8 +458,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
                      const float* backgrounds, const int32_t* radii, const float* means2d,
                      const int32_t* cum_tiles, const int32_t* tile_offsets, const int32_t* flatten_ids,
                      const float* render_alphas, const int32_t* last_ids, const float* v_render,
-                     const float* v_alphas, float* grad_slots, float* v_means2d, float* v_conics,
-                     float* v_opacities, float* v_colors, float* v_extra, void* stream) {
+                     const float* v_alphas, float* grad_slots, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     (void)means2d;
     const int D = channels + (has_extra ? 1 : 0);
@@ -482,6 +481,19 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
         set_error("mobgs_raster_bwd: %d total channels not compiled in", D);
         return rc;
     }
+    return check_launch("raster_bwd_kernel");
+}
+
+int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int32_t* cum_tiles,
+                            const float* grad_slots, float* v_means2d, float* v_conics, float* v_opacities,
+                            float* v_colors, float* v_extra, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int D = channels + (has_extra ? 1 : 0);
+    if (C <= 0 || N < 0 || D < 1) {
+        set_error("mobgs_raster_bwd_reduce: bad sizes C=%d N=%d channels=%d", C, N, channels);
+        return MOBGS_E_INVALID;
+    }
+    const int stride = record_stride(D);
     const int n = C * N;
     if (n > 0) {
         if (stride <= 8) {
@@ -498,7 +510,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
                                v_colors, v_extra);
         }
     }
-    return check_launch("raster_bwd_kernel");
+    return check_launch("slot_reduce_kernel");
 }
 
 }  // extern "C"

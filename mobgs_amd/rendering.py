@@ -15,10 +15,12 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
-from . import _lib
+from . import _lib, profiler
 from ._lib import check, f32c, ptr, stream
 
 TILE = 16
+# statistics of the most recent build_tile_lists() call (read by bench.py for the roofline line)
+last_stats = {}
 
 
 def _lib_():
@@ -129,6 +131,7 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, tiles_per_g
           "mobgs_isect_offsets")
     n_isects, max_len = (int(v) for v in stats.tolist())  # the pipeline's one host sync (as in gsplat)
     tl.n_isects, tl.max_tile_len = n_isects, max_len
+    last_stats.update(n_isects=n_isects, max_tile_len=max_len, n_tiles=nt)
     tl.flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
     tl.isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev) if want_isect_ids else None
     if n_isects > 0:
@@ -174,10 +177,11 @@ class _Rasterize(torch.autograd.Function):
         render = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
         alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
-        check(lib.mobgs_raster_fwd(C, N, channels, width, height, ptr(means2d), ptr(conics), ptr(colors),
-                                   colors_per_camera, ptr(opacities), opac_per_camera, ptr(extra), ptr(bg),
-                                   ptr(radii), ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(records), ptr(render),
-                                   ptr(alphas), ptr(last_ids), stream()), "mobgs_raster_fwd")
+        with profiler.region("raster_fwd"):
+            check(lib.mobgs_raster_fwd(C, N, channels, width, height, ptr(means2d), ptr(conics), ptr(colors),
+                                       colors_per_camera, ptr(opacities), opac_per_camera, ptr(extra), ptr(bg),
+                                       ptr(radii), ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(records),
+                                       ptr(render), ptr(alphas), ptr(last_ids), stream()), "mobgs_raster_fwd")
         ctx.save_for_backward(records, bg, radii, means2d, alphas, last_ids)
         ctx.tl = tl
         ctx.meta = (C, N, channels, extra is not None, width, height, colors_per_camera, opac_per_camera)
@@ -201,11 +205,14 @@ class _Rasterize(torch.autograd.Function):
         v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
         v_colors = torch.empty(C, N, channels, dtype=torch.float32, device=dev)
         v_extra = torch.empty(C, N, dtype=torch.float32, device=dev) if has_extra else None
-        check(lib.mobgs_raster_bwd(C, N, channels, int(has_extra), width, height, ptr(records), ptr(bg), ptr(radii),
-                                   ptr(means2d), ptr(tl.cum_tiles), ptr(tl.tile_offsets), ptr(tl.flatten_ids),
-                                   ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(slots),
-                                   ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra),
-                                   stream()), "mobgs_raster_bwd")
+        with profiler.region("raster_bwd"):
+            check(lib.mobgs_raster_bwd(C, N, channels, int(has_extra), width, height, ptr(records), ptr(bg),
+                                       ptr(radii), ptr(means2d), ptr(tl.cum_tiles), ptr(tl.tile_offsets),
+                                       ptr(tl.flatten_ids), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
+                                       ptr(slots), stream()), "mobgs_raster_bwd")
+        check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(tl.cum_tiles), ptr(slots),
+                                          ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra),
+                                          stream()), "mobgs_raster_bwd_reduce")
         if not colors_per_camera:
             v_colors = v_colors.sum(0) if C > 1 else v_colors[0]
         if not opac_per_camera:
