@@ -375,8 +375,13 @@ void ora_raster_fwd(int C, int N, int D, int W, int H, const float* means2d, con
 }
 
 /* ---- rasterize_to_pixels backward -------------------------------------------------------------------
- * Gradients are accumulated per thread in float (like upstream's float atomics, order differs) and the
- * per-thread buffers are summed in double at the end. */
+ * Per tile the per-splat gradients are accumulated in a tile-local float buffer (upstream: warp reduction),
+ * then added to the global arrays with atomic float adds (upstream: atomicAdd) -- order differs run to run. */
+static inline void atomic_addf(float* p, float v) {
+#pragma omp atomic
+    *p += v;
+}
+
 void ora_raster_bwd(int C, int N, int D, int W, int H, const float* means2d, const float* conics,
                     const float* colors, const float* opacities, const float* backgrounds,
                     const int32_t* isect_offsets, const int32_t* flatten_ids, int64_t n_isects,
@@ -386,89 +391,79 @@ void ora_raster_bwd(int C, int N, int D, int W, int H, const float* means2d, con
     int n_tiles = tw * th;
     size_t G = (size_t)C * N;
     int stride = 6 + D;
-    int nthreads = 1;
-#ifdef _OPENMP
-    nthreads = omp_get_max_threads();
-#endif
-    float* acc = (float*)calloc((size_t)nthreads * G * stride, sizeof(float));
-#pragma omp parallel
-    {
-        int tid = 0;
-#ifdef _OPENMP
-        tid = omp_get_thread_num();
-#endif
-        float* A = acc + (size_t)tid * G * stride;
-#pragma omp for schedule(dynamic, 4)
-        for (int t = 0; t < C * n_tiles; ++t) {
-            int cam = t / n_tiles, tl = t % n_tiles, ty = tl / tw, tx = tl % tw;
-            int s = isect_offsets[t];
-            int e = (t == C * n_tiles - 1) ? (int)n_isects : isect_offsets[t + 1];
-            if (e <= s) continue;
-            for (int i = ty * TILE; i < (ty + 1) * TILE && i < H; ++i)
-                for (int j = tx * TILE; j < (tx + 1) * TILE && j < W; ++j) {
-                    size_t p = ((size_t)cam * H + i) * W + j;
-                    float px = (float)j + 0.5f, py = (float)i + 0.5f;
-                    float T_final = 1.f - render_alphas[p];
-                    float T = T_final;
-                    float buffer[64];
-                    for (int k = 0; k < D; ++k) buffer[k] = 0.f;
-                    int bin_final = last_ids[p];
-                    const float* vr = v_render + p * D;
-                    float va = v_alphas ? v_alphas[p] : 0.f;
-                    int top = bin_final < e - 1 ? bin_final : e - 1;
-                    for (int idx = top; idx >= s; --idx) {
-                        int g = flatten_ids[idx];
-                        float dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
-                        float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
-                        float opac = opacities[g];
-                        float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
-                        float vis = expf(-sigma);
-                        float alpha = fminf(0.999f, opac * vis);
-                        if (sigma < 0.f || alpha < 1.f / 255.f) continue;
-                        float ra = 1.f / (1.f - alpha);
-                        T *= ra;
-                        float fac = alpha * T;
-                        float* a = A + (size_t)g * stride;
-                        const float* c = colors + (size_t)g * D;
-                        float v_alpha = 0.f;
-                        for (int k = 0; k < D; ++k) {
-                            a[6 + k] += fac * vr[k];
-                            v_alpha += (c[k] * T - buffer[k] * ra) * vr[k];
-                        }
-                        v_alpha += T_final * ra * va;
-                        if (backgrounds) {
-                            float accum = 0.f;
-                            for (int k = 0; k < D; ++k) accum += backgrounds[cam * D + k] * vr[k];
-                            v_alpha += -T_final * ra * accum;
-                        }
-                        if (opac * vis <= 0.999f) {
-                            float v_sigma = -opac * vis * v_alpha;
-                            a[0] += v_sigma * (ca * dx + cb * dy);
-                            a[1] += v_sigma * (cb * dx + cc * dy);
-                            a[2] += 0.5f * v_sigma * dx * dx;
-                            a[3] += v_sigma * dx * dy;
-                            a[4] += 0.5f * v_sigma * dy * dy;
-                            a[5] += vis * v_alpha;
-                        }
-                        for (int k = 0; k < D; ++k) buffer[k] += c[k] * fac;
+    memset(v_means2d, 0, sizeof(float) * 2 * G);
+    memset(v_conics, 0, sizeof(float) * 3 * G);
+    memset(v_colors, 0, sizeof(float) * D * G);
+    memset(v_opacities, 0, sizeof(float) * G);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int t = 0; t < C * n_tiles; ++t) {
+        int cam = t / n_tiles, tl = t % n_tiles, ty = tl / tw, tx = tl % tw;
+        int s = isect_offsets[t];
+        int e = (t == C * n_tiles - 1) ? (int)n_isects : isect_offsets[t + 1];
+        if (e <= s) continue;
+        float* loc = (float*)calloc((size_t)(e - s) * stride, sizeof(float));
+        for (int i = ty * TILE; i < (ty + 1) * TILE && i < H; ++i)
+            for (int j = tx * TILE; j < (tx + 1) * TILE && j < W; ++j) {
+                size_t p = ((size_t)cam * H + i) * W + j;
+                float px = (float)j + 0.5f, py = (float)i + 0.5f;
+                float T_final = 1.f - render_alphas[p];
+                float T = T_final;
+                float buffer[64];
+                for (int k = 0; k < D; ++k) buffer[k] = 0.f;
+                int bin_final = last_ids[p];
+                const float* vr = v_render + p * D;
+                float va = v_alphas ? v_alphas[p] : 0.f;
+                int top = bin_final < e - 1 ? bin_final : e - 1;
+                for (int idx = top; idx >= s; --idx) {
+                    int g = flatten_ids[idx];
+                    float dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+                    float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+                    float opac = opacities[g];
+                    float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+                    float vis = expf(-sigma);
+                    float alpha = fminf(0.999f, opac * vis);
+                    if (sigma < 0.f || alpha < 1.f / 255.f) continue;
+                    float ra = 1.f / (1.f - alpha);
+                    T *= ra;
+                    float fac = alpha * T;
+                    float* a = loc + (size_t)(idx - s) * stride;
+                    const float* c = colors + (size_t)g * D;
+                    float v_alpha = 0.f;
+                    for (int k = 0; k < D; ++k) {
+                        a[6 + k] += fac * vr[k];
+                        v_alpha += (c[k] * T - buffer[k] * ra) * vr[k];
                     }
+                    v_alpha += T_final * ra * va;
+                    if (backgrounds) {
+                        float accum = 0.f;
+                        for (int k = 0; k < D; ++k) accum += backgrounds[cam * D + k] * vr[k];
+                        v_alpha += -T_final * ra * accum;
+                    }
+                    if (opac * vis <= 0.999f) {
+                        float v_sigma = -opac * vis * v_alpha;
+                        a[0] += v_sigma * (ca * dx + cb * dy);
+                        a[1] += v_sigma * (cb * dx + cc * dy);
+                        a[2] += 0.5f * v_sigma * dx * dx;
+                        a[3] += v_sigma * dx * dy;
+                        a[4] += 0.5f * v_sigma * dy * dy;
+                        a[5] += vis * v_alpha;
+                    }
+                    for (int k = 0; k < D; ++k) buffer[k] += c[k] * fac;
                 }
+            }
+        for (int idx = s; idx < e; ++idx) {
+            const float* a = loc + (size_t)(idx - s) * stride;
+            size_t g = (size_t)flatten_ids[idx];
+            atomic_addf(&v_means2d[2 * g], a[0]);
+            atomic_addf(&v_means2d[2 * g + 1], a[1]);
+            atomic_addf(&v_conics[3 * g], a[2]);
+            atomic_addf(&v_conics[3 * g + 1], a[3]);
+            atomic_addf(&v_conics[3 * g + 2], a[4]);
+            atomic_addf(&v_opacities[g], a[5]);
+            for (int k = 0; k < D; ++k) atomic_addf(&v_colors[g * D + k], a[6 + k]);
         }
+        free(loc);
     }
-#pragma omp parallel for schedule(static)
-    for (long long g = 0; g < (long long)G; ++g) {
-        double sum[6 + 64];
-        for (int k = 0; k < stride; ++k) sum[k] = 0.0;
-        for (int th_ = 0; th_ < nthreads; ++th_) {
-            const float* a = acc + ((size_t)th_ * G + g) * stride;
-            for (int k = 0; k < stride; ++k) sum[k] += a[k];
-        }
-        v_means2d[2 * g] = (float)sum[0]; v_means2d[2 * g + 1] = (float)sum[1];
-        v_conics[3 * g] = (float)sum[2]; v_conics[3 * g + 1] = (float)sum[3]; v_conics[3 * g + 2] = (float)sum[4];
-        v_opacities[g] = (float)sum[5];
-        for (int k = 0; k < D; ++k) v_colors[(size_t)g * D + k] = (float)sum[6 + k];
-    }
-    free(acc);
 }
 
 int ora_num_threads(void) {
