@@ -161,17 +161,24 @@ decoder_bwd_kernel(int P, int CF, int has_depth, const float* __restrict__ feat_
     }
 }
 
-__global__ void __launch_bounds__(128) decoder_wgrad_reduce_kernel(int nblocks, const float* __restrict__ w_partial,
+// one workgroup per weight component: 90 workgroups x 256 threads sum the per-workgroup partial rows
+__global__ void __launch_bounds__(256) decoder_wgrad_reduce_kernel(int nblocks, const float* __restrict__ w_partial,
                                                                      float* __restrict__ g_w1,
                                                                      float* __restrict__ g_w2) {
-    const int k = threadIdx.x;
-    if (k >= 90) return;
+    const int k = blockIdx.x;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += w_partial[(size_t)b * 90 + k];
-    if (k < 72)
-        g_w1[k] = s;
-    else
-        g_w2[k - 72] = s;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += w_partial[(size_t)b * 90 + k];
+    s = wave_sum_f(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = red[0] + red[1] + red[2] + red[3];
+        if (k < 72)
+            g_w1[k] = t;
+        else
+            g_w2[k - 72] = t;
+    }
 }
 
 }  // namespace mobgs
@@ -213,7 +220,7 @@ int mobgs_decoder_bwd(int P, int CF, int has_depth, const float* feat_hw, const 
     const int g = decoder_grid(P);
     hipLaunchKernelGGL(decoder_bwd_kernel, dim3(g), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth,
                        feat_hw, alphas, rays, w1, w2, v_rgb, v_depth, v_feat_hw, v_alphas, v_rays, w_partial);
-    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, g, w_partial, g_w1,
+    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3(90), dim3(256), 0, (hipStream_t)stream, g, w_partial, g_w1,
                        g_w2);
     return check_launch("decoder_bwd_kernel");
 }

@@ -414,22 +414,17 @@ project_bwd_kernel(int N, const float* __restrict__ means, const float* __restri
     }
 }
 
-// sums the per-workgroup partial rows: one workgroup per camera, fixed order -> deterministic
+// sums the per-workgroup partial rows: one workgroup per (camera, component), fixed order -> deterministic
 __global__ void __launch_bounds__(256) viewmat_reduce_kernel(int nblocks, const float* __restrict__ partial,
                                                                float* __restrict__ v_viewmats) {
-    const int c = blockIdx.x;
-    const int comp = threadIdx.x & 15, part = threadIdx.x >> 4;  // 16 components x 16 strided partial sums
+    const int c = blockIdx.x >> 4, comp = blockIdx.x & 15;
     float acc = 0.f;
-    for (int b = part; b < nblocks; b += 16) acc += partial[((size_t)c * nblocks + b) * 16 + comp];
-    __shared__ float sm[256];
-    sm[threadIdx.x] = acc;
+    for (int b = threadIdx.x; b < nblocks; b += 256) acc += partial[((size_t)c * nblocks + b) * 16 + comp];
+    acc = wave_sum(acc);
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x < 16) {
-        float v = 0.f;
-#pragma unroll
-        for (int p2 = 0; p2 < 16; ++p2) v += sm[p2 * 16 + threadIdx.x];
-        v_viewmats[16 * c + threadIdx.x] = v;
-    }
+    if (threadIdx.x == 0) v_viewmats[16 * c + comp] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
 }  // namespace mobgs
@@ -484,7 +479,7 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
                            v_conics ? v_conics + (size_t)3 * c * N : nullptr, v_means, v_quats, v_scales,
                            v_viewmats_partial + (size_t)c * nblocks * 16, c > 0 ? 1 : 0);
     }
-    hipLaunchKernelGGL(viewmat_reduce_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, nblocks,
+    hipLaunchKernelGGL(viewmat_reduce_kernel, dim3(16 * C), dim3(256), 0, (hipStream_t)stream, nblocks,
                        v_viewmats_partial, v_viewmats);
     return check_launch("project_bwd_kernel");
 }

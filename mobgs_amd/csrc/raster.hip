@@ -201,23 +201,42 @@ raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
 // ---------------------------------------------------------------------------------------------------
 // backward, stage 1: per-(tile, splat) gradient records
 // ---------------------------------------------------------------------------------------------------
+// Wave-wide sum of NVP per-lane values with the cross-lane hardware of gfx950, no LDS traffic, no selects:
+//   1. v_permlane32_swap pairs component i with i+NVP/2: one swap + one add leaves the sum over lane bit 5 of
+//      the low-half components in lanes 0-31 and of the high-half components in lanes 32-63;
+//   2. v_permlane16_swap does the same for lane bit 4 (odd/even rows of 16 lanes);
+//   3. the NVP/4 survivors are all-reduced inside each 16-lane row with four DPP adds
+//      (quad_perm xor 1, quad_perm xor 2, row_half_mirror, row_ror:8).
+// Afterwards every lane of row r (= lane >> 4) holds, in v[0 .. NVP/4), the wave totals of components
+//   (r >> 1) * NVP/2 + (r & 1) * NVP/4 + k.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row_allreduce(float v) {
+    v = dpp_add<0xB1>(v);   // quad_perm:[1,0,3,2]
+    v = dpp_add<0x4E>(v);   // quad_perm:[2,3,0,1]
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    v = dpp_add<0x128>(v);  // row_ror:8
+    return v;
+}
 template <int NVP>
-__device__ __forceinline__ float butterfly_reduce(float (&v)[NVP], int lane) {
-    // after the halving steps lane l holds component (l & (NVP-1)) summed over its NVP-lane group
+__device__ __forceinline__ void wave_reduce_components(float (&v)[NVP]) {
+    static_assert(NVP >= 8 && (NVP & (NVP - 1)) == 0, "NVP must be a power of two >= 8");
 #pragma unroll
-    for (int m = NVP / 2; m >= 1; m >>= 1) {
-        const bool up = (lane & m) != 0;
-#pragma unroll
-        for (int i = 0; i < m; ++i) {
-            const float keep = up ? v[m + i] : v[i];
-            const float send = up ? v[i] : v[m + i];
-            v[i] = keep + __shfl_xor(send, m, 64);
-        }
+    for (int i = 0; i < NVP / 2; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + NVP / 2]), false,
+                                                        false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
-    float r = v[0];
 #pragma unroll
-    for (int b = NVP; b < 64; b <<= 1) r += __shfl_xor(r, b, 64);
-    return r;
+    for (int i = 0; i < NVP / 4; ++i) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + NVP / 4]), false,
+                                                        false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < NVP / 4; ++i) v[i] = row_allreduce(v[i]);
 }
 
 template <int CD>
@@ -357,8 +376,21 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
 #pragma unroll
                 for (int c = 0; c < CD; ++c) buf[k][c] = __fmaf_rn(rec[6 + c], fac, buf[k][c]);
             }
-            const float r = butterfly_reduce<NVP>(g, lane);
-            if (lane < RS) grad_slots[(size_t)slot_of[wv][j] * RS + lane] = r;
+            wave_reduce_components<NVP>(g);
+            // lane 0 of each 16-lane row stores its NVP/4 consecutive components (64 B per record for D = 10)
+            constexpr int Q = NVP / 4;
+            const int base = (lane >> 5) * (NVP / 2) + ((lane >> 4) & 1) * Q;
+            if ((lane & 15) == 0 && base < RS) {
+                float* dst = grad_slots + (size_t)slot_of[wv][j] * RS + base;
+                if constexpr (Q == 2) {
+                    *reinterpret_cast<float2*>(dst) = make_float2(g[0], g[1]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < Q; q += 4)
+                        if (base + q < RS)
+                            *reinterpret_cast<float4*>(dst + q) = make_float4(g[q], g[q + 1], g[q + 2], g[q + 3]);
+                }
+            }
         }
     }
 }
