@@ -65,7 +65,9 @@ class SubframeShard:
 
     def render_blurry_view(self, render_unit: Callable[[int], torch.Tensor], n_units: int,
                            like: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """render_unit(k) -> sharp latent image of sub-frame k.  Returns the blurry prediction (all ranks)."""
+        """render_unit(k) -> sharp latent image of sub-frame k.  Returns the blurry prediction (all ranks).
+        A rank that owns no sub-frame (world > n_units) contributes zeros; its prediction then does not require
+        grad, so it must skip loss.backward() but still call all_reduce_gradients()."""
         mine = self.units(n_units)
         local = None
         for k in mine:
