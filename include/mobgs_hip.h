@@ -168,6 +168,32 @@ int mobgs_decoder_bwd(int P, int CF, int has_depth, const float* feat_hw, const 
                       const float* v_depth, float* v_feat_hw, float* v_alphas, float* v_rays, float* w_partial,
                       float* g_w1, float* g_w2, void* stream);
 
+/* ---- K10: deformation network (the API the reference exposes as scene.deformation.deform_network) -----
+ * /root/reference/scene/hexplane.py:75-108,165-187 (HexPlane multi-resolution bilinear planes, product over the
+ * 6 planes of a level, concat over 3 levels -> 96 features); /root/reference/scene/deformation.py:158-199
+ * (Linear 96->128, three ReLU-Linear(128,128)-ReLU-Linear(128,{7,3,4}) heads, point/scale/rotation update).
+ *
+ * planes_host / gplanes_host: HOST arrays of 18 device pointers, index level*6 + plane with plane order
+ *   (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); every plane is CHANNELS-LAST [rb][ra][32] (ra = resolution of the first
+ *   axis of the pair, rb of the second) -- the host permutes the reference's [1,32,rb,ra] parameters.
+ * ra_host / rb_host: HOST int32[18].   aabb: device [2,3] = {xyz_max, xyz_min} (the reference's convention).
+ * mobgs_hexplane_fwd : pts [N,3], times [N]  ->  feat [N,96]
+ * mobgs_hexplane_bwd : v_feat [N,96] -> gplanes (ACCUMULATED with float atomics; zero them first),
+ *                      v_pts [N,3] (ADDED to its current content), v_times [N] (written)
+ * mobgs_deform_mlp_fwd: feat + pts/scales/rots [N,3]/[N,3]/[N,4] -> out_pts, out_scales, out_rots (MFMA fp32).
+ *   Weights K-major: W0t [96,128], b0 [128], W1t [3,128,128], b1 [3,128], W2t [3,128,32] (7/3/4 real columns,
+ *   zero padded), b2 [3,32]; head order: position, scale, rotation. */
+int mobgs_hexplane_fwd(int N, const float* pts, const float* times, const float* aabb,
+                       const float* const* planes_host, const int32_t* ra_host, const int32_t* rb_host,
+                       float* feat, void* stream);
+int mobgs_hexplane_bwd(int N, const float* pts, const float* times, const float* aabb,
+                       const float* const* planes_host, const int32_t* ra_host, const int32_t* rb_host,
+                       const float* v_feat, float* const* gplanes_host, float* v_pts, float* v_times,
+                       void* stream);
+int mobgs_deform_mlp_fwd(int N, const float* feat, const float* pts, const float* scales, const float* rots,
+                         const float* W0t, const float* b0, const float* W1t, const float* b1, const float* W2t,
+                         const float* b2, float* out_pts, float* out_scales, float* out_rots, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,9 @@ _SIGS = {
     "mobgs_decoder_fwd": (c_int, [c_int, c_int, c_int] + [P] * 7 + [P]),
     "mobgs_decoder_bwd_blocks": (c_int, [c_int]),
     "mobgs_decoder_bwd": (c_int, [c_int, c_int, c_int] + [P] * 13 + [P]),
+    "mobgs_hexplane_fwd": (c_int, [c_int] + [P] * 7 + [P]),
+    "mobgs_hexplane_bwd": (c_int, [c_int] + [P] * 10 + [P]),
+    "mobgs_deform_mlp_fwd": (c_int, [c_int] + [P] * 13 + [P]),
 }
 # entry points added by later translation units (bound if present in the header AND the library)
 _OPTIONAL_SIGS = {}

@@ -202,6 +202,55 @@ def gen_sandwich(name):
          grad_w2=np_(dec.mlp2.weight.grad))
 
 
+def deform_weights(net):
+    """Flat weight dict of a reference deform_network (state_dict key mapping used by mobgs_amd.deformation)."""
+    d = net.deformation_net
+    W = {"w0": d.feature_out[0].weight, "b0": d.feature_out[0].bias}
+    for name, seq in (("pos", d.pos_deform), ("scl", d.scales_deform), ("rot", d.rotations_deform)):
+        W[name + "_w1"], W[name + "_b1"] = seq[1].weight, seq[1].bias
+        W[name + "_w2"], W[name + "_b2"] = seq[3].weight, seq[3].bias
+    return W
+
+
+def gen_deform(name, n=700, seed=4):
+    dm = RH.ref_import("scene.deformation")
+    args = RH.Args()
+    args.kplanes_config = dict(args.kplanes_config, resolution=[8, 8, 8, 4])  # small planes keep the fixture small
+    with RH.CudaToCpu():
+        torch.manual_seed(seed)
+        net = dm.deform_network(args)
+        # biases keep PyTorch's default init upstream; randomise the planes so the product is not trivial
+        g = torch.Generator().manual_seed(seed)
+        for level in net.deformation_net.grid.grids:
+            for pl in level:
+                pl.data = 0.5 + 0.5 * torch.rand(pl.shape, generator=g)
+        xyz_max, xyz_min = [1.2, 1.0, 1.5], [-1.1, -0.9, -0.2]
+        net.deformation_net.set_aabb(xyz_max, xyz_min)
+    g = torch.Generator().manual_seed(seed + 1)
+    lo, hi = torch.tensor(xyz_min), torch.tensor(xyz_max)
+    pts = (lo + (hi - lo) * (1.2 * torch.rand(n, 3, generator=g) - 0.1)).requires_grad_(True)  # some outside the box
+    scales = (0.1 * torch.randn(n, 3, generator=g)).requires_grad_(True)
+    rots = torch.randn(n, 4, generator=g).requires_grad_(True)
+    times = torch.rand(n, 1, generator=g)
+    with RH.CudaToCpu():
+        o_pts, o_scl, o_rot = net(pts, scales, rots, times)
+    v = [torch.randn(o.shape, generator=g) for o in (o_pts, o_scl, o_rot)]
+    ((o_pts * v[0]).sum() + (o_scl * v[1]).sum() + (o_rot * v[2]).sum()).backward()
+    arrays = {"in_pts": np_(pts), "in_scales": np_(scales), "in_rots": np_(rots), "in_times": np_(times),
+              "in_aabb": np_(net.deformation_net.grid.aabb), "out_pts": np_(o_pts), "out_scales": np_(o_scl),
+              "out_rots": np_(o_rot), "cot_pts": np_(v[0]), "cot_scales": np_(v[1]), "cot_rots": np_(v[2]),
+              "grad_pts": np_(pts.grad), "grad_scales": np_(scales.grad), "grad_rots": np_(rots.grad)}
+    for k, w in deform_weights(net).items():
+        arrays["w_" + k] = np_(w)
+        arrays["gw_" + k] = np_(w.grad)
+    for li, level in enumerate(net.deformation_net.grid.grids):
+        for pi, pl in enumerate(level):
+            arrays[f"plane_{li}_{pi}"] = np_(pl)
+            arrays[f"gplane_{li}_{pi}"] = np_(pl.grad)
+    arrays["n_params"] = np.array([sum(p.numel() for p in net.parameters())])
+    save(name, **arrays)
+
+
 def main():
     RH.install()
     gen_hermite("hermite")
@@ -210,6 +259,7 @@ def main():
     gen_render("render_train_delta_flow", 900, 500, 80, 48, 1, True, True, 0.3, True, False)
     gen_render("render_train", 700, 400, 64, 48, 2, True, True, None, False, False)
     gen_get_flow("get_flow", 900, 500, 80, 48, 3, -0.4)
+    gen_deform("deform")
 
 
 if __name__ == "__main__":

@@ -242,3 +242,19 @@ def test_render_restatement_matches_reference_live():
                 close(mine[k], v, 1e-5, 1e-5 * max(1.0, float(v.abs().max())), k)
         else:
             assert mine[k] is None, k
+
+
+def test_deform_restatement_matches_reference_fixture():
+    from oracle import deform_torch as D
+    fx = load("deform")
+    T = torch.from_numpy
+    planes = [[T(fx[f"plane_{l}_{p}"]).requires_grad_(True) for p in range(6)] for l in range(3)]
+    W = {k[2:]: T(v).requires_grad_(True) for k, v in fx.items() if k.startswith("w_")}
+    pts, scales, rots = (T(fx[k]).requires_grad_(True) for k in ("in_pts", "in_scales", "in_rots"))
+    o = D.deform_forward(pts, scales, rots, T(fx["in_times"]), T(fx["in_aabb"]), planes, W)
+    for a, k in zip(o, ("out_pts", "out_scales", "out_rots")):
+        close(a, fx[k], 1e-6, 1e-6, k)
+    ((o[0] * T(fx["cot_pts"])).sum() + (o[1] * T(fx["cot_scales"])).sum() + (o[2] * T(fx["cot_rots"])).sum()).backward()
+    close(pts.grad, fx["grad_pts"], 1e-5, 1e-6, "grad pts")
+    close(W["w0"].grad, fx["gw_w0"], 1e-5, 1e-6, "grad w0")
+    close(planes[2][0].grad, fx["gplane_2_0"], 1e-5, 1e-7, "grad plane 2.0")
