@@ -251,6 +251,38 @@ def gen_deform(name, n=700, seed=4):
     save(name, **arrays)
 
 
+def gen_blce(name, num_views=3, seed=8):
+    bl = RH.ref_import("scene.blce")
+    with RH.CudaToCpu():
+        torch.manual_seed(seed)
+        model = bl.BLCE(num_views=num_views, view_dim=32, num_warp=9, method="euler", adjoint=False)
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():  # the decoders start at 1e-5 gain (near-identity warps): make the fixture non-trivial
+            for i in range(num_views):
+                for dec, sc in ((model.rot_decoder[i], 0.3), (model.trans_decoder[i], 0.05), (model.theta_decoder[i], 0.1)):
+                    dec.weight.copy_(sc * torch.randn(dec.weight.shape, generator=g))
+                    dec.bias.copy_(0.1 * sc * torch.randn(dec.bias.shape, generator=g))
+                model.wv_derivative[i].time_embedder.data = 0.5 * torch.randn(9, 8, generator=g)
+            model.view_embedder.data = torch.randn(num_views, 32, generator=g)
+            model.exposure_time_expo.data = torch.tensor([0.4, 0.25, 0.6])[:num_views]
+        c2w = torch.inverse(small_w2c())
+        img = torch.rand(3, 48, 64, generator=g)
+        blur = bl.compute_frequency_blur_feature(img)
+        idx = 1
+        Rt_new, expo = model(c2w, blur, idx)
+    v = torch.randn(Rt_new.shape, generator=g)
+    (Rt_new * v).sum().backward()
+    arrays = {"in_c2w": np_(c2w), "in_image": np_(img), "in_idx": np.array([idx]), "out_blur": np_(blur),
+              "out_Rt_new": np_(Rt_new), "out_exposure": np_(expo), "cot": np_(v),
+              "n_params": np.array([sum(p.numel() for p in model.parameters())])}
+    for k, p_ in model.state_dict().items():
+        arrays["sd_" + k] = np_(p_)
+    for k, p_ in model.named_parameters():
+        if p_.grad is not None and (f".{idx}." in k or k == "view_embedder"):
+            arrays["grad_" + k] = np_(p_.grad)
+    save(name, **arrays)
+
+
 def main():
     RH.install()
     gen_hermite("hermite")
@@ -260,6 +292,7 @@ def main():
     gen_render("render_train", 700, 400, 64, 48, 2, True, True, None, False, False)
     gen_get_flow("get_flow", 900, 500, 80, 48, 3, -0.4)
     gen_deform("deform")
+    gen_blce("blce")
 
 
 if __name__ == "__main__":

@@ -94,6 +94,8 @@ def install():
     scene = types.ModuleType("scene")
     scene.__path__ = [os.path.join(REF, "scene")]
     sys.modules["scene"] = scene
+    # scene.cameras drags in dycheck_geometry -> ffmpeg/jax...; blce.py only needs the Camera NAME
+    stub("scene.cameras", Camera=type("Camera", (), {}))
     # the reference's top-level packages must win over same-named ones in this repo
     sys.path.insert(0, REF)
 
