@@ -72,27 +72,40 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
                       float* v_scales, float* v_viewmats, float* v_viewmats_partial, void* stream);
 
 /* ---- K3a: intersection offsets (replaces isect_tiles pass 1 + cumsum + isect_offset_encode) ------------
- * in : tiles_per_gauss [C*N], means2d, radii
- * out: cum_tiles [C*N+1] exclusive prefix sum (cum_tiles[C*N] = total intersections I)
- *      tile_offsets [C*n_tiles+1] exclusive prefix sum of per-tile list lengths
- *      stats[0] = I, stats[1] = longest per-tile list (int64 each) -- the caller reads these back to size
- *      the intersection buffers (the one host sync of the pipeline, as in gsplat).
- * scratch: mobgs_isect_scratch_bytes(C*N, C*n_tiles) bytes. */
-size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles);
-int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, const int32_t* tiles_per_gauss,
-                        const float* means2d, const int32_t* radii, int32_t* cum_tiles,
-                        int32_t* tile_offsets, int64_t* stats, void* scratch, void* stream);
+ * in : tiles_per_gauss [C*N] (bounding-box tile counts from mobgs_project_fwd), means2d, radii, conics,
+ *      opacities ([C,N] when opac_per_camera else [N])
+ * cull = 0: every bounding-box intersection is listed -- exactly upstream's lists.
+ * cull = 1: a (tile, splat) pair is listed only if the splat can reach alpha >= 1/255 somewhere on the tile's
+ *      pixel rectangle (min over the rectangle of sigma <= ln(255*opacity), conservative margin).  Pairs that
+ *      fail are skipped by the compositor at all 256 pixels anyway, so every output pixel and gradient is
+ *      unchanged; lists, sort and gradient slots shrink (about 2x on anisotropic scenes).
+ * out: cum_tiles [C*N+1] exclusive prefix sum of the BOX counts (cum_tiles[C*N] = I_box)
+ *      keep_scan [capacity+1] exclusive prefix sum of the keep flags over the box intersections:
+ *                box intersection j is listed iff keep_scan[j+1] > keep_scan[j]; its compact index (= its
+ *                gradient slot in mobgs_raster_bwd) is keep_scan[j]
+ *      tile_offsets [C*n_tiles+1] exclusive prefix sum of the per-tile list lengths
+ *      stats int64[3] = {I_box, I_listed, longest per-tile list}; the caller reads them back to size the list
+ *      buffers (the one host sync of the pipeline, as in gsplat).  If I_box > capacity the flags were
+ *      truncated: call again with capacity >= I_box.
+ * scratch: mobgs_isect_scratch_bytes(C*N, C*n_tiles, capacity) bytes. */
+size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity);
+int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
+                        const int32_t* tiles_per_gauss, const float* means2d, const int32_t* radii,
+                        const float* conics, const float* opacities, int opac_per_camera,
+                        int32_t* cum_tiles, int32_t* keep_scan, int32_t* tile_offsets, int64_t* stats,
+                        void* scratch, void* stream);
 
 /* ---- K3b/K4: emit + per-tile depth sort (replaces isect_tiles pass 2 + CUB DeviceRadixSort) ------------
- * Writes, per tile, its Gaussians ordered by (float depth bits ascending, flat id ascending) -- the order a
+ * Writes, per tile, its listed splats ordered by (float depth bits ascending, flat id ascending) -- the order a
  * stable LSD radix sort on gsplat's 64-bit key produces.
- * out: flatten_ids [I] (cam*N+gaussian), isect_ids [I] (gsplat's u64 key; may be NULL)
- * scratch: tile_cursor [C*n_tiles] int32 (zeroed by this call); sort_keys [I] u64.
- * max_tile_len is stats[1] from mobgs_isect_offsets (selects the LDS sort variant). */
+ * n_isects = stats[1], max_tile_len = stats[2] of mobgs_isect_offsets (the latter selects the LDS sort variant).
+ * out: flatten_ids [n_isects] (cam*N+gaussian), isect_ids [n_isects] (gsplat's u64 key; may be NULL)
+ * scratch: tile_cursor [C*n_tiles] int32 (zeroed by this call); sort_keys [n_isects] u64. */
 int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int64_t n_isects, int64_t max_tile_len,
                           const float* means2d, const int32_t* radii, const float* depths,
-                          const int32_t* cum_tiles, const int32_t* tile_offsets, int32_t* tile_cursor,
-                          uint64_t* sort_keys, int32_t* flatten_ids, uint64_t* isect_ids, void* stream);
+                          const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
+                          int32_t* tile_cursor, uint64_t* sort_keys, int32_t* flatten_ids, uint64_t* isect_ids,
+                          void* stream);
 
 /* ---- K6: rasterise forward (replaces gsplat rasterize_to_pixels fwd) -----------------------------------
  * colors   : [C,N,channels] (colors_per_camera=1) or [N,channels] (0)
@@ -112,18 +125,19 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
  * Deterministic two-stage gradient reduction, no floating-point atomics:
  *   stage 1 (mobgs_raster_bwd) walks every tile back to front and writes ONE gradient record
  *     {v_x, v_y, v_conic a b c, v_opacity, v_colour[..]} per (tile, splat) intersection into
- *     grad_slots [I, stride]; slot = cum_tiles[flat id] + position of the tile inside the splat's tile
- *     rectangle.  grad_slots must be zero-filled by the caller (intersections that no pixel blended stay 0).
+ *     grad_slots [I_listed, stride]; slot = keep_scan[cum_tiles[flat id] + position of the tile inside the
+ *     splat's tile rectangle].  grad_slots must be zero-filled by the caller (intersections that no pixel blended stay 0).
  *   stage 2 (mobgs_raster_bwd_reduce) sums each splat's contiguous slots into the dense gradients
  *     v_means2d [C,N,2], v_conics [C,N,3], v_opacities [C,N], v_colors [C,N,channels], v_extra [C,N] (NULL when
  *     there was no extra channel); all fully written. */
 int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int height,
                      const float* records, const float* backgrounds, const int32_t* radii,
-                     const float* means2d, const int32_t* cum_tiles, const int32_t* tile_offsets,
-                     const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
-                     const float* v_render, const float* v_alphas, float* grad_slots, void* stream);
+                     const float* means2d, const int32_t* cum_tiles, const int32_t* keep_scan,
+                     const int32_t* tile_offsets, const int32_t* flatten_ids, const float* render_alphas,
+                     const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
+                     void* stream);
 int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int32_t* cum_tiles,
-                            const float* grad_slots, float* v_means2d, float* v_conics, float* v_opacities,
+                            const int32_t* keep_scan, const float* grad_slots, float* v_means2d, float* v_conics, float* v_opacities,
                             float* v_colors, float* v_extra, void* stream);
 
 /* 1 if raster kernels are compiled for `total_channels` (colour channels + optional extra channel). */

@@ -10,6 +10,13 @@
 // inside LDS by a bitonic network on the 64-bit key (depth bits << 32 | flat splat id).  The key is
 // unique, so the unstable network reproduces exactly the order of upstream's stable radix sort:
 // ascending depth bits, ties by ascending splat index.
+//
+// Reach culling (optional, on by default in the host wrapper): upstream lists a splat in every tile its
+// 3-sigma bounding BOX touches.  A (tile, splat) pair whose smallest possible sigma over the tile's pixel
+// rectangle already exceeds ln(255 * opacity) cannot reach alpha >= 1/255 at any pixel of the tile, so the
+// compositor would skip it at all 256 pixels; dropping the pair from the list leaves every pixel bit-identical
+// and removes ~half of the intersections on anisotropic scenes.  The test is conservative (margin on the
+// threshold); with culling off the lists are exactly upstream's.
 #include "common.h"
 
 namespace mobgs {
@@ -45,8 +52,17 @@ __device__ inline int block_incl_scan(int v, int* total) {
     return inc + base;
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_block_sums_kernel(int n, const int32_t* __restrict__ in,
+// n is read from device memory (*n_ptr, clamped to n_cap) so that a scan can follow a kernel that produced
+// its own length without a host round trip; grids are sized for n_cap.
+__device__ inline int scan_len(const int32_t* n_ptr, int n_cap) {
+    const int n = n_ptr ? *n_ptr : n_cap;
+    return n < n_cap ? n : n_cap;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_block_sums_kernel(const int32_t* __restrict__ n_ptr, int n_cap,
+                                                                         const int32_t* __restrict__ in,
                                                                          int32_t* __restrict__ block_sums) {
+    const int n = scan_len(n_ptr, n_cap);
     const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
     int s = 0;
 #pragma unroll
@@ -56,10 +72,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_block_sums_kernel(int n, co
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// single workgroup: in-place exclusive scan of block_sums[nb]; writes the grand total to out_total[0]
-__global__ void __launch_bounds__(SCAN_THREADS) scan_sums_kernel(int nb, int32_t* __restrict__ block_sums,
-                                                                   int32_t* __restrict__ out_last,
-                                                                   int64_t* __restrict__ stats0) {
+// single workgroup: in-place exclusive scan of block_sums[nb]; the grand total goes to out[n] and stats_slot
+__global__ void __launch_bounds__(SCAN_THREADS) scan_sums_kernel(const int32_t* __restrict__ n_ptr, int n_cap, int nb,
+                                                                   int32_t* __restrict__ block_sums,
+                                                                   int32_t* __restrict__ out,
+                                                                   int64_t* __restrict__ stats_slot) {
     int carry = 0;
     for (int start = 0; start < nb; start += SCAN_THREADS) {
         const int i = start + threadIdx.x;
@@ -70,15 +87,18 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_sums_kernel(int nb, int32_t
         carry += total;
     }
     if (threadIdx.x == 0) {
-        *out_last = carry;
-        if (stats0) *stats0 = (int64_t)carry;
+        out[scan_len(n_ptr, n_cap)] = carry;
+        if (stats_slot) *stats_slot = (int64_t)carry;
     }
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(int n, const int32_t* __restrict__ in,
+__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const int32_t* __restrict__ n_ptr, int n_cap,
+                                                                    const int32_t* __restrict__ in,
                                                                     const int32_t* __restrict__ block_sums,
                                                                     int32_t* __restrict__ out) {
+    const int n = scan_len(n_ptr, n_cap);
     const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+    if (blockIdx.x * SCAN_BLOCK >= n) return;
     int v[SCAN_ITEMS];
     int s = 0;
 #pragma unroll
@@ -123,16 +143,62 @@ __device__ inline int tile_of(int j, int g, int N, int tile_w, int tile_h, const
     return (cam * tile_h + ty) * tile_w + tx;
 }
 
-__global__ void __launch_bounds__(256) tile_hist_kernel(int n_gauss, int N, int tile_w, int tile_h,
-                                                          const int32_t* __restrict__ cum,
-                                                          const float* __restrict__ means2d,
-                                                          const int32_t* __restrict__ radii,
-                                                          int32_t* __restrict__ tile_count) {
-    const int I = cum[n_gauss];
+// Smallest sigma = 0.5 (a dx^2 + c dy^2) + b dx dy a splat can take over the pixel-centre rectangle of a tile
+// (convex quadratic: 0 if the centre is inside, else attained on one of the four edges).
+__device__ inline float min_sigma_over_tile(float mx, float my, float ca, float cb, float cc, float x0, float x1,
+                                            float y0, float y1) {
+    if (mx >= x0 && mx <= x1 && my >= y0 && my <= y1) return 0.f;
+    float best = 3.0e38f;
+    const float ex[2] = {x0, x1}, ey[2] = {y0, y1};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        {  // vertical edge px = ex[k]: optimum dy = -cb dx / cc
+            const float dx = mx - ex[k];
+            const float py = fminf(fmaxf(my + cb * dx / cc, y0), y1);
+            const float dy = my - py;
+            best = fminf(best, 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy);
+        }
+        {  // horizontal edge py = ey[k]
+            const float dy = my - ey[k];
+            const float px = fminf(fmaxf(mx + cb * dy / ca, x0), x1);
+            const float dx = mx - px;
+            best = fminf(best, 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy);
+        }
+    }
+    return best;
+}
+
+// one thread per bounding-box intersection j: keep flag (1 = listed) + per-tile histogram of the kept ones
+__global__ void __launch_bounds__(256)
+flag_hist_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
+                 const int32_t* __restrict__ cum, const float* __restrict__ means2d,
+                 const int32_t* __restrict__ radii, const float* __restrict__ conics,
+                 const float* __restrict__ opacities, int opac_per_camera, int32_t* __restrict__ flags,
+                 int32_t* __restrict__ tile_count) {
+    const int I = min(cum[n_gauss], capacity);
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < I; j += gridDim.x * blockDim.x) {
         const int g = owner_of(cum, n_gauss, j);
         const int t = tile_of(j, g, N, tile_w, tile_h, cum, means2d, radii);
-        atomicAdd(&tile_count[t], 1);
+        int keep = 1;
+        if (cull) {
+            const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+            const float op = opacities[opac_per_camera ? g : g % N];
+            if (!(op * 255.f >= 1.f)) {
+                keep = 0;  // alpha = min(0.999, op * exp(-sigma)) < 1/255 everywhere (sigma >= 0 where blended)
+            } else if (ca > 0.f && cc > 0.f) {
+                const int tl = t % (tile_w * tile_h);
+                const int ty = tl / tile_w, tx = tl - ty * tile_w;
+                const float x0 = (float)(tx * MOBGS_TILE) + 0.5f, y0 = (float)(ty * MOBGS_TILE) + 0.5f;
+                const float x1 = fminf((float)(tx * MOBGS_TILE) + 15.5f, (float)width - 0.5f);
+                const float y1 = fminf((float)(ty * MOBGS_TILE) + 15.5f, (float)height - 0.5f);
+                const float2 m = reinterpret_cast<const float2*>(means2d)[g];
+                const float tau = __logf(255.f * op);
+                const float smin = min_sigma_over_tile(m.x, m.y, ca, cb, cc, x0, x1, y0, y1);
+                keep = (smin <= tau + 0.05f + 0.02f * tau) ? 1 : 0;  // conservative: fp32 evaluation orders differ
+            }
+        }
+        flags[j] = keep;
+        if (keep) atomicAdd(&tile_count[t], 1);
     }
 }
 
@@ -159,12 +225,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(int nt, const i
     }
     if (threadIdx.x == 0) {
         tile_offsets[nt] = carry;
-        stats[1] = (int64_t)smax[0];
+        stats[2] = (int64_t)smax[0];
     }
 }
 
 __global__ void __launch_bounds__(256) emit_kernel(int n_gauss, int N, int tile_w, int tile_h,
                                                      const int32_t* __restrict__ cum,
+                                                     const int32_t* __restrict__ keep_scan,
                                                      const float* __restrict__ means2d,
                                                      const int32_t* __restrict__ radii,
                                                      const float* __restrict__ depths,
@@ -173,6 +240,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int n_gauss, int N, int tile_
                                                      uint64_t* __restrict__ sort_keys) {
     const int I = cum[n_gauss];
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < I; j += gridDim.x * blockDim.x) {
+        if (keep_scan[j + 1] == keep_scan[j]) continue;  // culled
         const int g = owner_of(cum, n_gauss, j);
         const int t = tile_of(j, g, N, tile_w, tile_h, cum, means2d, radii);
         const int r = atomicAdd(&tile_cursor[t], 1);
@@ -263,38 +331,57 @@ using namespace mobgs;
 
 extern "C" {
 
-size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles) {
-    const size_t nb = (size_t)(n_gauss + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
-    return sizeof(int32_t) * (nb + (size_t)n_tiles + 16);
+size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity) {
+    const size_t nb1 = (size_t)(n_gauss + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
+    const size_t nb2 = (size_t)(capacity + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
+    return sizeof(int32_t) * (nb1 + nb2 + (size_t)n_tiles + (size_t)capacity + 32);
 }
 
-int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, const int32_t* tiles_per_gauss,
-                        const float* means2d, const int32_t* radii, int32_t* cum_tiles, int32_t* tile_offsets,
-                        int64_t* stats, void* scratch, void* stream) {
+int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
+                        const int32_t* tiles_per_gauss, const float* means2d, const int32_t* radii,
+                        const float* conics, const float* opacities, int opac_per_camera, int32_t* cum_tiles,
+                        int32_t* keep_scan, int32_t* tile_offsets, int64_t* stats, void* scratch, void* stream) {
     const long long ng = (long long)C * N;
     const long long nt = (long long)C * tile_w * tile_h;
-    if (C <= 0 || N < 0 || ng >= (1ll << 31) - 1 || nt >= (1ll << 31) - 1) {
-        set_error("mobgs_isect_offsets: bad sizes C=%d N=%d tiles=%dx%d", C, N, tile_w, tile_h);
+    if (C <= 0 || N < 0 || capacity < 1 || ng >= (1ll << 31) - 1 || nt >= (1ll << 31) - 1) {
+        set_error("mobgs_isect_offsets: bad sizes C=%d N=%d tiles=%dx%d capacity=%d", C, N, tile_w, tile_h, capacity);
         return MOBGS_E_INVALID;
     }
     hipStream_t st = (hipStream_t)stream;
     const int n = (int)ng;
-    const int nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    int32_t* block_sums = (int32_t*)scratch;
-    int32_t* tile_count = block_sums + nb + 1;
+    const int nb1 = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    const int nb2 = (capacity + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    int32_t* block_sums1 = (int32_t*)scratch;
+    int32_t* block_sums2 = block_sums1 + nb1 + 1;
+    int32_t* tile_count = block_sums2 + nb2 + 1;
+    int32_t* flags = tile_count + nt;
     hipMemsetAsync(tile_count, 0, sizeof(int32_t) * nt, st);
     if (n == 0) {
         hipMemsetAsync(cum_tiles, 0, sizeof(int32_t), st);
-        hipMemsetAsync(stats, 0, 2 * sizeof(int64_t), st);
+        hipMemsetAsync(keep_scan, 0, sizeof(int32_t), st);
+        hipMemsetAsync(stats, 0, 3 * sizeof(int64_t), st);
         hipMemsetAsync(tile_offsets, 0, sizeof(int32_t) * (nt + 1), st);
         return check_launch("isect_offsets(empty)");
     }
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, n, tiles_per_gauss, block_sums);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, nb, block_sums, cum_tiles + n, stats);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, n, tiles_per_gauss, block_sums,
-                       cum_tiles);
-    hipLaunchKernelGGL(tile_hist_kernel, dim3(2048), dim3(256), 0, st, n, N, tile_w, tile_h, cum_tiles, means2d,
-                       radii, tile_count);
+    // bounding-box counts -> cum_tiles; stats[0] = I_box
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb1), dim3(SCAN_THREADS), 0, st, nullptr, n, tiles_per_gauss,
+                       block_sums1);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, nullptr, n, nb1, block_sums1, cum_tiles,
+                       stats);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb1), dim3(SCAN_THREADS), 0, st, nullptr, n, tiles_per_gauss,
+                       block_sums1, cum_tiles);
+    // keep flags + per-tile histogram (only the first `capacity` intersections; the caller re-runs with a larger
+    // buffer when stats[0] > capacity)
+    hipLaunchKernelGGL(flag_hist_kernel, dim3(2048), dim3(256), 0, st, n, N, tile_w, tile_h, width, height, cull,
+                       capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera, flags, tile_count);
+    // keep_scan = exclusive scan of the flags over [0, min(I_box, capacity)); stats[1] = I_kept
+    const int32_t* n_ptr = cum_tiles + n;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb2), dim3(SCAN_THREADS), 0, st, n_ptr, capacity, flags,
+                       block_sums2);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, n_ptr, capacity, nb2, block_sums2,
+                       keep_scan, stats + 1);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb2), dim3(SCAN_THREADS), 0, st, n_ptr, capacity, flags, block_sums2,
+                       keep_scan);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, (int)nt, tile_count, tile_offsets,
                        stats);
     return check_launch("isect_offsets");
@@ -302,8 +389,9 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, const int32_t* til
 
 int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int64_t n_isects, int64_t max_tile_len,
                           const float* means2d, const int32_t* radii, const float* depths,
-                          const int32_t* cum_tiles, const int32_t* tile_offsets, int32_t* tile_cursor,
-                          uint64_t* sort_keys, int32_t* flatten_ids, uint64_t* isect_ids, void* stream) {
+                          const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
+                          int32_t* tile_cursor, uint64_t* sort_keys, int32_t* flatten_ids, uint64_t* isect_ids,
+                          void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int tiles_per_cam = tile_w * tile_h;
     const int nt = C * tiles_per_cam;
@@ -314,10 +402,8 @@ int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int64_t n_isects
     if (n_isects == 0) return MOBGS_OK;
     hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * nt, st);
     const int n = C * N;
-    int grid = (int)((n_isects + 255) / 256);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(256), 0, st, n, N, tile_w, tile_h, cum_tiles, means2d, radii,
-                       depths, tile_offsets, tile_cursor, sort_keys);
+    hipLaunchKernelGGL(emit_kernel, dim3(4096), dim3(256), 0, st, n, N, tile_w, tile_h, cum_tiles, keep_scan, means2d,
+                       radii, depths, tile_offsets, tile_cursor, sort_keys);
     // gsplat: tile_n_bits = floor(log2(n_tiles)) + 1
     int tile_bits = 0;
     while ((1ll << tile_bits) <= (long long)tiles_per_cam) ++tile_bits;

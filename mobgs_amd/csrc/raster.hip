@@ -244,8 +244,9 @@ __global__ void __launch_bounds__(64 * TILES_PER_WG)
 raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
                   const float* __restrict__ records, const float* __restrict__ backgrounds,
                   const int32_t* __restrict__ radii, const int32_t* __restrict__ cum_tiles,
-                  const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-                  const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
+                  const int32_t* __restrict__ keep_scan, const int32_t* __restrict__ tile_offsets,
+                  const int32_t* __restrict__ flatten_ids, const float* __restrict__ render_alphas,
+                  const int32_t* __restrict__ last_ids,
                   const float* __restrict__ v_render, const float* __restrict__ v_alphas,
                   float* __restrict__ grad_slots) {
     constexpr int RS = (6 + CD + 3) & ~3;
@@ -321,7 +322,7 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
 #pragma unroll
             for (int q = 1; q < RQ; ++q) slab[wv][lane][q] = r[q];
             const TileRect tr = tile_rect(r0.x, r0.y, radii[g], tile_w, tile_h);
-            slot_of[wv][lane] = cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0);
+            slot_of[wv][lane] = keep_scan[cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0)];
         }
         wave_lds_fence();
         for (int j = 0; j < n; ++j) {
@@ -401,13 +402,13 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
 template <int LPG>  // lanes per splat, >= record stride
 __global__ void __launch_bounds__(256)
 slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, const int32_t* __restrict__ cum_tiles,
-                   const float* __restrict__ grad_slots, float* __restrict__ v_means2d,
+                   const int32_t* __restrict__ keep_scan, const float* __restrict__ grad_slots, float* __restrict__ v_means2d,
                    float* __restrict__ v_conics, float* __restrict__ v_opacities, float* __restrict__ v_colors,
                    float* __restrict__ v_extra) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPG;
     const int comp = threadIdx.x % LPG;
     if (gid >= n_gauss) return;
-    const int a = cum_tiles[gid], b = cum_tiles[gid + 1];
+    const int a = keep_scan[cum_tiles[gid]], b = keep_scan[cum_tiles[gid + 1]];
     float acc = 0.f;
     if (comp < stride) {
         const float* p = grad_slots + (size_t)a * stride + comp;
@@ -488,9 +489,9 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
 
 int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int height, const float* records,
                      const float* backgrounds, const int32_t* radii, const float* means2d,
-                     const int32_t* cum_tiles, const int32_t* tile_offsets, const int32_t* flatten_ids,
-                     const float* render_alphas, const int32_t* last_ids, const float* v_render,
-                     const float* v_alphas, float* grad_slots, void* stream) {
+                     const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
+                     const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
+                     const float* v_render, const float* v_alphas, float* grad_slots, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     (void)means2d;
     const int D = channels + (has_extra ? 1 : 0);
@@ -506,8 +507,8 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
     const int rc = dispatch_channels(D, [&](auto cd) {
         constexpr int CD = decltype(cd)::value;
         hipLaunchKernelGGL(raster_bwd_kernel<CD>, dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups, tile_w,
-                           tile_h, width, height, records, backgrounds, radii, cum_tiles, tile_offsets, flatten_ids,
-                           render_alphas, last_ids, v_render, v_alphas, grad_slots);
+                           tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan, tile_offsets,
+                           flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots);
     });
     if (rc != MOBGS_OK) {
         set_error("mobgs_raster_bwd: %d total channels not compiled in", D);
@@ -517,7 +518,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
 }
 
 int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int32_t* cum_tiles,
-                            const float* grad_slots, float* v_means2d, float* v_conics, float* v_opacities,
+                            const int32_t* keep_scan, const float* grad_slots, float* v_means2d, float* v_conics, float* v_opacities,
                             float* v_colors, float* v_extra, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int D = channels + (has_extra ? 1 : 0);
@@ -530,15 +531,15 @@ int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int
     if (n > 0) {
         if (stride <= 8) {
             hipLaunchKernelGGL(slot_reduce_kernel<8>, dim3((n * 8 + 255) / 256), dim3(256), 0, st, n, channels,
-                               has_extra, stride, cum_tiles, grad_slots, v_means2d, v_conics, v_opacities, v_colors,
+                               has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities, v_colors,
                                v_extra);
         } else if (stride <= 16) {
             hipLaunchKernelGGL(slot_reduce_kernel<16>, dim3((int)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, n,
-                               channels, has_extra, stride, cum_tiles, grad_slots, v_means2d, v_conics, v_opacities,
+                               channels, has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
                                v_colors, v_extra);
         } else {
             hipLaunchKernelGGL(slot_reduce_kernel<32>, dim3((int)(((size_t)n * 32 + 255) / 256)), dim3(256), 0, st, n,
-                               channels, has_extra, stride, cum_tiles, grad_slots, v_means2d, v_conics, v_opacities,
+                               channels, has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
                                v_colors, v_extra);
         }
     }

@@ -108,13 +108,29 @@ def fully_fused_projection(
 class TileLists:
     """Per-tile depth-ordered splat lists of one rasterization call."""
 
-    __slots__ = ("C", "N", "tile_w", "tile_h", "n_isects", "max_tile_len", "cum_tiles", "tile_offsets",
-                 "flatten_ids", "isect_ids")
+    __slots__ = ("C", "N", "tile_w", "tile_h", "n_box", "n_isects", "max_tile_len", "cum_tiles", "keep_scan",
+                 "tile_offsets", "flatten_ids", "isect_ids")
+
+
+_tile_culling = True
+_capacity = {}  # device index -> current capacity of the keep-flag buffer (grows geometrically, never shrinks)
+
+
+def set_tile_culling(flag: bool) -> None:
+    """True (default): a splat is listed in a tile only if it can reach alpha >= 1/255 there -- pixels and gradients
+    are bit-identical, `meta["flatten_ids" / "isect_ids" / "isect_offsets"]` are then a subset of gsplat's lists.
+    False: lists are exactly gsplat's (every tile the 3-sigma bounding box touches)."""
+    global _tile_culling
+    _tile_culling = bool(flag)
+
+
+def get_tile_culling() -> bool:
+    return _tile_culling
 
 
 @torch.no_grad()
-def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, tiles_per_gauss: Tensor, width: int,
-                     height: int, want_isect_ids: bool = True) -> TileLists:
+def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,
+                     tiles_per_gauss: Tensor, width: int, height: int, want_isect_ids: bool = True) -> TileLists:
     lib = _lib_()
     C, N = radii.shape
     dev = radii.device
@@ -124,22 +140,33 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, tiles_per_g
     tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
     tl.cum_tiles = torch.empty(C * N + 1, dtype=torch.int32, device=dev)
     tl.tile_offsets = torch.empty(nt + 1, dtype=torch.int32, device=dev)
-    stats = torch.empty(2, dtype=torch.int64, device=dev)
-    scratch = torch.empty(lib.mobgs_isect_scratch_bytes(C * N, nt), dtype=torch.uint8, device=dev)
-    check(lib.mobgs_isect_offsets(C, N, tile_w, tile_h, ptr(tiles_per_gauss), ptr(means2d), ptr(radii),
-                                  ptr(tl.cum_tiles), ptr(tl.tile_offsets), ptr(stats), ptr(scratch), stream()),
-          "mobgs_isect_offsets")
-    n_isects, max_len = (int(v) for v in stats.tolist())  # the pipeline's one host sync (as in gsplat)
-    tl.n_isects, tl.max_tile_len = n_isects, max_len
-    last_stats.update(n_isects=n_isects, max_tile_len=max_len, n_tiles=nt)
+    stats = torch.empty(3, dtype=torch.int64, device=dev)
+    opac = f32c(opacities)
+    key = dev.index if dev.index is not None else -1
+    cap = max(_capacity.get(key, 0), 16 * (C * N) + 1024)
+    while True:
+        tl.keep_scan = torch.empty(cap + 1, dtype=torch.int32, device=dev)
+        scratch = torch.empty(lib.mobgs_isect_scratch_bytes(C * N, nt, cap), dtype=torch.uint8, device=dev)
+        check(lib.mobgs_isect_offsets(C, N, tile_w, tile_h, width, height, int(_tile_culling), cap,
+                                      ptr(tiles_per_gauss), ptr(means2d), ptr(radii), ptr(conics), ptr(opac),
+                                      1 if opac.dim() == 2 else 0, ptr(tl.cum_tiles), ptr(tl.keep_scan),
+                                      ptr(tl.tile_offsets), ptr(stats), ptr(scratch), stream()),
+              "mobgs_isect_offsets")
+        n_box, n_isects, max_len = (int(v) for v in stats.tolist())  # the pipeline's one host sync (as in gsplat)
+        if n_box <= cap:
+            break
+        cap = int(n_box * 1.25) + 1024  # first call on a denser scene: grow and redo (rare)
+    _capacity[key] = cap
+    tl.n_box, tl.n_isects, tl.max_tile_len = n_box, n_isects, max_len
+    last_stats.update(n_isects=n_isects, n_box=n_box, max_tile_len=max_len, n_tiles=nt)
     tl.flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
     tl.isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev) if want_isect_ids else None
     if n_isects > 0:
         cursor = torch.empty(nt, dtype=torch.int32, device=dev)
         keys = torch.empty(n_isects, dtype=torch.int64, device=dev)
         check(lib.mobgs_isect_emit_sort(C, N, tile_w, tile_h, n_isects, max_len, ptr(means2d), ptr(radii),
-                                        ptr(depths), ptr(tl.cum_tiles), ptr(tl.tile_offsets), ptr(cursor),
-                                        ptr(keys), ptr(tl.flatten_ids), ptr(tl.isect_ids), stream()),
+                                        ptr(depths), ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(tl.tile_offsets),
+                                        ptr(cursor), ptr(keys), ptr(tl.flatten_ids), ptr(tl.isect_ids), stream()),
               "mobgs_isect_emit_sort")
     return tl
 
@@ -207,10 +234,11 @@ class _Rasterize(torch.autograd.Function):
         v_extra = torch.empty(C, N, dtype=torch.float32, device=dev) if has_extra else None
         with profiler.region("raster_bwd"):
             check(lib.mobgs_raster_bwd(C, N, channels, int(has_extra), width, height, ptr(records), ptr(bg),
-                                       ptr(radii), ptr(means2d), ptr(tl.cum_tiles), ptr(tl.tile_offsets),
-                                       ptr(tl.flatten_ids), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
-                                       ptr(slots), stream()), "mobgs_raster_bwd")
-        check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(tl.cum_tiles), ptr(slots),
+                                       ptr(radii), ptr(means2d), ptr(tl.cum_tiles), ptr(tl.keep_scan),
+                                       ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(alphas), ptr(last_ids),
+                                       ptr(v_render), ptr(v_alphas), ptr(slots), stream()), "mobgs_raster_bwd")
+        check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(tl.cum_tiles), ptr(tl.keep_scan),
+                                          ptr(slots),
                                           ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra),
                                           stream()), "mobgs_raster_bwd_reduce")
         if not colors_per_camera:
@@ -292,7 +320,8 @@ def rasterization(
     radii, means2d, depths, conics, tiles_per_gauss = _Project.apply(
         means, quats, scales, viewmats, Ks, width, height, float(eps2d), float(near_plane), float(far_plane),
         float(radius_clip))
-    tl = build_tile_lists(means2d.detach(), radii, depths.detach(), tiles_per_gauss, width, height)
+    tl = build_tile_lists(means2d.detach(), radii, depths.detach(), conics.detach(), opacities.detach(),
+                          tiles_per_gauss, width, height)
 
     extra = None
     bg = backgrounds

@@ -78,9 +78,14 @@ def test_rasterization_forward(hip_device, mode, channels, use_bg):
                                                s["viewmats"], s["Ks"], w, h, packed=False, backgrounds=bg,
                                                render_mode=mode)
     d = _to(s, hip_device)
-    img, a, meta = rasterization(d["means"], d["quats"], d["scales"], d["opacities"], d["colors"], d["viewmats"],
-                                 d["Ks"], w, h, packed=False, backgrounds=None if bg is None else bg.to(hip_device),
-                                 render_mode=mode)
+    from mobgs_amd import rendering
+    rendering.set_tile_culling(False)  # exactly upstream's lists
+    try:
+        img, a, meta = rasterization(d["means"], d["quats"], d["scales"], d["opacities"], d["colors"], d["viewmats"],
+                                     d["Ks"], w, h, packed=False,
+                                     backgrounds=None if bg is None else bg.to(hip_device), render_mode=mode)
+    finally:
+        rendering.set_tile_culling(True)
     assert img.shape == ref_img.shape and a.shape == ref_a.shape
     assert torch.equal(meta["radii"].cpu(), ref_meta["radii"])
     assert torch.equal(meta["tiles_per_gauss"].cpu(), ref_meta["tiles_per_gauss"])
@@ -145,3 +150,41 @@ def test_rasterization_backward(hip_device, mode, channels, use_bg):
         scale = float(refc.abs().max())
         _close(out[k], refc, 2e-4, 2e-5 * scale + 1e-7, f"grad[{k}] vs C oracle", flip_frac=2e-3,
                flip_atol=5e-4 * scale)
+
+
+@pytest.mark.parametrize("mode,channels", [("RGB+ED", 9), ("RGB", 2)])
+def test_tile_culling_is_bit_exact(hip_device, mode, channels):
+    """Reach culling drops only (tile, splat) pairs the compositor skips at every pixel: images AND gradients are
+    bit-identical to the un-culled run, the culled lists are ordered sub-sequences of upstream's."""
+    from mobgs_amd import rendering
+    from mobgs_amd.rendering import rasterization
+    n, w, h = 6000, 200, 152
+    s, _ = _scene(n, w, h, 11, channels)
+    names = ["means", "quats", "scales", "opacities", "colors", "viewmats"]
+    gen = torch.Generator().manual_seed(3)
+    res = {}
+    for cull in (False, True):
+        rendering.set_tile_culling(cull)
+        try:
+            t = {k: v.to(hip_device).clone().requires_grad_(k in names) for k, v in s.items()}
+            img, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                                         t["viewmats"], t["Ks"], w, h, packed=False, render_mode=mode)
+            g = torch.Generator().manual_seed(7)
+            v_img = torch.randn(img.shape, generator=g).to(hip_device)
+            ((img * v_img).sum() + a.sum()).backward()
+            res[cull] = (img.detach().cpu(), a.detach().cpu(), {k: t[k].grad.cpu() for k in names},
+                         meta["flatten_ids"].cpu(), meta["isect_offsets"].cpu().reshape(-1))
+        finally:
+            rendering.set_tile_culling(True)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for k in names:
+        assert torch.equal(res[True][2][k], res[False][2][k]), f"grad[{k}] changed under culling"
+    n_full, n_cull = res[False][3].numel(), res[True][3].numel()
+    assert n_cull < 0.8 * n_full, (n_cull, n_full)
+    # per tile: the culled list is a sub-sequence (same order) of the full list
+    of, oc = res[False][4].tolist() + [n_full], res[True][4].tolist() + [n_cull]
+    for tile in range(0, len(of) - 1, 7):
+        full = res[False][3][of[tile]:of[tile + 1]].tolist()
+        sub = res[True][3][oc[tile]:oc[tile + 1]].tolist()
+        it = iter(full)
+        assert all(x in it for x in sub), f"tile {tile}: not a sub-sequence"
