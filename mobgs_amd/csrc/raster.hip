@@ -132,16 +132,13 @@ raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
 
     // software pipeline: the records of batch b+1 are fetched into registers while batch b is blended
     float4 pre[RQ];
-    auto fetch = [&](int b) {
-        const int idx = b + lane;
-        if (idx < e) {
-            const int g = flatten_ids[idx];
-            const float4* r = reinterpret_cast<const float4*>(records + (size_t)g * RS);
 #pragma unroll
-            for (int q = 0; q < RQ; ++q) pre[q] = r[q];
-        }
-    };
-    if (s < e) fetch(s);
+    for (int q = 0; q < RQ; ++q) pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s + lane < e) {
+        const float4* r = reinterpret_cast<const float4*>(records + (size_t)flatten_ids[s + lane] * RS);
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) pre[q] = r[q];
+    }
     bool all_done = false;
     for (int b = s; b < e && !all_done; b += 64) {
         const int n = min(64, e - b);
@@ -149,31 +146,48 @@ raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
 #pragma unroll
         for (int q = 0; q < RQ; ++q) slab[wv][lane][q] = pre[q];
         wave_lds_fence();
-        if (b + 64 < e) fetch(b + 64);
-        for (int j = 0; j < n; ++j) {
-            float rec[RS];
+        if (b + 64 + lane < e) {
+            const float4* r = reinterpret_cast<const float4*>(records + (size_t)flatten_ids[b + 64 + lane] * RS);
 #pragma unroll
-            for (int q = 0; q < RQ; ++q) {
-                const float4 v = slab[wv][j][q];
-                rec[4 * q] = v.x;
-                rec[4 * q + 1] = v.y;
-                rec[4 * q + 2] = v.z;
-                rec[4 * q + 3] = v.w;
-            }
+            for (int q = 0; q < RQ; ++q) pre[q] = r[q];
+        }
+        for (int j = 0; j < n; ++j) {
+            const float4 r0 = slab[wv][j][0];
+            const float4 r1 = slab[wv][j][1];
+            // tests for the 4 pixels of this lane; one wave-level branch decides whether anything is blended
+            float alpha[PPL], nT[PPL];
+            bool blend[PPL];
+            bool any = false;
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
-                const Eval ev = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px, py[k]);
-                if (ev.pass && !((done >> k) & 1u)) {
-                    const float nT = T[k] * (1.f - ev.alpha);
-                    if (nT <= T_STOP) {
-                        done |= 1u << k;
-                    } else {
-                        const float w = ev.alpha * T[k];
+                const Eval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, px, py[k]);
+                const bool pass = ev.pass && !((done >> k) & 1u);
+                alpha[k] = ev.alpha;
+                nT[k] = T[k] * (1.f - ev.alpha);
+                const bool stop = pass && (nT[k] <= T_STOP);
+                done |= stop ? (1u << k) : 0u;
+                blend[k] = pass && !stop;
+                any = any || blend[k];
+            }
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+                float col[RS - 6];
+                col[0] = r1.z;
+                col[1] = r1.w;
 #pragma unroll
-                        for (int c = 0; c < CD; ++c) acc[k][c] = __fmaf_rn(rec[6 + c], w, acc[k][c]);
-                        last[k] = b + j;
-                        T[k] = nT;
-                    }
+                for (int q = 2; q < RQ; ++q) {
+                    const float4 v = slab[wv][j][q];
+                    col[4 * q - 6] = v.x;
+                    col[4 * q - 5] = v.y;
+                    col[4 * q - 4] = v.z;
+                    col[4 * q - 3] = v.w;
+                }
+#pragma unroll
+                for (int k = 0; k < PPL; ++k) {
+                    const float w = blend[k] ? alpha[k] * T[k] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < CD; ++c) acc[k][c] = __fmaf_rn(col[c], w, acc[k][c]);
+                    T[k] = blend[k] ? nT[k] : T[k];
+                    last[k] = blend[k] ? (b + j) : last[k];
                 }
             }
             if (__builtin_amdgcn_ballot_w64(done != 0xFu) == 0ull) {
@@ -272,8 +286,11 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
     const int e = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
     if (e <= s) return;
 
-    float py[PPL], T[PPL], Tf[PPL], va[PPL], bgdot[PPL];
-    float vo[PPL][CD], buf[PPL][CD];
+    // behind[k] = sum over the splats BEHIND the current one of fac * <colour, v_out>: upstream keeps the
+    // per-channel sums buffer[c] and forms sum_c (colour_c T - buffer_c ra) v_out_c; distributing v_out gives
+    // T <colour, v_out> - ra * behind, one scalar per pixel instead of D (fewer registers, D fewer FMAs per pair)
+    float py[PPL], T[PPL], Tf[PPL], va[PPL], bgdot[PPL], behind[PPL];
+    float vo[PPL][CD];
     int binf[PPL];
     int top = -1;
 #pragma unroll
@@ -285,11 +302,9 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
         Tf[k] = 1.f;
         va[k] = 0.f;
         bgdot[k] = 0.f;
+        behind[k] = 0.f;
 #pragma unroll
-        for (int c = 0; c < CD; ++c) {
-            vo[k][c] = 0.f;
-            buf[k][c] = 0.f;
-        }
+        for (int c = 0; c < CD; ++c) vo[k][c] = 0.f;
         if (inside) {
             const size_t pix = ((size_t)cam * height + pyi) * width + pxi;
             binf[k] = last_ids[pix];
@@ -352,15 +367,19 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
             for (int k = 0; k < PPL; ++k) {
                 if (!ev[k].pass) continue;
                 const float alpha = ev[k].alpha;
-                const float ra = 1.f / (1.f - alpha);
+                // 1 / (1 - alpha): hardware reciprocal + one Newton step (<= 1 ulp; 1 - alpha >= 1e-3)
+                const float om = 1.f - alpha;
+                float ra = __builtin_amdgcn_rcpf(om);
+                ra = __fmaf_rn(__fmaf_rn(-om, ra, 1.f), ra, ra);
                 T[k] *= ra;
                 const float fac = alpha * T[k];
-                float v_alpha = 0.f;
+                float dot = 0.f;
 #pragma unroll
                 for (int c = 0; c < CD; ++c) {
                     g[6 + c] = __fmaf_rn(fac, vo[k][c], g[6 + c]);
-                    v_alpha = __fmaf_rn(rec[6 + c] * T[k] - buf[k][c] * ra, vo[k][c], v_alpha);
+                    dot = __fmaf_rn(rec[6 + c], vo[k][c], dot);
                 }
+                float v_alpha = __fmaf_rn(T[k], dot, -ra * behind[k]);
                 v_alpha += Tf[k] * ra * va[k];
                 if (backgrounds) v_alpha -= Tf[k] * ra * bgdot[k];
                 const float ov = rec[5] * ev[k].vis;
@@ -374,8 +393,7 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
                     g[4] = __fmaf_rn(0.5f * v_sigma * dy, dy, g[4]);
                     g[5] = __fmaf_rn(ev[k].vis, v_alpha, g[5]);
                 }
-#pragma unroll
-                for (int c = 0; c < CD; ++c) buf[k][c] = __fmaf_rn(rec[6 + c], fac, buf[k][c]);
+                behind[k] = __fmaf_rn(fac, dot, behind[k]);
             }
             wave_reduce_components<NVP>(g);
             // lane 0 of each 16-lane row stores its NVP/4 consecutive components (64 B per record for D = 10)
