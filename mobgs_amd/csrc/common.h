@@ -55,4 +55,57 @@ __host__ __device__ inline TileRect tile_rect(float mx, float my, int radius, in
     return r;
 }
 
+
+// ---- reach tests (bit-exact culling of work the compositor would skip anyway) --------------------------------
+// Smallest sigma = 0.5 (a dx^2 + c dy^2) + b dx dy a splat can take over a pixel-centre rectangle
+// (convex quadratic: 0 if the centre is inside, else attained on one of the four edges).
+__device__ inline float min_sigma_over_tile(float mx, float my, float ca, float cb, float cc, float x0, float x1,
+                                            float y0, float y1) {
+    if (mx >= x0 && mx <= x1 && my >= y0 && my <= y1) return 0.f;
+    float best = 3.0e38f;
+    const float ex[2] = {x0, x1}, ey[2] = {y0, y1};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        {  // vertical edge px = ex[k]: optimum dy = -cb dx / cc
+            const float dx = mx - ex[k];
+            const float py = fminf(fmaxf(my + cb * dx / cc, y0), y1);
+            const float dy = my - py;
+            best = fminf(best, 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy);
+        }
+        {  // horizontal edge py = ey[k]
+            const float dy = my - ey[k];
+            const float px = fminf(fmaxf(mx + cb * dy / ca, x0), x1);
+            const float dx = mx - px;
+            best = fminf(best, 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy);
+        }
+    }
+    return best;
+}
+// alpha = min(0.999, op * exp(-sigma)) >= 1/255  <=>  sigma <= ln(255 op).  The returned threshold carries a
+// conservative margin (the compositor evaluates sigma at pixel centres in a different fp32 operation order);
+// NEGATIVE when the splat can never reach 1/255.
+__device__ inline float reach_threshold(float op) {
+    if (!(op * 255.f >= 1.f)) return -1.f;
+    const float tau = __logf(255.f * op);
+    return tau + 0.05f + 0.02f * tau;
+}
+// bit k set <=> the splat can reach alpha >= 1/255 somewhere in rows [4k, 4k+3] of the 16x16 tile (tx, ty)
+__device__ inline int band_mask(float mx, float my, float ca, float cb, float cc, float op, int tx, int ty, int width,
+                                int height) {
+    const float thr = reach_threshold(op);
+    if (thr < 0.f) return 0;
+    if (!(ca > 0.f && cc > 0.f)) return 0xF;
+    const float x0 = (float)(tx * MOBGS_TILE) + 0.5f;
+    const float x1 = fminf((float)(tx * MOBGS_TILE) + 15.5f, (float)width - 0.5f);
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float y0 = (float)(ty * MOBGS_TILE + 4 * k) + 0.5f;
+        if (y0 > (float)height) break;
+        const float y1 = fminf(y0 + 3.f, (float)height - 0.5f);
+        if (min_sigma_over_tile(mx, my, ca, cb, cc, x0, x1, y0, y1) <= thr) m |= 1 << k;
+    }
+    return m;
+}
+
 }  // namespace mobgs

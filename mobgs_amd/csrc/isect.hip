@@ -143,31 +143,6 @@ __device__ inline int tile_of(int j, int g, int N, int tile_w, int tile_h, const
     return (cam * tile_h + ty) * tile_w + tx;
 }
 
-// Smallest sigma = 0.5 (a dx^2 + c dy^2) + b dx dy a splat can take over the pixel-centre rectangle of a tile
-// (convex quadratic: 0 if the centre is inside, else attained on one of the four edges).
-__device__ inline float min_sigma_over_tile(float mx, float my, float ca, float cb, float cc, float x0, float x1,
-                                            float y0, float y1) {
-    if (mx >= x0 && mx <= x1 && my >= y0 && my <= y1) return 0.f;
-    float best = 3.0e38f;
-    const float ex[2] = {x0, x1}, ey[2] = {y0, y1};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        {  // vertical edge px = ex[k]: optimum dy = -cb dx / cc
-            const float dx = mx - ex[k];
-            const float py = fminf(fmaxf(my + cb * dx / cc, y0), y1);
-            const float dy = my - py;
-            best = fminf(best, 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy);
-        }
-        {  // horizontal edge py = ey[k]
-            const float dy = my - ey[k];
-            const float px = fminf(fmaxf(mx + cb * dy / ca, x0), x1);
-            const float dx = mx - px;
-            best = fminf(best, 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy);
-        }
-    }
-    return best;
-}
-
 // one thread per bounding-box intersection j: keep flag (1 = listed) + per-tile histogram of the kept ones
 __global__ void __launch_bounds__(256)
 flag_hist_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
@@ -192,9 +167,8 @@ flag_hist_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int heig
                 const float x1 = fminf((float)(tx * MOBGS_TILE) + 15.5f, (float)width - 0.5f);
                 const float y1 = fminf((float)(ty * MOBGS_TILE) + 15.5f, (float)height - 0.5f);
                 const float2 m = reinterpret_cast<const float2*>(means2d)[g];
-                const float tau = __logf(255.f * op);
                 const float smin = min_sigma_over_tile(m.x, m.y, ca, cb, cc, x0, x1, y0, y1);
-                keep = (smin <= tau + 0.05f + 0.02f * tau) ? 1 : 0;  // conservative: fp32 evaluation orders differ
+                keep = (smin <= reach_threshold(op)) ? 1 : 0;
             }
         }
         flags[j] = keep;

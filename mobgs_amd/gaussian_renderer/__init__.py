@@ -82,24 +82,26 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     w1, w2 = _decoder_weights(dyn_pc)
     Ns = stat_pc.get_xyz.shape[0]
 
+    dyn_sl, stat_sl, all_sl = slice(Ns, None), slice(0, Ns), slice(None)
     times = _times(cam, delta_exposure, dev)
     means, quats, scales, opac, cols = _prep(stat_pc, dyn_pc, times)
     if coherent is not None:
         means = torch.cat((means[:Ns], means[Ns:] + coherent), 0)
 
+    def pick(t, sl):
+        return t if sl is all_sl else t[sl]  # a full slice would still cost a zeros+copy pair in backward
+
     def raster(sl, colors, bgs, mode):
-        return _R.rasterization(means=means[sl], quats=quats[sl], scales=scales[sl], opacities=opac[sl],
-                                colors=colors, backgrounds=bgs, viewmats=viewmat[None], Ks=K[None], width=W,
-                                height=H, packed=False, render_mode=mode)
+        return _R.rasterization(means=pick(means, sl), quats=pick(quats, sl), scales=pick(scales, sl),
+                                opacities=pick(opac, sl), colors=colors, backgrounds=bgs, viewmats=viewmat[None],
+                                Ks=K[None], width=W, height=H, packed=False, render_mode=mode)
 
     def decode_ed(img, alphas):
-        return decode(img[0], alphas[0], cam.cam_ray, w1, w2, True)
+        return decode(img, alphas, cam.cam_ray, w1, w2, True)  # views only: no select/zeros/copy in backward
 
     out = {k: None for k in ("s_render", "s_depth", "d_render", "d_depth", "d_alpha", "d_means3d", "s_alpha",
                              "blending_factor", "world_coordinates", "splat_center", "ori_flow", "ori_coord_map",
                              "labels", "centroids")}
-    dyn_sl, stat_sl, all_sl = slice(Ns, None), slice(0, Ns), slice(None)
-
     if get_dynamic:
         d_img, d_a, _ = _raster_acc(raster, dyn_sl, cols[dyn_sl], bg[None])
         out["d_render"], d_depth = decode_ed(d_img, d_a)
@@ -145,7 +147,7 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
 def _raster_acc(raster, sl, colors, bgs):
     """'RGB+D' compositing (9 feature channels + accumulated depth); the ED division happens in the decoder."""
     img, alphas, info = raster(sl, colors, bgs, "RGB+D")
-    return img, alphas[..., 0], info
+    return img, alphas.squeeze(-1), info
 
 
 def _pixel_grid(cam, W, H, like):
@@ -184,7 +186,7 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     exp2mid = pix + e2m_img
     mid2exp = pix + raster(mid_m, mid_q, all_sl, -e2m, None, "RGB")[0]
     img, alphas, _ = raster(exp_m, exp_q, all_sl, exp_c, bg[None], "RGB+D")
-    latent_img, _ = decode(img[0], alphas[0, ..., 0], cam.cam_ray, w1, w2, True)
+    latent_img, _ = decode(img, alphas, cam.cam_ray, w1, w2, True)
     return exp2mid, mid2exp, latent_img, latent_alpha
 
 

@@ -113,6 +113,8 @@ class Decode(torch.autograd.Function):
 def decode(feat_hw: Tensor, alphas: Optional[Tensor], rays: Tensor, w1: Tensor, w2: Tensor, has_depth: bool):
     """feat_hw [..,H,W,CF>=9(+1)], alphas [..,H,W] or [..,H,W,1], rays [1,6,H,W] -> rgb [3,H,W], depth [H,W]|None."""
     H, W = feat_hw.shape[-3], feat_hw.shape[-2]
+    if feat_hw.numel() != H * W * feat_hw.shape[-1]:
+        raise NotImplementedError("decoder batch size must be 1 (as in every reference call)")
     if alphas is not None:
         alphas = alphas.reshape(H, W)
     rgb, depth = Decode.apply(feat_hw.reshape(H, W, feat_hw.shape[-1]), alphas, rays.reshape(6, H, W), w1, w2,
