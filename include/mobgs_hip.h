@@ -100,12 +100,12 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
  * stable LSD radix sort on gsplat's 64-bit key produces.
  * n_isects = stats[1], max_tile_len = stats[2] of mobgs_isect_offsets (the latter selects the LDS sort variant).
  * out: flatten_ids [n_isects] (cam*N+gaussian), isect_ids [n_isects] (gsplat's u64 key; may be NULL)
- * scratch: tile_cursor [C*n_tiles] int32 (zeroed by this call); sort_keys [n_isects] u64. */
-int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int64_t n_isects, int64_t max_tile_len,
-                          const float* means2d, const int32_t* radii, const float* depths,
-                          const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
-                          int32_t* tile_cursor, uint64_t* sort_keys, int32_t* flatten_ids, uint64_t* isect_ids,
-                          void* stream);
+ * offsets_scratch: the SAME scratch buffer (and capacity) that was passed to mobgs_isect_offsets -- it holds the
+ *   (flag, owner, tile, rank) of every bounding-box intersection; sort_keys [n_isects] u64 is scratch. */
+int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t n_isects,
+                          int64_t max_tile_len, const float* depths, const int32_t* cum_tiles,
+                          const int32_t* tile_offsets, const void* offsets_scratch, uint64_t* sort_keys,
+                          int32_t* flatten_ids, uint64_t* isect_ids, void* stream);
 
 /* ---- K6: rasterise forward (replaces gsplat rasterize_to_pixels fwd) -----------------------------------
  * colors   : [C,N,channels] (colors_per_camera=1) or [N,channels] (0)

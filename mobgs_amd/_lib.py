@@ -28,7 +28,7 @@ _SIGS = {
                                   P, P]),
     "mobgs_isect_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "mobgs_isect_offsets": (c_int, [c_int] * 8 + [P] * 5 + [c_int] + [P] * 5 + [P]),
-    "mobgs_isect_emit_sort": (c_int, [c_int, c_int, c_int, c_int, c_int64, c_int64] + [P] * 10 + [P]),
+    "mobgs_isect_emit_sort": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int64, c_int64] + [P] * 7 + [P]),
     "mobgs_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, P,
                                  P, P, P, P]),
     "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int] + [P] * 13 + [P]),

@@ -143,13 +143,15 @@ __device__ inline int tile_of(int j, int g, int N, int tile_w, int tile_h, const
     return (cam * tile_h + ty) * tile_w + tx;
 }
 
-// one thread per bounding-box intersection j: keep flag (1 = listed) + per-tile histogram of the kept ones
+// Pass A, one thread per bounding-box intersection j: owner splat (binary search), tile, reach test.  A kept
+// intersection takes its rank inside the tile's list with ONE returning atomic; (owner, tile, rank) are written
+// out so that pass B is a pure streaming scatter (no second search, no second atomic).
 __global__ void __launch_bounds__(256)
-flag_hist_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
-                 const int32_t* __restrict__ cum, const float* __restrict__ means2d,
-                 const int32_t* __restrict__ radii, const float* __restrict__ conics,
-                 const float* __restrict__ opacities, int opac_per_camera, int32_t* __restrict__ flags,
-                 int32_t* __restrict__ tile_count) {
+bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
+           const int32_t* __restrict__ cum, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
+           const float* __restrict__ conics, const float* __restrict__ opacities, int opac_per_camera,
+           int32_t* __restrict__ flags, int32_t* __restrict__ owner, int32_t* __restrict__ tile_of_j,
+           int32_t* __restrict__ rank_of_j, int32_t* __restrict__ tile_count) {
     const int I = min(cum[n_gauss], capacity);
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < I; j += gridDim.x * blockDim.x) {
         const int g = owner_of(cum, n_gauss, j);
@@ -172,7 +174,11 @@ flag_hist_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int heig
             }
         }
         flags[j] = keep;
-        if (keep) atomicAdd(&tile_count[t], 1);
+        if (keep) {
+            owner[j] = g;
+            tile_of_j[j] = t;
+            rank_of_j[j] = atomicAdd(&tile_count[t], 1);
+        }
     }
 }
 
@@ -203,61 +209,125 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(int nt, const i
     }
 }
 
-__global__ void __launch_bounds__(256) emit_kernel(int n_gauss, int N, int tile_w, int tile_h,
-                                                     const int32_t* __restrict__ cum,
-                                                     const int32_t* __restrict__ keep_scan,
-                                                     const float* __restrict__ means2d,
-                                                     const int32_t* __restrict__ radii,
+// Pass B: streaming scatter of the 64-bit sort keys into the tile-contiguous segments
+__global__ void __launch_bounds__(256) emit_kernel(const int32_t* __restrict__ n_box_ptr,
+                                                     const int32_t* __restrict__ flags,
+                                                     const int32_t* __restrict__ owner,
+                                                     const int32_t* __restrict__ tile_of_j,
+                                                     const int32_t* __restrict__ rank_of_j,
                                                      const float* __restrict__ depths,
                                                      const int32_t* __restrict__ tile_offsets,
-                                                     int32_t* __restrict__ tile_cursor,
                                                      uint64_t* __restrict__ sort_keys) {
-    const int I = cum[n_gauss];
+    const int I = *n_box_ptr;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < I; j += gridDim.x * blockDim.x) {
-        if (keep_scan[j + 1] == keep_scan[j]) continue;  // culled
-        const int g = owner_of(cum, n_gauss, j);
-        const int t = tile_of(j, g, N, tile_w, tile_h, cum, means2d, radii);
-        const int r = atomicAdd(&tile_cursor[t], 1);
+        if (!flags[j]) continue;
+        const int g = owner[j];
         const uint32_t db = __float_as_uint(depths[g]);
-        sort_keys[(size_t)tile_offsets[t] + r] = ((uint64_t)db << 32) | (uint32_t)g;
+        sort_keys[(size_t)tile_offsets[tile_of_j[j]] + rank_of_j[j]] = ((uint64_t)db << 32) | (uint32_t)g;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // per-tile bitonic sort ("mirror" formulation: every compare-exchange is ascending, so elements past the
 // end behave as +inf without being stored and any n works)
+//
+// Barrier economy: every step of a merge of size k only touches its own aligned k-block, and the steps with
+// compare distance j <= 64 only touch aligned 128-element chunks.  Each wave owns whole 128-element chunks
+// (64 compare-exchanges per step = one per lane), so all those steps need no workgroup barrier -- the LDS
+// queue of a wave is in order.  Only the mirror step and the j >= 128 steps of merges k >= 256 synchronise the
+// workgroup: 6 barriers instead of 45 for a 512-entry list.
 // ---------------------------------------------------------------------------------------------------
-template <typename PTR>
-__device__ inline void bitonic_sort(PTR a, int n, int nthreads) {
+constexpr int CHUNK = 128;
+
+__device__ __forceinline__ void cmpx(uint64_t* a, int lo, int hi, int n) {
+    if (hi < n) {
+        const uint64_t x = a[lo], y = a[hi];
+        if (x > y) {
+            a[lo] = y;
+            a[hi] = x;
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// steps j = j_first .. 1 (halving) inside every 128-chunk owned by this wave; no workgroup barrier
+__device__ __forceinline__ void local_halving_steps(uint64_t* a, int n, int n2, int j_first, int wave, int nwaves,
+                                                    int lane) {
+    for (int c = wave * CHUNK; c < n2 && c < n; c += nwaves * CHUNK) {
+        for (int j = j_first; j >= 1; j >>= 1) {
+            const int blk = lane / j, l = lane - blk * j;
+            const int lo = c + blk * 2 * j + l;
+            cmpx(a, lo, lo + j, n);
+            wave_lds_order();
+        }
+    }
+}
+
+template <int THREADS>
+__device__ inline void bitonic_sort_lds(uint64_t* a, int n) {
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = THREADS / 64;
+    // merges k = 2 .. 128: entirely chunk-local
+    for (int c = wave * CHUNK; c < n2 && c < n; c += NW * CHUNK) {
+        for (int k = 2; k <= CHUNK && k <= n2; k <<= 1) {
+            const int hk = k >> 1;
+            const int blk = lane / hk, l = lane - blk * hk;
+            cmpx(a, c + blk * k + l, c + blk * k + (k - 1 - l), n);
+            wave_lds_order();
+            for (int j = k >> 2; j >= 1; j >>= 1) {
+                const int b2 = lane / j, l2 = lane - b2 * j;
+                const int lo = c + b2 * 2 * j + l2;
+                cmpx(a, lo, lo + j, n);
+                wave_lds_order();
+            }
+        }
+    }
+    __syncthreads();
+    const int half = n2 >> 1;
+    for (int k = 2 * CHUNK; k <= n2; k <<= 1) {
+        const int hk = k >> 1;
+        for (int i = threadIdx.x; i < half; i += THREADS) {  // mirror step: spans the whole k-block
+            const int blk = i / hk, l = i - blk * hk;
+            cmpx(a, blk * k + l, blk * k + (k - 1 - l), n);
+        }
+        __syncthreads();
+        for (int j = k >> 2; j >= CHUNK; j >>= 1) {  // long-distance halving steps
+            for (int i = threadIdx.x; i < half; i += THREADS) {
+                const int blk = i / j, l = i - blk * j;
+                const int lo = blk * 2 * j + l;
+                cmpx(a, lo, lo + j, n);
+            }
+            __syncthreads();
+        }
+        local_halving_steps(a, n, n2, CHUNK / 2, wave, NW, lane);
+        __syncthreads();
+    }
+}
+
+// fallback for lists that do not fit in LDS: the same network in global memory, a barrier after every step
+__device__ inline void bitonic_sort_global(uint64_t* a, int n, int nthreads) {
     int n2 = 1;
     while (n2 < n) n2 <<= 1;
     const int half = n2 >> 1;
     for (int k = 2; k <= n2; k <<= 1) {
-        // mirror step
         const int hk = k >> 1;
         for (int i = threadIdx.x; i < half; i += nthreads) {
             const int blk = i / hk, l = i - blk * hk;
-            const int lo = blk * k + l, hi = blk * k + (k - 1 - l);
-            if (hi < n) {
-                const uint64_t x = a[lo], y = a[hi];
-                if (x > y) {
-                    a[lo] = y;
-                    a[hi] = x;
-                }
-            }
+            cmpx(a, blk * k + l, blk * k + (k - 1 - l), n);
         }
         __syncthreads();
         for (int j = k >> 2; j >= 1; j >>= 1) {
             for (int i = threadIdx.x; i < half; i += nthreads) {
                 const int blk = i / j, l = i - blk * j;
-                const int lo = blk * 2 * j + l, hi = lo + j;
-                if (hi < n) {
-                    const uint64_t x = a[lo], y = a[hi];
-                    if (x > y) {
-                        a[lo] = y;
-                        a[hi] = x;
-                    }
-                }
+                const int lo = blk * 2 * j + l;
+                cmpx(a, lo, lo + j, n);
             }
             __syncthreads();
         }
@@ -282,7 +352,7 @@ __global__ void __launch_bounds__(THREADS) tile_sort_kernel(int n_tiles_total, i
     if (n <= lds_cap) {
         for (int i = threadIdx.x; i < n; i += THREADS) lds_keys[i] = seg[i];
         __syncthreads();
-        if (n > 1) bitonic_sort(lds_keys, n, THREADS);
+        if (n > 1) bitonic_sort_lds<THREADS>(lds_keys, n);
         for (int i = threadIdx.x; i < n; i += THREADS) {
             const uint64_t k = lds_keys[i];
             flatten_ids[s + i] = (int32_t)(uint32_t)k;
@@ -290,7 +360,7 @@ __global__ void __launch_bounds__(THREADS) tile_sort_kernel(int n_tiles_total, i
         }
     } else {
         // pathological tile: sort in place in global memory (same workgroup, barrier-ordered)
-        bitonic_sort(seg, n, THREADS);
+        bitonic_sort_global(seg, n, THREADS);
         for (int i = threadIdx.x; i < n; i += THREADS) {
             const uint64_t k = seg[i];
             flatten_ids[s + i] = (int32_t)(uint32_t)k;
@@ -308,7 +378,7 @@ extern "C" {
 size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity) {
     const size_t nb1 = (size_t)(n_gauss + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
     const size_t nb2 = (size_t)(capacity + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
-    return sizeof(int32_t) * (nb1 + nb2 + (size_t)n_tiles + (size_t)capacity + 32);
+    return sizeof(int32_t) * (nb1 + nb2 + (size_t)n_tiles + 4 * (size_t)capacity + 32);
 }
 
 int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
@@ -346,8 +416,12 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
                        block_sums1, cum_tiles);
     // keep flags + per-tile histogram (only the first `capacity` intersections; the caller re-runs with a larger
     // buffer when stats[0] > capacity)
-    hipLaunchKernelGGL(flag_hist_kernel, dim3(2048), dim3(256), 0, st, n, N, tile_w, tile_h, width, height, cull,
-                       capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera, flags, tile_count);
+    int32_t* owner = flags + capacity;
+    int32_t* tile_of_j = owner + capacity;
+    int32_t* rank_of_j = tile_of_j + capacity;
+    hipLaunchKernelGGL(bin_kernel, dim3(4096), dim3(256), 0, st, n, N, tile_w, tile_h, width, height, cull, capacity,
+                       cum_tiles, means2d, radii, conics, opacities, opac_per_camera, flags, owner, tile_of_j,
+                       rank_of_j, tile_count);
     // keep_scan = exclusive scan of the flags over [0, min(I_box, capacity)); stats[1] = I_kept
     const int32_t* n_ptr = cum_tiles + n;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb2), dim3(SCAN_THREADS), 0, st, n_ptr, capacity, flags,
@@ -361,11 +435,10 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
     return check_launch("isect_offsets");
 }
 
-int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int64_t n_isects, int64_t max_tile_len,
-                          const float* means2d, const int32_t* radii, const float* depths,
-                          const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
-                          int32_t* tile_cursor, uint64_t* sort_keys, int32_t* flatten_ids, uint64_t* isect_ids,
-                          void* stream) {
+int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t n_isects,
+                          int64_t max_tile_len, const float* depths, const int32_t* cum_tiles,
+                          const int32_t* tile_offsets, const void* offsets_scratch, uint64_t* sort_keys,
+                          int32_t* flatten_ids, uint64_t* isect_ids, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int tiles_per_cam = tile_w * tile_h;
     const int nt = C * tiles_per_cam;
@@ -374,10 +447,16 @@ int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int64_t n_isects
         return MOBGS_E_INVALID;
     }
     if (n_isects == 0) return MOBGS_OK;
-    hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * nt, st);
     const int n = C * N;
-    hipLaunchKernelGGL(emit_kernel, dim3(4096), dim3(256), 0, st, n, N, tile_w, tile_h, cum_tiles, keep_scan, means2d,
-                       radii, depths, tile_offsets, tile_cursor, sort_keys);
+    // the (flag, owner, tile, rank) arrays pass A left in the scratch buffer of mobgs_isect_offsets
+    const int nb1 = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    const int nb2 = (capacity + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    const int32_t* flags = (const int32_t*)offsets_scratch + (nb1 + 1) + (nb2 + 1) + nt;
+    const int32_t* owner = flags + capacity;
+    const int32_t* tile_of_j = owner + capacity;
+    const int32_t* rank_of_j = tile_of_j + capacity;
+    hipLaunchKernelGGL(emit_kernel, dim3(4096), dim3(256), 0, st, cum_tiles + n, flags, owner, tile_of_j, rank_of_j,
+                       depths, tile_offsets, sort_keys);
     // gsplat: tile_n_bits = floor(log2(n_tiles)) + 1
     int tile_bits = 0;
     while ((1ll << tile_bits) <= (long long)tiles_per_cam) ++tile_bits;

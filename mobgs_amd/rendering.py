@@ -162,12 +162,10 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Ten
     tl.flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
     tl.isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev) if want_isect_ids else None
     if n_isects > 0:
-        cursor = torch.empty(nt, dtype=torch.int32, device=dev)
         keys = torch.empty(n_isects, dtype=torch.int64, device=dev)
-        check(lib.mobgs_isect_emit_sort(C, N, tile_w, tile_h, n_isects, max_len, ptr(means2d), ptr(radii),
-                                        ptr(depths), ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(tl.tile_offsets),
-                                        ptr(cursor), ptr(keys), ptr(tl.flatten_ids), ptr(tl.isect_ids), stream()),
-              "mobgs_isect_emit_sort")
+        check(lib.mobgs_isect_emit_sort(C, N, tile_w, tile_h, cap, n_isects, max_len, ptr(depths), ptr(tl.cum_tiles),
+                                        ptr(tl.tile_offsets), ptr(scratch), ptr(keys), ptr(tl.flatten_ids),
+                                        ptr(tl.isect_ids), stream()), "mobgs_isect_emit_sort")
     return tl
 
 

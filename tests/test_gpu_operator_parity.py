@@ -188,3 +188,34 @@ def test_tile_culling_is_bit_exact(hip_device, mode, channels):
         sub = res[True][3][oc[tile]:oc[tile + 1]].tolist()
         it = iter(full)
         assert all(x in it for x in sub), f"tile {tile}: not a sub-sequence"
+
+
+@pytest.mark.parametrize("n,w,h,scale", [(3000, 48, 32, 8.0), (12000, 64, 48, 3.0), (40000, 64, 48, 3.0)])
+def test_long_tile_lists_sort_exactly(hip_device, n, w, h, scale):
+    """Few tiles, many big splats: per-tile lists of several hundred to > 4096 entries exercise the multi-chunk
+    LDS sort phases, the 1024-thread variant and (last case) the global-memory fallback; order must be upstream's."""
+    from mobgs_amd import rendering
+    from mobgs_amd.rendering import rasterization
+    from oracle import gsplat_cpu as Cc
+    s, _ = _scene(n, w, h, 5, 3)
+    s["scales"] = s["scales"] * scale
+    g = torch.Generator().manual_seed(1)
+    s["means"][:, 2] = torch.round(s["means"][:, 2] * 4) / 4 + 1.0  # many exact depth ties -> index tie-break
+    d = _to(s, hip_device)
+    rendering.set_tile_culling(False)
+    try:
+        img, a, meta = rasterization(d["means"], d["quats"], d["scales"], d["opacities"], d["colors"], d["viewmats"],
+                                     d["Ks"], w, h, packed=False)
+    finally:
+        rendering.set_tile_culling(True)
+    # expected lists = upstream's binning + stable sort (C oracle) applied to the GPU's OWN projection outputs, so a
+    # last-ulp radius difference between the two projections cannot masquerade as an ordering error
+    tpg, ids, flat, eoffs = Cc.isect(meta["means2d"].cpu().numpy(), meta["radii"].cpu().numpy(),
+                                     meta["depths"].cpu().numpy(), w, h)
+    offs = meta["isect_offsets"].cpu().reshape(-1).tolist() + [meta["flatten_ids"].numel()]
+    longest = max(b - a_ for a_, b in zip(offs[:-1], offs[1:]))
+    assert longest > 500, longest
+    assert torch.equal(meta["tiles_per_gauss"].cpu(), torch.from_numpy(tpg))
+    assert torch.equal(meta["isect_offsets"].cpu().reshape(-1), torch.from_numpy(eoffs).reshape(-1))
+    assert torch.equal(meta["flatten_ids"].cpu(), torch.from_numpy(flat)), f"order differs (longest {longest})"
+    assert torch.equal(meta["isect_ids"].cpu(), torch.from_numpy(ids))
