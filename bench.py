@@ -105,12 +105,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MOBGS_BENCH_SHARE_GPU=1 + MOBGS_BENCH_BACKEND=gloo: functional check of the N>1 code path on a ONE-GPU box
+    # (all ranks on cuda:0, collectives through gloo); never used for reported numbers
+    share = os.environ.get("MOBGS_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("MOBGS_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mobgs_amd.distributed import SubframeShard
     from mobgs_amd.gaussian_renderer import render
@@ -177,7 +185,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not share else "synthetic (FUNCTIONAL CHECK: ranks share one GPU, not a measurement)",
         "config": {"workload": "BASELINE config #2: seesaw-synth (SURVEY 8d seed 0), "
                                f"{args.ns} static + {args.nd} dynamic Gaussians, {args.width}x{args.height}, "
                                "render() lean mode fwd+bwd incl. spline prep, decoder, camera gradient",
