@@ -139,8 +139,8 @@ def main():
             p.grad = None
         out = render(cam, stat, dyn, None, bg, delta_exposure=delta)
         pred = shard.mean_of_subframes(out["render"], world)  # all-reduce(SUM)/K + 1e-10 when world > 1
-        loss = (pred * v_render).sum() + (out["depth"] * v_depth).sum()
-        loss.backward()
+        # back-propagate fixed random cotangents: d(loss)/d(pred) = v_render, d(loss)/d(depth) = v_depth
+        torch.autograd.backward([pred, out["depth"]], [v_render, v_depth])
         shard.all_reduce_gradients(params)
         return out
 

@@ -140,6 +140,35 @@ int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int
                             const int32_t* keep_scan, const float* grad_slots, float* v_means2d, float* v_conics, float* v_opacities,
                             float* v_colors, float* v_extra, void* stream);
 
+/* Packs the compositor's per-splat inputs into records [C*N, mobgs_record_stride(D)] (the first step of
+ * mobgs_raster_fwd, exposed for mobgs_raster_layers_fwd). */
+int mobgs_pack_records(int C, int N, int channels, const float* means2d, const float* conics, const float* colors,
+                       int colors_per_camera, const float* opacities, int opac_per_camera, const float* extra,
+                       const int32_t* radii, float* records, void* stream);
+
+/* ---- K6'/K7': layered compositing (train-mode render(): combined + static-only + dynamic-only in one pass) ----
+ * Replaces the 5 rasterization() calls of /root/reference/gaussian_renderer/__init__.py:143-176,201-214,236-268
+ * that share one camera: splats with (flat id % N) < Ns are "static", the others "dynamic".
+ * layer_mask: bit 0 = all (required), bit 1 = static-only, bit 2 = dynamic-only.  10 total channels only
+ * (9 features + depth).  Per-layer tensors are passed as HOST arrays of 3 device pointers (index = layer;
+ * entries of layers that are not requested may be NULL): render [C,H,W,10], alphas [C,H,W], last_ids [C,H,W].
+ * Backward: v_render3 / v_alphas3 entries may be NULL (zero cotangent); grad_slots [I_listed, 2, 16] and
+ * grad_xy0 [I_listed, 2, 2] are zero-filled scratch (one record per HALF tile and splat); the dense gradients
+ * are fully written.  v_means2d is the total over the layers, v_means2d_layer0 the share of the combined render
+ * alone (what the reference's `viewspace_points.grad` holds, gaussian_renderer/__init__.py:218-223). */
+int mobgs_raster_layers_fwd(int C, int N, int Ns, int layer_mask, int channels_total, int width, int height,
+                            const float* records, const float* backgrounds, const int32_t* tile_offsets,
+                            const int32_t* flatten_ids, float* const* render3_host, float* const* alphas3_host,
+                            int32_t* const* last_ids3_host, void* stream);
+int mobgs_raster_layers_bwd(int C, int N, int Ns, int layer_mask, int channels, int has_extra, int width,
+                            int height, const float* records, const float* backgrounds, const int32_t* radii,
+                            const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
+                            const int32_t* flatten_ids, const float* const* render_alphas3_host,
+                            const int32_t* const* last_ids3_host, const float* const* v_render3_host,
+                            const float* const* v_alphas3_host, float* grad_slots, float* grad_xy0,
+                            float* v_means2d_layer0, float* v_means2d, float* v_conics, float* v_opacities,
+                            float* v_colors, float* v_extra, void* stream);
+
 /* 1 if raster kernels are compiled for `total_channels` (colour channels + optional extra channel). */
 int mobgs_raster_channels_supported(int total_channels);
 

@@ -471,6 +471,21 @@ int mobgs_raster_channels_supported(int D) {
     return D == 1 || D == 2 || D == 3 || D == 4 || D == 9 || D == 10 || D == 16 || D == 26;
 }
 
+int mobgs_pack_records(int C, int N, int channels, const float* means2d, const float* conics, const float* colors,
+                       int colors_per_camera, const float* opacities, int opac_per_camera, const float* extra,
+                       const int32_t* radii, float* records, void* stream) {
+    const int D = channels + (extra ? 1 : 0);
+    if (C <= 0 || N < 0 || channels < 0 || D < 1) {
+        set_error("mobgs_pack_records: bad sizes C=%d N=%d channels=%d", C, N, channels);
+        return MOBGS_E_INVALID;
+    }
+    if (N == 0) return MOBGS_OK;
+    hipLaunchKernelGGL(pack_records_kernel, dim3((N + 255) / 256, C), dim3(256), 0, (hipStream_t)stream, N, channels,
+                       record_stride(D), means2d, conics, colors, colors_per_camera, opacities, opac_per_camera, extra,
+                       radii, records);
+    return check_launch("pack_records_kernel");
+}
+
 int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const float* means2d,
                      const float* conics, const float* colors, int colors_per_camera, const float* opacities,
                      int opac_per_camera, const float* extra, const float* backgrounds, const int32_t* radii,

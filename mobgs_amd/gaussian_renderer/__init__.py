@@ -24,6 +24,10 @@ from . import network_gui  # noqa: F401  (train.py imports it from here)
 
 __all__ = ["render", "get_flow", "get_flow_static", "interpolate_cubic_hermite", "network_gui"]
 
+# True: train-mode render() composites its three splat sets in one layered pass (csrc/raster_layers.hip);
+# False: one rasterization per set, call for call like the reference (kept for A/B tests)
+FUSE_LAYERS = True
+
 
 def _device_of(pc):
     return pc.get_xyz.device
@@ -102,13 +106,6 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     out = {k: None for k in ("s_render", "s_depth", "d_render", "d_depth", "d_alpha", "d_means3d", "s_alpha",
                              "blending_factor", "world_coordinates", "splat_center", "ori_flow", "ori_coord_map",
                              "labels", "centroids")}
-    if get_dynamic:
-        d_img, d_a, _ = _raster_acc(raster, dyn_sl, cols[dyn_sl], bg[None])
-        out["d_render"], d_depth = decode_ed(d_img, d_a)
-        out["d_depth"] = d_depth.unsqueeze(0)
-        ones = torch.ones(cols.shape[0] - Ns, 1, device=dev)
-        out["d_alpha"] = raster(dyn_sl, ones, bg[0:1][None], "RGB")[0][..., 0]
-        out["d_means3d"] = means[dyn_sl]
 
     ori_m2d = None
     if delta_exposure is not None and get_flow:
@@ -116,7 +113,33 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
         _, ori_m2d, _, _, _ = _R.fully_fused_projection(means=o_means, covars=None, quats=o_quats, scales=scales,
                                                         viewmats=viewmat[None], Ks=K[None], width=W, height=H)
 
-    img, alphas, info = _raster_acc(raster, all_sl, cols, bg[None])
+    layered = (get_static or get_dynamic) and FUSE_LAYERS
+    if layered:
+        # ONE projection, ONE tile binning / sort and ONE compositing walk for the combined, static-only and
+        # dynamic-only renders (the reference: 5 rasterizations, :143-176, :201-214, :236-268)
+        imgs, alps, info = _R.rasterize_layers(means, quats, scales, opac, cols, viewmat[None], K[None], W, H, Ns,
+                                               backgrounds=bg[None], want_static=get_static,
+                                               want_dynamic=get_dynamic)
+        img, alphas = imgs[0], alps[0]
+    else:
+        img, alphas, info = _raster_acc(raster, all_sl, cols, bg[None])
+
+    def alpha_pass(a):
+        """The reference's ones-colour pass (:163-177, :255-269): sum_i w_i + T_final * bg = (1 - T) + T * bg."""
+        return a + (1.0 - a) * bg[0]
+
+    if get_dynamic:
+        if layered:
+            d_img, d_a = imgs[2], alps[2]
+            out["d_alpha"] = alpha_pass(d_a)
+        else:
+            d_img, d_a, _ = _raster_acc(raster, dyn_sl, cols[dyn_sl], bg[None])
+            ones = torch.ones(cols.shape[0] - Ns, 1, device=dev)
+            out["d_alpha"] = raster(dyn_sl, ones, bg[0:1][None], "RGB")[0][..., 0]
+        out["d_render"], d_depth = decode_ed(d_img, d_a)
+        out["d_depth"] = d_depth.unsqueeze(0)
+        out["d_means3d"] = means[dyn_sl]
+
     radii = info["radii"].squeeze(0)
     try:
         info["means2d"].retain_grad()
@@ -127,11 +150,15 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     out["depth"] = depth.unsqueeze(0)
 
     if get_static:
-        s_img, s_a, _ = _raster_acc(raster, stat_sl, cols[stat_sl], bg[None])
+        if layered:
+            s_img, s_a = imgs[1], alps[1]
+            out["s_alpha"] = alpha_pass(s_a)
+        else:
+            s_img, s_a, _ = _raster_acc(raster, stat_sl, cols[stat_sl], bg[None])
+            ones = torch.ones(Ns, 1, device=dev)
+            out["s_alpha"] = raster(stat_sl, ones, bg[0:1][None], "RGB")[0][..., 0]
         out["s_render"], _ = decode_ed(s_img, s_a)
         out["s_depth"] = rendered[..., -1]  # reference quirk (:250): slices the decoded image -> [3,H]
-        ones = torch.ones(Ns, 1, device=dev)
-        out["s_alpha"] = raster(stat_sl, ones, bg[0:1][None], "RGB")[0][..., 0]
 
     if ori_m2d is not None:
         flow_2d = (ori_m2d - info["means2d"].detach()).squeeze(0)

@@ -249,6 +249,128 @@ class _Rasterize(torch.autograd.Function):
         return v_means2d, v_conics, v_colors, v_opac, v_extra, v_bg, None, None, None, None
 
 
+def _ptr3(tensors):
+    import ctypes
+    return (ctypes.c_void_p * 3)(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+class _RasterizeLayers(torch.autograd.Function):
+    """Layered compositing (csrc/raster_layers.hip): the combined, static-only and dynamic-only renders of one
+    camera in a single walk over the combined tile lists.  Returns (render_all, alpha_all, render_static,
+    alpha_static, render_dynamic, alpha_dynamic): render [C,H,W,10], alpha [C,H,W]; layers not in `mask` are
+    empty tensors."""
+
+    @staticmethod
+    def forward(ctx, means2d, means2d_view, conics, colors, opacities, extra, backgrounds, radii, tl: TileLists,
+                width, height, Ns, mask):
+        # means2d_view is an autograd alias of means2d (same values): it receives the position gradient of the
+        # combined layer alone, means2d that of the static / dynamic layers -- see rasterize_layers()
+        lib = _lib_()
+        C, N = radii.shape
+        dev = means2d.device
+        means2d, conics, colors, opacities, extra = map(f32c, (means2d, conics, colors, opacities, extra))
+        channels = colors.shape[-1]
+        D = channels + 1
+        if D != 10:
+            raise NotImplementedError("layered compositing is built for 9 feature channels + depth")
+        bg = f32c(backgrounds) if backgrounds is not None else None
+        stride = lib.mobgs_record_stride(D)
+        records = torch.empty(C * N, stride, dtype=torch.float32, device=dev)
+        check(lib.mobgs_pack_records(C, N, channels, ptr(means2d), ptr(conics), ptr(colors),
+                                     1 if colors.dim() == 3 else 0, ptr(opacities), 1 if opacities.dim() == 2 else 0,
+                                     ptr(extra), ptr(radii), ptr(records), stream()), "mobgs_pack_records")
+        renders, alphas, lasts = [], [], []
+        for layer in range(3):
+            on = (mask >> layer) & 1
+            renders.append(torch.empty(C, height, width, D, dtype=torch.float32, device=dev) if on else None)
+            alphas.append(torch.empty(C, height, width, dtype=torch.float32, device=dev) if on else None)
+            lasts.append(torch.empty(C, height, width, dtype=torch.int32, device=dev) if on else None)
+        with profiler.region("raster_layers_fwd"):
+            check(lib.mobgs_raster_layers_fwd(C, N, Ns, mask, D, width, height, ptr(records), ptr(bg),
+                                              ptr(tl.tile_offsets), ptr(tl.flatten_ids), _ptr3(renders),
+                                              _ptr3(alphas), _ptr3(lasts), stream()), "mobgs_raster_layers_fwd")
+        ctx.save_for_backward(records, bg, radii, *[t for t in alphas + lasts if t is not None])
+        ctx.tl = tl
+        ctx.meta = (C, N, channels, width, height, colors.dim() == 3, opacities.dim() == 2, Ns, mask)
+        empty = means2d.new_empty(0)
+        out = []
+        for layer in range(3):
+            out += [renders[layer] if renders[layer] is not None else empty,
+                    alphas[layer] if alphas[layer] is not None else empty]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *cots):
+        lib = _lib_()
+        C, N, channels, width, height, colors_per_camera, opac_per_camera, Ns, mask = ctx.meta
+        records, bg, radii, *rest = ctx.saved_tensors
+        tl = ctx.tl
+        dev = records.device
+        stride = records.shape[1]
+        on = [(mask >> layer) & 1 for layer in range(3)]
+        n_on = sum(on)
+        it = iter(rest)
+        alphas = [next(it) if o else None for o in on]
+        lasts = [next(it) if o else None for o in on]
+        v_render = [f32c(cots[2 * layer]) if (on[layer] and cots[2 * layer] is not None) else None
+                    for layer in range(3)]
+        v_alphas = [f32c(cots[2 * layer + 1]) if (on[layer] and cots[2 * layer + 1] is not None) else None
+                    for layer in range(3)]
+        assert n_on >= 1
+        slots = torch.zeros(max(tl.n_isects, 1), 2, stride, dtype=torch.float32, device=dev)
+        slots_xy0 = torch.zeros(max(tl.n_isects, 1), 2, 2, dtype=torch.float32, device=dev)
+        v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        v_means2d_l0 = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
+        v_colors = torch.empty(C, N, channels, dtype=torch.float32, device=dev)
+        v_extra = torch.empty(C, N, dtype=torch.float32, device=dev)
+        with profiler.region("raster_layers_bwd"):
+            check(lib.mobgs_raster_layers_bwd(C, N, Ns, mask, channels, 1, width, height, ptr(records), ptr(bg),
+                                              ptr(radii), ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(tl.tile_offsets),
+                                              ptr(tl.flatten_ids), _ptr3(alphas), _ptr3(lasts), _ptr3(v_render),
+                                              _ptr3(v_alphas), ptr(slots), ptr(slots_xy0), ptr(v_means2d_l0),
+                                              ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra),
+                                              stream()), "mobgs_raster_layers_bwd")
+        if not colors_per_camera:
+            v_colors = v_colors.sum(0) if C > 1 else v_colors[0]
+        if not opac_per_camera:
+            v_opac = v_opac.sum(0) if C > 1 else v_opac[0]
+        return (v_means2d - v_means2d_l0, v_means2d_l0, v_conics, v_colors, v_opac, v_extra, None, None, None, None,
+                None, None, None)
+
+
+def rasterize_layers(means, quats, scales, opacities, colors, viewmats, Ks, width, height, Ns, backgrounds=None,
+                     want_static=True, want_dynamic=True, near_plane=0.01, far_plane=1e10, radius_clip=0.0,
+                     eps2d=0.3):
+    """One projection + one binning/sort + one layered compositing pass for the three splat sets of a train-mode
+    render(): all, static (first Ns splats), dynamic (the rest); "RGB+D" semantics (9 features + accumulated depth).
+    Returns (render, alphas, meta): lists indexed by layer (0 = all, 1 = static, 2 = dynamic; None when not
+    requested) of [C,H,W,10] / [C,H,W] tensors."""
+    width, height = int(width), int(height)
+    C, N = viewmats.shape[0], means.shape[0]
+    radii, means2d, depths, conics, tiles_per_gauss = _Project.apply(
+        means, quats, scales, viewmats, Ks, width, height, float(eps2d), float(near_plane), float(far_plane),
+        float(radius_clip))
+    tl = build_tile_lists(means2d.detach(), radii, depths.detach(), conics.detach(), opacities.detach(),
+                          tiles_per_gauss, width, height, want_isect_ids=False)
+    bg = backgrounds
+    if bg is not None:
+        bg = torch.cat([bg, bg.new_zeros(C, 1)], dim=-1)
+    mask = 1 | (2 if want_static else 0) | (4 if want_dynamic else 0)
+    # `means2d_view` carries the reference's viewspace_points semantics: its .grad is the position gradient of the
+    # COMBINED render only (the static / dynamic passes of the reference have their own, un-retained means2d)
+    means2d_view = means2d.view_as(means2d)
+    outs = _RasterizeLayers.apply(means2d, means2d_view, conics, colors, opacities, depths, bg, radii, tl, width,
+                                  height, int(Ns), mask)
+    render = [outs[0], outs[2] if want_static else None, outs[4] if want_dynamic else None]
+    alphas = [outs[1], outs[3] if want_static else None, outs[5] if want_dynamic else None]
+    meta = {"radii": radii, "means2d": means2d_view, "depths": depths, "conics": conics,
+            "tiles_per_gauss": tiles_per_gauss, "flatten_ids": tl.flatten_ids, "isect_offsets": tl.tile_offsets[:-1].reshape(C, tl.tile_h, tl.tile_w),
+            "width": width, "height": height, "tile_size": TILE, "n_cameras": C}
+    return render, alphas, meta
+
+
 def rasterize_to_pixels(means2d, conics, colors, opacities, radii, tl: TileLists, width, height, backgrounds=None,
                         extra=None):
     """Composite; channel counts without a compiled variant are zero-padded up to the next one."""
