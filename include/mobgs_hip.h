@@ -149,7 +149,7 @@ int mobgs_pack_records(int C, int N, int channels, const float* means2d, const f
 /* ---- K6'/K7': layered compositing (train-mode render(): combined + static-only + dynamic-only in one pass) ----
  * Replaces the 5 rasterization() calls of /root/reference/gaussian_renderer/__init__.py:143-176,201-214,236-268
  * that share one camera: splats with (flat id % N) < Ns are "static", the others "dynamic".
- * layer_mask: bit 0 = all (required), bit 1 = static-only, bit 2 = dynamic-only.  10 total channels only
+ * layer_mask (non-zero): bit 0 = all, bit 1 = static-only, bit 2 = dynamic-only.  10 total channels only
  * (9 features + depth).  Per-layer tensors are passed as HOST arrays of 3 device pointers (index = layer;
  * entries of layers that are not requested may be NULL): render [C,H,W,10], alphas [C,H,W], last_ids [C,H,W].
  * Backward: v_render3 / v_alphas3 entries may be NULL (zero cotangent); grad_slots [I_listed, 2, 16] and

@@ -158,11 +158,12 @@ raster_layers_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
             float col[CD];
 #pragma unroll
             for (int c = 0; c < CD; ++c) col[c] = rec[6 + c];
-            layer_blend<CD>(L[0], ev, col, b + j);
-            if (cls == 1)
-                layer_blend<CD>(L[1], ev, col, b + j);
-            else
-                layer_blend<CD>(L[2], ev, col, b + j);
+            if (layer_mask & 1) layer_blend<CD>(L[0], ev, col, b + j);
+            if (cls == 1) {
+                if (layer_mask & 2) layer_blend<CD>(L[1], ev, col, b + j);
+            } else {
+                if (layer_mask & 4) layer_blend<CD>(L[2], ev, col, b + j);
+            }
             bool live = false;
 #pragma unroll
             for (int l = 0; l < NL; ++l)
@@ -402,11 +403,13 @@ raster_layers_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
 #pragma unroll
             for (int i = 0; i < NVP; ++i) g[i] = 0.f;
             float e0 = 0.f, e1 = 0.f, dummy0 = 0.f, dummy1 = 0.f;
-            bool any = layer_grad<CD, NVP, true>(B[0], ev, rec, idx, has_bg, g, e0, e1);
-            if (cls == 1)
-                any = layer_grad<CD, NVP, false>(B[1], ev, rec, idx, has_bg, g, dummy0, dummy1) || any;
-            else
-                any = layer_grad<CD, NVP, false>(B[2], ev, rec, idx, has_bg, g, dummy0, dummy1) || any;
+            bool any = false;
+            if (layer_mask & 1) any = layer_grad<CD, NVP, true>(B[0], ev, rec, idx, has_bg, g, e0, e1);
+            if (cls == 1) {
+                if (layer_mask & 2) any = layer_grad<CD, NVP, false>(B[1], ev, rec, idx, has_bg, g, dummy0, dummy1) || any;
+            } else {
+                if (layer_mask & 4) any = layer_grad<CD, NVP, false>(B[2], ev, rec, idx, has_bg, g, dummy0, dummy1) || any;
+            }
             if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
             l_wave_reduce<NVP>(g);
             e0 = l_wave_allreduce(e0);
@@ -468,7 +471,7 @@ int mobgs_raster_layers_fwd(int C, int N, int Ns, int layer_mask, int channels_t
                             const float* records, const float* backgrounds, const int32_t* tile_offsets,
                             const int32_t* flatten_ids, float* const* render3_host, float* const* alphas3_host,
                             int32_t* const* last_ids3_host, void* stream) {
-    if (C <= 0 || N < 0 || Ns < 0 || Ns > N || channels_total != 10 || !(layer_mask & 1)) {
+    if (C <= 0 || N < 0 || Ns < 0 || Ns > N || channels_total != 10 || !(layer_mask & 7)) {
         set_error("mobgs_raster_layers_fwd: unsupported arguments (C=%d N=%d Ns=%d D=%d mask=%d)", C, N, Ns,
                   channels_total, layer_mask);
         return MOBGS_E_UNSUPPORTED;
@@ -502,7 +505,7 @@ int mobgs_raster_layers_bwd(int C, int N, int Ns, int layer_mask, int channels, 
                             float* v_means2d_layer0, float* v_means2d, float* v_conics, float* v_opacities,
                             float* v_colors, float* v_extra, void* stream) {
     const int D = channels + (has_extra ? 1 : 0);
-    if (C <= 0 || N < 0 || D != 10 || !(layer_mask & 1)) {
+    if (C <= 0 || N < 0 || D != 10 || !(layer_mask & 7)) {
         set_error("mobgs_raster_layers_bwd: unsupported arguments");
         return MOBGS_E_UNSUPPORTED;
     }

@@ -24,9 +24,52 @@ from . import network_gui  # noqa: F401  (train.py imports it from here)
 
 __all__ = ["render", "get_flow", "get_flow_static", "interpolate_cubic_hermite", "network_gui"]
 
-# True: train-mode render() composites its three splat sets in one layered pass (csrc/raster_layers.hip);
-# False: one rasterization per set, call for call like the reference (kept for A/B tests)
+# True: the static-only / dynamic-only images of a train-mode render() come from one layered compositing pass over
+# the lists of the combined render (csrc/raster_layers.hip); False: one rasterization per set, call for call like
+# the reference (kept for A/B tests)
 FUSE_LAYERS = True
+# True: those auxiliary images (s_render, s_alpha, d_render, d_depth, d_alpha) are computed on first access of
+# their dict entry.  train.py asks every one of the 8 latent sub-frame renders of a blurry view for them
+# (:512-516) and then reads only "render"/"depth" -- with lazy entries those calls cost a lean render.
+LAZY_AUX = True
+
+_PENDING = object()
+
+
+class RenderResult(dict):
+    """The reference's result dict; entries registered with defer() are materialised on first access."""
+
+    def defer(self, keys, thunk):
+        self._thunk = thunk
+        for k in keys:
+            dict.__setitem__(self, k, _PENDING)
+
+    def _materialise(self):
+        thunk, self._thunk = getattr(self, "_thunk", None), None
+        if thunk is not None:
+            dict.update(self, thunk())
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if v is _PENDING:
+            self._materialise()
+            v = dict.__getitem__(self, key)
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+    def copy(self):
+        self._materialise()
+        return dict(self)
 
 
 def _device_of(pc):
@@ -103,9 +146,9 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     def decode_ed(img, alphas):
         return decode(img, alphas, cam.cam_ray, w1, w2, True)  # views only: no select/zeros/copy in backward
 
-    out = {k: None for k in ("s_render", "s_depth", "d_render", "d_depth", "d_alpha", "d_means3d", "s_alpha",
-                             "blending_factor", "world_coordinates", "splat_center", "ori_flow", "ori_coord_map",
-                             "labels", "centroids")}
+    out = RenderResult({k: None for k in ("s_render", "s_depth", "d_render", "d_depth", "d_alpha", "d_means3d",
+                                          "s_alpha", "blending_factor", "world_coordinates", "splat_center",
+                                          "ori_flow", "ori_coord_map", "labels", "centroids")})
 
     ori_m2d = None
     if delta_exposure is not None and get_flow:
@@ -113,33 +156,12 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
         _, ori_m2d, _, _, _ = _R.fully_fused_projection(means=o_means, covars=None, quats=o_quats, scales=scales,
                                                         viewmats=viewmat[None], Ks=K[None], width=W, height=H)
 
-    layered = (get_static or get_dynamic) and FUSE_LAYERS
-    if layered:
-        # ONE projection, ONE tile binning / sort and ONE compositing walk for the combined, static-only and
-        # dynamic-only renders (the reference: 5 rasterizations, :143-176, :201-214, :236-268)
-        imgs, alps, info = _R.rasterize_layers(means, quats, scales, opac, cols, viewmat[None], K[None], W, H, Ns,
-                                               backgrounds=bg[None], want_static=get_static,
-                                               want_dynamic=get_dynamic)
-        img, alphas = imgs[0], alps[0]
-    else:
-        img, alphas, info = _raster_acc(raster, all_sl, cols, bg[None])
-
-    def alpha_pass(a):
-        """The reference's ones-colour pass (:163-177, :255-269): sum_i w_i + T_final * bg = (1 - T) + T * bg."""
-        return a + (1.0 - a) * bg[0]
-
-    if get_dynamic:
-        if layered:
-            d_img, d_a = imgs[2], alps[2]
-            out["d_alpha"] = alpha_pass(d_a)
-        else:
-            d_img, d_a, _ = _raster_acc(raster, dyn_sl, cols[dyn_sl], bg[None])
-            ones = torch.ones(cols.shape[0] - Ns, 1, device=dev)
-            out["d_alpha"] = raster(dyn_sl, ones, bg[0:1][None], "RGB")[0][..., 0]
-        out["d_render"], d_depth = decode_ed(d_img, d_a)
-        out["d_depth"] = d_depth.unsqueeze(0)
-        out["d_means3d"] = means[dyn_sl]
-
+    # ONE projection and ONE tile binning / sort per render() call; the whole-set image comes from the single-set
+    # compositor, the static-only / dynamic-only images (when asked for) from ONE layered walk over the same lists
+    # (the reference: 5 rasterizations, :143-176, :201-214, :236-268)
+    sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None], K[None], W, H)
+    img, alphas = sp.composite(cols, bg[None])
+    info = sp.meta()
     radii = info["radii"].squeeze(0)
     try:
         info["means2d"].retain_grad()
@@ -148,26 +170,55 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     rendered, depth = decode_ed(img, alphas)
     out["render"] = rendered
     out["depth"] = depth.unsqueeze(0)
-
+    if get_dynamic:
+        out["d_means3d"] = means[dyn_sl]
     if get_static:
-        if layered:
-            s_img, s_a = imgs[1], alps[1]
-            out["s_alpha"] = alpha_pass(s_a)
-        else:
-            s_img, s_a, _ = _raster_acc(raster, stat_sl, cols[stat_sl], bg[None])
-            ones = torch.ones(Ns, 1, device=dev)
-            out["s_alpha"] = raster(stat_sl, ones, bg[0:1][None], "RGB")[0][..., 0]
-        out["s_render"], _ = decode_ed(s_img, s_a)
         out["s_depth"] = rendered[..., -1]  # reference quirk (:250): slices the decoded image -> [3,H]
+
+    def alpha_pass(a):
+        """The reference's ones-colour pass (:163-177, :255-269): sum_i w_i + T_final * bg = (1 - T) + T * bg."""
+        return a + (1.0 - a) * bg[0]
+
+    def aux_images():
+        res = {}
+        if FUSE_LAYERS:
+            imgs, alps = sp.composite_layers(cols, Ns, bg[None], want_static=get_static, want_dynamic=get_dynamic)
+            if get_dynamic:
+                res["d_render"], d_depth = decode_ed(imgs[2], alps[2])
+                res["d_depth"] = d_depth.unsqueeze(0)
+                res["d_alpha"] = alpha_pass(alps[2])
+            if get_static:
+                res["s_render"], _ = decode_ed(imgs[1], alps[1])
+                res["s_alpha"] = alpha_pass(alps[1])
+            return res
+        # call-for-call like the reference (A/B tests): one rasterization per set + a ones-colour alpha pass
+        for name, sl, on in (("d", dyn_sl, get_dynamic), ("s", stat_sl, get_static)):
+            if not on:
+                continue
+            x_img, x_a, _ = _raster_acc(raster, sl, cols[sl], bg[None])
+            res[name + "_render"], x_depth = decode_ed(x_img, x_a)
+            if name == "d":
+                res["d_depth"] = x_depth.unsqueeze(0)
+            ones = torch.ones(cols[sl].shape[0], 1, device=dev)
+            res[name + "_alpha"] = raster(sl, ones, bg[0:1][None], "RGB")[0][..., 0]
+        return res
+
+    aux_keys = (["d_render", "d_depth", "d_alpha"] if get_dynamic else []) + \
+               (["s_render", "s_alpha"] if get_static else [])
 
     if ori_m2d is not None:
         flow_2d = (ori_m2d - info["means2d"].detach()).squeeze(0)
-        flow_img = raster(all_sl, flow_2d, None, "RGB")[0]
+        flow_img, _ = _R.rasterize_to_pixels(sp.means2d, sp.conics, flow_2d, opac, sp.radii, sp.tl, W, H)  # same lists
         out["ori_flow"] = flow_img
         out["ori_coord_map"] = _pixel_grid(cam, W, H, flow_img) + flow_img
 
     out.update({"viewspace_points": info["means2d"], "visibility_filter": radii > 0, "radii": radii,
                 "means_3d_final": means * 1e2, "colors_precomp_final": cols, "means_3d": means[dyn_sl]})
+    if aux_keys:
+        if LAZY_AUX and FUSE_LAYERS:
+            out.defer(aux_keys, aux_images)
+        else:
+            out.update(aux_images())
     return out
 
 
@@ -195,24 +246,25 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     mid_m, mid_q, scales, opac, _ = _prep(stat_pc, dyn_pc, _times(cam, None, dev))
     exp_m, exp_q, _, _, exp_c = _prep(stat_pc, dyn_pc, _times(cam, delta_exposure, dev))
 
-    def raster(m, q, sl, colors, bgs, mode):
-        return _R.rasterization(means=m[sl], quats=q[sl], scales=scales[sl], opacities=opac[sl], colors=colors,
-                                backgrounds=bgs, viewmats=viewmat[None], Ks=K[None], width=W, height=H, packed=False,
-                                render_mode=mode)
+    # two projections + two tile binnings in total (the reference: 2 explicit projections + 4 rasterizations)
+    sp_exp = _R.SharedProjection(exp_m, exp_q, scales, opac, viewmat[None], K[None], W, H)
+    sp_mid = _R.SharedProjection(mid_m, mid_q, scales, opac, viewmat[None], K[None], W, H)
 
-    def project(m, q):
-        return _R.fully_fused_projection(means=m, covars=None, quats=q, scales=scales, viewmats=viewmat[None],
-                                         Ks=K[None], width=W, height=H)[1]
+    def splat(sp, colors):
+        return _R.rasterize_to_pixels(sp.means2d, sp.conics, colors, opac, sp.radii, sp.tl, W, H)[0]
 
-    dyn_sl, all_sl = slice(Ns, None), slice(None)
+    dyn_sl = slice(Ns, None)
     ones = torch.ones(exp_c.shape[0] - Ns, 1, device=dev)
-    latent_alpha = raster(exp_m, exp_q, dyn_sl, ones, bg[0:1][None], "RGB")[0][..., 0]
-    e2m = (project(mid_m, mid_q) - project(exp_m, exp_q)).squeeze(0)
-    e2m_img = raster(exp_m, exp_q, all_sl, e2m, None, "RGB")[0]
+    latent_alpha = _R.rasterization(means=exp_m[dyn_sl], quats=exp_q[dyn_sl], scales=scales[dyn_sl],
+                                    opacities=opac[dyn_sl], colors=ones, backgrounds=bg[0:1][None],
+                                    viewmats=viewmat[None], Ks=K[None], width=W, height=H, packed=False,
+                                    render_mode="RGB")[0][..., 0]
+    e2m = (sp_mid.means2d - sp_exp.means2d).squeeze(0)
+    e2m_img = splat(sp_exp, e2m)
     pix = _pixel_grid(cam, W, H, e2m_img)
     exp2mid = pix + e2m_img
-    mid2exp = pix + raster(mid_m, mid_q, all_sl, -e2m, None, "RGB")[0]
-    img, alphas, _ = raster(exp_m, exp_q, all_sl, exp_c, bg[None], "RGB+D")
+    mid2exp = pix + splat(sp_mid, -e2m)
+    img, alphas = sp_exp.composite(exp_c, bg[None])
     latent_img, _ = decode(img, alphas, cam.cam_ray, w1, w2, True)
     return exp2mid, mid2exp, latent_img, latent_alpha
 

@@ -340,34 +340,76 @@ class _RasterizeLayers(torch.autograd.Function):
                 None, None, None)
 
 
+class SharedProjection:
+    """One projection + one tile binning/sort of a splat set, reusable by several compositing passes of the same
+    camera (`composite` = the usual single-set pass, `composite_layers` = static-only / dynamic-only layers)."""
+
+    def __init__(self, means, quats, scales, opacities, viewmats, Ks, width, height, near_plane=0.01, far_plane=1e10,
+                 radius_clip=0.0, eps2d=0.3, want_isect_ids=False):
+        self.width, self.height = int(width), int(height)
+        self.C, self.N = viewmats.shape[0], means.shape[0]
+        self.opacities = opacities
+        (self.radii, self.means2d, self.depths, self.conics, self.tiles_per_gauss) = _Project.apply(
+            means, quats, scales, viewmats, Ks, self.width, self.height, float(eps2d), float(near_plane),
+            float(far_plane), float(radius_clip))
+        self.tl = build_tile_lists(self.means2d.detach(), self.radii, self.depths.detach(), self.conics.detach(),
+                                   opacities.detach(), self.tiles_per_gauss, self.width, self.height,
+                                   want_isect_ids=want_isect_ids)
+        # autograd alias used by composite() and exposed as meta["means2d"] / viewspace_points: its .grad is the
+        # position gradient of the whole-set render alone (the reference's static / dynamic passes have their own,
+        # un-retained means2d tensors, gaussian_renderer/__init__.py:218-223)
+        self.means2d_main = self.means2d.view_as(self.means2d)
+
+    def _bg(self, backgrounds):
+        if backgrounds is None:
+            return None
+        return torch.cat([backgrounds, backgrounds.new_zeros(self.C, 1)], dim=-1)
+
+    def composite(self, colors, backgrounds=None):
+        """"RGB+D" compositing of the whole set: (render [C,H,W,D+1], alphas [C,H,W,1])."""
+        return rasterize_to_pixels(self.means2d_main, self.conics, colors, self.opacities, self.radii, self.tl,
+                                   self.width, self.height, backgrounds=self._bg(backgrounds), extra=self.depths)
+
+    def composite_layers(self, colors, Ns, backgrounds=None, want_all=False, want_static=True, want_dynamic=True):
+        """Layered "RGB+D" compositing over the SAME lists: lists (render, alphas) indexed by layer
+        (0 = all, 1 = the first Ns splats, 2 = the rest); None for layers that were not requested."""
+        mask = (1 if want_all else 0) | (2 if want_static else 0) | (4 if want_dynamic else 0)
+        if mask == 0:
+            return [None] * 3, [None] * 3
+        m2d_view = self.means2d.view_as(self.means2d)
+        outs = _RasterizeLayers.apply(self.means2d, m2d_view, self.conics, colors, self.opacities, self.depths,
+                                      self._bg(backgrounds), self.radii, self.tl, self.width, self.height, int(Ns),
+                                      mask)
+        on = [(mask >> layer) & 1 for layer in range(3)]
+        return ([outs[2 * layer] if on[layer] else None for layer in range(3)],
+                [outs[2 * layer + 1] if on[layer] else None for layer in range(3)])
+
+    def meta(self):
+        tl = self.tl
+        return {"radii": self.radii, "means2d": self.means2d_main, "depths": self.depths, "conics": self.conics,
+                "tiles_per_gauss": self.tiles_per_gauss, "flatten_ids": tl.flatten_ids,
+                "isect_offsets": tl.tile_offsets[:-1].reshape(self.C, tl.tile_h, tl.tile_w), "width": self.width,
+                "height": self.height, "tile_size": TILE, "n_cameras": self.C}
+
+
 def rasterize_layers(means, quats, scales, opacities, colors, viewmats, Ks, width, height, Ns, backgrounds=None,
                      want_static=True, want_dynamic=True, near_plane=0.01, far_plane=1e10, radius_clip=0.0,
                      eps2d=0.3):
     """One projection + one binning/sort + one layered compositing pass for the three splat sets of a train-mode
     render(): all, static (first Ns splats), dynamic (the rest); "RGB+D" semantics (9 features + accumulated depth).
     Returns (render, alphas, meta): lists indexed by layer (0 = all, 1 = static, 2 = dynamic; None when not
-    requested) of [C,H,W,10] / [C,H,W] tensors."""
-    width, height = int(width), int(height)
-    C, N = viewmats.shape[0], means.shape[0]
-    radii, means2d, depths, conics, tiles_per_gauss = _Project.apply(
-        means, quats, scales, viewmats, Ks, width, height, float(eps2d), float(near_plane), float(far_plane),
-        float(radius_clip))
-    tl = build_tile_lists(means2d.detach(), radii, depths.detach(), conics.detach(), opacities.detach(),
-                          tiles_per_gauss, width, height, want_isect_ids=False)
-    bg = backgrounds
-    if bg is not None:
-        bg = torch.cat([bg, bg.new_zeros(C, 1)], dim=-1)
+    requested) of [C,H,W,10] / [C,H,W] tensors.  meta["means2d"] receives the position gradient of the combined
+    layer only (the reference's viewspace_points semantics)."""
+    sp = SharedProjection(means, quats, scales, opacities, viewmats, Ks, width, height, near_plane, far_plane,
+                          radius_clip, eps2d)
     mask = 1 | (2 if want_static else 0) | (4 if want_dynamic else 0)
-    # `means2d_view` carries the reference's viewspace_points semantics: its .grad is the position gradient of the
-    # COMBINED render only (the static / dynamic passes of the reference have their own, un-retained means2d)
-    means2d_view = means2d.view_as(means2d)
-    outs = _RasterizeLayers.apply(means2d, means2d_view, conics, colors, opacities, depths, bg, radii, tl, width,
-                                  height, int(Ns), mask)
+    m2d_view = sp.means2d.view_as(sp.means2d)
+    outs = _RasterizeLayers.apply(sp.means2d, m2d_view, sp.conics, colors, opacities, sp.depths, sp._bg(backgrounds),
+                                  sp.radii, sp.tl, sp.width, sp.height, int(Ns), mask)
     render = [outs[0], outs[2] if want_static else None, outs[4] if want_dynamic else None]
     alphas = [outs[1], outs[3] if want_static else None, outs[5] if want_dynamic else None]
-    meta = {"radii": radii, "means2d": means2d_view, "depths": depths, "conics": conics,
-            "tiles_per_gauss": tiles_per_gauss, "flatten_ids": tl.flatten_ids, "isect_offsets": tl.tile_offsets[:-1].reshape(C, tl.tile_h, tl.tile_w),
-            "width": width, "height": height, "tile_size": TILE, "n_cameras": C}
+    meta = sp.meta()
+    meta["means2d"] = m2d_view
     return render, alphas, meta
 
 

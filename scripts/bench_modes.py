@@ -1,0 +1,91 @@
+#!/usr/bin/env python
+"""Secondary metrics: train-mode render() and blurry-view throughput on one GPU.
+    python scripts/bench_modes.py [--steps 20]
+Prints one JSON object; not part of the bench.py contract."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B  # noqa: E402
+import mobgs_amd.gaussian_renderer as GR  # noqa: E402
+from mobgs_amd.distributed import SubframeShard  # noqa: E402
+
+
+def timed(fn, steps, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    W, H = 1352, 1014
+    scam, cam, stat, dyn, _ = B.build_scene(dev, 200_000, 100_000, W, H)
+    bg = torch.zeros(9, device=dev)
+    g = torch.Generator().manual_seed(100)
+    v3 = torch.randn(3, H, W, generator=g).to(dev)
+    v1 = torch.randn(1, H, W, generator=g).to(dev)
+    params = B.leaves(stat, dyn)
+
+    def zero():
+        for p in params:
+            p.grad = None
+
+    def lean():
+        zero()
+        out = GR.render(cam, stat, dyn, None, bg)
+        torch.autograd.backward([out["render"], out["depth"]], [v3, v1])
+
+    def train_mode():
+        zero()
+        out = GR.render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True)
+        torch.autograd.backward([out["render"], out["depth"], out["s_render"], out["d_render"], out["d_alpha"],
+                                 out["s_alpha"], out["d_depth"]], [v3, v1, v3, v3, v1, v1, v1])
+
+    deltas = torch.linspace(-0.4, 0.4, 9).to(dev)
+    shard = SubframeShard(1, 0)
+
+    def blurry_view():
+        """train.py:441-541 for ONE view: mid render in train mode + 8 latent renders (the reference also asks for
+        static/dynamic outputs there, :512-516, and uses only render/depth) -> mean -> backward."""
+        zero()
+        mid = GR.render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True)
+
+        def unit(k):
+            if k == 4:
+                return mid["render"]
+            return GR.render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True,
+                             delta_exposure=deltas[k])["render"]
+
+        pred = shard.render_blurry_view(unit, 9)
+        torch.autograd.backward([pred, mid["depth"], mid["d_alpha"]], [v3, v1, v1])
+
+    res = {}
+    res["lean_ms"] = timed(lean, a.steps)
+    GR.FUSE_LAYERS = False
+    res["train_mode_separate_passes_ms"] = timed(train_mode, a.steps)
+    res["blurry_view_separate_passes_ms"] = timed(blurry_view, max(3, a.steps // 4), warmup=1)
+    GR.FUSE_LAYERS = True
+    res["train_mode_layered_ms"] = timed(train_mode, a.steps)
+    res["blurry_view_layered_ms"] = timed(blurry_view, max(3, a.steps // 4), warmup=1)
+    res["train_mode_renders_per_s"] = 1e3 / res["train_mode_layered_ms"]
+    res["blurry_views_per_s"] = 1e3 / res["blurry_view_layered_ms"]
+    res["config"] = "seesaw-synth 200k+100k, 1352x1014, K=9 (1 GPU)"
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

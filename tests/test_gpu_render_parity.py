@@ -133,3 +133,25 @@ def test_layered_render_equals_separate_passes(hip_device):
         close(res[True][1][k], g, 1e-4, 1e-5 * float(g.abs().max()) + 1e-8, f"grad[{k}]")
     g = res[False][2]
     close(res[True][2], g, 1e-4, 1e-5 * float(g.abs().max()), "viewspace_points.grad")
+
+
+def test_auxiliary_outputs_are_lazy(hip_device):
+    """render(get_static=True, get_dynamic=True) as the 8 latent sub-frame renders of train.py:512-516 use it
+    (only "render"/"depth" are read): the static / dynamic images are never composited."""
+    import mobgs_amd.gaussian_renderer as GR
+    from mobgs_amd import profiler
+    fx = load("render_train")
+    cam, stat, dyn, bg, _ = scene_from_fixture(fx, device=hip_device)
+    profiler.enable(True)
+    try:
+        out = GR.render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True)
+        (out["render"].sum() + out["depth"].sum()).backward()
+        assert "raster_layers_fwd" not in profiler.summary()
+        assert dict.__getitem__(out, "s_render") is GR._PENDING and "s_render" in out and len(out) == 22
+        s_render = out["s_render"]  # first access: one layered pass produces all five auxiliary images
+        assert profiler.summary()["raster_layers_fwd"]["calls"] == 1
+        assert torch.is_tensor(out["d_alpha"]) and torch.is_tensor(out["d_render"]) and torch.is_tensor(out["s_alpha"])
+        assert profiler.summary()["raster_layers_fwd"]["calls"] == 1
+        close(s_render, fx["out_s_render"], 0, 3e-5, "s_render", flip_frac=2e-3, flip_atol=0.01)
+    finally:
+        profiler.enable(False)
