@@ -15,7 +15,8 @@
  *   - every pointer is a DEVICE pointer unless the name ends in _host;
  *   - the caller owns every buffer (outputs and scratch); the library never allocates device memory and
  *     keeps no mutable global state apart from the thread-local last-error string;
- *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises, except
+ *     mobgs_project_and_bin (one documented read-back);
  *   - return value: 0 on success, negative MOBGS_E_* on failure (mobgs_last_error() gives the text);
  *   - tensors are row-major contiguous float32 / int32 exactly as gsplat lays them out
  *     (means [N,3], quats [N,4] wxyz, scales [N,3], viewmats [C,4,4] world->camera, Ks [C,3,3],
@@ -38,6 +39,7 @@ extern "C" {
 #define MOBGS_E_INVALID (-1)   /* bad argument (size, channel count, null pointer)            */
 #define MOBGS_E_LAUNCH (-2)    /* hipLaunchKernel / hipMemsetAsync reported an error           */
 #define MOBGS_E_UNSUPPORTED (-3)
+#define MOBGS_E_CAPACITY (-4)   /* a caller-owned arena is too small; required sizes were reported         */
 
 #define MOBGS_TILE 16
 #define MOBGS_MAX_CHANNELS 32
@@ -106,6 +108,23 @@ int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int capacity, in
                           int64_t max_tile_len, const float* depths, const int32_t* cum_tiles,
                           const int32_t* tile_offsets, const void* offsets_scratch, uint64_t* sort_keys,
                           int32_t* flatten_ids, uint64_t* isect_ids, void* stream);
+
+/* ---- K1 + K3-K5 in one call: projection -> offsets (+ reach test) -> read-back -> emit -> per-tile sort ------
+ * Same stages and buffers as mobgs_project_fwd + mobgs_isect_offsets + mobgs_isect_emit_sort, driven natively so
+ * that no host gap separates the ~12 short kernels.  Arena: keep_scan [capacity_box+1], scratch
+ * (mobgs_isect_scratch_bytes(C*N, C*n_tiles, capacity_box)), flatten_ids [capacity_listed], sort_keys
+ * [capacity_listed], isect_ids [capacity_listed] or NULL.  stats_dev: 3 x int64 device scratch; stats_host: 3 x int64
+ * HOST output {I_box, I_listed, longest list}.  Returns MOBGS_E_CAPACITY (stats_host valid, nothing written past
+ * the arena) when I_box > capacity_box or I_listed > capacity_listed: grow and call again.  This function
+ * synchronises `stream` once (the intersection-count read-back that upstream gsplat also performs). */
+int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, const float* scales,
+                          const float* viewmats, const float* Ks, const float* opacities, int opac_per_camera,
+                          int width, int height, float eps2d, float near_plane, float far_plane,
+                          float radius_clip, int cull, int32_t* radii, float* means2d, float* depths,
+                          float* conics, int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* tile_offsets,
+                          int64_t* stats_dev, int capacity_box, int32_t* keep_scan, void* scratch,
+                          int64_t capacity_listed, int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
+                          int64_t* stats_host, void* stream);
 
 /* ---- K6: rasterise forward (replaces gsplat rasterize_to_pixels fwd) -----------------------------------
  * colors   : [C,N,channels] (colors_per_camera=1) or [N,channels] (0)

@@ -33,6 +33,8 @@ _SIGS = {
                                  P, P, P, P]),
     "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int] + [P] * 13 + [P]),
     "mobgs_raster_bwd_reduce": (c_int, [c_int, c_int, c_int, c_int] + [P] * 8 + [P]),
+    "mobgs_project_and_bin": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
+                                      c_float, c_int, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, P, P, P]),
     "mobgs_pack_records": (c_int, [c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P]),
     "mobgs_raster_layers_fwd": (c_int, [c_int] * 7 + [P] * 7 + [P]),
     "mobgs_raster_layers_bwd": (c_int, [c_int] * 8 + [P] * 19 + [P]),  # incl. 7 host pointer arrays of length 3

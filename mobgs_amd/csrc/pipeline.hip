@@ -1,0 +1,48 @@
+// Native orchestration of the first half of a rasterization: projection -> intersection offsets (+ reach test)
+// -> [one 24-byte read-back] -> emit -> per-tile depth sort, as ONE C call.
+//
+// The stages are the same entry points a caller can drive one by one (mobgs_project_fwd, mobgs_isect_offsets,
+// mobgs_isect_emit_sort); doing it here removes the host gaps a Python driver leaves between ~12 short kernels
+// (allocation + ctypes + launch, 10-40 us each while the GPU idles -- profiles/r01: 0.2 ms of a 1.9 ms step).
+// Buffers whose size depends on the intersection count live in a caller-owned arena sized from the previous call;
+// when it is too small the function returns MOBGS_E_CAPACITY with the required sizes in `stats_host` and has
+// written nothing past the arena.
+#include "common.h"
+
+using namespace mobgs;
+
+extern "C" {
+
+int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, const float* scales,
+                          const float* viewmats, const float* Ks, const float* opacities, int opac_per_camera,
+                          int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                          int cull, int32_t* radii, float* means2d, float* depths, float* conics,
+                          int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* tile_offsets, int64_t* stats_dev,
+                          int capacity_box, int32_t* keep_scan, void* scratch, int64_t capacity_listed,
+                          int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids, int64_t* stats_host,
+                          void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
+    int rc = mobgs_project_fwd(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                               radius_clip, radii, means2d, depths, conics, tiles_per_gauss, stream);
+    if (rc != MOBGS_OK) return rc;
+    rc = mobgs_isect_offsets(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d, radii,
+                             conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, stats_dev, scratch,
+                             stream);
+    if (rc != MOBGS_OK) return rc;
+    // the pipeline's one host synchronisation (upstream gsplat has the same one): {I_box, I_listed, longest list}
+    if (hipMemcpyAsync(stats_host, stats_dev, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        set_error("mobgs_project_and_bin: statistics read-back failed: %s", hipGetErrorString(hipGetLastError()));
+        return MOBGS_E_LAUNCH;
+    }
+    if (stats_host[0] > (int64_t)capacity_box || stats_host[1] > capacity_listed) {
+        set_error("mobgs_project_and_bin: arena too small (box %lld > %d or listed %lld > %lld)",
+                  (long long)stats_host[0], capacity_box, (long long)stats_host[1], (long long)capacity_listed);
+        return MOBGS_E_CAPACITY;
+    }
+    return mobgs_isect_emit_sort(C, N, tile_w, tile_h, capacity_box, stats_host[1], stats_host[2], depths, cum_tiles,
+                                 tile_offsets, scratch, sort_keys, flatten_ids, isect_ids, stream);
+}
+
+}  // extern "C"

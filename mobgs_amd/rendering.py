@@ -340,6 +340,71 @@ class _RasterizeLayers(torch.autograd.Function):
                 None, None, None)
 
 
+_cap_listed = {}  # device index -> capacity of the listed-intersection buffers
+
+
+class _ProjectAndBin(torch.autograd.Function):
+    """Projection + tile lists through the native orchestrator mobgs_project_and_bin (one C call, one read-back).
+    The TileLists object passed in `tl` is filled as a side effect; backward is the projection backward."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, viewmats, Ks, opacities, tl, width, height, eps2d, near_plane, far_plane,
+                radius_clip, want_isect_ids):
+        import ctypes
+        lib = _lib_()
+        means, quats, scales, viewmats, Ks, opac = map(f32c, (means, quats, scales, viewmats, Ks, opacities))
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        tile_w, tile_h = math.ceil(width / TILE), math.ceil(height / TILE)
+        nt = C * tile_w * tile_h
+        radii = torch.empty(C, N, dtype=torch.int32, device=dev)
+        means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(C, N, dtype=torch.float32, device=dev)
+        conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
+        cum_tiles = torch.empty(C * N + 1, dtype=torch.int32, device=dev)
+        tile_offsets = torch.empty(nt + 1, dtype=torch.int32, device=dev)
+        stats_dev = torch.empty(3, dtype=torch.int64, device=dev)
+        stats_host = (ctypes.c_int64 * 3)()
+        key = dev.index if dev.index is not None else -1
+        cap_box = max(_capacity.get(key, 0), 16 * (C * N) + 1024)
+        cap_listed = max(_cap_listed.get(key, 0), cap_box // 2)
+        while True:
+            keep_scan = torch.empty(cap_box + 1, dtype=torch.int32, device=dev)
+            scratch = torch.empty(lib.mobgs_isect_scratch_bytes(C * N, nt, cap_box), dtype=torch.uint8, device=dev)
+            flatten_ids = torch.empty(cap_listed, dtype=torch.int32, device=dev)
+            sort_keys = torch.empty(cap_listed, dtype=torch.int64, device=dev)
+            isect_ids = torch.empty(cap_listed, dtype=torch.int64, device=dev) if want_isect_ids else None
+            rc = lib.mobgs_project_and_bin(C, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), ptr(opac),
+                                           1 if opac.dim() == 2 else 0, width, height, eps2d, near_plane, far_plane,
+                                           radius_clip, int(_tile_culling), ptr(radii), ptr(means2d), ptr(depths),
+                                           ptr(conics), ptr(tiles_per_gauss), ptr(cum_tiles), ptr(tile_offsets),
+                                           ptr(stats_dev), cap_box, ptr(keep_scan), ptr(scratch), cap_listed,
+                                           ptr(flatten_ids), ptr(sort_keys), ptr(isect_ids), stats_host, stream())
+            if rc != -4:  # MOBGS_E_CAPACITY: grow the arena (first call on a denser scene) and redo
+                check(rc, "mobgs_project_and_bin")
+                break
+            cap_box = max(cap_box, int(stats_host[0] * 1.25) + 1024)
+            cap_listed = max(cap_listed, int(stats_host[1] * 1.25) + 1024)
+        _capacity[key], _cap_listed[key] = cap_box, cap_listed
+        n_box, n_isects, max_len = int(stats_host[0]), int(stats_host[1]), int(stats_host[2])
+        tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
+        tl.n_box, tl.n_isects, tl.max_tile_len = n_box, n_isects, max_len
+        tl.cum_tiles, tl.keep_scan, tl.tile_offsets = cum_tiles, keep_scan, tile_offsets
+        tl.flatten_ids = flatten_ids[:n_isects]
+        tl.isect_ids = isect_ids[:n_isects] if isect_ids is not None else None
+        last_stats.update(n_isects=n_isects, n_box=n_box, max_tile_len=max_len, n_tiles=nt)
+        ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics)
+        ctx.dims = (width, height, eps2d)
+        ctx.mark_non_differentiable(radii, tiles_per_gauss)
+        return radii, means2d, depths, conics, tiles_per_gauss
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tpg):
+        grads = _Project.backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tpg)
+        return grads[0], grads[1], grads[2], grads[3], None, None, None, None, None, None, None, None, None, None
+
+
 class SharedProjection:
     """One projection + one tile binning/sort of a splat set, reusable by several compositing passes of the same
     camera (`composite` = the usual single-set pass, `composite_layers` = static-only / dynamic-only layers)."""
@@ -349,12 +414,10 @@ class SharedProjection:
         self.width, self.height = int(width), int(height)
         self.C, self.N = viewmats.shape[0], means.shape[0]
         self.opacities = opacities
-        (self.radii, self.means2d, self.depths, self.conics, self.tiles_per_gauss) = _Project.apply(
-            means, quats, scales, viewmats, Ks, self.width, self.height, float(eps2d), float(near_plane),
-            float(far_plane), float(radius_clip))
-        self.tl = build_tile_lists(self.means2d.detach(), self.radii, self.depths.detach(), self.conics.detach(),
-                                   opacities.detach(), self.tiles_per_gauss, self.width, self.height,
-                                   want_isect_ids=want_isect_ids)
+        self.tl = TileLists()
+        (self.radii, self.means2d, self.depths, self.conics, self.tiles_per_gauss) = _ProjectAndBin.apply(
+            means, quats, scales, viewmats, Ks, opacities.detach(), self.tl, self.width, self.height, float(eps2d),
+            float(near_plane), float(far_plane), float(radius_clip), bool(want_isect_ids))
         # autograd alias used by composite() and exposed as meta["means2d"] / viewspace_points: its .grad is the
         # position gradient of the whole-set render alone (the reference's static / dynamic passes have their own,
         # un-retained means2d tensors, gaussian_renderer/__init__.py:218-223)
