@@ -76,13 +76,32 @@ def _device_of(pc):
     return pc.get_xyz.device
 
 
+_time_cache = {}
+
+
 def _times(cam, delta_exposure, dev):
-    """[t_feat, t_curve] on the device, without a host sync when delta_exposure is a device tensor."""
-    t = torch.as_tensor(float(cam.time), dtype=torch.float32, device=dev)
-    if delta_exposure is not None:
-        d = delta_exposure if torch.is_tensor(delta_exposure) else torch.as_tensor(float(delta_exposure))
-        t = t + d.detach().to(device=dev, dtype=torch.float32).reshape(()) / cam.max_time
-    return torch.stack([t, torch.clamp(t, 0.0, 1.0)])
+    """[t_feat, t_curve] on the device.  No host->device copy on the hot path (a pageable H2D copy blocks the
+    host until the stream drains, which serialises consecutive render() calls): constants are cached per value,
+    a device-resident delta_exposure (BLCE exposure offset) is combined with device ops only."""
+    def const(t):
+        key = (str(dev), float(t))
+        v = _time_cache.get(key)
+        if v is None:
+            if len(_time_cache) > 4096:
+                _time_cache.clear()
+            v = torch.tensor([float(t), min(max(float(t), 0.0), 1.0)], dtype=torch.float32, device=dev)
+            _time_cache[key] = v
+        return v
+
+    if delta_exposure is None:
+        return const(cam.time)
+    if torch.is_tensor(delta_exposure) and delta_exposure.is_cuda:
+        t = const(cam.time)[0] + delta_exposure.detach().to(torch.float32).reshape(()) / cam.max_time
+        return torch.stack([t, torch.clamp(t, 0.0, 1.0)])
+    d = float(delta_exposure)
+    # same float32 arithmetic as the reference's tensor expression time + delta / max_time
+    t32 = torch.tensor(float(cam.time), dtype=torch.float32) + torch.tensor(d, dtype=torch.float32) / cam.max_time
+    return const(float(t32))
 
 
 def _prep(stat_pc, dyn_pc, times):
