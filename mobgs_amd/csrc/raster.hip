@@ -5,9 +5,11 @@
 // /root/reference/gaussian_renderer/__init__.py:143,163,201,236,255,274,379,437,456,473,538.
 //
 // MI355X mapping (not upstream's 256-thread block per tile):
-//   * one 64-lane wavefront owns one 16x16 tile; every lane carries 4 pixels (rows r, r+4, r+8, r+12 of
-//     column lane&15), so per-splat uniform work (record fetch, loop control, early-out votes) is amortised
-//     over 256 pixel evaluations and no workgroup barrier exists anywhere in the kernels;
+//   * one 64-lane wavefront owns one 16x16 tile; every lane carries 4 pixels -- the same (lane&7, lane>>3)
+//     position in each of the four 8x8 QUADRANTS of the tile -- so per-splat uniform work (record fetch, loop
+//     control, early-out votes) is amortised over 256 pixel evaluations and no workgroup barrier exists anywhere
+//     in the kernels.  Quadrants rather than 16x4 strips: a splat's footprint is a compact blob, so it usually
+//     misses whole quadrants (their code is skipped by a wave-level branch) and fills the ones it hits;
 //   * splats are staged 64 at a time (lane = splat) as packed 16-float records
 //     {x, y, conic a b c, opacity, colour[..]} into a per-wave LDS slab and re-read as broadcasts;
 //   * backward reduces the 6+D per-splat gradient components across the wave with a halving butterfly
@@ -104,15 +106,16 @@ raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
     const int cam = tile / tiles_per_cam;
     const int tl = tile - cam * tiles_per_cam;
     const int ty = tl / tile_w, tx = tl - ty * tile_w;
-    const int pxi = tx * MOBGS_TILE + (lane & 15);
-    const int pyi0 = ty * MOBGS_TILE + (lane >> 4);
-    const float px = (float)pxi + 0.5f;
-    float py[PPL];
+    int pxi[PPL], pyi[PPL];
+    float px[PPL], py[PPL];
     unsigned done = 0;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
-        py[k] = (float)(pyi0 + 4 * k) + 0.5f;
-        if (!(pxi < width && (pyi0 + 4 * k) < height)) done |= 1u << k;
+        pxi[k] = tx * MOBGS_TILE + 8 * (k & 1) + (lane & 7);
+        pyi[k] = ty * MOBGS_TILE + 8 * (k >> 1) + (lane >> 3);
+        px[k] = (float)pxi[k] + 0.5f;
+        py[k] = (float)pyi[k] + 0.5f;
+        if (!(pxi[k] < width && pyi[k] < height)) done |= 1u << k;
     }
     const unsigned outside = done;
 
@@ -160,7 +163,7 @@ raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
             bool any = false;
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
-                const Eval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, px, py[k]);
+                const Eval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, px[k], py[k]);
                 const bool pass = ev.pass && !((done >> k) & 1u);
                 alpha[k] = ev.alpha;
                 nT[k] = T[k] * (1.f - ev.alpha);
@@ -199,7 +202,7 @@ raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
         if ((outside >> k) & 1u) continue;
-        const size_t pix = ((size_t)cam * height + (pyi0 + 4 * k)) * width + pxi;
+        const size_t pix = ((size_t)cam * height + pyi[k]) * width + pxi[k];
         alphas[pix] = 1.f - T[k];
         last_ids[pix] = last[k];
         float* out = render + pix * CD;
@@ -278,9 +281,6 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
     const int cam = tile / tiles_per_cam;
     const int tl = tile - cam * tiles_per_cam;
     const int ty = tl / tile_w, tx = tl - ty * tile_w;
-    const int pxi = tx * MOBGS_TILE + (lane & 15);
-    const int pyi0 = ty * MOBGS_TILE + (lane >> 4);
-    const float px = (float)pxi + 0.5f;
 
     const int s = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
     const int e = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
@@ -289,13 +289,15 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
     // behind[k] = sum over the splats BEHIND the current one of fac * <colour, v_out>: upstream keeps the
     // per-channel sums buffer[c] and forms sum_c (colour_c T - buffer_c ra) v_out_c; distributing v_out gives
     // T <colour, v_out> - ra * behind, one scalar per pixel instead of D (fewer registers, D fewer FMAs per pair)
-    float py[PPL], T[PPL], Tf[PPL], va[PPL], bgdot[PPL], behind[PPL];
+    float px[PPL], py[PPL], T[PPL], Tf[PPL], va[PPL], bgdot[PPL], behind[PPL];
     float vo[PPL][CD];
     int binf[PPL];
     int top = -1;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
-        const int pyi = pyi0 + 4 * k;
+        const int pxi = tx * MOBGS_TILE + 8 * (k & 1) + (lane & 7);
+        const int pyi = ty * MOBGS_TILE + 8 * (k >> 1) + (lane >> 3);
+        px[k] = (float)pxi + 0.5f;
         py[k] = (float)pyi + 0.5f;
         const bool inside = pxi < width && pyi < height;
         binf[k] = -1;  // pixels outside the image never become valid
@@ -355,7 +357,7 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
             bool any = false;
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
-                ev[k] = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px, py[k]);
+                ev[k] = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px[k], py[k]);
                 ev[k].pass = ev[k].pass && (idx <= binf[k]);
                 any = any || ev[k].pass;
             }
