@@ -1,0 +1,118 @@
+"""Full-size checks on the GPU (BASELINE config #2: 300k splats, 1352x1014; config #5 scale: 800k splats).
+
+Direct comparison with the C oracle at full size (it finishes in seconds on the GPU box's host cores) plus
+size-independent properties: sorted lists, linearity in the colours, culling on/off identity, fp16 attribute storage.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import close, psnr
+from mobgs_amd.synth import SynthCamera, splat_inputs
+
+pytestmark = pytest.mark.gpu
+W, H = 1352, 1014
+
+
+@pytest.fixture(scope="module")
+def scene300k():
+    cam = SynthCamera()
+    return splat_inputs(300_000, cam, 0, 9), cam
+
+
+def _run(s, dev, mode="RGB+ED", bg=None, grads=False, colors=None):
+    from mobgs_amd.rendering import rasterization
+    names = ["means", "quats", "scales", "opacities", "colors", "viewmats"]
+    t = {k: v.to(dev).clone().requires_grad_(grads and k in names) for k, v in s.items()}
+    if colors is not None:
+        t["colors"] = colors.to(dev)
+    img, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], t["viewmats"],
+                                 t["Ks"], W, H, packed=False, backgrounds=bg, render_mode=mode)
+    return t, img, a, meta
+
+
+def test_fullsize_forward_backward_against_c_oracle(hip_device, scene300k):
+    from oracle import gsplat_cpu as Cc
+    s, _ = scene300k
+    g = torch.Generator().manual_seed(100)
+    v_img = torch.randn(1, H, W, 10, generator=g)
+    t, img, a, meta = _run(s, hip_device, grads=True, bg=torch.zeros(1, 9, device=hip_device))
+    meta["means2d"].retain_grad()
+    (img * v_img.to(hip_device)).sum().backward()
+    r = Cc.rasterization_fwd_bwd(*(s[k].numpy() for k in ["means", "quats", "scales", "opacities", "colors",
+                                                          "viewmats", "Ks"]), W, H,
+                                 backgrounds=np.zeros((1, 9), np.float32), render_mode="RGB+ED",
+                                 v_render=v_img.numpy())
+    # a handful of splats out of 300 000 sit within an ulp of a discrete decision (3-sigma radius ceil, image-border
+    # cull) and fall on the other side when the projection is contracted into FMAs differently
+    rad = meta["radii"].cpu().numpy().astype(np.int64)
+    ref_rad = r["radii"].astype(np.int64)
+    differ = rad != ref_rad
+    assert differ.sum() <= 30, int(differ.sum())
+    both = differ & (rad > 0) & (ref_rad > 0)
+    assert np.abs(rad - ref_rad)[both].max(initial=0) <= 1
+    ref = torch.from_numpy(r["render"])
+    scale = float(ref.abs().max())
+    close(img, ref, 0, 3e-5 * scale, "image", flip_frac=2e-3, flip_atol=scale / 50)
+    target = (ref[..., :9] / scale + 0.05 * torch.randn(ref[..., :9].shape, generator=g))
+    assert abs(psnr(img[..., :9].cpu() / scale, target) - psnr(ref[..., :9] / scale, target)) <= 1e-4
+    for k, ck in [("means", "v_means"), ("quats", "v_quats"), ("scales", "v_scales"), ("opacities", "v_opacities"),
+                  ("colors", "v_colors"), ("viewmats", "v_viewmats")]:
+        refg = torch.from_numpy(r[ck])
+        sc = float(refg.abs().max())
+        close(t[k].grad, refg, 2e-3, 1e-4 * sc, f"grad[{k}]", flip_frac=1e-3, flip_atol=0.05 * sc)
+
+
+def test_fullsize_lists_are_sorted_and_complete(hip_device, scene300k):
+    s, _ = scene300k
+    _, _, _, meta = _run(s, hip_device, mode="RGB")
+    ids = meta["isect_ids"]
+    assert bool((ids[1:] >= ids[:-1]).all()), "isect_ids (tile | depth bits) must be non-decreasing"
+    flat = meta["flatten_ids"].long()
+    depth_bits = meta["depths"].reshape(-1)[flat].view(torch.int32).long()
+    assert torch.equal(ids & 0xFFFFFFFF, depth_bits)
+    same = ids[1:] == ids[:-1]
+    assert bool((flat[1:][same] > flat[:-1][same]).all()), "equal keys must be ordered by splat index"
+    offs = meta["isect_offsets"].reshape(-1).long()
+    tile = ids >> 32
+    assert torch.equal(torch.searchsorted(tile.contiguous(), torch.arange(offs.numel(), device=ids.device)), offs)
+
+
+def test_fullsize_linearity_in_colours_and_culling_identity(hip_device, scene300k):
+    from mobgs_amd import rendering
+    s, _ = scene300k
+    g = torch.Generator().manual_seed(5)
+    c1, c2 = torch.randn(300_000, 3, generator=g), torch.randn(300_000, 3, generator=g)
+    imgs = {}
+    for name, c in (("a", c1), ("b", c2), ("ab", c1 + c2)):
+        imgs[name] = _run(s, hip_device, mode="RGB", colors=c)[1]
+    close(imgs["ab"], imgs["a"] + imgs["b"], 1e-5, 2e-5 * float(imgs["ab"].abs().max()), "linearity")
+    rendering.set_tile_culling(False)
+    try:
+        full = _run(s, hip_device, mode="RGB", colors=c1)[1]
+    finally:
+        rendering.set_tile_culling(True)
+    assert torch.equal(full, imgs["a"]), "reach culling changed pixels"
+
+
+def test_fp16_attribute_storage(hip_device, scene300k):
+    """BASELINE config #5 stores Gaussian attributes in fp16 (no such mode exists in the reference): inputs of any
+    float dtype are widened on load, compute stays fp32.  Reported, not a parity bar: PSNR vs the fp32 render."""
+    s, _ = scene300k
+    ref = _run(s, hip_device, mode="RGB", colors=torch.sigmoid(s["colors"][:, :3]))[1]
+    s16 = {k: (v.half() if k in ("quats", "scales", "opacities", "colors") else v) for k, v in s.items()}
+    s16["colors"] = torch.sigmoid(s["colors"][:, :3]).half()
+    img = _run(s16, hip_device, mode="RGB", colors=s16["colors"])[1]
+    p = psnr(img.cpu(), ref.cpu())
+    print(f"fp16-attribute render vs fp32: {p:.1f} dB")
+    assert p > 40.0
+
+
+def test_800k_gaussians_config5_scale(hip_device):
+    from mobgs_amd.gaussian_renderer import render
+    import bench as B
+    scam, cam, stat, dyn, _ = B.build_scene(hip_device, 533_000, 267_000, W, H, seed=1)
+    out = render(cam, stat, dyn, None, torch.zeros(9, device=hip_device))
+    (out["render"].sum() + out["depth"].sum()).backward()
+    assert torch.isfinite(out["render"]).all() and torch.isfinite(stat._xyz.grad).all()
+    assert int((out["radii"] > 0).sum()) > 700_000
