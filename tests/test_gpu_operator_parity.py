@@ -219,3 +219,48 @@ def test_long_tile_lists_sort_exactly(hip_device, n, w, h, scale):
     assert torch.equal(meta["isect_offsets"].cpu().reshape(-1), torch.from_numpy(eoffs).reshape(-1))
     assert torch.equal(meta["flatten_ids"].cpu(), torch.from_numpy(flat)), f"order differs (longest {longest})"
     assert torch.equal(meta["isect_ids"].cpu(), torch.from_numpy(ids))
+
+
+def test_two_cameras_forward_backward(hip_device):
+    """C = 2 cameras in one call (gsplat's batched-camera form): lists, images and all gradients incl. both viewmats."""
+    from mobgs_amd import rendering
+    from mobgs_amd.rendering import rasterization
+    from oracle import gsplat_torch as G
+    n, w, h = 1800, 104, 72
+    s, _ = _scene(n, w, h, 6, 3)
+    vm = torch.eye(4)[None].repeat(2, 1, 1)
+    ang = 0.06
+    vm[1, :3, :3] = torch.tensor([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
+    vm[1, :3, 3] = torch.tensor([0.1, 0.03, 0.2])
+    s["viewmats"] = vm
+    s["Ks"] = s["Ks"].repeat(2, 1, 1)
+    bg = torch.rand(2, 3, generator=torch.Generator().manual_seed(2))
+    names = ["means", "quats", "scales", "opacities", "colors", "viewmats"]
+
+    def run(fn, dev):
+        t = {k: v.to(dev).clone().requires_grad_(k in names) for k, v in s.items()}
+        img, a, meta = fn(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], t["viewmats"], t["Ks"],
+                          w, h, packed=False, backgrounds=bg.to(dev), render_mode="RGB+ED")
+        g = torch.Generator().manual_seed(7)
+        v_img = torch.randn(img.shape, generator=g).to(dev)
+        v_a = torch.randn(a.shape, generator=g).to(dev)
+        ((img * v_img).sum() + (a * v_a).sum()).backward()
+        return img.detach().cpu(), a.detach().cpu(), meta, {k: t[k].grad.cpu() for k in names}
+
+    ref = run(G.rasterization, torch.device("cpu"))
+    rendering.set_tile_culling(False)
+    try:
+        out = run(rasterization, hip_device)
+    finally:
+        rendering.set_tile_culling(True)
+    assert out[0].shape == (2, h, w, 4)
+    for key in ("radii", "tiles_per_gauss", "flatten_ids", "isect_offsets", "isect_ids"):
+        assert torch.equal(out[2][key].cpu(), ref[2][key]), key
+    scale = float(ref[0].abs().max())
+    close_ = lambda a, b, what, tol: _close(a, b, 0, tol, what, flip_frac=2e-3, flip_atol=scale / 50)  # noqa: E731
+    close_(out[0], ref[0], "image", 3e-5 * scale)
+    close_(out[1], ref[1], "alpha", 3e-5)
+    for k in names:
+        sc = float(ref[3][k].abs().max())
+        _close(out[3][k], ref[3][k], 1e-3, 5e-4 * sc + 1e-6, f"grad[{k}]")
+    assert float(out[3]["viewmats"][1].abs().max()) > 0 and float(out[3]["viewmats"][0].abs().max()) > 0
