@@ -79,8 +79,8 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
  * cull = 0: every bounding-box intersection is listed -- exactly upstream's lists.
  * cull = 1: a (tile, splat) pair is listed only if the splat can reach alpha >= 1/255 somewhere on the tile's
  *      pixel rectangle (min over the rectangle of sigma <= ln(255*opacity), conservative margin).  Pairs that
- *      fail are skipped by the compositor at all 256 pixels anyway, so every output pixel and gradient is
- *      unchanged; lists, sort and gradient slots shrink (about 2x on anisotropic scenes).
+ *      fail are skipped by the compositor at all 256 pixels anyway, so every output pixel is bit-identical and every
+ *      gradient keeps exactly its non-zero terms; lists, sort and gradient slots shrink (about 2x on anisotropic scenes).
  * out: cum_tiles [C*N+1] exclusive prefix sum of the BOX counts (cum_tiles[C*N] = I_box)
  *      keep_scan [capacity+1] exclusive prefix sum of the keep flags over the box intersections:
  *                box intersection j is listed iff keep_scan[j+1] > keep_scan[j]; its compact index (= its

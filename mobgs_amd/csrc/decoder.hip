@@ -188,7 +188,7 @@ using namespace mobgs;
 extern "C" {
 
 static int decoder_grid(int P) {
-    int g = (P + DEC_THREADS * 8 - 1) / (DEC_THREADS * 8);  // ~8 pixels per thread
+    int g = (P + DEC_THREADS * 8 - 1) / (DEC_THREADS * 8);  // ~8 pixels per thread (fewer waves = fewer 90-value end reductions)
     if (g < 1) g = 1;
     if (g > 1024) g = 1024;
     return g;

@@ -14,7 +14,7 @@
 // Reach culling (optional, on by default in the host wrapper): upstream lists a splat in every tile its
 // 3-sigma bounding BOX touches.  A (tile, splat) pair whose smallest possible sigma over the tile's pixel
 // rectangle already exceeds ln(255 * opacity) cannot reach alpha >= 1/255 at any pixel of the tile, so the
-// compositor would skip it at all 256 pixels; dropping the pair from the list leaves every pixel bit-identical
+// compositor would skip it at all 256 pixels; dropping the pair from the list leaves every pixel bit-identical (gradients: same terms)
 // and removes ~half of the intersections on anisotropic scenes.  The test is conservative (margin on the
 // threshold); with culling off the lists are exactly upstream's.
 #include "common.h"

@@ -431,8 +431,19 @@ slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, const i
     const int a = keep_scan[cum_tiles[gid]], b = keep_scan[cum_tiles[gid + 1]];
     float acc = 0.f;
     if (comp < stride) {
+        // 4 independent partial sums keep 4 loads in flight per lane (the loop is latency-bound otherwise);
+        // fixed association order -> still deterministic
         const float* p = grad_slots + (size_t)a * stride + comp;
-        for (int k = a; k < b; ++k, p += stride) acc += *p;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = a;
+        for (; k + 4 <= b; k += 4, p += 4 * stride) {
+            s0 += p[0];
+            s1 += p[stride];
+            s2 += p[2 * stride];
+            s3 += p[3 * stride];
+        }
+        for (; k < b; ++k, p += stride) s0 += *p;
+        acc = (s0 + s1) + (s2 + s3);
     }
     const size_t g = (size_t)gid;
     if (comp < 2)

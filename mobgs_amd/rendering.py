@@ -118,7 +118,7 @@ _capacity = {}  # device index -> current capacity of the keep-flag buffer (grow
 
 def set_tile_culling(flag: bool) -> None:
     """True (default): a splat is listed in a tile only if it can reach alpha >= 1/255 there -- pixels and gradients
-    are bit-identical, `meta["flatten_ids" / "isect_ids" / "isect_offsets"]` are then a subset of gsplat's lists.
+    are bit-identical (gradients equal up to summation order), `meta["flatten_ids" / "isect_ids" / "isect_offsets"]` are then a subset of gsplat's lists.
     False: lists are exactly gsplat's (every tile the 3-sigma bounding box touches)."""
     global _tile_culling
     _tile_culling = bool(flag)

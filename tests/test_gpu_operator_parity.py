@@ -154,8 +154,9 @@ def test_rasterization_backward(hip_device, mode, channels, use_bg):
 
 @pytest.mark.parametrize("mode,channels", [("RGB+ED", 9), ("RGB", 2)])
 def test_tile_culling_is_bit_exact(hip_device, mode, channels):
-    """Reach culling drops only (tile, splat) pairs the compositor skips at every pixel: images AND gradients are
-    bit-identical to the un-culled run, the culled lists are ordered sub-sequences of upstream's."""
+    """Reach culling drops only (tile, splat) pairs the compositor skips at every pixel: images are bit-identical
+    to the un-culled run, gradients consist of the same non-zero terms (equal up to fp32 summation order), the
+    culled lists are ordered sub-sequences of upstream's."""
     from mobgs_amd import rendering
     from mobgs_amd.rendering import rasterization
     n, w, h = 6000, 200, 152
@@ -177,8 +178,9 @@ def test_tile_culling_is_bit_exact(hip_device, mode, channels):
         finally:
             rendering.set_tile_culling(True)
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
-    for k in names:
-        assert torch.equal(res[True][2][k], res[False][2][k]), f"grad[{k}] changed under culling"
+    for k in names:  # same terms; the per-splat slot sum associates them differently once the zero slots are gone
+        g = res[False][2][k]
+        _close(res[True][2][k], g, 1e-5, 1e-6 * float(g.abs().max()), f"grad[{k}] under culling")
     n_full, n_cull = res[False][3].numel(), res[True][3].numel()
     assert n_cull < 0.8 * n_full, (n_cull, n_full)
     # per tile: the culled list is a sub-sequence (same order) of the full list
