@@ -219,16 +219,21 @@ int mobgs_prep_bwd(int Ns, int Nd, const float* times, const int64_t* d_ncp, con
 /* ---- K9: colour decoder + expected-depth normalisation (replaces Sandwich.forward + gsplat's "ED" step) ---
  * /root/reference/helper_model.py:19-28; /root/reference/gaussian_renderer/__init__.py:216-227.
  * feat_hw [P,CF] channels-last compositor output (CF >= 9; channel 9 = accumulated depth when has_depth),
- * alphas [P], rays [6,P] planar (cam_ray), w1 [6,12], w2 [3,6]  ->  rgb [3,P] planar, depth [P]. */
-int mobgs_decoder_fwd(int P, int CF, int has_depth, const float* feat_hw, const float* alphas,
-                      const float* rays, const float* w1, const float* w2, float* rgb, float* depth,
-                      void* stream);
-/* w_partial: scratch [mobgs_decoder_bwd_blocks(P), 90] floats.  v_depth / v_rays may be NULL. */
+ * alphas [P], w1 [6,12], w2 [3,6]  ->  rgb [3,P] planar, depth [P].
+ * Camera rays, one of:
+ *   rays   [6,P] planar (the reference's cam_ray map, /root/reference/scene/cameras.py:132-146), raycam = NULL;
+ *   rays = NULL, raycam = device float[16] {fx, fy, cx, cy, c2w row-major 3x4}, width = image width: the origin
+ *          and the unit view direction through each pixel centre are generated in registers. */
+int mobgs_decoder_fwd(int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
+                      const float* rays, const float* raycam, const float* w1, const float* w2, float* rgb,
+                      float* depth, void* stream);
+/* w_partial: scratch [mobgs_decoder_bwd_blocks(P), 102] floats.  v_depth / v_rays may be NULL.
+ * g_c2w (float[12], may be NULL): gradient of the c2w entries of raycam (in-kernel-ray mode only). */
 int mobgs_decoder_bwd_blocks(int P);
-int mobgs_decoder_bwd(int P, int CF, int has_depth, const float* feat_hw, const float* alphas,
-                      const float* rays, const float* w1, const float* w2, const float* v_rgb,
-                      const float* v_depth, float* v_feat_hw, float* v_alphas, float* v_rays, float* w_partial,
-                      float* g_w1, float* g_w2, void* stream);
+int mobgs_decoder_bwd(int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
+                      const float* rays, const float* raycam, const float* w1, const float* w2,
+                      const float* v_rgb, const float* v_depth, float* v_feat_hw, float* v_alphas, float* v_rays,
+                      float* w_partial, float* g_w1, float* g_w2, float* g_c2w, void* stream);
 
 /* ---- K10: deformation network (the API the reference exposes as scene.deformation.deform_network) -----
  * /root/reference/scene/hexplane.py:75-108,165-187 (HexPlane multi-resolution bilinear planes, product over the

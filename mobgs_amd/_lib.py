@@ -40,9 +40,9 @@ _SIGS = {
     "mobgs_raster_layers_bwd": (c_int, [c_int] * 8 + [P] * 19 + [P]),  # incl. 7 host pointer arrays of length 3
     "mobgs_prep_fwd": (c_int, [c_int, c_int] + [P] * 21 + [P]),
     "mobgs_prep_bwd": (c_int, [c_int, c_int] + [P] * 23 + [P]),
-    "mobgs_decoder_fwd": (c_int, [c_int, c_int, c_int] + [P] * 7 + [P]),
+    "mobgs_decoder_fwd": (c_int, [c_int, c_int, c_int, c_int] + [P] * 8 + [P]),
     "mobgs_decoder_bwd_blocks": (c_int, [c_int]),
-    "mobgs_decoder_bwd": (c_int, [c_int, c_int, c_int] + [P] * 13 + [P]),
+    "mobgs_decoder_bwd": (c_int, [c_int, c_int, c_int, c_int] + [P] * 15 + [P]),
     "mobgs_hexplane_fwd": (c_int, [c_int] + [P] * 7 + [P]),
     "mobgs_hexplane_bwd": (c_int, [c_int] + [P] * 10 + [P]),
     "mobgs_deform_mlp_fwd": (c_int, [c_int] + [P] * 13 + [P]),

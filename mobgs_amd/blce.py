@@ -163,7 +163,20 @@ class WarpedCamera:
         self.world_view_transform = w2c.transpose(0, 1)
         self.camera_center = c2w[:3, 3]
         self._w2c = w2c
+        self._c2w = c2w
         self._ray = None
+
+    @property
+    def ray_intrinsics(self):
+        src = self._src
+        if hasattr(src, "ray_intrinsics"):
+            return src.ray_intrinsics
+        K = self.K
+        return torch.stack([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
+
+    @property
+    def ray_c2w(self):  # differentiable: the decoder kernel reduces the ray gradient into these 12 entries
+        return self._c2w[:3, :]
 
     def __getattr__(self, name):  # everything else (K, time, max_time, image, uid, sizes, ...) comes from the source
         return getattr(self._src, name)
@@ -171,7 +184,8 @@ class WarpedCamera:
     @property
     def cam_ray(self):
         if self._ray is None:
-            self._ray = PinholeCamera.build_cam_ray(int(self.image_width), int(self.image_height), self.K, self._w2c)
+            self._ray = PinholeCamera.build_cam_ray_c2w(int(self.image_width), int(self.image_height), self.K,
+                                                        self._c2w)
         return self._ray
 
 

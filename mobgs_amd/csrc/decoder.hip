@@ -6,6 +6,12 @@
 //   gsplat rendering.py "ED" post-process [upstream]      depth = acc_depth / clamp(alpha, 1e-10)
 //   /root/reference/gaussian_renderer/__init__.py:216-227 depth = img[..., -1]; feat = img[..., :-1].permute(0,3,1,2)
 //
+// Camera rays: the reference keeps a [1,6,H,W] map per camera (origin + unit view direction through each pixel
+// centre, /root/reference/scene/cameras.py:132-146) -- 33 MB at 1352x1014, rebuilt for each of the 9 BLCE-warped
+// cameras of a blurry view.  When the caller passes the pinhole parameters instead
+// (`raycam` = {fx, fy, cx, cy, c2w[3][4]}, `rays` = NULL) the rays are generated in registers and the backward
+// pass reduces their gradient straight into the 12 entries of c2w.
+//
 // One thread per pixel; the 90 weights live in SGPRs (wave-uniform, scalar loads).  Reads the compositor's
 // channels-last image [H,W,10] (one 40-byte row per lane), the planar ray map [6,H,W] and writes planar rgb
 // [3,H,W] + depth [H,W]: every access is a unit-stride stream.  HBM-bound: 68 B read + 16 B written per pixel.
@@ -14,6 +20,7 @@
 namespace mobgs {
 
 constexpr int DEC_THREADS = 256;
+constexpr int NRED = 102;  // per-workgroup partial row: 72 (w1) + 18 (w2) + 12 (c2w) gradients
 
 struct Weights {
     float w1[72];  // [6][12]
@@ -29,19 +36,54 @@ __device__ inline Weights load_weights(const float* __restrict__ w1, const float
     return W;
 }
 
+struct RayCam {
+    float fx, fy, cx, cy;
+    float c2w[12];  // row-major 3x4: [R | t], camera -> world
+};
+__device__ inline RayCam load_raycam(const float* __restrict__ rc) {
+    RayCam c;
+    c.fx = rc[0]; c.fy = rc[1]; c.cx = rc[2]; c.cy = rc[3];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) c.c2w[k] = rc[4 + k];
+    return c;
+}
+// origin + normalised direction of pixel p (row-major, width W); also returns the local direction and 1/|d|
+__device__ inline void pixel_ray(const RayCam& c, int p, int W, float r[6], float loc[2], float& inv_n) {
+    const int py = p / W, px = p - py * W;
+    loc[0] = ((float)px + 0.5f - c.cx) / c.fx;
+    loc[1] = ((float)py + 0.5f - c.cy) / c.fy;
+    float d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = c.c2w[4 * i] * loc[0] + c.c2w[4 * i + 1] * loc[1] + c.c2w[4 * i + 2];
+    inv_n = 1.f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        r[i] = c.c2w[4 * i + 3];
+        r[3 + i] = d[i] * inv_n;
+    }
+}
+
 // feat_hw: [P, CF] channels-last with CF >= 9 (+1 accumulated depth when has_depth)
 __global__ void __launch_bounds__(DEC_THREADS)
-decoder_fwd_kernel(int P, int CF, int has_depth, const float* __restrict__ feat_hw,
-                   const float* __restrict__ alphas, const float* __restrict__ rays, const float* __restrict__ w1,
-                   const float* __restrict__ w2, float* __restrict__ rgb, float* __restrict__ depth) {
+decoder_fwd_kernel(int P, int CF, int has_depth, int width, const float* __restrict__ feat_hw,
+                   const float* __restrict__ alphas, const float* __restrict__ rays,
+                   const float* __restrict__ raycam, const float* __restrict__ w1, const float* __restrict__ w2,
+                   float* __restrict__ rgb, float* __restrict__ depth) {
     const Weights W = load_weights(w1, w2);
+    RayCam cam;
+    if (!rays) cam = load_raycam(raycam);
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         const float* f = feat_hw + (size_t)p * CF;
         float x[12];
 #pragma unroll
         for (int k = 0; k < 6; ++k) x[k] = f[3 + k];
+        if (rays) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) x[6 + k] = rays[(size_t)k * P + p];
+            for (int k = 0; k < 6; ++k) x[6 + k] = rays[(size_t)k * P + p];
+        } else {
+            float loc[2], inv_n;
+            pixel_ray(cam, p, width, x + 6, loc, inv_n);
+        }
         float h[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -71,22 +113,30 @@ __device__ inline float wave_sum_f(float v) {
 // v_feat_hw [P, CF] is fully written (channels >= 10 get 0); v_alphas [P] written when has_depth;
 // v_rays [6,P] written when non-null; weight gradients go to w_partial [gridDim.x, 90] (summed by the next kernel)
 __global__ void __launch_bounds__(DEC_THREADS)
-decoder_bwd_kernel(int P, int CF, int has_depth, const float* __restrict__ feat_hw,
-                   const float* __restrict__ alphas, const float* __restrict__ rays, const float* __restrict__ w1,
+decoder_bwd_kernel(int P, int CF, int has_depth, int width, const float* __restrict__ feat_hw,
+                   const float* __restrict__ alphas, const float* __restrict__ rays,
+                   const float* __restrict__ raycam, int want_cam_grad, const float* __restrict__ w1,
                    const float* __restrict__ w2, const float* __restrict__ v_rgb, const float* __restrict__ v_depth,
                    float* __restrict__ v_feat_hw, float* __restrict__ v_alphas, float* __restrict__ v_rays,
                    float* __restrict__ w_partial) {
     const Weights W = load_weights(w1, w2);
-    float gw[90];
+    RayCam cam;
+    if (!rays) cam = load_raycam(raycam);
+    float gw[NRED];  // 90 weight gradients + 12 c2w gradients
 #pragma unroll
-    for (int k = 0; k < 90; ++k) gw[k] = 0.f;
+    for (int k = 0; k < NRED; ++k) gw[k] = 0.f;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         const float* f = feat_hw + (size_t)p * CF;
         float x[12];
+        float loc[2] = {0.f, 0.f}, inv_n = 0.f;
 #pragma unroll
         for (int k = 0; k < 6; ++k) x[k] = f[3 + k];
+        if (rays) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) x[6 + k] = rays[(size_t)k * P + p];
+            for (int k = 0; k < 6; ++k) x[6 + k] = rays[(size_t)k * P + p];
+        } else {
+            pixel_ray(cam, p, width, x + 6, loc, inv_n);
+        }
         float h[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -143,31 +193,44 @@ decoder_bwd_kernel(int P, int CF, int has_depth, const float* __restrict__ feat_
 #pragma unroll
             for (int k = 0; k < 6; ++k) v_rays[(size_t)k * P + p] = vx[6 + k];
         }
+        if (!rays && want_cam_grad) {
+            // origin = t; dir = d / |d| with d = R loc + [third column]:  v_d = (v_dir - dir <dir, v_dir>) / |d|
+            const float dotp = x[9] * vx[9] + x[10] * vx[10] + x[11] * vx[11];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float vd = (vx[9 + i] - x[9 + i] * dotp) * inv_n;
+                gw[90 + 4 * i] += vd * loc[0];
+                gw[90 + 4 * i + 1] += vd * loc[1];
+                gw[90 + 4 * i + 2] += vd;
+                gw[90 + 4 * i + 3] += vx[6 + i];
+            }
+        }
     }
-    // 90 weight-gradient components: wave reduce -> LDS -> one row per workgroup
-    __shared__ float red[DEC_THREADS / 64][90];
+    // 90 weight-gradient (+ 12 camera-gradient) components: wave reduce -> LDS -> one row per workgroup
+    __shared__ float red[DEC_THREADS / 64][NRED];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 90; ++k) {
+    for (int k = 0; k < NRED; ++k) {
         const float s = wave_sum_f(gw[k]);
         if (lane == 0) red[wv][k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 90) {
+    if (threadIdx.x < NRED) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < DEC_THREADS / 64; ++w) s += red[w][threadIdx.x];
-        w_partial[(size_t)blockIdx.x * 90 + threadIdx.x] = s;
+        w_partial[(size_t)blockIdx.x * NRED + threadIdx.x] = s;
     }
 }
 
 // one workgroup per weight component: 90 workgroups x 256 threads sum the per-workgroup partial rows
 __global__ void __launch_bounds__(256) decoder_wgrad_reduce_kernel(int nblocks, const float* __restrict__ w_partial,
                                                                      float* __restrict__ g_w1,
-                                                                     float* __restrict__ g_w2) {
+                                                                     float* __restrict__ g_w2,
+                                                                     float* __restrict__ g_c2w) {
     const int k = blockIdx.x;
     float s = 0.f;
-    for (int b = threadIdx.x; b < nblocks; b += 256) s += w_partial[(size_t)b * 90 + k];
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += w_partial[(size_t)b * NRED + k];
     s = wave_sum_f(s);
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -176,8 +239,10 @@ __global__ void __launch_bounds__(256) decoder_wgrad_reduce_kernel(int nblocks, 
         const float t = red[0] + red[1] + red[2] + red[3];
         if (k < 72)
             g_w1[k] = t;
-        else
+        else if (k < 90)
             g_w2[k - 72] = t;
+        else if (g_c2w)
+            g_c2w[k - 90] = t;
     }
 }
 
@@ -196,32 +261,35 @@ static int decoder_grid(int P) {
 
 int mobgs_decoder_bwd_blocks(int P) { return decoder_grid(P); }
 
-int mobgs_decoder_fwd(int P, int CF, int has_depth, const float* feat_hw, const float* alphas, const float* rays,
-                      const float* w1, const float* w2, float* rgb, float* depth, void* stream) {
-    if (P < 0 || CF < 9 + (has_depth ? 1 : 0)) {
-        set_error("mobgs_decoder_fwd: bad sizes P=%d CF=%d", P, CF);
+int mobgs_decoder_fwd(int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
+                      const float* rays, const float* raycam, const float* w1, const float* w2, float* rgb,
+                      float* depth, void* stream) {
+    if (P < 0 || CF < 9 + (has_depth ? 1 : 0) || (!rays && (!raycam || width <= 0))) {
+        set_error("mobgs_decoder_fwd: bad arguments P=%d CF=%d (rays or raycam+width required)", P, CF);
         return MOBGS_E_INVALID;
     }
     if (P == 0) return MOBGS_OK;
     int g = (P + DEC_THREADS - 1) / DEC_THREADS;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(decoder_fwd_kernel, dim3(g), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth,
-                       feat_hw, alphas, rays, w1, w2, rgb, depth);
+    hipLaunchKernelGGL(decoder_fwd_kernel, dim3(g), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth, width,
+                       feat_hw, alphas, rays, raycam, w1, w2, rgb, depth);
     return check_launch("decoder_fwd_kernel");
 }
 
-int mobgs_decoder_bwd(int P, int CF, int has_depth, const float* feat_hw, const float* alphas, const float* rays,
-                      const float* w1, const float* w2, const float* v_rgb, const float* v_depth, float* v_feat_hw,
-                      float* v_alphas, float* v_rays, float* w_partial, float* g_w1, float* g_w2, void* stream) {
-    if (P <= 0 || CF < 9 + (has_depth ? 1 : 0)) {
-        set_error("mobgs_decoder_bwd: bad sizes P=%d CF=%d", P, CF);
+int mobgs_decoder_bwd(int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
+                      const float* rays, const float* raycam, const float* w1, const float* w2, const float* v_rgb,
+                      const float* v_depth, float* v_feat_hw, float* v_alphas, float* v_rays, float* w_partial,
+                      float* g_w1, float* g_w2, float* g_c2w, void* stream) {
+    if (P <= 0 || CF < 9 + (has_depth ? 1 : 0) || (!rays && (!raycam || width <= 0))) {
+        set_error("mobgs_decoder_bwd: bad arguments P=%d CF=%d", P, CF);
         return MOBGS_E_INVALID;
     }
     const int g = decoder_grid(P);
-    hipLaunchKernelGGL(decoder_bwd_kernel, dim3(g), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth,
-                       feat_hw, alphas, rays, w1, w2, v_rgb, v_depth, v_feat_hw, v_alphas, v_rays, w_partial);
-    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3(90), dim3(256), 0, (hipStream_t)stream, g, w_partial, g_w1,
-                       g_w2);
+    hipLaunchKernelGGL(decoder_bwd_kernel, dim3(g), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth, width,
+                       feat_hw, alphas, rays, raycam, g_c2w ? 1 : 0, w1, w2, v_rgb, v_depth, v_feat_hw, v_alphas,
+                       v_rays, w_partial);
+    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3(NRED), dim3(256), 0, (hipStream_t)stream, g, w_partial, g_w1,
+                       g_w2, g_c2w);
     return check_launch("decoder_bwd_kernel");
 }
 

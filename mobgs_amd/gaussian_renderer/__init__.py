@@ -111,6 +111,18 @@ def _prep(stat_pc, dyn_pc, times):
                             dyn_pc._opacity, dyn_pc._features_dc, dyn_pc._features_t, dyn_pc.get_trbfcenter)
 
 
+# True: cameras that expose their pinhole parameters (`ray_intrinsics`, `ray_c2w` -- mobgs_amd.camera.PinholeCamera,
+# mobgs_amd.blce.WarpedCamera) get their rays generated inside the decoder kernel; other cameras (e.g. the
+# reference's scene.cameras.Camera) are read through their `cam_ray` map exactly as the reference does
+INKERNEL_RAYS = True
+
+
+def _rays_of(cam):
+    if INKERNEL_RAYS and hasattr(cam, "ray_c2w") and hasattr(cam, "ray_intrinsics"):
+        return (cam.ray_intrinsics, cam.ray_c2w)
+    return cam.cam_ray
+
+
 def _decoder_weights(dyn_pc):
     dec = dyn_pc.rgbdecoder
     return dec.mlp1.weight, dec.mlp2.weight
@@ -162,8 +174,10 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
                                 opacities=pick(opac, sl), colors=colors, backgrounds=bgs, viewmats=viewmat[None],
                                 Ks=K[None], width=W, height=H, packed=False, render_mode=mode)
 
+    rays = _rays_of(cam)
+
     def decode_ed(img, alphas):
-        return decode(img, alphas, cam.cam_ray, w1, w2, True)  # views only: no select/zeros/copy in backward
+        return decode(img, alphas, rays, w1, w2, True)  # views only: no select/zeros/copy in backward
 
     out = RenderResult({k: None for k in ("s_render", "s_depth", "d_render", "d_depth", "d_alpha", "d_means3d",
                                           "s_alpha", "blending_factor", "world_coordinates", "splat_center",
@@ -284,7 +298,7 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     exp2mid = pix + e2m_img
     mid2exp = pix + splat(sp_mid, -e2m)
     img, alphas = sp_exp.composite(exp_c, bg[None])
-    latent_img, _ = decode(img, alphas, cam.cam_ray, w1, w2, True)
+    latent_img, _ = decode(img, alphas, _rays_of(cam), w1, w2, True)
     return exp2mid, mid2exp, latent_img, latent_alpha
 
 

@@ -65,23 +65,30 @@ class PrepSplats(torch.autograd.Function):
 
 
 class Decode(torch.autograd.Function):
-    """Channels-last compositor image (+alpha) -> planar rgb [3,H,W] (+ expected depth [H,W])."""
+    """Channels-last compositor image (+alpha) -> planar rgb [3,H,W] (+ expected depth [H,W]).
+    Rays: either the reference's map `rays` [6,H,W], or (rays=None) the pinhole parameters `intr` = [fx,fy,cx,cy]
+    and `c2w` [3,4] from which the kernel generates them (gradient flows into c2w)."""
 
     @staticmethod
-    def forward(ctx, feat_hw, alphas, rays, w1, w2, has_depth: bool):
+    def forward(ctx, feat_hw, alphas, rays, intr, c2w, w1, w2, has_depth: bool):
         lib = _lib.load()
-        feat_hw, rays, w1, w2 = map(f32c, (feat_hw, rays, w1, w2))
+        feat_hw, w1, w2 = map(f32c, (feat_hw, w1, w2))
         H, W, CF = feat_hw.shape[-3:]
         P = H * W
         dev = feat_hw.device
         alphas_c = f32c(alphas) if alphas is not None else None
+        rays_c = f32c(rays) if rays is not None else None
+        raycam = None
+        if rays_c is None:
+            raycam = torch.cat([f32c(intr).reshape(4), f32c(c2w).reshape(12)])
         rgb = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(H, W, dtype=torch.float32, device=dev) if has_depth else None
-        check(lib.mobgs_decoder_fwd(P, CF, int(has_depth), ptr(feat_hw), ptr(alphas_c), ptr(rays), ptr(w1), ptr(w2),
-                                    ptr(rgb), ptr(depth), stream()), "mobgs_decoder_fwd")
-        ctx.save_for_backward(feat_hw, alphas_c, rays, w1, w2)
+        check(lib.mobgs_decoder_fwd(P, CF, int(has_depth), W, ptr(feat_hw), ptr(alphas_c), ptr(rays_c), ptr(raycam),
+                                    ptr(w1), ptr(w2), ptr(rgb), ptr(depth), stream()), "mobgs_decoder_fwd")
+        ctx.save_for_backward(feat_hw, alphas_c, rays_c, raycam, w1, w2)
         ctx.has_depth = has_depth
-        ctx.rays_need_grad = ctx.needs_input_grad[2]
+        ctx.rays_need_grad = rays is not None and ctx.needs_input_grad[2]
+        ctx.c2w_needs_grad = rays is None and ctx.needs_input_grad[4]
         ctx.feat_shape = feat_hw.shape
         if has_depth:
             return rgb, depth
@@ -90,7 +97,7 @@ class Decode(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_rgb, v_depth):
         lib = _lib.load()
-        feat_hw, alphas, rays, w1, w2 = ctx.saved_tensors
+        feat_hw, alphas, rays, raycam, w1, w2 = ctx.saved_tensors
         H, W, CF = feat_hw.shape[-3:]
         P = H * W
         dev = feat_hw.device
@@ -100,25 +107,32 @@ class Decode(torch.autograd.Function):
         v_feat = torch.empty(ctx.feat_shape, dtype=torch.float32, device=dev)
         v_alphas = torch.empty(alphas.shape, dtype=torch.float32, device=dev) if has_depth else None
         v_rays = torch.empty_like(rays) if ctx.rays_need_grad else None
+        g_c2w = torch.empty(3, 4, dtype=torch.float32, device=dev) if ctx.c2w_needs_grad else None
         nb = lib.mobgs_decoder_bwd_blocks(P)
-        partial = torch.empty(nb, 90, dtype=torch.float32, device=dev)
+        partial = torch.empty(nb, 102, dtype=torch.float32, device=dev)
         g_w1 = torch.empty_like(w1)
         g_w2 = torch.empty_like(w2)
-        check(lib.mobgs_decoder_bwd(P, CF, int(has_depth), ptr(feat_hw), ptr(alphas), ptr(rays), ptr(w1), ptr(w2),
-                                    ptr(v_rgb), ptr(v_depth), ptr(v_feat), ptr(v_alphas), ptr(v_rays), ptr(partial),
-                                    ptr(g_w1), ptr(g_w2), stream()), "mobgs_decoder_bwd")
-        return v_feat, v_alphas, v_rays, g_w1, g_w2, None
+        check(lib.mobgs_decoder_bwd(P, CF, int(has_depth), W, ptr(feat_hw), ptr(alphas), ptr(rays), ptr(raycam),
+                                    ptr(w1), ptr(w2), ptr(v_rgb), ptr(v_depth), ptr(v_feat), ptr(v_alphas),
+                                    ptr(v_rays), ptr(partial), ptr(g_w1), ptr(g_w2), ptr(g_c2w), stream()),
+              "mobgs_decoder_bwd")
+        return v_feat, v_alphas, v_rays, None, g_c2w, g_w1, g_w2, None
 
 
-def decode(feat_hw: Tensor, alphas: Optional[Tensor], rays: Tensor, w1: Tensor, w2: Tensor, has_depth: bool):
-    """feat_hw [..,H,W,CF>=9(+1)], alphas [..,H,W] or [..,H,W,1], rays [1,6,H,W] -> rgb [3,H,W], depth [H,W]|None."""
+def decode(feat_hw: Tensor, alphas: Optional[Tensor], rays, w1: Tensor, w2: Tensor, has_depth: bool):
+    """feat_hw [..,H,W,CF>=9(+1)], alphas [..,H,W] or [..,H,W,1] -> rgb [3,H,W], depth [H,W]|None.
+    `rays`: the reference's cam_ray map [1,6,H,W], or a pair (intr [4] = fx,fy,cx,cy, c2w [3,4]) to have the kernel
+    generate the pinhole rays itself."""
     H, W = feat_hw.shape[-3], feat_hw.shape[-2]
     if feat_hw.numel() != H * W * feat_hw.shape[-1]:
         raise NotImplementedError("decoder batch size must be 1 (as in every reference call)")
     if alphas is not None:
         alphas = alphas.reshape(H, W)
-    rgb, depth = Decode.apply(feat_hw.reshape(H, W, feat_hw.shape[-1]), alphas, rays.reshape(6, H, W), w1, w2,
-                              bool(has_depth))
+    feat = feat_hw.reshape(H, W, feat_hw.shape[-1])
+    if isinstance(rays, (tuple, list)):
+        rgb, depth = Decode.apply(feat, alphas, None, rays[0], rays[1], w1, w2, bool(has_depth))
+    else:
+        rgb, depth = Decode.apply(feat, alphas, rays.reshape(6, H, W), None, None, w1, w2, bool(has_depth))
     return rgb, (depth if has_depth else None)
 
 
