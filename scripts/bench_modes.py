@@ -73,8 +73,34 @@ def main():
         pred = shard.render_blurry_view(unit, 9)
         torch.autograd.backward([pred, mid["depth"], mid["d_alpha"]], [v3, v1, v1])
 
+    # the same with BLCE-warped latent cameras and exposure offsets (train.py:472, 502-541): pose gradients flow
+    # through the warped cameras (w2c of the rasterizer AND the decoder's view rays) into the BLCE parameters
+    from mobgs_amd.blce import blceKernel
+    cam.uid = 0
+    cam.image = torch.rand(3, H, W, generator=g).to(dev)
+    kern = blceKernel(num_views=2, num_warp=9, iteration=10000).to(dev)
+
+    def blurry_view_blce():
+        zero()
+        kern.optimizer.zero_grad(set_to_none=True)
+        cams, expo = kern.get_warped_cams(cam, cam, cam)
+        mid = GR.render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True)
+
+        def unit(k):
+            if k == 4:
+                return mid["render"]
+            return GR.render(cams[k], stat, dyn, None, bg, get_static=True, get_dynamic=True,
+                             delta_exposure=expo[k])["render"]
+
+        pred = shard.render_blurry_view(unit, 9)
+        torch.autograd.backward([pred, mid["depth"], mid["d_alpha"]], [v3, v1, v1])
+
     res = {}
     res["lean_ms"] = timed(lean, a.steps)
+    GR.INKERNEL_RAYS = False
+    res["blurry_view_blce_ray_maps_ms"] = timed(blurry_view_blce, max(3, a.steps // 4), warmup=1)
+    GR.INKERNEL_RAYS = True
+    res["blurry_view_blce_inkernel_rays_ms"] = timed(blurry_view_blce, max(3, a.steps // 4), warmup=1)
     GR.FUSE_LAYERS = False
     res["train_mode_separate_passes_ms"] = timed(train_mode, a.steps)
     res["blurry_view_separate_passes_ms"] = timed(blurry_view, max(3, a.steps // 4), warmup=1)
