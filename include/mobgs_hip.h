@@ -261,6 +261,19 @@ int mobgs_deform_mlp_fwd(int N, const float* feat, const float* pts, const float
                          const float* W0t, const float* b0, const float* W1t, const float* b1, const float* W2t,
                          const float* b2, float* out_pts, float* out_scales, float* out_rots, void* stream);
 
+/* ---- K11: fused photometric loss (L1 + SSIM), forward and backward -------------------------------------
+ * /root/reference/utils/loss_utils.py:233-239 (l1_loss, mask=None), :251-260 + :351-381 (ssim: 11x11 Gaussian
+ * window sigma 1.5, zero padding, per channel, mean over all elements); /root/reference/train.py:621-628.
+ * img1, img2 [C,H,W].  fwd: partial [mobgs_ssim_l1_blocks(C,H,W), 2] = per-workgroup {sum ssim_map, sum |img1-img2|}
+ * (the caller sums and divides by C*H*W); dmaps [3,C,H,W] = d ssim_map / d{mu1, E[x^2], E[xy]} (NULL when no
+ * backward is needed).  bwd: scales = device float[C,2], per channel {d loss / d sum-of-ssim_map, d loss / d sum-of-|diff|}
+ * (i.e. the mean's 1/(C*H*W) already applied); v_img1 [C,H,W] is fully written (gradient w.r.t. img1 only). */
+int mobgs_ssim_l1_blocks(int C, int H, int W);
+int mobgs_ssim_l1_fwd(int C, int H, int W, const float* img1, const float* img2, float* partial, float* dmaps,
+                      void* stream);
+int mobgs_ssim_l1_bwd(int C, int H, int W, const float* img1, const float* img2, const float* dmaps,
+                      const float* scales, float* v_img1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,9 @@ _SIGS = {
     "mobgs_decoder_fwd": (c_int, [c_int, c_int, c_int, c_int] + [P] * 8 + [P]),
     "mobgs_decoder_bwd_blocks": (c_int, [c_int]),
     "mobgs_decoder_bwd": (c_int, [c_int, c_int, c_int, c_int] + [P] * 15 + [P]),
+    "mobgs_ssim_l1_blocks": (c_int, [c_int, c_int, c_int]),
+    "mobgs_ssim_l1_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P]),
+    "mobgs_ssim_l1_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P]),
     "mobgs_hexplane_fwd": (c_int, [c_int] + [P] * 7 + [P]),
     "mobgs_hexplane_bwd": (c_int, [c_int] + [P] * 10 + [P]),
     "mobgs_deform_mlp_fwd": (c_int, [c_int] + [P] * 13 + [P]),

@@ -12,7 +12,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "libmobgs_hip.so"
-SOURCES = ["project.hip", "isect.hip", "raster.hip", "raster_layers.hip", "pipeline.hip", "prep.hip", "decoder.hip", "deform.hip"]
+SOURCES = ["project.hip", "isect.hip", "raster.hip", "raster_layers.hip", "pipeline.hip", "prep.hip", "decoder.hip", "deform.hip", "loss.hip"]
 ARCH = "gfx950"
 
 

@@ -95,7 +95,24 @@ def main():
         pred = shard.render_blurry_view(unit, 9)
         torch.autograd.backward([pred, mid["depth"], mid["d_alpha"]], [v3, v1, v1])
 
+    # photometric loss of one 1352x1014 view (train.py:621-628), fwd + bwd: torch ops as the reference calls them
+    # vs the fused kernels
+    from mobgs_amd.loss_utils import photometric_loss
+    from oracle import loss_torch as LT  # timing leg only: the reference's call pattern, on the GPU
+    gt_img = torch.rand(1, 3, H, W, generator=g).to(dev)
+    pred_img = torch.rand(1, 3, H, W, generator=g).to(dev).requires_grad_(True)
+
+    def loss_torch_ops():
+        pred_img.grad = None
+        (LT.l1_loss(pred_img, gt_img) + 0.2 * (1.0 - LT.ssim(pred_img, gt_img))).backward()
+
+    def loss_fused():
+        pred_img.grad = None
+        photometric_loss(pred_img, gt_img, 0.2).backward()
+
     res = {}
+    res["photo_loss_torch_ops_ms"] = timed(loss_torch_ops, a.steps)
+    res["photo_loss_fused_ms"] = timed(loss_fused, a.steps)
     res["lean_ms"] = timed(lean, a.steps)
     GR.INKERNEL_RAYS = False
     res["blurry_view_blce_ray_maps_ms"] = timed(blurry_view_blce, max(3, a.steps // 4), warmup=1)

@@ -283,6 +283,24 @@ def gen_blce(name, num_views=3, seed=8):
     save(name, **arrays)
 
 
+def gen_losses(name):
+    lu = RH.ref_import("utils.loss_utils")
+    iu = RH.ref_import("utils.image_utils")
+    g = torch.Generator().manual_seed(12)
+    H, W = 45, 71  # not multiples of the 16-pixel tile: border handling
+    gt = torch.rand(2, 3, H, W, generator=g)
+    img = (gt + 0.15 * torch.randn(2, 3, H, W, generator=g)).clamp(0, 1).requires_grad_(True)
+    with RH.CudaToCpu():
+        l1 = lu.l1_loss(img, gt)
+        s = lu.ssim(img, gt)
+        s_per = lu.ssim(img, gt, size_average=False)
+        loss = l1 + 0.2 * (1.0 - s)
+        p = iu.psnr(img.detach(), gt)
+    loss.backward()
+    save(name, img=np_(img), gt=np_(gt), l1=np_(l1), ssim=np_(s), ssim_per_image=np_(s_per), loss=np_(loss),
+         grad_img=np_(img.grad), psnr=np_(p))
+
+
 def main():
     RH.install()
     gen_hermite("hermite")
@@ -293,6 +311,7 @@ def main():
     gen_get_flow("get_flow", 900, 500, 80, 48, 3, -0.4)
     gen_deform("deform")
     gen_blce("blce")
+    gen_losses("losses")
 
 
 if __name__ == "__main__":

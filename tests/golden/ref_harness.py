@@ -84,6 +84,8 @@ def install():
     stub("pytorch3d.transforms", quaternion_to_matrix=None, matrix_to_quaternion=None,
          axis_angle_to_matrix=None, matrix_to_axis_angle=None, se3_exp_map=None, se3_log_map=None)
     stub("mmengine")
+    stub("lpips")
+    stub("pytorch3d.ops", ball_query=None)
     stub("open3d")
     stub("gsplat")
     stub("gsplat.rendering", rasterization=gsplat_torch.rasterization,

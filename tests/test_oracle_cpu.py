@@ -258,3 +258,16 @@ def test_deform_restatement_matches_reference_fixture():
     close(pts.grad, fx["grad_pts"], 1e-5, 1e-6, "grad pts")
     close(W["w0"].grad, fx["gw_w0"], 1e-5, 1e-6, "grad w0")
     close(planes[2][0].grad, fx["gplane_2_0"], 1e-5, 1e-7, "grad plane 2.0")
+
+
+def test_loss_restatement_matches_reference_fixture():
+    from oracle import loss_torch as L
+    fx = load("losses")
+    gt = torch.from_numpy(fx["gt"])
+    img = torch.from_numpy(fx["img"]).requires_grad_(True)
+    close(L.l1_loss(img, gt), fx["l1"], 1e-6, 1e-7, "l1")
+    close(L.ssim(img, gt), fx["ssim"], 1e-6, 1e-7, "ssim")
+    close(L.ssim(img, gt, size_average=False), fx["ssim_per_image"], 1e-6, 1e-7, "ssim per image")
+    close(L.psnr(img.detach(), gt), fx["psnr"], 1e-6, 1e-6, "psnr")
+    (L.l1_loss(img, gt) + 0.2 * (1 - L.ssim(img, gt))).backward()
+    close(img.grad, fx["grad_img"], 1e-5, 1e-8, "grad")
