@@ -261,8 +261,23 @@ def _raster_acc(raster, sl, colors, bgs):
     return img, alphas.squeeze(-1), info
 
 
+_pixel_grid_cache = {}
+
+
 def _pixel_grid(cam, W, H, like):
-    return torch.tensor(cam.get_pixels(W, H, use_center=False)).type_as(like)
+    """cam.get_pixels(W, H, use_center=False) (/root/reference/scene/cameras.py:206-213: integer pixel corners,
+    a function of (W, H) only) built once per size ON the device; the reference rebuilds it with numpy and copies
+    11 MB host->device on every call."""
+    key = (W, H, str(like.device), like.dtype)
+    g = _pixel_grid_cache.get(key)
+    if g is None:
+        if len(_pixel_grid_cache) > 8:
+            _pixel_grid_cache.clear()
+        xs = torch.arange(W, dtype=torch.float32, device=like.device)
+        ys = torch.arange(H, dtype=torch.float32, device=like.device)
+        g = torch.stack([xs[None, :].expand(H, W), ys[:, None].expand(H, W)], dim=-1).to(like.dtype).contiguous()
+        _pixel_grid_cache[key] = g
+    return g
 
 
 def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=None):

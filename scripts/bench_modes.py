@@ -110,7 +110,16 @@ def main():
         pred_img.grad = None
         photometric_loss(pred_img, gt_img, 0.2).backward()
 
+    v2 = torch.randn(1, H, W, 2, generator=g).to(dev)
+
+    def flow_call():
+        """One of the 9 get_flow() calls per view (train.py:570-579), forward + backward."""
+        zero()
+        e2m, m2e, img, alpha = GR.get_flow(cam, stat, dyn, None, bg, delta_exposure=deltas[1])
+        torch.autograd.backward([e2m, m2e, img, alpha], [v2, v2, v3, v1])
+
     res = {}
+    res["get_flow_ms"] = timed(flow_call, a.steps)
     res["photo_loss_torch_ops_ms"] = timed(loss_torch_ops, a.steps)
     res["photo_loss_fused_ms"] = timed(loss_fused, a.steps)
     res["lean_ms"] = timed(lean, a.steps)
