@@ -86,6 +86,10 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
  *                box intersection j is listed iff keep_scan[j+1] > keep_scan[j]; its compact index (= its
  *                gradient slot in mobgs_raster_bwd) is keep_scan[j]
  *      tile_offsets [C*n_tiles+1] exclusive prefix sum of the per-tile list lengths
+ *      tile_order [C*n_tiles] (may be NULL) the tile ids by descending list length (1024 length classes): the
+ *                order in which the compositing kernels hand tiles to workgroups (longest lists first, lists of
+ *                similar length share a workgroup).  A schedule only -- results do not depend on it; the
+ *                compositing entry points accept NULL for "raster order".
  *      stats int64[3] = {I_box, I_listed, longest per-tile list}; the caller reads them back to size the list
  *      buffers (the one host sync of the pipeline, as in gsplat).  If I_box > capacity the flags were
  *      truncated: call again with capacity >= I_box.
@@ -94,8 +98,8 @@ size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity);
 int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
                         const int32_t* tiles_per_gauss, const float* means2d, const int32_t* radii,
                         const float* conics, const float* opacities, int opac_per_camera,
-                        int32_t* cum_tiles, int32_t* keep_scan, int32_t* tile_offsets, int64_t* stats,
-                        void* scratch, void* stream);
+                        int32_t* cum_tiles, int32_t* keep_scan, int32_t* tile_offsets, int32_t* tile_order,
+                        int64_t* stats, void* scratch, void* stream);
 
 /* ---- K3b/K4: emit + per-tile depth sort (replaces isect_tiles pass 2 + CUB DeviceRadixSort) ------------
  * Writes, per tile, its listed splats ordered by (float depth bits ascending, flat id ascending) -- the order a
@@ -122,7 +126,7 @@ int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, 
                           int width, int height, float eps2d, float near_plane, float far_plane,
                           float radius_clip, int cull, int32_t* radii, float* means2d, float* depths,
                           float* conics, int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* tile_offsets,
-                          int64_t* stats_dev, int capacity_box, int32_t* keep_scan, void* scratch,
+                          int32_t* tile_order, int64_t* stats_dev, int capacity_box, int32_t* keep_scan, void* scratch,
                           int64_t capacity_listed, int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
                           int64_t* stats_host, void* stream);
 
@@ -137,8 +141,8 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
                      const float* conics, const float* colors, int colors_per_camera,
                      const float* opacities, int opac_per_camera, const float* extra,
                      const float* backgrounds, const int32_t* radii, const int32_t* tile_offsets,
-                     const int32_t* flatten_ids, float* records, float* render, float* alphas,
-                     int32_t* last_ids, void* stream);
+                     const int32_t* tile_order, const int32_t* flatten_ids, float* records, float* render,
+                     float* alphas, int32_t* last_ids, void* stream);
 
 /* ---- K7: rasterise backward (replaces gsplat rasterize_to_pixels bwd) ----------------------------------
  * Deterministic two-stage gradient reduction, no floating-point atomics:
@@ -152,9 +156,9 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
 int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int height,
                      const float* records, const float* backgrounds, const int32_t* radii,
                      const float* means2d, const int32_t* cum_tiles, const int32_t* keep_scan,
-                     const int32_t* tile_offsets, const int32_t* flatten_ids, const float* render_alphas,
-                     const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
-                     void* stream);
+                     const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
+                     const float* render_alphas, const int32_t* last_ids, const float* v_render,
+                     const float* v_alphas, float* grad_slots, void* stream);
 int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int32_t* cum_tiles,
                             const int32_t* keep_scan, const float* grad_slots, float* v_means2d, float* v_conics, float* v_opacities,
                             float* v_colors, float* v_extra, void* stream);
@@ -177,12 +181,14 @@ int mobgs_pack_records(int C, int N, int channels, const float* means2d, const f
  * alone (what the reference's `viewspace_points.grad` holds, gaussian_renderer/__init__.py:218-223). */
 int mobgs_raster_layers_fwd(int C, int N, int Ns, int layer_mask, int channels_total, int width, int height,
                             const float* records, const float* backgrounds, const int32_t* tile_offsets,
-                            const int32_t* flatten_ids, float* const* render3_host, float* const* alphas3_host,
+                            const int32_t* tile_order, const int32_t* flatten_ids, float* const* render3_host,
+                            float* const* alphas3_host,
                             int32_t* const* last_ids3_host, void* stream);
 int mobgs_raster_layers_bwd(int C, int N, int Ns, int layer_mask, int channels, int has_extra, int width,
                             int height, const float* records, const float* backgrounds, const int32_t* radii,
                             const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
-                            const int32_t* flatten_ids, const float* const* render_alphas3_host,
+                            const int32_t* tile_order, const int32_t* flatten_ids,
+                            const float* const* render_alphas3_host,
                             const int32_t* const* last_ids3_host, const float* const* v_render3_host,
                             const float* const* v_alphas3_host, float* grad_slots, float* grad_xy0,
                             float* v_means2d_layer0, float* v_means2d, float* v_conics, float* v_opacities,

@@ -27,17 +27,17 @@ _SIGS = {
     "mobgs_project_bwd": (c_int, [c_int, c_int, P, P, P, P, P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P,
                                   P, P]),
     "mobgs_isect_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "mobgs_isect_offsets": (c_int, [c_int] * 8 + [P] * 5 + [c_int] + [P] * 5 + [P]),
+    "mobgs_isect_offsets": (c_int, [c_int] * 8 + [P] * 5 + [c_int] + [P] * 6 + [P]),
     "mobgs_isect_emit_sort": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int64, c_int64] + [P] * 7 + [P]),
-    "mobgs_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, P,
+    "mobgs_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, P, P,
                                  P, P, P, P]),
-    "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int] + [P] * 13 + [P]),
+    "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int] + [P] * 14 + [P]),
     "mobgs_raster_bwd_reduce": (c_int, [c_int, c_int, c_int, c_int] + [P] * 8 + [P]),
     "mobgs_project_and_bin": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
-                                      c_float, c_int, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, P, P, P]),
+                                      c_float, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, P, P, P]),
     "mobgs_pack_records": (c_int, [c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P]),
-    "mobgs_raster_layers_fwd": (c_int, [c_int] * 7 + [P] * 7 + [P]),
-    "mobgs_raster_layers_bwd": (c_int, [c_int] * 8 + [P] * 19 + [P]),  # incl. 7 host pointer arrays of length 3
+    "mobgs_raster_layers_fwd": (c_int, [c_int] * 7 + [P] * 8 + [P]),
+    "mobgs_raster_layers_bwd": (c_int, [c_int] * 8 + [P] * 20 + [P]),  # incl. 7 host pointer arrays of length 3
     "mobgs_prep_fwd": (c_int, [c_int, c_int] + [P] * 21 + [P]),
     "mobgs_prep_bwd": (c_int, [c_int, c_int] + [P] * 23 + [P]),
     "mobgs_decoder_fwd": (c_int, [c_int, c_int, c_int, c_int] + [P] * 8 + [P]),

@@ -182,11 +182,18 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
     }
 }
 
-// single workgroup: exclusive scan of tile_count[nt] -> tile_offsets[nt+1]; stats[1] = max count
+// single workgroup: exclusive scan of tile_count[nt] -> tile_offsets[nt+1]; stats[2] = max count;
+// tile_order[nt] (optional) = the tiles by DESCENDING list length (counting sort on ORDER_BUCKETS length classes):
+// the order in which the compositing kernels hand tiles to workgroups, so that the longest lists start first and
+// the waves of one workgroup get lists of similar length (longest-processing-time-first scheduling).  Only a
+// schedule: any permutation gives the same images and gradients.
+constexpr int ORDER_BUCKETS = 1024;
 __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(int nt, const int32_t* __restrict__ tile_count,
                                                                    int32_t* __restrict__ tile_offsets,
-                                                                   int64_t* __restrict__ stats) {
+                                                                   int64_t* __restrict__ stats,
+                                                                   int32_t* __restrict__ tile_order) {
     __shared__ int smax[SCAN_THREADS];
+    __shared__ int hist[ORDER_BUCKETS];
     int carry = 0, mx = 0;
     for (int start = 0; start < nt; start += SCAN_THREADS) {
         const int i = start + threadIdx.x;
@@ -203,9 +210,40 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(int nt, const i
         if (threadIdx.x < s) smax[threadIdx.x] = max(smax[threadIdx.x], smax[threadIdx.x + s]);
         __syncthreads();
     }
+    const int longest = smax[0];
     if (threadIdx.x == 0) {
         tile_offsets[nt] = carry;
-        stats[2] = (int64_t)smax[0];
+        stats[2] = (int64_t)longest;
+    }
+    if (!tile_order) return;
+    auto bucket = [&](int len) {
+        const int q = longest > 0 ? (int)(((int64_t)len * (ORDER_BUCKETS - 1)) / longest) : 0;
+        return ORDER_BUCKETS - 1 - q;  // bucket 0 = the longest lists
+    };
+    for (int b = threadIdx.x; b < ORDER_BUCKETS; b += SCAN_THREADS) hist[b] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt; i += SCAN_THREADS) atomicAdd(&hist[bucket(tile_count[i])], 1);
+    __syncthreads();
+    {  // exclusive scan of hist: each thread owns ORDER_BUCKETS / SCAN_THREADS consecutive buckets
+        constexpr int PER = ORDER_BUCKETS / SCAN_THREADS;
+        int loc[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            loc[k] = hist[threadIdx.x * PER + k];
+            sum += loc[k];
+        }
+        int total;
+        int base = block_incl_scan(sum, &total) - sum;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            hist[threadIdx.x * PER + k] = base;
+            base += loc[k];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt; i += SCAN_THREADS) {
+        const int pos = atomicAdd(&hist[bucket(tile_count[i])], 1);
+        tile_order[pos] = i;
     }
 }
 
@@ -384,7 +422,8 @@ size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity) {
 int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
                         const int32_t* tiles_per_gauss, const float* means2d, const int32_t* radii,
                         const float* conics, const float* opacities, int opac_per_camera, int32_t* cum_tiles,
-                        int32_t* keep_scan, int32_t* tile_offsets, int64_t* stats, void* scratch, void* stream) {
+                        int32_t* keep_scan, int32_t* tile_offsets, int32_t* tile_order, int64_t* stats,
+                        void* scratch, void* stream) {
     const long long ng = (long long)C * N;
     const long long nt = (long long)C * tile_w * tile_h;
     if (C <= 0 || N < 0 || capacity < 1 || ng >= (1ll << 31) - 1 || nt >= (1ll << 31) - 1) {
@@ -404,7 +443,8 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
         hipMemsetAsync(cum_tiles, 0, sizeof(int32_t), st);
         hipMemsetAsync(keep_scan, 0, sizeof(int32_t), st);
         hipMemsetAsync(stats, 0, 3 * sizeof(int64_t), st);
-        hipMemsetAsync(tile_offsets, 0, sizeof(int32_t) * (nt + 1), st);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, (int)nt, tile_count, tile_offsets,
+                           stats, tile_order);
         return check_launch("isect_offsets(empty)");
     }
     // bounding-box counts -> cum_tiles; stats[0] = I_box
@@ -431,7 +471,7 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nb2), dim3(SCAN_THREADS), 0, st, n_ptr, capacity, flags, block_sums2,
                        keep_scan);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, (int)nt, tile_count, tile_offsets,
-                       stats);
+                       stats, tile_order);
     return check_launch("isect_offsets");
 }
 

@@ -17,7 +17,8 @@ int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, 
                           const float* viewmats, const float* Ks, const float* opacities, int opac_per_camera,
                           int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip,
                           int cull, int32_t* radii, float* means2d, float* depths, float* conics,
-                          int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* tile_offsets, int64_t* stats_dev,
+                          int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* tile_offsets, int32_t* tile_order,
+                          int64_t* stats_dev,
                           int capacity_box, int32_t* keep_scan, void* scratch, int64_t capacity_listed,
                           int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids, int64_t* stats_host,
                           void* stream) {
@@ -27,7 +28,7 @@ int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, 
                                radius_clip, radii, means2d, depths, conics, tiles_per_gauss, stream);
     if (rc != MOBGS_OK) return rc;
     rc = mobgs_isect_offsets(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d, radii,
-                             conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, stats_dev, scratch,
+                             conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order, stats_dev, scratch,
                              stream);
     if (rc != MOBGS_OK) return rc;
     // the pipeline's one host synchronisation (upstream gsplat has the same one): {I_box, I_listed, longest list}

@@ -28,6 +28,19 @@ constexpr float T_STOP = 1e-4f;
 constexpr int PPL = 4;            // pixels per lane
 constexpr int TILES_PER_WG = 4;   // waves per workgroup, each on its own tile
 
+// Which tile this wave works on: with a schedule, workgroups take tiles in the given order (heaviest first);
+// without, tiles are taken in XCD-chunked raster order.  -1: nothing to do.
+__device__ inline int scheduled_tile(const int32_t* tile_order, int n_groups, int n_tiles_total, int wv) {
+    if (tile_order) {
+        const int slot = blockIdx.x * TILES_PER_WG + wv;
+        return slot < n_tiles_total ? tile_order[slot] : -1;
+    }
+    const int group = xcd_chunked(blockIdx.x, n_groups);
+    if (group >= n_groups) return -1;
+    const int tile = group * TILES_PER_WG + wv;
+    return tile < n_tiles_total ? tile : -1;
+}
+
 __device__ inline void wave_lds_fence() {
     // LDS operations of one wave execute in issue order; only the compiler has to be told
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -93,15 +106,14 @@ __global__ void __launch_bounds__(64 * TILES_PER_WG)
 raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
                   const float* __restrict__ records, const float* __restrict__ backgrounds,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-                  float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids) {
+                  float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
+                  const int32_t* __restrict__ tile_order) {
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
     __shared__ float4 slab[TILES_PER_WG][64][RQ];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int group = xcd_chunked(blockIdx.x, n_groups);
-    if (group >= n_groups) return;
-    const int tile = group * TILES_PER_WG + wv;
-    if (tile >= n_tiles_total) return;
+    const int tile = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
+    if (tile < 0) return;
     const int tiles_per_cam = tile_w * tile_h;
     const int cam = tile / tiles_per_cam;
     const int tl = tile - cam * tiles_per_cam;
@@ -265,7 +277,7 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
                   const int32_t* __restrict__ flatten_ids, const float* __restrict__ render_alphas,
                   const int32_t* __restrict__ last_ids,
                   const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                  float* __restrict__ grad_slots) {
+                  float* __restrict__ grad_slots, const int32_t* __restrict__ tile_order) {
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
     constexpr int NV = 6 + CD;
@@ -273,10 +285,8 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
     __shared__ float4 slab[TILES_PER_WG][64][RQ];
     __shared__ int slot_of[TILES_PER_WG][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int group = xcd_chunked(blockIdx.x, n_groups);
-    if (group >= n_groups) return;
-    const int tile = group * TILES_PER_WG + wv;
-    if (tile >= n_tiles_total) return;
+    const int tile = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
+    if (tile < 0) return;
     const int tiles_per_cam = tile_w * tile_h;
     const int cam = tile / tiles_per_cam;
     const int tl = tile - cam * tiles_per_cam;
@@ -502,8 +512,8 @@ int mobgs_pack_records(int C, int N, int channels, const float* means2d, const f
 int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const float* means2d,
                      const float* conics, const float* colors, int colors_per_camera, const float* opacities,
                      int opac_per_camera, const float* extra, const float* backgrounds, const int32_t* radii,
-                     const int32_t* tile_offsets, const int32_t* flatten_ids, float* records, float* render,
-                     float* alphas, int32_t* last_ids, void* stream) {
+                     const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
+                     float* records, float* render, float* alphas, int32_t* last_ids, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int D = channels + (extra ? 1 : 0);
     if (C <= 0 || N < 0 || channels < 0 || D < 1 || width <= 0 || height <= 0) {
@@ -524,7 +534,7 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
         constexpr int CD = decltype(cd)::value;
         hipLaunchKernelGGL(raster_fwd_kernel<CD>, dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups, tile_w,
                            tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render, alphas,
-                           last_ids);
+                           last_ids, tile_order);
     });
     if (rc != MOBGS_OK) {
         set_error("mobgs_raster_fwd: %d total channels not compiled in (pad to a supported count)", D);
@@ -536,8 +546,9 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
 int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int height, const float* records,
                      const float* backgrounds, const int32_t* radii, const float* means2d,
                      const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
-                     const int32_t* flatten_ids, const float* render_alphas, const int32_t* last_ids,
-                     const float* v_render, const float* v_alphas, float* grad_slots, void* stream) {
+                     const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
+                     const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
+                     void* stream) {
     hipStream_t st = (hipStream_t)stream;
     (void)means2d;
     const int D = channels + (has_extra ? 1 : 0);
@@ -554,7 +565,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
         constexpr int CD = decltype(cd)::value;
         hipLaunchKernelGGL(raster_bwd_kernel<CD>, dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups, tile_w,
                            tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan, tile_offsets,
-                           flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots);
+                           flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots, tile_order);
     });
     if (rc != MOBGS_OK) {
         set_error("mobgs_raster_bwd: %d total channels not compiled in", D);

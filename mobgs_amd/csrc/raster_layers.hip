@@ -91,18 +91,25 @@ template <int CD>
 __global__ void __launch_bounds__(64 * LWAVES)
 raster_layers_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height, int N, int Ns,
                          int layer_mask, const float* __restrict__ records, const float* __restrict__ backgrounds,
-                         const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-                         LayerOut out_ptrs) {
+                         const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ tile_order,
+                         const int32_t* __restrict__ flatten_ids, LayerOut out_ptrs) {
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
     __shared__ float4 slab[LWAVES][64][RQ];
     __shared__ int cls_of[LWAVES][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int group = xcd_chunked(blockIdx.x, n_groups);
-    if (group >= n_groups) return;
-    const int tile = group * 2 + (wv >> 1);
     const int half = wv & 1;
-    if (tile >= n_tiles_total) return;
+    int tile;
+    if (tile_order) {  // heaviest-first schedule (see tile_scan_kernel); otherwise XCD-chunked raster order
+        const int slot = blockIdx.x * 2 + (wv >> 1);
+        if (slot >= n_tiles_total) return;
+        tile = tile_order[slot];
+    } else {
+        const int group = xcd_chunked(blockIdx.x, n_groups);
+        if (group >= n_groups) return;
+        tile = group * 2 + (wv >> 1);
+        if (tile >= n_tiles_total) return;
+    }
     const int tiles_per_cam = tile_w * tile_h;
     const int cam = tile / tiles_per_cam;
     const int tl = tile - cam * tiles_per_cam;
@@ -301,8 +308,8 @@ raster_layers_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
                          int layer_mask, const float* __restrict__ records, const float* __restrict__ backgrounds,
                          const int32_t* __restrict__ radii, const int32_t* __restrict__ cum_tiles,
                          const int32_t* __restrict__ keep_scan, const int32_t* __restrict__ tile_offsets,
-                         const int32_t* __restrict__ flatten_ids, LayerIn in_ptrs, float* __restrict__ grad_slots,
-                         float* __restrict__ grad_xy0) {
+                         const int32_t* __restrict__ tile_order, const int32_t* __restrict__ flatten_ids, LayerIn in_ptrs,
+                         float* __restrict__ grad_slots, float* __restrict__ grad_xy0) {
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
     constexpr int NV = 6 + CD;
@@ -311,11 +318,18 @@ raster_layers_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
     __shared__ int slot_of[LWAVES][64];
     __shared__ int cls_of[LWAVES][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int group = xcd_chunked(blockIdx.x, n_groups);
-    if (group >= n_groups) return;
-    const int tile = group * 2 + (wv >> 1);
     const int half = wv & 1;
-    if (tile >= n_tiles_total) return;
+    int tile;
+    if (tile_order) {  // heaviest-first schedule (see tile_scan_kernel); otherwise XCD-chunked raster order
+        const int slot = blockIdx.x * 2 + (wv >> 1);
+        if (slot >= n_tiles_total) return;
+        tile = tile_order[slot];
+    } else {
+        const int group = xcd_chunked(blockIdx.x, n_groups);
+        if (group >= n_groups) return;
+        tile = group * 2 + (wv >> 1);
+        if (tile >= n_tiles_total) return;
+    }
     const int tiles_per_cam = tile_w * tile_h;
     const int cam = tile / tiles_per_cam;
     const int tl = tile - cam * tiles_per_cam;
@@ -469,7 +483,7 @@ extern "C" {
 
 int mobgs_raster_layers_fwd(int C, int N, int Ns, int layer_mask, int channels_total, int width, int height,
                             const float* records, const float* backgrounds, const int32_t* tile_offsets,
-                            const int32_t* flatten_ids, float* const* render3_host, float* const* alphas3_host,
+                            const int32_t* tile_order, const int32_t* flatten_ids, float* const* render3_host, float* const* alphas3_host,
                             int32_t* const* last_ids3_host, void* stream) {
     if (C <= 0 || N < 0 || Ns < 0 || Ns > N || channels_total != 10 || !(layer_mask & 7)) {
         set_error("mobgs_raster_layers_fwd: unsupported arguments (C=%d N=%d Ns=%d D=%d mask=%d)", C, N, Ns,
@@ -491,15 +505,16 @@ int mobgs_raster_layers_fwd(int C, int N, int Ns, int layer_mask, int channels_t
     const int n_groups = (nt + 1) / 2;
     const int grid = ((n_groups + 7) / 8) * 8;
     hipLaunchKernelGGL(raster_layers_fwd_kernel<10>, dim3(grid), dim3(64 * LWAVES), 0, (hipStream_t)stream, nt, n_groups,
-                       tile_w, tile_h, width, height, N, Ns, layer_mask, records, backgrounds, tile_offsets, flatten_ids,
-                       o);
+                       tile_w, tile_h, width, height, N, Ns, layer_mask, records, backgrounds, tile_offsets, tile_order,
+                       flatten_ids, o);
     return check_launch("raster_layers_fwd_kernel");
 }
 
 int mobgs_raster_layers_bwd(int C, int N, int Ns, int layer_mask, int channels, int has_extra, int width, int height,
                             const float* records, const float* backgrounds, const int32_t* radii,
                             const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
-                            const int32_t* flatten_ids, const float* const* render_alphas3_host,
+                            const int32_t* tile_order, const int32_t* flatten_ids,
+                            const float* const* render_alphas3_host,
                             const int32_t* const* last_ids3_host, const float* const* v_render3_host,
                             const float* const* v_alphas3_host, float* grad_slots, float* grad_xy0,
                             float* v_means2d_layer0, float* v_means2d, float* v_conics, float* v_opacities,
@@ -527,7 +542,7 @@ int mobgs_raster_layers_bwd(int C, int N, int Ns, int layer_mask, int channels, 
     const int grid = ((n_groups + 7) / 8) * 8;
     hipLaunchKernelGGL(raster_layers_bwd_kernel<10>, dim3(grid), dim3(64 * LWAVES), 0, st, nt, n_groups, tile_w, tile_h,
                        width, height, N, Ns, layer_mask, records, backgrounds, radii, cum_tiles, keep_scan, tile_offsets,
-                       flatten_ids, in, grad_slots, grad_xy0);
+                       tile_order, flatten_ids, in, grad_slots, grad_xy0);
     const int n = C * N;
     if (n > 0)
         hipLaunchKernelGGL(layers_slot_reduce_kernel, dim3((int)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, n,

@@ -109,10 +109,12 @@ class TileLists:
     """Per-tile depth-ordered splat lists of one rasterization call."""
 
     __slots__ = ("C", "N", "tile_w", "tile_h", "n_box", "n_isects", "max_tile_len", "cum_tiles", "keep_scan",
-                 "tile_offsets", "flatten_ids", "isect_ids")
+                 "tile_offsets", "tile_order", "flatten_ids", "isect_ids")
 
 
 _tile_culling = True
+# True: the compositing kernels take tiles heaviest-list-first (TileLists.tile_order); False: raster order
+TILE_SCHEDULE = True
 _capacity = {}  # device index -> current capacity of the keep-flag buffer (grows geometrically, never shrinks)
 
 
@@ -140,6 +142,7 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Ten
     tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
     tl.cum_tiles = torch.empty(C * N + 1, dtype=torch.int32, device=dev)
     tl.tile_offsets = torch.empty(nt + 1, dtype=torch.int32, device=dev)
+    tl.tile_order = torch.empty(nt, dtype=torch.int32, device=dev) if TILE_SCHEDULE else None
     stats = torch.empty(3, dtype=torch.int64, device=dev)
     opac = f32c(opacities)
     key = dev.index if dev.index is not None else -1
@@ -150,7 +153,7 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Ten
         check(lib.mobgs_isect_offsets(C, N, tile_w, tile_h, width, height, int(_tile_culling), cap,
                                       ptr(tiles_per_gauss), ptr(means2d), ptr(radii), ptr(conics), ptr(opac),
                                       1 if opac.dim() == 2 else 0, ptr(tl.cum_tiles), ptr(tl.keep_scan),
-                                      ptr(tl.tile_offsets), ptr(stats), ptr(scratch), stream()),
+                                      ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(stats), ptr(scratch), stream()),
               "mobgs_isect_offsets")
         n_box, n_isects, max_len = (int(v) for v in stats.tolist())  # the pipeline's one host sync (as in gsplat)
         if n_box <= cap:
@@ -205,7 +208,7 @@ class _Rasterize(torch.autograd.Function):
         with profiler.region("raster_fwd"):
             check(lib.mobgs_raster_fwd(C, N, channels, width, height, ptr(means2d), ptr(conics), ptr(colors),
                                        colors_per_camera, ptr(opacities), opac_per_camera, ptr(extra), ptr(bg),
-                                       ptr(radii), ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(records),
+                                       ptr(radii), ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(records),
                                        ptr(render), ptr(alphas), ptr(last_ids), stream()), "mobgs_raster_fwd")
         ctx.save_for_backward(records, bg, radii, means2d, alphas, last_ids)
         ctx.tl = tl
@@ -233,7 +236,8 @@ class _Rasterize(torch.autograd.Function):
         with profiler.region("raster_bwd"):
             check(lib.mobgs_raster_bwd(C, N, channels, int(has_extra), width, height, ptr(records), ptr(bg),
                                        ptr(radii), ptr(means2d), ptr(tl.cum_tiles), ptr(tl.keep_scan),
-                                       ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(alphas), ptr(last_ids),
+                                       ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas),
+                                       ptr(last_ids),
                                        ptr(v_render), ptr(v_alphas), ptr(slots), stream()), "mobgs_raster_bwd")
         check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(tl.cum_tiles), ptr(tl.keep_scan),
                                           ptr(slots),
@@ -287,7 +291,8 @@ class _RasterizeLayers(torch.autograd.Function):
             lasts.append(torch.empty(C, height, width, dtype=torch.int32, device=dev) if on else None)
         with profiler.region("raster_layers_fwd"):
             check(lib.mobgs_raster_layers_fwd(C, N, Ns, mask, D, width, height, ptr(records), ptr(bg),
-                                              ptr(tl.tile_offsets), ptr(tl.flatten_ids), _ptr3(renders),
+                                              ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids),
+                                              _ptr3(renders),
                                               _ptr3(alphas), _ptr3(lasts), stream()), "mobgs_raster_layers_fwd")
         ctx.save_for_backward(records, bg, radii, *[t for t in alphas + lasts if t is not None])
         ctx.tl = tl
@@ -328,7 +333,8 @@ class _RasterizeLayers(torch.autograd.Function):
         with profiler.region("raster_layers_bwd"):
             check(lib.mobgs_raster_layers_bwd(C, N, Ns, mask, channels, 1, width, height, ptr(records), ptr(bg),
                                               ptr(radii), ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(tl.tile_offsets),
-                                              ptr(tl.flatten_ids), _ptr3(alphas), _ptr3(lasts), _ptr3(v_render),
+                                              ptr(tl.tile_order), ptr(tl.flatten_ids), _ptr3(alphas), _ptr3(lasts),
+                                              _ptr3(v_render),
                                               _ptr3(v_alphas), ptr(slots), ptr(slots_xy0), ptr(v_means2d_l0),
                                               ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra),
                                               stream()), "mobgs_raster_layers_bwd")
@@ -364,6 +370,7 @@ class _ProjectAndBin(torch.autograd.Function):
         tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
         cum_tiles = torch.empty(C * N + 1, dtype=torch.int32, device=dev)
         tile_offsets = torch.empty(nt + 1, dtype=torch.int32, device=dev)
+        tile_order = torch.empty(nt, dtype=torch.int32, device=dev) if TILE_SCHEDULE else None
         stats_dev = torch.empty(3, dtype=torch.int64, device=dev)
         stats_host = (ctypes.c_int64 * 3)()
         key = dev.index if dev.index is not None else -1
@@ -379,7 +386,7 @@ class _ProjectAndBin(torch.autograd.Function):
                                            1 if opac.dim() == 2 else 0, width, height, eps2d, near_plane, far_plane,
                                            radius_clip, int(_tile_culling), ptr(radii), ptr(means2d), ptr(depths),
                                            ptr(conics), ptr(tiles_per_gauss), ptr(cum_tiles), ptr(tile_offsets),
-                                           ptr(stats_dev), cap_box, ptr(keep_scan), ptr(scratch), cap_listed,
+                                           ptr(tile_order), ptr(stats_dev), cap_box, ptr(keep_scan), ptr(scratch), cap_listed,
                                            ptr(flatten_ids), ptr(sort_keys), ptr(isect_ids), stats_host, stream())
             if rc != -4:  # MOBGS_E_CAPACITY: grow the arena (first call on a denser scene) and redo
                 check(rc, "mobgs_project_and_bin")
@@ -390,7 +397,7 @@ class _ProjectAndBin(torch.autograd.Function):
         n_box, n_isects, max_len = int(stats_host[0]), int(stats_host[1]), int(stats_host[2])
         tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
         tl.n_box, tl.n_isects, tl.max_tile_len = n_box, n_isects, max_len
-        tl.cum_tiles, tl.keep_scan, tl.tile_offsets = cum_tiles, keep_scan, tile_offsets
+        tl.cum_tiles, tl.keep_scan, tl.tile_offsets, tl.tile_order = cum_tiles, keep_scan, tile_offsets, tile_order
         tl.flatten_ids = flatten_ids[:n_isects]
         tl.isect_ids = isect_ids[:n_isects] if isect_ids is not None else None
         last_stats.update(n_isects=n_isects, n_box=n_box, max_tile_len=max_len, n_tiles=nt)

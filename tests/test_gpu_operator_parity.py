@@ -192,6 +192,44 @@ def test_tile_culling_is_bit_exact(hip_device, mode, channels):
         assert all(x in it for x in sub), f"tile {tile}: not a sub-sequence"
 
 
+def test_tile_schedule_is_a_permutation_and_changes_nothing(hip_device):
+    """TileLists.tile_order: every tile exactly once, list lengths non-increasing up to the width of one length
+    class; images and gradients are bit-identical with the schedule on or off (it only reorders workgroups)."""
+    from mobgs_amd import rendering
+    n, w, h = 6000, 200, 152
+    s, _ = _scene(n, w, h, 21, 9)
+    names = ["means", "quats", "scales", "opacities", "colors", "viewmats"]
+    res = {}
+    for sched in (False, True):
+        rendering.TILE_SCHEDULE = sched
+        try:
+            t = {k: v.to(hip_device).clone().requires_grad_(k in names) for k, v in s.items()}
+            sp = rendering.SharedProjection(t["means"], t["quats"], t["scales"], t["opacities"], t["viewmats"],
+                                            t["Ks"], w, h)
+            img, a = sp.composite(t["colors"])
+            g = torch.Generator().manual_seed(7)
+            v_img = torch.randn(img.shape, generator=g).to(hip_device)
+            ((img * v_img).sum() + a.sum()).backward()
+            res[sched] = (img.detach().cpu(), a.detach().cpu(),
+                          {k: t[k].grad.cpu() for k in names if t[k].grad is not None})
+            if sched:
+                off = sp.tl.tile_offsets.cpu()
+                lens = (off[1:] - off[:-1])
+                order = sp.tl.tile_order.cpu().long()
+                assert sorted(order.tolist()) == list(range(lens.numel()))
+                ol = lens[order]
+                width_of_class = int(lens.max()) // 1023 + 1
+                assert bool((ol[1:] <= ol[:-1] + width_of_class).all())
+                assert int(ol[0]) >= int(lens.max()) - width_of_class
+            else:
+                assert sp.tl.tile_order is None
+        finally:
+            rendering.TILE_SCHEDULE = True
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for k in res[False][2]:
+        assert torch.equal(res[True][2][k], res[False][2][k]), k
+
+
 @pytest.mark.parametrize("n,w,h,scale", [(3000, 48, 32, 8.0), (12000, 64, 48, 3.0), (40000, 64, 48, 3.0)])
 def test_long_tile_lists_sort_exactly(hip_device, n, w, h, scale):
     """Few tiles, many big splats: per-tile lists of several hundred to > 4096 entries exercise the multi-chunk
