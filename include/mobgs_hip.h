@@ -93,13 +93,16 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
  *      stats int64[3] = {I_box, I_listed, longest per-tile list}; the caller reads them back to size the list
  *      buffers (the one host sync of the pipeline, as in gsplat).  If I_box > capacity the flags were
  *      truncated: call again with capacity >= I_box.
+ * capacity_listed > 0 (speculative callers, see mobgs_isect_emit_sort_speculative): when I_box > capacity or
+ *      I_listed > capacity_listed, tile_offsets is written as all zeros (every list empty) so that consumers
+ *      already enqueued behind this call touch nothing; stats still hold the true counts.  <= 0: no such check.
  * scratch: mobgs_isect_scratch_bytes(C*N, C*n_tiles, capacity) bytes. */
 size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity);
 int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
                         const int32_t* tiles_per_gauss, const float* means2d, const int32_t* radii,
                         const float* conics, const float* opacities, int opac_per_camera,
                         int32_t* cum_tiles, int32_t* keep_scan, int32_t* tile_offsets, int32_t* tile_order,
-                        int64_t* stats, void* scratch, void* stream);
+                        int64_t capacity_listed, int64_t* stats, void* scratch, void* stream);
 
 /* ---- K3b/K4: emit + per-tile depth sort (replaces isect_tiles pass 2 + CUB DeviceRadixSort) ------------
  * Writes, per tile, its listed splats ordered by (float depth bits ascending, flat id ascending) -- the order a
@@ -112,6 +115,17 @@ int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int capacity, in
                           int64_t max_tile_len, const float* depths, const int32_t* cum_tiles,
                           const int32_t* tile_offsets, const void* offsets_scratch, uint64_t* sort_keys,
                           int32_t* flatten_ids, uint64_t* isect_ids, void* stream);
+
+/* The same stage enqueued BEFORE the counts are known on the host: the kernels read them from stats_dev (the
+ * buffer mobgs_isect_offsets filled, called with the same capacity / capacity_listed) and do nothing when the
+ * arena is too small.  max_tile_len_hint only selects the sort variant (any list length sorts correctly with
+ * either; pass the previous frame's longest list).  sort_keys / flatten_ids / isect_ids hold capacity_listed
+ * entries. */
+int mobgs_isect_emit_sort_speculative(int C, int N, int tile_w, int tile_h, int capacity, int64_t capacity_listed,
+                                      int64_t max_tile_len_hint, const float* depths, const int32_t* cum_tiles,
+                                      const int32_t* tile_offsets, const int64_t* stats_dev,
+                                      const void* offsets_scratch, uint64_t* sort_keys, int32_t* flatten_ids,
+                                      uint64_t* isect_ids, void* stream);
 
 /* ---- K1 + K3-K5 in one call: projection -> offsets (+ reach test) -> read-back -> emit -> per-tile sort ------
  * Same stages and buffers as mobgs_project_fwd + mobgs_isect_offsets + mobgs_isect_emit_sort, driven natively so
@@ -129,6 +143,22 @@ int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, 
                           int32_t* tile_order, int64_t* stats_dev, int capacity_box, int32_t* keep_scan, void* scratch,
                           int64_t capacity_listed, int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
                           int64_t* stats_host, void* stream);
+
+/* mobgs_project_and_bin WITHOUT the host synchronisation: every stage is enqueued, the three counts are copied
+ * asynchronously into stats_host_pinned (page-locked host memory, valid once the caller has waited on an event
+ * recorded after this call) and the function returns.  When the arena turns out too small (counts exceed
+ * capacity_box / capacity_listed) every per-tile list was written EMPTY: compositing kernels enqueued in the
+ * meantime are harmless no-ops, and the caller redoes the binning with a larger arena (mobgs_isect_offsets +
+ * mobgs_isect_emit_sort on the projection outputs, which do not depend on the arena). */
+int mobgs_project_and_bin_speculative(int C, int N, const float* means, const float* quats, const float* scales,
+                                      const float* viewmats, const float* Ks, const float* opacities,
+                                      int opac_per_camera, int width, int height, float eps2d, float near_plane,
+                                      float far_plane, float radius_clip, int cull, int32_t* radii, float* means2d,
+                                      float* depths, float* conics, int32_t* tiles_per_gauss, int32_t* cum_tiles,
+                                      int32_t* tile_offsets, int32_t* tile_order, int64_t* stats_dev,
+                                      int capacity_box, int32_t* keep_scan, void* scratch, int64_t capacity_listed,
+                                      int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
+                                      int64_t max_tile_len_hint, int64_t* stats_host_pinned, void* stream);
 
 /* ---- K6: rasterise forward (replaces gsplat rasterize_to_pixels fwd) -----------------------------------
  * colors   : [C,N,channels] (colors_per_camera=1) or [N,channels] (0)

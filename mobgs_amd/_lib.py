@@ -27,7 +27,7 @@ _SIGS = {
     "mobgs_project_bwd": (c_int, [c_int, c_int, P, P, P, P, P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P,
                                   P, P]),
     "mobgs_isect_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "mobgs_isect_offsets": (c_int, [c_int] * 8 + [P] * 5 + [c_int] + [P] * 6 + [P]),
+    "mobgs_isect_offsets": (c_int, [c_int] * 8 + [P] * 5 + [c_int] + [P] * 4 + [c_int64] + [P] * 2 + [P]),
     "mobgs_isect_emit_sort": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int64, c_int64] + [P] * 7 + [P]),
     "mobgs_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, P, P,
                                  P, P, P, P]),
@@ -35,6 +35,10 @@ _SIGS = {
     "mobgs_raster_bwd_reduce": (c_int, [c_int, c_int, c_int, c_int] + [P] * 8 + [P]),
     "mobgs_project_and_bin": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
                                       c_float, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, P, P, P]),
+    "mobgs_isect_emit_sort_speculative": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int64, c_int64] + [P] * 8 + [P]),
+    "mobgs_project_and_bin_speculative": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float,
+                                                  c_float, c_float, c_float, c_int, P, P, P, P, P, P, P, P, P, c_int,
+                                                  P, P, c_int64, P, P, P, c_int64, P, P]),
     "mobgs_pack_records": (c_int, [c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P]),
     "mobgs_raster_layers_fwd": (c_int, [c_int] * 7 + [P] * 8 + [P]),
     "mobgs_raster_layers_bwd": (c_int, [c_int] * 8 + [P] * 20 + [P]),  # incl. 7 host pointer arrays of length 3
@@ -104,6 +108,26 @@ def ptr(t: Optional[torch.Tensor]):
     if not t.is_contiguous():
         raise RuntimeError("mobgs_amd: internal error, non-contiguous tensor passed to the C ABI")
     return c_void_p(t.data_ptr())
+
+
+class DerivedCache:
+    """One-entry memo for a small tensor derived from other tensors (a padded background row, packed camera
+    parameters ...): rebuilt unless the SAME tensor objects, unmodified since (Tensor._version), are passed again.
+    The sources are kept alive by the entry, so a recycled address can never alias them.  Sources that require grad
+    are never cached (the derived tensor must stay in their autograd graph)."""
+
+    def __init__(self):
+        self.srcs, self.versions, self.value = (), (), None
+
+    def get(self, srcs, build):
+        if any(t.requires_grad for t in srcs):
+            return build()
+        if len(srcs) == len(self.srcs) and all(a is b for a, b in zip(srcs, self.srcs)) and \
+                all(t._version == v for t, v in zip(srcs, self.versions)):
+            return self.value
+        value = build()
+        self.srcs, self.versions, self.value = tuple(srcs), tuple(t._version for t in srcs), value
+        return value
 
 
 def stream():

@@ -191,7 +191,8 @@ constexpr int ORDER_BUCKETS = 1024;
 __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(int nt, const int32_t* __restrict__ tile_count,
                                                                    int32_t* __restrict__ tile_offsets,
                                                                    int64_t* __restrict__ stats,
-                                                                   int32_t* __restrict__ tile_order) {
+                                                                   int32_t* __restrict__ tile_order,
+                                                                   int64_t capacity_box, int64_t capacity_listed) {
     __shared__ int smax[SCAN_THREADS];
     __shared__ int hist[ORDER_BUCKETS];
     int carry = 0, mx = 0;
@@ -214,6 +215,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(int nt, const i
     if (threadIdx.x == 0) {
         tile_offsets[nt] = carry;
         stats[2] = (int64_t)longest;
+    }
+    // Arena too small (only checked when the caller runs ahead of the read-back, capacity_listed > 0): hand every
+    // consumer EMPTY lists, so that kernels already enqueued behind this one touch nothing; stats keep the true
+    // counts and the host redoes the binning with a larger arena.
+    if (capacity_listed > 0 && (stats[0] > capacity_box || (int64_t)carry > capacity_listed)) {
+        __syncthreads();
+        for (int i = threadIdx.x; i <= nt; i += SCAN_THREADS) tile_offsets[i] = 0;
     }
     if (!tile_order) return;
     auto bucket = [&](int len) {
@@ -255,8 +263,11 @@ __global__ void __launch_bounds__(256) emit_kernel(const int32_t* __restrict__ n
                                                      const int32_t* __restrict__ rank_of_j,
                                                      const float* __restrict__ depths,
                                                      const int32_t* __restrict__ tile_offsets,
-                                                     uint64_t* __restrict__ sort_keys) {
-    const int I = *n_box_ptr;
+                                                     uint64_t* __restrict__ sort_keys, int capacity,
+                                                     const int64_t* __restrict__ stats, int64_t capacity_listed) {
+    // speculative launch (stats != NULL): nothing to do when the arena was too small (see tile_scan_kernel)
+    if (stats && (stats[0] > (int64_t)capacity || stats[1] > capacity_listed)) return;
+    const int I = min(*n_box_ptr, capacity);
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < I; j += gridDim.x * blockDim.x) {
         if (!flags[j]) continue;
         const int g = owner[j];
@@ -422,8 +433,8 @@ size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity) {
 int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
                         const int32_t* tiles_per_gauss, const float* means2d, const int32_t* radii,
                         const float* conics, const float* opacities, int opac_per_camera, int32_t* cum_tiles,
-                        int32_t* keep_scan, int32_t* tile_offsets, int32_t* tile_order, int64_t* stats,
-                        void* scratch, void* stream) {
+                        int32_t* keep_scan, int32_t* tile_offsets, int32_t* tile_order, int64_t capacity_listed,
+                        int64_t* stats, void* scratch, void* stream) {
     const long long ng = (long long)C * N;
     const long long nt = (long long)C * tile_w * tile_h;
     if (C <= 0 || N < 0 || capacity < 1 || ng >= (1ll << 31) - 1 || nt >= (1ll << 31) - 1) {
@@ -444,7 +455,7 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
         hipMemsetAsync(keep_scan, 0, sizeof(int32_t), st);
         hipMemsetAsync(stats, 0, 3 * sizeof(int64_t), st);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, (int)nt, tile_count, tile_offsets,
-                           stats, tile_order);
+                           stats, tile_order, (int64_t)capacity, (int64_t)0);
         return check_launch("isect_offsets(empty)");
     }
     // bounding-box counts -> cum_tiles; stats[0] = I_box
@@ -471,14 +482,15 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nb2), dim3(SCAN_THREADS), 0, st, n_ptr, capacity, flags, block_sums2,
                        keep_scan);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, (int)nt, tile_count, tile_offsets,
-                       stats, tile_order);
+                       stats, tile_order, (int64_t)capacity, capacity_listed);
     return check_launch("isect_offsets");
 }
 
-int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t n_isects,
-                          int64_t max_tile_len, const float* depths, const int32_t* cum_tiles,
-                          const int32_t* tile_offsets, const void* offsets_scratch, uint64_t* sort_keys,
-                          int32_t* flatten_ids, uint64_t* isect_ids, void* stream) {
+// shared by the synchronous entry point (stats_dev = NULL: the caller has read the counts) and the speculative one
+static int emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t n_isects, int64_t max_tile_len,
+                     const float* depths, const int32_t* cum_tiles, const int32_t* tile_offsets,
+                     const void* offsets_scratch, uint64_t* sort_keys, int32_t* flatten_ids, uint64_t* isect_ids,
+                     const int64_t* stats_dev, int64_t capacity_listed, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int tiles_per_cam = tile_w * tile_h;
     const int nt = C * tiles_per_cam;
@@ -496,7 +508,7 @@ int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int capacity, in
     const int32_t* tile_of_j = owner + capacity;
     const int32_t* rank_of_j = tile_of_j + capacity;
     hipLaunchKernelGGL(emit_kernel, dim3(4096), dim3(256), 0, st, cum_tiles + n, flags, owner, tile_of_j, rank_of_j,
-                       depths, tile_offsets, sort_keys);
+                       depths, tile_offsets, sort_keys, capacity, stats_dev, capacity_listed);
     // gsplat: tile_n_bits = floor(log2(n_tiles)) + 1
     int tile_bits = 0;
     while ((1ll << tile_bits) <= (long long)tiles_per_cam) ++tile_bits;
@@ -510,6 +522,28 @@ int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int capacity, in
                            tile_bits, tile_offsets, sort_keys, flatten_ids, isect_ids, tiles_per_cam);
     }
     return check_launch("isect_emit_sort");
+}
+
+int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t n_isects,
+                          int64_t max_tile_len, const float* depths, const int32_t* cum_tiles,
+                          const int32_t* tile_offsets, const void* offsets_scratch, uint64_t* sort_keys,
+                          int32_t* flatten_ids, uint64_t* isect_ids, void* stream) {
+    return emit_sort(C, N, tile_w, tile_h, capacity, n_isects, max_tile_len, depths, cum_tiles, tile_offsets,
+                     offsets_scratch, sort_keys, flatten_ids, isect_ids, nullptr, 0, stream);
+}
+
+int mobgs_isect_emit_sort_speculative(int C, int N, int tile_w, int tile_h, int capacity, int64_t capacity_listed,
+                                      int64_t max_tile_len_hint, const float* depths, const int32_t* cum_tiles,
+                                      const int32_t* tile_offsets, const int64_t* stats_dev,
+                                      const void* offsets_scratch, uint64_t* sort_keys, int32_t* flatten_ids,
+                                      uint64_t* isect_ids, void* stream) {
+    if (!stats_dev || capacity_listed < 1) {
+        set_error("mobgs_isect_emit_sort_speculative: stats_dev and capacity_listed are required");
+        return MOBGS_E_INVALID;
+    }
+    return emit_sort(C, N, tile_w, tile_h, capacity, /*n_isects (unknown, > 0)*/ 1, max_tile_len_hint, depths,
+                     cum_tiles, tile_offsets, offsets_scratch, sort_keys, flatten_ids, isect_ids, stats_dev,
+                     capacity_listed, stream);
 }
 
 }  // extern "C"

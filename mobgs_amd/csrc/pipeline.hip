@@ -28,7 +28,8 @@ int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, 
                                radius_clip, radii, means2d, depths, conics, tiles_per_gauss, stream);
     if (rc != MOBGS_OK) return rc;
     rc = mobgs_isect_offsets(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d, radii,
-                             conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order, stats_dev, scratch,
+                             conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order, /*capacity_listed (checked on the host)*/ 0,
+                             stats_dev, scratch,
                              stream);
     if (rc != MOBGS_OK) return rc;
     // the pipeline's one host synchronisation (upstream gsplat has the same one): {I_box, I_listed, longest list}
@@ -50,6 +51,38 @@ int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, 
     }
     return mobgs_isect_emit_sort(C, N, tile_w, tile_h, capacity_box, stats_host[1], stats_host[2], depths, cum_tiles,
                                  tile_offsets, scratch, sort_keys, flatten_ids, isect_ids, stream);
+}
+
+int mobgs_project_and_bin_speculative(int C, int N, const float* means, const float* quats, const float* scales,
+                                      const float* viewmats, const float* Ks, const float* opacities,
+                                      int opac_per_camera, int width, int height, float eps2d, float near_plane,
+                                      float far_plane, float radius_clip, int cull, int32_t* radii, float* means2d,
+                                      float* depths, float* conics, int32_t* tiles_per_gauss, int32_t* cum_tiles,
+                                      int32_t* tile_offsets, int32_t* tile_order, int64_t* stats_dev,
+                                      int capacity_box, int32_t* keep_scan, void* scratch, int64_t capacity_listed,
+                                      int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
+                                      int64_t max_tile_len_hint, int64_t* stats_host_pinned, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
+    if (!stats_host_pinned || capacity_listed < 1) {
+        set_error("mobgs_project_and_bin_speculative: stats_host_pinned and capacity_listed are required");
+        return MOBGS_E_INVALID;
+    }
+    int rc = mobgs_project_fwd(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                               radius_clip, radii, means2d, depths, conics, tiles_per_gauss, stream);
+    if (rc != MOBGS_OK) return rc;
+    rc = mobgs_isect_offsets(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d, radii,
+                             conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order,
+                             capacity_listed, stats_dev, scratch, stream);
+    if (rc != MOBGS_OK) return rc;
+    hipError_t e = hipMemcpyAsync(stats_host_pinned, stats_dev, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) {
+        set_error("mobgs_project_and_bin_speculative: statistics copy failed: %s", hipGetErrorString(e));
+        return MOBGS_E_LAUNCH;
+    }
+    return mobgs_isect_emit_sort_speculative(C, N, tile_w, tile_h, capacity_box, capacity_listed, max_tile_len_hint,
+                                             depths, cum_tiles, tile_offsets, stats_dev, scratch, sort_keys,
+                                             flatten_ids, isect_ids, stream);
 }
 
 }  // extern "C"

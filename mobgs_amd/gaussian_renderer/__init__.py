@@ -19,6 +19,7 @@ from __future__ import annotations
 import torch
 
 from .. import rendering as _R
+from .._lib import DerivedCache
 from ..ops import PrepSplats, decode
 from . import network_gui  # noqa: F401  (train.py imports it from here)
 
@@ -37,22 +38,30 @@ _PENDING = object()
 
 
 class RenderResult(dict):
-    """The reference's result dict; entries registered with defer() are materialised on first access."""
+    """The reference's result dict; entries registered with defer() are materialised on first access (each defer()
+    call registers one group of keys computed together by `thunk() -> {key: value}`)."""
 
     def defer(self, keys, thunk):
-        self._thunk = thunk
+        if not hasattr(self, "_thunks"):
+            self._thunks = {}
         for k in keys:
             dict.__setitem__(self, k, _PENDING)
+            self._thunks[k] = thunk
 
-    def _materialise(self):
-        thunk, self._thunk = getattr(self, "_thunk", None), None
-        if thunk is not None:
+    def _materialise(self, key=None):
+        thunks = getattr(self, "_thunks", None)
+        if not thunks:
+            return
+        todo = [thunks[key]] if key is not None else list({id(t): t for t in thunks.values()}.values())
+        for thunk in todo:
+            for k in [k for k, t in thunks.items() if t is thunk]:
+                del thunks[k]
             dict.update(self, thunk())
 
     def __getitem__(self, key):
         v = dict.__getitem__(self, key)
         if v is _PENDING:
-            self._materialise()
+            self._materialise(key)
             v = dict.__getitem__(self, key)
         return v
 
@@ -123,6 +132,14 @@ def _rays_of(cam):
     return cam.cam_ray
 
 
+_bg9_cache = DerivedCache()
+
+
+def _bg9(bg_color):
+    """The 9-channel background row the reference builds per call (:77), bg_color[:3] three times, as [1,9]."""
+    return _bg9_cache.get((bg_color,), lambda: torch.cat([bg_color[:3]] * 3, dim=-1)[None])
+
+
 def _decoder_weights(dyn_pc):
     dec = dyn_pc.rgbdecoder
     return dec.mlp1.weight, dec.mlp2.weight
@@ -156,7 +173,8 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     W, H = int(cam.image_width), int(cam.image_height)
     viewmat = cam.world_view_transform.transpose(0, 1) if w2c is None else w2c
     K = cam.K
-    bg = torch.cat([bg_color[:3]] * 3, dim=-1)
+    bg1 = _bg9(bg_color)
+    bg = bg1[0]
     w1, w2 = _decoder_weights(dyn_pc)
     Ns = stat_pc.get_xyz.shape[0]
 
@@ -193,7 +211,7 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     # compositor, the static-only / dynamic-only images (when asked for) from ONE layered walk over the same lists
     # (the reference: 5 rasterizations, :143-176, :201-214, :236-268)
     sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None], K[None], W, H)
-    img, alphas = sp.composite(cols, bg[None])
+    img, alphas = sp.composite(cols, bg1)
     info = sp.meta()
     radii = info["radii"].squeeze(0)
     try:
@@ -215,7 +233,7 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     def aux_images():
         res = {}
         if FUSE_LAYERS:
-            imgs, alps = sp.composite_layers(cols, Ns, bg[None], want_static=get_static, want_dynamic=get_dynamic)
+            imgs, alps = sp.composite_layers(cols, Ns, bg1, want_static=get_static, want_dynamic=get_dynamic)
             if get_dynamic:
                 res["d_render"], d_depth = decode_ed(imgs[2], alps[2])
                 res["d_depth"] = d_depth.unsqueeze(0)
@@ -228,7 +246,7 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
         for name, sl, on in (("d", dyn_sl, get_dynamic), ("s", stat_sl, get_static)):
             if not on:
                 continue
-            x_img, x_a, _ = _raster_acc(raster, sl, cols[sl], bg[None])
+            x_img, x_a, _ = _raster_acc(raster, sl, cols[sl], bg1)
             res[name + "_render"], x_depth = decode_ed(x_img, x_a)
             if name == "d":
                 res["d_depth"] = x_depth.unsqueeze(0)
@@ -245,8 +263,13 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
         out["ori_flow"] = flow_img
         out["ori_coord_map"] = _pixel_grid(cam, W, H, flow_img) + flow_img
 
-    out.update({"viewspace_points": info["means2d"], "visibility_filter": radii > 0, "radii": radii,
-                "means_3d_final": means * 1e2, "colors_precomp_final": cols, "means_3d": means[dyn_sl]})
+    out.update({"viewspace_points": info["means2d"], "radii": radii, "colors_precomp_final": cols,
+                "means_3d": means[dyn_sl]})
+    if LAZY_AUX:  # train.py reads these two from the mid sub-frame only (:448-456), not from the 8 latent ones
+        out.defer(["visibility_filter"], lambda: {"visibility_filter": radii > 0})
+        out.defer(["means_3d_final"], lambda: {"means_3d_final": means * 1e2})
+    else:
+        out.update({"visibility_filter": radii > 0, "means_3d_final": means * 1e2})
     if aux_keys:
         if LAZY_AUX and FUSE_LAYERS:
             out.defer(aux_keys, aux_images)
@@ -288,7 +311,8 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     W, H = int(cam.image_width), int(cam.image_height)
     viewmat = cam.world_view_transform.transpose(0, 1)
     K = cam.K
-    bg = torch.cat([bg_color[:3]] * 3, dim=-1)
+    bg1 = _bg9(bg_color)
+    bg = bg1[0]
     w1, w2 = _decoder_weights(dyn_pc)
     Ns = stat_pc.get_xyz.shape[0]
     mid_m, mid_q, scales, opac, _ = _prep(stat_pc, dyn_pc, _times(cam, None, dev))
@@ -312,7 +336,7 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     pix = _pixel_grid(cam, W, H, e2m_img)
     exp2mid = pix + e2m_img
     mid2exp = pix + splat(sp_mid, -e2m)
-    img, alphas = sp_exp.composite(exp_c, bg[None])
+    img, alphas = sp_exp.composite(exp_c, bg1)
     latent_img, _ = decode(img, alphas, _rays_of(cam), w1, w2, True)
     return exp2mid, mid2exp, latent_img, latent_alpha
 

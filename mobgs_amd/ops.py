@@ -64,6 +64,9 @@ class PrepSplats(torch.autograd.Function):
                 g["d_ft"], None)
 
 
+_raycam_cache = _lib.DerivedCache()
+
+
 class Decode(torch.autograd.Function):
     """Channels-last compositor image (+alpha) -> planar rgb [3,H,W] (+ expected depth [H,W]).
     Rays: either the reference's map `rays` [6,H,W], or (rays=None) the pinhole parameters `intr` = [fx,fy,cx,cy]
@@ -80,7 +83,8 @@ class Decode(torch.autograd.Function):
         rays_c = f32c(rays) if rays is not None else None
         raycam = None
         if rays_c is None:
-            raycam = torch.cat([f32c(intr).reshape(4), f32c(c2w).reshape(12)])
+            raycam = _raycam_cache.get((intr, c2w), lambda: torch.cat([f32c(intr.detach()).reshape(4),
+                                                                       f32c(c2w.detach()).reshape(12)]))
         rgb = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(H, W, dtype=torch.float32, device=dev) if has_depth else None
         check(lib.mobgs_decoder_fwd(P, CF, int(has_depth), W, ptr(feat_hw), ptr(alphas_c), ptr(rays_c), ptr(raycam),

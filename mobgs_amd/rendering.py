@@ -16,7 +16,7 @@ import torch
 from torch import Tensor
 
 from . import _lib, profiler
-from ._lib import check, f32c, ptr, stream
+from ._lib import DerivedCache, check, f32c, ptr, stream
 
 TILE = 16
 # statistics of the most recent build_tile_lists() call (read by bench.py for the roofline line)
@@ -48,6 +48,7 @@ class _Project(torch.autograd.Function):
         ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics)
         ctx.dims = (width, height, eps2d)
         ctx.mark_non_differentiable(radii, tiles_per_gauss)
+        ctx.set_materialize_grads(False)  # no zero tensors for the outputs nothing back-propagates through
         return radii, means2d, depths, conics, tiles_per_gauss
 
     @staticmethod
@@ -106,13 +107,102 @@ def fully_fused_projection(
 # tile intersection lists (no autograd)
 # --------------------------------------------------------------------------------------------------
 class TileLists:
-    """Per-tile depth-ordered splat lists of one rasterization call."""
+    """Per-tile depth-ordered splat lists of one rasterization call.
 
-    __slots__ = ("C", "N", "tile_w", "tile_h", "n_box", "n_isects", "max_tile_len", "cum_tiles", "keep_scan",
-                 "tile_offsets", "tile_order", "flatten_ids", "isect_ids")
+    Lists built speculatively (SPECULATIVE_BINNING) are usable by the compositing kernels at once -- those read the
+    lists through device pointers only -- while the three counts {n_box, n_isects, max_tile_len} are still on their
+    way to the host.  Reading a count (or a count-sized view: flatten_ids, isect_ids) calls resolve(), which waits
+    for them; if the arena was too small the kernels saw EMPTY lists and resolve() rebuilds the lists synchronously
+    with a larger arena and returns True, upon which the caller re-issues what it had enqueued."""
+
+    __slots__ = ("C", "N", "tile_w", "tile_h", "cum_tiles", "keep_scan", "tile_offsets", "tile_order",
+                 "flatten_arena", "_n_box", "_n_isects", "_max_tile_len", "_flatten_ids", "_isect_ids", "_pending")
+
+    def __init__(self):
+        self._pending = None
+
+    @property
+    def pending(self) -> bool:
+        return self._pending is not None
+
+    def resolve(self) -> bool:
+        p, self._pending = self._pending, None
+        return p.finish(self) if p is not None else False
+
+    def _set_counts(self, n_box, n_isects, max_len, flatten_arena, isect_arena):
+        self._n_box, self._n_isects, self._max_tile_len = n_box, n_isects, max_len
+        self.flatten_arena = flatten_arena
+        self._flatten_ids = flatten_arena[:n_isects]
+        self._isect_ids = isect_arena[:n_isects] if isect_arena is not None else None
+
+    n_box = property(lambda self: (self.resolve(), self._n_box)[1])
+    n_isects = property(lambda self: (self.resolve(), self._n_isects)[1])
+    max_tile_len = property(lambda self: (self.resolve(), self._max_tile_len)[1])
+    flatten_ids = property(lambda self: (self.resolve(), self._flatten_ids)[1])
+    isect_ids = property(lambda self: (self.resolve(), self._isect_ids)[1])
+
+
+class _StatsSlots:
+    """Page-locked landing slots (3 x int64 each) for the asynchronous count read-back, one pool per process."""
+
+    def __init__(self, n=256):
+        self.block = torch.empty(n, 3, dtype=torch.int64, pin_memory=True)
+        self.free = list(range(n))
+
+    def take(self):
+        if self.free:
+            i = self.free.pop()
+            return self.block[i], i
+        return torch.empty(3, dtype=torch.int64, pin_memory=True), None
+
+    def give(self, i):
+        if i is not None:
+            self.free.append(i)
+
+
+_stats_slots = None
+
+
+class _PendingCounts:
+    """The read-back half of a speculative mobgs_project_and_bin_speculative call."""
+
+    def __init__(self, row, slot, event, caps, arenas, rebuild_args):
+        self.row, self.slot, self.event = row, slot, event
+        self.caps, self.arenas, self.rebuild_args = caps, arenas, rebuild_args
+
+    def __del__(self):
+        if self.slot is not None and _stats_slots is not None:
+            _stats_slots.give(self.slot)
+            self.slot = None
+
+    def finish(self, tl) -> bool:
+        self.event.synchronize()
+        n_box, n_isects, max_len = (int(v) for v in self.row.tolist())
+        _stats_slots.give(self.slot)
+        self.slot = None
+        key, cap_box, cap_listed = self.caps
+        if n_box <= cap_box and n_isects <= cap_listed:
+            tl._set_counts(n_box, n_isects, max_len, *self.arenas)
+            _len_hint[key] = max_len
+            last_stats.update(n_isects=n_isects, n_box=n_box, max_tile_len=max_len,
+                              n_tiles=tl.C * tl.tile_w * tl.tile_h)
+            return False
+        # arena too small (first frame of a scene, or the scene grew): every kernel enqueued so far saw empty
+        # lists; rebuild synchronously -- the projection outputs do not depend on the arena
+        _capacity[key] = max(_capacity.get(key, 0), int(n_box * 1.25) + 1024)
+        fresh = build_tile_lists(*self.rebuild_args)
+        for name in ("cum_tiles", "keep_scan", "tile_offsets", "tile_order"):
+            setattr(tl, name, getattr(fresh, name))
+        tl._set_counts(fresh._n_box, fresh._n_isects, fresh._max_tile_len, fresh.flatten_arena, fresh._isect_ids)
+        _cap_listed[key] = max(_cap_listed.get(key, 0), int(fresh._n_isects * 1.25) + 1024)
+        _len_hint[key] = fresh._max_tile_len
+        return True
 
 
 _tile_culling = True
+# True: the projection/binning call does not wait for the intersection counts (see TileLists); False: it does
+SPECULATIVE_BINNING = True
+_len_hint = {}  # device index -> longest per-tile list of the previous frame (selects the sort variant)
 # True: the compositing kernels take tiles heaviest-list-first (TileLists.tile_order); False: raster order
 TILE_SCHEDULE = True
 _capacity = {}  # device index -> current capacity of the keep-flag buffer (grows geometrically, never shrinks)
@@ -153,22 +243,23 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Ten
         check(lib.mobgs_isect_offsets(C, N, tile_w, tile_h, width, height, int(_tile_culling), cap,
                                       ptr(tiles_per_gauss), ptr(means2d), ptr(radii), ptr(conics), ptr(opac),
                                       1 if opac.dim() == 2 else 0, ptr(tl.cum_tiles), ptr(tl.keep_scan),
-                                      ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(stats), ptr(scratch), stream()),
+                                      ptr(tl.tile_offsets), ptr(tl.tile_order), 0, ptr(stats), ptr(scratch),
+                                      stream()),
               "mobgs_isect_offsets")
         n_box, n_isects, max_len = (int(v) for v in stats.tolist())  # the pipeline's one host sync (as in gsplat)
         if n_box <= cap:
             break
         cap = int(n_box * 1.25) + 1024  # first call on a denser scene: grow and redo (rare)
     _capacity[key] = cap
-    tl.n_box, tl.n_isects, tl.max_tile_len = n_box, n_isects, max_len
     last_stats.update(n_isects=n_isects, n_box=n_box, max_tile_len=max_len, n_tiles=nt)
-    tl.flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
-    tl.isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev) if want_isect_ids else None
+    flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
+    isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev) if want_isect_ids else None
+    tl._set_counts(n_box, n_isects, max_len, flatten_ids, isect_ids)
     if n_isects > 0:
         keys = torch.empty(n_isects, dtype=torch.int64, device=dev)
         check(lib.mobgs_isect_emit_sort(C, N, tile_w, tile_h, cap, n_isects, max_len, ptr(depths), ptr(tl.cum_tiles),
-                                        ptr(tl.tile_offsets), ptr(scratch), ptr(keys), ptr(tl.flatten_ids),
-                                        ptr(tl.isect_ids), stream()), "mobgs_isect_emit_sort")
+                                        ptr(tl.tile_offsets), ptr(scratch), ptr(keys), ptr(flatten_ids),
+                                        ptr(isect_ids), stream()), "mobgs_isect_emit_sort")
     return tl
 
 
@@ -206,10 +297,14 @@ class _Rasterize(torch.autograd.Function):
         alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
         with profiler.region("raster_fwd"):
-            check(lib.mobgs_raster_fwd(C, N, channels, width, height, ptr(means2d), ptr(conics), ptr(colors),
-                                       colors_per_camera, ptr(opacities), opac_per_camera, ptr(extra), ptr(bg),
-                                       ptr(radii), ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(records),
-                                       ptr(render), ptr(alphas), ptr(last_ids), stream()), "mobgs_raster_fwd")
+            while True:
+                check(lib.mobgs_raster_fwd(C, N, channels, width, height, ptr(means2d), ptr(conics), ptr(colors),
+                                           colors_per_camera, ptr(opacities), opac_per_camera, ptr(extra), ptr(bg),
+                                           ptr(radii), ptr(tl.tile_offsets), ptr(tl.tile_order),
+                                           ptr(tl.flatten_arena), ptr(records), ptr(render), ptr(alphas),
+                                           ptr(last_ids), stream()), "mobgs_raster_fwd")
+                if not tl.resolve():  # speculative lists whose arena was too small were just rebuilt: composite again
+                    break
         ctx.save_for_backward(records, bg, radii, means2d, alphas, last_ids)
         ctx.tl = tl
         ctx.meta = (C, N, channels, extra is not None, width, height, colors_per_camera, opac_per_camera)
@@ -290,10 +385,13 @@ class _RasterizeLayers(torch.autograd.Function):
             alphas.append(torch.empty(C, height, width, dtype=torch.float32, device=dev) if on else None)
             lasts.append(torch.empty(C, height, width, dtype=torch.int32, device=dev) if on else None)
         with profiler.region("raster_layers_fwd"):
-            check(lib.mobgs_raster_layers_fwd(C, N, Ns, mask, D, width, height, ptr(records), ptr(bg),
-                                              ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids),
-                                              _ptr3(renders),
-                                              _ptr3(alphas), _ptr3(lasts), stream()), "mobgs_raster_layers_fwd")
+            while True:
+                check(lib.mobgs_raster_layers_fwd(C, N, Ns, mask, D, width, height, ptr(records), ptr(bg),
+                                                  ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_arena),
+                                                  _ptr3(renders), _ptr3(alphas), _ptr3(lasts), stream()),
+                      "mobgs_raster_layers_fwd")
+                if not tl.resolve():
+                    break
         ctx.save_for_backward(records, bg, radii, *[t for t in alphas + lasts if t is not None])
         ctx.tl = tl
         ctx.meta = (C, N, channels, width, height, colors.dim() == 3, opacities.dim() == 2, Ns, mask)
@@ -382,6 +480,28 @@ class _ProjectAndBin(torch.autograd.Function):
             flatten_ids = torch.empty(cap_listed, dtype=torch.int32, device=dev)
             sort_keys = torch.empty(cap_listed, dtype=torch.int64, device=dev)
             isect_ids = torch.empty(cap_listed, dtype=torch.int64, device=dev) if want_isect_ids else None
+            if SPECULATIVE_BINNING:
+                global _stats_slots
+                if _stats_slots is None:
+                    _stats_slots = _StatsSlots()
+                row, slot = _stats_slots.take()
+                check(lib.mobgs_project_and_bin_speculative(
+                    C, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), ptr(opac),
+                    1 if opac.dim() == 2 else 0, width, height, eps2d, near_plane, far_plane, radius_clip,
+                    int(_tile_culling), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(tiles_per_gauss),
+                    ptr(cum_tiles), ptr(tile_offsets), ptr(tile_order), ptr(stats_dev), cap_box, ptr(keep_scan),
+                    ptr(scratch), cap_listed, ptr(flatten_ids), ptr(sort_keys), ptr(isect_ids),
+                    _len_hint.get(key, 0), ctypes.c_void_p(row.data_ptr()), stream()),
+                    "mobgs_project_and_bin_speculative")
+                event = torch.cuda.Event()
+                event.record()
+                tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
+                tl.cum_tiles, tl.keep_scan, tl.tile_offsets, tl.tile_order = cum_tiles, keep_scan, tile_offsets, tile_order
+                tl.flatten_arena = flatten_ids
+                tl._pending = _PendingCounts(row, slot, event, (key, cap_box, cap_listed), (flatten_ids, isect_ids),
+                                             (means2d, radii, depths, conics, opac, tiles_per_gauss, width, height,
+                                              want_isect_ids))
+                break
             rc = lib.mobgs_project_and_bin(C, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), ptr(opac),
                                            1 if opac.dim() == 2 else 0, width, height, eps2d, near_plane, far_plane,
                                            radius_clip, int(_tile_culling), ptr(radii), ptr(means2d), ptr(depths),
@@ -394,22 +514,25 @@ class _ProjectAndBin(torch.autograd.Function):
             cap_box = max(cap_box, int(stats_host[0] * 1.25) + 1024)
             cap_listed = max(cap_listed, int(stats_host[1] * 1.25) + 1024)
         _capacity[key], _cap_listed[key] = cap_box, cap_listed
-        n_box, n_isects, max_len = int(stats_host[0]), int(stats_host[1]), int(stats_host[2])
-        tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
-        tl.n_box, tl.n_isects, tl.max_tile_len = n_box, n_isects, max_len
-        tl.cum_tiles, tl.keep_scan, tl.tile_offsets, tl.tile_order = cum_tiles, keep_scan, tile_offsets, tile_order
-        tl.flatten_ids = flatten_ids[:n_isects]
-        tl.isect_ids = isect_ids[:n_isects] if isect_ids is not None else None
-        last_stats.update(n_isects=n_isects, n_box=n_box, max_tile_len=max_len, n_tiles=nt)
+        if not tl.pending:
+            n_box, n_isects, max_len = int(stats_host[0]), int(stats_host[1]), int(stats_host[2])
+            tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
+            tl.cum_tiles, tl.keep_scan, tl.tile_offsets, tl.tile_order = cum_tiles, keep_scan, tile_offsets, tile_order
+            tl._set_counts(n_box, n_isects, max_len, flatten_ids, isect_ids)
+            last_stats.update(n_isects=n_isects, n_box=n_box, max_tile_len=max_len, n_tiles=nt)
         ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics)
         ctx.dims = (width, height, eps2d)
         ctx.mark_non_differentiable(radii, tiles_per_gauss)
+        ctx.set_materialize_grads(False)  # no zero tensors for the outputs nothing back-propagates through
         return radii, means2d, depths, conics, tiles_per_gauss
 
     @staticmethod
     def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tpg):
         grads = _Project.backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tpg)
         return grads[0], grads[1], grads[2], grads[3], None, None, None, None, None, None, None, None, None, None
+
+
+_bg_ext_cache = DerivedCache()
 
 
 class SharedProjection:
@@ -433,7 +556,8 @@ class SharedProjection:
     def _bg(self, backgrounds):
         if backgrounds is None:
             return None
-        return torch.cat([backgrounds, backgrounds.new_zeros(self.C, 1)], dim=-1)
+        return _bg_ext_cache.get((backgrounds,),
+                                 lambda: torch.cat([backgrounds, backgrounds.new_zeros(self.C, 1)], dim=-1))
 
     def composite(self, colors, backgrounds=None):
         """"RGB+D" compositing of the whole set: (render [C,H,W,D+1], alphas [C,H,W,1])."""
