@@ -82,9 +82,13 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
  *      fail are skipped by the compositor at all 256 pixels anyway, so every output pixel is bit-identical and every
  *      gradient keeps exactly its non-zero terms; lists, sort and gradient slots shrink (about 2x on anisotropic scenes).
  * out: cum_tiles [C*N+1] exclusive prefix sum of the BOX counts (cum_tiles[C*N] = I_box)
- *      keep_scan [capacity+1] exclusive prefix sum of the keep flags over the box intersections:
- *                box intersection j is listed iff keep_scan[j+1] > keep_scan[j]; its compact index (= its
- *                gradient slot in mobgs_raster_bwd) is keep_scan[j]
+ *      keep_scan [mobgs_keep_scan_len(capacity)] exclusive prefix sum of the keep flags over the box
+ *                intersections, stored in chunks of 2048 intersections, each preceded by one base word:
+ *                chunk c = [base_c | local_0 .. local_2047], local_i = kept intersections before i inside the
+ *                chunk, base_c = kept intersections in all earlier chunks.  The compact index of box intersection
+ *                j (= its gradient slot in mobgs_raster_bwd) is
+ *                    keep_scan[(j >> 11) * 2049] + keep_scan[(j >> 11) * 2049 + 1 + (j & 2047)],
+ *                defined for 0 <= j <= min(I_box, capacity).
  *      tile_offsets [C*n_tiles+1] exclusive prefix sum of the per-tile list lengths
  *      tile_order [C*n_tiles] (may be NULL) the tile ids by descending list length (1024 length classes): the
  *                order in which the compositing kernels hand tiles to workgroups (longest lists first, lists of
@@ -98,6 +102,7 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
  *      already enqueued behind this call touch nothing; stats still hold the true counts.  <= 0: no such check.
  * scratch: mobgs_isect_scratch_bytes(C*N, C*n_tiles, capacity) bytes. */
 size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity);
+size_t mobgs_keep_scan_len(int capacity); /* int32 entries of keep_scan for `capacity` box intersections */
 int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
                         const int32_t* tiles_per_gauss, const float* means2d, const int32_t* radii,
                         const float* conics, const float* opacities, int opac_per_camera,
@@ -129,7 +134,7 @@ int mobgs_isect_emit_sort_speculative(int C, int N, int tile_w, int tile_h, int 
 
 /* ---- K1 + K3-K5 in one call: projection -> offsets (+ reach test) -> read-back -> emit -> per-tile sort ------
  * Same stages and buffers as mobgs_project_fwd + mobgs_isect_offsets + mobgs_isect_emit_sort, driven natively so
- * that no host gap separates the ~12 short kernels.  Arena: keep_scan [capacity_box+1], scratch
+ * that no host gap separates the ~12 short kernels.  Arena: keep_scan [mobgs_keep_scan_len(capacity_box)], scratch
  * (mobgs_isect_scratch_bytes(C*N, C*n_tiles, capacity_box)), flatten_ids [capacity_listed], sort_keys
  * [capacity_listed], isect_ids [capacity_listed] or NULL.  stats_dev: 3 x int64 device scratch; stats_host: 3 x int64
  * HOST output {I_box, I_listed, longest list}.  Returns MOBGS_E_CAPACITY (stats_host valid, nothing written past
@@ -178,7 +183,7 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
  * Deterministic two-stage gradient reduction, no floating-point atomics:
  *   stage 1 (mobgs_raster_bwd) walks every tile back to front and writes ONE gradient record
  *     {v_x, v_y, v_conic a b c, v_opacity, v_colour[..]} per (tile, splat) intersection into
- *     grad_slots [I_listed, stride]; slot = keep_scan[cum_tiles[flat id] + position of the tile inside the
+ *     grad_slots [I_listed, stride]; slot = compact index (see keep_scan) of cum_tiles[flat id] + position of the tile inside the
  *     splat's tile rectangle].  grad_slots must be zero-filled by the caller (intersections that no pixel blended stay 0).
  *   stage 2 (mobgs_raster_bwd_reduce) sums each splat's contiguous slots into the dense gradients
  *     v_means2d [C,N,2], v_conics [C,N,3], v_opacities [C,N], v_colors [C,N,channels], v_extra [C,N] (NULL when

@@ -56,6 +56,20 @@ __host__ __device__ inline TileRect tile_rect(float mx, float my, int radius, in
 }
 
 
+// ---- compact index of a bounding-box intersection (= its gradient slot) -----------------------------------------
+// keep_scan is stored in chunks of KEEP_CHUNK intersections, each preceded by one word: [base_c | local_0 ..
+// local_2047] with local_i = number of kept intersections before i inside the chunk and base_c = number kept in
+// all earlier chunks, so the chunks can be scanned independently and the bases filled in afterwards.
+constexpr int KEEP_CHUNK_LOG2 = 11;
+constexpr int KEEP_CHUNK = 1 << KEEP_CHUNK_LOG2;
+__host__ __device__ inline size_t keep_scan_len(size_t capacity) {
+    return ((capacity >> KEEP_CHUNK_LOG2) + 1) * (size_t)(KEEP_CHUNK + 1);
+}
+__device__ inline int keep_index(const int32_t* __restrict__ keep_scan, int j) {
+    const int32_t* p = keep_scan + (size_t)(j >> KEEP_CHUNK_LOG2) * (KEEP_CHUNK + 1);
+    return p[0] + p[1 + (j & (KEEP_CHUNK - 1))];
+}
+
 // ---- reach tests (bit-exact culling of work the compositor would skip anyway) --------------------------------
 // Smallest sigma = 0.5 (a dx^2 + c dy^2) + b dx dy a splat can take over a pixel-centre rectangle
 // (convex quadratic: 0 if the centre is inside, else attained on one of the four edges).

@@ -22,11 +22,20 @@
 namespace mobgs {
 
 // ---------------------------------------------------------------------------------------------------
-// exclusive scan of int32 (3 launches: block sums, scan of sums, local scan + add)
+// single-pass exclusive scans (chained scan with decoupled look-back)
+//
+// Each workgroup owns one chunk of SCAN_BLOCK consecutive elements.  Chunks are handed out through an atomic
+// ticket, so a workgroup only ever waits for chunks whose workgroups are already running (forward progress
+// does not depend on the dispatch order).  A workgroup publishes its chunk total in a 64-bit status word
+// {flag, value}, walks back over its predecessors until it meets one that already knows its inclusive prefix,
+// and publishes its own.  The status words and tickets live in the caller's scratch and are zeroed by the one
+// memset that also clears the per-tile counters.  The status word IS the message (no other memory is handed from
+// workgroup to workgroup), so relaxed agent-scope atomics suffice -- release/acquire at agent scope would write
+// back / invalidate the whole XCD L2 on every access (measured: 10x slower kernels).
 // ---------------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
-constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;  // 2048 ints per workgroup
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;  // 2048 elements per workgroup
 
 __device__ inline int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -37,68 +46,83 @@ __device__ inline int wave_incl_scan(int v, int lane) {
     return v;
 }
 
-// inclusive scan across the 256-thread workgroup; returns this thread's inclusive value, *total = block sum
-__device__ inline int block_incl_scan(int v, int* total) {
-    __shared__ int wsum[4];
+// inclusive scan across a workgroup of NW waves; returns this thread's inclusive value, *total = block sum
+template <int NW>
+__device__ inline int block_incl_scan_w(int v, int* total) {
+    __shared__ int wsum[NW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int inc = wave_incl_scan(v, lane);
     if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-    int base = 0;
+    int base = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) base += (k < wv) ? wsum[k] : 0;
-    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    for (int k = 0; k < NW; ++k) {
+        base += (k < wv) ? wsum[k] : 0;
+        tot += wsum[k];
+    }
+    *total = tot;
     __syncthreads();
     return inc + base;
 }
+__device__ inline int block_incl_scan(int v, int* total) { return block_incl_scan_w<SCAN_THREADS / 64>(v, total); }
 
-// n is read from device memory (*n_ptr, clamped to n_cap) so that a scan can follow a kernel that produced
-// its own length without a host round trip; grids are sized for n_cap.
-__device__ inline int scan_len(const int32_t* n_ptr, int n_cap) {
-    const int n = n_ptr ? *n_ptr : n_cap;
-    return n < n_cap ? n : n_cap;
+constexpr uint64_t LB_AGGREGATE = 1ull << 32, LB_PREFIX = 2ull << 32;
+
+__device__ inline int take_ticket(int32_t* counter) {
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(counter, 1);
+    __syncthreads();
+    return s_ticket;
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_block_sums_kernel(const int32_t* __restrict__ n_ptr, int n_cap,
-                                                                         const int32_t* __restrict__ in,
-                                                                         int32_t* __restrict__ block_sums) {
-    const int n = scan_len(n_ptr, n_cap);
-    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
-    int s = 0;
+// exclusive prefix of chunk `chunk` given its total `aggregate` (uniform over the workgroup).  The first wave
+// inspects 64 predecessors per step: it needs every status word down to the nearest one that already holds an
+// inclusive prefix, sums those and stops there (a serial walk costs one L2 round trip per predecessor).
+__device__ inline int lookback_exclusive(uint64_t* status, int chunk, int aggregate) {
+    __shared__ int s_excl;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int excl = 0;
+        if (chunk > 0) {
+            if (lane == 0)
+                __hip_atomic_store(&status[chunk], LB_AGGREGATE | (uint32_t)aggregate, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            int top = chunk - 1;  // lane l looks at chunk top - l; chunk "-1" counts as prefix 0
+            for (;;) {
+                const int idx = top - lane;
+                const uint64_t w = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                            : LB_PREFIX;
+                const uint64_t not_ready = __builtin_amdgcn_ballot_w64((w >> 32) == 0);
+                const uint64_t is_prefix = __builtin_amdgcn_ballot_w64((w >> 32) == 2);
+                const int first = is_prefix ? __builtin_ctzll(is_prefix) : 64;
+                const uint64_t needed = first >= 63 ? ~0ull : ((2ull << first) - 1);
+                if (not_ready & needed) continue;  // a needed predecessor has not published yet: look again
+                int v = lane <= first ? (int)(uint32_t)w : 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) s += (base + k < n) ? in[base + k] : 0;
-    int total;
-    block_incl_scan(s, &total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                excl += v;
+                if (first < 64) break;
+                top -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&status[chunk], LB_PREFIX | (uint32_t)(excl + aggregate), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+        }
+    }
+    __syncthreads();
+    return s_excl;
 }
 
-// single workgroup: in-place exclusive scan of block_sums[nb]; the grand total goes to out[n] and stats_slot
-__global__ void __launch_bounds__(SCAN_THREADS) scan_sums_kernel(const int32_t* __restrict__ n_ptr, int n_cap, int nb,
-                                                                   int32_t* __restrict__ block_sums,
-                                                                   int32_t* __restrict__ out,
-                                                                   int64_t* __restrict__ stats_slot) {
-    int carry = 0;
-    for (int start = 0; start < nb; start += SCAN_THREADS) {
-        const int i = start + threadIdx.x;
-        const int v = (i < nb) ? block_sums[i] : 0;
-        int total;
-        const int inc = block_incl_scan(v, &total);
-        if (i < nb) block_sums[i] = carry + inc - v;
-        carry += total;
-    }
-    if (threadIdx.x == 0) {
-        out[scan_len(n_ptr, n_cap)] = carry;
-        if (stats_slot) *stats_slot = (int64_t)carry;
-    }
-}
-
-__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const int32_t* __restrict__ n_ptr, int n_cap,
-                                                                    const int32_t* __restrict__ in,
-                                                                    const int32_t* __restrict__ block_sums,
-                                                                    int32_t* __restrict__ out) {
-    const int n = scan_len(n_ptr, n_cap);
-    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
-    if (blockIdx.x * SCAN_BLOCK >= n) return;
+// cum[i] = sum of in[0..i), cum[n] = total (also stats_slot); n > 0
+__global__ void __launch_bounds__(SCAN_THREADS) scan_lookback_kernel(int n, const int32_t* __restrict__ in,
+                                                                       int32_t* __restrict__ cum,
+                                                                       int32_t* __restrict__ counter,
+                                                                       uint64_t* __restrict__ status,
+                                                                       int64_t* __restrict__ stats_slot) {
+    const int chunk = take_ticket(counter);
+    const int base = chunk * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
     int v[SCAN_ITEMS];
     int s = 0;
 #pragma unroll
@@ -108,20 +132,24 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const int32_t*
     }
     int total;
     const int inc = block_incl_scan(s, &total);
-    int run = block_sums[blockIdx.x] + inc - s;
+    int run = lookback_exclusive(status, chunk, total) + inc - s;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (base + k < n) out[base + k] = run;
+        if (base + k < n) cum[base + k] = run;
         run += v[k];
+    }
+    if (base <= n - 1 && n - 1 < base + SCAN_ITEMS) {  // the thread that owns the last element
+        cum[n] = run;
+        if (stats_slot) *stats_slot = (int64_t)run;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// one thread per intersection: owner lookup (binary search in cum_tiles) + tile id
+// pass A: one workgroup per chunk of SCAN_BLOCK consecutive bounding-box intersections
 // ---------------------------------------------------------------------------------------------------
-__device__ inline int owner_of(const int32_t* __restrict__ cum, int n, int j) {
-    // largest g in [0,n) with cum[g] <= j   (cum is non-decreasing, cum[n] = I > j)
-    int lo = 0, hi = n;
+// largest g in [lo, hi) with cum[g] <= j   (cum is non-decreasing, cum[lo] <= j < cum[hi])
+template <typename Cum>
+__device__ inline int owner_in(const Cum& cum, int lo, int hi, int j) {
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (cum[mid] <= j)
@@ -132,53 +160,116 @@ __device__ inline int owner_of(const int32_t* __restrict__ cum, int n, int j) {
     return lo;
 }
 
-__device__ inline int tile_of(int j, int g, int N, int tile_w, int tile_h, const int32_t* __restrict__ cum,
-                              const float* __restrict__ means2d, const int32_t* __restrict__ radii) {
-    const float2 m = reinterpret_cast<const float2*>(means2d)[g];
-    const TileRect tr = tile_rect(m.x, m.y, radii[g], tile_w, tile_h);
-    const int k = j - cum[g];
-    const int w = tr.x1 - tr.x0;
-    const int ty = tr.y0 + k / w, tx = tr.x0 + k % w;
-    const int cam = g / N;
-    return (cam * tile_h + ty) * tile_w + tx;
-}
+constexpr int OWNER_LDS = 4096;  // cum_tiles entries of the chunk's owner range cached in LDS
+static_assert(SCAN_BLOCK == KEEP_CHUNK, "one workgroup per keep_scan chunk");
 
-// Pass A, one thread per bounding-box intersection j: owner splat (binary search), tile, reach test.  A kept
-// intersection takes its rank inside the tile's list with ONE returning atomic; (owner, tile, rank) are written
-// out so that pass B is a pure streaming scatter (no second search, no second atomic).
-__global__ void __launch_bounds__(256)
+// Owner splat (search in the chunk's slice of cum_tiles, cached in LDS), tile and reach test of every
+// intersection of the chunk.  A kept intersection takes its rank inside the tile's list with ONE returning
+// atomic; (owner, tile, rank) are written out so that pass B is a pure streaming scatter.  The keep flags are
+// scanned inside the chunk (keep_scan locals, see common.h); the chunk's total goes to its base word, which
+// tile_scan_kernel turns into the exclusive prefix over the chunks.
+__global__ void __launch_bounds__(SCAN_THREADS)
 bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
            const int32_t* __restrict__ cum, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
            const float* __restrict__ conics, const float* __restrict__ opacities, int opac_per_camera,
            int32_t* __restrict__ flags, int32_t* __restrict__ owner, int32_t* __restrict__ tile_of_j,
-           int32_t* __restrict__ rank_of_j, int32_t* __restrict__ tile_count) {
+           int32_t* __restrict__ rank_of_j, int32_t* __restrict__ tile_count, int32_t* __restrict__ keep_scan) {
+    __shared__ int s_cum[OWNER_LDS + 1];
+    const int chunk = blockIdx.x;
+    int32_t* kchunk = keep_scan + (size_t)chunk * (KEEP_CHUNK + 1);
     const int I = min(cum[n_gauss], capacity);
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < I; j += gridDim.x * blockDim.x) {
-        const int g = owner_of(cum, n_gauss, j);
-        const int t = tile_of(j, g, N, tile_w, tile_h, cum, means2d, radii);
-        int keep = 1;
-        if (cull) {
-            const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
-            const float op = opacities[opac_per_camera ? g : g % N];
-            if (!(op * 255.f >= 1.f)) {
-                keep = 0;  // alpha = min(0.999, op * exp(-sigma)) < 1/255 everywhere (sigma >= 0 where blended)
-            } else if (ca > 0.f && cc > 0.f) {
-                const int tl = t % (tile_w * tile_h);
-                const int ty = tl / tile_w, tx = tl - ty * tile_w;
-                const float x0 = (float)(tx * MOBGS_TILE) + 0.5f, y0 = (float)(ty * MOBGS_TILE) + 0.5f;
-                const float x1 = fminf((float)(tx * MOBGS_TILE) + 15.5f, (float)width - 0.5f);
-                const float y1 = fminf((float)(ty * MOBGS_TILE) + 15.5f, (float)height - 0.5f);
-                const float2 m = reinterpret_cast<const float2*>(means2d)[g];
-                const float smin = min_sigma_over_tile(m.x, m.y, ca, cb, cc, x0, x1, y0, y1);
-                keep = (smin <= reach_threshold(op)) ? 1 : 0;
+    const int start = chunk * SCAN_BLOCK;
+    if (start >= I) {
+        if (threadIdx.x == 0) {
+            kchunk[0] = 0;                   // empty chunk
+            if (start == I) kchunk[1] = 0;  // local of position I (one past the last intersection)
+        }
+        return;
+    }
+    const int end = min(I, start + SCAN_BLOCK);
+    const int g_lo = owner_in(cum, 0, n_gauss, start);
+    const int g_hi = owner_in(cum, g_lo, n_gauss, end - 1);
+    const int span = g_hi - g_lo + 1;
+    const bool cached = span <= OWNER_LDS;
+    if (cached) {
+        for (int t = threadIdx.x; t <= span; t += SCAN_THREADS) s_cum[t] = cum[g_lo + t];
+        __syncthreads();
+    }
+    const int tiles_per_cam = tile_w * tile_h;
+    // item k of thread t is intersection start + k * 256 + t: neighbouring lanes work on neighbouring
+    // intersections (coalesced stores, shared owner data)
+    __shared__ int s_cnt[SCAN_ITEMS][SCAN_THREADS / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int keep[SCAN_ITEMS], own[SCAN_ITEMS], til[SCAN_ITEMS], before[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int j = start + k * SCAN_THREADS + threadIdx.x;
+        int kp = 0, g = 0, t = 0;
+        if (j < end) {
+            g = cached ? g_lo + owner_in(s_cum, 0, span, j) : owner_in(cum, g_lo, g_hi + 1, j);
+            const float2 m = reinterpret_cast<const float2*>(means2d)[g];
+            const TileRect tr = tile_rect(m.x, m.y, radii[g], tile_w, tile_h);
+            const int q = j - (cached ? s_cum[g - g_lo] : cum[g]);
+            const int w = tr.x1 - tr.x0;
+            const int ty = tr.y0 + q / w, tx = tr.x0 + q % w;
+            t = (g / N) * tiles_per_cam + ty * tile_w + tx;
+            kp = 1;
+            if (cull) {
+                const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+                const float op = opacities[opac_per_camera ? g : g % N];
+                if (!(op * 255.f >= 1.f)) {
+                    kp = 0;  // alpha = min(0.999, op * exp(-sigma)) < 1/255 everywhere (sigma >= 0 where blended)
+                } else if (ca > 0.f && cc > 0.f) {
+                    const float x0 = (float)(tx * MOBGS_TILE) + 0.5f, y0 = (float)(ty * MOBGS_TILE) + 0.5f;
+                    const float x1 = fminf((float)(tx * MOBGS_TILE) + 15.5f, (float)width - 0.5f);
+                    const float y1 = fminf((float)(ty * MOBGS_TILE) + 15.5f, (float)height - 0.5f);
+                    kp = (min_sigma_over_tile(m.x, m.y, ca, cb, cc, x0, x1, y0, y1) <= reach_threshold(op)) ? 1 : 0;
+                }
             }
         }
-        flags[j] = keep;
-        if (keep) {
-            owner[j] = g;
-            tile_of_j[j] = t;
-            rank_of_j[j] = atomicAdd(&tile_count[t], 1);
+        keep[k] = kp;
+        own[k] = g;
+        til[k] = t;
+        const uint64_t ballot = __builtin_amdgcn_ballot_w64(kp != 0);
+        before[k] = __builtin_popcountll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) s_cnt[k][wv] = __builtin_popcountll(ballot);
+    }
+    // ranks inside the tiles' lists: all returning atomics in flight before the first result is consumed
+    int rank[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = keep[k] ? atomicAdd(&tile_count[til[k]], 1) : 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int j = start + k * SCAN_THREADS + threadIdx.x;
+        if (j < end) {
+            flags[j] = keep[k];
+            if (keep[k]) {
+                owner[j] = own[k];
+                tile_of_j[j] = til[k];
+                rank_of_j[j] = rank[k];
+            }
         }
+    }
+    __syncthreads();
+    // exclusive prefix of every (item row, wave) segment in intersection order, and the chunk total
+    int seg[SCAN_ITEMS];
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+#pragma unroll
+        for (int w2 = 0; w2 < SCAN_THREADS / 64; ++w2) {
+            if (w2 == wv) seg[k] = total;
+            total += s_cnt[k][w2];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int i = k * SCAN_THREADS + threadIdx.x;
+        if (start + i < end) kchunk[1 + i] = seg[k] + before[k];
+    }
+    if (threadIdx.x == 0) {
+        kchunk[0] = total;
+        if (end == I && end - start < SCAN_BLOCK) kchunk[1 + (end - start)] = total;  // local of position I
     }
 }
 
@@ -188,30 +279,48 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
 // the waves of one workgroup get lists of similar length (longest-processing-time-first scheduling).  Only a
 // schedule: any permutation gives the same images and gradients.
 constexpr int ORDER_BUCKETS = 1024;
-__global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(int nt, const int32_t* __restrict__ tile_count,
-                                                                   int32_t* __restrict__ tile_offsets,
-                                                                   int64_t* __restrict__ stats,
-                                                                   int32_t* __restrict__ tile_order,
-                                                                   int64_t capacity_box, int64_t capacity_listed) {
-    __shared__ int smax[SCAN_THREADS];
+constexpr int TSCAN_THREADS = 1024;
+__global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const int32_t* __restrict__ tile_count,
+                                                                    int32_t* __restrict__ tile_offsets,
+                                                                    int64_t* __restrict__ stats,
+                                                                    int32_t* __restrict__ tile_order,
+                                                                    int64_t capacity_box, int64_t capacity_listed,
+                                                                    int32_t* __restrict__ keep_scan, int n_chunks) {
+    __shared__ int smax[TSCAN_THREADS / 64];
+    // chunk totals -> chunk bases of keep_scan (bin_kernel left each chunk's total in its base word);
+    // stats[1] = I_listed
+    if (keep_scan) {
+        int base = 0;
+        for (int c0 = 0; c0 < n_chunks; c0 += TSCAN_THREADS) {
+            const int c = c0 + threadIdx.x;
+            int32_t* w = keep_scan + (size_t)c * (KEEP_CHUNK + 1);
+            const int v = (c < n_chunks) ? *w : 0;
+            int total;
+            const int inc = block_incl_scan_w<TSCAN_THREADS / 64>(v, &total);
+            if (c < n_chunks) *w = base + inc - v;
+            base += total;
+        }
+        if (threadIdx.x == 0) stats[1] = (int64_t)base;
+        __syncthreads();
+    }
     __shared__ int hist[ORDER_BUCKETS];
     int carry = 0, mx = 0;
-    for (int start = 0; start < nt; start += SCAN_THREADS) {
+    for (int start = 0; start < nt; start += TSCAN_THREADS) {
         const int i = start + threadIdx.x;
         const int v = (i < nt) ? tile_count[i] : 0;
         mx = max(mx, v);
         int total;
-        const int inc = block_incl_scan(v, &total);
+        const int inc = block_incl_scan_w<TSCAN_THREADS / 64>(v, &total);
         if (i < nt) tile_offsets[i] = carry + inc - v;
         carry += total;
     }
-    smax[threadIdx.x] = mx;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
     __syncthreads();
-    for (int s = SCAN_THREADS / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) smax[threadIdx.x] = max(smax[threadIdx.x], smax[threadIdx.x + s]);
-        __syncthreads();
-    }
-    const int longest = smax[0];
+    int longest = 0;
+#pragma unroll
+    for (int k = 0; k < TSCAN_THREADS / 64; ++k) longest = max(longest, smax[k]);
     if (threadIdx.x == 0) {
         tile_offsets[nt] = carry;
         stats[2] = (int64_t)longest;
@@ -221,35 +330,26 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(int nt, const i
     // counts and the host redoes the binning with a larger arena.
     if (capacity_listed > 0 && (stats[0] > capacity_box || (int64_t)carry > capacity_listed)) {
         __syncthreads();
-        for (int i = threadIdx.x; i <= nt; i += SCAN_THREADS) tile_offsets[i] = 0;
+        for (int i = threadIdx.x; i <= nt; i += TSCAN_THREADS) tile_offsets[i] = 0;
     }
     if (!tile_order) return;
     auto bucket = [&](int len) {
         const int q = longest > 0 ? (int)(((int64_t)len * (ORDER_BUCKETS - 1)) / longest) : 0;
         return ORDER_BUCKETS - 1 - q;  // bucket 0 = the longest lists
     };
-    for (int b = threadIdx.x; b < ORDER_BUCKETS; b += SCAN_THREADS) hist[b] = 0;
+    static_assert(ORDER_BUCKETS == TSCAN_THREADS, "one histogram bin per thread");
+    hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < nt; i += SCAN_THREADS) atomicAdd(&hist[bucket(tile_count[i])], 1);
+    for (int i = threadIdx.x; i < nt; i += TSCAN_THREADS) atomicAdd(&hist[bucket(tile_count[i])], 1);
     __syncthreads();
-    {  // exclusive scan of hist: each thread owns ORDER_BUCKETS / SCAN_THREADS consecutive buckets
-        constexpr int PER = ORDER_BUCKETS / SCAN_THREADS;
-        int loc[PER], sum = 0;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            loc[k] = hist[threadIdx.x * PER + k];
-            sum += loc[k];
-        }
+    {
+        const int mine = hist[threadIdx.x];
         int total;
-        int base = block_incl_scan(sum, &total) - sum;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            hist[threadIdx.x * PER + k] = base;
-            base += loc[k];
-        }
+        const int inc = block_incl_scan_w<TSCAN_THREADS / 64>(mine, &total);
+        hist[threadIdx.x] = inc - mine;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nt; i += SCAN_THREADS) {
+    for (int i = threadIdx.x; i < nt; i += TSCAN_THREADS) {
         const int pos = atomicAdd(&hist[bucket(tile_count[i])], 1);
         tile_order[pos] = i;
     }
@@ -424,10 +524,35 @@ using namespace mobgs;
 
 extern "C" {
 
+// Layout of the scratch buffer shared by mobgs_isect_offsets and mobgs_isect_emit_sort (int32 units):
+//   [tile_count nt | ticket (+3 pad) | status 2*(nb1+1)]  <- zeroed by one memset
+//   [flags cap | owner cap | tile cap | rank cap]
+struct IsectScratch {
+    int32_t *tile_count, *tickets, *flags, *owner, *tile_of_j, *rank_of_j;
+    uint64_t* status1;
+    size_t zeroed_ints, total_ints;
+    int nb1;
+    IsectScratch(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity) {
+        nb1 = (int)((n_gauss + SCAN_BLOCK - 1) / SCAN_BLOCK);
+        const size_t nt_pad = (n_tiles + 1) & ~(size_t)1;  // keeps the 64-bit status words 8-byte aligned
+        int32_t* p = (int32_t*)scratch;
+        tile_count = p;
+        tickets = p + nt_pad;
+        status1 = (uint64_t*)(p + nt_pad + 4);
+        zeroed_ints = nt_pad + 4 + 2 * (size_t)(nb1 + 1);
+        flags = p + zeroed_ints;
+        owner = flags + capacity;
+        tile_of_j = owner + capacity;
+        rank_of_j = tile_of_j + capacity;
+        total_ints = zeroed_ints + 4 * capacity;
+    }
+};
+
+size_t mobgs_keep_scan_len(int capacity) { return keep_scan_len((size_t)capacity); }
+
 size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity) {
-    const size_t nb1 = (size_t)(n_gauss + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
-    const size_t nb2 = (size_t)(capacity + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
-    return sizeof(int32_t) * (nb1 + nb2 + (size_t)n_tiles + 4 * (size_t)capacity + 32);
+    const IsectScratch L(nullptr, (size_t)n_gauss, (size_t)n_tiles, (size_t)capacity);
+    return sizeof(int32_t) * (L.total_ints + 32);
 }
 
 int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
@@ -441,48 +566,33 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
         set_error("mobgs_isect_offsets: bad sizes C=%d N=%d tiles=%dx%d capacity=%d", C, N, tile_w, tile_h, capacity);
         return MOBGS_E_INVALID;
     }
+    if (((uintptr_t)scratch & 7) != 0) {
+        set_error("mobgs_isect_offsets: scratch must be 8-byte aligned");
+        return MOBGS_E_INVALID;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int n = (int)ng;
-    const int nb1 = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    const int nb2 = (capacity + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    int32_t* block_sums1 = (int32_t*)scratch;
-    int32_t* block_sums2 = block_sums1 + nb1 + 1;
-    int32_t* tile_count = block_sums2 + nb2 + 1;
-    int32_t* flags = tile_count + nt;
-    hipMemsetAsync(tile_count, 0, sizeof(int32_t) * nt, st);
+    const IsectScratch L(scratch, (size_t)n, (size_t)nt, (size_t)capacity);
+    hipMemsetAsync(L.tile_count, 0, sizeof(int32_t) * L.zeroed_ints, st);  // tile counters, tickets, status words
     if (n == 0) {
         hipMemsetAsync(cum_tiles, 0, sizeof(int32_t), st);
-        hipMemsetAsync(keep_scan, 0, sizeof(int32_t), st);
+        hipMemsetAsync(keep_scan, 0, 2 * sizeof(int32_t), st);  // base and first local of chunk 0
         hipMemsetAsync(stats, 0, 3 * sizeof(int64_t), st);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, (int)nt, tile_count, tile_offsets,
-                           stats, tile_order, (int64_t)capacity, (int64_t)0);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
+                           stats, tile_order, (int64_t)capacity, (int64_t)0, (int32_t*)nullptr, 0);
         return check_launch("isect_offsets(empty)");
     }
     // bounding-box counts -> cum_tiles; stats[0] = I_box
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb1), dim3(SCAN_THREADS), 0, st, nullptr, n, tiles_per_gauss,
-                       block_sums1);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, nullptr, n, nb1, block_sums1, cum_tiles,
-                       stats);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb1), dim3(SCAN_THREADS), 0, st, nullptr, n, tiles_per_gauss,
-                       block_sums1, cum_tiles);
-    // keep flags + per-tile histogram (only the first `capacity` intersections; the caller re-runs with a larger
-    // buffer when stats[0] > capacity)
-    int32_t* owner = flags + capacity;
-    int32_t* tile_of_j = owner + capacity;
-    int32_t* rank_of_j = tile_of_j + capacity;
-    hipLaunchKernelGGL(bin_kernel, dim3(4096), dim3(256), 0, st, n, N, tile_w, tile_h, width, height, cull, capacity,
-                       cum_tiles, means2d, radii, conics, opacities, opac_per_camera, flags, owner, tile_of_j,
-                       rank_of_j, tile_count);
-    // keep_scan = exclusive scan of the flags over [0, min(I_box, capacity)); stats[1] = I_kept
-    const int32_t* n_ptr = cum_tiles + n;
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb2), dim3(SCAN_THREADS), 0, st, n_ptr, capacity, flags,
-                       block_sums2);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, n_ptr, capacity, nb2, block_sums2,
-                       keep_scan, stats + 1);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb2), dim3(SCAN_THREADS), 0, st, n_ptr, capacity, flags, block_sums2,
-                       keep_scan);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, (int)nt, tile_count, tile_offsets,
-                       stats, tile_order, (int64_t)capacity, capacity_listed);
+    hipLaunchKernelGGL(scan_lookback_kernel, dim3(L.nb1), dim3(SCAN_THREADS), 0, st, n, tiles_per_gauss, cum_tiles,
+                       L.tickets, L.status1, stats);
+    // keep flags, per-tile ranks and keep_scan over the first min(I_box, capacity) intersections (the caller
+    // re-runs with a larger buffer when stats[0] > capacity); stats[1] = I_listed
+    const int n_chunks = (capacity >> KEEP_CHUNK_LOG2) + 1;
+    hipLaunchKernelGGL(bin_kernel, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h, width, height, cull,
+                       capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera, L.flags, L.owner,
+                       L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
+                       stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks);
     return check_launch("isect_offsets");
 }
 
@@ -501,14 +611,9 @@ static int emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t
     if (n_isects == 0) return MOBGS_OK;
     const int n = C * N;
     // the (flag, owner, tile, rank) arrays pass A left in the scratch buffer of mobgs_isect_offsets
-    const int nb1 = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    const int nb2 = (capacity + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    const int32_t* flags = (const int32_t*)offsets_scratch + (nb1 + 1) + (nb2 + 1) + nt;
-    const int32_t* owner = flags + capacity;
-    const int32_t* tile_of_j = owner + capacity;
-    const int32_t* rank_of_j = tile_of_j + capacity;
-    hipLaunchKernelGGL(emit_kernel, dim3(4096), dim3(256), 0, st, cum_tiles + n, flags, owner, tile_of_j, rank_of_j,
-                       depths, tile_offsets, sort_keys, capacity, stats_dev, capacity_listed);
+    const IsectScratch L(const_cast<void*>(offsets_scratch), (size_t)n, (size_t)nt, (size_t)capacity);
+    hipLaunchKernelGGL(emit_kernel, dim3(4096), dim3(256), 0, st, cum_tiles + n, L.flags, L.owner, L.tile_of_j,
+                       L.rank_of_j, depths, tile_offsets, sort_keys, capacity, stats_dev, capacity_listed);
     // gsplat: tile_n_bits = floor(log2(n_tiles)) + 1
     int tile_bits = 0;
     while ((1ll << tile_bits) <= (long long)tiles_per_cam) ++tile_bits;

@@ -349,7 +349,7 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
 #pragma unroll
             for (int q = 1; q < RQ; ++q) slab[wv][lane][q] = r[q];
             const TileRect tr = tile_rect(r0.x, r0.y, radii[g], tile_w, tile_h);
-            slot_of[wv][lane] = keep_scan[cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0)];
+            slot_of[wv][lane] = keep_index(keep_scan, cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0));
         }
         wave_lds_fence();
         for (int j = 0; j < n; ++j) {
@@ -377,8 +377,12 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
             for (int i = 0; i < NVP; ++i) g[i] = 0.f;
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
-                if (!ev[k].pass) continue;
-                const float alpha = ev[k].alpha;
+                // one 8x8 quadrant: skipped as a whole when none of its pixels blends this splat (wave-uniform
+                // branch); otherwise every lane runs the same arithmetic with alpha = 0 standing in for "this
+                // pixel does not blend it" -- T, behind and the sums then stay exactly as they were (x * 1, + 0)
+                if (__builtin_amdgcn_ballot_w64(ev[k].pass) == 0ull) continue;
+                const bool pass = ev[k].pass;
+                const float alpha = pass ? ev[k].alpha : 0.f;
                 // 1 / (1 - alpha): hardware reciprocal + one Newton step (<= 1 ulp; 1 - alpha >= 1e-3)
                 const float om = 1.f - alpha;
                 float ra = __builtin_amdgcn_rcpf(om);
@@ -395,16 +399,16 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
                 v_alpha += Tf[k] * ra * va[k];
                 if (backgrounds) v_alpha -= Tf[k] * ra * bgdot[k];
                 const float ov = rec[5] * ev[k].vis;
-                if (ov <= ALPHA_MAX) {
-                    const float v_sigma = -ov * v_alpha;
-                    const float dx = ev[k].dx, dy = ev[k].dy;
-                    g[0] = __fmaf_rn(v_sigma, rec[2] * dx + rec[3] * dy, g[0]);
-                    g[1] = __fmaf_rn(v_sigma, rec[3] * dx + rec[4] * dy, g[1]);
-                    g[2] = __fmaf_rn(0.5f * v_sigma * dx, dx, g[2]);
-                    g[3] = __fmaf_rn(v_sigma * dx, dy, g[3]);
-                    g[4] = __fmaf_rn(0.5f * v_sigma * dy, dy, g[4]);
-                    g[5] = __fmaf_rn(ev[k].vis, v_alpha, g[5]);
-                }
+                const bool live = pass && ov <= ALPHA_MAX;  // the clamp at 0.999 has zero slope
+                const float v_sigma = live ? -ov * v_alpha : 0.f;
+                const float v_op = live ? v_alpha : 0.f;
+                const float dx = ev[k].dx, dy = ev[k].dy;
+                g[0] = __fmaf_rn(v_sigma, rec[2] * dx + rec[3] * dy, g[0]);
+                g[1] = __fmaf_rn(v_sigma, rec[3] * dx + rec[4] * dy, g[1]);
+                g[2] = __fmaf_rn(0.5f * v_sigma * dx, dx, g[2]);
+                g[3] = __fmaf_rn(v_sigma * dx, dy, g[3]);
+                g[4] = __fmaf_rn(0.5f * v_sigma * dy, dy, g[4]);
+                g[5] = __fmaf_rn(ev[k].vis, v_op, g[5]);
                 behind[k] = __fmaf_rn(fac, dot, behind[k]);
             }
             wave_reduce_components<NVP>(g);
@@ -438,7 +442,7 @@ slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, const i
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPG;
     const int comp = threadIdx.x % LPG;
     if (gid >= n_gauss) return;
-    const int a = keep_scan[cum_tiles[gid]], b = keep_scan[cum_tiles[gid + 1]];
+    const int a = keep_index(keep_scan, cum_tiles[gid]), b = keep_index(keep_scan, cum_tiles[gid + 1]);
     float acc = 0.f;
     if (comp < stride) {
         // 4 independent partial sums keep 4 loads in flight per lane (the loop is latency-bound otherwise);

@@ -394,7 +394,7 @@ raster_layers_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
 #pragma unroll
             for (int q = 1; q < RQ; ++q) slab[wv][lane][q] = r[q];
             const TileRect tr = tile_rect(r0.x, r0.y, radii[g], tile_w, tile_h);
-            slot_of[wv][lane] = keep_scan[cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0)];
+            slot_of[wv][lane] = keep_index(keep_scan, cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0));
             cls_of[wv][lane] = ((g % N) < Ns) ? 1 : 2;
         }
         l_fence();
@@ -452,7 +452,7 @@ layers_slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, 
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / 16;
     const int comp = threadIdx.x % 16;
     if (gid >= n_gauss) return;
-    const int a = 2 * keep_scan[cum_tiles[gid]], b = 2 * keep_scan[cum_tiles[gid + 1]];
+    const int a = 2 * keep_index(keep_scan, cum_tiles[gid]), b = 2 * keep_index(keep_scan, cum_tiles[gid + 1]);
     float acc = 0.f;
     if (comp < stride) {
         const float* p = grad_slots + (size_t)a * stride + comp;

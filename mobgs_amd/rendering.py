@@ -238,7 +238,7 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Ten
     key = dev.index if dev.index is not None else -1
     cap = max(_capacity.get(key, 0), 16 * (C * N) + 1024)
     while True:
-        tl.keep_scan = torch.empty(cap + 1, dtype=torch.int32, device=dev)
+        tl.keep_scan = torch.empty(lib.mobgs_keep_scan_len(cap), dtype=torch.int32, device=dev)
         scratch = torch.empty(lib.mobgs_isect_scratch_bytes(C * N, nt, cap), dtype=torch.uint8, device=dev)
         check(lib.mobgs_isect_offsets(C, N, tile_w, tile_h, width, height, int(_tile_culling), cap,
                                       ptr(tiles_per_gauss), ptr(means2d), ptr(radii), ptr(conics), ptr(opac),
@@ -475,7 +475,7 @@ class _ProjectAndBin(torch.autograd.Function):
         cap_box = max(_capacity.get(key, 0), 16 * (C * N) + 1024)
         cap_listed = max(_cap_listed.get(key, 0), cap_box // 2)
         while True:
-            keep_scan = torch.empty(cap_box + 1, dtype=torch.int32, device=dev)
+            keep_scan = torch.empty(lib.mobgs_keep_scan_len(cap_box), dtype=torch.int32, device=dev)
             scratch = torch.empty(lib.mobgs_isect_scratch_bytes(C * N, nt, cap_box), dtype=torch.uint8, device=dev)
             flatten_ids = torch.empty(cap_listed, dtype=torch.int32, device=dev)
             sort_keys = torch.empty(cap_listed, dtype=torch.int64, device=dev)
