@@ -287,9 +287,10 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
                                                                     int64_t capacity_box, int64_t capacity_listed,
                                                                     int32_t* __restrict__ keep_scan, int n_chunks) {
     __shared__ int smax[TSCAN_THREADS / 64];
-    // chunk totals -> chunk bases of keep_scan (bin_kernel left each chunk's total in its base word);
-    // stats[1] = I_listed
-    if (keep_scan) {
+    __shared__ int hist[ORDER_BUCKETS];
+    // workgroup 1: chunk totals -> chunk bases of keep_scan (bin_kernel left each chunk's total in its base
+    // word); stats[1] = I_listed.  Workgroup 0 does the per-tile work below at the same time.
+    if (blockIdx.x == 1) {
         int base = 0;
         for (int c0 = 0; c0 < n_chunks; c0 += TSCAN_THREADS) {
             const int c = c0 + threadIdx.x;
@@ -301,9 +302,8 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
             base += total;
         }
         if (threadIdx.x == 0) stats[1] = (int64_t)base;
-        __syncthreads();
+        return;
     }
-    __shared__ int hist[ORDER_BUCKETS];
     int carry = 0, mx = 0;
     for (int start = 0; start < nt; start += TSCAN_THREADS) {
         const int i = start + threadIdx.x;
@@ -591,7 +591,7 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
     hipLaunchKernelGGL(bin_kernel, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h, width, height, cull,
                        capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera, L.flags, L.owner,
                        L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
                        stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks);
     return check_launch("isect_offsets");
 }
