@@ -301,6 +301,138 @@ def gen_losses(name):
          grad_img=np_(img.grad), psnr=np_(p))
 
 
+# per-splat optimiser groups of the reference (scene/gaussian_model.py:598-617) and the attribute each one backs
+DENSIFY_GROUPS = [("xyz", "_xyz"), ("control_xyz", "control_xyz"), ("current_control_num", "current_control_num"),
+                  ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("f_t", "_features_t"),
+                  ("opacity", "_opacity"), ("scaling", "_scaling"), ("rotation", "_rotation"), ("omega", "_omega"),
+                  ("zeta", "_zeta"), ("trbf_center", "_trbf_center"), ("trbf_scale", "_trbf_scale"),
+                  ("motion", "_motion")]
+DENSIFY_AUX = ["xyz_gradient_accum", "denom", "max_radii2D", "_deformation_table", "_deformation_accum"]
+
+
+class OptArgs:
+    """OptimizationParams defaults (arguments/__init__.py:117-185) read by GaussianModel.training_setup."""
+    percent_dense = 0.01
+    position_lr_init = 0.00016
+    position_lr_final = 0.0000016
+    position_lr_max_steps = 20_000
+    deformation_lr_init = 0.00016
+    deformation_lr_final = 0.000016
+    grid_lr_init = 0.0016
+    grid_lr_final = 0.00016
+    feature_lr = 0.0025
+    featuret_lr = 0.001
+    opacity_lr = 0.05
+    scaling_lr = 0.005
+    rotation_lr = 0.001
+    omega_lr = 0.0001
+    zeta_lr = 0.0001
+    trbfc_lr = 0.0001
+    trbfs_lr = 0.03
+    movelr = 3.5
+    rgb_lr = 0.0001
+    pose_lr_init = 0.0005
+    pose_lr_final = 0.00005
+
+
+def gen_densify(name, n=600, seed=21):
+    """GaussianModel's densification / optimiser surgery (scene/gaussian_model.py:897-904, :1029-1244, :1352-1356,
+    :1417-1434, :1480-1506) on a dynamic model with a populated Adam state.  Recorded: every per-splat parameter,
+    its exp_avg / exp_avg_sq, and the per-splat statistics after each operation."""
+    gm = RH.ref_import("scene.gaussian_model")
+    cam = SynthCamera(96, 64)
+    g = torch.Generator().manual_seed(seed)
+    p = gaussian_cloud(n, cam, seed)
+    p.update(dynamic_extras(p["xyz"], seed))
+    with RH.CudaToCpu():
+        torch.manual_seed(seed)
+        pc = gm.GaussianModel(0, RH.Args())
+        P = torch.nn.Parameter
+        pc._xyz = P(p["xyz"].clone())
+        pc._scaling = P(p["scaling"].clone() + 1.2 * torch.randn(n, 3, generator=g))  # both sides of percent_dense
+        pc._rotation = P(p["rotation"].clone())
+        pc._opacity = P(p["opacity"].reshape(n, 1).clone())
+        pc._features_dc = P(p["features_dc"].clone())
+        pc._features_rest = P(torch.zeros(n, 0, 3))
+        pc._features_t = P(p["features_t"].clone())
+        pc._omega = P(p["omega"].clone())
+        pc._zeta = P(0.1 * torch.randn(n, 1, generator=g))
+        pc._trbf_center = P(p["trbf_center"].clone())
+        pc._trbf_scale = P(0.1 * torch.randn(n, 1, generator=g))
+        pc._motion = P(0.1 * torch.randn(n, 9, generator=g))
+        pc.control_xyz = P(p["control_xyz"].clone())
+        pc.current_control_num = p["current_control_num"].clone().reshape(n, 1)
+        pc._deformation_table = torch.rand(n, generator=g) > 0.3
+        pc.max_radii2D = torch.zeros(n)
+        pc.spatial_lr_scale = 1.0
+        pc.training_setup(OptArgs())
+        # the reference hands current_control_num to Adam as a plain tensor; populate the Adam state with one step
+        for gname, attr in DENSIFY_GROUPS:
+            t = getattr(pc, attr)
+            if t.requires_grad and t.numel() > 0:
+                t.grad = torch.randn(t.shape, generator=g) * 0.01
+        pc.optimizer.step()
+
+        def state(tag):
+            out = {}
+            groups = {gr["name"]: gr for gr in pc.optimizer.param_groups}
+            for gname, attr in DENSIFY_GROUPS:
+                t = getattr(pc, attr)
+                assert groups[gname]["params"][0] is t, gname  # the attribute IS the optimiser's parameter
+                out[f"{tag}.{gname}"] = np_(t).copy()
+                st = pc.optimizer.state.get(t, None)
+                if st is not None and "exp_avg" in st:
+                    out[f"{tag}.{gname}.exp_avg"] = np_(st["exp_avg"]).copy()
+                    out[f"{tag}.{gname}.exp_avg_sq"] = np_(st["exp_avg_sq"]).copy()
+            for a in DENSIFY_AUX:
+                out[f"{tag}.{a}"] = np_(getattr(pc, a)).copy()
+            return out
+
+        rec = {}
+        rec.update(state("s0"))
+        # two iterations of per-step statistics (helper_train.py:263-264)
+        stats_in = []
+        for it in range(2):
+            vsp = torch.randn(n, 3, generator=g) * 3e-4
+            vis = torch.rand(n, generator=g) > 0.4
+            radii = torch.randint(0, 40, (n,), generator=g).to(torch.float32)
+            pc.max_radii2D[vis] = torch.max(pc.max_radii2D[vis], radii[vis])
+            pc.add_densification_stats(vsp, vis)
+            stats_in.append((vsp, vis, radii))
+        rec.update(state("s1"))
+        for it, (vsp, vis, radii) in enumerate(stats_in):
+            rec[f"stats{it}.viewspace_grad"], rec[f"stats{it}.visible"], rec[f"stats{it}.radii"] = \
+                np_(vsp), np_(vis), np_(radii)
+        # densify_pruneclone = clone + splitv2 (scene/gaussian_model.py:1417-1434), grads as formed there
+        grads = pc.xyz_gradient_accum / pc.denom
+        grads[grads.isnan()] = 0.0
+        max_grad, extent = 2.0e-4, 4.0
+        rec["grads"], rec["max_grad"], rec["extent"] = np_(grads), np.float32(max_grad), np.float32(extent)
+        pc.densify_and_clone(grads, max_grad, extent)
+        rec.update(state("s2"))
+        drawn = {}
+        real_normal = torch.normal
+
+        def recording_normal(mean, std, **kw):
+            drawn["samples"] = real_normal(mean=mean, std=std, generator=g)
+            return drawn["samples"]
+
+        torch.normal = recording_normal
+        try:
+            pc.densify_and_splitv2(grads, max_grad, extent, 2)
+        finally:
+            torch.normal = real_normal
+        rec["split.samples"] = np_(drawn["samples"])
+        rec.update(state("s3"))
+        prune_mask = (pc.get_opacity < 0.3).squeeze()
+        rec["prune.mask"] = np_(prune_mask)
+        pc.prune_points(prune_mask)
+        rec.update(state("s4"))
+        pc.reset_opacity()
+        rec.update(state("s5"))
+    save(name, **rec)
+
+
 def main():
     RH.install()
     gen_hermite("hermite")
@@ -312,6 +444,7 @@ def main():
     gen_deform("deform")
     gen_blce("blce")
     gen_losses("losses")
+    gen_densify("densify")
 
 
 if __name__ == "__main__":

@@ -271,3 +271,47 @@ def test_loss_restatement_matches_reference_fixture():
     close(L.psnr(img.detach(), gt), fx["psnr"], 1e-6, 1e-6, "psnr")
     (L.l1_loss(img, gt) + 0.2 * (1 - L.ssim(img, gt))).backward()
     close(img.grad, fx["grad_img"], 1e-5, 1e-8, "grad")
+
+
+def _assert_state(st, fx, tag, atol=0.0):
+    from oracle import densify_torch as D
+    for g in D.GROUPS:
+        for kind, store in (("", st["params"]), (".exp_avg", st["exp_avg"]), (".exp_avg_sq", st["exp_avg_sq"])):
+            key = f"{tag}.{g}{kind}"
+            if key not in fx:
+                assert kind and g not in store
+                continue
+            ref = torch.from_numpy(fx[key])
+            got = store[g]
+            assert got.shape == ref.shape, (key, got.shape, ref.shape)
+            if atol == 0.0:
+                assert torch.equal(got, ref), key
+            else:
+                assert torch.allclose(got, ref, rtol=1e-6, atol=atol), key
+    for a in D.AUX:
+        ref = torch.from_numpy(fx[f"{tag}.{a}"])
+        assert st["aux"][a].shape == ref.shape and torch.equal(st["aux"][a], ref), f"{tag}.{a}"
+
+
+def test_densify_oracle_matches_reference_fixture():
+    """oracle/densify_torch.py replays the reference GaussianModel's statistics -> clone -> split -> prune ->
+    opacity-reset sequence state for state (parameters, Adam moments, per-splat statistics)."""
+    from oracle import densify_torch as D
+    fx = load("densify")
+    st = D.state_from_fixture(fx, "s0")
+    for it in range(2):
+        D.add_densification_stats(st, torch.from_numpy(fx[f"stats{it}.viewspace_grad"]),
+                                  torch.from_numpy(fx[f"stats{it}.visible"]),
+                                  torch.from_numpy(fx[f"stats{it}.radii"]))
+    _assert_state(st, fx, "s1")
+    grads = D.mean_grads(st)
+    assert torch.equal(grads, torch.from_numpy(fx["grads"]))
+    thr, extent = float(fx["max_grad"]), float(fx["extent"])
+    D.densify_and_clone(st, grads, thr, extent)
+    _assert_state(st, fx, "s2")
+    D.densify_and_splitv2(st, grads, thr, extent, 2, samples=torch.from_numpy(fx["split.samples"]))
+    _assert_state(st, fx, "s3")
+    D.prune_points(st, torch.from_numpy(fx["prune.mask"]))
+    _assert_state(st, fx, "s4")
+    D.reset_opacity(st)
+    _assert_state(st, fx, "s5")
