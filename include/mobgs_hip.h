@@ -229,6 +229,38 @@ int mobgs_raster_layers_bwd(int C, int N, int Ns, int layer_mask, int channels, 
                             float* v_means2d_layer0, float* v_means2d, float* v_conics, float* v_opacities,
                             float* v_colors, float* v_extra, void* stream);
 
+/* ---- K13: densification ---------------------------------------------------------------
+ * The per-splat table (14 optimiser groups + their Adam moments + 5 statistics arrays) of
+ * /root/reference/scene/gaussian_model.py:598-617 is resized by clone / split / prune
+ * (:1044-1155, :1207-1244, :1480-1506).  The reference does it with ~50 torch index/cat/repeat calls per
+ * operation; here a resize is: masks (mobgs_densify_select) -> row list (mobgs_mask_indices + list arithmetic) ->
+ * ONE mobgs_rows_gather launch that moves every field into a second buffer set -> mobgs_split_children.
+ *
+ * mobgs_densify_stats: the per-iteration statistics of helper_train.py:263-264 + gaussian_model.py:1352-1356,
+ *   for rows with visible[i] != 0 (visible == NULL: radii[i] > 0): max_radii2D[i] = max(., radii[i]) (skipped when
+ *   radii or max_radii2D is NULL), xyz_gradient_accum[i] += |viewspace_grad[i, 0:2]|, denom[i] += 1.
+ *   viewspace_grad is [n, grad_stride] (2 for means2d.grad, 3 for the reference's screenspace tensor).
+ * mobgs_densify_select: g = accum/denom (NaN -> 0; rows >= n_grads count as 0), big = max_k exp(scaling[i,k]) >
+ *   size_threshold (= percent_dense * scene_extent): clone_sel = |g| >= thr && !big, split_sel = g >= thr && big.
+ * mobgs_mask_indices: indices[0..count) = ascending rows with (mask[i] != 0) == (want != 0); count is a device int.
+ * mobgs_rows_gather: for every field f (host arrays of n_fields device pointers / row sizes in bytes / flags) and
+ *   output row r: dst_f[dst_offset + r] = src_f[index[r]] if index[r] >= 0; a negative index marks a NEW copy of
+ *   row -(index[r]+1): fields with zero_new[f] != 0 (Adam moments) get zeros there, the others the copy.
+ * mobgs_split_children: rows [first_row, first_row + n_children) hold copies of their parents;
+ *   xyz += R(rotation) * sample, scaling = log(exp(scaling) / (0.8 * n_split))  (gaussian_model.py:1218-1221). */
+int mobgs_densify_stats(int n, const float* viewspace_grad, int grad_stride, const uint8_t* visible,
+                        const int32_t* radii, float* xyz_gradient_accum, float* denom, float* max_radii2D,
+                        void* stream);
+int mobgs_densify_select(int n, int n_grads, const float* xyz_gradient_accum, const float* denom,
+                         const float* scaling, float grad_threshold, float size_threshold, uint8_t* clone_sel,
+                         uint8_t* split_sel, void* stream);
+int mobgs_mask_indices(int n, const uint8_t* mask, int want, int32_t* indices, int32_t* count, void* stream);
+int mobgs_rows_gather(int n_fields, const void* const* src_host, void* const* dst_host,
+                      const int32_t* row_bytes_host, const int32_t* zero_new_host, const int32_t* index, int n_out,
+                      int dst_offset, void* stream);
+int mobgs_split_children(int n_children, int first_row, int n_split, const float* samples, const float* rotation,
+                         float* xyz, float* scaling, void* stream);
+
 /* 1 if raster kernels are compiled for `total_channels` (colour channels + optional extra channel). */
 int mobgs_raster_channels_supported(int total_channels);
 

@@ -40,6 +40,11 @@ _SIGS = {
     "mobgs_project_and_bin_speculative": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float,
                                                   c_float, c_float, c_float, c_int, P, P, P, P, P, P, P, P, P, c_int,
                                                   P, P, c_int64, P, P, P, c_int64, P, P]),
+    "mobgs_densify_stats": (c_int, [c_int, P, c_int, P, P, P, P, P, P]),
+    "mobgs_densify_select": (c_int, [c_int, c_int, P, P, P, c_float, c_float, P, P, P]),
+    "mobgs_mask_indices": (c_int, [c_int, P, c_int, P, P, P]),
+    "mobgs_rows_gather": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P]),
+    "mobgs_split_children": (c_int, [c_int, c_int, c_int, P, P, P, P, P]),
     "mobgs_pack_records": (c_int, [c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P]),
     "mobgs_raster_layers_fwd": (c_int, [c_int] * 7 + [P] * 8 + [P]),
     "mobgs_raster_layers_bwd": (c_int, [c_int] * 8 + [P] * 20 + [P]),  # incl. 7 host pointer arrays of length 3

@@ -27,6 +27,124 @@ def timed(fn, steps, warmup=3):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def densify_legs(dev, steps, n=300_000):
+    """per-iteration statistics and one densify_pruneclone on a 300k-splat table -- the fused path
+    (mobgs_amd.densify) beside the reference's op sequence (torch index / cat / repeat per optimiser group,
+    scene/gaussian_model.py:1044-1244, :1352-1356, :1480-1506) run with torch on the same GPU."""
+    from mobgs_amd.densify import GROUPS, TrainableGaussians
+    from mobgs_amd.synth import SynthCamera, dynamic_extras, gaussian_cloud
+
+    class Opt:
+        percent_dense, position_lr_init, feature_lr, featuret_lr, opacity_lr = 0.01, 0.00016, 0.0025, 0.001, 0.05
+        scaling_lr, rotation_lr, omega_lr, zeta_lr, trbfc_lr, trbfs_lr, movelr, rgb_lr = \
+            0.005, 0.001, 0.0001, 0.0001, 0.0001, 0.03, 3.5, 0.0001
+
+    cam = SynthCamera(1352, 1014)
+    p = gaussian_cloud(n, cam, 5)
+    p.update(dynamic_extras(p["xyz"], 5))
+    g = torch.Generator().manual_seed(1)
+    p["scaling"] = p["scaling"] + 1.2 * torch.randn(n, 3, generator=g)
+    vsp = (torch.randn(n, 2, generator=g) * 3e-4).to(dev)
+    vis = (torch.rand(n, generator=g) > 0.4).to(dev)
+    radii = torch.randint(0, 40, (n,), generator=g).to(torch.int32).to(dev)
+
+    def fresh():
+        pc = TrainableGaussians({k: p[k] for k in ("xyz", "scaling", "rotation", "opacity", "features_dc",
+                                                    "features_t")},
+                                {k: p[k] for k in ("omega", "trbf_center", "control_xyz", "current_control_num")},
+                                device=dev)
+        pc.training_setup(Opt())
+        for gr in pc.optimizer.param_groups:
+            for q in gr["params"]:
+                if q.requires_grad and q.numel():
+                    q.grad = torch.full_like(q, 1e-3)
+        pc.optimizer.step()
+        pc.add_densification_stats(vsp, vis, radii=radii)
+        return pc
+
+    out = {}
+    pc = fresh()
+    out["densify_stats_fused_ms"] = timed(lambda: pc.add_densification_stats(vsp, vis, radii=radii), steps)
+    accum, denom, maxr = pc.xyz_gradient_accum, pc.denom, pc.max_radii2D
+    rf = radii.float()
+
+    def stats_torch():
+        maxr[vis] = torch.max(maxr[vis], rf[vis])
+        accum[vis] += torch.norm(vsp[vis, :2], dim=-1, keepdim=True)
+        denom[vis] += 1
+
+    out["densify_stats_torch_ops_ms"] = timed(stats_torch, steps)
+
+    def fused_once():
+        m = fresh()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.densify_pruneclone(2e-4, 0.005, 4.0, None, 2)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, m.get_xyz.shape[0]
+
+    def torch_once():
+        """the reference's sequence on plain tensors: clone (per-group index + cat, Adam moments cat zeros),
+        split (per-group index + repeat + cat), prune (per-group boolean index incl. moments)"""
+        m = fresh()
+        st = m.table_state()
+        names = [g for g, _ in GROUPS]
+        P = {g: st[g].clone() for g in names}
+        M = {g: (st[g + ".exp_avg"].clone(), st[g + ".exp_avg_sq"].clone()) for g in names if g + ".exp_avg" in st}
+        table = st["_deformation_table"].clone()
+        grads = (st["xyz_gradient_accum"] / st["denom"])
+        grads[grads.isnan()] = 0.0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+
+        def append(new, new_table):
+            nonlocal table
+            for g2 in names:
+                P[g2] = torch.cat((P[g2], new[g2]), 0)
+                if g2 in M:
+                    M[g2] = (torch.cat((M[g2][0], torch.zeros_like(new[g2])), 0),
+                             torch.cat((M[g2][1], torch.zeros_like(new[g2])), 0))
+            table = torch.cat([table, new_table], -1)
+
+        big = torch.max(torch.exp(P["scaling"]), dim=1).values > 0.01 * 4.0
+        sel = torch.logical_and(torch.norm(grads, dim=-1) >= 2e-4, ~big)
+        append({g2: P[g2][sel] for g2 in names}, table[sel])
+        nn_ = P["xyz"].shape[0]
+        padded = torch.zeros(nn_, device=dev)
+        padded[:grads.shape[0]] = grads.squeeze()
+        scale = torch.exp(P["scaling"])
+        sel2 = torch.logical_and(padded >= 2e-4, torch.max(scale, dim=1).values > 0.01 * 4.0)
+        stds = scale[sel2].repeat(2, 1)
+        samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
+        q = torch.nn.functional.normalize(P["rotation"][sel2])
+        w, x, y, z = q.unbind(-1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+                         1 - 2 * (x * x + z * z), 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+                         1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3).repeat(2, 1, 1)
+        new = {g2: P[g2][sel2].repeat(2, *([1] * (P[g2].dim() - 1))) for g2 in names}
+        new["xyz"] = torch.bmm(R, samples.unsqueeze(-1)).squeeze(-1) + P["xyz"][sel2].repeat(2, 1)
+        new["scaling"] = torch.log(scale[sel2].repeat(2, 1) / 1.6)
+        append(new, table[sel2].repeat(2))
+        keep = ~torch.cat((sel2, torch.zeros(2 * int(sel2.sum()), dtype=torch.bool, device=dev)))
+        for g2 in names:
+            P[g2] = P[g2][keep]
+            if g2 in M:
+                M[g2] = (M[g2][0][keep], M[g2][1][keep])
+        table = table[keep]
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, P["xyz"].shape[0]
+
+    fused_once()
+    torch_once()
+    f = [fused_once() for _ in range(3)]
+    t = [torch_once() for _ in range(3)]
+    assert f[0][1] == t[0][1], (f[0][1], t[0][1])
+    out["densify_pruneclone_fused_ms"] = min(v[0] for v in f)
+    out["densify_pruneclone_torch_ops_ms"] = min(v[0] for v in t)
+    out["densify_rows_after"] = f[0][1]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
@@ -135,6 +253,7 @@ def main():
     res["blurry_view_layered_ms"] = timed(blurry_view, max(3, a.steps // 4), warmup=1)
     res["train_mode_renders_per_s"] = 1e3 / res["train_mode_layered_ms"]
     res["blurry_views_per_s"] = 1e3 / res["blurry_view_layered_ms"]
+    res.update(densify_legs(dev, a.steps))
     res["config"] = "seesaw-synth 200k+100k, 1352x1014, K=9 (1 GPU)"
     print(json.dumps(res))
 

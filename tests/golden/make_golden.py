@@ -390,6 +390,33 @@ def gen_densify(name, n=600, seed=21):
 
         rec = {}
         rec.update(state("s0"))
+        # the reference's own save_ply (scene/gaussian_model.py:761-804) with plyfile replaced by a recorder:
+        # property names in file order and the row matrix it hands to PlyElement.describe
+        captured = {}
+
+        class _Elem:
+            @staticmethod
+            def describe(elements, name):
+                captured["names"], captured["element"] = list(elements.dtype.names), name
+                captured["rows"] = np.stack([elements[k] for k in elements.dtype.names], 1).astype(np.float32)
+                return None
+
+        class _Data:
+            def __init__(self, els):
+                pass
+
+            def write(self, path):
+                captured["path"] = path
+
+        old = gm.PlyElement, gm.PlyData, gm.torch.save, gm.mkdir_p
+        gm.PlyElement, gm.PlyData, gm.torch.save, gm.mkdir_p = _Elem, _Data, (lambda *a, **k: None), (lambda *a: None)
+        try:
+            pc.save_ply("/tmp/_mobgs_golden/point_cloud.ply")
+        finally:
+            gm.PlyElement, gm.PlyData, gm.torch.save, gm.mkdir_p = old
+        rec["ply.names"] = np.array(captured["names"])
+        rec["ply.rows"] = captured["rows"]
+        rec["ply.element"] = np.array(captured["element"])
         # two iterations of per-step statistics (helper_train.py:263-264)
         stats_in = []
         for it in range(2):
