@@ -10,6 +10,7 @@ include/mobgs_hip.h.  Options the reference never uses raise NotImplementedError
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -204,7 +205,7 @@ _tile_culling = True
 SPECULATIVE_BINNING = True
 _len_hint = {}  # device index -> longest per-tile list of the previous frame (selects the sort variant)
 # True: the compositing kernels take tiles heaviest-list-first (TileLists.tile_order); False: raster order
-TILE_SCHEDULE = True
+TILE_SCHEDULE = os.environ.get("MOBGS_TILE_SCHEDULE", "1") != "0"
 _capacity = {}  # device index -> current capacity of the keep-flag buffer (grows geometrically, never shrinks)
 
 
