@@ -304,3 +304,48 @@ def test_two_cameras_forward_backward(hip_device):
         sc = float(ref[3][k].abs().max())
         _close(out[3][k], ref[3][k], 1e-3, 5e-4 * sc + 1e-6, f"grad[{k}]")
     assert float(out[3]["viewmats"][1].abs().max()) > 0 and float(out[3]["viewmats"][0].abs().max()) > 0
+
+
+def test_speculative_arena_overflow_is_transparent(hip_device):
+    """First frame of a dense scene: the speculative binning arena (sized by guess) is too small, the kernels enqueued
+    behind it see empty lists, resolve() rebuilds the lists synchronously and the compositing launch is re-issued.
+    Outputs and gradients equal the synchronous path bit for bit."""
+    from mobgs_amd import rendering
+    n, w, h = 2000, 256, 192
+    s, _ = _scene(n, w, h, 31, 9)
+    s["scales"] = s["scales"] * 12.0  # every splat covers dozens of tiles: I_box >> 16 N + 1024
+    names = ["means", "quats", "scales", "opacities", "colors", "viewmats"]
+    res = {}
+    for spec in (True, False):
+        rendering.SPECULATIVE_BINNING = spec
+        rendering._capacity.clear()
+        rendering._cap_listed.clear()
+        rendering._len_hint.clear()
+        try:
+            t = {k: v.to(hip_device).clone().requires_grad_(k in names) for k, v in s.items()}
+            sp = rendering.SharedProjection(t["means"], t["quats"], t["scales"], t["opacities"], t["viewmats"],
+                                            t["Ks"], w, h)
+            if spec:
+                assert sp.tl.pending
+            img, a = sp.composite(t["colors"])
+            assert not sp.tl.pending
+            if spec:
+                assert sp.tl.n_box > 16 * n + 1024, sp.tl.n_box  # the guess WAS too small
+            g = torch.Generator().manual_seed(7)
+            v_img = torch.randn(img.shape, generator=g).to(hip_device)
+            ((img * v_img).sum() + a.sum()).backward()
+            res[spec] = (img.detach().cpu(), a.detach().cpu(), sp.tl.flatten_ids.cpu(),
+                         {k: t[k].grad.cpu() for k in names if t[k].grad is not None})
+            # second frame: the arena has grown, no rebuild
+            if spec:
+                sp2 = rendering.SharedProjection(t["means"], t["quats"], t["scales"], t["opacities"], t["viewmats"],
+                                                 t["Ks"], w, h)
+                img2, _ = sp2.composite(t["colors"])
+                assert torch.equal(img2.detach().cpu(), res[spec][0])
+        finally:
+            rendering.SPECULATIVE_BINNING = True
+    assert float(res[True][1].max()) > 0.5  # something was actually rendered
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert torch.equal(res[True][2], res[False][2])
+    for k in res[False][3]:
+        assert torch.equal(res[True][3][k], res[False][3][k]), k
