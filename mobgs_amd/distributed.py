@@ -90,14 +90,12 @@ class SubframeShard:
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32)
                           for p in params])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        # the reduced gradients stay in the flat buffer: every .grad becomes a view of it (no copy back)
         off = 0
         for p in params:
             n = p.numel()
             g = flat[off:off + n].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
+            p.grad = g if p.dtype == torch.float32 else g.to(p.dtype)
             off += n
 
 
