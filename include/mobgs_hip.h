@@ -90,10 +90,12 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
  *                    keep_scan[(j >> 11) * 2049] + keep_scan[(j >> 11) * 2049 + 1 + (j & 2047)],
  *                defined for 0 <= j <= min(I_box, capacity).
  *      tile_offsets [C*n_tiles+1] exclusive prefix sum of the per-tile list lengths
- *      tile_order [C*n_tiles] (may be NULL) the tile ids by descending list length (1024 length classes): the
- *                order in which the compositing kernels hand tiles to workgroups (longest lists first, lists of
- *                similar length share a workgroup).  A schedule only -- results do not depend on it; the
- *                compositing entry points accept NULL for "raster order".
+ *      tile_order [mobgs_tile_order_len(C*n_tiles)] (may be NULL) the schedule of the compositing kernels, 4
+ *                slots per workgroup: tile ids by descending list length (1024 length classes; longest lists
+ *                first, lists of similar length share a workgroup), -1 = unused slot.  Tiles whose list is at
+ *                least mobgs_get_heavy_tile_len() long (at most an eighth of the tiles) appear as id | 1<<30 in
+ *                the 4 slots of one workgroup, whose 4 waves then composite one 8x8 quadrant each.  A schedule
+ *                only -- images do not depend on it; the compositing entry points accept NULL for raster order.
  *      stats int64[3] = {I_box, I_listed, longest per-tile list}; the caller reads them back to size the list
  *      buffers (the one host sync of the pipeline, as in gsplat).  If I_box > capacity the flags were
  *      truncated: call again with capacity >= I_box.
@@ -102,6 +104,9 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
  *      already enqueued behind this call touch nothing; stats still hold the true counts.  <= 0: no such check.
  * scratch: mobgs_isect_scratch_bytes(C*N, C*n_tiles, capacity) bytes. */
 size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity);
+size_t mobgs_tile_order_len(int n_tiles);  /* int32 entries of tile_order */
+void mobgs_set_heavy_tile_len(int len);    /* scheduling policy, default 1024; 0 = never split a tile */
+int mobgs_get_heavy_tile_len(void);
 size_t mobgs_keep_scan_len(int capacity); /* int32 entries of keep_scan for `capacity` box intersections */
 int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
                         const int32_t* tiles_per_gauss, const float* means2d, const int32_t* radii,

@@ -56,6 +56,15 @@ __host__ __device__ inline TileRect tile_rect(float mx, float my, int radius, in
 }
 
 
+// ---- tile schedule (tile_scan_kernel) ------------------------------------------------------------------------------
+// tile_order has sched_slots(n_tiles) entries, 4 per workgroup of the compositing kernels: a tile id, a tile id |
+// SCHED_HEAVY (in all 4 slots of one workgroup: the 4 waves share that tile, one 8x8 quadrant each) or -1 (unused).
+// At most an eighth of the tiles (the longest) are scheduled heavy: when more lists than that are long, long is
+// the norm and no single list is the critical path.
+constexpr int SCHED_HEAVY = 1 << 30;
+__host__ __device__ inline size_t sched_max_heavy(size_t n_tiles) { return n_tiles / 8; }
+__host__ __device__ inline size_t sched_slots(size_t n_tiles) { return n_tiles + 3 * sched_max_heavy(n_tiles) + 4; }
+
 // ---- compact index of a bounding-box intersection (= its gradient slot) -----------------------------------------
 // keep_scan is stored in chunks of KEEP_CHUNK intersections, each preceded by one word: [base_c | local_0 ..
 // local_2047] with local_i = number of kept intersections before i inside the chunk and base_c = number kept in

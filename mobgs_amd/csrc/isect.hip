@@ -274,10 +274,13 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
 }
 
 // single workgroup: exclusive scan of tile_count[nt] -> tile_offsets[nt+1]; stats[2] = max count;
-// tile_order[nt] (optional) = the tiles by DESCENDING list length (counting sort on ORDER_BUCKETS length classes):
-// the order in which the compositing kernels hand tiles to workgroups, so that the longest lists start first and
-// the waves of one workgroup get lists of similar length (longest-processing-time-first scheduling).  Only a
-// schedule: any permutation gives the same images and gradients.
+// tile_order[sched_slots(nt)] (optional) = the tiles by DESCENDING list length (counting sort on ORDER_BUCKETS length
+// classes): the order in which the compositing kernels hand tiles to workgroups, so that the longest lists start
+// first and the waves of one workgroup get lists of similar length (longest-processing-time-first scheduling).
+// Tiles whose list is at least `heavy_len` long (at most nt/8 of them, the longest) take a whole workgroup: their
+// id is written with SCHED_HEAVY into 4 consecutive slots and each of the 4 waves composites one 8x8 quadrant, so
+// that one very long list does not become the critical path of the launch.  Only a schedule: images are
+// bit-identical for any permutation / heavy marking, gradients equal up to the summation order of the quadrants.
 constexpr int ORDER_BUCKETS = 1024;
 constexpr int TSCAN_THREADS = 1024;
 __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const int32_t* __restrict__ tile_count,
@@ -285,7 +288,8 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
                                                                     int64_t* __restrict__ stats,
                                                                     int32_t* __restrict__ tile_order,
                                                                     int64_t capacity_box, int64_t capacity_listed,
-                                                                    int32_t* __restrict__ keep_scan, int n_chunks) {
+                                                                    int32_t* __restrict__ keep_scan, int n_chunks,
+                                                                    int heavy_len) {
     __shared__ int smax[TSCAN_THREADS / 64];
     __shared__ int hist[ORDER_BUCKETS];
     // workgroup 1: chunk totals -> chunk bases of keep_scan (bin_kernel left each chunk's total in its base
@@ -349,9 +353,31 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
         hist[threadIdx.x] = inc - mine;
     }
     __syncthreads();
+    // heavy = every tile in a length class above class B, where B is the class `heavy_len` falls into, lowered until
+    // at most sched_max_heavy tiles qualify: the heavy SET depends only on the tiles' classes (deterministic -- the
+    // atomic order inside a class must not decide who is heavy, or gradients would differ from run to run)
+    __shared__ int s_heavy, s_cut;
+    if (threadIdx.x == 0) s_cut = 0;
+    __syncthreads();
+    if (heavy_len > 0 && longest >= heavy_len) {
+        const int b_thr = bucket(heavy_len);
+        if ((int)threadIdx.x <= b_thr && hist[threadIdx.x] <= (int)sched_max_heavy((size_t)nt))
+            atomicMax(&s_cut, (int)threadIdx.x);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_heavy = hist[s_cut];  // tiles in the classes before the cut (hist = exclusive prefix)
+    const int n_slots = (int)sched_slots((size_t)nt);
+    for (int i = threadIdx.x; i < n_slots; i += TSCAN_THREADS) tile_order[i] = -1;
+    __syncthreads();
+    const int n_heavy = s_heavy;
     for (int i = threadIdx.x; i < nt; i += TSCAN_THREADS) {
         const int pos = atomicAdd(&hist[bucket(tile_count[i])], 1);
-        tile_order[pos] = i;
+        if (pos < n_heavy) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tile_order[4 * pos + q] = i | SCHED_HEAVY;
+        } else {
+            tile_order[3 * n_heavy + pos] = i;
+        }
     }
 }
 
@@ -522,6 +548,9 @@ __global__ void __launch_bounds__(THREADS) tile_sort_kernel(int n_tiles_total, i
 
 using namespace mobgs;
 
+// list length from which a tile is composited by a whole workgroup (scheduling policy, see tile_scan_kernel)
+static int g_heavy_len = 1024;
+
 extern "C" {
 
 // Layout of the scratch buffer shared by mobgs_isect_offsets and mobgs_isect_emit_sort (int32 units):
@@ -547,6 +576,11 @@ struct IsectScratch {
         total_ints = zeroed_ints + 4 * capacity;
     }
 };
+
+size_t mobgs_tile_order_len(int n_tiles) { return sched_slots((size_t)n_tiles); }
+
+void mobgs_set_heavy_tile_len(int len) { g_heavy_len = len < 0 ? 0 : len; }
+int mobgs_get_heavy_tile_len(void) { return g_heavy_len; }
 
 size_t mobgs_keep_scan_len(int capacity) { return keep_scan_len((size_t)capacity); }
 
@@ -579,7 +613,7 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
         hipMemsetAsync(keep_scan, 0, 2 * sizeof(int32_t), st);  // base and first local of chunk 0
         hipMemsetAsync(stats, 0, 3 * sizeof(int64_t), st);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
-                           stats, tile_order, (int64_t)capacity, (int64_t)0, (int32_t*)nullptr, 0);
+                           stats, tile_order, (int64_t)capacity, (int64_t)0, (int32_t*)nullptr, 0, g_heavy_len);
         return check_launch("isect_offsets(empty)");
     }
     // bounding-box counts -> cum_tiles; stats[0] = I_box
@@ -592,7 +626,7 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
                        capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera, L.flags, L.owner,
                        L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
-                       stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks);
+                       stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, g_heavy_len);
     return check_launch("isect_offsets");
 }
 

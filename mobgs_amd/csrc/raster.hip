@@ -29,11 +29,12 @@ constexpr int PPL = 4;            // pixels per lane
 constexpr int TILES_PER_WG = 4;   // waves per workgroup, each on its own tile
 
 // Which tile this wave works on: with a schedule, workgroups take tiles in the given order (heaviest first);
-// without, tiles are taken in XCD-chunked raster order.  -1: nothing to do.
+// without, tiles are taken in XCD-chunked raster order.  -1: nothing to do.  With a schedule the value may carry
+// SCHED_HEAVY: the 4 waves of the workgroup then share that ONE tile, wave w taking its 8x8 quadrant w.
 __device__ inline int scheduled_tile(const int32_t* tile_order, int n_groups, int n_tiles_total, int wv) {
     if (tile_order) {
         const int slot = blockIdx.x * TILES_PER_WG + wv;
-        return slot < n_tiles_total ? tile_order[slot] : -1;
+        return slot < (int)sched_slots((size_t)n_tiles_total) ? tile_order[slot] : -1;
     }
     const int group = xcd_chunked(blockIdx.x, n_groups);
     if (group >= n_groups) return -1;
@@ -101,19 +102,21 @@ pack_records_kernel(int N, int channels, int stride, const float* __restrict__ m
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-template <int CD>
-__global__ void __launch_bounds__(64 * TILES_PER_WG)
-raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
-                  const float* __restrict__ records, const float* __restrict__ backgrounds,
-                  const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-                  float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
-                  const int32_t* __restrict__ tile_order) {
+// One wave composites NP pixels per lane of `tile` front to back: NP = 4 -> the whole 16x16 tile (pixel k of a lane
+// lies in quadrant k), NP = 1 -> only the 8x8 quadrant `quad` (heavy tiles: 4 waves share the list walk, which cuts
+// the critical path of a long list ~2.6x; every pixel sees exactly the same arithmetic either way).
+template <int CD, int NP>
+__device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int lane,
+                                              float4 (*slab)[64][((6 + CD + 3) & ~3) / 4], int tile_w, int tile_h,
+                                              int width, int height, const float* __restrict__ records,
+                                              const float* __restrict__ backgrounds,
+                                              const int32_t* __restrict__ tile_offsets,
+                                              const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
+                                              float* __restrict__ alphas, int32_t* __restrict__ last_ids) {
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
-    __shared__ float4 slab[TILES_PER_WG][64][RQ];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
-    if (tile < 0) return;
+    constexpr int PPL = NP;
+    constexpr unsigned ALL_DONE = (1u << NP) - 1u;
     const int tiles_per_cam = tile_w * tile_h;
     const int cam = tile / tiles_per_cam;
     const int tl = tile - cam * tiles_per_cam;
@@ -123,8 +126,9 @@ raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
     unsigned done = 0;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
-        pxi[k] = tx * MOBGS_TILE + 8 * (k & 1) + (lane & 7);
-        pyi[k] = ty * MOBGS_TILE + 8 * (k >> 1) + (lane >> 3);
+        const int qd = NP == 4 ? k : quad;
+        pxi[k] = tx * MOBGS_TILE + 8 * (qd & 1) + (lane & 7);
+        pyi[k] = ty * MOBGS_TILE + 8 * (qd >> 1) + (lane >> 3);
         px[k] = (float)pxi[k] + 0.5f;
         py[k] = (float)pyi[k] + 0.5f;
         if (!(pxi[k] < width && pyi[k] < height)) done |= 1u << k;
@@ -205,7 +209,7 @@ raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
                     last[k] = blend[k] ? (b + j) : last[k];
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(done != 0xFu) == 0ull) {
+            if (__builtin_amdgcn_ballot_w64(done != ALL_DONE) == 0ull) {
                 all_done = true;
                 break;
             }
@@ -225,6 +229,26 @@ raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
             out[c] = v;
         }
     }
+}
+
+template <int CD>
+__global__ void __launch_bounds__(64 * TILES_PER_WG)
+raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
+                  const float* __restrict__ records, const float* __restrict__ backgrounds,
+                  const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+                  float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
+                  const int32_t* __restrict__ tile_order) {
+    constexpr int RQ = ((6 + CD + 3) & ~3) / 4;
+    __shared__ float4 slab[TILES_PER_WG][64][RQ];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
+    if (slot < 0) return;
+    if (slot & SCHED_HEAVY)
+        composite_fwd<CD, 1>(slot & ~SCHED_HEAVY, wv, wv, lane, slab, tile_w, tile_h, width, height, records,
+                             backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids);
+    else
+        composite_fwd<CD, 4>(slot, 0, wv, lane, slab, tile_w, tile_h, width, height, records, backgrounds,
+                             tile_offsets, flatten_ids, render, alphas, last_ids);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -268,25 +292,42 @@ __device__ __forceinline__ void wave_reduce_components(float (&v)[NVP]) {
     for (int i = 0; i < NVP / 4; ++i) v[i] = row_allreduce(v[i]);
 }
 
+// LDS of one workgroup of the backward kernel
 template <int CD>
-__global__ void __launch_bounds__(64 * TILES_PER_WG)
-raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
-                  const float* __restrict__ records, const float* __restrict__ backgrounds,
-                  const int32_t* __restrict__ radii, const int32_t* __restrict__ cum_tiles,
-                  const int32_t* __restrict__ keep_scan, const int32_t* __restrict__ tile_offsets,
-                  const int32_t* __restrict__ flatten_ids, const float* __restrict__ render_alphas,
-                  const int32_t* __restrict__ last_ids,
-                  const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                  float* __restrict__ grad_slots, const int32_t* __restrict__ tile_order) {
+struct BwdShared {
+    static constexpr int RS = (6 + CD + 3) & ~3;
+    float4 slab[TILES_PER_WG][64][RS / 4];  // the batch's splat records, one copy per wave
+    int slot_of[TILES_PER_WG][64];          // gradient slot of each batch entry
+    float part[TILES_PER_WG][64][RS];       // heavy tiles: per-wave (= per-quadrant) gradient records of the batch
+    unsigned long long touched[TILES_PER_WG];
+    int top[TILES_PER_WG];
+};
+
+// One wave walks `tile` back to front for NP pixels per lane.  NP = 4: the whole tile, one gradient record per
+// (tile, splat) straight to grad_slots.  NP = 1 (HEAVY): the 4 waves of the workgroup share the tile, wave `quad`
+// taking one 8x8 quadrant; they walk the same batches in step, leave their partial records in LDS and the
+// workgroup sums the (up to 4) partials of every entry into its ONE slot -- still no floating-point atomics, and a
+// fixed summation order (quadrant 0..3), so gradients stay bit-reproducible.
+template <int CD, int NP>
+__device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int lane, BwdShared<CD>& sh, int tile_w,
+                                              int tile_h, int width, int height, const float* __restrict__ records,
+                                              const float* __restrict__ backgrounds,
+                                              const int32_t* __restrict__ radii, const int32_t* __restrict__ cum_tiles,
+                                              const int32_t* __restrict__ keep_scan,
+                                              const int32_t* __restrict__ tile_offsets,
+                                              const int32_t* __restrict__ flatten_ids,
+                                              const float* __restrict__ render_alphas,
+                                              const int32_t* __restrict__ last_ids,
+                                              const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+                                              float* __restrict__ grad_slots) {
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
     constexpr int NV = 6 + CD;
     constexpr int NVP = NV <= 8 ? 8 : (NV <= 16 ? 16 : (NV <= 32 ? 32 : 64));
-    __shared__ float4 slab[TILES_PER_WG][64][RQ];
-    __shared__ int slot_of[TILES_PER_WG][64];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
-    if (tile < 0) return;
+    constexpr int PPL = NP;
+    constexpr bool HEAVY = NP == 1;
+    auto& slab = sh.slab;
+    auto& slot_of = sh.slot_of;
     const int tiles_per_cam = tile_w * tile_h;
     const int cam = tile / tiles_per_cam;
     const int tl = tile - cam * tiles_per_cam;
@@ -305,8 +346,9 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
     int top = -1;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
-        const int pxi = tx * MOBGS_TILE + 8 * (k & 1) + (lane & 7);
-        const int pyi = ty * MOBGS_TILE + 8 * (k >> 1) + (lane >> 3);
+        const int qd = HEAVY ? quad : k;
+        const int pxi = tx * MOBGS_TILE + 8 * (qd & 1) + (lane & 7);
+        const int pyi = ty * MOBGS_TILE + 8 * (qd >> 1) + (lane >> 3);
         px[k] = (float)pxi + 0.5f;
         py[k] = (float)pyi + 0.5f;
         const bool inside = pxi < width && pyi < height;
@@ -336,10 +378,16 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
     // highest list index any pixel of the tile blended
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
+    if (HEAVY) {  // all 4 quadrant waves walk the same batches
+        if (lane == 0) sh.top[wv] = top;
+        __syncthreads();
+        top = max(max(sh.top[0], sh.top[1]), max(sh.top[2], sh.top[3]));
+    }
     top = min(top, e - 1);
 
     for (int hi = top; hi >= s; hi -= 64) {
         const int n = min(64, hi - s + 1);
+        unsigned long long touched = 0ull;  // heavy: batch entries this wave produced a record for
         wave_lds_fence();
         if (lane < n) {
             const int g = flatten_ids[hi - lane];
@@ -415,8 +463,9 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
             // lane 0 of each 16-lane row stores its NVP/4 consecutive components (64 B per record for D = 10)
             constexpr int Q = NVP / 4;
             const int base = (lane >> 5) * (NVP / 2) + ((lane >> 4) & 1) * Q;
+            if (HEAVY) touched |= 1ull << j;
             if ((lane & 15) == 0 && base < RS) {
-                float* dst = grad_slots + (size_t)slot_of[wv][j] * RS + base;
+                float* dst = HEAVY ? &sh.part[wv][j][base] : grad_slots + (size_t)slot_of[wv][j] * RS + base;
                 if constexpr (Q == 2) {
                     *reinterpret_cast<float2*>(dst) = make_float2(g[0], g[1]);
                 } else {
@@ -427,8 +476,56 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
                 }
             }
         }
+        if (HEAVY) {
+            if (lane == 0) sh.touched[wv] = touched;
+            __syncthreads();
+            // entry r of the batch, 16-byte part q: sum of the partial records of the quadrants that touched it
+            for (int t = threadIdx.x; t < n * RQ; t += 64 * TILES_PER_WG) {
+                const int r = t / RQ, q = t - r * RQ;
+                float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                bool any = false;
+#pragma unroll
+                for (int w = 0; w < TILES_PER_WG; ++w) {
+                    if ((sh.touched[w] >> r) & 1ull) {
+                        const float4 v = reinterpret_cast<const float4*>(sh.part[w][r])[q];
+                        acc4.x += v.x;
+                        acc4.y += v.y;
+                        acc4.z += v.z;
+                        acc4.w += v.w;
+                        any = true;
+                    }
+                }
+                if (any) reinterpret_cast<float4*>(grad_slots + (size_t)slot_of[0][r] * RS)[q] = acc4;
+            }
+            __syncthreads();  // the partial records and slot table are free for the next batch
+        }
     }
 }
+
+template <int CD>
+__global__ void __launch_bounds__(64 * TILES_PER_WG)
+raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
+                  const float* __restrict__ records, const float* __restrict__ backgrounds,
+                  const int32_t* __restrict__ radii, const int32_t* __restrict__ cum_tiles,
+                  const int32_t* __restrict__ keep_scan, const int32_t* __restrict__ tile_offsets,
+                  const int32_t* __restrict__ flatten_ids, const float* __restrict__ render_alphas,
+                  const int32_t* __restrict__ last_ids,
+                  const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+                  float* __restrict__ grad_slots, const int32_t* __restrict__ tile_order) {
+    __shared__ BwdShared<CD> sh;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
+    if (slot < 0) return;
+    if (slot & SCHED_HEAVY)  // workgroup-uniform: all 4 slots of a heavy workgroup carry the flag
+        composite_bwd<CD, 1>(slot & ~SCHED_HEAVY, wv, wv, lane, sh, tile_w, tile_h, width, height, records,
+                             backgrounds, radii, cum_tiles, keep_scan, tile_offsets, flatten_ids, render_alphas,
+                             last_ids, v_render, v_alphas, grad_slots);
+    else
+        composite_bwd<CD, 4>(slot, 0, wv, lane, sh, tile_w, tile_h, width, height, records, backgrounds, radii,
+                             cum_tiles, keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids, v_render,
+                             v_alphas, grad_slots);
+}
+
 
 // ---------------------------------------------------------------------------------------------------
 // backward, stage 2: per-splat sum of its slots -> dense gradient tensors
@@ -533,7 +630,7 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
                            records);
     }
     const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
-    const int grid = ((n_groups + 7) / 8) * 8;
+    const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
     const int rc = dispatch_channels(D, [&](auto cd) {
         constexpr int CD = decltype(cd)::value;
         hipLaunchKernelGGL(raster_fwd_kernel<CD>, dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups, tile_w,
@@ -564,7 +661,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
     const int nt = C * tile_w * tile_h;
     const int stride = record_stride(D);
     const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
-    const int grid = ((n_groups + 7) / 8) * 8;
+    const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
     const int rc = dispatch_channels(D, [&](auto cd) {
         constexpr int CD = decltype(cd)::value;
         hipLaunchKernelGGL(raster_bwd_kernel<CD>, dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups, tile_w,

@@ -102,8 +102,13 @@ raster_layers_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
     int tile;
     if (tile_order) {  // heaviest-first schedule (see tile_scan_kernel); otherwise XCD-chunked raster order
         const int slot = blockIdx.x * 2 + (wv >> 1);
-        if (slot >= n_tiles_total) return;
+        if (slot >= (int)sched_slots((size_t)n_tiles_total)) return;
         tile = tile_order[slot];
+        if (tile < 0) return;
+        if (tile & SCHED_HEAVY) {  // a heavy tile fills 4 slots; this kernel always uses 2 waves per tile
+            if (slot & 3) return;
+            tile &= ~SCHED_HEAVY;
+        }
     } else {
         const int group = xcd_chunked(blockIdx.x, n_groups);
         if (group >= n_groups) return;
@@ -322,8 +327,13 @@ raster_layers_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
     int tile;
     if (tile_order) {  // heaviest-first schedule (see tile_scan_kernel); otherwise XCD-chunked raster order
         const int slot = blockIdx.x * 2 + (wv >> 1);
-        if (slot >= n_tiles_total) return;
+        if (slot >= (int)sched_slots((size_t)n_tiles_total)) return;
         tile = tile_order[slot];
+        if (tile < 0) return;
+        if (tile & SCHED_HEAVY) {  // a heavy tile fills 4 slots; this kernel always uses 2 waves per tile
+            if (slot & 3) return;
+            tile &= ~SCHED_HEAVY;
+        }
     } else {
         const int group = xcd_chunked(blockIdx.x, n_groups);
         if (group >= n_groups) return;
@@ -503,7 +513,7 @@ int mobgs_raster_layers_fwd(int C, int N, int Ns, int layer_mask, int channels_t
     const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
     const int nt = C * tile_w * tile_h;
     const int n_groups = (nt + 1) / 2;
-    const int grid = ((n_groups + 7) / 8) * 8;
+    const int grid = tile_order ? (int)((sched_slots((size_t)nt) + 1) / 2) : ((n_groups + 7) / 8) * 8;
     hipLaunchKernelGGL(raster_layers_fwd_kernel<10>, dim3(grid), dim3(64 * LWAVES), 0, (hipStream_t)stream, nt, n_groups,
                        tile_w, tile_h, width, height, N, Ns, layer_mask, records, backgrounds, tile_offsets, tile_order,
                        flatten_ids, o);
@@ -539,7 +549,7 @@ int mobgs_raster_layers_bwd(int C, int N, int Ns, int layer_mask, int channels, 
     const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
     const int nt = C * tile_w * tile_h;
     const int n_groups = (nt + 1) / 2;
-    const int grid = ((n_groups + 7) / 8) * 8;
+    const int grid = tile_order ? (int)((sched_slots((size_t)nt) + 1) / 2) : ((n_groups + 7) / 8) * 8;
     hipLaunchKernelGGL(raster_layers_bwd_kernel<10>, dim3(grid), dim3(64 * LWAVES), 0, st, nt, n_groups, tile_w, tile_h,
                        width, height, N, Ns, layer_mask, records, backgrounds, radii, cum_tiles, keep_scan, tile_offsets,
                        tile_order, flatten_ids, in, grad_slots, grad_xy0);

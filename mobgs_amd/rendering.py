@@ -233,7 +233,8 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Ten
     tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
     tl.cum_tiles = torch.empty(C * N + 1, dtype=torch.int32, device=dev)
     tl.tile_offsets = torch.empty(nt + 1, dtype=torch.int32, device=dev)
-    tl.tile_order = torch.empty(nt, dtype=torch.int32, device=dev) if TILE_SCHEDULE else None
+    tl.tile_order = (torch.empty(lib.mobgs_tile_order_len(nt), dtype=torch.int32, device=dev)
+                     if TILE_SCHEDULE else None)
     stats = torch.empty(3, dtype=torch.int64, device=dev)
     opac = f32c(opacities)
     key = dev.index if dev.index is not None else -1
@@ -469,7 +470,8 @@ class _ProjectAndBin(torch.autograd.Function):
         tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
         cum_tiles = torch.empty(C * N + 1, dtype=torch.int32, device=dev)
         tile_offsets = torch.empty(nt + 1, dtype=torch.int32, device=dev)
-        tile_order = torch.empty(nt, dtype=torch.int32, device=dev) if TILE_SCHEDULE else None
+        tile_order = (torch.empty(lib.mobgs_tile_order_len(nt), dtype=torch.int32, device=dev)
+                      if TILE_SCHEDULE else None)
         stats_dev = torch.empty(3, dtype=torch.int64, device=dev)
         stats_host = (ctypes.c_int64 * 3)()
         key = dev.index if dev.index is not None else -1
