@@ -117,10 +117,12 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
 /* ---- K3b/K4: emit + per-tile depth sort (replaces isect_tiles pass 2 + CUB DeviceRadixSort) ------------
  * Writes, per tile, its listed splats ordered by (float depth bits ascending, flat id ascending) -- the order a
  * stable LSD radix sort on gsplat's 64-bit key produces.
- * n_isects = stats[1], max_tile_len = stats[2] of mobgs_isect_offsets (the latter selects the LDS sort variant).
+ * n_isects = stats[1], max_tile_len = stats[2] of mobgs_isect_offsets (lists longer than 4096 get a second launch
+ * of the 1024-thread / 128-KiB-LDS sort variant over a compacted list of those tiles).
  * out: flatten_ids [n_isects] (cam*N+gaussian), isect_ids [n_isects] (gsplat's u64 key; may be NULL)
  * offsets_scratch: the SAME scratch buffer (and capacity) that was passed to mobgs_isect_offsets -- it holds the
- *   (flag, owner, tile, rank) of every bounding-box intersection; sort_keys [n_isects] u64 is scratch. */
+ *   (flag, owner, tile, rank) of every bounding-box intersection (its dead per-tile counters are reused as
+ *   scratch, so one call per mobgs_isect_offsets call); sort_keys [n_isects] u64 is scratch. */
 int mobgs_isect_emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t n_isects,
                           int64_t max_tile_len, const float* depths, const int32_t* cum_tiles,
                           const int32_t* tile_offsets, const void* offsets_scratch, uint64_t* sort_keys,

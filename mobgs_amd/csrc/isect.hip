@@ -160,6 +160,9 @@ __device__ inline int owner_in(const Cum& cum, int lo, int hi, int j) {
     return lo;
 }
 
+// stride of the per-tile list counters (1 = packed; giving each counter its own 128-byte line was measured: no gain
+// for the atomics of a dense image region, +12 us in tile_scan)
+constexpr int TC_STRIDE = 1;
 constexpr int OWNER_LDS = 4096;  // cum_tiles entries of the chunk's owner range cached in LDS
 static_assert(SCAN_BLOCK == KEEP_CHUNK, "one workgroup per keep_scan chunk");
 
@@ -237,7 +240,7 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
     // ranks inside the tiles' lists: all returning atomics in flight before the first result is consumed
     int rank[SCAN_ITEMS];
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = keep[k] ? atomicAdd(&tile_count[til[k]], 1) : 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = keep[k] ? atomicAdd(&tile_count[til[k] * TC_STRIDE], 1) : 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const int j = start + k * SCAN_THREADS + threadIdx.x;
@@ -311,7 +314,7 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
     int carry = 0, mx = 0;
     for (int start = 0; start < nt; start += TSCAN_THREADS) {
         const int i = start + threadIdx.x;
-        const int v = (i < nt) ? tile_count[i] : 0;
+        const int v = (i < nt) ? tile_count[i * TC_STRIDE] : 0;
         mx = max(mx, v);
         int total;
         const int inc = block_incl_scan_w<TSCAN_THREADS / 64>(v, &total);
@@ -344,7 +347,7 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
     static_assert(ORDER_BUCKETS == TSCAN_THREADS, "one histogram bin per thread");
     hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < nt; i += TSCAN_THREADS) atomicAdd(&hist[bucket(tile_count[i])], 1);
+    for (int i = threadIdx.x; i < nt; i += TSCAN_THREADS) atomicAdd(&hist[bucket(tile_count[i * TC_STRIDE])], 1);
     __syncthreads();
     {
         const int mine = hist[threadIdx.x];
@@ -371,7 +374,7 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
     __syncthreads();
     const int n_heavy = s_heavy;
     for (int i = threadIdx.x; i < nt; i += TSCAN_THREADS) {
-        const int pos = atomicAdd(&hist[bucket(tile_count[i])], 1);
+        const int pos = atomicAdd(&hist[bucket(tile_count[i * TC_STRIDE])], 1);
         if (pos < n_heavy) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) tile_order[4 * pos + q] = i | SCHED_HEAVY;
@@ -509,38 +512,63 @@ __device__ inline void bitonic_sort_global(uint64_t* a, int n, int nthreads) {
     }
 }
 
+// tiles whose list is longer than `min_len`, in no particular order: long_ids[0 .. *long_count)
+__global__ void __launch_bounds__(256) long_lists_kernel(int nt, const int32_t* __restrict__ tile_offsets, int min_len,
+                                                           int32_t* __restrict__ long_ids,
+                                                           int32_t* __restrict__ long_count) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nt && tile_offsets[t + 1] - tile_offsets[t] > min_len) long_ids[atomicAdd(long_count, 1)] = t;
+}
+
+// Lists with n_min <= length <= n_max are sorted by this launch (the others belong to the launch of the other
+// variant).  long_ids != NULL: instead of one workgroup per tile, a small grid walks that list of tiles -- the
+// long-list variant needs 128 KiB of LDS per workgroup, and dispatching one such workgroup per tile just to find
+// that the tile is short costs more than the sort.
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) tile_sort_kernel(int n_tiles_total, int lds_cap, int tile_bits,
                                                               const int32_t* __restrict__ tile_offsets,
                                                               uint64_t* __restrict__ sort_keys,
                                                               int32_t* __restrict__ flatten_ids,
-                                                              uint64_t* __restrict__ isect_ids, int tiles_per_cam) {
+                                                              uint64_t* __restrict__ isect_ids, int tiles_per_cam,
+                                                              int n_min, int n_max,
+                                                              const int32_t* __restrict__ long_ids,
+                                                              const int32_t* __restrict__ long_count) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds_keys[];
-    const int t = blockIdx.x;
-    if (t >= n_tiles_total) return;
-    const int s = tile_offsets[t], e = tile_offsets[t + 1];
-    const int n = e - s;
-    if (n <= 0) return;
-    uint64_t* seg = sort_keys + s;
-    const int cam = t / tiles_per_cam, tl = t - cam * tiles_per_cam;
-    const uint64_t hi_bits = (((uint64_t)cam << tile_bits) | (uint64_t)tl) << 32;
-    if (n <= lds_cap) {
-        for (int i = threadIdx.x; i < n; i += THREADS) lds_keys[i] = seg[i];
-        __syncthreads();
-        if (n > 1) bitonic_sort_lds<THREADS>(lds_keys, n);
-        for (int i = threadIdx.x; i < n; i += THREADS) {
-            const uint64_t k = lds_keys[i];
-            flatten_ids[s + i] = (int32_t)(uint32_t)k;
-            if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+    for (int h = blockIdx.x;; h += gridDim.x) {
+        int t = h;
+        if (long_ids) {
+            if (h >= *long_count) return;
+            t = long_ids[h];
+        } else if (t >= n_tiles_total) {
+            return;
         }
-    } else {
-        // pathological tile: sort in place in global memory (same workgroup, barrier-ordered)
-        bitonic_sort_global(seg, n, THREADS);
-        for (int i = threadIdx.x; i < n; i += THREADS) {
-            const uint64_t k = seg[i];
-            flatten_ids[s + i] = (int32_t)(uint32_t)k;
-            if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+        const int s = tile_offsets[t], e = tile_offsets[t + 1];
+        const int n = e - s;
+        if (n > 0 && n >= n_min && n <= n_max) {
+            uint64_t* seg = sort_keys + s;
+            const int cam = t / tiles_per_cam, tl = t - cam * tiles_per_cam;
+            const uint64_t hi_bits = (((uint64_t)cam << tile_bits) | (uint64_t)tl) << 32;
+            if (n <= lds_cap) {
+                for (int i = threadIdx.x; i < n; i += THREADS) lds_keys[i] = seg[i];
+                __syncthreads();
+                if (n > 1) bitonic_sort_lds<THREADS>(lds_keys, n);
+                for (int i = threadIdx.x; i < n; i += THREADS) {
+                    const uint64_t k = lds_keys[i];
+                    flatten_ids[s + i] = (int32_t)(uint32_t)k;
+                    if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+                }
+            } else {
+                // pathological tile: sort in place in global memory (same workgroup, barrier-ordered)
+                bitonic_sort_global(seg, n, THREADS);
+                for (int i = threadIdx.x; i < n; i += THREADS) {
+                    const uint64_t k = seg[i];
+                    flatten_ids[s + i] = (int32_t)(uint32_t)k;
+                    if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+                }
+            }
         }
+        if (!long_ids) return;
+        __syncthreads();  // lds_keys is reused by the next long list
     }
 }
 
@@ -554,7 +582,7 @@ static int g_heavy_len = 1024;
 extern "C" {
 
 // Layout of the scratch buffer shared by mobgs_isect_offsets and mobgs_isect_emit_sort (int32 units):
-//   [tile_count nt | ticket (+3 pad) | status 2*(nb1+1)]  <- zeroed by one memset
+//   [tile_count nt * TC_STRIDE | ticket (+3 pad) | status 2*(nb1+1)]  <- zeroed by one memset
 //   [flags cap | owner cap | tile cap | rank cap]
 struct IsectScratch {
     int32_t *tile_count, *tickets, *flags, *owner, *tile_of_j, *rank_of_j;
@@ -563,7 +591,7 @@ struct IsectScratch {
     int nb1;
     IsectScratch(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity) {
         nb1 = (int)((n_gauss + SCAN_BLOCK - 1) / SCAN_BLOCK);
-        const size_t nt_pad = (n_tiles + 1) & ~(size_t)1;  // keeps the 64-bit status words 8-byte aligned
+        const size_t nt_pad = (n_tiles * TC_STRIDE + 1) & ~(size_t)1;  // keeps the 64-bit status words 8-byte aligned
         int32_t* p = (int32_t*)scratch;
         tile_count = p;
         tickets = p + nt_pad;
@@ -651,14 +679,24 @@ static int emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t
     // gsplat: tile_n_bits = floor(log2(n_tiles)) + 1
     int tile_bits = 0;
     while ((1ll << tile_bits) <= (long long)tiles_per_cam) ++tile_bits;
-    if (max_tile_len <= 4096) {
-        const int cap = 4096;
-        hipLaunchKernelGGL(tile_sort_kernel<256>, dim3(nt), dim3(256), cap * sizeof(uint64_t), st, nt, cap, tile_bits,
-                           tile_offsets, sort_keys, flatten_ids, isect_ids, tiles_per_cam);
-    } else {
-        const int cap = 16384;  // 128 KiB of the 160 KiB LDS; longer lists fall back to global memory
-        hipLaunchKernelGGL(tile_sort_kernel<1024>, dim3(nt), dim3(1024), cap * sizeof(uint64_t), st, nt, cap,
-                           tile_bits, tile_offsets, sort_keys, flatten_ids, isect_ids, tiles_per_cam);
+    // lists <= 4096: 256 threads, 32 KiB LDS, one workgroup per tile.  Longer ones (if any are expected): 1024
+    // threads, 128 KiB of the 160 KiB LDS (<= 16384 keys; beyond that in place in global memory), in a separate
+    // launch over a compacted list of those tiles, so that the short lists keep their occupancy.  The per-tile
+    // counters of pass A (dead since tile_scan) hold that list, a zeroed ticket word its length.
+    const int small_cap = 4096, big_cap = 16384;
+    const bool split = max_tile_len > small_cap;
+    const int nmax_small = split ? small_cap : 0x7fffffff;
+    hipLaunchKernelGGL(tile_sort_kernel<256>, dim3(nt), dim3(256), small_cap * sizeof(uint64_t), st, nt, small_cap,
+                       tile_bits, tile_offsets, sort_keys, flatten_ids, isect_ids, tiles_per_cam, 0, nmax_small,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr);
+    if (split) {
+        int32_t* long_ids = L.tile_count;
+        int32_t* long_count = L.tickets + 1;
+        hipLaunchKernelGGL(long_lists_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, nt, tile_offsets, small_cap,
+                           long_ids, long_count);
+        hipLaunchKernelGGL(tile_sort_kernel<1024>, dim3(nt < 256 ? nt : 256), dim3(1024), big_cap * sizeof(uint64_t), st,
+                           nt, big_cap, tile_bits, tile_offsets, sort_keys, flatten_ids, isect_ids, tiles_per_cam,
+                           small_cap + 1, 0x7fffffff, long_ids, long_count);
     }
     return check_launch("isect_emit_sort");
 }
