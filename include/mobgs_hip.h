@@ -268,6 +268,16 @@ int mobgs_rows_gather(int n_fields, const void* const* src_host, void* const* ds
 int mobgs_split_children(int n_children, int first_row, int n_split, const float* samples, const float* rotation,
                          float* xyz, float* scaling, void* stream);
 
+/* ---- K14: normals from a depth map (replaces /root/reference/main_utils.py:95-141 get_normals, train.py:590) ----
+ * z [H,W] -> normals [3,H,W]: every pixel is back-projected with its view direction
+ *   y = (i + pixel_offset - cy) / fy,  x = (j + pixel_offset - cx - y * skew) / fx,  point = (x, y, 1) * z,
+ * n = normalize(cross(right - left, top - bottom), eps 1e-12) on the interior, zeros on the 1-pixel border.
+ * pixel_offset = 0.5 for dycheck cameras with use_center (the default).  Backward: v_z [H,W] fully written. */
+int mobgs_normals_fwd(int H, int W, float fx, float fy, float cx, float cy, float skew, float pixel_offset,
+                      const float* z, float* normals, void* stream);
+int mobgs_normals_bwd(int H, int W, float fx, float fy, float cx, float cy, float skew, float pixel_offset,
+                      const float* z, const float* v_normals, float* v_z, void* stream);
+
 /* 1 if raster kernels are compiled for `total_channels` (colour channels + optional extra channel). */
 int mobgs_raster_channels_supported(int total_channels);
 

@@ -145,6 +145,35 @@ def densify_legs(dev, steps, n=300_000):
     return out
 
 
+def normals_legs(dev, steps, W, H):
+    """get_normals (main_utils.py:95-141, train.py:590): the reference's op sequence (numpy direction map + H2D
+    copy + torch ops, per call) beside the fused kernel, forward only (train.py never back-propagates through it)."""
+    import types
+
+    import numpy as np
+
+    from mobgs_amd.main_utils import get_normals
+    meta = types.SimpleNamespace(scale_factor_x=1170.0, scale_factor_y=1170.0, principal_point_x=W / 2,
+                                 principal_point_y=H / 2, skew=0.0, use_center=True)
+    z = (2.0 + torch.rand(1, H, W)).to(dev)
+
+    def reference_ops():
+        xx, yy = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+        pixels = np.stack([xx, yy], axis=-1) + 0.5
+        y = (pixels[..., 1] - meta.principal_point_y) / meta.scale_factor_y
+        x = (pixels[..., 0] - meta.principal_point_x - y * meta.skew) / meta.scale_factor_x
+        viewdirs = torch.from_numpy(np.stack([x, y, np.ones_like(x)], axis=-1)).to(dev)
+        coords = (viewdirs[None] * z[..., None]).squeeze(0)
+        hd, wd, _ = coords.shape
+        n = torch.cross(coords[1:hd - 1, 2:wd] - coords[1:hd - 1, 0:wd - 2],
+                        coords[0:hd - 2, 1:wd - 1] - coords[2:hd, 1:wd - 1], dim=-1)
+        n = torch.nn.functional.normalize(n, p=2, dim=-1)
+        return torch.nn.functional.pad(n.permute(2, 0, 1), (1, 1, 1, 1), mode="constant")[None]
+
+    return {"get_normals_reference_ops_ms": timed(reference_ops, max(3, steps // 4)),
+            "get_normals_fused_ms": timed(lambda: get_normals(z, meta), steps)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
@@ -254,6 +283,7 @@ def main():
     res["train_mode_renders_per_s"] = 1e3 / res["train_mode_layered_ms"]
     res["blurry_views_per_s"] = 1e3 / res["blurry_view_layered_ms"]
     res.update(densify_legs(dev, a.steps))
+    res.update(normals_legs(dev, a.steps, W, H))
     res["config"] = "seesaw-synth 200k+100k, 1352x1014, K=9 (1 GPU)"
     print(json.dumps(res))
 

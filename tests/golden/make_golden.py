@@ -460,6 +460,40 @@ def gen_densify(name, n=600, seed=21):
     save(name, **rec)
 
 
+def gen_normals(name):
+    """main_utils.get_normals (main_utils.py:95-141) on a small depth map, with its gradient w.r.t. the depth."""
+    import types as _t
+    for mod in ("matplotlib", "PIL"):
+        if mod not in sys.modules:
+            sys.modules[mod] = _t.ModuleType(mod)
+    sys.modules["matplotlib"].cm = getattr(sys.modules["matplotlib"], "cm", None)
+    sys.modules["PIL"].Image = getattr(sys.modules["PIL"], "Image", None)
+    mu = RH.ref_import("main_utils")
+    H, W = 37, 53
+
+    class Meta:  # what get_normals reads from a dycheck camera (dycheck_geometry/camera.py:600-613 for get_pixels)
+        principal_point_x, principal_point_y = 25.3, 19.1
+        scale_factor_x, scale_factor_y = 61.0, 58.5
+        skew = 0.02
+        use_center = True
+        image_size_x, image_size_y = W, H
+
+        def get_pixels(self, use_center=None, normalize=False):
+            xx, yy = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+            return np.stack([xx, yy], axis=-1) + 0.5
+
+    g = torch.Generator().manual_seed(17)
+    z = (2.0 + torch.rand(1, H, W, generator=g) + 0.3 * torch.randn(1, H, W, generator=g).abs()).requires_grad_(True)
+    z.data[0, 5:9, 7:12] = 3.0  # a flat patch: cross product from exactly equal depths
+    with RH.CudaToCpu():
+        n = mu.get_normals(z + 1e-6, Meta())
+    w = torch.randn(n.shape, generator=g)
+    (n * w).sum().backward()
+    save(name, z=np_(z), normals=np_(n), cotangent=np_(w), grad_z=np_(z.grad),
+         intrinsics=np.array([Meta.scale_factor_x, Meta.scale_factor_y, Meta.principal_point_x,
+                              Meta.principal_point_y, Meta.skew], dtype=np.float32))
+
+
 def main():
     RH.install()
     gen_hermite("hermite")
@@ -472,6 +506,7 @@ def main():
     gen_blce("blce")
     gen_losses("losses")
     gen_densify("densify")
+    gen_normals("normals")
 
 
 if __name__ == "__main__":

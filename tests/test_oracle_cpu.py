@@ -315,3 +315,15 @@ def test_densify_oracle_matches_reference_fixture():
     _assert_state(st, fx, "s4")
     D.reset_opacity(st)
     _assert_state(st, fx, "s5")
+
+
+def test_normals_oracle_matches_reference_fixture():
+    from oracle import normals_torch as NT
+    fx = load("normals")
+    z = torch.from_numpy(fx["z"]).requires_grad_(True)
+    k = [float(v) for v in fx["intrinsics"]]
+    n = NT.get_normals(z + 1e-6, *k)
+    assert torch.allclose(n, torch.from_numpy(fx["normals"]), rtol=0, atol=2e-6)
+    (n * torch.from_numpy(fx["cotangent"])).sum().backward()
+    ref = torch.from_numpy(fx["grad_z"])
+    assert torch.allclose(z.grad, ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
