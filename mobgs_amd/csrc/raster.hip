@@ -579,6 +579,7 @@ inline int dispatch_channels(int D, F&& f) {
         case 4: f(std::integral_constant<int, 4>{}); return MOBGS_OK;
         case 9: f(std::integral_constant<int, 9>{}); return MOBGS_OK;
         case 10: f(std::integral_constant<int, 10>{}); return MOBGS_OK;
+        case 12: f(std::integral_constant<int, 12>{}); return MOBGS_OK;
         case 16: f(std::integral_constant<int, 16>{}); return MOBGS_OK;
         case 26: f(std::integral_constant<int, 26>{}); return MOBGS_OK;
         default: return MOBGS_E_UNSUPPORTED;
@@ -592,7 +593,7 @@ using namespace mobgs;
 extern "C" {
 
 int mobgs_raster_channels_supported(int D) {
-    return D == 1 || D == 2 || D == 3 || D == 4 || D == 9 || D == 10 || D == 16 || D == 26;
+    return D == 1 || D == 2 || D == 3 || D == 4 || D == 9 || D == 10 || D == 12 || D == 16 || D == 26;
 }
 
 int mobgs_pack_records(int C, int N, int channels, const float* means2d, const float* conics, const float* colors,

@@ -140,6 +140,14 @@ def _bg9(bg_color):
     return _bg9_cache.get((bg_color,), lambda: torch.cat([bg_color[:3]] * 3, dim=-1)[None])
 
 
+_bg11_cache = DerivedCache()
+
+
+def _bg11(bg1):
+    """[1,9] feature background + zeros for the two flow channels splatted in the same pass."""
+    return _bg11_cache.get((bg1,), lambda: torch.cat([bg1, bg1.new_zeros(1, 2)], dim=-1))
+
+
 def _decoder_weights(dyn_pc):
     dec = dyn_pc.rgbdecoder
     return dec.mlp1.weight, dec.mlp2.weight
@@ -332,12 +340,14 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
                                     viewmats=viewmat[None], Ks=K[None], width=W, height=H, packed=False,
                                     render_mode="RGB")[0][..., 0]
     e2m = (sp_mid.means2d - sp_exp.means2d).squeeze(0)
-    e2m_img = splat(sp_exp, e2m)
+    # the exposure-time lists are walked ONCE for the 9 colour features and the 2 flow channels (the reference: one
+    # rasterization each, :436-452 and :461-476; channels accumulate independently, so the images are identical)
+    img12, alphas = sp_exp.composite(torch.cat([exp_c, e2m], dim=-1), _bg11(bg1))  # [1,H,W, 9 + 2 + depth]
+    e2m_img = img12[..., 9:11]
     pix = _pixel_grid(cam, W, H, e2m_img)
     exp2mid = pix + e2m_img
     mid2exp = pix + splat(sp_mid, -e2m)
-    img, alphas = sp_exp.composite(exp_c, bg1)
-    latent_img, _ = decode(img, alphas, _rays_of(cam), w1, w2, True)
+    latent_img, _ = decode(img12, alphas, _rays_of(cam), w1, w2, False)  # reads the 9 feature channels only
     return exp2mid, mid2exp, latent_img, latent_alpha
 
 

@@ -268,7 +268,7 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Ten
 # --------------------------------------------------------------------------------------------------
 # compositing
 # --------------------------------------------------------------------------------------------------
-_SUPPORTED = (1, 2, 3, 4, 9, 10, 16, 26)
+_SUPPORTED = (1, 2, 3, 4, 9, 10, 12, 16, 26)
 
 
 def _pad_channels(D: int) -> int:
