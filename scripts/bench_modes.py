@@ -245,13 +245,27 @@ def main():
     # photometric loss of one 1352x1014 view (train.py:621-628), fwd + bwd: torch ops as the reference calls them
     # vs the fused kernels
     from mobgs_amd.loss_utils import photometric_loss
-    from oracle import loss_torch as LT  # timing leg only: the reference's call pattern, on the GPU
+    import torch.nn.functional as F
+
+    def ref_ops_loss(x, y):
+        """the op sequence of utils/loss_utils.py:233-239, 351-381 (L1 + 11x11 Gaussian-window SSIM as six depthwise
+        convolutions), run with torch on the GPU: timing baseline only"""
+        k = torch.exp(-(torch.arange(11, dtype=torch.float32, device=x.device) - 5) ** 2 / (2 * 1.5 ** 2))
+        k = k / k.sum()
+        win = (k[:, None] * k[None, :])[None, None].expand(3, 1, 11, 11).contiguous()
+        conv = lambda t: F.conv2d(t, win, padding=5, groups=3)  # noqa: E731
+        mx, my = conv(x), conv(y)
+        sx, sy, sxy = conv(x * x) - mx * mx, conv(y * y) - my * my, conv(x * y) - mx * my
+        c1, c2 = 0.01 ** 2, 0.03 ** 2
+        ssim_map = ((2 * mx * my + c1) * (2 * sxy + c2)) / ((mx * mx + my * my + c1) * (sx + sy + c2))
+        return (x - y).abs().mean() + 0.2 * (1.0 - ssim_map.mean())
+
     gt_img = torch.rand(1, 3, H, W, generator=g).to(dev)
     pred_img = torch.rand(1, 3, H, W, generator=g).to(dev).requires_grad_(True)
 
     def loss_torch_ops():
         pred_img.grad = None
-        (LT.l1_loss(pred_img, gt_img) + 0.2 * (1.0 - LT.ssim(pred_img, gt_img))).backward()
+        ref_ops_loss(pred_img, gt_img).backward()
 
     def loss_fused():
         pred_img.grad = None
