@@ -278,6 +278,24 @@ int mobgs_normals_fwd(int H, int W, float fx, float fy, float cx, float cy, floa
 int mobgs_normals_bwd(int H, int W, float fx, float fy, float cx, float cy, float skew, float pixel_offset,
                       const float* z, const float* v_normals, float* v_z, void* stream);
 
+/* ---- K6''/K7'': class-restricted passes of the single-set compositor -----------------------------------------
+ * The static-only (class_sel = 1: flat id % N < Ns) or dynamic-only (class_sel = 2) "RGB+D" render over the lists
+ * of the WHOLE set: entries of the other class are dropped as each 64-entry batch is staged.  Every splat belongs
+ * to exactly one class, so the two passes together blend each (tile, splat) pair once and their backward passes
+ * write disjoint records of ONE grad_slots buffer (zero-filled [I_listed, stride]), reduced by one
+ * mobgs_raster_bwd_reduce.  10 total channels (9 features + depth); records from mobgs_pack_records; last_ids index
+ * the whole set's lists. */
+int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_total, int width, int height,
+                           const float* records, const float* backgrounds, const int32_t* tile_offsets,
+                           const int32_t* tile_order, const int32_t* flatten_ids, float* render, float* alphas,
+                           int32_t* last_ids, void* stream);
+int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_total, int width, int height,
+                           const float* records, const float* backgrounds, const int32_t* radii,
+                           const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
+                           const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
+                           const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
+                           void* stream);
+
 /* 1 if raster kernels are compiled for `total_channels` (colour channels + optional extra channel). */
 int mobgs_raster_channels_supported(int total_channels);
 

@@ -49,6 +49,15 @@ __device__ inline void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Optional restriction of a compositing pass to one class of splats: sel = 1 keeps flat ids with (id % N) < Ns
+// ("static"), sel = 2 the others ("dynamic"), 0 = no restriction.  The pass walks the SAME per-tile lists and list
+// indices as the unrestricted one; entries of the other class are dropped when a batch is staged, so they cost a
+// class test per batch, not a trip through the blend loop.
+struct ClassSel {
+    int sel, N, Ns;
+    __device__ __forceinline__ bool keeps(int flat_id) const { return sel == 0 || (((flat_id % N) < Ns) == (sel == 1)); }
+};
+
 // sigma / visibility / alpha of one splat at one pixel; the same instruction sequence in fwd and bwd
 struct Eval {
     float dx, dy, vis, alpha;
@@ -105,9 +114,10 @@ pack_records_kernel(int N, int channels, int stride, const float* __restrict__ m
 // One wave composites NP pixels per lane of `tile` front to back: NP = 4 -> the whole 16x16 tile (pixel k of a lane
 // lies in quadrant k), NP = 1 -> only the 8x8 quadrant `quad` (heavy tiles: 4 waves share the list walk, which cuts
 // the critical path of a long list ~2.6x; every pixel sees exactly the same arithmetic either way).
-template <int CD, int NP>
+template <int CD, int NP, bool FILTER>
 __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int lane,
-                                              float4 (*slab)[64][((6 + CD + 3) & ~3) / 4], int tile_w, int tile_h,
+                                              float4 (*slab)[64][((6 + CD + 3) & ~3) / 4], int (*idx_of)[64],
+                                              ClassSel cls, int tile_w, int tile_h,
                                               int width, int height, const float* __restrict__ records,
                                               const float* __restrict__ backgrounds,
                                               const int32_t* __restrict__ tile_offsets,
@@ -153,24 +163,46 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
     float4 pre[RQ];
 #pragma unroll
     for (int q = 0; q < RQ; ++q) pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool pre_keep = false;  // FILTER: the prefetched entry belongs to the wanted class
     if (s + lane < e) {
-        const float4* r = reinterpret_cast<const float4*>(records + (size_t)flatten_ids[s + lane] * RS);
-#pragma unroll
-        for (int q = 0; q < RQ; ++q) pre[q] = r[q];
-    }
-    bool all_done = false;
-    for (int b = s; b < e && !all_done; b += 64) {
-        const int n = min(64, e - b);
-        wave_lds_fence();
-#pragma unroll
-        for (int q = 0; q < RQ; ++q) slab[wv][lane][q] = pre[q];
-        wave_lds_fence();
-        if (b + 64 + lane < e) {
-            const float4* r = reinterpret_cast<const float4*>(records + (size_t)flatten_ids[b + 64 + lane] * RS);
+        const int g = flatten_ids[s + lane];
+        pre_keep = !FILTER || cls.keeps(g);
+        if (pre_keep) {
+            const float4* r = reinterpret_cast<const float4*>(records + (size_t)g * RS);
 #pragma unroll
             for (int q = 0; q < RQ; ++q) pre[q] = r[q];
         }
+    }
+    bool all_done = false;
+    for (int b = s; b < e && !all_done; b += 64) {
+        int n = min(64, e - b);
+        wave_lds_fence();
+        if (FILTER) {  // stage only the wanted class, compacted, remembering each entry's list index
+            const unsigned long long km = __builtin_amdgcn_ballot_w64(pre_keep);
+            n = __builtin_popcountll(km);
+            if (pre_keep) {
+                const int pos = __builtin_popcountll(km & ((1ull << lane) - 1ull));
+#pragma unroll
+                for (int q = 0; q < RQ; ++q) slab[wv][pos][q] = pre[q];
+                idx_of[wv][pos] = b + lane;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) slab[wv][lane][q] = pre[q];
+        }
+        wave_lds_fence();
+        pre_keep = false;
+        if (b + 64 + lane < e) {
+            const int g = flatten_ids[b + 64 + lane];
+            pre_keep = !FILTER || cls.keeps(g);
+            if (pre_keep) {
+                const float4* r = reinterpret_cast<const float4*>(records + (size_t)g * RS);
+#pragma unroll
+                for (int q = 0; q < RQ; ++q) pre[q] = r[q];
+            }
+        }
         for (int j = 0; j < n; ++j) {
+            const int list_idx = FILTER ? idx_of[wv][j] : b + j;
             const float4 r0 = slab[wv][j][0];
             const float4 r1 = slab[wv][j][1];
             // tests for the 4 pixels of this lane; one wave-level branch decides whether anything is blended
@@ -206,7 +238,7 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
 #pragma unroll
                     for (int c = 0; c < CD; ++c) acc[k][c] = __fmaf_rn(col[c], w, acc[k][c]);
                     T[k] = blend[k] ? nT[k] : T[k];
-                    last[k] = blend[k] ? (b + j) : last[k];
+                    last[k] = blend[k] ? list_idx : last[k];
                 }
             }
             if (__builtin_amdgcn_ballot_w64(done != ALL_DONE) == 0ull) {
@@ -231,24 +263,25 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
     }
 }
 
-template <int CD>
+template <int CD, bool FILTER>
 __global__ void __launch_bounds__(64 * TILES_PER_WG)
 raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
                   const float* __restrict__ records, const float* __restrict__ backgrounds,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
                   float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
-                  const int32_t* __restrict__ tile_order) {
+                  const int32_t* __restrict__ tile_order, ClassSel cls) {
     constexpr int RQ = ((6 + CD + 3) & ~3) / 4;
     __shared__ float4 slab[TILES_PER_WG][64][RQ];
+    __shared__ int idx_of[FILTER ? TILES_PER_WG : 1][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
     if (slot < 0) return;
     if (slot & SCHED_HEAVY)
-        composite_fwd<CD, 1>(slot & ~SCHED_HEAVY, wv, wv, lane, slab, tile_w, tile_h, width, height, records,
-                             backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids);
+        composite_fwd<CD, 1, FILTER>(slot & ~SCHED_HEAVY, wv, wv, lane, slab, idx_of, cls, tile_w, tile_h, width, height,
+                                     records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids);
     else
-        composite_fwd<CD, 4>(slot, 0, wv, lane, slab, tile_w, tile_h, width, height, records, backgrounds,
-                             tile_offsets, flatten_ids, render, alphas, last_ids);
+        composite_fwd<CD, 4, FILTER>(slot, 0, wv, lane, slab, idx_of, cls, tile_w, tile_h, width, height, records,
+                                     backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -298,6 +331,7 @@ struct BwdShared {
     static constexpr int RS = (6 + CD + 3) & ~3;
     float4 slab[TILES_PER_WG][64][RS / 4];  // the batch's splat records, one copy per wave
     int slot_of[TILES_PER_WG][64];          // gradient slot of each batch entry
+    int idx_of[TILES_PER_WG][64];           // class-filtered passes: list index of each staged entry
     float part[TILES_PER_WG][64][RS];       // heavy tiles: per-wave (= per-quadrant) gradient records of the batch
     unsigned long long touched[TILES_PER_WG];
     int top[TILES_PER_WG];
@@ -308,8 +342,9 @@ struct BwdShared {
 // taking one 8x8 quadrant; they walk the same batches in step, leave their partial records in LDS and the
 // workgroup sums the (up to 4) partials of every entry into its ONE slot -- still no floating-point atomics, and a
 // fixed summation order (quadrant 0..3), so gradients stay bit-reproducible.
-template <int CD, int NP>
-__device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int lane, BwdShared<CD>& sh, int tile_w,
+template <int CD, int NP, bool FILTER>
+__device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int lane, BwdShared<CD>& sh, ClassSel cls,
+                                              int tile_w,
                                               int tile_h, int width, int height, const float* __restrict__ records,
                                               const float* __restrict__ backgrounds,
                                               const int32_t* __restrict__ radii, const int32_t* __restrict__ cum_tiles,
@@ -386,22 +421,32 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
     top = min(top, e - 1);
 
     for (int hi = top; hi >= s; hi -= 64) {
-        const int n = min(64, hi - s + 1);
+        int n = min(64, hi - s + 1);
         unsigned long long touched = 0ull;  // heavy: batch entries this wave produced a record for
         wave_lds_fence();
-        if (lane < n) {
-            const int g = flatten_ids[hi - lane];
-            const float4* r = reinterpret_cast<const float4*>(records + (size_t)g * RS);
-            float4 r0 = r[0];
-            slab[wv][lane][0] = r0;
+        {
+            const int g = lane < n ? flatten_ids[hi - lane] : 0;
+            const bool keep = lane < n && (!FILTER || cls.keeps(g));
+            int pos = lane;
+            if (FILTER) {  // stage only the wanted class, compacted (still back to front)
+                const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+                n = __builtin_popcountll(km);
+                pos = __builtin_popcountll(km & ((1ull << lane) - 1ull));
+            }
+            if (keep) {
+                const float4* r = reinterpret_cast<const float4*>(records + (size_t)g * RS);
+                float4 r0 = r[0];
+                slab[wv][pos][0] = r0;
 #pragma unroll
-            for (int q = 1; q < RQ; ++q) slab[wv][lane][q] = r[q];
-            const TileRect tr = tile_rect(r0.x, r0.y, radii[g], tile_w, tile_h);
-            slot_of[wv][lane] = keep_index(keep_scan, cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0));
+                for (int q = 1; q < RQ; ++q) slab[wv][pos][q] = r[q];
+                const TileRect tr = tile_rect(r0.x, r0.y, radii[g], tile_w, tile_h);
+                slot_of[wv][pos] = keep_index(keep_scan, cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0));
+                if (FILTER) sh.idx_of[wv][pos] = hi - lane;
+            }
         }
         wave_lds_fence();
         for (int j = 0; j < n; ++j) {
-            const int idx = hi - j;
+            const int idx = FILTER ? sh.idx_of[wv][j] : hi - j;
             float rec[RS];
 #pragma unroll
             for (int q = 0; q < RQ; ++q) {
@@ -502,7 +547,7 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
     }
 }
 
-template <int CD>
+template <int CD, bool FILTER>
 __global__ void __launch_bounds__(64 * TILES_PER_WG)
 raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
                   const float* __restrict__ records, const float* __restrict__ backgrounds,
@@ -511,19 +556,19 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
                   const int32_t* __restrict__ flatten_ids, const float* __restrict__ render_alphas,
                   const int32_t* __restrict__ last_ids,
                   const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                  float* __restrict__ grad_slots, const int32_t* __restrict__ tile_order) {
+                  float* __restrict__ grad_slots, const int32_t* __restrict__ tile_order, ClassSel cls) {
     __shared__ BwdShared<CD> sh;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
     if (slot < 0) return;
     if (slot & SCHED_HEAVY)  // workgroup-uniform: all 4 slots of a heavy workgroup carry the flag
-        composite_bwd<CD, 1>(slot & ~SCHED_HEAVY, wv, wv, lane, sh, tile_w, tile_h, width, height, records,
-                             backgrounds, radii, cum_tiles, keep_scan, tile_offsets, flatten_ids, render_alphas,
-                             last_ids, v_render, v_alphas, grad_slots);
+        composite_bwd<CD, 1, FILTER>(slot & ~SCHED_HEAVY, wv, wv, lane, sh, cls, tile_w, tile_h, width, height, records,
+                                     backgrounds, radii, cum_tiles, keep_scan, tile_offsets, flatten_ids,
+                                     render_alphas, last_ids, v_render, v_alphas, grad_slots);
     else
-        composite_bwd<CD, 4>(slot, 0, wv, lane, sh, tile_w, tile_h, width, height, records, backgrounds, radii,
-                             cum_tiles, keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids, v_render,
-                             v_alphas, grad_slots);
+        composite_bwd<CD, 4, FILTER>(slot, 0, wv, lane, sh, cls, tile_w, tile_h, width, height, records, backgrounds,
+                                     radii, cum_tiles, keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids,
+                                     v_render, v_alphas, grad_slots);
 }
 
 
@@ -634,9 +679,9 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
     const int rc = dispatch_channels(D, [&](auto cd) {
         constexpr int CD = decltype(cd)::value;
-        hipLaunchKernelGGL(raster_fwd_kernel<CD>, dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups, tile_w,
-                           tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render, alphas,
-                           last_ids, tile_order);
+        hipLaunchKernelGGL((raster_fwd_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
+                           tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render,
+                           alphas, last_ids, tile_order, ClassSel{0, 1, 0});
     });
     if (rc != MOBGS_OK) {
         set_error("mobgs_raster_fwd: %d total channels not compiled in (pad to a supported count)", D);
@@ -665,15 +710,57 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
     const int rc = dispatch_channels(D, [&](auto cd) {
         constexpr int CD = decltype(cd)::value;
-        hipLaunchKernelGGL(raster_bwd_kernel<CD>, dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups, tile_w,
-                           tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan, tile_offsets,
-                           flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots, tile_order);
+        hipLaunchKernelGGL((raster_bwd_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
+                           tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan,
+                           tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots,
+                           tile_order, ClassSel{0, 1, 0});
     });
     if (rc != MOBGS_OK) {
         set_error("mobgs_raster_bwd: %d total channels not compiled in", D);
         return rc;
     }
     return check_launch("raster_bwd_kernel");
+}
+
+// class-restricted passes over the lists of the whole set (10 total channels: the render() configuration)
+int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_total, int width, int height,
+                           const float* records, const float* backgrounds, const int32_t* tile_offsets,
+                           const int32_t* tile_order, const int32_t* flatten_ids, float* render, float* alphas,
+                           int32_t* last_ids, void* stream) {
+    if (C <= 0 || N <= 0 || Ns < 0 || Ns > N || (class_sel != 1 && class_sel != 2) || channels_total != 10) {
+        set_error("mobgs_raster_class_fwd: unsupported arguments (C=%d N=%d Ns=%d class=%d D=%d)", C, N, Ns, class_sel,
+                  channels_total);
+        return MOBGS_E_UNSUPPORTED;
+    }
+    const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
+    const int nt = C * tile_w * tile_h;
+    const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
+    const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
+    hipLaunchKernelGGL((raster_fwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream, nt,
+                       n_groups, tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render,
+                       alphas, last_ids, tile_order, ClassSel{class_sel, N, Ns});
+    return check_launch("raster_fwd_kernel(class)");
+}
+
+int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_total, int width, int height,
+                           const float* records, const float* backgrounds, const int32_t* radii,
+                           const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
+                           const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
+                           const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
+                           void* stream) {
+    if (C <= 0 || N <= 0 || Ns < 0 || Ns > N || (class_sel != 1 && class_sel != 2) || channels_total != 10) {
+        set_error("mobgs_raster_class_bwd: unsupported arguments");
+        return MOBGS_E_UNSUPPORTED;
+    }
+    const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
+    const int nt = C * tile_w * tile_h;
+    const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
+    const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
+    hipLaunchKernelGGL((raster_bwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream, nt,
+                       n_groups, tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan,
+                       tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots, tile_order,
+                       ClassSel{class_sel, N, Ns});
+    return check_launch("raster_bwd_kernel(class)");
 }
 
 int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int32_t* cum_tiles,

@@ -446,6 +446,104 @@ class _RasterizeLayers(torch.autograd.Function):
                 None, None, None)
 
 
+# True: static-only / dynamic-only images (without the combined one) come from two class-restricted passes of the
+# single-set compositor over the combined lists (every splat belongs to exactly one class, so together they do the
+# work of ONE pass and share one gradient-slot buffer); False: from the generic 3-layer kernel
+CLASS_PASSES = True
+
+
+class _RasterizeClasses(torch.autograd.Function):
+    """Static-only and/or dynamic-only "RGB+D" renders over the lists of the whole set: mobgs_raster_class_fwd/bwd
+    (csrc/raster.hip with a class filter).  Returns (render_static, alpha_static, render_dynamic, alpha_dynamic);
+    classes not in `mask` (bit 1 = static, bit 2 = dynamic) are empty tensors."""
+
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, extra, backgrounds, radii, tl: TileLists, width, height, Ns,
+                mask):
+        lib = _lib_()
+        C, N = radii.shape
+        dev = means2d.device
+        means2d, conics, colors, opacities, extra = map(f32c, (means2d, conics, colors, opacities, extra))
+        channels = colors.shape[-1]
+        D = channels + 1
+        if D != 10:
+            raise NotImplementedError("class-restricted compositing is built for 9 feature channels + depth")
+        bg = f32c(backgrounds) if backgrounds is not None else None
+        records = torch.empty(C * N, lib.mobgs_record_stride(D), dtype=torch.float32, device=dev)
+        check(lib.mobgs_pack_records(C, N, channels, ptr(means2d), ptr(conics), ptr(colors),
+                                     1 if colors.dim() == 3 else 0, ptr(opacities), 1 if opacities.dim() == 2 else 0,
+                                     ptr(extra), ptr(radii), ptr(records), stream()), "mobgs_pack_records")
+        outs = {}
+        with profiler.region("raster_class_fwd"):
+            for cls in (1, 2):
+                if not (mask >> cls) & 1:
+                    continue
+                render = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
+                alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
+                last = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+                while True:
+                    check(lib.mobgs_raster_class_fwd(C, N, Ns, cls, D, width, height, ptr(records), ptr(bg),
+                                                     ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_arena),
+                                                     ptr(render), ptr(alphas), ptr(last), stream()),
+                          "mobgs_raster_class_fwd")
+                    if not tl.resolve():
+                        break
+                outs[cls] = (render, alphas, last)
+        saved = [records, bg, radii]
+        for cls in (1, 2):
+            if cls in outs:
+                saved += [outs[cls][1], outs[cls][2]]
+        ctx.save_for_backward(*saved)
+        ctx.tl = tl
+        ctx.meta = (C, N, channels, width, height, colors.dim() == 3, opacities.dim() == 2, Ns, mask)
+        empty = means2d.new_empty(0)
+        res = []
+        for cls in (1, 2):
+            res += [outs[cls][0], outs[cls][1]] if cls in outs else [empty, empty]
+        return tuple(res)
+
+    @staticmethod
+    def backward(ctx, *cots):
+        lib = _lib_()
+        C, N, channels, width, height, colors_per_camera, opac_per_camera, Ns, mask = ctx.meta
+        records, bg, radii, *rest = ctx.saved_tensors
+        tl = ctx.tl
+        dev = records.device
+        D = channels + 1
+        stride = records.shape[1]
+        slots = torch.zeros(max(tl.n_isects, 1), stride, dtype=torch.float32, device=dev)
+        it = iter(rest)
+        with profiler.region("raster_class_bwd"):
+            for i, cls in enumerate((1, 2)):
+                if not (mask >> cls) & 1:
+                    continue
+                alphas, last = next(it), next(it)
+                v_render, v_alpha = cots[2 * i], cots[2 * i + 1]
+                if v_render is None and v_alpha is None:
+                    continue
+                v_render = f32c(v_render) if v_render is not None else torch.zeros(C, height, width, D, device=dev)
+                v_alpha = f32c(v_alpha) if v_alpha is not None else None
+                # the two classes own disjoint slots of the one buffer
+                check(lib.mobgs_raster_class_bwd(C, N, Ns, cls, D, width, height, ptr(records), ptr(bg), ptr(radii),
+                                                 ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(tl.tile_offsets),
+                                                 ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas), ptr(last),
+                                                 ptr(v_render), ptr(v_alpha), ptr(slots), stream()),
+                      "mobgs_raster_class_bwd")
+        v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
+        v_colors = torch.empty(C, N, channels, dtype=torch.float32, device=dev)
+        v_extra = torch.empty(C, N, dtype=torch.float32, device=dev)
+        check(lib.mobgs_raster_bwd_reduce(C, N, channels, 1, ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(slots),
+                                          ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra),
+                                          stream()), "mobgs_raster_bwd_reduce")
+        if not colors_per_camera:
+            v_colors = v_colors.sum(0) if C > 1 else v_colors[0]
+        if not opac_per_camera:
+            v_opac = v_opac.sum(0) if C > 1 else v_opac[0]
+        return v_means2d, v_conics, v_colors, v_opac, v_extra, None, None, None, None, None, None, None
+
+
 _cap_listed = {}  # device index -> capacity of the listed-intersection buffers
 
 
@@ -573,6 +671,12 @@ class SharedProjection:
         mask = (1 if want_all else 0) | (2 if want_static else 0) | (4 if want_dynamic else 0)
         if mask == 0:
             return [None] * 3, [None] * 3
+        if CLASS_PASSES and not want_all and colors.shape[-1] == 9:
+            rs, a_s, rd, a_d = _RasterizeClasses.apply(self.means2d, self.conics, colors, self.opacities, self.depths,
+                                                       self._bg(backgrounds), self.radii, self.tl, self.width,
+                                                       self.height, int(Ns), mask)
+            return ([None, rs if want_static else None, rd if want_dynamic else None],
+                    [None, a_s if want_static else None, a_d if want_dynamic else None])
         m2d_view = self.means2d.view_as(self.means2d)
         outs = _RasterizeLayers.apply(self.means2d, m2d_view, self.conics, colors, self.opacities, self.depths,
                                       self._bg(backgrounds), self.radii, self.tl, self.width, self.height, int(Ns),

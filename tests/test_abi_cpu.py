@@ -69,7 +69,7 @@ def test_unsupported_gsplat_options_raise():
         rasterization(packed=False, render_mode="XYZ", **a)
     with pytest.raises(NotImplementedError):
         fully_fused_projection(a["means"], torch.rand(n, 3, 3), None, None, a["viewmats"], a["Ks"], 32, 32)
-    assert [_pad_channels(d) for d in (1, 2, 3, 4, 5, 9, 10, 11, 17, 26)] == [1, 2, 3, 4, 9, 9, 10, 16, 26, 26]
+    assert [_pad_channels(d) for d in (1, 2, 3, 4, 5, 9, 10, 11, 13, 17, 26)] == [1, 2, 3, 4, 9, 9, 10, 12, 16, 26, 26]
     with pytest.raises(NotImplementedError):
         _pad_channels(27)
 

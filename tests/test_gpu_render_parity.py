@@ -108,14 +108,18 @@ def test_sandwich_module_matches_reference_fixture(hip_device):
     close(dec.mlp2.weight.grad, fx["grad_w2"], 1e-4, 1e-5, "grad w2")
 
 
-def test_layered_render_equals_separate_passes(hip_device):
-    """Train-mode render(): the one-pass layered compositor reproduces the five separate rasterizations --
-    images bit for bit (same per-pixel operation sequence), gradients up to summation order."""
+@pytest.mark.parametrize("class_passes", [True, False])
+def test_layered_render_equals_separate_passes(hip_device, class_passes):
+    """Train-mode render(): the static-only / dynamic-only images from the shared lists -- two class-restricted
+    passes of the single-set compositor (default) or the generic 3-layer kernel -- reproduce the five separate
+    rasterizations: images bit for bit (same per-pixel operation sequence), gradients up to summation order."""
     import mobgs_amd.gaussian_renderer as GR
+    from mobgs_amd import rendering
     fx = load("render_train")
     res = {}
     for fuse in (False, True):
         GR.FUSE_LAYERS = fuse
+        rendering.CLASS_PASSES = class_passes
         try:
             cam, stat, dyn, bg, _ = scene_from_fixture(fx, device=hip_device)
             out = GR.render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True)
@@ -125,6 +129,7 @@ def test_layered_render_equals_separate_passes(hip_device):
                          out["viewspace_points"].grad.cpu())
         finally:
             GR.FUSE_LAYERS = True
+            rendering.CLASS_PASSES = True
     for k in ("render", "depth", "s_render", "d_render", "d_depth", "radii"):
         assert torch.equal(res[True][0][k], res[False][0][k]), f"{k} differs"
     for k in ("s_alpha", "d_alpha"):  # (1 - T) + T bg  vs  sum_i w_i + T bg: telescoping sum, fp32 rounding
@@ -146,12 +151,12 @@ def test_auxiliary_outputs_are_lazy(hip_device):
     try:
         out = GR.render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True)
         (out["render"].sum() + out["depth"].sum()).backward()
-        assert "raster_layers_fwd" not in profiler.summary()
+        assert "raster_class_fwd" not in profiler.summary() and "raster_layers_fwd" not in profiler.summary()
         assert dict.__getitem__(out, "s_render") is GR._PENDING and "s_render" in out and len(out) == 22
-        s_render = out["s_render"]  # first access: one layered pass produces all five auxiliary images
-        assert profiler.summary()["raster_layers_fwd"]["calls"] == 1
+        s_render = out["s_render"]  # first access: one call (two class-restricted passes) produces all five images
+        assert profiler.summary()["raster_class_fwd"]["calls"] == 1
         assert torch.is_tensor(out["d_alpha"]) and torch.is_tensor(out["d_render"]) and torch.is_tensor(out["s_alpha"])
-        assert profiler.summary()["raster_layers_fwd"]["calls"] == 1
+        assert profiler.summary()["raster_class_fwd"]["calls"] == 1
         close(s_render, fx["out_s_render"], 0, 3e-5, "s_render", flip_frac=2e-3, flip_atol=0.01)
     finally:
         profiler.enable(False)
