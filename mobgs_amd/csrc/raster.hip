@@ -264,7 +264,7 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
 }
 
 template <int CD, bool FILTER>
-__global__ void __launch_bounds__(64 * TILES_PER_WG)
+__global__ void __launch_bounds__(64 * TILES_PER_WG) __attribute__((amdgpu_waves_per_eu(CD <= 10 ? 5 : 1)))
 raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
                   const float* __restrict__ records, const float* __restrict__ backgrounds,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
@@ -548,7 +548,7 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
 }
 
 template <int CD, bool FILTER>
-__global__ void __launch_bounds__(64 * TILES_PER_WG)
+__global__ void __launch_bounds__(64 * TILES_PER_WG) __attribute__((amdgpu_waves_per_eu(CD <= 10 ? 4 : 1)))
 raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
                   const float* __restrict__ records, const float* __restrict__ backgrounds,
                   const int32_t* __restrict__ radii, const int32_t* __restrict__ cum_tiles,
