@@ -19,6 +19,9 @@ ARCH = "gfx950"
 # +6% renders/s on the compositing kernels without it (measured).
 NOSLP_FILES = os.environ.get("MOBGS_NOSLP_FILES", "raster.hip,raster_layers.hip").split(",")
 EXTRA_FLAGS = {f: ["-fno-slp-vectorize"] for f in NOSLP_FILES if f}
+for _f in ("raster.hip", "raster_layers.hip"):  # experiment hook: extra flags for the compositing kernels
+    EXTRA_FLAGS.setdefault(_f, [])
+    EXTRA_FLAGS[_f] = EXTRA_FLAGS[_f] + os.environ.get("MOBGS_RASTER_EXTRA_FLAGS", "").split()
 
 
 def _hipcc() -> str:
