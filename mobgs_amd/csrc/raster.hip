@@ -406,6 +406,13 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
 #pragma unroll
                 for (int c = 0; c < CD; ++c) bgdot[k] = __fmaf_rn(backgrounds[cam * CD + c], vo[k][c], bgdot[k]);
             }
+            // a pixel whose cotangents are all exactly zero (masked-out loss, loss term with weight 0) contributes
+            // nothing to any gradient: treat it like a pixel that blended nothing, so that it neither extends the
+            // walk (top) nor passes a test -- tiles without any cotangent cost only this prologue
+            bool nz = va[k] != 0.f;
+#pragma unroll
+            for (int c = 0; c < CD; ++c) nz = nz || (vo[k][c] != 0.f);
+            if (!nz) binf[k] = -1;
             top = max(top, binf[k]);
         }
         T[k] = Tf[k];

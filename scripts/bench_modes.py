@@ -279,8 +279,18 @@ def main():
         e2m, m2e, img, alpha = GR.get_flow(cam, stat, dyn, None, bg, delta_exposure=deltas[1])
         torch.autograd.backward([e2m, m2e, img, alpha], [v2, v2, v3, v1])
 
+    z2, z3, z1 = torch.zeros_like(v2), torch.zeros_like(v3), torch.zeros_like(v1)
+
+    def flow_call_zero_weight():
+        """the same with lambda_flow_loss = 0 (arguments/stereo/seesaw.py): the flow loss is still formed and
+        back-propagated, but every cotangent is exactly zero -- the compositor's backward skips such pixels"""
+        zero()
+        e2m, m2e, img, alpha = GR.get_flow(cam, stat, dyn, None, bg, delta_exposure=deltas[1])
+        torch.autograd.backward([e2m, m2e, img, alpha], [z2, z2, z3, z1])
+
     res = {}
     res["get_flow_ms"] = timed(flow_call, a.steps)
+    res["get_flow_zero_weight_ms"] = timed(flow_call_zero_weight, a.steps)
     res["photo_loss_torch_ops_ms"] = timed(loss_torch_ops, a.steps)
     res["photo_loss_fused_ms"] = timed(loss_fused, a.steps)
     res["lean_ms"] = timed(lean, a.steps)

@@ -417,3 +417,34 @@ def test_heavy_tiles_are_split_over_a_workgroup(hip_device):
             # same terms, summed per quadrant first: fp32 re-association (amplified by cancellation in the
             # projection backward for a few quaternion / scale components)
             _close(res["heavy"][2][k], ref, 1e-4, 1e-5 * float(ref.abs().max()), f"grad[{k}] heavy vs {other}")
+
+
+def test_zero_cotangent_pixels_are_skipped_exactly(hip_device):
+    """Pixels whose cotangents are exactly zero are dropped from the backward walk: gradients equal those of the
+    same cotangent image with a tiny non-zero value there, up to that value's contribution; an all-zero cotangent
+    gives exactly zero gradients."""
+    from mobgs_amd import rendering
+    n, w, h = 4000, 160, 112
+    s, _ = _scene(n, w, h, 51, 9)
+    names = ["means", "quats", "scales", "opacities", "colors"]
+
+    def grads(v_img, v_a):
+        t = {k: v.to(hip_device).clone().requires_grad_(k in names) for k, v in s.items()}
+        sp = rendering.SharedProjection(t["means"], t["quats"], t["scales"], t["opacities"], t["viewmats"], t["Ks"],
+                                        w, h)
+        img, a = sp.composite(t["colors"])
+        torch.autograd.backward([img, a], [v_img.to(hip_device), v_a.to(hip_device)])
+        return {k: t[k].grad.cpu() for k in names}
+
+    g = torch.Generator().manual_seed(3)
+    v_img = torch.randn(1, h, w, 10, generator=g)
+    v_a = torch.randn(1, h, w, 1, generator=g)
+    mask = torch.zeros(1, h, w, 1)
+    mask[:, 20:70, 30:120] = 1.0  # loss restricted to a window
+    ref = grads(v_img * mask + 1e-30 * (1 - mask), v_a * mask)   # nowhere exactly zero: nothing is skipped
+    got = grads(v_img * mask, v_a * mask)
+    for k in names:
+        _close(got[k], ref[k], 1e-6, 1e-7 * float(ref[k].abs().max()) + 1e-12, f"grad[{k}] with masked cotangents")
+    zero = grads(torch.zeros_like(v_img), torch.zeros_like(v_a))
+    for k in names:
+        assert float(zero[k].abs().max()) == 0.0, k
