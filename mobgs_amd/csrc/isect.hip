@@ -512,6 +512,130 @@ __device__ inline void bitonic_sort_global(uint64_t* a, int n, int nthreads) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// long lists (4096 < n <= 16384): stable LSD radix sort on the depth bits, 8 bits per pass, 1024 threads, all in LDS.
+//
+// A bitonic network needs log2(n)^2 / 2 ~ 100 dependent steps for 16 k keys (169 us measured for one 15 k-entry
+// list -- the critical path of the whole launch); a radix sort needs one pass per depth byte that actually varies.
+// LDS holds the 32-bit depth keys (64 KiB) and two 16-bit permutations (2 x 32 KiB) that the passes ping-pong
+// between; the flat ids stay in the list's global segment and are gathered once at the end.  Equal depth bits are
+// rare; the stable passes leave such a run in the (arbitrary) input order, and a fix-up orders each run by flat id
+// -- the order of upstream's stable sort on the full 64-bit key.
+//
+// One pass: wave w owns positions [1024 w, 1024 w + 1024) in 16 rounds of 64 consecutive entries.  In a round the
+// lanes holding the same byte find each other with 8 ballots (a match-any emulation), their order inside the round is
+// the lane order, and the wave's running count of that byte (LDS, wave-private, no atomics) gives the entry's rank
+// among the wave's entries with that byte.  After a workgroup barrier the per-(byte, wave) counts are turned into
+// global offsets (byte-major, then wave) and every entry is scattered to offset + rank: stable, as LSD requires.
+// ---------------------------------------------------------------------------------------------------
+constexpr int RADIX_WAVES = 16;
+constexpr int RADIX_CAP = 16384;
+struct RadixShared {
+    uint32_t depth[RADIX_CAP];
+    uint16_t perm[2][RADIX_CAP];
+    int cnt[RADIX_WAVES][256];
+    int flag;
+};
+
+// seg: the list's n 64-bit keys (depth bits << 32 | flat id) in global memory, any order.  On return
+// sh.perm[result][i] is the position in seg of the i-th entry of the sorted list.
+__device__ inline int radix_sort_long(const uint64_t* __restrict__ seg, int n, RadixShared& sh) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        sh.depth[i] = (uint32_t)(seg[i] >> 32);
+        sh.perm[0][i] = (uint16_t)i;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        for (int i = threadIdx.x; i < RADIX_WAVES * 256; i += 1024) (&sh.cnt[0][0])[i] = 0;
+        if (threadIdx.x == 0) sh.flag = 0;
+        __syncthreads();
+        uint16_t item[16];
+        uint8_t digit[16];
+        int rank[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = wv * 1024 + r * 64 + lane;
+            const bool valid = p < n;
+            item[r] = valid ? sh.perm[cur][p] : (uint16_t)0;
+            const int d = valid ? (int)((sh.depth[item[r]] >> (8 * pass)) & 255u) : 0;
+            digit[r] = (uint8_t)d;
+            uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint64_t bm = __builtin_amdgcn_ballot_w64(((d >> b) & 1) != 0);
+                peers &= ((d >> b) & 1) ? bm : ~bm;
+            }
+            rank[r] = 0;
+            int before = 0;
+            if (valid) before = sh.cnt[wv][d];  // every peer reads the same word before the leader updates it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                rank[r] = before + __builtin_popcountll(peers & lt);
+                if ((peers & lt) == 0ull) sh.cnt[wv][d] = before + __builtin_popcountll(peers);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        __syncthreads();
+        // byte totals -> offsets (byte-major, wave-minor); a byte holding all n entries makes the pass a no-op
+        int total = 0;
+        if (threadIdx.x < 256) {
+#pragma unroll
+            for (int w = 0; w < RADIX_WAVES; ++w) {
+                const int c = sh.cnt[w][threadIdx.x];
+                sh.cnt[w][threadIdx.x] = total;  // exclusive over the waves, inside this byte
+                total += c;
+            }
+            if (total == n) sh.flag = 1;
+        }
+        int scan_total;
+        const int incl = block_incl_scan_w<RADIX_WAVES>(threadIdx.x < 256 ? total : 0, &scan_total);
+        __syncthreads();
+        if (sh.flag == 0) {
+            if (threadIdx.x < 256) {
+                const int base = incl - total;
+#pragma unroll
+                for (int w = 0; w < RADIX_WAVES; ++w) sh.cnt[w][threadIdx.x] += base;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = wv * 1024 + r * 64 + lane;
+                if (p < n) sh.perm[cur ^ 1][sh.cnt[wv][digit[r]] + rank[r]] = item[r];
+            }
+            cur ^= 1;
+        }
+        __syncthreads();
+    }
+    // runs of equal depth bits: order by flat id (the thread at the head of a run sorts it; runs are rare and short)
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t di = sh.depth[sh.perm[cur][i]];
+        const bool head = (i == 0 || sh.depth[sh.perm[cur][i - 1]] != di) && i + 1 < n &&
+                          sh.depth[sh.perm[cur][i + 1]] == di;
+        if (head) {
+            int e = i + 1;
+            while (e < n && sh.depth[sh.perm[cur][e]] == di) ++e;
+            for (int a = i + 1; a < e; ++a) {  // insertion sort on the flat id (low 32 bits of the global key)
+                const uint16_t pa = sh.perm[cur][a];
+                const uint32_t ida = (uint32_t)seg[pa];
+                int b = a - 1;
+                while (b >= i && (uint32_t)seg[sh.perm[cur][b]] > ida) {
+                    sh.perm[cur][b + 1] = sh.perm[cur][b];
+                    --b;
+                }
+                sh.perm[cur][b + 1] = pa;
+            }
+        }
+    }
+    __syncthreads();
+    return cur;
+}
+
 // tiles whose list is longer than `min_len`, in no particular order: long_ids[0 .. *long_count)
 __global__ void __launch_bounds__(256) long_lists_kernel(int nt, const int32_t* __restrict__ tile_offsets, int min_len,
                                                            int32_t* __restrict__ long_ids,
@@ -549,13 +673,23 @@ __global__ void __launch_bounds__(THREADS) tile_sort_kernel(int n_tiles_total, i
             const int cam = t / tiles_per_cam, tl = t - cam * tiles_per_cam;
             const uint64_t hi_bits = (((uint64_t)cam << tile_bits) | (uint64_t)tl) << 32;
             if (n <= lds_cap) {
-                for (int i = threadIdx.x; i < n; i += THREADS) lds_keys[i] = seg[i];
-                __syncthreads();
-                if (n > 1) bitonic_sort_lds<THREADS>(lds_keys, n);
-                for (int i = threadIdx.x; i < n; i += THREADS) {
-                    const uint64_t k = lds_keys[i];
-                    flatten_ids[s + i] = (int32_t)(uint32_t)k;
-                    if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+                if constexpr (THREADS == 64 * RADIX_WAVES) {
+                    RadixShared& rs = *reinterpret_cast<RadixShared*>(lds_keys);
+                    const int cur = radix_sort_long(seg, n, rs);
+                    for (int i = threadIdx.x; i < n; i += THREADS) {
+                        const uint64_t k = seg[rs.perm[cur][i]];
+                        flatten_ids[s + i] = (int32_t)(uint32_t)k;
+                        if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+                    }
+                } else {
+                    for (int i = threadIdx.x; i < n; i += THREADS) lds_keys[i] = seg[i];
+                    __syncthreads();
+                    if (n > 1) bitonic_sort_lds<THREADS>(lds_keys, n);
+                    for (int i = threadIdx.x; i < n; i += THREADS) {
+                        const uint64_t k = lds_keys[i];
+                        flatten_ids[s + i] = (int32_t)(uint32_t)k;
+                        if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+                    }
                 }
             } else {
                 // pathological tile: sort in place in global memory (same workgroup, barrier-ordered)
@@ -694,7 +828,8 @@ static int emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t
         int32_t* long_count = L.tickets + 1;
         hipLaunchKernelGGL(long_lists_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, nt, tile_offsets, small_cap,
                            long_ids, long_count);
-        hipLaunchKernelGGL(tile_sort_kernel<1024>, dim3(nt < 256 ? nt : 256), dim3(1024), big_cap * sizeof(uint64_t), st,
+        static_assert(sizeof(RadixShared) <= 160 * 1024, "radix sort state must fit the LDS of a CU");
+        hipLaunchKernelGGL(tile_sort_kernel<1024>, dim3(nt < 256 ? nt : 256), dim3(1024), sizeof(RadixShared), st,
                            nt, big_cap, tile_bits, tile_offsets, sort_keys, flatten_ids, isect_ids, tiles_per_cam,
                            small_cap + 1, 0x7fffffff, long_ids, long_count);
     }
