@@ -530,6 +530,7 @@ __device__ inline void bitonic_sort_global(uint64_t* a, int n, int nthreads) {
 // ---------------------------------------------------------------------------------------------------
 constexpr int RADIX_WAVES = 16;
 constexpr int RADIX_CAP = 16384;
+constexpr int RADIX_MAX_RUN = 48;
 struct RadixShared {
     uint32_t depth[RADIX_CAP];
     uint16_t perm[2][RADIX_CAP];
@@ -612,14 +613,22 @@ __device__ inline int radix_sort_long(const uint64_t* __restrict__ seg, int n, R
         }
         __syncthreads();
     }
-    // runs of equal depth bits: order by flat id (the thread at the head of a run sorts it; runs are rare and short)
+    // runs of equal depth bits: order by flat id (the thread at the head of a run sorts it; runs are rare and
+    // short).  A run longer than RADIX_MAX_RUN (many splats at exactly the same depth, e.g. a fronto-parallel plane)
+    // would serialise in one thread: give up (-1) and let the caller sort the full 64-bit keys with the network.
+    if (threadIdx.x == 0) sh.flag = 0;
+    __syncthreads();
     for (int i = threadIdx.x; i < n; i += 1024) {
         const uint32_t di = sh.depth[sh.perm[cur][i]];
         const bool head = (i == 0 || sh.depth[sh.perm[cur][i - 1]] != di) && i + 1 < n &&
                           sh.depth[sh.perm[cur][i + 1]] == di;
         if (head) {
             int e = i + 1;
-            while (e < n && sh.depth[sh.perm[cur][e]] == di) ++e;
+            while (e < n && e - i <= RADIX_MAX_RUN && sh.depth[sh.perm[cur][e]] == di) ++e;
+            if (e - i > RADIX_MAX_RUN) {
+                sh.flag = 1;
+                continue;
+            }
             for (int a = i + 1; a < e; ++a) {  // insertion sort on the flat id (low 32 bits of the global key)
                 const uint16_t pa = sh.perm[cur][a];
                 const uint32_t ida = (uint32_t)seg[pa];
@@ -633,7 +642,7 @@ __device__ inline int radix_sort_long(const uint64_t* __restrict__ seg, int n, R
         }
     }
     __syncthreads();
-    return cur;
+    return sh.flag ? -1 : cur;
 }
 
 // tiles whose list is longer than `min_len`, in no particular order: long_ids[0 .. *long_count)
@@ -676,10 +685,22 @@ __global__ void __launch_bounds__(THREADS) tile_sort_kernel(int n_tiles_total, i
                 if constexpr (THREADS == 64 * RADIX_WAVES) {
                     RadixShared& rs = *reinterpret_cast<RadixShared*>(lds_keys);
                     const int cur = radix_sort_long(seg, n, rs);
-                    for (int i = threadIdx.x; i < n; i += THREADS) {
-                        const uint64_t k = seg[rs.perm[cur][i]];
-                        flatten_ids[s + i] = (int32_t)(uint32_t)k;
-                        if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+                    if (cur >= 0) {
+                        for (int i = threadIdx.x; i < n; i += THREADS) {
+                            const uint64_t k = seg[rs.perm[cur][i]];
+                            flatten_ids[s + i] = (int32_t)(uint32_t)k;
+                            if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+                        }
+                    } else {  // long runs of equal depth: the network on the full keys (128 KiB of the same LDS)
+                        __syncthreads();
+                        for (int i = threadIdx.x; i < n; i += THREADS) lds_keys[i] = seg[i];
+                        __syncthreads();
+                        bitonic_sort_lds<THREADS>(lds_keys, n);
+                        for (int i = threadIdx.x; i < n; i += THREADS) {
+                            const uint64_t k = lds_keys[i];
+                            flatten_ids[s + i] = (int32_t)(uint32_t)k;
+                            if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+                        }
                     }
                 } else {
                     for (int i = threadIdx.x; i < n; i += THREADS) lds_keys[i] = seg[i];

@@ -236,17 +236,20 @@ def test_tile_schedule_is_a_permutation_and_changes_nothing(hip_device):
         assert torch.equal(res[True][2][k], res[False][2][k]), k
 
 
-@pytest.mark.parametrize("n,w,h,scale", [(3000, 48, 32, 8.0), (12000, 64, 48, 3.0), (40000, 64, 48, 3.0)])
-def test_long_tile_lists_sort_exactly(hip_device, n, w, h, scale):
+@pytest.mark.parametrize("n,w,h,scale,quant", [(3000, 48, 32, 8.0, 4), (12000, 64, 48, 3.0, 4),
+                                               (12000, 64, 48, 3.0, 2048), (40000, 64, 48, 3.0, 4)])
+def test_long_tile_lists_sort_exactly(hip_device, n, w, h, scale, quant):
     """Few tiles, many big splats: per-tile lists of several hundred to > 4096 entries exercise the multi-chunk
-    LDS sort phases, the 1024-thread variant and (last case) the global-memory fallback; order must be upstream's."""
+    LDS network, the radix sort of the 1024-thread variant -- with short runs of equal depth (quant 2048: tie fix-up
+    by flat id) and with runs of hundreds (quant 4: falls back to the network on the full keys) -- and (last case)
+    the global-memory fallback; order must be upstream's."""
     from mobgs_amd import rendering
     from mobgs_amd.rendering import rasterization
     from oracle import gsplat_cpu as Cc
     s, _ = _scene(n, w, h, 5, 3)
     s["scales"] = s["scales"] * scale
     g = torch.Generator().manual_seed(1)
-    s["means"][:, 2] = torch.round(s["means"][:, 2] * 4) / 4 + 1.0  # many exact depth ties -> index tie-break
+    s["means"][:, 2] = torch.round(s["means"][:, 2] * quant) / quant + 1.0  # exact depth ties -> index tie-break
     d = _to(s, hip_device)
     rendering.set_tile_culling(False)
     try:
