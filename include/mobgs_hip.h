@@ -106,6 +106,8 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
 size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity);
 size_t mobgs_tile_order_len(int n_tiles);  /* int32 entries of tile_order */
 void mobgs_set_heavy_tile_len(int len);    /* scheduling policy, default 1024; 0 = never split a tile */
+void mobgs_hint_longest_list(int len);     /* longest list expected (e.g. last frame's): >= 2048 makes the next
+                                              mobgs_isect_offsets rank through LDS first (dense image regions) */
 int mobgs_get_heavy_tile_len(void);
 size_t mobgs_keep_scan_len(int capacity); /* int32 entries of keep_scan for `capacity` box intersections */
 int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,

@@ -31,6 +31,7 @@ _SIGS = {
     "mobgs_tile_order_len": (c_size_t, [c_int]),
     "mobgs_set_heavy_tile_len": (None, [c_int]),
     "mobgs_get_heavy_tile_len": (c_int, []),
+    "mobgs_hint_longest_list": (None, [c_int]),
     "mobgs_isect_offsets": (c_int, [c_int] * 8 + [P] * 5 + [c_int] + [P] * 4 + [c_int64] + [P] * 2 + [P]),
     "mobgs_isect_emit_sort": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int64, c_int64] + [P] * 7 + [P]),
     "mobgs_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, P, P,

@@ -171,13 +171,22 @@ static_assert(SCAN_BLOCK == KEEP_CHUNK, "one workgroup per keep_scan chunk");
 // atomic; (owner, tile, rank) are written out so that pass B is a pure streaming scatter.  The keep flags are
 // scanned inside the chunk (keep_scan locals, see common.h); the chunk's total goes to its base word, which
 // tile_scan_kernel turns into the exclusive prefix over the chunks.
+//
+// DENSE variant (chosen when the previous frame had long lists): a dense image region sends thousands of rank
+// atomics to the same few counters, which serialise in L2 (bin 73 -> 249 us on scripts/heavy_tail.py).  The
+// workgroup first ranks its kept intersections per tile in LDS (one int per tile, dynamic shared memory), then ONE
+// thread per touched tile reserves the workgroup's range with a single global atomic: up to 20x fewer same-address
+// atomics there, ~10 % more work on uniform scenes (hence not the default).
+template <bool DENSE>
 __global__ void __launch_bounds__(SCAN_THREADS)
 bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
            const int32_t* __restrict__ cum, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
            const float* __restrict__ conics, const float* __restrict__ opacities, int opac_per_camera,
            int32_t* __restrict__ flags, int32_t* __restrict__ owner, int32_t* __restrict__ tile_of_j,
-           int32_t* __restrict__ rank_of_j, int32_t* __restrict__ tile_count, int32_t* __restrict__ keep_scan) {
+           int32_t* __restrict__ rank_of_j, int32_t* __restrict__ tile_count, int32_t* __restrict__ keep_scan,
+           int n_tiles_total) {
     __shared__ int s_cum[OWNER_LDS + 1];
+    extern __shared__ int s_tile[];  // DENSE: per-tile count of this workgroup, then the base of its range
     const int chunk = blockIdx.x;
     int32_t* kchunk = keep_scan + (size_t)chunk * (KEEP_CHUNK + 1);
     const int I = min(cum[n_gauss], capacity);
@@ -239,8 +248,28 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
     }
     // ranks inside the tiles' lists: all returning atomics in flight before the first result is consumed
     int rank[SCAN_ITEMS];
+    if (DENSE) {
+        for (int t = threadIdx.x; t < n_tiles_total; t += SCAN_THREADS) s_tile[t] = 0;
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = keep[k] ? atomicAdd(&tile_count[til[k] * TC_STRIDE], 1) : 0;
+        for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = keep[k] ? atomicAdd(&s_tile[til[k]], 1) : 0;
+        __syncthreads();
+        int base_of[SCAN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k)  // the intersection that got local rank 0 speaks for its tile
+            base_of[k] = (keep[k] && rank[k] == 0) ? atomicAdd(&tile_count[til[k] * TC_STRIDE], s_tile[til[k]]) : 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k)
+            if (keep[k] && rank[k] == 0) s_tile[til[k]] = base_of[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k)
+            if (keep[k]) rank[k] += s_tile[til[k]];
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = keep[k] ? atomicAdd(&tile_count[til[k] * TC_STRIDE], 1) : 0;
+    }
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const int j = start + k * SCAN_THREADS + threadIdx.x;
@@ -733,6 +762,11 @@ using namespace mobgs;
 
 // list length from which a tile is composited by a whole workgroup (scheduling policy, see tile_scan_kernel)
 static int g_heavy_len = 1024;
+// longest list of the previous frame as told by the orchestrator (mobgs_project_and_bin_speculative): selects the
+// dense variant of bin_kernel
+static int g_dense_hint = 0;
+constexpr int DENSE_LIST_LEN = 2048;
+constexpr int DENSE_MAX_TILES = 8192;  // 32 KiB of LDS
 
 extern "C" {
 
@@ -763,6 +797,7 @@ struct IsectScratch {
 size_t mobgs_tile_order_len(int n_tiles) { return sched_slots((size_t)n_tiles); }
 
 void mobgs_set_heavy_tile_len(int len) { g_heavy_len = len < 0 ? 0 : len; }
+void mobgs_hint_longest_list(int len) { g_dense_hint = len < 0 ? 0 : len; }
 int mobgs_get_heavy_tile_len(void) { return g_heavy_len; }
 
 size_t mobgs_keep_scan_len(int capacity) { return keep_scan_len((size_t)capacity); }
@@ -805,9 +840,16 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
     // keep flags, per-tile ranks and keep_scan over the first min(I_box, capacity) intersections (the caller
     // re-runs with a larger buffer when stats[0] > capacity); stats[1] = I_listed
     const int n_chunks = (capacity >> KEEP_CHUNK_LOG2) + 1;
-    hipLaunchKernelGGL(bin_kernel, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h, width, height, cull,
-                       capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera, L.flags, L.owner,
-                       L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan);
+    // dense variant: long lists last frame (g_dense_hint, set by the orchestrator) and one int per tile fits in LDS
+    if (g_dense_hint >= DENSE_LIST_LEN && nt <= DENSE_MAX_TILES)
+        hipLaunchKernelGGL(bin_kernel<true>, dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n, N,
+                           tile_w, tile_h, width, height, cull, capacity, cum_tiles, means2d, radii, conics, opacities,
+                           opac_per_camera, L.flags, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan,
+                           (int)nt);
+    else
+        hipLaunchKernelGGL(bin_kernel<false>, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h, width,
+                           height, cull, capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera,
+                           L.flags, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
                        stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, g_heavy_len);
     return check_launch("isect_offsets");

@@ -71,6 +71,7 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
     int rc = mobgs_project_fwd(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
                                radius_clip, radii, means2d, depths, conics, tiles_per_gauss, stream);
     if (rc != MOBGS_OK) return rc;
+    mobgs_hint_longest_list((int)(max_tile_len_hint > 0x7fffffff ? 0x7fffffff : max_tile_len_hint));
     rc = mobgs_isect_offsets(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d, radii,
                              conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order,
                              capacity_listed, stats_dev, scratch, stream);

@@ -254,6 +254,7 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Ten
         cap = int(n_box * 1.25) + 1024  # first call on a denser scene: grow and redo (rare)
     _capacity[key] = cap
     last_stats.update(n_isects=n_isects, n_box=n_box, max_tile_len=max_len, n_tiles=nt)
+    lib.mobgs_hint_longest_list(max_len)  # next frame: dense-region variant of the binning when lists are long
     flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
     isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev) if want_isect_ids else None
     tl._set_counts(n_box, n_isects, max_len, flatten_ids, isect_ids)
