@@ -23,7 +23,7 @@ from .._lib import DerivedCache
 from ..ops import PrepSplats, decode
 from . import network_gui  # noqa: F401  (train.py imports it from here)
 
-__all__ = ["render", "get_flow", "get_flow_static", "interpolate_cubic_hermite", "network_gui"]
+__all__ = ["render", "get_flow", "get_flow_many", "get_flow_static", "interpolate_cubic_hermite", "network_gui"]
 
 # True: the static-only / dynamic-only images of a train-mode render() come from one layered compositing pass over
 # the lists of the combined render (csrc/raster_layers.hip); False: one rasterization per set, call for call like
@@ -311,7 +311,16 @@ def _pixel_grid(cam, W, H, like):
     return g
 
 
-def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=None):
+def _flow_mid_state(cam, stat_pc, dyn_pc, dev):
+    """Projection + tile lists of the scene at the camera's own (mid-exposure) time: the part of get_flow() that does
+    not depend on delta_exposure."""
+    W, H = int(cam.image_width), int(cam.image_height)
+    viewmat = cam.world_view_transform.transpose(0, 1)
+    mid_m, mid_q, scales, opac, _ = _prep(stat_pc, dyn_pc, _times(cam, None, dev))
+    return _R.SharedProjection(mid_m, mid_q, scales, opac, viewmat[None], cam.K[None], W, H)
+
+
+def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=None, _mid=None):
     """/root/reference/gaussian_renderer/__init__.py:318-492 ->
     (exp2mid_coord_map [1,H,W,2], mid2exp_coord_map [1,H,W,2], latent_img [3,H,W], latent_alpha [1,H,W])."""
     cam = viewpoint_camera
@@ -323,22 +332,22 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     bg = bg1[0]
     w1, w2 = _decoder_weights(dyn_pc)
     Ns = stat_pc.get_xyz.shape[0]
-    mid_m, mid_q, scales, opac, _ = _prep(stat_pc, dyn_pc, _times(cam, None, dev))
-    exp_m, exp_q, _, _, exp_c = _prep(stat_pc, dyn_pc, _times(cam, delta_exposure, dev))
+    exp_m, exp_q, scales, opac, exp_c = _prep(stat_pc, dyn_pc, _times(cam, delta_exposure, dev))
 
-    # two projections + two tile binnings in total (the reference: 2 explicit projections + 4 rasterizations)
+    # two projections + two tile binnings of the whole set (the reference: 2 explicit projections + 4 rasterizations)
     sp_exp = _R.SharedProjection(exp_m, exp_q, scales, opac, viewmat[None], K[None], W, H)
-    sp_mid = _R.SharedProjection(mid_m, mid_q, scales, opac, viewmat[None], K[None], W, H)
+    sp_mid = _mid if _mid is not None else _flow_mid_state(cam, stat_pc, dyn_pc, dev)
 
     def splat(sp, colors):
         return _R.rasterize_to_pixels(sp.means2d, sp.conics, colors, opac, sp.radii, sp.tl, W, H)[0]
 
+    # dynamic-only coverage (:477-490): its own (smaller) projection and lists, without a host synchronisation
     dyn_sl = slice(Ns, None)
-    ones = torch.ones(exp_c.shape[0] - Ns, 1, device=dev)
-    latent_alpha = _R.rasterization(means=exp_m[dyn_sl], quats=exp_q[dyn_sl], scales=scales[dyn_sl],
-                                    opacities=opac[dyn_sl], colors=ones, backgrounds=bg[0:1][None],
-                                    viewmats=viewmat[None], Ks=K[None], width=W, height=H, packed=False,
-                                    render_mode="RGB")[0][..., 0]
+    sp_dyn = _R.SharedProjection(exp_m[dyn_sl], exp_q[dyn_sl], scales[dyn_sl], opac[dyn_sl], viewmat[None], K[None],
+                                 W, H)
+    ones = _ones_column(exp_c.shape[0] - Ns, dev)
+    latent_alpha = _R.rasterize_to_pixels(sp_dyn.means2d, sp_dyn.conics, ones, opac[dyn_sl], sp_dyn.radii, sp_dyn.tl,
+                                          W, H, backgrounds=bg[0:1][None])[0][..., 0]
     e2m = (sp_mid.means2d - sp_exp.means2d).squeeze(0)
     # the exposure-time lists are walked ONCE for the 9 colour features and the 2 flow channels (the reference: one
     # rasterization each, :436-452 and :461-476; channels accumulate independently, so the images are identical)
@@ -349,6 +358,28 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     mid2exp = pix + splat(sp_mid, -e2m)
     latent_img, _ = decode(img12, alphas, _rays_of(cam), w1, w2, False)  # reads the 9 feature channels only
     return exp2mid, mid2exp, latent_img, latent_alpha
+
+
+def get_flow_many(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposures):
+    """[get_flow(..., delta_exposure=d) for d in delta_exposures] -- the 9 calls per view of train.py:570-579 -- with
+    the mid-exposure prep / projection / tile lists (which do not depend on d) built once and shared by all of them
+    (not in the reference; the results are identical)."""
+    mid = _flow_mid_state(viewpoint_camera, stat_pc, dyn_pc, _device_of(dyn_pc))
+    return [get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=d, _mid=mid)
+            for d in delta_exposures]
+
+
+_ones_cache = {}
+
+
+def _ones_column(n, dev):
+    key = (n, str(dev))
+    t = _ones_cache.get(key)
+    if t is None:
+        if len(_ones_cache) > 8:
+            _ones_cache.clear()
+        t = _ones_cache[key] = torch.ones(n, 1, device=dev)
+    return t
 
 
 def get_flow_static(source_camera, target_camera, splat_camera, stat_pc, dyn_pc, pipe, bg_color):

@@ -288,7 +288,14 @@ def main():
         e2m, m2e, img, alpha = GR.get_flow(cam, stat, dyn, None, bg, delta_exposure=deltas[1])
         torch.autograd.backward([e2m, m2e, img, alpha], [z2, z2, z3, z1])
 
+    def flow_many_zero_weight():
+        """all 9 get_flow calls of one view through get_flow_many (shared mid-exposure state), weight 0"""
+        zero()
+        outs = GR.get_flow_many(cam, stat, dyn, None, bg, [deltas[k] for k in range(9)])
+        torch.autograd.backward([t for o in outs for t in o], [z2, z2, z3, z1] * 9)
+
     res = {}
+    res["get_flow_x9_many_zero_weight_ms"] = timed(flow_many_zero_weight, max(3, a.steps // 4), warmup=1)
     res["get_flow_ms"] = timed(flow_call, a.steps)
     res["get_flow_zero_weight_ms"] = timed(flow_call_zero_weight, a.steps)
     res["photo_loss_torch_ops_ms"] = timed(loss_torch_ops, a.steps)

@@ -199,3 +199,26 @@ def test_inkernel_rays_match_ray_map_and_reach_the_pose(hip_device):
 
 
 import math  # noqa: E402
+
+
+def test_get_flow_many_equals_separate_calls(hip_device):
+    """get_flow_many shares the mid-exposure projection / lists between the calls: outputs bit-identical to separate
+    get_flow calls, summed gradients equal up to fp32 accumulation order."""
+    from mobgs_amd.gaussian_renderer import get_flow, get_flow_many
+    fx = load("get_flow")
+    deltas = [-0.4, 0.1, 0.3]
+    res = {}
+    for many in (False, True):
+        cam, stat, dyn, bg, _ = scene_from_fixture(fx, device=hip_device)
+        if many:
+            outs = get_flow_many(cam, stat, dyn, None, bg, deltas)
+        else:
+            outs = [get_flow(cam, stat, dyn, None, bg, delta_exposure=d) for d in deltas]
+        loss = sum((t * (i + 1)).sum() for i, o in enumerate(outs) for t in o)
+        loss.backward()
+        res[many] = ([t.detach().cpu() for o in outs for t in o],
+                     {k: t.grad.cpu() for k, t in leaf_map(stat, dyn).items() if t.grad is not None})
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    for k, g in res[False][1].items():
+        close(res[True][1][k], g, 1e-4, 1e-5 * float(g.abs().max()) + 1e-8, f"grad[{k}]")
