@@ -10,11 +10,17 @@
  *   /root/reference/gaussian_renderer/__init__.py:23-56     interpolate_cubic_hermite
  *   /root/reference/gaussian_renderer/__init__.py:93-125    time offset, rotation, colour feature build
  *   /root/reference/helper_model.py:19-28                   Sandwich colour decoder
+ * and, either side of the path:
+ *   /root/reference/scene/deformation.py, scene/hexplane.py deform_network (HexPlane + MLP heads)
+ *   /root/reference/utils/loss_utils.py:233-239,351-381     L1 + SSIM
+ *   /root/reference/main_utils.py:95-141                    normals from depth
+ *   /root/reference/scene/gaussian_model.py:1044-1244,1352-1356,1480-1506   densification / optimiser surgery
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in _host;
- *   - the caller owns every buffer (outputs and scratch); the library never allocates device memory and
- *     keeps no mutable global state apart from the thread-local last-error string;
+ *   - the caller owns every buffer (outputs and scratch); the library never allocates device memory; its only
+ *     mutable state is the thread-local last-error string and two process-wide scheduling hints
+ *     (mobgs_set_heavy_tile_len, mobgs_hint_longest_list) that change how work is distributed, never a result;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises, except
  *     mobgs_project_and_bin (one documented read-back);
  *   - return value: 0 on success, negative MOBGS_E_* on failure (mobgs_last_error() gives the text);
@@ -281,6 +287,9 @@ int mobgs_normals_bwd(int H, int W, float fx, float fy, float cx, float cy, floa
                       const float* z, const float* v_normals, float* v_z, void* stream);
 
 /* ---- K6''/K7'': class-restricted passes of the single-set compositor -----------------------------------------
+ * Replaces the static-only / dynamic-only rasterization() calls of
+ * /root/reference/gaussian_renderer/__init__.py:201-214 (dynamic), :236-250 (static) and their ones-colour alpha
+ * passes :163-177, :255-269, for splat sets that are the two halves of one projected set.
  * The static-only (class_sel = 1: flat id % N < Ns) or dynamic-only (class_sel = 2) "RGB+D" render over the lists
  * of the WHOLE set: entries of the other class are dropped as each 64-entry batch is staged.  Every splat belongs
  * to exactly one class, so the two passes together blend each (tile, splat) pair once and their backward passes
