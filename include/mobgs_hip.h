@@ -333,7 +333,7 @@ int mobgs_prep_bwd(int Ns, int Nd, const float* times, const int64_t* d_ncp, con
                    const float* v_scales, const float* v_opacities, const float* v_colors, float* g_s_xyz,
                    float* g_s_scaling, float* g_s_rotation, float* g_s_opacity, float* g_s_fdc, float* g_s_ft,
                    float* g_d_control, float* g_d_scaling, float* g_d_rotation, float* g_d_omega,
-                   float* g_d_opacity, float* g_d_fdc, float* g_d_ft, void* stream);
+                   float* g_d_opacity, float* g_d_fdc, float* g_d_ft, int accumulate, void* stream);
 
 /* ---- K9: colour decoder + expected-depth normalisation (replaces Sandwich.forward + gsplat's "ED" step) ---
  * /root/reference/helper_model.py:19-28; /root/reference/gaussian_renderer/__init__.py:216-227.

@@ -141,7 +141,8 @@ class BLCE(nn.Module):
         G = eye[None] * theta + (1 - torch.cos(theta)) * K + (theta - torch.sin(theta)) * K2
         p = torch.matmul(G, v_rigid[..., None])
         top = torch.cat([R_exp, p], dim=-1)
-        fill = torch.tensor([0, 0, 0, 1], device=dev, dtype=Rt.dtype)[None].repeat(top.size(0), 1, 1)
+        fill = eye.new_zeros(top.size(0), 1, 4)  # [0 0 0 1] rows built on the device (no host constant: the
+        fill[..., 3] = 1.0                       # forward must be capturable in a HIP graph)
         Rt_new = torch.einsum("ij,tjk->tik", Rt, torch.cat([top, fill], dim=1))
         exposure_time = torch.linspace(-1, 1, self.num_warp, device=self.exposure_time_expo.device) \
             * self.exposure_time_expo[idx_view]
@@ -189,6 +190,27 @@ class WarpedCamera:
         return self._ray
 
 
+# True: the per-view BLCE forward / backward is captured once per view in a HIP graph and replayed (see
+# blceKernel._view_fn); False: eager launches
+GRAPH_CAPTURE = True
+
+
+class _ViewModule(nn.Module):
+    """The part of BLCE one view uses, as a module of its own (graph capture collects ITS parameters)."""
+
+    def __init__(self, model: "BLCE", idx_view: int):
+        super().__init__()
+        self.idx = idx_view
+        self.owner = [model]  # not registered: parameters are listed explicitly below
+        for n in ("view_encoder", "Rt_encoder", "wv_derivative", "rot_decoder", "trans_decoder", "theta_decoder",
+                  "blur_feature_encoder"):
+            setattr(self, n, getattr(model, n)[idx_view])
+        self.view_embedder = model.view_embedder
+
+    def forward(self, Rt, bf):
+        return self.owner[0](Rt, bf, self.idx)
+
+
 class blceKernel(nn.Module):
     def __init__(self, num_views=None, view_dim=32, num_warp=9, method="euler", adjoint=False, iteration=None):
         super().__init__()
@@ -201,6 +223,8 @@ class blceKernel(nn.Module):
         # how a warped camera object is built; replace with a factory creating the caller's own Camera class
         self.camera_factory: Callable = WarpedCamera
         self._blur_cache = {}
+        self._c2w_cache = {}
+        self._graphed = {}
 
     @staticmethod
     def _w2c_of(cam) -> torch.Tensor:
@@ -208,8 +232,16 @@ class blceKernel(nn.Module):
         return wvt.transpose(0, 1) if torch.is_tensor(wvt) else torch.as_tensor(wvt).transpose(0, 1)
 
     def get_Rt_c2w(self, cam) -> torch.Tensor:
-        """c2w of the view, detached (the reference goes through numpy, :215-225)."""
-        return torch.inverse(self._w2c_of(cam).detach().to(torch.float32))
+        """c2w of the view, detached (the reference goes through numpy, :215-225); cached per view while the camera's
+        pose tensor is unchanged (torch.inverse synchronises)."""
+        w2c = self._w2c_of(cam)
+        key = getattr(cam, "uid", id(cam))
+        hit = self._c2w_cache.get(key)
+        if hit is not None and hit[0] is cam.world_view_transform and hit[1] == getattr(w2c, "_version", 0):
+            return hit[2]
+        c2w = torch.inverse(w2c.detach().to(torch.float32))
+        self._c2w_cache[key] = (cam.world_view_transform, getattr(w2c, "_version", 0), c2w)
+        return c2w
 
     def blur_feature(self, cam) -> torch.Tensor:
         """FFT statistic of the view's (constant) input image: computed once per view instead of per call."""
@@ -218,12 +250,27 @@ class blceKernel(nn.Module):
             self._blur_cache[key] = compute_frequency_blur_feature(cam.image).detach()
         return self._blur_cache[key]
 
+    def _view_fn(self, idx_view, Rt, bf):
+        """model(Rt, bf, idx_view), replayed as ONE HIP graph when GRAPH_CAPTURE is on: the forward is ~180 launches
+        of a few microseconds of work each (8 Euler steps of two 56->16 linears, SE(3) exponential), its backward
+        ~350 -- launch latency, not arithmetic (1.9 / 5.9 ms per view measured eagerly)."""
+        if not (GRAPH_CAPTURE and Rt.is_cuda and torch.is_grad_enabled()):
+            return self.model(Rt, bf, idx_view)
+        fn = self._graphed.get(idx_view)
+        if fn is None:
+            fn = torch.cuda.make_graphed_callables(_ViewModule(self.model, idx_view), (Rt.clone(), bf.clone()))
+            self._graphed[idx_view] = fn
+        return fn(Rt, bf)
+
     def get_warped_cams(self, cam=None, fwd_cam=None, bwd_cam=None):
         dev = next(self.model.parameters()).device
         Rt = self.get_Rt_c2w(cam).to(dev)
-        warped_c2w, exposure_time = self.model(Rt, self.blur_feature(cam).to(dev), cam.uid)
+        warped_c2w, exposure_time = self._view_fn(cam.uid, Rt, self.blur_feature(cam).to(dev))
         warped_w2c = torch.inverse(warped_c2w)
-        cams: List = [self.camera_factory(cam, warped_w2c[i], warped_c2w[i]) for i in range(self.num_warp)]
+        # unbind: ONE autograd node per stack (its backward is a single stack) instead of 2 x num_warp selects whose
+        # backward each zero-fills and copies a [num_warp,4,4] tensor
+        cams: List = [self.camera_factory(cam, w2c_i, c2w_i)
+                      for w2c_i, c2w_i in zip(warped_w2c.unbind(0), warped_c2w.unbind(0))]
         return cams, exposure_time
 
     def adjust_lr(self) -> None:

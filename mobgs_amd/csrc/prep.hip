@@ -110,6 +110,9 @@ prep_fwd_kernel(int Ns, int Nd, const float* __restrict__ times,
     for (int k = 0; k < 9; ++k) colors[9 * i + k] = col[k];
 }
 
+// ACC: the leaf gradients are ADDED to what the buffers hold (several renders of one backward pass write into one
+// set of buffers, see mobgs_amd.ops.LeafGradSink) instead of overwriting them
+template <bool ACC>
 __global__ void __launch_bounds__(256)
 prep_bwd_kernel(int Ns, int Nd, const float* __restrict__ times, const long long* __restrict__ d_ncp,
                 const float* __restrict__ d_trbf,
@@ -148,22 +151,31 @@ prep_bwd_kernel(int Ns, int Nd, const float* __restrict__ times, const long long
     if (i < Ns) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            g_s_xyz[3 * i + k] = vm[k];
-            g_s_scaling[3 * i + k] = vs[k];
-            g_s_ft[3 * i + k] = 0.0f * vc[6 + k];
+            g_s_xyz[3 * i + k] = (ACC ? g_s_xyz[3 * i + k] : 0.f) + vm[k];
+            g_s_scaling[3 * i + k] = (ACC ? g_s_scaling[3 * i + k] : 0.f) + vs[k];
+            g_s_ft[3 * i + k] = (ACC ? g_s_ft[3 * i + k] : 0.f) + 0.0f * vc[6 + k];
         }
-        reinterpret_cast<float4*>(g_s_rotation)[i] = make_float4(vq[0], vq[1], vq[2], vq[3]);
-        g_s_opacity[i] = vo;
+        {
+            float4 q = make_float4(vq[0], vq[1], vq[2], vq[3]);
+            if (ACC) {
+                const float4 o = reinterpret_cast<const float4*>(g_s_rotation)[i];
+                q = make_float4(o.x + q.x, o.y + q.y, o.z + q.z, o.w + q.w);
+            }
+            reinterpret_cast<float4*>(g_s_rotation)[i] = q;
+        }
+        g_s_opacity[i] = (ACC ? g_s_opacity[i] : 0.f) + vo;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) g_s_fdc[6 * i + k] = vc[k];
+        for (int k = 0; k < 6; ++k) g_s_fdc[6 * i + k] = (ACC ? g_s_fdc[6 * i + k] : 0.f) + vc[k];
     } else {
         const int j = i - Ns;
         const float tfp = times[0] - d_trbf[j];
         const int n = (int)d_ncp[j];
         const Hermite H = hermite_setup(times[1], n);
         float* gc = g_d_control + (size_t)j * 36;
+        if (!ACC) {
 #pragma unroll
-        for (int k = 0; k < 36; ++k) gc[k] = 0.f;
+            for (int k = 0; k < 36; ++k) gc[k] = 0.f;
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float v = vm[k] * 1e-2f;
@@ -188,14 +200,24 @@ prep_bwd_kernel(int Ns, int Nd, const float* __restrict__ times, const long long
             gc[3 * H.i1 + k] += a1;
             gc[3 * H.i2 + k] += a2;
             gc[3 * H.i3 + k] += a3;
-            g_d_scaling[3 * j + k] = vs[k];
-            g_d_ft[3 * j + k] = tfp * vc[6 + k];
+            g_d_scaling[3 * j + k] = (ACC ? g_d_scaling[3 * j + k] : 0.f) + vs[k];
+            g_d_ft[3 * j + k] = (ACC ? g_d_ft[3 * j + k] : 0.f) + tfp * vc[6 + k];
         }
-        reinterpret_cast<float4*>(g_d_rotation)[j] = make_float4(vq[0], vq[1], vq[2], vq[3]);
-        reinterpret_cast<float4*>(g_d_omega)[j] = make_float4(tfp * vq[0], tfp * vq[1], tfp * vq[2], tfp * vq[3]);
-        g_d_opacity[j] = vo;
+        {
+            float4 q = make_float4(vq[0], vq[1], vq[2], vq[3]);
+            float4 w = make_float4(tfp * vq[0], tfp * vq[1], tfp * vq[2], tfp * vq[3]);
+            if (ACC) {
+                const float4 o = reinterpret_cast<const float4*>(g_d_rotation)[j];
+                const float4 p = reinterpret_cast<const float4*>(g_d_omega)[j];
+                q = make_float4(o.x + q.x, o.y + q.y, o.z + q.z, o.w + q.w);
+                w = make_float4(p.x + w.x, p.y + w.y, p.z + w.z, p.w + w.w);
+            }
+            reinterpret_cast<float4*>(g_d_rotation)[j] = q;
+            reinterpret_cast<float4*>(g_d_omega)[j] = w;
+        }
+        g_d_opacity[j] = (ACC ? g_d_opacity[j] : 0.f) + vo;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) g_d_fdc[6 * j + k] = vc[k];
+        for (int k = 0; k < 6; ++k) g_d_fdc[6 * j + k] = (ACC ? g_d_fdc[6 * j + k] : 0.f) + vc[k];
     }
 }
 
@@ -228,17 +250,23 @@ int mobgs_prep_bwd(int Ns, int Nd, const float* times, const int64_t* d_ncp, con
                    const float* v_scales, const float* v_opacities, const float* v_colors, float* g_s_xyz,
                    float* g_s_scaling, float* g_s_rotation, float* g_s_opacity, float* g_s_fdc, float* g_s_ft,
                    float* g_d_control, float* g_d_scaling, float* g_d_rotation, float* g_d_omega, float* g_d_opacity,
-                   float* g_d_fdc, float* g_d_ft, void* stream) {
+                   float* g_d_fdc, float* g_d_ft, int accumulate, void* stream) {
     if (Ns < 0 || Nd < 0) {
         set_error("mobgs_prep_bwd: bad sizes Ns=%d Nd=%d", Ns, Nd);
         return MOBGS_E_INVALID;
     }
     const int N = Ns + Nd;
     if (N == 0) return MOBGS_OK;
-    hipLaunchKernelGGL(prep_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, Ns, Nd, times,
-                       (const long long*)d_ncp, d_trbf, scales, opacities, v_means, v_quats, v_scales, v_opacities,
-                       v_colors, g_s_xyz, g_s_scaling, g_s_rotation, g_s_opacity, g_s_fdc, g_s_ft, g_d_control,
-                       g_d_scaling, g_d_rotation, g_d_omega, g_d_opacity, g_d_fdc, g_d_ft);
+    if (accumulate)
+        hipLaunchKernelGGL(prep_bwd_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, Ns, Nd,
+                           times, (const long long*)d_ncp, d_trbf, scales, opacities, v_means, v_quats, v_scales,
+                           v_opacities, v_colors, g_s_xyz, g_s_scaling, g_s_rotation, g_s_opacity, g_s_fdc, g_s_ft,
+                           g_d_control, g_d_scaling, g_d_rotation, g_d_omega, g_d_opacity, g_d_fdc, g_d_ft);
+    else
+        hipLaunchKernelGGL(prep_bwd_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, Ns, Nd,
+                           times, (const long long*)d_ncp, d_trbf, scales, opacities, v_means, v_quats, v_scales,
+                           v_opacities, v_colors, g_s_xyz, g_s_scaling, g_s_rotation, g_s_opacity, g_s_fdc, g_s_ft,
+                           g_d_control, g_d_scaling, g_d_rotation, g_d_omega, g_d_opacity, g_d_fdc, g_d_ft);
     return check_launch("prep_bwd_kernel");
 }
 

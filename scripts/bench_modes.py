@@ -311,6 +311,25 @@ def main():
     GR.FUSE_LAYERS = True
     res["train_mode_layered_ms"] = timed(train_mode, a.steps)
     res["blurry_view_layered_ms"] = timed(blurry_view, max(3, a.steps // 4), warmup=1)
+
+    from mobgs_amd.ops import LeafGradSink
+
+    def blurry_view_sink():
+        """the same with the 9 renders' leaf gradients accumulated in-kernel (LeafGradSink around backward)"""
+        zero()
+        mid = GR.render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True)
+
+        def unit(k):
+            if k == 4:
+                return mid["render"]
+            return GR.render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True,
+                             delta_exposure=deltas[k])["render"]
+
+        pred = shard.render_blurry_view(unit, 9)
+        with LeafGradSink(stat, dyn):
+            torch.autograd.backward([pred, mid["depth"], mid["d_alpha"]], [v3, v1, v1])
+
+    res["blurry_view_layered_gradsink_ms"] = timed(blurry_view_sink, max(3, a.steps // 4), warmup=1)
     res["train_mode_renders_per_s"] = 1e3 / res["train_mode_layered_ms"]
     res["blurry_views_per_s"] = 1e3 / res["blurry_view_layered_ms"]
     res.update(densify_legs(dev, a.steps))

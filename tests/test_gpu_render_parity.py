@@ -222,3 +222,26 @@ def test_get_flow_many_equals_separate_calls(hip_device):
         assert torch.equal(a, b)
     for k, g in res[False][1].items():
         close(res[True][1][k], g, 1e-4, 1e-5 * float(g.abs().max()) + 1e-8, f"grad[{k}]")
+
+
+def test_leaf_grad_sink_equals_autograd_accumulation(hip_device):
+    """LeafGradSink: several render() calls back-propagated with their leaf gradients accumulated in-kernel give the
+    same .grad as autograd's own accumulation (same sums, same order), also on top of an existing .grad."""
+    import mobgs_amd.gaussian_renderer as GR
+    from mobgs_amd.ops import LeafGradSink
+    fx = load("render_train")
+    res = {}
+    for sink in (False, True):
+        cam, stat, dyn, bg, _ = scene_from_fixture(fx, device=hip_device)
+        for rep in range(2):  # second round: .grad already exists
+            outs = [GR.render(cam, stat, dyn, None, bg, delta_exposure=d)["render"] for d in (None, 0.2, -0.3)]
+            loss = sum((o * (i + 1)).sum() for i, o in enumerate(outs))
+            if sink:
+                with LeafGradSink(stat, dyn):
+                    loss.backward()
+            else:
+                loss.backward()
+        res[sink] = {k: t.grad.cpu() for k, t in leaf_map(stat, dyn).items() if t.grad is not None}
+    assert set(res[True]) == set(res[False])
+    for k, g in res[False].items():
+        close(res[True][k], g, 1e-6, 1e-7 * float(g.abs().max()) + 1e-12, f"grad[{k}]")
