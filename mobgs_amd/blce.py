@@ -258,8 +258,15 @@ class blceKernel(nn.Module):
             return self.model(Rt, bf, idx_view)
         fn = self._graphed.get(idx_view)
         if fn is None:
-            fn = torch.cuda.make_graphed_callables(_ViewModule(self.model, idx_view), (Rt.clone(), bf.clone()))
+            try:
+                fn = torch.cuda.make_graphed_callables(_ViewModule(self.model, idx_view), (Rt.clone(), bf.clone()))
+            except RuntimeError as e:  # capture unsupported in this setup: say so once and run eagerly from now on
+                import warnings
+                warnings.warn(f"mobgs_amd.blce: HIP graph capture failed ({e}); running BLCE eagerly")
+                fn = False
             self._graphed[idx_view] = fn
+        if fn is False:
+            return self.model(Rt, bf, idx_view)
         return fn(Rt, bf)
 
     def get_warped_cams(self, cam=None, fwd_cam=None, bwd_cam=None):
