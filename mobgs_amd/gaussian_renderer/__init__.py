@@ -219,14 +219,26 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     # compositor, the static-only / dynamic-only images (when asked for) from ONE layered walk over the same lists
     # (the reference: 5 rasterizations, :143-176, :201-214, :236-268)
     sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None], K[None], W, H)
-    img, alphas = sp.composite(cols, bg1)
+    # The intersection counts are still on their way to the host (speculative binning).  Compositing AND decoding are
+    # enqueued before waiting for them, so that the device has the rest of the forward pass queued while the host
+    # waits -- on small scenes (tens of thousands of splats) the step is host-bound and this wait was a bubble.
+    rebuilds = sp.tl.rebuilds
+    sp.tl.defer = True
+    try:
+        img, alphas = sp.composite(cols, bg1)
+        rendered, depth = decode_ed(img, alphas)
+    finally:
+        sp.tl.defer = False
+    sp.tl.resolve()
+    if sp.tl.rebuilds != rebuilds:  # arena too small (first frame / scene grew): lists were rebuilt, do it again
+        img, alphas = sp.composite(cols, bg1)
+        rendered, depth = decode_ed(img, alphas)
     info = sp.meta()
     radii = info["radii"].squeeze(0)
     try:
         info["means2d"].retain_grad()
     except Exception:  # noqa: BLE001  (no grad mode)
         pass
-    rendered, depth = decode_ed(img, alphas)
     out["render"] = rendered
     out["depth"] = depth.unsqueeze(0)
     if get_dynamic:

@@ -117,10 +117,13 @@ class TileLists:
     with a larger arena and returns True, upon which the caller re-issues what it had enqueued."""
 
     __slots__ = ("C", "N", "tile_w", "tile_h", "cum_tiles", "keep_scan", "tile_offsets", "tile_order",
-                 "flatten_arena", "_n_box", "_n_isects", "_max_tile_len", "_flatten_ids", "_isect_ids", "_pending")
+                 "flatten_arena", "_n_box", "_n_isects", "_max_tile_len", "_flatten_ids", "_isect_ids", "_pending",
+                 "rebuilds", "defer")
 
     def __init__(self):
         self._pending = None
+        self.rebuilds = 0     # how many times resolve() had to rebuild the lists (arena overflow)
+        self.defer = False    # True: compositing calls do not resolve; the caller does, later, and re-issues them
 
     @property
     def pending(self) -> bool:
@@ -197,6 +200,7 @@ class _PendingCounts:
         tl._set_counts(fresh._n_box, fresh._n_isects, fresh._max_tile_len, fresh.flatten_arena, fresh._isect_ids)
         _cap_listed[key] = max(_cap_listed.get(key, 0), int(fresh._n_isects * 1.25) + 1024)
         _len_hint[key] = fresh._max_tile_len
+        tl.rebuilds += 1
         return True
 
 
@@ -306,7 +310,9 @@ class _Rasterize(torch.autograd.Function):
                                            ptr(radii), ptr(tl.tile_offsets), ptr(tl.tile_order),
                                            ptr(tl.flatten_arena), ptr(records), ptr(render), ptr(alphas),
                                            ptr(last_ids), stream()), "mobgs_raster_fwd")
-                if not tl.resolve():  # speculative lists whose arena was too small were just rebuilt: composite again
+                # speculative lists whose arena was too small get rebuilt by resolve(): composite again.  A caller that
+                # wants to enqueue more work before waiting for the counts sets tl.defer and does this itself.
+                if tl.defer or not tl.resolve():
                     break
         ctx.save_for_backward(records, bg, radii, means2d, alphas, last_ids)
         ctx.tl = tl
