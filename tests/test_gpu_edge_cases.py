@@ -93,3 +93,26 @@ def test_two_cameras_with_heavy_tiles(hip_device):
         lib.mobgs_set_heavy_tile_len(old)
     for c in range(2):
         assert torch.equal(both[0][c], singles[c][0][0]) and torch.equal(both[1][c], singles[c][1][0])
+
+
+def test_4k_image_many_tiles(hip_device):
+    """3840x2160 (32 400 tiles: more than the LDS-resident per-tile tables of some variants hold) with 200 k splats:
+    speculative and synchronous binning agree bit for bit, forward + backward finite."""
+    from mobgs_amd import rendering
+    w, h = 3840, 2160
+    s = _inputs(200_000, w, h, 9, hip_device, channels=9)
+    out = {}
+    for spec in (True, False):
+        rendering.SPECULATIVE_BINNING = spec
+        try:
+            t = {k: v.clone().requires_grad_(k in ("means", "colors")) for k, v in s.items()}
+            sp = rendering.SharedProjection(t["means"], t["quats"], t["scales"], t["opacities"], t["viewmats"],
+                                            t["Ks"], w, h)
+            img, a = sp.composite(t["colors"])
+            (img.sum() + a.sum()).backward()
+            assert bool(torch.isfinite(img).all()) and bool(torch.isfinite(t["means"].grad).all())
+            out[spec] = (img.detach().cpu(), t["means"].grad.cpu(), sp.tl.n_isects)
+        finally:
+            rendering.SPECULATIVE_BINNING = True
+    assert out[True][2] == out[False][2] and out[True][2] > 100_000
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
