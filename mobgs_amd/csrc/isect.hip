@@ -674,6 +674,92 @@ __device__ inline int radix_sort_long(const uint64_t* __restrict__ seg, int n, R
     return sh.flag ? -1 : cur;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// short lists (n <= 512): one WAVE per tile, the bitonic network in registers.
+//
+// Element i of the (virtually +inf padded) list lives in lane i / EPL, register i % EPL.  Compare-exchange steps
+// with distance < EPL stay inside a lane (register pairs); the others exchange whole registers with lane ^ (j / EPL)
+// through the cross-lane network.  No LDS, no barriers, and four tiles per 256-thread workgroup instead of four waves
+// that mostly wait at the barriers of one tile -- 53 -> ~25 us for the 5440 lists (~311 entries) of the benchmark.
+// ---------------------------------------------------------------------------------------------------
+template <int EPL>
+__device__ __forceinline__ void wave_bitonic_sort(uint64_t (&key)[EPL], int lane) {
+    constexpr int N2 = 64 * EPL;
+#pragma unroll
+    for (int k = 2; k <= N2; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            if (j >= EPL) {
+                const int d = j / EPL;                       // partner lane distance
+                const bool lower = (lane & d) == 0;           // this lane holds the lower index of each pair
+                const bool asc = k >= N2 ? true : ((lane & (k / EPL)) == 0);
+                const bool want_min = lower == asc;
+#pragma unroll
+                for (int r = 0; r < EPL; ++r) {
+                    const uint64_t other = __shfl_xor(key[r], d, 64);
+                    const bool other_less = other < key[r];
+                    key[r] = (other_less == want_min) ? other : key[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < EPL; ++r) {
+                    if ((r & j) == 0) {
+                        // direction of the k-block this pair belongs to: a register bit for k < EPL, a lane bit else
+                        const bool asc = k >= N2 ? true : (k < EPL ? ((r & k) == 0) : ((lane & (k / EPL)) == 0));
+                        const uint64_t a = key[r], b = key[r | j];
+                        const bool swap = (b < a) == asc;
+                        key[r] = swap ? b : a;
+                        key[r | j] = swap ? a : b;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int EPL>
+__device__ __forceinline__ void sort_tile_in_wave(const uint64_t* __restrict__ seg, int n, int s, uint64_t hi_bits,
+                                                  int32_t* __restrict__ flatten_ids, uint64_t* __restrict__ isect_ids,
+                                                  int lane) {
+    uint64_t key[EPL];
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {  // coalesced load; the initial arrangement is irrelevant to a sort
+        const int i = r * 64 + lane;
+        key[r] = i < n ? seg[i] : ~0ull;
+    }
+    wave_bitonic_sort<EPL>(key, lane);
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+        const int i = lane * EPL + r;
+        if (i < n) {
+            flatten_ids[s + i] = (int32_t)(uint32_t)key[r];
+            if (isect_ids) isect_ids[s + i] = hi_bits | (key[r] >> 32);
+        }
+    }
+}
+
+constexpr int WAVE_SORT_MAX = 512;
+__global__ void __launch_bounds__(256) tile_sort_wave_kernel(int n_tiles_total, int tile_bits,
+                                                               const int32_t* __restrict__ tile_offsets,
+                                                               const uint64_t* __restrict__ sort_keys,
+                                                               int32_t* __restrict__ flatten_ids,
+                                                               uint64_t* __restrict__ isect_ids, int tiles_per_cam) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tiles_total) return;
+    const int s = tile_offsets[t], n = tile_offsets[t + 1] - s;
+    if (n <= 0 || n > WAVE_SORT_MAX) return;  // longer lists: tile_sort_kernel
+    const uint64_t* seg = sort_keys + s;
+    const int cam = t / tiles_per_cam, tl = t - cam * tiles_per_cam;
+    const uint64_t hi_bits = (((uint64_t)cam << tile_bits) | (uint64_t)tl) << 32;
+    if (n <= 128)
+        sort_tile_in_wave<2>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
+    else if (n <= 256)
+        sort_tile_in_wave<4>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
+    else
+        sort_tile_in_wave<8>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
+}
+
 // tiles whose list is longer than `min_len`, in no particular order: long_ids[0 .. *long_count)
 __global__ void __launch_bounds__(256) long_lists_kernel(int nt, const int32_t* __restrict__ tile_offsets, int min_len,
                                                            int32_t* __restrict__ long_ids,
@@ -883,9 +969,13 @@ static int emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t
     const int small_cap = 4096, big_cap = 16384;
     const bool split = max_tile_len > small_cap;
     const int nmax_small = split ? small_cap : 0x7fffffff;
-    hipLaunchKernelGGL(tile_sort_kernel<256>, dim3(nt), dim3(256), small_cap * sizeof(uint64_t), st, nt, small_cap,
-                       tile_bits, tile_offsets, sort_keys, flatten_ids, isect_ids, tiles_per_cam, 0, nmax_small,
-                       (const int32_t*)nullptr, (const int32_t*)nullptr);
+    // lists <= 512: one wave per tile, in registers; (with a known longest list <= 512 nothing else is launched)
+    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3((nt + 3) / 4), dim3(256), 0, st, nt, tile_bits, tile_offsets,
+                       sort_keys, flatten_ids, isect_ids, tiles_per_cam);
+    if (stats_dev != nullptr || max_tile_len > WAVE_SORT_MAX)
+        hipLaunchKernelGGL(tile_sort_kernel<256>, dim3(nt), dim3(256), small_cap * sizeof(uint64_t), st, nt, small_cap,
+                           tile_bits, tile_offsets, sort_keys, flatten_ids, isect_ids, tiles_per_cam,
+                           WAVE_SORT_MAX + 1, nmax_small, (const int32_t*)nullptr, (const int32_t*)nullptr);
     if (split) {
         int32_t* long_ids = L.tile_count;
         int32_t* long_count = L.tickets + 1;
