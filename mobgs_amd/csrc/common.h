@@ -131,4 +131,52 @@ __device__ inline int band_mask(float mx, float my, float ca, float cb, float cc
     return m;
 }
 
+// bit q = 2 * qy + qx set <=> the splat may reach alpha >= 1/255 at a pixel centre of the 8x8 quadrant (qx, qy) of
+// the 16x16 tile (tx, ty).  Same conservative test as min_sigma_over_tile / reach_threshold, on the four quadrant
+// rectangles at once: the 4 + 4 lines carrying their edges are each solved once (optimum of the convex quadratic
+// along the line, clamped to the two segments).  Quadrants are NOT clipped to the image (only more conservative).
+__device__ inline unsigned quadrant_reach_mask(float mx, float my, float ca, float cb, float cc, float op, int tx,
+                                               int ty) {
+    const float thr = reach_threshold(op);
+    if (thr < 0.f) return 0u;
+    if (!(ca > 0.f && cc > 0.f)) return 0xFu;
+    const float x0 = (float)(tx * MOBGS_TILE) + 0.5f, y0 = (float)(ty * MOBGS_TILE) + 0.5f;
+    const float sx = cb / cc, sy = cb / ca;
+    float best[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float off = (float)((i & 1) * 7 + (i >> 1) * 8);
+        {  // vertical line px = x0 + off: an edge of the quadrants of column i >> 1
+            const float dx = mx - (x0 + off);
+            const float ystar = my + sx * dx;
+#pragma unroll
+            for (int qy = 0; qy < 2; ++qy) {
+                const float ya = y0 + (float)(8 * qy);
+                const float dy = my - fminf(fmaxf(ystar, ya), ya + 7.f);
+                const float sg = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+                best[2 * qy + (i >> 1)] = fminf(best[2 * qy + (i >> 1)], sg);
+            }
+        }
+        {  // horizontal line py = y0 + off: an edge of the quadrants of row i >> 1
+            const float dy = my - (y0 + off);
+            const float xstar = mx + sy * dy;
+#pragma unroll
+            for (int qx = 0; qx < 2; ++qx) {
+                const float xa = x0 + (float)(8 * qx);
+                const float dx = mx - fminf(fmaxf(xstar, xa), xa + 7.f);
+                const float sg = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+                best[2 * (i >> 1) + qx] = fminf(best[2 * (i >> 1) + qx], sg);
+            }
+        }
+    }
+    unsigned m = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float xa = x0 + (float)(8 * (q & 1)), ya = y0 + (float)(8 * (q >> 1));
+        const bool inside = mx >= xa && mx <= xa + 7.f && my >= ya && my <= ya + 7.f;
+        if (inside || best[q] <= thr) m |= 1u << q;
+    }
+    return m;
+}
+
 }  // namespace mobgs

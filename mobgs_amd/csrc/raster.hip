@@ -117,7 +117,7 @@ pack_records_kernel(int N, int channels, int stride, const float* __restrict__ m
 template <int CD, int NP, bool FILTER>
 __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int lane,
                                               float4 (*slab)[64][((6 + CD + 3) & ~3) / 4], int (*idx_of)[64],
-                                              ClassSel cls, int tile_w, int tile_h,
+                                              unsigned (*reach_of)[64], ClassSel cls, int tile_w, int tile_h,
                                               int width, int height, const float* __restrict__ records,
                                               const float* __restrict__ backgrounds,
                                               const int32_t* __restrict__ tile_offsets,
@@ -126,14 +126,19 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
     constexpr int PPL = NP;
-    constexpr unsigned ALL_DONE = (1u << NP) - 1u;
     const int tiles_per_cam = tile_w * tile_h;
     const int cam = tile / tiles_per_cam;
     const int tl = tile - cam * tiles_per_cam;
     const int ty = tl / tile_w, tx = tl - ty * tile_w;
     int pxi[PPL], pyi[PPL];
     float px[PPL], py[PPL];
-    unsigned done = 0;
+    // T < 0 marks a pixel that takes no more splats (transmittance exhausted, or outside the image); |T| is its
+    // transmittance.  The flag rides in the sign so that "finished" costs no register and no test of its own: a
+    // negative T makes the candidate transmittance negative, which the stop test below already rejects.
+    float T[PPL];
+    float acc[PPL][CD];
+    int last[PPL];
+    unsigned alive = 0u;  // wave-uniform: pixel slots k that still have an unfinished pixel in some lane
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
         const int qd = NP == 4 ? k : quad;
@@ -141,23 +146,16 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
         pyi[k] = ty * MOBGS_TILE + 8 * (qd >> 1) + (lane >> 3);
         px[k] = (float)pxi[k] + 0.5f;
         py[k] = (float)pyi[k] + 0.5f;
-        if (!(pxi[k] < width && pyi[k] < height)) done |= 1u << k;
-    }
-    const unsigned outside = done;
-
-    const int s = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
-    const int e = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
-
-    float T[PPL];
-    float acc[PPL][CD];
-    int last[PPL];
-#pragma unroll
-    for (int k = 0; k < PPL; ++k) {
-        T[k] = 1.f;
+        const bool inside = pxi[k] < width && pyi[k] < height;
+        T[k] = inside ? 1.f : -1.f;
         last[k] = 0;
+        if (__builtin_amdgcn_ballot_w64(inside) != 0ull) alive |= 1u << k;
 #pragma unroll
         for (int c = 0; c < CD; ++c) acc[k][c] = 0.f;
     }
+
+    const int s = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
+    const int e = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
 
     // software pipeline: the records of batch b+1 are fetched into registers while batch b is blended
     float4 pre[RQ];
@@ -173,22 +171,28 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
             for (int q = 0; q < RQ; ++q) pre[q] = r[q];
         }
     }
-    bool all_done = false;
-    for (int b = s; b < e && !all_done; b += 64) {
+    for (int b = s; b < e && alive != 0u; b += 64) {
         int n = min(64, e - b);
         wave_lds_fence();
-        if (FILTER) {  // stage only the wanted class, compacted, remembering each entry's list index
-            const unsigned long long km = __builtin_amdgcn_ballot_w64(pre_keep);
-            n = __builtin_popcountll(km);
-            if (pre_keep) {
-                const int pos = __builtin_popcountll(km & ((1ull << lane) - 1ull));
+        {
+            // which 8x8 quadrants of the tile the splat can reach at all (lane = splat: one test per entry, not per
+            // pixel): ~40 % of the (entry, quadrant) pairs of a typical list are out of reach and are never evaluated
+            unsigned reach = quadrant_reach_mask(pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, tx, ty);
+            if (NP == 1) reach = (reach >> quad) & 1u;
+            int pos = lane;
+            bool keep = true;
+            if (FILTER) {  // stage only the wanted class, compacted, remembering each entry's list index
+                const unsigned long long km = __builtin_amdgcn_ballot_w64(pre_keep);
+                n = __builtin_popcountll(km);
+                pos = __builtin_popcountll(km & ((1ull << lane) - 1ull));
+                keep = pre_keep;
+            }
+            if (keep) {
 #pragma unroll
                 for (int q = 0; q < RQ; ++q) slab[wv][pos][q] = pre[q];
-                idx_of[wv][pos] = b + lane;
+                reach_of[wv][pos] = reach;
+                if (FILTER) idx_of[wv][pos] = b + lane;
             }
-        } else {
-#pragma unroll
-            for (int q = 0; q < RQ; ++q) slab[wv][lane][q] = pre[q];
         }
         wave_lds_fence();
         pre_keep = false;
@@ -202,62 +206,47 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
             }
         }
         for (int j = 0; j < n; ++j) {
+            const unsigned todo = __builtin_amdgcn_readfirstlane(reach_of[wv][j]) & alive;
+            if (todo == 0u) continue;
             const int list_idx = FILTER ? idx_of[wv][j] : b + j;
-            const float4 r0 = slab[wv][j][0];
-            const float4 r1 = slab[wv][j][1];
-            // tests for the 4 pixels of this lane; one wave-level branch decides whether anything is blended
-            float alpha[PPL], nT[PPL];
-            bool blend[PPL];
-            bool any = false;
+            float rec[RS];
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const float4 v = slab[wv][j][q];
+                rec[4 * q] = v.x;
+                rec[4 * q + 1] = v.y;
+                rec[4 * q + 2] = v.z;
+                rec[4 * q + 3] = v.w;
+            }
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
-                const Eval ev = eval_splat(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, px[k], py[k]);
-                const bool pass = ev.pass && !((done >> k) & 1u);
-                alpha[k] = ev.alpha;
-                nT[k] = T[k] * (1.f - ev.alpha);
-                const bool stop = pass && (nT[k] <= T_STOP);
-                done |= stop ? (1u << k) : 0u;
-                blend[k] = pass && !stop;
-                any = any || blend[k];
-            }
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-                float col[RS - 6];
-                col[0] = r1.z;
-                col[1] = r1.w;
+                if (!((todo >> k) & 1u)) continue;  // wave-uniform
+                const Eval ev = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px[k], py[k]);
+                const float nT = T[k] * (1.f - ev.alpha);
+                const bool blend = ev.pass && nT > T_STOP;   // never for a finished pixel (nT < 0)
+                const bool stop = ev.pass && !(nT > T_STOP);
+                const float w = blend ? ev.alpha * T[k] : 0.f;
 #pragma unroll
-                for (int q = 2; q < RQ; ++q) {
-                    const float4 v = slab[wv][j][q];
-                    col[4 * q - 6] = v.x;
-                    col[4 * q - 5] = v.y;
-                    col[4 * q - 4] = v.z;
-                    col[4 * q - 3] = v.w;
-                }
-#pragma unroll
-                for (int k = 0; k < PPL; ++k) {
-                    const float w = blend[k] ? alpha[k] * T[k] : 0.f;
-#pragma unroll
-                    for (int c = 0; c < CD; ++c) acc[k][c] = __fmaf_rn(col[c], w, acc[k][c]);
-                    T[k] = blend[k] ? nT[k] : T[k];
-                    last[k] = blend[k] ? list_idx : last[k];
-                }
+                for (int c = 0; c < CD; ++c) acc[k][c] = __fmaf_rn(rec[6 + c], w, acc[k][c]);
+                T[k] = blend ? nT : (stop ? -fabsf(T[k]) : T[k]);
+                last[k] = blend ? list_idx : last[k];
+                if (__builtin_amdgcn_ballot_w64(T[k] > 0.f) == 0ull) alive &= ~(1u << k);
             }
-            if (__builtin_amdgcn_ballot_w64(done != ALL_DONE) == 0ull) {
-                all_done = true;
-                break;
-            }
+            if (alive == 0u) break;
         }
     }
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
-        if ((outside >> k) & 1u) continue;
+        if (!(pxi[k] < width && pyi[k] < height)) continue;
+        const float Tk = fabsf(T[k]);
         const size_t pix = ((size_t)cam * height + pyi[k]) * width + pxi[k];
-        alphas[pix] = 1.f - T[k];
+        alphas[pix] = 1.f - Tk;
         last_ids[pix] = last[k];
         float* out = render + pix * CD;
 #pragma unroll
         for (int c = 0; c < CD; ++c) {
             float v = acc[k][c];
-            if (backgrounds) v = __fmaf_rn(T[k], backgrounds[cam * CD + c], v);
+            if (backgrounds) v = __fmaf_rn(Tk, backgrounds[cam * CD + c], v);
             out[c] = v;
         }
     }
@@ -273,14 +262,15 @@ raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
     constexpr int RQ = ((6 + CD + 3) & ~3) / 4;
     __shared__ float4 slab[TILES_PER_WG][64][RQ];
     __shared__ int idx_of[FILTER ? TILES_PER_WG : 1][64];
+    __shared__ unsigned reach_of[TILES_PER_WG][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
     if (slot < 0) return;
     if (slot & SCHED_HEAVY)
-        composite_fwd<CD, 1, FILTER>(slot & ~SCHED_HEAVY, wv, wv, lane, slab, idx_of, cls, tile_w, tile_h, width, height,
+        composite_fwd<CD, 1, FILTER>(slot & ~SCHED_HEAVY, wv, wv, lane, slab, idx_of, reach_of, cls, tile_w, tile_h, width, height,
                                      records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids);
     else
-        composite_fwd<CD, 4, FILTER>(slot, 0, wv, lane, slab, idx_of, cls, tile_w, tile_h, width, height, records,
+        composite_fwd<CD, 4, FILTER>(slot, 0, wv, lane, slab, idx_of, reach_of, cls, tile_w, tile_h, width, height, records,
                                      backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids);
 }
 
@@ -332,6 +322,7 @@ struct BwdShared {
     float4 slab[TILES_PER_WG][64][RS / 4];  // the batch's splat records, one copy per wave
     int slot_of[TILES_PER_WG][64];          // gradient slot of each batch entry
     int idx_of[TILES_PER_WG][64];           // class-filtered passes: list index of each staged entry
+    unsigned reach_of[TILES_PER_WG][64];    // quadrants of the tile each staged entry can reach
     float part[TILES_PER_WG][64][RS];       // heavy tiles: per-wave (= per-quadrant) gradient records of the batch
     unsigned long long touched[TILES_PER_WG];
     int top[TILES_PER_WG];
@@ -442,17 +433,32 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
             }
             if (keep) {
                 const float4* r = reinterpret_cast<const float4*>(records + (size_t)g * RS);
-                float4 r0 = r[0];
+                const float4 r0 = r[0], r1 = r[1];
                 slab[wv][pos][0] = r0;
+                slab[wv][pos][1] = r1;
 #pragma unroll
-                for (int q = 1; q < RQ; ++q) slab[wv][pos][q] = r[q];
+                for (int q = 2; q < RQ; ++q) slab[wv][pos][q] = r[q];
+                sh.reach_of[wv][pos] = quadrant_reach_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty);
                 const TileRect tr = tile_rect(r0.x, r0.y, radii[g], tile_w, tile_h);
                 slot_of[wv][pos] = keep_index(keep_scan, cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0));
                 if (FILTER) sh.idx_of[wv][pos] = hi - lane;
             }
         }
         wave_lds_fence();
-        for (int j = 0; j < n; ++j) {
+        // per pixel slot k, the batch entries that can reach its 8x8 quadrant at all (wave-uniform bit masks):
+        // ~40 % of the (entry, quadrant) pairs of a typical list are out of reach and are never evaluated
+        unsigned long long reach[PPL];
+        {
+            const unsigned rm = lane < n ? sh.reach_of[wv][lane] : 0u;
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) reach[k] = __builtin_amdgcn_ballot_w64((rm >> (HEAVY ? quad : k)) & 1u);
+        }
+        unsigned long long rem = reach[0];
+#pragma unroll
+        for (int k = 1; k < PPL; ++k) rem |= reach[k];
+        while (rem != 0ull) {
+            const int j = __builtin_ctzll(rem);
+            rem &= rem - 1ull;
             const int idx = FILTER ? sh.idx_of[wv][j] : hi - j;
             float rec[RS];
 #pragma unroll
@@ -463,24 +469,22 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                 rec[4 * q + 2] = v.z;
                 rec[4 * q + 3] = v.w;
             }
-            Eval ev[PPL];
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < PPL; ++k) {
-                ev[k] = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px[k], py[k]);
-                ev[k].pass = ev[k].pass && (idx <= binf[k]);
-                any = any || ev[k].pass;
-            }
-            if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
             float g[NVP];
 #pragma unroll
             for (int i = 0; i < NVP; ++i) g[i] = 0.f;
+            bool contributed = false;  // wave-uniform
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
-                // one 8x8 quadrant: skipped as a whole when none of its pixels blends this splat (wave-uniform
-                // branch); otherwise every lane runs the same arithmetic with alpha = 0 standing in for "this
-                // pixel does not blend it" -- T, behind and the sums then stay exactly as they were (x * 1, + 0)
+                // one 8x8 quadrant: skipped as a whole when the splat cannot reach it or none of its pixels blends
+                // this splat (wave-uniform branches); otherwise every lane runs the same arithmetic with alpha = 0
+                // standing in for "this pixel does not blend it" -- T, behind and the sums then stay exactly as
+                // they were (x * 1, + 0)
+                if (!((reach[k] >> j) & 1ull)) continue;
+                Eval ev[PPL];
+                ev[k] = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px[k], py[k]);
+                ev[k].pass = ev[k].pass && (idx <= binf[k]);
                 if (__builtin_amdgcn_ballot_w64(ev[k].pass) == 0ull) continue;
+                contributed = true;
                 const bool pass = ev[k].pass;
                 const float alpha = pass ? ev[k].alpha : 0.f;
                 // 1 / (1 - alpha): hardware reciprocal + one Newton step (<= 1 ulp; 1 - alpha >= 1e-3)
@@ -511,6 +515,7 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                 g[5] = __fmaf_rn(ev[k].vis, v_op, g[5]);
                 behind[k] = __fmaf_rn(fac, dot, behind[k]);
             }
+            if (!contributed) continue;
             wave_reduce_components<NVP>(g);
             // lane 0 of each 16-lane row stores its NVP/4 consecutive components (64 B per record for D = 10)
             constexpr int Q = NVP / 4;
