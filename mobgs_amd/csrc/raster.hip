@@ -205,8 +205,9 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
                 for (int q = 0; q < RQ; ++q) pre[q] = r[q];
             }
         }
+        const unsigned reach_lane = reach_of[wv][lane];  // lane j: the mask of staged entry j
         for (int j = 0; j < n; ++j) {
-            const unsigned todo = __builtin_amdgcn_readfirstlane(reach_of[wv][j]) & alive;
+            const unsigned todo = (unsigned)__builtin_amdgcn_readlane((int)reach_lane, j) & alive;
             if (todo == 0u) continue;
             const int list_idx = FILTER ? idx_of[wv][j] : b + j;
             float rec[RS];
