@@ -316,6 +316,86 @@ __device__ __forceinline__ void wave_reduce_components(float (&v)[NVP]) {
     for (int i = 0; i < NVP / 4; ++i) v[i] = row_allreduce(v[i]);
 }
 
+// NVP = 16: the same two swap stages, then HALVING steps inside each 16-lane row instead of four all-reduces of
+// four registers: a DPP add written under a bank mask lets the two halves of a row keep different components, so
+// 4 registers -> 2 (row_ror:8, lanes 8-15 take the partner register) -> 1 (row_half_mirror, banks 1/3 take the
+// partner) in 6 instructions, and the last two quad_perm steps run on ONE register: 8 instead of 16 VALU.
+// Afterwards every lane holds the wave total of component lane >> 2.
+// (v_add_f32_dpp with a partial bank_mask keeps the destination in the masked-off lanes; the builtins cannot
+// express that, hence the inline assembly.  s_nop 1 on both sides: a DPP source written by the previous VALU needs
+// 2 wait states, and the compiler's hazard recogniser does not look inside the asm.)
+__device__ __forceinline__ float dpp_add_ror8_hi(float keep, float v) {  // lanes 8-15 of each row: v + v[lane ^ 8]
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\ts_nop 1" : "+v"(keep) : "v"(v));
+    return keep;
+}
+__device__ __forceinline__ float dpp_add_mirror_odd(float keep, float v) {  // banks 1, 3: v + v[half-row mirror]
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\ts_nop 1" : "+v"(keep) : "v"(v));
+    return keep;
+}
+__device__ __forceinline__ float wave_reduce16_scatter(float (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    // row r now holds components 4 r + {0, 1, 2, 3} in v[0..3]
+    float u0 = dpp_add<0x128>(v[0]);      // lanes 0-7: component 0 summed over {l, l ^ 8}
+    u0 = dpp_add_ror8_hi(u0, v[2]);       // lanes 8-15: component 2
+    float u1 = dpp_add<0x128>(v[1]);      // lanes 0-7: component 1
+    u1 = dpp_add_ror8_hi(u1, v[3]);       // lanes 8-15: component 3
+    float w = dpp_add<0x141>(u0);         // banks 0, 2: components 0, 2 over 8 lanes ...
+    w = dpp_add_mirror_odd(w, u1);        // banks 1, 3: components 1, 3
+    w = dpp_add<0xB1>(w);
+    w = dpp_add<0x4E>(w);
+    return w;
+}
+
+// One (pixel, splat) pair of the backward pass: rebuilds the transmittance in front of the splat, forms the
+// cotangent of alpha and adds the pair's share of the 6 + CD gradient components to g (FIRST: g is written, not
+// accumulated; unused -- selecting the variant per entry makes the compiler shuffle the 16 sums between two
+// register sets, which costs more than the zero fill it saves).
+// tvab = Tf * (v_alpha_out - <background, v_out>): both terms enter v_alpha as ra * Tf * (...)
+template <int CD, int RS, int NVP, bool FIRST>
+__device__ __forceinline__ void blend_bwd(const float (&rec)[RS], const Eval& ev, bool pass, float& T, float& behind,
+                                          float tvab, const float (&vo)[CD], float (&g)[NVP]) {
+    auto acc = [](float& dst, float a, float b) { dst = FIRST ? a * b : __fmaf_rn(a, b, dst); };
+    const float alpha = pass ? ev.alpha : 0.f;
+    // 1 / (1 - alpha): hardware reciprocal + one Newton step (<= 1 ulp; 1 - alpha >= 1e-3)
+    const float om = 1.f - alpha;
+    float ra = __builtin_amdgcn_rcpf(om);
+    ra = __fmaf_rn(__fmaf_rn(-om, ra, 1.f), ra, ra);
+    T *= ra;
+    const float fac = alpha * T;
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < CD; ++c) {
+        acc(g[6 + c], fac, vo[c]);
+        dot = __fmaf_rn(rec[6 + c], vo[c], dot);
+    }
+    const float v_alpha = __fmaf_rn(T, dot, ra * (tvab - behind));
+    const float ov = rec[5] * ev.vis;
+    const bool live = pass && ov <= ALPHA_MAX;  // the clamp at 0.999 has zero slope
+    const float v_sigma = live ? -ov * v_alpha : 0.f;
+    const float v_op = live ? v_alpha : 0.f;
+    const float dx = ev.dx, dy = ev.dy;
+    acc(g[0], v_sigma, rec[2] * dx + rec[3] * dy);
+    acc(g[1], v_sigma, rec[3] * dx + rec[4] * dy);
+    acc(g[2], 0.5f * v_sigma * dx, dx);
+    acc(g[3], v_sigma * dx, dy);
+    acc(g[4], 0.5f * v_sigma * dy, dy);
+    acc(g[5], ev.vis, v_op);
+    if (FIRST) {
+#pragma unroll
+        for (int i = 6 + CD; i < NVP; ++i) g[i] = 0.f;
+    }
+    behind = __fmaf_rn(fac, dot, behind);
+}
+
 // LDS of one workgroup of the backward kernel
 template <int CD>
 struct BwdShared {
@@ -367,7 +447,7 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
     // behind[k] = sum over the splats BEHIND the current one of fac * <colour, v_out>: upstream keeps the
     // per-channel sums buffer[c] and forms sum_c (colour_c T - buffer_c ra) v_out_c; distributing v_out gives
     // T <colour, v_out> - ra * behind, one scalar per pixel instead of D (fewer registers, D fewer FMAs per pair)
-    float px[PPL], py[PPL], T[PPL], Tf[PPL], va[PPL], bgdot[PPL], behind[PPL];
+    float px[PPL], py[PPL], T[PPL], Tf[PPL], va[PPL], bgdot[PPL], behind[PPL], tvab[PPL];
     float vo[PPL][CD];
     int binf[PPL];
     int top = -1;
@@ -408,6 +488,7 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
             top = max(top, binf[k]);
         }
         T[k] = Tf[k];
+        tvab[k] = Tf[k] * (va[k] - bgdot[k]);
     }
     // highest list index any pixel of the tile blended
 #pragma unroll
@@ -481,47 +562,27 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                 // standing in for "this pixel does not blend it" -- T, behind and the sums then stay exactly as
                 // they were (x * 1, + 0)
                 if (!((reach[k] >> j) & 1ull)) continue;
-                Eval ev[PPL];
-                ev[k] = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px[k], py[k]);
-                ev[k].pass = ev[k].pass && (idx <= binf[k]);
-                if (__builtin_amdgcn_ballot_w64(ev[k].pass) == 0ull) continue;
+                Eval ev = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px[k], py[k]);
+                const bool pass = ev.pass && (idx <= binf[k]);
+                if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
+                blend_bwd<CD, RS, NVP, false>(rec, ev, pass, T[k], behind[k], tvab[k], vo[k], g);
                 contributed = true;
-                const bool pass = ev[k].pass;
-                const float alpha = pass ? ev[k].alpha : 0.f;
-                // 1 / (1 - alpha): hardware reciprocal + one Newton step (<= 1 ulp; 1 - alpha >= 1e-3)
-                const float om = 1.f - alpha;
-                float ra = __builtin_amdgcn_rcpf(om);
-                ra = __fmaf_rn(__fmaf_rn(-om, ra, 1.f), ra, ra);
-                T[k] *= ra;
-                const float fac = alpha * T[k];
-                float dot = 0.f;
-#pragma unroll
-                for (int c = 0; c < CD; ++c) {
-                    g[6 + c] = __fmaf_rn(fac, vo[k][c], g[6 + c]);
-                    dot = __fmaf_rn(rec[6 + c], vo[k][c], dot);
-                }
-                float v_alpha = __fmaf_rn(T[k], dot, -ra * behind[k]);
-                v_alpha += Tf[k] * ra * va[k];
-                if (backgrounds) v_alpha -= Tf[k] * ra * bgdot[k];
-                const float ov = rec[5] * ev[k].vis;
-                const bool live = pass && ov <= ALPHA_MAX;  // the clamp at 0.999 has zero slope
-                const float v_sigma = live ? -ov * v_alpha : 0.f;
-                const float v_op = live ? v_alpha : 0.f;
-                const float dx = ev[k].dx, dy = ev[k].dy;
-                g[0] = __fmaf_rn(v_sigma, rec[2] * dx + rec[3] * dy, g[0]);
-                g[1] = __fmaf_rn(v_sigma, rec[3] * dx + rec[4] * dy, g[1]);
-                g[2] = __fmaf_rn(0.5f * v_sigma * dx, dx, g[2]);
-                g[3] = __fmaf_rn(v_sigma * dx, dy, g[3]);
-                g[4] = __fmaf_rn(0.5f * v_sigma * dy, dy, g[4]);
-                g[5] = __fmaf_rn(ev[k].vis, v_op, g[5]);
-                behind[k] = __fmaf_rn(fac, dot, behind[k]);
             }
             if (!contributed) continue;
+            if (HEAVY) touched |= 1ull << j;
+            if constexpr (NVP == 16) {
+                // every lane ends up with the total of component lane >> 2: one 64-byte store from 16 lanes
+                const float w = wave_reduce16_scatter(g);
+                if ((lane & 3) == 0 && (lane >> 2) < RS) {
+                    float* dst = HEAVY ? &sh.part[wv][j][0] : grad_slots + (size_t)slot_of[wv][j] * RS;
+                    dst[lane >> 2] = w;
+                }
+                continue;
+            }
             wave_reduce_components<NVP>(g);
-            // lane 0 of each 16-lane row stores its NVP/4 consecutive components (64 B per record for D = 10)
+            // lane 0 of each 16-lane row stores its NVP/4 consecutive components
             constexpr int Q = NVP / 4;
             const int base = (lane >> 5) * (NVP / 2) + ((lane >> 4) & 1) * Q;
-            if (HEAVY) touched |= 1ull << j;
             if ((lane & 15) == 0 && base < RS) {
                 float* dst = HEAVY ? &sh.part[wv][j][base] : grad_slots + (size_t)slot_of[wv][j] * RS + base;
                 if constexpr (Q == 2) {
