@@ -333,16 +333,33 @@ __device__ __forceinline__ float dpp_add_mirror_odd(float keep, float v) {  // b
     return keep;
 }
 __device__ __forceinline__ float wave_reduce16_scatter(float (&v)[16]) {
+    // the swaps exchange register halves IN PLACE; through the builtin the compiler copies one operand of every
+    // swap first (7 v_mov + a 2-cycle bubble each), in assembly the sixteen sums are simply consumed where they lie
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %8\n\t"
+        "v_permlane32_swap_b32 %1, %9\n\t"
+        "v_permlane32_swap_b32 %2, %10\n\t"
+        "v_permlane32_swap_b32 %3, %11\n\t"
+        "v_permlane32_swap_b32 %4, %12\n\t"
+        "v_permlane32_swap_b32 %5, %13\n\t"
+        "v_permlane32_swap_b32 %6, %14\n\t"
+        "v_permlane32_swap_b32 %7, %15\n\t"
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+          "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
+    for (int i = 0; i < 8; ++i) v[i] += v[i + 8];
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %4\n\t"
+        "v_permlane16_swap_b32 %1, %5\n\t"
+        "v_permlane16_swap_b32 %2, %6\n\t"
+        "v_permlane16_swap_b32 %3, %7\n\t"
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
+    for (int i = 0; i < 4; ++i) v[i] += v[i + 4];
     // row r now holds components 4 r + {0, 1, 2, 3} in v[0..3]
     float u0 = dpp_add<0x128>(v[0]);      // lanes 0-7: component 0 summed over {l, l ^ 8}
     u0 = dpp_add_ror8_hi(u0, v[2]);       // lanes 8-15: component 2
