@@ -11,7 +11,8 @@ import subprocess
 from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
-LIB_PATH = CSRC / "libmobgs_hip.so"
+# MOBGS_LIB: load another build of the same library instead (A/B timing of kernel variants on one GPU box)
+LIB_PATH = Path(os.environ["MOBGS_LIB"]).resolve() if os.environ.get("MOBGS_LIB") else CSRC / "libmobgs_hip.so"
 SOURCES = ["project.hip", "isect.hip", "raster.hip", "raster_layers.hip", "pipeline.hip", "prep.hip", "decoder.hip", "deform.hip", "loss.hip", "densify.hip", "normals.hip"]
 ARCH = "gfx950"
 # Per-file extra flags.  -fno-slp-vectorize: the SLP vectoriser pairs independent fp32 FMAs into v_pk_fma_f32,
@@ -36,6 +37,8 @@ def sources() -> list[Path]:
 
 
 def is_stale() -> bool:
+    if os.environ.get("MOBGS_LIB"):
+        return False
     if not LIB_PATH.exists():
         return True
     t = LIB_PATH.stat().st_mtime
