@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
                                                                     int32_t* __restrict__ tile_order,
                                                                     int64_t capacity_box, int64_t capacity_listed,
                                                                     int32_t* __restrict__ keep_scan, int n_chunks,
-                                                                    int heavy_len) {
+                                                                    int heavy_len, int64_t* stats_mirror) {
     __shared__ int smax[TSCAN_THREADS / 64];
     __shared__ int hist[ORDER_BUCKETS];
     // workgroup 1: chunk totals -> chunk bases of keep_scan (bin_kernel left each chunk's total in its base
@@ -360,6 +360,14 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
     if (threadIdx.x == 0) {
         tile_offsets[nt] = carry;
         stats[2] = (int64_t)longest;
+        // the host's copy of {I_box, I_listed, longest list}: written straight into its pinned, device-mapped slot
+        // (visible to the host once the event recorded behind this kernel has completed) -- no copy kernel
+        if (stats_mirror) {
+            stats_mirror[0] = stats[0];
+            stats_mirror[1] = (int64_t)carry;
+            stats_mirror[2] = (int64_t)longest;
+            __threadfence_system();
+        }
     }
     // Arena too small (only checked when the caller runs ahead of the read-back, capacity_listed > 0): hand every
     // consumer EMPTY lists, so that kernels already enqueued behind this one touch nothing; stats keep the true
@@ -898,6 +906,27 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
                         const float* conics, const float* opacities, int opac_per_camera, int32_t* cum_tiles,
                         int32_t* keep_scan, int32_t* tile_offsets, int32_t* tile_order, int64_t capacity_listed,
                         int64_t* stats, void* scratch, void* stream) {
+    return mobgs::isect_offsets_launch(C, N, tile_w, tile_h, width, height, cull, capacity, tiles_per_gauss, means2d, radii,
+                                       conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order,
+                                       capacity_listed, stats, scratch, /*scratch_zeroed=*/false, /*stats_mirror=*/nullptr,
+                                       stream);
+}
+
+}  // extern "C"
+
+void mobgs::isect_zeroed_region(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity, int32_t** ptr,
+                                size_t* count) {
+    const IsectScratch L(scratch, n_gauss, n_tiles, capacity);
+    *ptr = L.tile_count;
+    *count = L.zeroed_ints;
+}
+
+int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
+                                const int32_t* tiles_per_gauss, const float* means2d, const int32_t* radii,
+                                const float* conics, const float* opacities, int opac_per_camera, int32_t* cum_tiles,
+                                int32_t* keep_scan, int32_t* tile_offsets, int32_t* tile_order, int64_t capacity_listed,
+                                int64_t* stats, void* scratch, bool scratch_zeroed, int64_t* stats_mirror,
+                                void* stream) {
     const long long ng = (long long)C * N;
     const long long nt = (long long)C * tile_w * tile_h;
     if (C <= 0 || N < 0 || capacity < 1 || ng >= (1ll << 31) - 1 || nt >= (1ll << 31) - 1) {
@@ -911,13 +940,15 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
     hipStream_t st = (hipStream_t)stream;
     const int n = (int)ng;
     const IsectScratch L(scratch, (size_t)n, (size_t)nt, (size_t)capacity);
-    hipMemsetAsync(L.tile_count, 0, sizeof(int32_t) * L.zeroed_ints, st);  // tile counters, tickets, status words
+    if (!scratch_zeroed || n == 0)
+        hipMemsetAsync(L.tile_count, 0, sizeof(int32_t) * L.zeroed_ints, st);  // tile counters, tickets, status words
     if (n == 0) {
         hipMemsetAsync(cum_tiles, 0, sizeof(int32_t), st);
         hipMemsetAsync(keep_scan, 0, 2 * sizeof(int32_t), st);  // base and first local of chunk 0
         hipMemsetAsync(stats, 0, 3 * sizeof(int64_t), st);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
-                           stats, tile_order, (int64_t)capacity, (int64_t)0, (int32_t*)nullptr, 0, g_heavy_len);
+                           stats, tile_order, (int64_t)capacity, (int64_t)0, (int32_t*)nullptr, 0, g_heavy_len,
+                           stats_mirror);
         return check_launch("isect_offsets(empty)");
     }
     // bounding-box counts -> cum_tiles; stats[0] = I_box
@@ -937,9 +968,12 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
                            height, cull, capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera,
                            L.flags, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
-                       stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, g_heavy_len);
+                       stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, g_heavy_len,
+                       stats_mirror);
     return check_launch("isect_offsets");
 }
+
+extern "C" {
 
 // shared by the synchronous entry point (stats_dev = NULL: the caller has read the counts) and the speculative one
 static int emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t n_isects, int64_t max_tile_len,

@@ -68,18 +68,33 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
         set_error("mobgs_project_and_bin_speculative: stats_host_pinned and capacity_listed are required");
         return MOBGS_E_INVALID;
     }
-    int rc = mobgs_project_fwd(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
-                               radius_clip, radii, means2d, depths, conics, tiles_per_gauss, stream);
+    // two launches fewer on the critical path: project_fwd clears the binning counters on the way, and tile_scan
+    // writes the host's copy of the counts itself when the pinned slot is mapped into the device address space
+    int32_t* zero_ptr = nullptr;
+    size_t zero_n = 0;
+    const long long n_all = (long long)C * N, nt_all = (long long)C * tile_w * tile_h;
+    const bool fuse_zero = N > 0 && capacity_box >= 1 && n_all < (1ll << 31) - 1 && nt_all < (1ll << 31) - 1 &&
+                           ((uintptr_t)scratch & 7) == 0;
+    if (fuse_zero) mobgs::isect_zeroed_region(scratch, (size_t)n_all, (size_t)nt_all, (size_t)capacity_box, &zero_ptr, &zero_n);
+    int rc = mobgs::project_fwd_launch(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                                       radius_clip, radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, zero_n, stream);
     if (rc != MOBGS_OK) return rc;
     mobgs_hint_longest_list((int)(max_tile_len_hint > 0x7fffffff ? 0x7fffffff : max_tile_len_hint));
-    rc = mobgs_isect_offsets(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d, radii,
-                             conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order,
-                             capacity_listed, stats_dev, scratch, stream);
+    void* mirror = nullptr;
+    if (hipHostGetDevicePointer(&mirror, stats_host_pinned, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        mirror = nullptr;
+    }
+    rc = mobgs::isect_offsets_launch(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d, radii,
+                                     conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order,
+                                     capacity_listed, stats_dev, scratch, fuse_zero, (int64_t*)mirror, stream);
     if (rc != MOBGS_OK) return rc;
-    hipError_t e = hipMemcpyAsync(stats_host_pinned, stats_dev, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) {
-        set_error("mobgs_project_and_bin_speculative: statistics copy failed: %s", hipGetErrorString(e));
-        return MOBGS_E_LAUNCH;
+    if (!mirror) {
+        hipError_t e = hipMemcpyAsync(stats_host_pinned, stats_dev, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) {
+            set_error("mobgs_project_and_bin_speculative: statistics copy failed: %s", hipGetErrorString(e));
+            return MOBGS_E_LAUNCH;
+        }
     }
     return mobgs_isect_emit_sort_speculative(C, N, tile_w, tile_h, capacity_box, capacity_listed, max_tile_len_hint,
                                              depths, cum_tiles, tile_offsets, stats_dev, scratch, sort_keys,

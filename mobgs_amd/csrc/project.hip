@@ -119,9 +119,13 @@ project_fwd_kernel(int N, const float* __restrict__ means, const float* __restri
                    const float* __restrict__ Ks, int width, int height, float eps2d, float near_plane,
                    float far_plane, float radius_clip, int tile_w, int tile_h,
                    int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
-                   float* __restrict__ conics, int32_t* __restrict__ tiles_per_gauss) {
+                   float* __restrict__ conics, int32_t* __restrict__ tiles_per_gauss, int32_t* __restrict__ zero_ptr,
+                   unsigned zero_n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
+    // side job for the orchestrator: clear the binning counters (saves a memset launch on the critical path)
+    if (zero_ptr && c == 0)
+        for (unsigned z = (unsigned)i; z < zero_n; z += gridDim.x * blockDim.x) zero_ptr[z] = 0;
     if (i >= N) return;
     const Cam cam = load_cam(viewmats, Ks, c);
     const size_t o = (size_t)c * N + i;
@@ -441,18 +445,34 @@ int mobgs_project_fwd(int C, int N, const float* means, const float* quats, cons
                       const float* viewmats, const float* Ks, int width, int height, float eps2d,
                       float near_plane, float far_plane, float radius_clip, int32_t* radii, float* means2d,
                       float* depths, float* conics, int32_t* tiles_per_gauss, void* stream) {
+    return mobgs::project_fwd_launch(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                                     radius_clip, radii, means2d, depths, conics, tiles_per_gauss, nullptr, 0, stream);
+}
+
+}  // extern "C"
+
+int mobgs::project_fwd_launch(int C, int N, const float* means, const float* quats, const float* scales,
+                              const float* viewmats, const float* Ks, int width, int height, float eps2d,
+                              float near_plane, float far_plane, float radius_clip, int32_t* radii, float* means2d,
+                              float* depths, float* conics, int32_t* tiles_per_gauss, int32_t* zero_ptr, size_t zero_n,
+                              void* stream) {
     if (C <= 0 || N < 0 || width <= 0 || height <= 0) {
         set_error("mobgs_project_fwd: bad sizes C=%d N=%d W=%d H=%d", C, N, width, height);
         return MOBGS_E_INVALID;
     }
-    if (N == 0) return MOBGS_OK;
+    if (N == 0) {
+        if (zero_ptr && zero_n) hipMemsetAsync(zero_ptr, 0, sizeof(int32_t) * zero_n, (hipStream_t)stream);
+        return MOBGS_OK;
+    }
     const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
     dim3 grid((N + 255) / 256, C);
     hipLaunchKernelGGL(project_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, means, quats, scales,
                        viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip, tile_w, tile_h,
-                       radii, means2d, depths, conics, tiles_per_gauss);
+                       radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, (unsigned)zero_n);
     return check_launch("project_fwd_kernel");
 }
+
+extern "C" {
 
 size_t mobgs_project_bwd_scratch_floats(int C, int N) { return (size_t)C * ((N + 255) / 256) * 16; }
 

@@ -16,6 +16,8 @@ exactly as the reference ignores them.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from .. import rendering as _R
@@ -169,6 +171,22 @@ def interpolate_cubic_hermite(signal, times, N):
     return means * 1e2
 
 
+def _keep_grad(t: torch.Tensor) -> None:
+    """`viewspace_points.retain_grad()` of the reference (gaussian_renderer/__init__.py:121-124) without the copy:
+    retain_grad() clones the incoming gradient (2.4 MB device copy per render); the hook keeps a reference to the
+    gradient tensor itself, which nothing downstream writes to."""
+    if not t.requires_grad:
+        return
+    ref = weakref.ref(t)
+
+    def hook(g):
+        target = ref()
+        if target is not None:
+            target.grad = g
+
+    t.register_hook(hook)
+
+
 def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1.0, override_color=None,
            stage="fine", cam_type=None, is_static=False, over_t=None, over_vde=None, get_static=False,
            get_dynamic=False, stat_stat=True, ref_wc=None, iter_fact=1, flow=None, coherent=None, target_ts=None,
@@ -235,10 +253,7 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
         rendered, depth = decode_ed(img, alphas)
     info = sp.meta()
     radii = info["radii"].squeeze(0)
-    try:
-        info["means2d"].retain_grad()
-    except Exception:  # noqa: BLE001  (no grad mode)
-        pass
+    _keep_grad(info["means2d"])
     out["render"] = rendered
     out["depth"] = depth.unsqueeze(0)
     if get_dynamic:

@@ -31,7 +31,7 @@ def step():
 for _ in range(5):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step()
     torch.cuda.synchronize()
 evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("aten::")]
@@ -43,3 +43,6 @@ for e in evs:
         seen.append((e.name, list(e.input_shapes) if e.input_shapes else "", ks))
 for s in seen:
     print(s)
+for e in evs:
+    if e.name in ("aten::copy_", "aten::fill_") and e.kernels:
+        print(e.name, e.input_shapes, "\n   ", "\n    ".join(e.stack[:12]))
