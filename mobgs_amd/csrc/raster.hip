@@ -705,6 +705,62 @@ slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, const i
         v_extra[g] = acc;
 }
 
+// 64-byte records (stride 16, the render() configuration): 16 lanes per splat, every lane loads 16 BYTES -- lane
+// quarter q = lane & 3 of slot k + ((lane >> 2) & 3) -- so one load instruction of a group covers four slots (four
+// times the bytes in flight of the one-float-per-lane version: the kernel is latency-bound), two slots-of-four in
+// flight per lane; the four partial sums per component are combined with two DPP adds (row_ror 4, 8).
+// Fixed association order -> deterministic.
+__global__ void __launch_bounds__(256)
+slot_reduce16_kernel(int n_gauss, int channels, int has_extra, const int32_t* __restrict__ cum_tiles,
+                     const int32_t* __restrict__ keep_scan, const float* __restrict__ grad_slots,
+                     float* __restrict__ v_means2d, float* __restrict__ v_conics, float* __restrict__ v_opacities,
+                     float* __restrict__ v_colors, float* __restrict__ v_extra) {
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l16 = threadIdx.x & 15;
+    const int q = l16 & 3, sub = l16 >> 2;
+    const bool live = gid < n_gauss;
+    int a = 0, b = 0;
+    if (live) {
+        a = keep_index(keep_scan, cum_tiles[gid]);
+        b = keep_index(keep_scan, cum_tiles[gid + 1]);
+    }
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    const float4* p = reinterpret_cast<const float4*>(grad_slots) + q;
+    int k = a + sub;
+    for (; k + 4 < b; k += 8) {
+        const float4 u = p[(size_t)k * 4], v = p[(size_t)(k + 4) * 4];
+        s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+    }
+    if (k < b) {
+        const float4 u = p[(size_t)k * 4];
+        s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+    }
+    float acc[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // sum over the four sub-groups (lanes l, l^4, l^8, l^12 of the 16-lane row)
+        acc[i] = dpp_add<0x124>(acc[i]);  // row_ror:4
+        acc[i] = dpp_add<0x128>(acc[i]);  // row_ror:8
+    }
+    if (!live || sub != 0) return;
+    const size_t g = (size_t)gid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int comp = 4 * q + i;
+        const float v = acc[i];
+        if (comp < 2)
+            v_means2d[2 * g + comp] = v;
+        else if (comp < 5)
+            v_conics[3 * g + (comp - 2)] = v;
+        else if (comp == 5)
+            v_opacities[g] = v;
+        else if (comp - 6 < channels)
+            v_colors[g * channels + (comp - 6)] = v;
+        else if (has_extra && comp - 6 == channels)
+            v_extra[g] = v;
+    }
+}
+
 // supported total channel counts (compile-time accumulators); other counts are zero-padded by the host wrapper
 template <typename F>
 inline int dispatch_channels(int D, F&& f) {
@@ -870,6 +926,10 @@ int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int
             hipLaunchKernelGGL(slot_reduce_kernel<8>, dim3((n * 8 + 255) / 256), dim3(256), 0, st, n, channels,
                                has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities, v_colors,
                                v_extra);
+        } else if (stride == 16) {
+            hipLaunchKernelGGL(slot_reduce16_kernel, dim3((int)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, n,
+                               channels, has_extra, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
+                               v_colors, v_extra);
         } else if (stride <= 16) {
             hipLaunchKernelGGL(slot_reduce_kernel<16>, dim3((int)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
