@@ -550,7 +550,7 @@ __device__ inline void bitonic_sort_global(uint64_t* a, int n, int nthreads) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// long lists (4096 < n <= 16384): stable LSD radix sort on the depth bits, 8 bits per pass, 1024 threads, all in LDS.
+// long lists (2048 < n <= 16384): stable LSD radix sort on the depth bits, 8 bits per pass, 1024 threads, all in LDS.
 //
 // A bitonic network needs log2(n)^2 / 2 ~ 100 dependent steps for 16 k keys (169 us measured for one 15 k-entry
 // list -- the critical path of the whole launch); a radix sort needs one pass per depth byte that actually varies.
@@ -747,25 +747,72 @@ __device__ __forceinline__ void sort_tile_in_wave(const uint64_t* __restrict__ s
 }
 
 constexpr int WAVE_SORT_MAX = 512;
-__global__ void __launch_bounds__(256) tile_sort_wave_kernel(int n_tiles_total, int tile_bits,
-                                                               const int32_t* __restrict__ tile_offsets,
-                                                               const uint64_t* __restrict__ sort_keys,
-                                                               int32_t* __restrict__ flatten_ids,
-                                                               uint64_t* __restrict__ isect_ids, int tiles_per_cam) {
+constexpr int SHORT_SORT_LDS_KEYS = 2048;  // 16 KiB: longer lists belong to the long-list launch (or sort in global memory)
+
+// A workgroup sorts one list of any length: bitonic network in LDS when it fits, in place in global memory else.
+template <int THREADS>
+__device__ __forceinline__ void sort_tile_by_block(uint64_t* lds_keys, int lds_cap, uint64_t* seg, int n, int s,
+                                                   uint64_t hi_bits, int32_t* __restrict__ flatten_ids,
+                                                   uint64_t* __restrict__ isect_ids) {
+    if (n <= lds_cap) {
+        for (int i = threadIdx.x; i < n; i += THREADS) lds_keys[i] = seg[i];
+        __syncthreads();
+        if (n > 1) bitonic_sort_lds<THREADS>(lds_keys, n);
+        for (int i = threadIdx.x; i < n; i += THREADS) {
+            const uint64_t k = lds_keys[i];
+            flatten_ids[s + i] = (int32_t)(uint32_t)k;
+            if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+        }
+    } else {
+        // pathological tile: sort in place in global memory (same workgroup, barrier-ordered)
+        bitonic_sort_global(seg, n, THREADS);
+        for (int i = threadIdx.x; i < n; i += THREADS) {
+            const uint64_t k = seg[i];
+            flatten_ids[s + i] = (int32_t)(uint32_t)k;
+            if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+        }
+    }
+}
+
+// All lists of up to n_max entries in ONE launch: four tiles per workgroup; each wave sorts its tile in registers
+// when the list has <= 512 entries (nearly all of them), and the workgroup then takes the longer ones among its four
+// tiles together, one after the other (LDS network).
+__global__ void __launch_bounds__(256) tile_sort_short_kernel(int n_tiles_total, int tile_bits,
+                                                                const int32_t* __restrict__ tile_offsets,
+                                                                uint64_t* __restrict__ sort_keys,
+                                                                int32_t* __restrict__ flatten_ids,
+                                                                uint64_t* __restrict__ isect_ids, int tiles_per_cam,
+                                                                int n_max) {
+    __shared__ __attribute__((aligned(16))) uint64_t lds_keys[SHORT_SORT_LDS_KEYS];
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= n_tiles_total) return;
-    const int s = tile_offsets[t], n = tile_offsets[t + 1] - s;
-    if (n <= 0 || n > WAVE_SORT_MAX) return;  // longer lists: tile_sort_kernel
-    const uint64_t* seg = sort_keys + s;
-    const int cam = t / tiles_per_cam, tl = t - cam * tiles_per_cam;
-    const uint64_t hi_bits = (((uint64_t)cam << tile_bits) | (uint64_t)tl) << 32;
-    if (n <= 128)
-        sort_tile_in_wave<2>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
-    else if (n <= 256)
-        sort_tile_in_wave<4>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
-    else
-        sort_tile_in_wave<8>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
+    int s = 0, n = 0;
+    if (t < n_tiles_total) {
+        s = tile_offsets[t];
+        n = tile_offsets[t + 1] - s;
+    }
+    if (n > 0 && n <= WAVE_SORT_MAX) {
+        const uint64_t* seg = sort_keys + s;
+        const int cam = t / tiles_per_cam, tl = t - cam * tiles_per_cam;
+        const uint64_t hi_bits = (((uint64_t)cam << tile_bits) | (uint64_t)tl) << 32;
+        if (n <= 128)
+            sort_tile_in_wave<2>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
+        else if (n <= 256)
+            sort_tile_in_wave<4>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
+        else
+            sort_tile_in_wave<8>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
+    }
+    if (!__syncthreads_or(n > WAVE_SORT_MAX && n <= n_max)) return;
+    for (int w = 0; w < 4; ++w) {
+        const int t2 = blockIdx.x * 4 + w;
+        if (t2 >= n_tiles_total) break;
+        const int s2 = tile_offsets[t2], n2 = tile_offsets[t2 + 1] - s2;
+        if (n2 <= WAVE_SORT_MAX || n2 > n_max) continue;
+        const int cam = t2 / tiles_per_cam, tl = t2 - cam * tiles_per_cam;
+        const uint64_t hi_bits = (((uint64_t)cam << tile_bits) | (uint64_t)tl) << 32;
+        sort_tile_by_block<256>(lds_keys, SHORT_SORT_LDS_KEYS, sort_keys + s2, n2, s2, hi_bits, flatten_ids, isect_ids);
+        __syncthreads();  // lds_keys is reused
+    }
 }
 
 // tiles whose list is longer than `min_len`, in no particular order: long_ids[0 .. *long_count)
@@ -996,20 +1043,16 @@ static int emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t
     // gsplat: tile_n_bits = floor(log2(n_tiles)) + 1
     int tile_bits = 0;
     while ((1ll << tile_bits) <= (long long)tiles_per_cam) ++tile_bits;
-    // lists <= 4096: 256 threads, 32 KiB LDS, one workgroup per tile.  Longer ones (if any are expected): 1024
-    // threads, 128 KiB of the 160 KiB LDS (<= 16384 keys; beyond that in place in global memory), in a separate
-    // launch over a compacted list of those tiles, so that the short lists keep their occupancy.  The per-tile
-    // counters of pass A (dead since tile_scan) hold that list, a zeroed ticket word its length.
-    const int small_cap = 4096, big_cap = 16384;
+    // lists <= 2048 (all of them unless longer ones are expected): ONE launch, four tiles per workgroup, a wave per
+    // list of <= 512 entries (registers), the workgroup for the few longer ones (16 KiB LDS).  Longer lists, when the
+    // previous frame had any: 1024 threads, 128 KiB of the 160 KiB LDS (<= 16384 keys; beyond that in place in global
+    // memory), in a separate launch over a compacted list of those tiles, so that the short lists keep their
+    // occupancy.  The per-tile counters of pass A (dead since tile_scan) hold that list, a zeroed ticket word its length.
+    const int small_cap = SHORT_SORT_LDS_KEYS, big_cap = 16384;
     const bool split = max_tile_len > small_cap;
     const int nmax_small = split ? small_cap : 0x7fffffff;
-    // lists <= 512: one wave per tile, in registers; (with a known longest list <= 512 nothing else is launched)
-    hipLaunchKernelGGL(tile_sort_wave_kernel, dim3((nt + 3) / 4), dim3(256), 0, st, nt, tile_bits, tile_offsets,
-                       sort_keys, flatten_ids, isect_ids, tiles_per_cam);
-    if (stats_dev != nullptr || max_tile_len > WAVE_SORT_MAX)
-        hipLaunchKernelGGL(tile_sort_kernel<256>, dim3(nt), dim3(256), small_cap * sizeof(uint64_t), st, nt, small_cap,
-                           tile_bits, tile_offsets, sort_keys, flatten_ids, isect_ids, tiles_per_cam,
-                           WAVE_SORT_MAX + 1, nmax_small, (const int32_t*)nullptr, (const int32_t*)nullptr);
+    hipLaunchKernelGGL(tile_sort_short_kernel, dim3((nt + 3) / 4), dim3(256), 0, st, nt, tile_bits, tile_offsets,
+                       sort_keys, flatten_ids, isect_ids, tiles_per_cam, nmax_small);
     if (split) {
         int32_t* long_ids = L.tile_count;
         int32_t* long_count = L.tickets + 1;
