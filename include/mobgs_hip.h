@@ -19,8 +19,9 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in _host;
  *   - the caller owns every buffer (outputs and scratch); the library never allocates device memory; its only
- *     mutable state is the thread-local last-error string and two process-wide scheduling hints
- *     (mobgs_set_heavy_tile_len, mobgs_hint_longest_list) that change how work is distributed, never a result;
+ *     mutable state is the thread-local last-error string, two process-wide scheduling hints
+ *     (mobgs_set_heavy_tile_len, mobgs_hint_longest_list) and one testing switch (mobgs_set_quadrant_culling) that
+ *     change how work is distributed or skipped, never a result;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises, except
  *     mobgs_project_and_bin (one documented read-back);
  *   - return value: 0 on success, negative MOBGS_E_* on failure (mobgs_last_error() gives the text);
@@ -112,6 +113,10 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
 size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity);
 size_t mobgs_tile_order_len(int n_tiles);  /* int32 entries of tile_order */
 void mobgs_set_heavy_tile_len(int len);    /* scheduling policy, default 1024; 0 = never split a tile */
+/* Testing aid, default on: the compositors skip, per list entry, the 8x8 quadrants of the tile the splat cannot
+ * reach (work that is predicated off at every pixel); 0 evaluates everything -- results are identical. */
+void mobgs_set_quadrant_culling(int on);
+int mobgs_get_quadrant_culling(void);
 void mobgs_hint_longest_list(int len);     /* longest list expected (e.g. last frame's): >= 2048 makes the next
                                               mobgs_isect_offsets rank through LDS first (dense image regions) */
 int mobgs_get_heavy_tile_len(void);

@@ -30,6 +30,8 @@ _SIGS = {
     "mobgs_keep_scan_len": (c_size_t, [c_int]),
     "mobgs_tile_order_len": (c_size_t, [c_int]),
     "mobgs_set_heavy_tile_len": (None, [c_int]),
+    "mobgs_set_quadrant_culling": (None, [c_int]),
+    "mobgs_get_quadrant_culling": (c_int, []),
     "mobgs_get_heavy_tile_len": (c_int, []),
     "mobgs_hint_longest_list": (None, [c_int]),
     "mobgs_isect_offsets": (c_int, [c_int] * 8 + [P] * 5 + [c_int] + [P] * 4 + [c_int64] + [P] * 2 + [P]),

@@ -55,6 +55,7 @@ __device__ inline void wave_lds_fence() {
 // class test per batch, not a trip through the blend loop.
 struct ClassSel {
     int sel, N, Ns;
+    int all_reach;  // testing aid (mobgs_set_quadrant_culling(0)): treat every quadrant as reachable
     __device__ __forceinline__ bool keeps(int flat_id) const { return sel == 0 || (((flat_id % N) < Ns) == (sel == 1)); }
 };
 
@@ -177,7 +178,9 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
         {
             // which 8x8 quadrants of the tile the splat can reach at all (lane = splat: one test per entry, not per
             // pixel): ~40 % of the (entry, quadrant) pairs of a typical list are out of reach and are never evaluated
-            unsigned reach = quadrant_reach_mask(pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, tx, ty);
+            unsigned reach = cls.all_reach ? 0xFu
+                                           : quadrant_reach_mask(pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x,
+                                                                 pre[1].y, tx, ty);
             if (NP == 1) reach = (reach >> quad) & 1u;
             int pos = lane;
             bool keep = true;
@@ -537,7 +540,8 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                 slab[wv][pos][1] = r1;
 #pragma unroll
                 for (int q = 2; q < RQ; ++q) slab[wv][pos][q] = r[q];
-                sh.reach_of[wv][pos] = quadrant_reach_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty);
+                sh.reach_of[wv][pos] =
+                    cls.all_reach ? 0xFu : quadrant_reach_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty);
                 const TileRect tr = tile_rect(r0.x, r0.y, radii[g], tile_w, tile_h);
                 slot_of[wv][pos] = keep_index(keep_scan, cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0));
                 if (FILTER) sh.idx_of[wv][pos] = hi - lane;
@@ -782,7 +786,14 @@ inline int dispatch_channels(int D, F&& f) {
 
 using namespace mobgs;
 
+// testing aid: 0 = the compositors evaluate every quadrant of every entry (the per-quadrant reach masks only skip
+// work that is predicated off at every pixel, so results must not change)
+static int g_all_reach = 0;
+
 extern "C" {
+
+void mobgs_set_quadrant_culling(int on) { g_all_reach = on ? 0 : 1; }
+int mobgs_get_quadrant_culling(void) { return g_all_reach ? 0 : 1; }
 
 int mobgs_raster_channels_supported(int D) {
     return D == 1 || D == 2 || D == 3 || D == 4 || D == 9 || D == 10 || D == 12 || D == 16 || D == 26;
@@ -828,7 +839,7 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
         constexpr int CD = decltype(cd)::value;
         hipLaunchKernelGGL((raster_fwd_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
                            tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render,
-                           alphas, last_ids, tile_order, ClassSel{0, 1, 0});
+                           alphas, last_ids, tile_order, ClassSel{0, 1, 0, g_all_reach});
     });
     if (rc != MOBGS_OK) {
         set_error("mobgs_raster_fwd: %d total channels not compiled in (pad to a supported count)", D);
@@ -860,7 +871,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
         hipLaunchKernelGGL((raster_bwd_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
                            tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan,
                            tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots,
-                           tile_order, ClassSel{0, 1, 0});
+                           tile_order, ClassSel{0, 1, 0, g_all_reach});
     });
     if (rc != MOBGS_OK) {
         set_error("mobgs_raster_bwd: %d total channels not compiled in", D);
@@ -885,7 +896,7 @@ int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_tot
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
     hipLaunchKernelGGL((raster_fwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream, nt,
                        n_groups, tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render,
-                       alphas, last_ids, tile_order, ClassSel{class_sel, N, Ns});
+                       alphas, last_ids, tile_order, ClassSel{class_sel, N, Ns, g_all_reach});
     return check_launch("raster_fwd_kernel(class)");
 }
 
@@ -906,7 +917,7 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
     hipLaunchKernelGGL((raster_bwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream, nt,
                        n_groups, tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan,
                        tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots, tile_order,
-                       ClassSel{class_sel, N, Ns});
+                       ClassSel{class_sel, N, Ns, g_all_reach});
     return check_launch("raster_bwd_kernel(class)");
 }
 

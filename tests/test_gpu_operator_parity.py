@@ -192,6 +192,44 @@ def test_tile_culling_is_bit_exact(hip_device, mode, channels):
         assert all(x in it for x in sub), f"tile {tile}: not a sub-sequence"
 
 
+@pytest.mark.parametrize("mode,channels,tile_cull", [("RGB+ED", 9, True), ("RGB", 3, True), ("RGB+ED", 9, False)])
+def test_quadrant_reach_masks_change_nothing(hip_device, mode, channels, tile_cull):
+    """Inside the compositors every list entry carries a 4-bit mask of the 8x8 quadrants its splat can reach; the
+    other quadrants are not evaluated.  That only removes work that is predicated off at every pixel, so with the
+    masks switched off (mobgs_set_quadrant_culling(0): everything is evaluated) images, alphas AND gradients must
+    be bit-identical -- skipped terms are exact zeros added to the same sums in the same order.  Small, thin and
+    rotated splats stress the conservative margin of the reach test; with tile culling off the lists also hold
+    entries that reach no quadrant at all."""
+    from mobgs_amd import _lib, rendering
+    from mobgs_amd.rendering import rasterization
+    lib = _lib.load()
+    n, w, h = 8000, 232, 168
+    s, _ = _scene(n, w, h, 21, channels)
+    g0 = torch.Generator().manual_seed(5)
+    s["scales"] = s["scales"] * torch.exp(torch.randn(s["scales"].shape, generator=g0) * 0.9)  # needles and blobs
+    names = ["means", "quats", "scales", "opacities", "colors", "viewmats"]
+    res = {}
+    rendering.set_tile_culling(tile_cull)
+    try:
+        for masks in (1, 0):
+            lib.mobgs_set_quadrant_culling(masks)
+            assert lib.mobgs_get_quadrant_culling() == masks
+            t = {k: v.to(hip_device).clone().requires_grad_(k in names) for k, v in s.items()}
+            img, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                                         t["viewmats"], t["Ks"], w, h, packed=False, render_mode=mode)
+            g = torch.Generator().manual_seed(7)
+            v_img = torch.randn(img.shape, generator=g).to(hip_device)
+            ((img * v_img).sum() + (a * a).sum()).backward()
+            res[masks] = (img.detach().cpu(), a.detach().cpu(), {k: t[k].grad.cpu() for k in names})
+    finally:
+        lib.mobgs_set_quadrant_culling(1)
+        rendering.set_tile_culling(True)
+    assert torch.equal(res[1][0], res[0][0]), "image differs"
+    assert torch.equal(res[1][1], res[0][1]), "alpha differs"
+    for k in names:
+        assert torch.equal(res[1][2][k], res[0][2][k]), f"grad[{k}] differs"
+
+
 def test_tile_schedule_is_a_permutation_and_changes_nothing(hip_device):
     """TileLists.tile_order: every tile exactly once, list lengths non-increasing up to the width of one length
     class; images and gradients are bit-identical with the schedule on or off (it only reorders workgroups)."""
