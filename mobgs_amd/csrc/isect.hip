@@ -168,9 +168,11 @@ static_assert(SCAN_BLOCK == KEEP_CHUNK, "one workgroup per keep_scan chunk");
 
 // Owner splat (search in the chunk's slice of cum_tiles, cached in LDS), tile and reach test of every
 // intersection of the chunk.  A kept intersection takes its rank inside the tile's list with ONE returning
-// atomic; (owner, tile, rank) are written out so that pass B is a pure streaming scatter.  The keep flags are
-// scanned inside the chunk (keep_scan locals, see common.h); the chunk's total goes to its base word, which
-// tile_scan_kernel turns into the exclusive prefix over the chunks.
+// atomic.  The keep flags are scanned inside the chunk (keep_scan locals, see common.h); the chunk's total goes to its
+// base word, which tile_scan_kernel turns into the exclusive prefix over the chunks.  (owner, tile, rank) of the KEPT
+// intersections are written out compacted inside the chunk's own range [chunk * 2048, + kept) with the count in
+// chunk_cnt, so that pass B is a pure streaming scatter that reads 12 bytes per listed entry instead of 16 per
+// bounding-box intersection.
 //
 // DENSE variant (chosen when the previous frame had long lists): a dense image region sends thousands of rank
 // atomics to the same few counters, which serialise in L2 (bin 73 -> 249 us on scripts/heavy_tail.py).  The
@@ -182,7 +184,7 @@ __global__ void __launch_bounds__(SCAN_THREADS)
 bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
            const int32_t* __restrict__ cum, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
            const float* __restrict__ conics, const float* __restrict__ opacities, int opac_per_camera,
-           int32_t* __restrict__ flags, int32_t* __restrict__ owner, int32_t* __restrict__ tile_of_j,
+           int32_t* __restrict__ chunk_cnt, int32_t* __restrict__ owner, int32_t* __restrict__ tile_of_j,
            int32_t* __restrict__ rank_of_j, int32_t* __restrict__ tile_count, int32_t* __restrict__ keep_scan,
            int n_tiles_total) {
     __shared__ int s_cum[OWNER_LDS + 1];
@@ -194,6 +196,7 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
     if (start >= I) {
         if (threadIdx.x == 0) {
             kchunk[0] = 0;                   // empty chunk
+            chunk_cnt[chunk] = 0;
             if (start == I) kchunk[1] = 0;  // local of position I (one past the last intersection)
         }
         return;
@@ -270,18 +273,6 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = keep[k] ? atomicAdd(&tile_count[til[k] * TC_STRIDE], 1) : 0;
     }
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        const int j = start + k * SCAN_THREADS + threadIdx.x;
-        if (j < end) {
-            flags[j] = keep[k];
-            if (keep[k]) {
-                owner[j] = own[k];
-                tile_of_j[j] = til[k];
-                rank_of_j[j] = rank[k];
-            }
-        }
-    }
     __syncthreads();
     // exclusive prefix of every (item row, wave) segment in intersection order, and the chunk total
     int seg[SCAN_ITEMS];
@@ -297,9 +288,18 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const int i = k * SCAN_THREADS + threadIdx.x;
-        if (start + i < end) kchunk[1 + i] = seg[k] + before[k];
+        if (start + i < end) {
+            const int local = seg[k] + before[k];
+            kchunk[1 + i] = local;
+            if (keep[k]) {  // compacted: the chunk's kept intersections in order, at the start of its own range
+                owner[start + local] = own[k];
+                tile_of_j[start + local] = til[k];
+                rank_of_j[start + local] = rank[k];
+            }
+        }
     }
     if (threadIdx.x == 0) {
+        chunk_cnt[chunk] = total;
         kchunk[0] = total;
         if (end == I && end - start < SCAN_BLOCK) kchunk[1 + (end - start)] = total;  // local of position I
     }
@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
 
 // Pass B: streaming scatter of the 64-bit sort keys into the tile-contiguous segments
 __global__ void __launch_bounds__(256) emit_kernel(const int32_t* __restrict__ n_box_ptr,
-                                                     const int32_t* __restrict__ flags,
+                                                     const int32_t* __restrict__ chunk_cnt,
                                                      const int32_t* __restrict__ owner,
                                                      const int32_t* __restrict__ tile_of_j,
                                                      const int32_t* __restrict__ rank_of_j,
@@ -434,11 +434,15 @@ __global__ void __launch_bounds__(256) emit_kernel(const int32_t* __restrict__ n
     // speculative launch (stats != NULL): nothing to do when the arena was too small (see tile_scan_kernel)
     if (stats && (stats[0] > (int64_t)capacity || stats[1] > capacity_listed)) return;
     const int I = min(*n_box_ptr, capacity);
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < I; j += gridDim.x * blockDim.x) {
-        if (!flags[j]) continue;
-        const int g = owner[j];
-        const uint32_t db = __float_as_uint(depths[g]);
-        sort_keys[(size_t)tile_offsets[tile_of_j[j]] + rank_of_j[j]] = ((uint64_t)db << 32) | (uint32_t)g;
+    const int n_chunks = (I + KEEP_CHUNK - 1) >> KEEP_CHUNK_LOG2;
+    for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int cnt = chunk_cnt[chunk];
+        for (int l = threadIdx.x; l < cnt; l += 256) {
+            const int j = (chunk << KEEP_CHUNK_LOG2) + l;
+            const int g = owner[j];
+            const uint32_t db = __float_as_uint(depths[g]);
+            sort_keys[(size_t)tile_offsets[tile_of_j[j]] + rank_of_j[j]] = ((uint64_t)db << 32) | (uint32_t)g;
+        }
     }
 }
 
@@ -913,9 +917,9 @@ extern "C" {
 
 // Layout of the scratch buffer shared by mobgs_isect_offsets and mobgs_isect_emit_sort (int32 units):
 //   [tile_count nt * TC_STRIDE | ticket (+3 pad) | status 2*(nb1+1)]  <- zeroed by one memset
-//   [flags cap | owner cap | tile cap | rank cap]
+//   [owner cap | tile cap | rank cap | chunk_cnt (cap >> 11) + 1]
 struct IsectScratch {
-    int32_t *tile_count, *tickets, *flags, *owner, *tile_of_j, *rank_of_j;
+    int32_t *tile_count, *tickets, *chunk_cnt, *owner, *tile_of_j, *rank_of_j;
     uint64_t* status1;
     size_t zeroed_ints, total_ints;
     int nb1;
@@ -927,11 +931,11 @@ struct IsectScratch {
         tickets = p + nt_pad;
         status1 = (uint64_t*)(p + nt_pad + 4);
         zeroed_ints = nt_pad + 4 + 2 * (size_t)(nb1 + 1);
-        flags = p + zeroed_ints;
-        owner = flags + capacity;
+        owner = p + zeroed_ints;
         tile_of_j = owner + capacity;
         rank_of_j = tile_of_j + capacity;
-        total_ints = zeroed_ints + 4 * capacity;
+        chunk_cnt = rank_of_j + capacity;
+        total_ints = zeroed_ints + 3 * capacity + (capacity >> KEEP_CHUNK_LOG2) + 1;
     }
 };
 
@@ -1008,12 +1012,12 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
     if (g_dense_hint >= DENSE_LIST_LEN && nt <= DENSE_MAX_TILES)
         hipLaunchKernelGGL(bin_kernel<true>, dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n, N,
                            tile_w, tile_h, width, height, cull, capacity, cum_tiles, means2d, radii, conics, opacities,
-                           opac_per_camera, L.flags, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan,
+                           opac_per_camera, L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan,
                            (int)nt);
     else
         hipLaunchKernelGGL(bin_kernel<false>, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h, width,
                            height, cull, capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera,
-                           L.flags, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt);
+                           L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
                        stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, g_heavy_len,
                        stats_mirror);
@@ -1036,9 +1040,9 @@ static int emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t
     }
     if (n_isects == 0) return MOBGS_OK;
     const int n = C * N;
-    // the (flag, owner, tile, rank) arrays pass A left in the scratch buffer of mobgs_isect_offsets
+    // the compacted (owner, tile, rank) arrays pass A left in the scratch buffer of mobgs_isect_offsets
     const IsectScratch L(const_cast<void*>(offsets_scratch), (size_t)n, (size_t)nt, (size_t)capacity);
-    hipLaunchKernelGGL(emit_kernel, dim3(4096), dim3(256), 0, st, cum_tiles + n, L.flags, L.owner, L.tile_of_j,
+    hipLaunchKernelGGL(emit_kernel, dim3(4096), dim3(256), 0, st, cum_tiles + n, L.chunk_cnt, L.owner, L.tile_of_j,
                        L.rank_of_j, depths, tile_offsets, sort_keys, capacity, stats_dev, capacity_listed);
     // gsplat: tile_n_bits = floor(log2(n_tiles)) + 1
     int tile_bits = 0;
