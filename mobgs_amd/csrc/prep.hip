@@ -131,6 +131,21 @@ prep_bwd_kernel(int Ns, int Nd, const float* __restrict__ times, const long long
                 float* __restrict__ g_d_ft) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = Ns + Nd;
+    if (!ACC) {
+        // the 144-byte control-point gradient rows of this WAVE's dynamic splats are contiguous: clear them with
+        // coalesced 16-byte stores (a thread clearing its own row issues 36 stores that each touch 64 lines), then
+        // every thread drops its <= 12 non-zero entries into its row.  Same wave, program order: the fill's stores
+        // are complete (s_waitcnt vmcnt(0) of the wavefront-scope release) before the entries are written.
+        const int wave_first = (blockIdx.x * blockDim.x + (threadIdx.x & ~63)) - Ns;  // first dynamic index
+        const int j0 = max(wave_first, 0), j1 = min(wave_first + 64, Nd);
+        if (j1 > j0) {
+            float4* row = reinterpret_cast<float4*>(g_d_control + (size_t)j0 * 36);
+            const int n4 = (j1 - j0) * 9;
+            for (int t = threadIdx.x & 63; t < n4; t += 64) row[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+    }
     if (i >= N) return;
     float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vo = 0.f, vc[9];
 #pragma unroll
@@ -172,10 +187,6 @@ prep_bwd_kernel(int Ns, int Nd, const float* __restrict__ times, const long long
         const int n = (int)d_ncp[j];
         const Hermite H = hermite_setup(times[1], n);
         float* gc = g_d_control + (size_t)j * 36;
-        if (!ACC) {
-#pragma unroll
-            for (int k = 0; k < 36; ++k) gc[k] = 0.f;
-        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float v = vm[k] * 1e-2f;
@@ -195,11 +206,19 @@ prep_bwd_kernel(int Ns, int Nd, const float* __restrict__ times, const long long
                 a3 += 0.5f * vm1;
                 a1 -= 0.5f * vm1;
             }
-            // knots may coincide at the curve ends: sequential read-modify-write by the owning thread
-            gc[3 * H.i0 + k] += a0;
-            gc[3 * H.i1 + k] += a1;
-            gc[3 * H.i2 + k] += a2;
-            gc[3 * H.i3 + k] += a3;
+            // knots coincide only at the curve ends (i0 == i1: a0 is 0; i3 == i2: a3 is 0), where the dead term is
+            // simply not stored.  !ACC: the rows were zero-filled above, plain stores; ACC: read-modify-write
+            if (ACC) {
+                if (!H.left_edge) gc[3 * H.i0 + k] += a0;
+                gc[3 * H.i1 + k] += a1;
+                gc[3 * H.i2 + k] += a2;
+                if (!H.right_edge) gc[3 * H.i3 + k] += a3;
+            } else {
+                if (!H.left_edge) gc[3 * H.i0 + k] = a0;
+                gc[3 * H.i1 + k] = a1;
+                gc[3 * H.i2 + k] = a2;
+                if (!H.right_edge) gc[3 * H.i3 + k] = a3;
+            }
             g_d_scaling[3 * j + k] = (ACC ? g_d_scaling[3 * j + k] : 0.f) + vs[k];
             g_d_ft[3 * j + k] = (ACC ? g_d_ft[3 * j + k] : 0.f) + tfp * vc[6 + k];
         }
