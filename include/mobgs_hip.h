@@ -174,7 +174,11 @@ int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, 
  * recorded after this call) and the function returns.  When the arena turns out too small (counts exceed
  * capacity_box / capacity_listed) every per-tile list was written EMPTY: compositing kernels enqueued in the
  * meantime are harmless no-ops, and the caller redoes the binning with a larger arena (mobgs_isect_offsets +
- * mobgs_isect_emit_sort on the projection outputs, which do not depend on the arena). */
+ * mobgs_isect_emit_sort on the projection outputs, which do not depend on the arena).
+ * pack_records (optional, else NULL): [C*N, mobgs_record_stride(pack_channels + 1)] -- the projection kernel also
+ * writes the compositor's packed records {means2d, conic, opacity, pack_colors, depth as the extra channel} of the
+ * visible splats (what mobgs_pack_records / mobgs_raster_fwd would do in a launch of its own); hand them to
+ * mobgs_raster_fwd with colors = NULL.  pack_colors: [C,N,ch] (colors_per_camera = 1) or [N,ch]. */
 int mobgs_project_and_bin_speculative(int C, int N, const float* means, const float* quats, const float* scales,
                                       const float* viewmats, const float* Ks, const float* opacities,
                                       int opac_per_camera, int width, int height, float eps2d, float near_plane,
@@ -183,10 +187,12 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
                                       int32_t* tile_offsets, int32_t* tile_order, int64_t* stats_dev,
                                       int capacity_box, int32_t* keep_scan, void* scratch, int64_t capacity_listed,
                                       int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
-                                      int64_t max_tile_len_hint, int64_t* stats_host_pinned, void* stream);
+                                      int64_t max_tile_len_hint, int64_t* stats_host_pinned, const float* pack_colors,
+                                      int colors_per_camera, int pack_channels, float* pack_records, void* stream);
 
 /* ---- K6: rasterise forward (replaces gsplat rasterize_to_pixels fwd) -----------------------------------
- * colors   : [C,N,channels] (colors_per_camera=1) or [N,channels] (0)
+ * colors   : [C,N,channels] (colors_per_camera=1) or [N,channels] (0); NULL: `records` are already packed (by
+ *            mobgs_project_and_bin_speculative or mobgs_pack_records) and only `extra != NULL` is looked at
  * opacities: [C,N] (opac_per_camera=1) or [N] (0)
  * extra    : optional [C,N] channel appended after `channels` (gsplat's "+D"/"+ED" depth channel), or NULL
  * backgrounds: [C, channels(+1 if extra)] or NULL

@@ -131,12 +131,41 @@ __device__ inline int band_mask(float mx, float my, float ca, float cb, float cc
     return m;
 }
 
+// The compositor's packed splat record {x, y, conic a b | c, opacity, colour[0..1] | colour ... (extra) 0...}:
+// `stride` floats (a multiple of 4), 16-byte aligned.
+__device__ inline void write_splat_record(float* __restrict__ r, float x, float y, float ca, float cb, float cc,
+                                          float op, const float* __restrict__ col, int channels, bool has_extra,
+                                          float extra) {
+    reinterpret_cast<float4*>(r)[0] = make_float4(x, y, ca, cb);
+    const int D = channels + (has_extra ? 1 : 0);
+    float buf[4] = {cc, op, 0.f, 0.f};
+    int fill = 2;
+    int q = 1;
+    for (int k = 0; k < D; ++k) {
+        buf[fill++] = (k < channels) ? col[k] : extra;
+        if (fill == 4) {
+            reinterpret_cast<float4*>(r)[q++] = make_float4(buf[0], buf[1], buf[2], buf[3]);
+            fill = 0;
+            buf[0] = buf[1] = buf[2] = buf[3] = 0.f;
+        }
+    }
+    if (fill > 0) reinterpret_cast<float4*>(r)[q++] = make_float4(buf[0], buf[1], buf[2], buf[3]);
+}
+// optional side job of project_fwd: pack the records with the depth as extra channel (records == NULL: off)
+struct PackArgs {
+    const float* opacities;
+    const float* colors;
+    float* records;
+    int opac_per_camera, colors_per_camera, channels, stride;
+};
+
 // ---- launchers shared between translation units (the orchestrator in pipeline.hip fuses small steps) ---------
-// project_fwd with the option to clear `zero_n` ints at `zero_ptr` on the way (the binning scratch counters)
+// project_fwd with the option to clear `zero_n` ints at `zero_ptr` on the way (the binning scratch counters) and to
+// pack the compositor's records
 int project_fwd_launch(int C, int N, const float* means, const float* quats, const float* scales, const float* viewmats,
                        const float* Ks, int width, int height, float eps2d, float near_plane, float far_plane,
                        float radius_clip, int32_t* radii, float* means2d, float* depths, float* conics,
-                       int32_t* tiles_per_gauss, int32_t* zero_ptr, size_t zero_n, void* stream);
+                       int32_t* tiles_per_gauss, int32_t* zero_ptr, size_t zero_n, PackArgs pack, void* stream);
 // mobgs_isect_offsets; scratch_zeroed: the counters were cleared by the caller; stats_mirror: device-visible host
 // address that receives a copy of stats[0..2] (or NULL)
 int isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,

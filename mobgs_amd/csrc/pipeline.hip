@@ -61,7 +61,8 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
                                       int32_t* tile_offsets, int32_t* tile_order, int64_t* stats_dev,
                                       int capacity_box, int32_t* keep_scan, void* scratch, int64_t capacity_listed,
                                       int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
-                                      int64_t max_tile_len_hint, int64_t* stats_host_pinned, void* stream) {
+                                      int64_t max_tile_len_hint, int64_t* stats_host_pinned, const float* pack_colors,
+                                      int colors_per_camera, int pack_channels, float* pack_records, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
     if (!stats_host_pinned || capacity_listed < 1) {
@@ -76,8 +77,18 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
     const bool fuse_zero = N > 0 && capacity_box >= 1 && n_all < (1ll << 31) - 1 && nt_all < (1ll << 31) - 1 &&
                            ((uintptr_t)scratch & 7) == 0;
     if (fuse_zero) mobgs::isect_zeroed_region(scratch, (size_t)n_all, (size_t)nt_all, (size_t)capacity_box, &zero_ptr, &zero_n);
+    PackArgs pack{nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    if (pack_records) {
+        if (!pack_colors || !opacities || pack_channels < 0) {
+            set_error("mobgs_project_and_bin_speculative: pack_records needs pack_colors and opacities");
+            return MOBGS_E_INVALID;
+        }
+        pack = PackArgs{opacities, pack_colors, pack_records, opac_per_camera, colors_per_camera, pack_channels,
+                        mobgs_record_stride(pack_channels + 1)};
+    }
     int rc = mobgs::project_fwd_launch(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
-                                       radius_clip, radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, zero_n, stream);
+                                       radius_clip, radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, zero_n, pack,
+                                       stream);
     if (rc != MOBGS_OK) return rc;
     mobgs_hint_longest_list((int)(max_tile_len_hint > 0x7fffffff ? 0x7fffffff : max_tile_len_hint));
     void* mirror = nullptr;

@@ -120,7 +120,7 @@ project_fwd_kernel(int N, const float* __restrict__ means, const float* __restri
                    float far_plane, float radius_clip, int tile_w, int tile_h,
                    int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
                    float* __restrict__ conics, int32_t* __restrict__ tiles_per_gauss, int32_t* __restrict__ zero_ptr,
-                   unsigned zero_n) {
+                   unsigned zero_n, PackArgs pack) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     // side job for the orchestrator: clear the binning counters (saves a memset launch on the critical path)
@@ -195,6 +195,13 @@ project_fwd_kernel(int N, const float* __restrict__ means, const float* __restri
     conics[3 * o + 1] = cb;
     conics[3 * o + 2] = cc;
     tiles_per_gauss[o] = ntiles;
+    // side job for the orchestrator: the compositor's record of this splat (depth as the extra channel) while
+    // everything it needs is in registers -- saves the pack launch and re-reading means2d / conics / depths
+    if (pack.records && rad > 0)
+        write_splat_record(pack.records + o * pack.stride, m2x, m2y, ca, cb, cc,
+                           pack.opacities[pack.opac_per_camera ? o : (size_t)i],
+                           pack.colors + (pack.colors_per_camera ? o : (size_t)i) * pack.channels, pack.channels, true,
+                           depth);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -446,7 +453,8 @@ int mobgs_project_fwd(int C, int N, const float* means, const float* quats, cons
                       float near_plane, float far_plane, float radius_clip, int32_t* radii, float* means2d,
                       float* depths, float* conics, int32_t* tiles_per_gauss, void* stream) {
     return mobgs::project_fwd_launch(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
-                                     radius_clip, radii, means2d, depths, conics, tiles_per_gauss, nullptr, 0, stream);
+                                     radius_clip, radii, means2d, depths, conics, tiles_per_gauss, nullptr, 0,
+                                     PackArgs{nullptr, nullptr, nullptr, 0, 0, 0, 0}, stream);
 }
 
 }  // extern "C"
@@ -455,7 +463,7 @@ int mobgs::project_fwd_launch(int C, int N, const float* means, const float* qua
                               const float* viewmats, const float* Ks, int width, int height, float eps2d,
                               float near_plane, float far_plane, float radius_clip, int32_t* radii, float* means2d,
                               float* depths, float* conics, int32_t* tiles_per_gauss, int32_t* zero_ptr, size_t zero_n,
-                              void* stream) {
+                              PackArgs pack, void* stream) {
     if (C <= 0 || N < 0 || width <= 0 || height <= 0) {
         set_error("mobgs_project_fwd: bad sizes C=%d N=%d W=%d H=%d", C, N, width, height);
         return MOBGS_E_INVALID;
@@ -468,7 +476,7 @@ int mobgs::project_fwd_launch(int C, int N, const float* means, const float* qua
     dim3 grid((N + 255) / 256, C);
     hipLaunchKernelGGL(project_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, means, quats, scales,
                        viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip, tile_w, tile_h,
-                       radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, (unsigned)zero_n);
+                       radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, (unsigned)zero_n, pack);
     return check_launch("project_fwd_kernel");
 }
 

@@ -89,24 +89,10 @@ pack_records_kernel(int N, int channels, int stride, const float* __restrict__ m
     if (i >= N) return;
     const size_t o = (size_t)c * N + i;
     if (radii[o] <= 0) return;  // culled splats are never referenced by a tile list
-    float* r = records + o * stride;
     const float2 m = reinterpret_cast<const float2*>(means2d)[o];
-    const float op = opacities[opac_per_camera ? o : (size_t)i];
-    reinterpret_cast<float4*>(r)[0] = make_float4(m.x, m.y, conics[3 * o], conics[3 * o + 1]);
-    const float* col = colors + (colors_per_camera ? o : (size_t)i) * channels;
-    const int D = channels + (extra ? 1 : 0);
-    float buf[4] = {conics[3 * o + 2], op, 0.f, 0.f};
-    int fill = 2;
-    int q = 1;
-    for (int k = 0; k < D; ++k) {
-        buf[fill++] = (k < channels) ? col[k] : extra[o];
-        if (fill == 4) {
-            reinterpret_cast<float4*>(r)[q++] = make_float4(buf[0], buf[1], buf[2], buf[3]);
-            fill = 0;
-            buf[0] = buf[1] = buf[2] = buf[3] = 0.f;
-        }
-    }
-    if (fill > 0) reinterpret_cast<float4*>(r)[q++] = make_float4(buf[0], buf[1], buf[2], buf[3]);
+    write_splat_record(records + o * stride, m.x, m.y, conics[3 * o], conics[3 * o + 1], conics[3 * o + 2],
+                       opacities[opac_per_camera ? o : (size_t)i], colors + (colors_per_camera ? o : (size_t)i) * channels,
+                       channels, extra != nullptr, extra ? extra[o] : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -828,7 +814,7 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
     const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
     const int nt = C * tile_w * tile_h;
     const int stride = record_stride(D);
-    if (N > 0) {
+    if (N > 0 && colors != nullptr) {  // colors == NULL: `records` were packed by mobgs_project_and_bin_speculative
         hipLaunchKernelGGL(pack_records_kernel, dim3((N + 255) / 256, C), dim3(256), 0, st, N, channels, stride,
                            means2d, conics, colors, colors_per_camera, opacities, opac_per_camera, extra, radii,
                            records);

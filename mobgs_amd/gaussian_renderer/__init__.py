@@ -236,7 +236,7 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     # ONE projection and ONE tile binning / sort per render() call; the whole-set image comes from the single-set
     # compositor, the static-only / dynamic-only images (when asked for) from ONE layered walk over the same lists
     # (the reference: 5 rasterizations, :143-176, :201-214, :236-268)
-    sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None], K[None], W, H)
+    sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None], K[None], W, H, pack_colors=cols)
     # The intersection counts are still on their way to the host (speculative binning).  Compositing AND decoding are
     # enqueued before waiting for them, so that the device has the rest of the forward pass queued while the host
     # waits -- on small scenes (tens of thousands of splats) the step is host-bound and this wait was a bubble.

@@ -118,7 +118,7 @@ class TileLists:
 
     __slots__ = ("C", "N", "tile_w", "tile_h", "cum_tiles", "keep_scan", "tile_offsets", "tile_order",
                  "flatten_arena", "_n_box", "_n_isects", "_max_tile_len", "_flatten_ids", "_isect_ids", "_pending",
-                 "rebuilds", "defer")
+                 "rebuilds", "defer", "records")
 
     def __init__(self):
         self._pending = None
@@ -287,7 +287,8 @@ class _Rasterize(torch.autograd.Function):
     """rasterize_to_pixels: (means2d, conics, colors, opacities[, extra channel], backgrounds) -> image, alpha."""
 
     @staticmethod
-    def forward(ctx, means2d, conics, colors, opacities, extra, backgrounds, radii, tl: TileLists, width, height):
+    def forward(ctx, means2d, conics, colors, opacities, extra, backgrounds, radii, tl: TileLists, width, height,
+                packed=None):
         lib = _lib_()
         C, N = radii.shape
         dev = means2d.device
@@ -299,13 +300,18 @@ class _Rasterize(torch.autograd.Function):
         opac_per_camera = 1 if opacities.dim() == 2 else 0
         bg = f32c(backgrounds) if backgrounds is not None else None
         stride = lib.mobgs_record_stride(D)
-        records = torch.empty(C * N, stride, dtype=torch.float32, device=dev)
+        # `packed`: records of exactly these inputs written by the projection kernel (SharedProjection(pack_colors=)):
+        # no pack launch (colors = NULL tells mobgs_raster_fwd so)
+        if packed is not None and tuple(packed.shape) != (C * N, stride):
+            packed = None
+        records = packed if packed is not None else torch.empty(C * N, stride, dtype=torch.float32, device=dev)
+        colors_arg = None if packed is not None else colors
         render = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
         alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
         with profiler.region("raster_fwd"):
             while True:
-                check(lib.mobgs_raster_fwd(C, N, channels, width, height, ptr(means2d), ptr(conics), ptr(colors),
+                check(lib.mobgs_raster_fwd(C, N, channels, width, height, ptr(means2d), ptr(conics), ptr(colors_arg),
                                            colors_per_camera, ptr(opacities), opac_per_camera, ptr(extra), ptr(bg),
                                            ptr(radii), ptr(tl.tile_offsets), ptr(tl.tile_order),
                                            ptr(tl.flatten_arena), ptr(records), ptr(render), ptr(alphas),
@@ -354,7 +360,7 @@ class _Rasterize(torch.autograd.Function):
         v_bg = None
         if ctx.bg_needs_grad:
             v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
-        return v_means2d, v_conics, v_colors, v_opac, v_extra, v_bg, None, None, None, None
+        return v_means2d, v_conics, v_colors, v_opac, v_extra, v_bg, None, None, None, None, None
 
 
 def _ptr3(tensors):
@@ -466,7 +472,7 @@ class _RasterizeClasses(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, extra, backgrounds, radii, tl: TileLists, width, height, Ns,
-                mask):
+                mask, packed=None):
         lib = _lib_()
         C, N = radii.shape
         dev = means2d.device
@@ -476,10 +482,14 @@ class _RasterizeClasses(torch.autograd.Function):
         if D != 10:
             raise NotImplementedError("class-restricted compositing is built for 9 feature channels + depth")
         bg = f32c(backgrounds) if backgrounds is not None else None
-        records = torch.empty(C * N, lib.mobgs_record_stride(D), dtype=torch.float32, device=dev)
-        check(lib.mobgs_pack_records(C, N, channels, ptr(means2d), ptr(conics), ptr(colors),
-                                     1 if colors.dim() == 3 else 0, ptr(opacities), 1 if opacities.dim() == 2 else 0,
-                                     ptr(extra), ptr(radii), ptr(records), stream()), "mobgs_pack_records")
+        if packed is not None and tuple(packed.shape) == (C * N, lib.mobgs_record_stride(D)):
+            records = packed  # written by the projection kernel (SharedProjection(pack_colors=))
+        else:
+            records = torch.empty(C * N, lib.mobgs_record_stride(D), dtype=torch.float32, device=dev)
+            check(lib.mobgs_pack_records(C, N, channels, ptr(means2d), ptr(conics), ptr(colors),
+                                         1 if colors.dim() == 3 else 0, ptr(opacities),
+                                         1 if opacities.dim() == 2 else 0, ptr(extra), ptr(radii), ptr(records),
+                                         stream()), "mobgs_pack_records")
         outs = {}
         with profiler.region("raster_class_fwd"):
             for cls in (1, 2):
@@ -548,7 +558,7 @@ class _RasterizeClasses(torch.autograd.Function):
             v_colors = v_colors.sum(0) if C > 1 else v_colors[0]
         if not opac_per_camera:
             v_opac = v_opac.sum(0) if C > 1 else v_opac[0]
-        return v_means2d, v_conics, v_colors, v_opac, v_extra, None, None, None, None, None, None, None
+        return v_means2d, v_conics, v_colors, v_opac, v_extra, None, None, None, None, None, None, None, None
 
 
 _cap_listed = {}  # device index -> capacity of the listed-intersection buffers
@@ -560,7 +570,7 @@ class _ProjectAndBin(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, viewmats, Ks, opacities, tl, width, height, eps2d, near_plane, far_plane,
-                radius_clip, want_isect_ids):
+                radius_clip, want_isect_ids, pack_colors=None):
         import ctypes
         lib = _lib_()
         means, quats, scales, viewmats, Ks, opac = map(f32c, (means, quats, scales, viewmats, Ks, opacities))
@@ -579,6 +589,14 @@ class _ProjectAndBin(torch.autograd.Function):
                       if TILE_SCHEDULE else None)
         stats_dev = torch.empty(3, dtype=torch.int64, device=dev)
         stats_host = (ctypes.c_int64 * 3)()
+        # optional: the projection kernel also writes the compositor's packed records (colours + depth channel)
+        tl.records = None
+        records = None
+        if pack_colors is not None and SPECULATIVE_BINNING:
+            pack_colors = f32c(pack_colors)
+            pack_ch = pack_colors.shape[-1]
+            if lib.mobgs_raster_channels_supported(pack_ch + 1):
+                records = torch.empty(C * N, lib.mobgs_record_stride(pack_ch + 1), dtype=torch.float32, device=dev)
         key = dev.index if dev.index is not None else -1
         cap_box = max(_capacity.get(key, 0), 16 * (C * N) + 1024)
         cap_listed = max(_cap_listed.get(key, 0), cap_box // 2)
@@ -599,8 +617,12 @@ class _ProjectAndBin(torch.autograd.Function):
                     int(_tile_culling), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(tiles_per_gauss),
                     ptr(cum_tiles), ptr(tile_offsets), ptr(tile_order), ptr(stats_dev), cap_box, ptr(keep_scan),
                     ptr(scratch), cap_listed, ptr(flatten_ids), ptr(sort_keys), ptr(isect_ids),
-                    _len_hint.get(key, 0), ctypes.c_void_p(row.data_ptr()), stream()),
+                    _len_hint.get(key, 0), ctypes.c_void_p(row.data_ptr()),
+                    ptr(pack_colors) if records is not None else None,
+                    1 if (records is not None and pack_colors.dim() == 3) else 0,
+                    pack_colors.shape[-1] if records is not None else 0, ptr(records), stream()),
                     "mobgs_project_and_bin_speculative")
+                tl.records = records
                 event = torch.cuda.Event()
                 event.record()
                 tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
@@ -637,7 +659,8 @@ class _ProjectAndBin(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tpg):
         grads = _Project.backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tpg)
-        return grads[0], grads[1], grads[2], grads[3], None, None, None, None, None, None, None, None, None, None
+        return (grads[0], grads[1], grads[2], grads[3], None, None, None, None, None, None, None, None, None, None,
+                None)
 
 
 _bg_ext_cache = DerivedCache()
@@ -648,14 +671,19 @@ class SharedProjection:
     camera (`composite` = the usual single-set pass, `composite_layers` = static-only / dynamic-only layers)."""
 
     def __init__(self, means, quats, scales, opacities, viewmats, Ks, width, height, near_plane=0.01, far_plane=1e10,
-                 radius_clip=0.0, eps2d=0.3, want_isect_ids=False):
+                 radius_clip=0.0, eps2d=0.3, want_isect_ids=False, pack_colors=None):
+        """pack_colors: the colours composite() / composite_layers() will be called with, when already known: the
+        projection kernel then writes the compositor's packed records itself (one launch and one pass over the
+        projection outputs fewer); passing other colours later simply packs again."""
         self.width, self.height = int(width), int(height)
         self.C, self.N = viewmats.shape[0], means.shape[0]
         self.opacities = opacities
         self.tl = TileLists()
         (self.radii, self.means2d, self.depths, self.conics, self.tiles_per_gauss) = _ProjectAndBin.apply(
             means, quats, scales, viewmats, Ks, opacities.detach(), self.tl, self.width, self.height, float(eps2d),
-            float(near_plane), float(far_plane), float(radius_clip), bool(want_isect_ids))
+            float(near_plane), float(far_plane), float(radius_clip), bool(want_isect_ids),
+            pack_colors.detach() if pack_colors is not None else None)
+        self._packed_colors = pack_colors if self.tl.records is not None else None
         # autograd alias used by composite() and exposed as meta["means2d"] / viewspace_points: its .grad is the
         # position gradient of the whole-set render alone (the reference's static / dynamic passes have their own,
         # un-retained means2d tensors, gaussian_renderer/__init__.py:218-223)
@@ -667,10 +695,14 @@ class SharedProjection:
         return _bg_ext_cache.get((backgrounds,),
                                  lambda: torch.cat([backgrounds, backgrounds.new_zeros(self.C, 1)], dim=-1))
 
+    def _packed_for(self, colors):
+        return self.tl.records if (self._packed_colors is not None and colors is self._packed_colors) else None
+
     def composite(self, colors, backgrounds=None):
         """"RGB+D" compositing of the whole set: (render [C,H,W,D+1], alphas [C,H,W,1])."""
         return rasterize_to_pixels(self.means2d_main, self.conics, colors, self.opacities, self.radii, self.tl,
-                                   self.width, self.height, backgrounds=self._bg(backgrounds), extra=self.depths)
+                                   self.width, self.height, backgrounds=self._bg(backgrounds), extra=self.depths,
+                                   packed=self._packed_for(colors))
 
     def composite_layers(self, colors, Ns, backgrounds=None, want_all=False, want_static=True, want_dynamic=True):
         """Layered "RGB+D" compositing over the SAME lists: lists (render, alphas) indexed by layer
@@ -681,7 +713,7 @@ class SharedProjection:
         if CLASS_PASSES and not want_all and colors.shape[-1] == 9:
             rs, a_s, rd, a_d = _RasterizeClasses.apply(self.means2d, self.conics, colors, self.opacities, self.depths,
                                                        self._bg(backgrounds), self.radii, self.tl, self.width,
-                                                       self.height, int(Ns), mask)
+                                                       self.height, int(Ns), mask, self._packed_for(colors))
             return ([None, rs if want_static else None, rd if want_dynamic else None],
                     [None, a_s if want_static else None, a_d if want_dynamic else None])
         m2d_view = self.means2d.view_as(self.means2d)
@@ -722,14 +754,16 @@ def rasterize_layers(means, quats, scales, opacities, colors, viewmats, Ks, widt
 
 
 def rasterize_to_pixels(means2d, conics, colors, opacities, radii, tl: TileLists, width, height, backgrounds=None,
-                        extra=None):
-    """Composite; channel counts without a compiled variant are zero-padded up to the next one."""
+                        extra=None, packed=None):
+    """Composite; channel counts without a compiled variant are zero-padded up to the next one.
+    packed: records of exactly these inputs already written by the projection kernel (see SharedProjection)."""
     C = radii.shape[0]
     channels = colors.shape[-1]
     D = channels + (1 if extra is not None else 0)
     Dp = _pad_channels(D)
     if Dp == D:
-        return _Rasterize.apply(means2d, conics, colors, opacities, extra, backgrounds, radii, tl, width, height)
+        return _Rasterize.apply(means2d, conics, colors, opacities, extra, backgrounds, radii, tl, width, height,
+                                packed if extra is not None else None)
     parts = [colors if colors.dim() == 3 else colors.unsqueeze(0).expand(C, *colors.shape)]
     if extra is not None:
         parts.append(extra.unsqueeze(-1))
