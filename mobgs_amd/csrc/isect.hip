@@ -340,11 +340,14 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
         if (threadIdx.x == 0) stats[1] = (int64_t)base;
         return;
     }
+    // workgroup 2 (launched when a schedule is wanted): the tile order, concurrently with the offsets of workgroup 0
+    const bool order_wg = blockIdx.x == 2;
     int carry = 0, mx = 0;
     for (int start = 0; start < nt; start += TSCAN_THREADS) {
         const int i = start + threadIdx.x;
         const int v = (i < nt) ? tile_count[i * TC_STRIDE] : 0;
         mx = max(mx, v);
+        if (order_wg) continue;  // only needs the longest list
         int total;
         const int inc = block_incl_scan_w<TSCAN_THREADS / 64>(v, &total);
         if (i < nt) tile_offsets[i] = carry + inc - v;
@@ -357,7 +360,7 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
     int longest = 0;
 #pragma unroll
     for (int k = 0; k < TSCAN_THREADS / 64; ++k) longest = max(longest, smax[k]);
-    if (threadIdx.x == 0) {
+    if (!order_wg && threadIdx.x == 0) {
         tile_offsets[nt] = carry;
         stats[2] = (int64_t)longest;
         // the host's copy of {I_box, I_listed, longest list}: written straight into its pinned, device-mapped slot
@@ -372,9 +375,12 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
     // Arena too small (only checked when the caller runs ahead of the read-back, capacity_listed > 0): hand every
     // consumer EMPTY lists, so that kernels already enqueued behind this one touch nothing; stats keep the true
     // counts and the host redoes the binning with a larger arena.
-    if (capacity_listed > 0 && (stats[0] > capacity_box || (int64_t)carry > capacity_listed)) {
-        __syncthreads();
-        for (int i = threadIdx.x; i <= nt; i += TSCAN_THREADS) tile_offsets[i] = 0;
+    if (!order_wg) {
+        if (capacity_listed > 0 && (stats[0] > capacity_box || (int64_t)carry > capacity_listed)) {
+            __syncthreads();
+            for (int i = threadIdx.x; i <= nt; i += TSCAN_THREADS) tile_offsets[i] = 0;
+        }
+        return;
     }
     if (!tile_order) return;
     auto bucket = [&](int len) {
@@ -997,7 +1003,7 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
         hipMemsetAsync(cum_tiles, 0, sizeof(int32_t), st);
         hipMemsetAsync(keep_scan, 0, 2 * sizeof(int32_t), st);  // base and first local of chunk 0
         hipMemsetAsync(stats, 0, 3 * sizeof(int64_t), st);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
                            stats, tile_order, (int64_t)capacity, (int64_t)0, (int32_t*)nullptr, 0, g_heavy_len,
                            stats_mirror);
         return check_launch("isect_offsets(empty)");
@@ -1018,7 +1024,7 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
         hipLaunchKernelGGL(bin_kernel<false>, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h, width,
                            height, cull, capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera,
                            L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
                        stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, g_heavy_len,
                        stats_mirror);
     return check_launch("isect_offsets");
