@@ -200,17 +200,27 @@ def main():
             # + 4 (last_id) read
             alg_bytes = 132.0 * I + 52.0 * P
             achieved = alg_bytes / (rb["avg_ms"] * 1e-3) / 1e9
-            traffic = None
+            traffic = valu_insts = None
             pmc = os.path.join(ROOT, "profiles", "r01_raster_bwd_pmc.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    counters = json.load(open(pmc))
+                    traffic = counters.get("hbm_bytes_per_launch")
+                    valu_insts = counters.get("valu_wave_insts_per_launch")
                 except Exception:  # noqa: BLE001
-                    traffic = None
+                    traffic = valu_insts = None
             result["roofline"] = {"kernel": "raster_bwd_kernel<10>", "bound": "hbm", "achieved": round(achieved, 2),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                                   "traffic": traffic, "avg_kernel_ms": round(rb["avg_ms"], 4),
                                   "algorithmic_bytes": alg_bytes, "calls": rb["calls"]}
+            if valu_insts:
+                # what actually bounds the kernel: VALU issue.  A wave64 VALU instruction holds
+                # one of the 1024 SIMDs for 4 cycles; counted instructions (SQ_INSTS_VALU, committed PMC pass) x 4 /
+                # 1024 / 2.4 GHz peak clock against the live kernel time (the chip sustains ~2.2 GHz here, so the
+                # true occupancy of the issue slots is ~9 % higher than this figure)
+                floor_ms = valu_insts * 4.0 / 1024.0 / 2.4e9 * 1e3
+                result["roofline"]["valu_issue"] = {"wave_insts": valu_insts, "floor_ms_at_2.4GHz": round(floor_ms, 4),
+                                                    "frac": round(floor_ms / rb["avg_ms"], 4)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(*raw, scam, args.width, args.height, args.cpu_reps)
