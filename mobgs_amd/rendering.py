@@ -124,6 +124,7 @@ class TileLists:
         self._pending = None
         self.rebuilds = 0     # how many times resolve() had to rebuild the lists (arena overflow)
         self.defer = False    # True: compositing calls do not resolve; the caller does, later, and re-issues them
+        self.records = None   # compositor records written by the projection kernel (SharedProjection(pack_colors=))
 
     @property
     def pending(self) -> bool:
