@@ -695,18 +695,21 @@ slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, const i
         v_extra[g] = acc;
 }
 
-// 64-byte records (stride 16, the render() configuration): 16 lanes per splat, every lane loads 16 BYTES -- lane
-// quarter q = lane & 3 of slot k + ((lane >> 2) & 3) -- so one load instruction of a group covers four slots (four
-// times the bytes in flight of the one-float-per-lane version: the kernel is latency-bound), two slots-of-four in
-// flight per lane; the four partial sums per component are combined with two DPP adds (row_ror 4, 8).
+// 64-byte records (stride 16, the render() configuration): LPS lanes per splat, every lane loads 16 BYTES -- quarter
+// q = lane & 3 of slot k + sub-group -- so one load instruction of a group covers LPS / 4 slots (the kernel is
+// latency-bound: 4x the bytes in flight of a one-float-per-lane loop), two such loads in flight per lane; the
+// partial sums per component are combined with DPP adds.  Measured: 16 lanes 33 us, 8 lanes (twice the splats per
+// wave, half the waves to schedule) 30 us, 4 lanes 34 us.
 // Fixed association order -> deterministic.
+template <int LPS>  // lanes per splat: 16 (four slots per load instruction and splat) or 8 (two)
 __global__ void __launch_bounds__(256)
 slot_reduce16_kernel(int n_gauss, int channels, int has_extra, const int32_t* __restrict__ cum_tiles,
                      const int32_t* __restrict__ keep_scan, const float* __restrict__ grad_slots,
                      float* __restrict__ v_means2d, float* __restrict__ v_conics, float* __restrict__ v_opacities,
                      float* __restrict__ v_colors, float* __restrict__ v_extra) {
-    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int l16 = threadIdx.x & 15;
+    constexpr int SUBS = LPS / 4;
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPS;
+    const int l16 = threadIdx.x & (LPS - 1);
     const int q = l16 & 3, sub = l16 >> 2;
     const bool live = gid < n_gauss;
     int a = 0, b = 0;
@@ -717,8 +720,8 @@ slot_reduce16_kernel(int n_gauss, int channels, int has_extra, const int32_t* __
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     const float4* p = reinterpret_cast<const float4*>(grad_slots) + q;
     int k = a + sub;
-    for (; k + 4 < b; k += 8) {
-        const float4 u = p[(size_t)k * 4], v = p[(size_t)(k + 4) * 4];
+    for (; k + SUBS < b; k += 2 * SUBS) {
+        const float4 u = p[(size_t)k * 4], v = p[(size_t)(k + SUBS) * 4];
         s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
         s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
     }
@@ -728,9 +731,17 @@ slot_reduce16_kernel(int n_gauss, int channels, int has_extra, const int32_t* __
     }
     float acc[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {  // sum over the four sub-groups (lanes l, l^4, l^8, l^12 of the 16-lane row)
-        acc[i] = dpp_add<0x124>(acc[i]);  // row_ror:4
-        acc[i] = dpp_add<0x128>(acc[i]);  // row_ror:8
+    for (int i = 0; i < 4; ++i) {  // sum over the sub-groups (lanes l, l^4[, l^8, l^12] of the row)
+        if (SUBS == 4) {
+            acc[i] = dpp_add<0x124>(acc[i]);  // row_ror:4
+            acc[i] = dpp_add<0x128>(acc[i]);  // row_ror:8
+        } else if (SUBS == 2) {
+            // lane l of an 8-lane group with l ^ 4: row_half_mirror pairs l with 7 - l (other quarter!), so use the
+            // two masked shifts instead: banks {0, 2} take lane + 4, banks {1, 3} lane - 4
+            const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[i]), 0x104, 0xF, 0x5, true));
+            const float dn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[i]), 0x114, 0xF, 0xA, true));
+            acc[i] = acc[i] + (up + dn);
+        }
     }
     if (!live || sub != 0) return;
     const size_t g = (size_t)gid;
@@ -924,7 +935,7 @@ int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int
                                has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities, v_colors,
                                v_extra);
         } else if (stride == 16) {
-            hipLaunchKernelGGL(slot_reduce16_kernel, dim3((int)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, n,
+            hipLaunchKernelGGL(slot_reduce16_kernel<8>, dim3((int)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
                                v_colors, v_extra);
         } else if (stride <= 16) {
