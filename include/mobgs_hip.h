@@ -175,6 +175,11 @@ int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, 
  * capacity_box / capacity_listed) every per-tile list was written EMPTY: compositing kernels enqueued in the
  * meantime are harmless no-ops, and the caller redoes the binning with a larger arena (mobgs_isect_offsets +
  * mobgs_isect_emit_sort on the projection outputs, which do not depend on the arena).
+ * stats_host_pinned holds FOUR words: {I_box, I_listed, longest list, sequence}.  With stats_seq != 0 and a pinned
+ * buffer that is mapped into the device address space, the last binning kernel stores the three counts and then
+ * stats_seq into word 3 (system-scope release): the caller clears word 3 beforehand and simply polls it -- no event,
+ * hence no marker packet between the binning and the compositing kernels.  Return value 0 says so; 1 means the
+ * counts travel by an asynchronous copy and the caller waits on an event recorded after this call, as before.
  * pack_records (optional, else NULL): [C*N, mobgs_record_stride(pack_channels + 1)] -- the projection kernel also
  * writes the compositor's packed records {means2d, conic, opacity, pack_colors, depth as the extra channel} of the
  * visible splats (what mobgs_pack_records / mobgs_raster_fwd would do in a launch of its own); hand them to
@@ -187,8 +192,9 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
                                       int32_t* tile_offsets, int32_t* tile_order, int64_t* stats_dev,
                                       int capacity_box, int32_t* keep_scan, void* scratch, int64_t capacity_listed,
                                       int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
-                                      int64_t max_tile_len_hint, int64_t* stats_host_pinned, const float* pack_colors,
-                                      int colors_per_camera, int pack_channels, float* pack_records, void* stream);
+                                      int64_t max_tile_len_hint, int64_t* stats_host_pinned, int64_t stats_seq,
+                                      const float* pack_colors, int colors_per_camera, int pack_channels,
+                                      float* pack_records, void* stream);
 
 /* ---- K6: rasterise forward (replaces gsplat rasterize_to_pixels fwd) -----------------------------------
  * colors   : [C,N,channels] (colors_per_camera=1) or [N,channels] (0); NULL: `records` are already packed (by

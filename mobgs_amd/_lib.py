@@ -45,7 +45,7 @@ _SIGS = {
     "mobgs_isect_emit_sort_speculative": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int64, c_int64] + [P] * 8 + [P]),
     "mobgs_project_and_bin_speculative": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float,
                                                   c_float, c_float, c_float, c_int, P, P, P, P, P, P, P, P, P, c_int,
-                                                  P, P, c_int64, P, P, P, c_int64, P, P, c_int, c_int, P, P]),
+                                                  P, P, c_int64, P, P, P, c_int64, P, c_int64, P, c_int, c_int, P, P]),
     "mobgs_densify_stats": (c_int, [c_int, P, c_int, P, P, P, P, P, P]),
     "mobgs_densify_select": (c_int, [c_int, c_int, P, P, P, c_float, c_float, P, P, P]),
     "mobgs_mask_indices": (c_int, [c_int, P, c_int, P, P, P]),

@@ -167,12 +167,12 @@ int project_fwd_launch(int C, int N, const float* means, const float* quats, con
                        float radius_clip, int32_t* radii, float* means2d, float* depths, float* conics,
                        int32_t* tiles_per_gauss, int32_t* zero_ptr, size_t zero_n, PackArgs pack, void* stream);
 // mobgs_isect_offsets; scratch_zeroed: the counters were cleared by the caller; stats_mirror: device-visible host
-// address that receives a copy of stats[0..2] (or NULL)
+// address that receives a copy of stats[0..2] (or NULL) and then, in word 3, stats_seq (when non-zero)
 int isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
                          const int32_t* tiles_per_gauss, const float* means2d, const int32_t* radii, const float* conics,
                          const float* opacities, int opac_per_camera, int32_t* cum_tiles, int32_t* keep_scan,
                          int32_t* tile_offsets, int32_t* tile_order, int64_t capacity_listed, int64_t* stats,
-                         void* scratch, bool scratch_zeroed, int64_t* stats_mirror, void* stream);
+                         void* scratch, bool scratch_zeroed, int64_t* stats_mirror, int64_t stats_seq, void* stream);
 void isect_zeroed_region(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity, int32_t** ptr, size_t* count);
 
 // bit q = 2 * qy + qx set <=> the splat may reach alpha >= 1/255 at a pixel centre of the 8x8 quadrant (qx, qy) of

@@ -321,7 +321,8 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
                                                                     int32_t* __restrict__ tile_order,
                                                                     int64_t capacity_box, int64_t capacity_listed,
                                                                     int32_t* __restrict__ keep_scan, int n_chunks,
-                                                                    int heavy_len, int64_t* stats_mirror) {
+                                                                    int heavy_len, int64_t* stats_mirror,
+                                                                    int64_t stats_seq) {
     __shared__ int smax[TSCAN_THREADS / 64];
     __shared__ int hist[ORDER_BUCKETS];
     // workgroup 1: chunk totals -> chunk bases of keep_scan (bin_kernel left each chunk's total in its base
@@ -370,6 +371,10 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
             stats_mirror[1] = (int64_t)carry;
             stats_mirror[2] = (int64_t)longest;
             __threadfence_system();
+            // sequence number LAST: a host that polls this word needs no event (no marker packet in the queue)
+            if (stats_seq) {
+                __hip_atomic_store(&stats_mirror[3], stats_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     // Arena too small (only checked when the caller runs ahead of the read-back, capacity_listed > 0): hand every
@@ -966,7 +971,7 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
     return mobgs::isect_offsets_launch(C, N, tile_w, tile_h, width, height, cull, capacity, tiles_per_gauss, means2d, radii,
                                        conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order,
                                        capacity_listed, stats, scratch, /*scratch_zeroed=*/false, /*stats_mirror=*/nullptr,
-                                       stream);
+                                       /*stats_seq=*/0, stream);
 }
 
 }  // extern "C"
@@ -983,7 +988,7 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
                                 const float* conics, const float* opacities, int opac_per_camera, int32_t* cum_tiles,
                                 int32_t* keep_scan, int32_t* tile_offsets, int32_t* tile_order, int64_t capacity_listed,
                                 int64_t* stats, void* scratch, bool scratch_zeroed, int64_t* stats_mirror,
-                                void* stream) {
+                                int64_t stats_seq, void* stream) {
     const long long ng = (long long)C * N;
     const long long nt = (long long)C * tile_w * tile_h;
     if (C <= 0 || N < 0 || capacity < 1 || ng >= (1ll << 31) - 1 || nt >= (1ll << 31) - 1) {
@@ -1005,7 +1010,7 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
         hipMemsetAsync(stats, 0, 3 * sizeof(int64_t), st);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
                            stats, tile_order, (int64_t)capacity, (int64_t)0, (int32_t*)nullptr, 0, g_heavy_len,
-                           stats_mirror);
+                           stats_mirror, stats_seq);
         return check_launch("isect_offsets(empty)");
     }
     // bounding-box counts -> cum_tiles; stats[0] = I_box
@@ -1026,7 +1031,7 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
                            L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
                        stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, g_heavy_len,
-                       stats_mirror);
+                       stats_mirror, stats_seq);
     return check_launch("isect_offsets");
 }
 

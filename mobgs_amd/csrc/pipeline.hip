@@ -61,8 +61,9 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
                                       int32_t* tile_offsets, int32_t* tile_order, int64_t* stats_dev,
                                       int capacity_box, int32_t* keep_scan, void* scratch, int64_t capacity_listed,
                                       int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
-                                      int64_t max_tile_len_hint, int64_t* stats_host_pinned, const float* pack_colors,
-                                      int colors_per_camera, int pack_channels, float* pack_records, void* stream) {
+                                      int64_t max_tile_len_hint, int64_t* stats_host_pinned, int64_t stats_seq,
+                                      const float* pack_colors, int colors_per_camera, int pack_channels,
+                                      float* pack_records, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
     if (!stats_host_pinned || capacity_listed < 1) {
@@ -98,7 +99,8 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
     }
     rc = mobgs::isect_offsets_launch(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d, radii,
                                      conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order,
-                                     capacity_listed, stats_dev, scratch, fuse_zero, (int64_t*)mirror, stream);
+                                     capacity_listed, stats_dev, scratch, fuse_zero, (int64_t*)mirror,
+                                     mirror ? stats_seq : 0, stream);
     if (rc != MOBGS_OK) return rc;
     if (!mirror) {
         hipError_t e = hipMemcpyAsync(stats_host_pinned, stats_dev, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st);
@@ -107,9 +109,13 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
             return MOBGS_E_LAUNCH;
         }
     }
-    return mobgs_isect_emit_sort_speculative(C, N, tile_w, tile_h, capacity_box, capacity_listed, max_tile_len_hint,
-                                             depths, cum_tiles, tile_offsets, stats_dev, scratch, sort_keys,
-                                             flatten_ids, isect_ids, stream);
+    rc = mobgs_isect_emit_sort_speculative(C, N, tile_w, tile_h, capacity_box, capacity_listed, max_tile_len_hint,
+                                           depths, cum_tiles, tile_offsets, stats_dev, scratch, sort_keys, flatten_ids,
+                                           isect_ids, stream);
+    if (rc != MOBGS_OK) return rc;
+    // 1: the counts travel by an ordinary asynchronous copy (or no sequence number was asked for) -- the caller
+    // records an event behind this call and waits on it; 0: poll stats_host_pinned[3] for stats_seq instead
+    return (mirror && stats_seq) ? MOBGS_OK : 1;
 }
 
 }  // extern "C"

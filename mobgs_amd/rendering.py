@@ -148,17 +148,24 @@ class TileLists:
 
 
 class _StatsSlots:
-    """Page-locked landing slots (3 x int64 each) for the asynchronous count read-back, one pool per process."""
+    """Page-locked landing slots (4 x int64 each: three counts + a sequence word the device writes last) for the
+    asynchronous count read-back, one pool per process."""
 
     def __init__(self, n=256):
-        self.block = torch.empty(n, 3, dtype=torch.int64, pin_memory=True)
+        self.block = torch.zeros(n, 4, dtype=torch.int64, pin_memory=True)
+        self.view = self.block.numpy()  # same memory: polled without going through the dispatcher
         self.free = list(range(n))
+        self.seq = 0
 
     def take(self):
         if self.free:
             i = self.free.pop()
             return self.block[i], i
-        return torch.empty(3, dtype=torch.int64, pin_memory=True), None
+        return torch.zeros(4, dtype=torch.int64, pin_memory=True), None
+
+    def next_seq(self) -> int:
+        self.seq += 1
+        return self.seq
 
     def give(self, i):
         if i is not None:
@@ -171,8 +178,8 @@ _stats_slots = None
 class _PendingCounts:
     """The read-back half of a speculative mobgs_project_and_bin_speculative call."""
 
-    def __init__(self, row, slot, event, caps, arenas, rebuild_args):
-        self.row, self.slot, self.event = row, slot, event
+    def __init__(self, row, slot, event, caps, arenas, rebuild_args, seq=0):
+        self.row, self.slot, self.event, self.seq = row, slot, event, seq
         self.caps, self.arenas, self.rebuild_args = caps, arenas, rebuild_args
 
     def __del__(self):
@@ -180,9 +187,26 @@ class _PendingCounts:
             _stats_slots.give(self.slot)
             self.slot = None
 
+    def _wait(self):
+        if self.event is not None:
+            self.event.synchronize()
+            return
+        # the device stores the counts and then the sequence number into the pinned row: poll it (no event was
+        # recorded, so nothing sits between the binning kernels and what was enqueued behind them)
+        import time
+        word = self.row.numpy()
+        deadline = None
+        while int(word[3]) != self.seq:
+            if deadline is None:
+                deadline = time.monotonic() + 10.0
+            elif time.monotonic() > deadline:
+                torch.cuda.synchronize()
+                if int(word[3]) != self.seq:
+                    raise RuntimeError("mobgs: the intersection counts never arrived (device fault?)")
+
     def finish(self, tl) -> bool:
-        self.event.synchronize()
-        n_box, n_isects, max_len = (int(v) for v in self.row.tolist())
+        self._wait()
+        n_box, n_isects, max_len = (int(v) for v in self.row.tolist()[:3])
         _stats_slots.give(self.slot)
         self.slot = None
         key, cap_box, cap_listed = self.caps
@@ -612,26 +636,31 @@ class _ProjectAndBin(torch.autograd.Function):
                 if _stats_slots is None:
                     _stats_slots = _StatsSlots()
                 row, slot = _stats_slots.take()
-                check(lib.mobgs_project_and_bin_speculative(
+                seq = _stats_slots.next_seq()
+                row[3] = 0
+                rc = lib.mobgs_project_and_bin_speculative(
                     C, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), ptr(opac),
                     1 if opac.dim() == 2 else 0, width, height, eps2d, near_plane, far_plane, radius_clip,
                     int(_tile_culling), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(tiles_per_gauss),
                     ptr(cum_tiles), ptr(tile_offsets), ptr(tile_order), ptr(stats_dev), cap_box, ptr(keep_scan),
                     ptr(scratch), cap_listed, ptr(flatten_ids), ptr(sort_keys), ptr(isect_ids),
-                    _len_hint.get(key, 0), ctypes.c_void_p(row.data_ptr()),
+                    _len_hint.get(key, 0), ctypes.c_void_p(row.data_ptr()), seq,
                     ptr(pack_colors) if records is not None else None,
                     1 if (records is not None and pack_colors.dim() == 3) else 0,
-                    pack_colors.shape[-1] if records is not None else 0, ptr(records), stream()),
-                    "mobgs_project_and_bin_speculative")
+                    pack_colors.shape[-1] if records is not None else 0, ptr(records), stream())
+                if rc not in (0, 1):
+                    check(rc, "mobgs_project_and_bin_speculative")
                 tl.records = records
-                event = torch.cuda.Event()
-                event.record()
+                event = None
+                if rc == 1:  # counts by asynchronous copy: wait on an event (0: poll the sequence word)
+                    event = torch.cuda.Event()
+                    event.record()
                 tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
                 tl.cum_tiles, tl.keep_scan, tl.tile_offsets, tl.tile_order = cum_tiles, keep_scan, tile_offsets, tile_order
                 tl.flatten_arena = flatten_ids
                 tl._pending = _PendingCounts(row, slot, event, (key, cap_box, cap_listed), (flatten_ids, isect_ids),
                                              (means2d, radii, depths, conics, opac, tiles_per_gauss, width, height,
-                                              want_isect_ids))
+                                              want_isect_ids), seq)
                 break
             rc = lib.mobgs_project_and_bin(C, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), ptr(opac),
                                            1 if opac.dim() == 2 else 0, width, height, eps2d, near_plane, far_plane,
