@@ -144,6 +144,10 @@ def main():
         shard.all_reduce_gradients(params)
         return out
 
+    # backward on the calling thread: handing each backward pass to autograd's device thread costs ~0.35 ms of
+    # wake-up latency per step on this host (scripts/autograd_threads.py: 30 k splats 0.82 -> 0.47 ms/step; nothing
+    # at 300 k, where the step is GPU-bound) -- the setting a training script on this stack would use
+    torch.autograd.set_multithreading_enabled(False)
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()

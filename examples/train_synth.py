@@ -14,6 +14,8 @@ import sys
 
 import torch
 
+torch.autograd.set_multithreading_enabled(False)  # backward on the calling thread: no device-thread wake-up per step
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mobgs_amd.camera import PinholeCamera  # noqa: E402
 from mobgs_amd.densify import TrainableGaussians  # noqa: E402
