@@ -12,6 +12,10 @@
 //     misses whole quadrants (their code is skipped by a wave-level branch) and fills the ones it hits;
 //   * splats are staged 64 at a time (lane = splat) as packed 16-float records
 //     {x, y, conic a b c, opacity, colour[..]} into a per-wave LDS slab and re-read as broadcasts;
+//   * while a batch is staged every lane also works out which of the four quadrants ITS splat can reach at all
+//     (quadrant_reach_mask, common.h); evaluation and blend of the others are skipped by scalar branches -- ~40 % of
+//     the (entry, quadrant) pairs of a typical list, bit-identical results (mobgs_set_quadrant_culling(0) turns it
+//     off for the test that proves it);
 //   * backward reduces the 6+D per-splat gradient components across the wave with a halving butterfly
 //     (log-depth, D+6 -> 1 value per lane) and writes ONE 64-byte gradient record per (tile, splat) into a
 //     slot owned by that intersection; a second streaming kernel sums each splat's contiguous slots.
