@@ -149,23 +149,33 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
     const int e = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
 
     // software pipeline: the records of batch b+1 are fetched into registers while batch b is blended
-    float4 pre[RQ];
+    constexpr int PQ = RQ < 2 ? RQ : 2;  // prefetched quarters: position, conic, opacity (and 2 colours)
+    float4 pre[PQ];
 #pragma unroll
-    for (int q = 0; q < RQ; ++q) pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < PQ; ++q) pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     bool pre_keep = false;  // FILTER: the prefetched entry belongs to the wanted class
+    int pre_g = 0;
     if (s + lane < e) {
-        const int g = flatten_ids[s + lane];
-        pre_keep = !FILTER || cls.keeps(g);
+        pre_g = flatten_ids[s + lane];
+        pre_keep = !FILTER || cls.keeps(pre_g);
         if (pre_keep) {
-            const float4* r = reinterpret_cast<const float4*>(records + (size_t)g * RS);
+            const float4* r = reinterpret_cast<const float4*>(records + (size_t)pre_g * RS);
 #pragma unroll
-            for (int q = 0; q < RQ; ++q) pre[q] = r[q];
+            for (int q = 0; q < PQ; ++q) pre[q] = r[q];
         }
     }
     for (int b = s; b < e && alive != 0u; b += 64) {
         int n = min(64, e - b);
         wave_lds_fence();
         {
+            // the colour quarters of the record were not prefetched (8 registers fewer across the blend loop): fetch
+            // them now, the reach computation below covers their latency
+            float4 rest[RQ > PQ ? RQ - PQ : 1];
+            if (RQ > PQ && pre_keep) {
+                const float4* r = reinterpret_cast<const float4*>(records + (size_t)pre_g * RS);
+#pragma unroll
+                for (int q = PQ; q < RQ; ++q) rest[q - PQ] = r[q];
+            }
             // which 8x8 quadrants of the tile the splat can reach at all (lane = splat: one test per entry, not per
             // pixel): ~40 % of the (entry, quadrant) pairs of a typical list are out of reach and are never evaluated
             unsigned reach = cls.all_reach ? 0xFu
@@ -182,7 +192,9 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
             }
             if (keep) {
 #pragma unroll
-                for (int q = 0; q < RQ; ++q) slab[wv][pos][q] = pre[q];
+                for (int q = 0; q < PQ; ++q) slab[wv][pos][q] = pre[q];
+#pragma unroll
+                for (int q = PQ; q < RQ; ++q) slab[wv][pos][q] = rest[q - PQ];
                 reach_of[wv][pos] = reach;
                 if (FILTER) idx_of[wv][pos] = b + lane;
             }
@@ -190,12 +202,12 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
         wave_lds_fence();
         pre_keep = false;
         if (b + 64 + lane < e) {
-            const int g = flatten_ids[b + 64 + lane];
-            pre_keep = !FILTER || cls.keeps(g);
+            pre_g = flatten_ids[b + 64 + lane];
+            pre_keep = !FILTER || cls.keeps(pre_g);
             if (pre_keep) {
-                const float4* r = reinterpret_cast<const float4*>(records + (size_t)g * RS);
+                const float4* r = reinterpret_cast<const float4*>(records + (size_t)pre_g * RS);
 #pragma unroll
-                for (int q = 0; q < RQ; ++q) pre[q] = r[q];
+                for (int q = 0; q < PQ; ++q) pre[q] = r[q];
             }
         }
         const unsigned reach_lane = reach_of[wv][lane];  // lane j: the mask of staged entry j
