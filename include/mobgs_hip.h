@@ -203,13 +203,16 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
  * extra    : optional [C,N] channel appended after `channels` (gsplat's "+D"/"+ED" depth channel), or NULL
  * backgrounds: [C, channels(+1 if extra)] or NULL
  * records  : scratch/out [C*N, mobgs_record_stride(D)] packed splat records (kept for backward), D = total
- * out: render [C,H,W,D], alphas [C,H,W], last_ids [C,H,W] (index into flatten_ids of the last blended splat) */
+ * out: render [C,H,W,D], alphas [C,H,W], last_ids [C,H,W] (index into flatten_ids of the last blended splat)
+ * isect_reach (optional out, else NULL): [I_listed] bytes -- per list entry, the 8x8 quadrants of its tile the splat
+ *   can reach (what the kernel computes anyway to skip the others); hand it to mobgs_raster_bwd for the same lists and
+ *   the backward pass does not recompute it */
 int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const float* means2d,
                      const float* conics, const float* colors, int colors_per_camera,
                      const float* opacities, int opac_per_camera, const float* extra,
                      const float* backgrounds, const int32_t* radii, const int32_t* tile_offsets,
                      const int32_t* tile_order, const int32_t* flatten_ids, float* records, float* render,
-                     float* alphas, int32_t* last_ids, void* stream);
+                     float* alphas, int32_t* last_ids, uint8_t* isect_reach, void* stream);
 
 /* ---- K7: rasterise backward (replaces gsplat rasterize_to_pixels bwd) ----------------------------------
  * Deterministic two-stage gradient reduction, no floating-point atomics:
@@ -225,7 +228,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
                      const float* means2d, const int32_t* cum_tiles, const int32_t* keep_scan,
                      const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
                      const float* render_alphas, const int32_t* last_ids, const float* v_render,
-                     const float* v_alphas, float* grad_slots, void* stream);
+                     const float* v_alphas, float* grad_slots, const uint8_t* isect_reach, void* stream);
 int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int32_t* cum_tiles,
                             const int32_t* keep_scan, const float* grad_slots, float* v_means2d, float* v_conics, float* v_opacities,
                             float* v_colors, float* v_extra, void* stream);
@@ -316,13 +319,13 @@ int mobgs_normals_bwd(int H, int W, float fx, float fy, float cx, float cy, floa
 int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_total, int width, int height,
                            const float* records, const float* backgrounds, const int32_t* tile_offsets,
                            const int32_t* tile_order, const int32_t* flatten_ids, float* render, float* alphas,
-                           int32_t* last_ids, void* stream);
+                           int32_t* last_ids, uint8_t* isect_reach, void* stream);
 int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_total, int width, int height,
                            const float* records, const float* backgrounds, const int32_t* radii,
                            const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
                            const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
                            const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
-                           void* stream);
+                           const uint8_t* isect_reach, void* stream);
 
 /* 1 if raster kernels are compiled for `total_channels` (colour channels + optional extra channel). */
 int mobgs_raster_channels_supported(int total_channels);

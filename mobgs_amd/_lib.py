@@ -37,8 +37,8 @@ _SIGS = {
     "mobgs_isect_offsets": (c_int, [c_int] * 8 + [P] * 5 + [c_int] + [P] * 4 + [c_int64] + [P] * 2 + [P]),
     "mobgs_isect_emit_sort": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int64, c_int64] + [P] * 7 + [P]),
     "mobgs_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, P, P,
-                                 P, P, P, P]),
-    "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int] + [P] * 14 + [P]),
+                                 P, P, P, P, P]),
+    "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int] + [P] * 15 + [P]),
     "mobgs_raster_bwd_reduce": (c_int, [c_int, c_int, c_int, c_int] + [P] * 8 + [P]),
     "mobgs_project_and_bin": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
                                       c_float, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, P, P, P]),
@@ -53,8 +53,8 @@ _SIGS = {
     "mobgs_split_children": (c_int, [c_int, c_int, c_int, P, P, P, P, P]),
     "mobgs_normals_fwd": (c_int, [c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P]),
     "mobgs_normals_bwd": (c_int, [c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P, P]),
-    "mobgs_raster_class_fwd": (c_int, [c_int] * 7 + [P] * 8 + [P]),
-    "mobgs_raster_class_bwd": (c_int, [c_int] * 7 + [P] * 13 + [P]),
+    "mobgs_raster_class_fwd": (c_int, [c_int] * 7 + [P] * 9 + [P]),
+    "mobgs_raster_class_bwd": (c_int, [c_int] * 7 + [P] * 14 + [P]),
     "mobgs_pack_records": (c_int, [c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P]),
     "mobgs_raster_layers_fwd": (c_int, [c_int] * 7 + [P] * 8 + [P]),
     "mobgs_raster_layers_bwd": (c_int, [c_int] * 8 + [P] * 20 + [P]),  # incl. 7 host pointer arrays of length 3

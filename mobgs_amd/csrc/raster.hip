@@ -113,7 +113,8 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
                                               const float* __restrict__ backgrounds,
                                               const int32_t* __restrict__ tile_offsets,
                                               const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
-                                              float* __restrict__ alphas, int32_t* __restrict__ last_ids) {
+                                              float* __restrict__ alphas, int32_t* __restrict__ last_ids,
+                                              uint8_t* __restrict__ isect_reach) {
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
     constexpr int PPL = NP;
@@ -181,6 +182,9 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
             unsigned reach = cls.all_reach ? 0xFu
                                            : quadrant_reach_mask(pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x,
                                                                  pre[1].y, tx, ty);
+            // kept for the backward pass (it walks the same lists): one byte per list entry.  (Heavy tiles: all four
+            // quadrant waves store the same byte -- any of them may leave the walk first.)
+            if (isect_reach && b + lane < e && (!FILTER || pre_keep)) isect_reach[b + lane] = (uint8_t)reach;
             if (NP == 1) reach = (reach >> quad) & 1u;
             int pos = lane;
             bool keep = true;
@@ -264,7 +268,7 @@ raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
                   const float* __restrict__ records, const float* __restrict__ backgrounds,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
                   float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
-                  const int32_t* __restrict__ tile_order, ClassSel cls) {
+                  const int32_t* __restrict__ tile_order, ClassSel cls, uint8_t* __restrict__ isect_reach) {
     constexpr int RQ = ((6 + CD + 3) & ~3) / 4;
     __shared__ float4 slab[TILES_PER_WG][64][RQ];
     __shared__ int idx_of[FILTER ? TILES_PER_WG : 1][64];
@@ -274,10 +278,10 @@ raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
     if (slot < 0) return;
     if (slot & SCHED_HEAVY)
         composite_fwd<CD, 1, FILTER>(slot & ~SCHED_HEAVY, wv, wv, lane, slab, idx_of, reach_of, cls, tile_w, tile_h, width, height,
-                                     records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids);
+                                     records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids, isect_reach);
     else
         composite_fwd<CD, 4, FILTER>(slot, 0, wv, lane, slab, idx_of, reach_of, cls, tile_w, tile_h, width, height, records,
-                                     backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids);
+                                     backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids, isect_reach);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -448,7 +452,8 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                                               const float* __restrict__ render_alphas,
                                               const int32_t* __restrict__ last_ids,
                                               const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                                              float* __restrict__ grad_slots) {
+                                              float* __restrict__ grad_slots,
+                                              const uint8_t* __restrict__ isect_reach) {
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
     constexpr int NV = 6 + CD;
@@ -542,8 +547,11 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                 slab[wv][pos][1] = r1;
 #pragma unroll
                 for (int q = 2; q < RQ; ++q) slab[wv][pos][q] = r[q];
-                sh.reach_of[wv][pos] =
-                    cls.all_reach ? 0xFu : quadrant_reach_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty);
+                // the forward pass left the masks of these very lists behind (isect_reach); else recompute
+                sh.reach_of[wv][pos] = isect_reach ? (unsigned)isect_reach[hi - lane]
+                                       : cls.all_reach
+                                           ? 0xFu
+                                           : quadrant_reach_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty);
                 const TileRect tr = tile_rect(r0.x, r0.y, radii[g], tile_w, tile_h);
                 slot_of[wv][pos] = keep_index(keep_scan, cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0));
                 if (FILTER) sh.idx_of[wv][pos] = hi - lane;
@@ -653,7 +661,8 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
                   const int32_t* __restrict__ flatten_ids, const float* __restrict__ render_alphas,
                   const int32_t* __restrict__ last_ids,
                   const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                  float* __restrict__ grad_slots, const int32_t* __restrict__ tile_order, ClassSel cls) {
+                  float* __restrict__ grad_slots, const int32_t* __restrict__ tile_order, ClassSel cls,
+                  const uint8_t* __restrict__ isect_reach) {
     __shared__ BwdShared<CD> sh;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
@@ -661,11 +670,11 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
     if (slot & SCHED_HEAVY)  // workgroup-uniform: all 4 slots of a heavy workgroup carry the flag
         composite_bwd<CD, 1, FILTER>(slot & ~SCHED_HEAVY, wv, wv, lane, sh, cls, tile_w, tile_h, width, height, records,
                                      backgrounds, radii, cum_tiles, keep_scan, tile_offsets, flatten_ids,
-                                     render_alphas, last_ids, v_render, v_alphas, grad_slots);
+                                     render_alphas, last_ids, v_render, v_alphas, grad_slots, isect_reach);
     else
         composite_bwd<CD, 4, FILTER>(slot, 0, wv, lane, sh, cls, tile_w, tile_h, width, height, records, backgrounds,
                                      radii, cum_tiles, keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids,
-                                     v_render, v_alphas, grad_slots);
+                                     v_render, v_alphas, grad_slots, isect_reach);
 }
 
 
@@ -831,7 +840,8 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
                      const float* conics, const float* colors, int colors_per_camera, const float* opacities,
                      int opac_per_camera, const float* extra, const float* backgrounds, const int32_t* radii,
                      const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
-                     float* records, float* render, float* alphas, int32_t* last_ids, void* stream) {
+                     float* records, float* render, float* alphas, int32_t* last_ids, uint8_t* isect_reach,
+                     void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int D = channels + (extra ? 1 : 0);
     if (C <= 0 || N < 0 || channels < 0 || D < 1 || width <= 0 || height <= 0) {
@@ -852,7 +862,7 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
         constexpr int CD = decltype(cd)::value;
         hipLaunchKernelGGL((raster_fwd_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
                            tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render,
-                           alphas, last_ids, tile_order, ClassSel{0, 1, 0, g_all_reach});
+                           alphas, last_ids, tile_order, ClassSel{0, 1, 0, g_all_reach}, isect_reach);
     });
     if (rc != MOBGS_OK) {
         set_error("mobgs_raster_fwd: %d total channels not compiled in (pad to a supported count)", D);
@@ -866,7 +876,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
                      const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
                      const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
                      const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
-                     void* stream) {
+                     const uint8_t* isect_reach, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     (void)means2d;
     const int D = channels + (has_extra ? 1 : 0);
@@ -884,7 +894,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
         hipLaunchKernelGGL((raster_bwd_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
                            tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan,
                            tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots,
-                           tile_order, ClassSel{0, 1, 0, g_all_reach});
+                           tile_order, ClassSel{0, 1, 0, g_all_reach}, isect_reach);
     });
     if (rc != MOBGS_OK) {
         set_error("mobgs_raster_bwd: %d total channels not compiled in", D);
@@ -897,7 +907,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
 int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_total, int width, int height,
                            const float* records, const float* backgrounds, const int32_t* tile_offsets,
                            const int32_t* tile_order, const int32_t* flatten_ids, float* render, float* alphas,
-                           int32_t* last_ids, void* stream) {
+                           int32_t* last_ids, uint8_t* isect_reach, void* stream) {
     if (C <= 0 || N <= 0 || Ns < 0 || Ns > N || (class_sel != 1 && class_sel != 2) || channels_total != 10) {
         set_error("mobgs_raster_class_fwd: unsupported arguments (C=%d N=%d Ns=%d class=%d D=%d)", C, N, Ns, class_sel,
                   channels_total);
@@ -909,7 +919,7 @@ int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_tot
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
     hipLaunchKernelGGL((raster_fwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream, nt,
                        n_groups, tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render,
-                       alphas, last_ids, tile_order, ClassSel{class_sel, N, Ns, g_all_reach});
+                       alphas, last_ids, tile_order, ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach);
     return check_launch("raster_fwd_kernel(class)");
 }
 
@@ -918,7 +928,7 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
                            const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
                            const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
                            const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
-                           void* stream) {
+                           const uint8_t* isect_reach, void* stream) {
     if (C <= 0 || N <= 0 || Ns < 0 || Ns > N || (class_sel != 1 && class_sel != 2) || channels_total != 10) {
         set_error("mobgs_raster_class_bwd: unsupported arguments");
         return MOBGS_E_UNSUPPORTED;
@@ -930,7 +940,7 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
     hipLaunchKernelGGL((raster_bwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream, nt,
                        n_groups, tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan,
                        tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots, tile_order,
-                       ClassSel{class_sel, N, Ns, g_all_reach});
+                       ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach);
     return check_launch("raster_bwd_kernel(class)");
 }
 

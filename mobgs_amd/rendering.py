@@ -334,19 +334,25 @@ class _Rasterize(torch.autograd.Function):
         render = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
         alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+        # per list entry: the quadrants of its tile the splat can reach -- computed by the forward kernel anyway,
+        # kept for the backward pass over the same lists
+        reach = torch.empty(max(tl.flatten_arena.numel(), 1), dtype=torch.uint8, device=dev)
         with profiler.region("raster_fwd"):
             while True:
+                if reach.numel() < tl.flatten_arena.numel():  # lists rebuilt into a larger arena
+                    reach = torch.empty(tl.flatten_arena.numel(), dtype=torch.uint8, device=dev)
                 check(lib.mobgs_raster_fwd(C, N, channels, width, height, ptr(means2d), ptr(conics), ptr(colors_arg),
                                            colors_per_camera, ptr(opacities), opac_per_camera, ptr(extra), ptr(bg),
                                            ptr(radii), ptr(tl.tile_offsets), ptr(tl.tile_order),
                                            ptr(tl.flatten_arena), ptr(records), ptr(render), ptr(alphas),
-                                           ptr(last_ids), stream()), "mobgs_raster_fwd")
+                                           ptr(last_ids), ptr(reach), stream()), "mobgs_raster_fwd")
                 # speculative lists whose arena was too small get rebuilt by resolve(): composite again.  A caller that
                 # wants to enqueue more work before waiting for the counts sets tl.defer and does this itself.
                 if tl.defer or not tl.resolve():
                     break
-        ctx.save_for_backward(records, bg, radii, means2d, alphas, last_ids)
+        ctx.save_for_backward(records, bg, radii, means2d, alphas, last_ids, reach)
         ctx.tl = tl
+        ctx.arena = tl.flatten_arena  # the lists `reach` belongs to (a rebuild replaces the arena)
         ctx.meta = (C, N, channels, extra is not None, width, height, colors_per_camera, opac_per_camera)
         ctx.bg_needs_grad = backgrounds is not None and backgrounds.requires_grad
         return render, alphas.unsqueeze(-1)
@@ -354,8 +360,10 @@ class _Rasterize(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_render, v_alphas):
         lib = _lib_()
-        records, bg, radii, means2d, alphas, last_ids = ctx.saved_tensors
+        records, bg, radii, means2d, alphas, last_ids, reach = ctx.saved_tensors
         tl = ctx.tl
+        if tl.flatten_arena is not ctx.arena:  # lists rebuilt after this forward ran (deferred resolve): recompute
+            reach = None
         C, N, channels, has_extra, width, height, colors_per_camera, opac_per_camera = ctx.meta
         dev = records.device
         D = channels + (1 if has_extra else 0)
@@ -373,7 +381,8 @@ class _Rasterize(torch.autograd.Function):
                                        ptr(radii), ptr(means2d), ptr(tl.cum_tiles), ptr(tl.keep_scan),
                                        ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas),
                                        ptr(last_ids),
-                                       ptr(v_render), ptr(v_alphas), ptr(slots), stream()), "mobgs_raster_bwd")
+                                       ptr(v_render), ptr(v_alphas), ptr(slots), ptr(reach), stream()),
+                  "mobgs_raster_bwd")
         check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(tl.cum_tiles), ptr(tl.keep_scan),
                                           ptr(slots),
                                           ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra),
@@ -526,7 +535,7 @@ class _RasterizeClasses(torch.autograd.Function):
                 while True:
                     check(lib.mobgs_raster_class_fwd(C, N, Ns, cls, D, width, height, ptr(records), ptr(bg),
                                                      ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_arena),
-                                                     ptr(render), ptr(alphas), ptr(last), stream()),
+                                                     ptr(render), ptr(alphas), ptr(last), None, stream()),
                           "mobgs_raster_class_fwd")
                     if not tl.resolve():
                         break
@@ -569,7 +578,7 @@ class _RasterizeClasses(torch.autograd.Function):
                 check(lib.mobgs_raster_class_bwd(C, N, Ns, cls, D, width, height, ptr(records), ptr(bg), ptr(radii),
                                                  ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(tl.tile_offsets),
                                                  ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas), ptr(last),
-                                                 ptr(v_render), ptr(v_alpha), ptr(slots), stream()),
+                                                 ptr(v_render), ptr(v_alpha), ptr(slots), None, stream()),
                       "mobgs_raster_class_bwd")
         v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
         v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
