@@ -525,6 +525,9 @@ class _RasterizeClasses(torch.autograd.Function):
                                          1 if opacities.dim() == 2 else 0, ptr(extra), ptr(radii), ptr(records),
                                          stream()), "mobgs_pack_records")
         outs = {}
+        # quadrant masks per list entry, written by the forward passes (each for the entries of its class) and read
+        # back by the backward passes over the same lists
+        reach = torch.empty(max(tl.flatten_arena.numel(), 1), dtype=torch.uint8, device=dev)
         with profiler.region("raster_class_fwd"):
             for cls in (1, 2):
                 if not (mask >> cls) & 1:
@@ -533,9 +536,11 @@ class _RasterizeClasses(torch.autograd.Function):
                 alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
                 last = torch.empty(C, height, width, dtype=torch.int32, device=dev)
                 while True:
+                    if reach.numel() < tl.flatten_arena.numel():  # lists rebuilt into a larger arena
+                        reach = torch.empty(tl.flatten_arena.numel(), dtype=torch.uint8, device=dev)
                     check(lib.mobgs_raster_class_fwd(C, N, Ns, cls, D, width, height, ptr(records), ptr(bg),
                                                      ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_arena),
-                                                     ptr(render), ptr(alphas), ptr(last), None, stream()),
+                                                     ptr(render), ptr(alphas), ptr(last), ptr(reach), stream()),
                           "mobgs_raster_class_fwd")
                     if not tl.resolve():
                         break
@@ -546,6 +551,7 @@ class _RasterizeClasses(torch.autograd.Function):
                 saved += [outs[cls][1], outs[cls][2]]
         ctx.save_for_backward(*saved)
         ctx.tl = tl
+        ctx.reach, ctx.arena = reach, tl.flatten_arena
         ctx.meta = (C, N, channels, width, height, colors.dim() == 3, opacities.dim() == 2, Ns, mask)
         empty = means2d.new_empty(0)
         res = []
@@ -563,6 +569,7 @@ class _RasterizeClasses(torch.autograd.Function):
         D = channels + 1
         stride = records.shape[1]
         slots = torch.zeros(max(tl.n_isects, 1), stride, dtype=torch.float32, device=dev)
+        reach = ctx.reach if tl.flatten_arena is ctx.arena else None
         it = iter(rest)
         with profiler.region("raster_class_bwd"):
             for i, cls in enumerate((1, 2)):
@@ -578,7 +585,7 @@ class _RasterizeClasses(torch.autograd.Function):
                 check(lib.mobgs_raster_class_bwd(C, N, Ns, cls, D, width, height, ptr(records), ptr(bg), ptr(radii),
                                                  ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(tl.tile_offsets),
                                                  ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas), ptr(last),
-                                                 ptr(v_render), ptr(v_alpha), ptr(slots), None, stream()),
+                                                 ptr(v_render), ptr(v_alpha), ptr(slots), ptr(reach), stream()),
                       "mobgs_raster_class_bwd")
         v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
         v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
