@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
 }
 
 // Pass B: streaming scatter of the 64-bit sort keys into the tile-contiguous segments
-__global__ void __launch_bounds__(256) emit_kernel(const int32_t* __restrict__ n_box_ptr,
+__global__ void __launch_bounds__(1024) emit_kernel(const int32_t* __restrict__ n_box_ptr,
                                                      const int32_t* __restrict__ chunk_cnt,
                                                      const int32_t* __restrict__ owner,
                                                      const int32_t* __restrict__ tile_of_j,
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256) emit_kernel(const int32_t* __restrict__ n
     const int n_chunks = (I + KEEP_CHUNK - 1) >> KEEP_CHUNK_LOG2;
     for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const int cnt = chunk_cnt[chunk];
-        for (int l = threadIdx.x; l < cnt; l += 256) {
+        for (int l = threadIdx.x; l < cnt; l += 1024) {  // two rounds per chunk at most
             const int j = (chunk << KEEP_CHUNK_LOG2) + l;
             const int g = owner[j];
             const uint32_t db = __float_as_uint(depths[g]);
@@ -1053,7 +1053,7 @@ static int emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t
     const int n = C * N;
     // the compacted (owner, tile, rank) arrays pass A left in the scratch buffer of mobgs_isect_offsets
     const IsectScratch L(const_cast<void*>(offsets_scratch), (size_t)n, (size_t)nt, (size_t)capacity);
-    hipLaunchKernelGGL(emit_kernel, dim3(4096), dim3(256), 0, st, cum_tiles + n, L.chunk_cnt, L.owner, L.tile_of_j,
+    hipLaunchKernelGGL(emit_kernel, dim3(4096), dim3(1024), 0, st, cum_tiles + n, L.chunk_cnt, L.owner, L.tile_of_j,
                        L.rank_of_j, depths, tile_offsets, sort_keys, capacity, stats_dev, capacity_listed);
     // gsplat: tile_n_bits = floor(log2(n_tiles)) + 1
     int tile_bits = 0;
