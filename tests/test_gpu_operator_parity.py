@@ -230,6 +230,26 @@ def test_quadrant_reach_masks_change_nothing(hip_device, mode, channels, tile_cu
         assert torch.equal(res[1][2][k], res[0][2][k]), f"grad[{k}] differs"
 
 
+def test_counts_reach_the_host_without_an_event(hip_device):
+    """Speculative binning: the last binning kernel stores {I_box, I, longest list} and then a sequence number into
+    the caller's pinned, device-mapped slot; the host polls that word.  No event is recorded (no marker packet
+    between the binning kernels and the compositing launch) and the counts are the synchronous path's."""
+    from mobgs_amd import rendering
+    n, w, h = 5000, 176, 144
+    s, _ = _scene(n, w, h, 13, 3)
+    d = _to(s, hip_device)
+    assert rendering.SPECULATIVE_BINNING
+    sp = rendering.SharedProjection(d["means"], d["quats"], d["scales"], d["opacities"], d["viewmats"], d["Ks"], w, h)
+    pend = sp.tl._pending
+    assert pend is not None and pend.event is None and pend.seq > 0
+    n_spec = sp.tl.n_isects  # resolves by polling
+    assert not sp.tl.pending
+    tl = rendering.build_tile_lists(sp.means2d.detach(), sp.radii, sp.depths.detach(), sp.conics.detach(),
+                                    d["opacities"], sp.tiles_per_gauss, w, h)
+    assert n_spec == tl.n_isects and n_spec > 0
+    assert torch.equal(sp.tl.tile_offsets.cpu(), tl.tile_offsets.cpu())
+
+
 def test_tile_schedule_is_a_permutation_and_changes_nothing(hip_device):
     """TileLists.tile_order: every tile exactly once, list lengths non-increasing up to the width of one length
     class; images and gradients are bit-identical with the schedule on or off (it only reorders workgroups)."""
