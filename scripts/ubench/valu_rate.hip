@@ -19,9 +19,15 @@ __global__ void __launch_bounds__(256) k(float* out, int iters) {
         } else if (MODE == 2) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) a[i] = __builtin_amdgcn_exp2f(a[i] * 1e-3f);
-        } else {
+        } else if (MODE == 3) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) a[i] = (a[i] > c) ? a[i] * m : c;  // cmp + cndmask + mul
+        } else if (MODE == 4) {  // 8 x v_mov_b64 (is a 64-bit move one pass or two?)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_mov_b64 %0, %1" : "=v"(p[i]) : "v"(p[(i + 1) & 7]));
+        } else {                 // 16 x v_mov_b32
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 15]));
         }
     }
     float s = 0;
@@ -54,5 +60,7 @@ int main() {
     run<1>("v_pk_fma_f32", 8);
     run<2>("v_mul + v_exp_f32", 32);
     run<3>("v_cmp + v_cndmask + v_mul", 48);
+    run<4>("v_mov_b64", 8);
+    run<5>("v_mov_b32", 16);
     return 0;
 }
