@@ -388,7 +388,19 @@ int mobgs_decoder_bwd(int P, int CF, int has_depth, int width, const float* feat
  *                      v_pts [N,3] (ADDED to its current content), v_times [N] (written)
  * mobgs_deform_mlp_fwd: feat + pts/scales/rots [N,3]/[N,3]/[N,4] -> out_pts, out_scales, out_rots (MFMA fp32).
  *   Weights K-major: W0t [96,128], b0 [128], W1t [3,128,128], b1 [3,128], W2t [3,128,32] (7/3/4 real columns,
- *   zero padded), b2 [3,32]; head order: position, scale, rotation. */
+ *   zero padded), b2 [3,32]; head order: position, scale, rotation.
+ *   o_raw [N,16] (may be NULL): the 14 raw head outputs per point (position 0..6, scale 7..9, rotation 10..13),
+ *   all the backward pass keeps of the forward pass.
+ * mobgs_deform_mlp_bwd: replaces torch autograd over the reference's nn.Sequential heads
+ *   (/root/reference/scene/deformation.py:56-73,158-199).  Recomputes the hidden activations from `feat`, then
+ *   data gradients (v_feat [N,96], v_pts [N,3], v_rots [N,4], all WRITTEN; the scale input's cotangent is
+ *   v_out_scales itself) and weight gradients, everything on fp32 MFMA.  Besides the K-major W0t / W1t it reads
+ *   the weights in their original (out, in) layouts: W0 [128,96], W1 [3,128,128], W2pad [3,8,128] (rows >= 7/3/4
+ *   zero).  v_out_* may be NULL (zero cotangent).  v_o: scratch [N,16] (cotangents of the raw head outputs).
+ *   partials: scratch of mobgs_deform_mlp_bwd_blocks(N) x
+ *   mobgs_deform_mlp_grad_floats() floats (one block of partial sums per workgroup, reduced in workgroup order:
+ *   deterministic).  grads (mobgs_deform_mlp_grad_floats() = 66 080 floats, WRITTEN): W0 [128,96] | b0 [128] |
+ *   W1 [3,128,128] | b1 [3,128] | W2 [32,128] (row 8h + o = output o of head h) | b2 [32] (same indexing). */
 int mobgs_hexplane_fwd(int N, const float* pts, const float* times, const float* aabb,
                        const float* const* planes_host, const int32_t* ra_host, const int32_t* rb_host,
                        float* feat, void* stream);
@@ -398,7 +410,15 @@ int mobgs_hexplane_bwd(int N, const float* pts, const float* times, const float*
                        void* stream);
 int mobgs_deform_mlp_fwd(int N, const float* feat, const float* pts, const float* scales, const float* rots,
                          const float* W0t, const float* b0, const float* W1t, const float* b1, const float* W2t,
-                         const float* b2, float* out_pts, float* out_scales, float* out_rots, void* stream);
+                         const float* b2, float* out_pts, float* out_scales, float* out_rots, float* o_raw,
+                         void* stream);
+int mobgs_deform_mlp_bwd_blocks(int N);
+size_t mobgs_deform_mlp_grad_floats(void);
+int mobgs_deform_mlp_bwd(int N, const float* feat, const float* pts, const float* rots, const float* o_raw,
+                         const float* W0t, const float* b0, const float* W1t, const float* b1, const float* W0,
+                         const float* W1, const float* W2pad, const float* v_out_pts, const float* v_out_scales,
+                         const float* v_out_rots, float* v_feat, float* v_pts, float* v_rots, float* v_o,
+                         float* partials, float* grads, void* stream);
 
 /* ---- K11: fused photometric loss (L1 + SSIM), forward and backward -------------------------------------
  * /root/reference/utils/loss_utils.py:233-239 (l1_loss, mask=None), :251-260 + :351-381 (ssim: 11x11 Gaussian

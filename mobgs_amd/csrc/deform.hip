@@ -15,6 +15,8 @@
 //                network (no workgroup barrier): v_mfma_f32_32x32x2_f32 (exact fp32, the vector-rate MFMA) with the
 //                activation tile in a per-wave padded LDS slab and K-major weights streamed from L2.
 //                63 232 MAC per point = 1152 MFMAs per 32 points.
+#include <atomic>
+
 #include "common.h"
 
 namespace mobgs {
@@ -196,7 +198,8 @@ deform_mlp_fwd_kernel(int N, const float* __restrict__ feat, const float* __rest
                       const float* __restrict__ scales, const float* __restrict__ rots,
                       const float* __restrict__ W0t, const float* __restrict__ b0, const float* __restrict__ W1t,
                       const float* __restrict__ b1, const float* __restrict__ W2t, const float* __restrict__ b2,
-                      float* __restrict__ out_pts, float* __restrict__ out_scales, float* __restrict__ out_rots) {
+                      float* __restrict__ out_pts, float* __restrict__ out_scales, float* __restrict__ out_rots,
+                      float* __restrict__ o_raw) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float(*sA)[LDA] = reinterpret_cast<float(*)[LDA]>(lds + (size_t)wv * (2 * 32 * LDA + 32 * 16));
@@ -269,6 +272,10 @@ deform_mlp_fwd_kernel(int N, const float* __restrict__ feat, const float* __rest
         float o[14];
 #pragma unroll
         for (int k = 0; k < 14; ++k) o[k] = sO[lane][k];
+        if (o_raw) {  // what the backward pass needs of the forward: the 14 raw head outputs (64 B per point)
+#pragma unroll
+            for (int k = 0; k < 14; ++k) o_raw[(size_t)n * 16 + k] = o[k];
+        }
         // points: R(quat2mat5(dx[3:7])) (p + dx[0:3])
         const float px = pts[3 * n] + o[0], py = pts[3 * n + 1] + o[1], pz = pts[3 * n + 2] + o[2];
         const float inv5 = 1.f / sqrtf(1.f + o[3] * o[3] + o[4] * o[4] + o[5] * o[5] + o[6] * o[6]);
@@ -353,21 +360,27 @@ int mobgs_hexplane_bwd(int N, const float* pts, const float* times, const float*
 
 int mobgs_deform_mlp_fwd(int N, const float* feat, const float* pts, const float* scales, const float* rots,
                          const float* W0t, const float* b0, const float* W1t, const float* b1, const float* W2t,
-                         const float* b2, float* out_pts, float* out_scales, float* out_rots, void* stream) {
+                         const float* b2, float* out_pts, float* out_scales, float* out_rots, float* o_raw,
+                         void* stream) {
     if (N < 0) {
         set_error("mobgs_deform_mlp_fwd: bad N=%d", N);
         return MOBGS_E_INVALID;
     }
     if (N == 0) return MOBGS_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(deform_mlp_fwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)MLP_LDS_BYTES);
-        attr_set = true;
+    {  // hipFuncSetAttribute is per device: one flag per device ordinal
+        static std::atomic<unsigned long long> done{0};
+        int dev = 0;
+        hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(deform_mlp_fwd_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)MLP_LDS_BYTES);
+            done.fetch_or(bit, std::memory_order_release);
+        }
     }
     const int grid = (N + 127) / 128;
     hipLaunchKernelGGL(deform_mlp_fwd_kernel, dim3(grid), dim3(256), MLP_LDS_BYTES, (hipStream_t)stream, N, feat, pts,
-                       scales, rots, W0t, b0, W1t, b1, W2t, b2, out_pts, out_scales, out_rots);
+                       scales, rots, W0t, b0, W1t, b1, W2t, b2, out_pts, out_scales, out_rots, o_raw);
     return check_launch("deform_mlp_fwd_kernel");
 }
 

@@ -12,11 +12,13 @@ mirrors /root/reference/scene/deformation.py:228-303 (deform_network), :18-199 (
 SURVEY.md section 0, surprise #1: the reference builds, optimises and checkpoints this network but never calls it
 from render(); it is provided because the north star names it (BASELINE config #3).
 
-Compute: HexPlane gather/product in csrc/deform.hip (channels-last planes, 32 lanes = 32 channels of a tap); the
-MLP + update rules in an MFMA kernel (v_mfma_f32_32x32x2_f32, exact fp32).  Backward: the HexPlane part is a HIP
-scatter kernel (plane gradients, point/time gradients); the MLP + update rules back-propagate through plain
-rocBLAS GEMMs (torch.matmul) recomputed from the saved 96-float feature rows -- a hand-written MFMA backward is
-the next step.  Only the configuration the reference trains with is supported
+Compute: HexPlane gather/product in csrc/deform.hip (32 lanes = 32 channels of a tap); the MLP + update rules in
+an MFMA kernel (v_mfma_f32_32x32x2_f32, exact fp32).  Backward: the HexPlane part is a HIP scatter kernel (plane
+gradients, point/time gradients); the MLP + update rules back-propagate in csrc/deform_bwd.hip (recomputed hidden
+activations, data and weight gradients on fp32 MFMA, per-workgroup partial sums reduced in fixed order).
+The plane parameters keep the reference's shape [1,32,rb,ra] but live in torch.channels_last memory format, i.e.
+physically [rb][ra][32]: one bilinear tap is one 128-byte row and no per-call re-layout is needed (state_dict /
+load_state_dict / optimisers are layout-agnostic).  Only the configuration the reference trains with is supported
 (no_grid=False, grid_pe=0, static_mlp=False, empty_voxel=False, defor_depth=1, no_dx/no_ds/no_dr=False,
 apply_rotation=False): anything else raises NotImplementedError.
 """
@@ -48,6 +50,25 @@ def _plane_args(planes_cl: List[torch.Tensor]):
     return ptrs, ra, rb
 
 
+_view_memo = {}
+
+
+def _plane_view(p: torch.Tensor) -> torch.Tensor:
+    """Physical [rb, ra, 32] view of a [1,32,rb,ra] plane.  For a channels_last tensor it aliases the parameter's
+    storage, so the view is remembered per (storage, shape) instead of being rebuilt (3 view ops x 18 planes per call)."""
+    if p.dtype == torch.float32 and p.is_contiguous(memory_format=torch.channels_last):
+        key = (p.data_ptr(), tuple(p.shape), str(p.device))
+        v = _view_memo.get(key)
+        if v is None or v[0]() is not p:
+            import weakref
+            view = p.detach()[0].permute(1, 2, 0)
+            if len(_view_memo) > 256:
+                _view_memo.clear()
+            _view_memo[key] = v = (weakref.ref(p), view)
+        return v[1]
+    return f32c(p.detach()[0].permute(1, 2, 0))
+
+
 class _HexPlane(torch.autograd.Function):
     """pts [N,3], times [N,1], aabb [2,3], 18 planes [1,32,rb,ra] -> features [N,96]."""
 
@@ -57,7 +78,8 @@ class _HexPlane(torch.autograd.Function):
         pts, times, aabb = f32c(pts), f32c(times), f32c(aabb)
         if any(p.shape[1] != 32 for p in planes):
             raise NotImplementedError("the HexPlane kernel is built for output_coordinate_dim = 32")
-        planes_cl = [f32c(p[0].permute(1, 2, 0)) for p in planes]  # [rb, ra, 32]
+        # [rb, ra, 32] views of channels_last parameters (no copy); any other layout is copied here
+        planes_cl = [_plane_view(p) for p in planes]
         N = pts.shape[0]
         feat = torch.empty(N, 96, dtype=torch.float32, device=pts.device)
         ptrs, ra, rb = _plane_args(planes_cl)
@@ -83,37 +105,53 @@ class _HexPlane(torch.autograd.Function):
         return (v_pts, v_times, None, *g_std)
 
 
-def _mlp_update_torch(feat, pts, scales, rots, W):
-    """MLP heads + update rules with library GEMMs (used for the backward pass only)."""
-    hidden = F.linear(feat, W["w0"], W["b0"])
-
-    def head(n):
-        return F.linear(F.relu(F.linear(F.relu(hidden), W[n + "_w1"], W[n + "_b1"])), W[n + "_w2"], W[n + "_b2"])
-
-    dx, ds, dr = head("pos"), head("scl"), head("rot")
-    p = pts + dx[:, 0:3]
-    nq = torch.cat([torch.ones_like(dx[:, :1]), dx[:, 3:]], dim=1)
-    nq = nq / nq.norm(p=2, dim=1, keepdim=True)
-    w, x, y, z = nq[:, 0], nq[:, 1], nq[:, 2], nq[:, 3]
-    R = torch.stack([w * w + x * x - y * y - z * z, 2 * x * y - 2 * w * z, 2 * w * y + 2 * x * z,
-                     2 * w * z + 2 * x * y, w * w - x * x + y * y - z * z, 2 * y * z - 2 * w * x,
-                     2 * x * z - 2 * w * y, 2 * w * x + 2 * y * z, w * w - x * x - y * y + z * z], dim=1).view(-1, 3, 3)
-    out_pts = R.bmm(p.unsqueeze(-1)).squeeze(-1)
-    out_scales = scales + torch.clamp(ds, -LOG100, LOG100)
-    q1, q2 = rots + dr, dx[:, 3:]
-    q3 = torch.stack((q1[:, 0] * q2[:, 0] - q1[:, 1] * q2[:, 1] - q1[:, 2] * q2[:, 2] - q1[:, 3] * q2[:, 3],
-                      q1[:, 0] * q2[:, 1] + q1[:, 1] * q2[:, 0] + q1[:, 2] * q2[:, 3] - q1[:, 3] * q2[:, 2],
-                      q1[:, 0] * q2[:, 2] - q1[:, 1] * q2[:, 3] + q1[:, 2] * q2[:, 0] + q1[:, 3] * q2[:, 1],
-                      q1[:, 0] * q2[:, 3] + q1[:, 1] * q2[:, 2] - q1[:, 2] * q2[:, 1] + q1[:, 3] * q2[:, 0]), dim=1)
-    return out_pts, out_scales, q3 / torch.norm(q3, dim=1, keepdim=True)
-
-
 _W_KEYS = ("w0", "b0", "pos_w1", "pos_b1", "pos_w2", "pos_b2", "scl_w1", "scl_b1", "scl_w2", "scl_b2", "rot_w1",
            "rot_b1", "rot_w2", "rot_b2")
+_HEADS = ("pos", "scl", "rot")
+_NOUT = (7, 3, 4)
+# offsets inside the gradient block mobgs_deform_mlp_bwd writes (include/mobgs_hip.h)
+_OFF_W0, _OFF_B0, _OFF_W1, _OFF_B1, _OFF_W2, _OFF_B2 = 0, 12288, 12416, 61568, 61952, 66048
+
+
+def _pack_weights(W, dev):
+    """Layouts the kernels read: K-major W0t / W1t / W2t (forward, recompute) and the original (out, in) layouts
+    W0 / W1 / W2pad (data gradients)."""
+    w0 = f32c(W["w0"].detach())
+    w1 = torch.stack([W[h + "_w1"].detach() for h in _HEADS]).contiguous().float()  # [3,128(out),128(in)]
+    W2t = torch.zeros(3, 128, 32, dtype=torch.float32, device=dev)
+    W2pad = torch.zeros(3, 8, 128, dtype=torch.float32, device=dev)
+    b2 = torch.zeros(3, 32, dtype=torch.float32, device=dev)
+    for i, h in enumerate(_HEADS):
+        w2 = W[h + "_w2"].detach().float()
+        W2t[i, :, :_NOUT[i]] = w2.t()
+        W2pad[i, :_NOUT[i]] = w2
+        b2[i, :_NOUT[i]] = W[h + "_b2"].detach()
+    return {"W0t": w0.t().contiguous(), "b0": f32c(W["b0"].detach()), "W1t": w1.transpose(1, 2).contiguous(),
+            "b1": torch.stack([W[h + "_b1"].detach() for h in _HEADS]).contiguous().float(), "W2t": W2t, "b2": b2,
+            "W0": w0, "W1": w1, "W2pad": W2pad}
+
+
+_pack_memo = {}
+
+
+def _packed(weights, W, dev):
+    """_pack_weights, rebuilt only when a weight tensor was replaced or modified in place (optimizer step):
+    ~25 small launches saved per call."""
+    key = tuple(id(w) for w in weights)
+    ver = tuple(w._version for w in weights)
+    hit = _pack_memo.get(key)
+    if hit is not None and hit[0] == ver and all(a() is b for a, b in zip(hit[1], weights)):
+        return hit[2]
+    import weakref
+    pk = _pack_weights(W, dev)
+    if len(_pack_memo) > 16:
+        _pack_memo.clear()
+    _pack_memo[key] = (ver, [weakref.ref(w) for w in weights], pk)
+    return pk
 
 
 class _MlpUpdate(torch.autograd.Function):
-    """feat [N,96] + (pts, scales, rots) -> (pts', scales', rots'): MFMA forward, library-GEMM backward."""
+    """feat [N,96] + (pts, scales, rots) -> (pts', scales', rots'): fp32-MFMA forward and backward."""
 
     @staticmethod
     def forward(ctx, feat, pts, scales, rots, *weights):
@@ -122,34 +160,48 @@ class _MlpUpdate(torch.autograd.Function):
         feat, pts, scales, rots = map(f32c, (feat, pts, scales, rots))
         dev = feat.device
         N = feat.shape[0]
-        W0t = f32c(W["w0"].t())  # [96,128] K-major
-        heads = ("pos", "scl", "rot")
-        W1t = torch.stack([W[h + "_w1"].t() for h in heads]).contiguous()  # [3,128,128]
-        b1 = torch.stack([W[h + "_b1"] for h in heads]).contiguous()
-        W2t = torch.zeros(3, 128, 32, dtype=torch.float32, device=dev)
-        b2 = torch.zeros(3, 32, dtype=torch.float32, device=dev)
-        for i, h in enumerate(heads):
-            n = W[h + "_w2"].shape[0]
-            W2t[i, :, :n] = W[h + "_w2"].t()
-            b2[i, :n] = W[h + "_b2"]
+        pk = _packed(weights, W, dev)
+        need_bwd = any(ctx.needs_input_grad)
         out_pts = torch.empty(N, 3, dtype=torch.float32, device=dev)
         out_scales = torch.empty(N, 3, dtype=torch.float32, device=dev)
         out_rots = torch.empty(N, 4, dtype=torch.float32, device=dev)
-        check(lib.mobgs_deform_mlp_fwd(N, ptr(feat), ptr(pts), ptr(scales), ptr(rots), ptr(W0t), ptr(f32c(W["b0"])),
-                                       ptr(W1t), ptr(b1), ptr(W2t), ptr(b2), ptr(out_pts), ptr(out_scales),
-                                       ptr(out_rots), stream()), "mobgs_deform_mlp_fwd")
-        ctx.save_for_backward(feat, pts, scales, rots, *weights)
+        o_raw = torch.empty(N, 16, dtype=torch.float32, device=dev) if need_bwd else None
+        check(lib.mobgs_deform_mlp_fwd(N, ptr(feat), ptr(pts), ptr(scales), ptr(rots), ptr(pk["W0t"]), ptr(pk["b0"]),
+                                       ptr(pk["W1t"]), ptr(pk["b1"]), ptr(pk["W2t"]), ptr(pk["b2"]), ptr(out_pts),
+                                       ptr(out_scales), ptr(out_rots), ptr(o_raw), stream()), "mobgs_deform_mlp_fwd")
+        if need_bwd:
+            ctx.save_for_backward(feat, pts, rots, o_raw, pk["W0t"], pk["b0"], pk["W1t"], pk["b1"], pk["W0"], pk["W1"],
+                                  pk["W2pad"])
         return out_pts, out_scales, out_rots
 
     @staticmethod
     def backward(ctx, v_pts, v_scales, v_rots):
-        feat, pts, scales, rots, *weights = ctx.saved_tensors
-        with torch.enable_grad():
-            leaves = [t.detach().requires_grad_(True) for t in (feat, pts, scales, rots, *weights)]
-            outs = _mlp_update_torch(*leaves[:4], dict(zip(_W_KEYS, leaves[4:])))
-            cots = [v if v is not None else torch.zeros_like(o) for v, o in zip((v_pts, v_scales, v_rots), outs)]
-            grads = torch.autograd.grad(outs, leaves, cots, allow_unused=True)
-        return tuple(grads)
+        lib = _lib.load()
+        feat, pts, rots, o_raw, W0t, b0, W1t, b1, W0, W1, W2pad = ctx.saved_tensors
+        N, dev = feat.shape[0], feat.device
+        c = [f32c(v) if v is not None else None for v in (v_pts, v_scales, v_rots)]
+
+        def E(*shape):
+            return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+        g_feat, g_pts, g_rots, v_o = E(N, 96), E(N, 3), E(N, 4), E(N, 16)
+        nfl = int(lib.mobgs_deform_mlp_grad_floats())
+        partials = E(max(1, lib.mobgs_deform_mlp_bwd_blocks(N)), nfl)
+        g = E(nfl)
+        check(lib.mobgs_deform_mlp_bwd(N, ptr(feat), ptr(pts), ptr(rots), ptr(o_raw), ptr(W0t), ptr(b0), ptr(W1t),
+                                       ptr(b1), ptr(W0), ptr(W1), ptr(W2pad), ptr(c[0]), ptr(c[1]), ptr(c[2]),
+                                       ptr(g_feat), ptr(g_pts), ptr(g_rots), ptr(v_o), ptr(partials), ptr(g),
+                                       stream()), "mobgs_deform_mlp_bwd")
+        gw = {"w0": g[_OFF_W0:_OFF_B0].view(128, 96), "b0": g[_OFF_B0:_OFF_W1]}
+        gW2 = g[_OFF_W2:_OFF_B2].view(32, 128)
+        gb2 = g[_OFF_B2:_OFF_B2 + 32]
+        for i, h in enumerate(_HEADS):
+            gw[h + "_w1"] = g[_OFF_W1 + i * 16384:_OFF_W1 + (i + 1) * 16384].view(128, 128)
+            gw[h + "_b1"] = g[_OFF_B1 + i * 128:_OFF_B1 + (i + 1) * 128]
+            gw[h + "_w2"] = gW2[8 * i:8 * i + _NOUT[i]]
+            gw[h + "_b2"] = gb2[8 * i:8 * i + _NOUT[i]]
+        g_scales = c[1] if c[1] is not None else torch.zeros(N, 3, dtype=torch.float32, device=dev)
+        return (g_feat, g_pts, g_scales, g_rots, *[gw[k] for k in _W_KEYS])
 
 
 class HexPlaneField(nn.Module):
@@ -167,7 +219,8 @@ class HexPlaneField(nn.Module):
             reso = [r * res for r in planeconfig["resolution"][:3]] + list(planeconfig["resolution"][3:])
             gp = nn.ParameterList()
             for comb in COMBS:
-                p = nn.Parameter(torch.empty([1, planeconfig["output_coordinate_dim"]] + [reso[c] for c in comb[::-1]]))
+                p = nn.Parameter(torch.empty([1, planeconfig["output_coordinate_dim"]] + [reso[c] for c in comb[::-1]])
+                                 .contiguous(memory_format=torch.channels_last))  # physically [rb][ra][32]
                 if 3 in comb:
                     nn.init.ones_(p)  # time planes start at 1
                 else:
@@ -279,3 +332,54 @@ class deform_network(nn.Module):
 
     def get_grid_parameters(self):
         return self.deformation_net.get_grid_parameters()
+
+
+class SeesawArgs:
+    """The hidden-model hyper-parameters the reference trains the seesaw scene with
+    (/root/reference/arguments/__init__.py:77-107 overridden by arguments/stereo/default.py and seesaw.py)."""
+    net_width, timebase_pe, defor_depth, posebase_pe, scale_rotation_pe, opacity_pe = 128, 4, 1, 10, 2, 2
+    timenet_width, timenet_output, bounds, grid_pe = 64, 32, 1.6, 0
+    kplanes_config = {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32,
+                      "resolution": [64, 64, 64, 12]}
+    multires = [1, 2, 4]
+    no_dx = no_grid = no_ds = no_dr = empty_voxel = static_mlp = apply_rotation = False
+    no_do = no_dshs = True
+
+
+def kernel_times(net, pts, scales, rots, times, cots, steps, timer):
+    """Per-kernel times of one deform_network call (scripts/bench_deform.py): each C-ABI entry point by itself."""
+    lib = _lib.load()
+    d = net.deformation_net
+    planes_cl = [_plane_view(p) for p in d.grid.planes()]
+    aabb = f32c(d.grid.aabb.detach())
+    N, dev = pts.shape[0], pts.device
+    t1 = f32c(times.reshape(-1, 1))
+    ptrs, ra, rb = _plane_args(planes_cl)
+    feat = torch.empty(N, 96, dtype=torch.float32, device=dev)
+    W = dict(zip(_W_KEYS, d.weights()))
+    pk = _pack_weights(W, dev)
+
+    def E(*shape):
+        return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+    o_pts, o_scl, o_rot, o_raw = E(N, 3), E(N, 3), E(N, 4), E(N, 16)
+    out = {}
+    out["hexplane_fwd_ms"] = timer(lambda: check(lib.mobgs_hexplane_fwd(
+        N, ptr(pts), ptr(t1), ptr(aabb), ptrs, ra, rb, ptr(feat), stream()), "hexplane_fwd"), steps)
+    out["mlp_fwd_ms"] = timer(lambda: check(lib.mobgs_deform_mlp_fwd(
+        N, ptr(feat), ptr(pts), ptr(scales), ptr(rots), ptr(pk["W0t"]), ptr(pk["b0"]), ptr(pk["W1t"]), ptr(pk["b1"]),
+        ptr(pk["W2t"]), ptr(pk["b2"]), ptr(o_pts), ptr(o_scl), ptr(o_rot), ptr(o_raw), stream()), "mlp_fwd"), steps)
+    g_feat, g_pts, g_rots, v_o = E(N, 96), E(N, 3), E(N, 4), E(N, 16)
+    nfl = int(lib.mobgs_deform_mlp_grad_floats())
+    partials, g = E(lib.mobgs_deform_mlp_bwd_blocks(N), nfl), E(nfl)
+    out["mlp_bwd_ms"] = timer(lambda: check(lib.mobgs_deform_mlp_bwd(
+        N, ptr(feat), ptr(pts), ptr(rots), ptr(o_raw), ptr(pk["W0t"]), ptr(pk["b0"]), ptr(pk["W1t"]), ptr(pk["b1"]),
+        ptr(pk["W0"]), ptr(pk["W1"]), ptr(pk["W2pad"]), ptr(cots[0]), ptr(cots[1]), ptr(cots[2]), ptr(g_feat),
+        ptr(g_pts), ptr(g_rots), ptr(v_o), ptr(partials), ptr(g), stream()), "mlp_bwd"), steps)
+    gplanes = [torch.zeros_like(p) for p in planes_cl]
+    gptrs = (ctypes.c_void_p * 18)(*[x.data_ptr() for x in gplanes])
+    v_pts, v_times = torch.zeros_like(pts), torch.empty_like(t1)
+    out["hexplane_bwd_ms"] = timer(lambda: check(lib.mobgs_hexplane_bwd(
+        N, ptr(pts), ptr(t1), ptr(aabb), ptrs, ra, rb, ptr(g_feat), gptrs, ptr(v_pts), ptr(v_times), stream()),
+        "hexplane_bwd"), steps)
+    return out
