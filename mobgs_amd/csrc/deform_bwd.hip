@@ -28,7 +28,10 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int TP = 64;     // points per workgroup tile
 constexpr int LDB = 129;   // padded row stride of the LDS slabs (column reads of 32 different rows hit 32 banks)
-constexpr int LDO = 33;    // row stride of the head-output cotangents
+constexpr int LDO = 33;
+#ifndef GEMM_U
+#define GEMM_U 4
+#endif    // row stride of the head-output cotangents
 
 // partial / final gradient block (floats)
 constexpr int OFF_W0 = 0;                      // [128][96]
@@ -56,14 +59,53 @@ __device__ inline void zero(f32x16& a) {
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
 // acc += A[row0 + ., 0..K) * B[0..K)[col0 + .]   (A: LDS slab, B: global, row stride ldb)
+// Operands are fetched one group of U k-steps AHEAD of the MFMAs that consume them (explicit double buffering in
+// registers): a dependent v_mfma_f32_32x32x2_f32 chain issues one instruction per 64 cycles, so without the
+// look-ahead the loads of a group only leave once the previous group's last MFMA has issued and their latency
+// (LDS ~100, L2 ~300-500 cycles) is exposed every U MFMAs.
 template <int K>
 __device__ __forceinline__ void gemm_tile(const float (*A)[LDB], int row0, const float* __restrict__ B, int ldb,
                                           int col0, int lane, f32x16& acc) {
+    constexpr int U = GEMM_U;      // k-steps per group
+    constexpr int G = K / 2 / U;   // groups; processed two at a time (ping / pong register sets)
+    static_assert(G % 2 == 0, "K/2 must be a multiple of twice the group size");
     const int r = lane & 31, kh = lane >> 5;
-#pragma unroll 8
-    for (int k0 = 0; k0 < K; k0 += 2) {
-        const int kk = k0 + kh;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[row0 + r][kk], B[(size_t)kk * ldb + col0 + r], acc, 0, 0, 0);
+    const float* ap = &A[row0 + r][kh];
+    const float* bp = B + (size_t)kh * ldb + col0 + r;
+    float a0[U], b0[U], a1[U], b1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        a0[u] = ap[2 * u];
+        b0[u] = bp[(size_t)(2 * u) * ldb];
+    }
+#pragma unroll 1
+    for (int g = 0; g < G; g += 2) {
+        {
+            const float* an = ap + 2 * U * (g + 1);
+            const float* bn = bp + (size_t)(2 * U * (g + 1)) * ldb;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                a1[u] = an[2 * u];
+                b1[u] = bn[(size_t)(2 * u) * ldb];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads AHEAD of the MFMAs (the scheduler would sink them)
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < G) {
+            const float* an = ap + 2 * U * (g + 2);
+            const float* bn = bp + (size_t)(2 * U * (g + 2)) * ldb;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                a0[u] = an[2 * u];
+                b0[u] = bn[(size_t)(2 * u) * ldb];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -195,21 +237,28 @@ deform_mlp_bwd_kernel(int N, int n_tiles, const float* __restrict__ feat, const 
     const int r = lane & 31, kh = lane >> 5;
     // data GEMMs [64 points x 128]: this wave's output tile = rows 32 hf .., columns col0 ..
     // weight gradients [128 x 128]: rows col0 .. (the same 32-wide block), column tiles 2 hf, 2 hf + 1
-    const int col0 = 32 * (wv & 3), hf = wv >> 2, prow0 = 32 * hf;
+    const int col0_ = 32 * (wv & 3), hf = wv >> 2, prow0_ = 32 * hf;
 
-    f32x16 gW1[3][2], gW0[2], gW2;
+    // gW1 lives in registers for the whole walk.  The W0 and W2 gradient tiles are touched in one short phase per
+    // tile each: they are PARKED in this workgroup's partial block between tiles (48 + 16 KB, L2-resident; every
+    // lane re-reads exactly the addresses it wrote) -- with them resident the kernel needs ~300 registers per lane
+    // and spills inside the MFMA loops.
+    f32x16 gW1[3][2];
     float gb1[3] = {0.f, 0.f, 0.f}, gb0 = 0.f, gb2 = 0.f;
+    float* const P = partials + (size_t)blockIdx.x * GRAD_FLOATS;
 #pragma unroll
     for (int h = 0; h < 3; ++h) {
         zero(gW1[h][0]);
         zero(gW1[h][1]);
     }
-    zero(gW0[0]);
-    zero(gW0[1]);
-    zero(gW2);
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int row0 = tile * TP;
+        // An opaque zero folded into the per-wave offsets: the compiler would otherwise hoist every address that
+        // does not depend on the tile out of this loop (3 unrolled heads x 6 arrays) and spill them (149 VGPRs).
+        int zv = 0;
+        asm volatile("" : "+v"(zv));
+        const int col0 = col0_ + zv, prow0 = prow0_ + zv;
         // ---- P0: features and head-output cotangents -> LDS ---------------------------------------------
         for (int idx = tid; idx < TP * 96; idx += 512) {
             const int p = idx / 96, k = idx - p * 96;
@@ -233,8 +282,14 @@ deform_mlp_bwd_kernel(int N, int n_tiles, const float* __restrict__ feat, const 
             for (int i = 0; i < 16; ++i) S.A1[prow0 + acc_row(i, lane)][col0 + r] = fmaxf(acc[i] + bias, 0.f);
         }
         __syncthreads();
-        f32x16 va1;
+        f32x16 va1, gW2;
         zero(va1);
+        zero(gW2);
+        const bool first = tile == (int)blockIdx.x;
+        if (hf == 1 && !first) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gW2[i] = P[OFF_W2 + acc_row(i, lane) * 128 + col0 + r];
+        }
 #pragma unroll
         for (int h = 0; h < 3; ++h) {
             // ---- P2: z1 = A1 W1^T + b1 -> A2 = relu(z1) ---------------------------------------------------
@@ -288,6 +343,10 @@ deform_mlp_bwd_kernel(int N, int n_tiles, const float* __restrict__ feat, const 
             }
             __syncthreads();
         }
+        if (hf == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) P[OFF_W2 + acc_row(i, lane) * 128 + col0 + r] = gW2[i];
+        }
         // ---- P5: v_hidden = v_a1 where hidden > 0 -> VZ slab ---------------------------------------------
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -297,6 +356,17 @@ deform_mlp_bwd_kernel(int N, int n_tiles, const float* __restrict__ feat, const 
         __syncthreads();
         // ---- P6: gW0 += VH^T F ; gb0 ; v_feat = VH W0 ---------------------------------------------------
         {
+            f32x16 gW0[2];
+            zero(gW0[0]);
+            zero(gW0[1]);
+            if (!first) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = col0 + acc_row(i, lane);
+                    gW0[0][i] = P[OFF_W0 + row * 96 + 64 * hf + r];
+                    if (hf == 0) gW0[1][i] = P[OFF_W0 + row * 96 + 32 + r];
+                }
+            }
             float bsum = 0.f;
 #pragma unroll 4
             for (int p0 = 0; p0 < TP; p0 += 2) {
@@ -308,6 +378,12 @@ deform_mlp_bwd_kernel(int N, int n_tiles, const float* __restrict__ feat, const 
                 if (hf == 0) gW0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, S.F[p][32 + r], gW0[1], 0, 0, 0);
             }
             gb0 += bsum;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = col0 + acc_row(i, lane);
+                P[OFF_W0 + row * 96 + 64 * hf + r] = gW0[0][i];
+                if (hf == 0) P[OFF_W0 + row * 96 + 32 + r] = gW0[1][i];
+            }
             if (col0 < 96) {  // 2 x 3 output tiles of v_feat [64 x 96]
                 f32x16 acc;
                 zero(acc);
@@ -322,19 +398,15 @@ deform_mlp_bwd_kernel(int N, int n_tiles, const float* __restrict__ feat, const 
         __syncthreads();
     }
 
-    // ---- this workgroup's partial sums ---------------------------------------------------------------------
-    float* P = partials + (size_t)blockIdx.x * GRAD_FLOATS;
+    // ---- this workgroup's partial sums (W0 / W2 are already in place) -----------------------------------------
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int row = col0 + acc_row(i, lane);
-        P[OFF_W0 + row * 96 + 64 * hf + r] = gW0[0][i];
-        if (hf == 0) P[OFF_W0 + row * 96 + 32 + r] = gW0[1][i];
+        const int row = col0_ + acc_row(i, lane);
 #pragma unroll
         for (int h = 0; h < 3; ++h) {
             P[OFF_W1 + h * 16384 + row * 128 + 64 * hf + r] = gW1[h][0][i];
             P[OFF_W1 + h * 16384 + row * 128 + 64 * hf + 32 + r] = gW1[h][1][i];
         }
-        if (hf == 1) P[OFF_W2 + acc_row(i, lane) * 128 + col0 + r] = gW2[i];
     }
     // bias sums: lanes l and l + 32 hold the two halves of the point sum
     gb0 += __shfl_xor(gb0, 32, 64);
@@ -342,9 +414,9 @@ deform_mlp_bwd_kernel(int N, int n_tiles, const float* __restrict__ feat, const 
 #pragma unroll
     for (int h = 0; h < 3; ++h) gb1[h] += __shfl_xor(gb1[h], 32, 64);
     if (kh == 0 && hf == 1) {
-        P[OFF_B0 + col0 + r] = gb0;
+        P[OFF_B0 + col0_ + r] = gb0;
 #pragma unroll
-        for (int h = 0; h < 3; ++h) P[OFF_B1 + h * 128 + col0 + r] = gb1[h];
+        for (int h = 0; h < 3; ++h) P[OFF_B1 + h * 128 + col0_ + r] = gb1[h];
         if (wv == 4) P[OFF_B2 + r] = gb2;
     }
 }
