@@ -44,8 +44,9 @@ __device__ inline Tap make_tap(float x, float y, int ra, int rb) {
     Tap t;
     float ix = (x + 1.f) * 0.5f * (float)(ra - 1);
     float iy = (y + 1.f) * 0.5f * (float)(rb - 1);
-    t.gx = (ix >= 0.f && ix <= (float)(ra - 1)) ? 0.5f * (float)(ra - 1) : 0.f;
-    t.gy = (iy >= 0.f && iy <= (float)(rb - 1)) ? 0.5f * (float)(rb - 1) : 0.f;
+    // clip_coordinates_set_grad: the borders themselves count as out of bounds (gradient 0 for ix <= 0, ix >= ra-1)
+    t.gx = (ix > 0.f && ix < (float)(ra - 1)) ? 0.5f * (float)(ra - 1) : 0.f;
+    t.gy = (iy > 0.f && iy < (float)(rb - 1)) ? 0.5f * (float)(rb - 1) : 0.f;
     ix = fminf(fmaxf(ix, 0.f), (float)(ra - 1));
     iy = fminf(fmaxf(iy, 0.f), (float)(rb - 1));
     const float fx = floorf(ix), fy = floorf(iy);

@@ -251,6 +251,64 @@ def gen_deform(name, n=700, seed=4):
     save(name, **arrays)
 
 
+def mid_planes(planes, seed):
+    """Plane values of the mid-size deformation fixture: drawn from a seeded generator in plane order so that the
+    tests regenerate them instead of loading 8 MB (shared with tests/test_gpu_config3.py)."""
+    g = torch.Generator().manual_seed(seed)
+    return [0.5 + 0.5 * torch.rand(tuple(pl.shape), generator=g) for pl in planes]
+
+
+def gen_deform_mid(name, n=4000, seed=14, base=32):
+    """deform_network of the reference at planes [32,32,32,12] x multires [1,2,4] (half the seesaw resolution per
+    axis; the toy fixture `deform` has 8): outputs, input gradients, all MLP weight gradients, the 9 time-plane
+    gradients in full, and for the 9 spatial planes {sum, sum |.|, 2048 seeded samples} of the gradient."""
+    dm = RH.ref_import("scene.deformation")
+    args = RH.Args()
+    args.kplanes_config = dict(args.kplanes_config, resolution=[base, base, base, 12])
+    with RH.CudaToCpu():
+        torch.manual_seed(seed)
+        net = dm.deform_network(args)
+        planes = [pl for level in net.deformation_net.grid.grids for pl in level]
+        for pl, v in zip(planes, mid_planes(planes, seed)):
+            pl.data = v
+        xyz_max, xyz_min = [1.3, 0.9, 1.6], [-1.0, -1.1, -0.3]
+        net.deformation_net.set_aabb(xyz_max, xyz_min)
+        with torch.no_grad():  # Xavier weights give sub-millimetre deformations: scale the heads up
+            for p_ in net.deformation_net.get_mlp_parameters():
+                p_.mul_(2.0)
+    g = torch.Generator().manual_seed(seed + 1)
+    lo, hi = torch.tensor(xyz_min), torch.tensor(xyz_max)
+    pts = (lo + (hi - lo) * (1.1 * torch.rand(n, 3, generator=g) - 0.05)).requires_grad_(True)
+    scales = (0.1 * torch.randn(n, 3, generator=g)).requires_grad_(True)
+    rots = torch.randn(n, 4, generator=g).requires_grad_(True)
+    times = torch.full((n, 1), 11.0 / 23.0)  # one time stamp per call, as a training view has
+    times[: n // 8] = torch.rand(n // 8, 1, generator=g)  # ... and a block of per-point times (API allows it)
+    with RH.CudaToCpu():
+        o_pts, o_scl, o_rot = net(pts, scales, rots, times)
+    v = [torch.randn(o.shape, generator=g) for o in (o_pts, o_scl, o_rot)]
+    ((o_pts * v[0]).sum() + (o_scl * v[1]).sum() + (o_rot * v[2]).sum()).backward()
+    arrays = {"in_pts": np_(pts), "in_scales": np_(scales), "in_rots": np_(rots), "in_times": np_(times),
+              "in_aabb": np_(net.deformation_net.grid.aabb), "out_pts": np_(o_pts), "out_scales": np_(o_scl),
+              "out_rots": np_(o_rot), "cot_pts": np_(v[0]), "cot_scales": np_(v[1]), "cot_rots": np_(v[2]),
+              "grad_pts": np_(pts.grad), "grad_scales": np_(scales.grad), "grad_rots": np_(rots.grad),
+              "meta": np.array([seed, base, n])}
+    for k, w in deform_weights(net).items():
+        arrays["w_" + k] = np_(w)
+        arrays["gw_" + k] = np_(w.grad)
+    gs = torch.Generator().manual_seed(seed + 2)
+    for li, level in enumerate(net.deformation_net.grid.grids):
+        for pi, pl in enumerate(level):
+            gr = pl.grad.reshape(-1)
+            if pi in (2, 4, 5):  # planes with the time axis: small, stored in full
+                arrays[f"gplane_{li}_{pi}"] = np_(pl.grad)
+            else:
+                idx = torch.randint(0, gr.numel(), (2048,), generator=gs)
+                arrays[f"gplane_idx_{li}_{pi}"] = idx.numpy()
+                arrays[f"gplane_val_{li}_{pi}"] = np_(gr[idx])
+                arrays[f"gplane_sum_{li}_{pi}"] = np.array([float(gr.double().sum()), float(gr.double().abs().sum())])
+    save(name, **arrays)
+
+
 def gen_blce(name, num_views=3, seed=8):
     bl = RH.ref_import("scene.blce")
     with RH.CudaToCpu():
@@ -503,6 +561,7 @@ def main():
     gen_render("render_train", 700, 400, 64, 48, 2, True, True, None, False, False)
     gen_get_flow("get_flow", 900, 500, 80, 48, 3, -0.4)
     gen_deform("deform")
+    gen_deform_mid("deform_mid")
     gen_blce("blce")
     gen_losses("losses")
     gen_densify("densify")

@@ -80,3 +80,32 @@ def close(a, b, rtol, atol, what, flip_frac=0.0, flip_atol=0.0):
 def psnr(img, target):
     mse = ((img.double() - target.double()) ** 2).mean()
     return float(20 * torch.log10(1.0 / torch.sqrt(mse)))
+
+
+def mid_planes(shapes, seed):
+    """Plane values of tests/golden/deform_mid.npz (same draws as make_golden.mid_planes: the fixture does not store
+    the 2.1 M plane values, only the seed)."""
+    g = torch.Generator().manual_seed(int(seed))
+    return [0.5 + 0.5 * torch.rand(tuple(s), generator=g) for s in shapes]
+
+
+def check_deform_fixture_grads(fx, get_plane_grad, what=""):
+    """Plane gradients of the mid-size fixture: time planes in full, spatial planes by {sum, sum|.|, 2048 samples}.
+    One point whose ReLU decision flips (see test_gpu_config3) moves the 4 x 32 entries it touches in every plane
+    by a few per cent of its own contribution: up to 2 % of a small plane's entries may be off by 2 % of the max."""
+    for li in range(3):
+        for pi in range(6):
+            g = get_plane_grad(li, pi).detach().cpu()
+            if pi in (2, 4, 5):
+                ref = fx[f"gplane_{li}_{pi}"]
+                sc = float(np.abs(ref).max())
+                close(g, ref, 1e-3, 1e-4 * sc + 1e-6, f"{what}grad plane {li}.{pi}", flip_frac=0.02, flip_atol=0.02 * sc)
+            else:
+                flat = g.reshape(-1)
+                ref = fx[f"gplane_val_{li}_{pi}"]
+                s_ref, a_ref = fx[f"gplane_sum_{li}_{pi}"]
+                sc = float(np.abs(ref).max())
+                close(flat[torch.from_numpy(fx[f"gplane_idx_{li}_{pi}"])], ref, 1e-3, 1e-4 * sc + 1e-6,
+                      f"{what}grad plane {li}.{pi} samples", flip_frac=0.02, flip_atol=0.02 * sc)
+                assert abs(float(flat.double().abs().sum()) - a_ref) <= 1e-4 * a_ref, (li, pi)
+                assert abs(float(flat.double().sum()) - s_ref) <= 1e-4 * a_ref, (li, pi)

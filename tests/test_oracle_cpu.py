@@ -260,6 +260,30 @@ def test_deform_restatement_matches_reference_fixture():
     close(planes[2][0].grad, fx["gplane_2_0"], 1e-5, 1e-7, "grad plane 2.0")
 
 
+def test_deform_restatement_matches_reference_at_mid_size_planes():
+    """Second pin of oracle/deform_torch.py: planes [32,32,32,12] x [1,2,4] (tests/golden/deform_mid.npz, produced by
+    the reference's deform_network), 4000 points, mixed per-call / per-point time stamps, points outside the box."""
+    from helpers import check_deform_fixture_grads, mid_planes
+    from oracle import deform_torch as D
+    fx = load("deform_mid")
+    T = torch.from_numpy
+    seed, base, _ = (int(v) for v in fx["meta"])
+    shapes = [[1, 32, (base * m if b < 3 else 12), (base * m if a < 3 else 12)] for m in (1, 2, 4) for a, b in D.COMBS]
+    vals = mid_planes(shapes, seed)
+    planes = [[vals[6 * l + p].clone().requires_grad_(True) for p in range(6)] for l in range(3)]
+    W = {k[2:]: T(v).requires_grad_(True) for k, v in fx.items() if k.startswith("w_")}
+    pts, scales, rots = (T(fx[k]).requires_grad_(True) for k in ("in_pts", "in_scales", "in_rots"))
+    o = D.deform_forward(pts, scales, rots, T(fx["in_times"]), T(fx["in_aabb"]), planes, W)
+    for a, k in zip(o, ("out_pts", "out_scales", "out_rots")):
+        close(a, fx[k], 1e-6, 1e-6, k)
+    ((o[0] * T(fx["cot_pts"])).sum() + (o[1] * T(fx["cot_scales"])).sum() + (o[2] * T(fx["cot_rots"])).sum()).backward()
+    for n, t in (("pts", pts), ("scales", scales), ("rots", rots)):
+        close(t.grad, fx["grad_" + n], 1e-5, 1e-6 * float(np.abs(fx["grad_" + n]).max()), "grad " + n)
+    for k, w in W.items():
+        close(w.grad, fx["gw_" + k], 1e-4, 1e-5 * float(np.abs(fx["gw_" + k]).max()), "grad " + k)
+    check_deform_fixture_grads(fx, lambda li, pi: planes[li][pi].grad, "oracle ")
+
+
 def test_loss_restatement_matches_reference_fixture():
     from oracle import loss_torch as L
     fx = load("losses")
