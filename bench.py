@@ -5,22 +5,33 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): train-step renders/sec -- one "step" on one GPU is one full `render()` forward+backward
-of BASELINE config #2: the synthetic "seesaw" scene of SURVEY.md section 8d (200k static + 100k dynamic Gaussians,
-1352x1014, lean mode as eval.py:125), i.e. per-splat prep (Hermite spline, activations) -> projection -> tile
-lists + per-tile depth sort -> 10-channel compositing -> expected depth + colour decoder, and the backward pass
-to every Gaussian leaf, the decoder weights and the camera matrix.  Inputs are resident in HBM before the timed
-region.  With N > 1 every rank renders a different latent sub-frame of one blurry view (weak scaling: per-GPU
-work fixed), the partial images are summed with an RCCL all-reduce into the blurry prediction, and the
-parameter gradients are all-reduced as one flat buffer (train.py:502-541 sharded as SURVEY.md section 8e).
+Metric (BASELINE.json): train-step renders/sec (fwd+bwd, 1352x1014, 300k Gaussians) at 1/2/4/8 GPU.
 
-Prints ONE JSON line on rank 0 (see the task contract), including
-  roofline     -- the dominant kernel (raster_bwd): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
-  cpu_baseline -- oracle/gsplat_cpu.c (OpenMP port of upstream's kernels) timed on this host, N=1 only.
+N = 1   one step = one full `render()` forward + backward of BASELINE config #2: the synthetic "seesaw" scene of
+        SURVEY.md section 8d (200k static + 100k dynamic Gaussians, 1352x1014, lean mode as eval.py:125), i.e. per-splat
+        prep (Hermite spline, activations) -> projection -> tile lists + per-tile depth sort -> 10-channel compositing
+        -> expected depth + colour decoder, and the backward pass to every Gaussian leaf, the decoder weights and the
+        camera matrix.  `value` = renders/s.  The same line carries, as the secondary object `deblur`, the K = 9
+        blurry-view throughput on this one GPU (the N > 1 step below with world = 1).
+N > 1   one step = one training iteration's blurry-view part (train.py:430-541) for a batch of 2 views (the
+        reference's batch_size, arguments/stereo/default.py): per view 1 train-mode mid render + 8 latent renders
+        through BLCE-warped cameras with exposure offsets, K = 9; the 18 (view, sub-frame) units are sharded
+        round-robin over the ranks (mobgs_amd.distributed), the partial image sums are all-reduced (RCCL) into the
+        blurry predictions, fixed cotangents are back-propagated (prediction on every rank, depth / mask terms on the
+        rank that rendered the mid frame) and ONE in-place all-reduce of the persistent flat gradient buffer (all
+        Gaussian leaves, decoder, BLCE parameters, mid-frame densification statistics) completes the step.
+        `value` = 18 renders x steps / time = whole-job renders/s; total work per step is fixed: "scaling": "strong".
+
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 (see the task contract) with
+  roofline     -- the dominant kernel (raster_bwd): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak, plus
+                  pixel-splat pairs/s, fp32 FLOP/s against the 157.3 TFLOP/s vector peak
+  cpu_baseline -- oracle/gsplat_cpu.c (OpenMP port of upstream's kernels) at the full workload and the north-star
+                  "PyTorch-CPU render" (oracle/render_torch + gsplat_torch, config #1) timed on this host, N=1 only.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -37,7 +48,8 @@ from mobgs_amd.gaussian_model import GaussianParams  # noqa: E402
 from mobgs_amd.helper_model import Sandwich  # noqa: E402
 from mobgs_amd.synth import SynthCamera, dynamic_extras, gaussian_cloud  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_VECTOR_PEAK_TF = 157.3  # same guide: peak fp32 (vector)
 
 
 def build_scene(dev, ns, nd, width, height, seed=0):
@@ -56,6 +68,19 @@ def build_scene(dev, ns, nd, width, height, seed=0):
 def leaves(stat, dyn):
     ls = list(stat.leaf_tensors(False).values()) + list(dyn.leaf_tensors(True).values())
     return ls + list(dyn.rgbdecoder.parameters())
+
+
+def view_pose(i):
+    """World-to-camera matrices of the batch's views: view 0 = identity, the others a few degrees / centimetres off."""
+    import math
+    w2c = torch.eye(4)
+    if i:
+        a, b = 0.03 * i, -0.02 * i
+        Ry = torch.tensor([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+        Rx = torch.tensor([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+        w2c[:3, :3] = Ry @ Rx
+        w2c[:3, 3] = torch.tensor([0.03 * i, -0.02 * i, 0.04 * i])
+    return w2c
 
 
 def cpu_baseline(stat_p, dyn_p, dyn_x, scam, width, height, reps):
@@ -83,6 +108,110 @@ def cpu_baseline(stat_p, dyn_p, dyn_x, scam, width, height, reps):
                       f"{width}x{height}, I={int(r['flatten_ids'].shape[0])}) by oracle/gsplat_cpu.c (OpenMP)"}
 
 
+def cpu_torch_reference(width, height, ns=10_000):
+    """The north star's "reference PyTorch-CPU render": BASELINE config #1 (10k static Gaussians, one sharp frame,
+    FORWARD) through the restated reference glue (oracle/render_torch.render) over the pure-PyTorch restatement of
+    gsplat (oracle/gsplat_torch) on the host cores.  One render (tens of seconds)."""
+    from oracle import render_torch as R
+    scam = SynthCamera().scaled(width, height) if (width, height) != (1352, 1014) else SynthCamera()
+    stat_p = gaussian_cloud(ns, scam, 0)
+    dyn_p = gaussian_cloud(8, scam, 1)  # the reference always renders both sets; 8 dynamic splats
+    dyn_x = dynamic_extras(dyn_p["xyz"], 0)
+    torch.manual_seed(0)
+    dec = Sandwich(9, 3)
+    cpu = torch.device("cpu")
+    stat = GaussianParams(stat_p, None, dec, cpu, requires_grad=False)
+    dyn = GaussianParams(dyn_p, dyn_x, dec, cpu, requires_grad=False)
+    cam = PinholeCamera(width, height, scam.K, torch.eye(4), time=scam.time, max_time=scam.max_time, device=cpu)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = R.render(cam, stat, dyn, torch.zeros(9))
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out["render"]).all()
+    return {"value": 1.0 / dt, "unit": "renders/s (forward only)", "seconds": round(dt, 2),
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 x render() forward of BASELINE config #1 ({ns} static Gaussians, {width}x{height}) by "
+                      "oracle/render_torch.py + oracle/gsplat_torch.py (PyTorch CPU)"}
+
+
+def source_sha():
+    """Identity of the compositor / binning sources a committed PMC summary was collected with."""
+    h = hashlib.sha256()
+    for f in ("raster.hip", "isect.hip", "common.h"):
+        with open(os.path.join(ROOT, "mobgs_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+class DeblurWorkload:
+    """The blurry-view part of one training iteration for a batch of views (train.py:430-541), see module docstring."""
+
+    def __init__(self, dev, stat, dyn, scam, width, height, shard, n_views=2, n_sub=9, seed=100):
+        from mobgs_amd.blce import blceKernel
+        from mobgs_amd.distributed import FlatGradients
+        self.dev, self.stat, self.dyn, self.shard, self.V, self.K = dev, stat, dyn, shard, n_views, n_sub
+        g = torch.Generator().manual_seed(seed)
+        self.cams = []
+        for i in range(n_views):
+            cam = PinholeCamera(width, height, scam.K, view_pose(i), time=scam.time, max_time=scam.max_time, device=dev)
+            cam.uid = i
+            cam.image = torch.rand(3, height, width, generator=g).to(dev)  # BLCE's blur statistic reads it once
+            self.cams.append(cam)
+        torch.manual_seed(seed)
+        self.blce = blceKernel(num_views=n_views, num_warp=n_sub, iteration=10000).to(dev)
+        self.bg = torch.zeros(9, device=dev)
+        self.v_pred = torch.randn(n_views, 3, height, width, generator=g).to(dev)
+        self.v_depth = torch.randn(1, height, width, generator=g).to(dev)
+        self.v_alpha = torch.randn(1, height, width, generator=g).to(dev)
+        self.params = leaves(stat, dyn) + list(self.blce.model.get_params())
+        n = stat.get_xyz.shape[0] + dyn.get_xyz.shape[0]
+        self.bucket = FlatGradients(self.params, extra={f"view{v}": 3 * n for v in range(n_views)})
+        self.mids = {}
+
+    def step(self):
+        from mobgs_amd.deblur import render_blurry_batch
+        from mobgs_amd.ops import LeafGradSink
+        self.bucket.zero()
+        pred, mids = render_blurry_batch(self.cams, self.stat, self.dyn, self.bg, self.shard, blce=self.blce,
+                                         n_sub=self.K)
+        outs, cots = [pred], [self.v_pred]
+        for v, pkg in mids.items():  # depth / mask terms live on the rank that rendered the mid frame
+            outs += [pkg["depth"], pkg["d_alpha"]]
+            cots += [self.v_depth, self.v_alpha]
+        if any(o.requires_grad for o in outs):
+            with LeafGradSink(self.stat, self.dyn):
+                torch.autograd.backward([o for o in outs if o.requires_grad],
+                                        [c for o, c in zip(outs, cots) if o.requires_grad])
+        for v, pkg in mids.items():
+            self.shard.put_densification_stats(self.bucket, f"view{v}", pkg["viewspace_points"].grad, pkg["radii"])
+        self.shard.all_reduce_gradients(self.bucket)
+        self.mids = mids
+        return pred
+
+
+def timed(step, steps, warmup, world, dist):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; per-step HIP events on the current
+    stream give the median next to the wall-clock mean."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        step()
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    return dt, per[len(per) // 2]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,7 +221,10 @@ def main():
     ap.add_argument("--nd", type=int, default=100_000)
     ap.add_argument("--width", type=int, default=1352)
     ap.add_argument("--height", type=int, default=1014)
+    ap.add_argument("--views", type=int, default=2, help="views per training iteration in the deblur step")
+    ap.add_argument("--deblur-steps", type=int, default=10, help="N=1: steps of the secondary deblur leg (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-torch", action="store_true", help="skip the PyTorch-CPU config #1 render (tens of s)")
     ap.add_argument("--cpu-reps", type=int, default=2)
     args = ap.parse_args()
 
@@ -130,52 +262,66 @@ def main():
     v_depth = torch.randn(1, args.height, args.width, generator=g).to(dev)
     params = leaves(stat, dyn)
     shard = SubframeShard(world, rank)
-    # one latent sub-frame per rank: exposure offsets linspace(-0.4, 0.4, world) (BLCE default, scene/blce.py)
-    deltas = torch.linspace(-0.4, 0.4, world) if world > 1 else torch.zeros(1)
-    delta = None if world == 1 else deltas[rank].to(dev)
+    last = {}
 
-    def step():
+    def lean_step():
         for p in params:
             p.grad = None
-        out = render(cam, stat, dyn, None, bg, delta_exposure=delta)
-        pred = shard.mean_of_subframes(out["render"], world)  # all-reduce(SUM)/K + 1e-10 when world > 1
+        out = render(cam, stat, dyn, None, bg)
         # back-propagate fixed random cotangents: d(loss)/d(pred) = v_render, d(loss)/d(depth) = v_depth
-        torch.autograd.backward([pred, out["depth"]], [v_render, v_depth])
-        shard.all_reduce_gradients(params)
-        return out
+        torch.autograd.backward([out["render"], out["depth"]], [v_render, v_depth])
+        last["out"] = out
 
     # backward on the calling thread: handing each backward pass to autograd's device thread costs ~0.35 ms of
     # wake-up latency per step on this host (scripts/autograd_threads.py: 30 k splats 0.82 -> 0.47 ms/step; nothing
     # at 300 k, where the step is GPU-bound) -- the setting a training script on this stack would use
     torch.autograd.set_multithreading_enabled(False)
-    for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    profiler.enable(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    prof = profiler.summary()
-    profiler.enable(False)
-    if world > 1:
+
+    P = args.width * args.height
+    n_units = args.views * 9
+    deblur = None
+    if world == 1:
+        profiler.enable(True)
+        dt, med_ms = timed(lean_step, args.steps, args.warmup, world, dist)
+        prof = profiler.summary()
+        profiler.enable(False)
+        renders = args.steps
+        workload = ("BASELINE config #2: seesaw-synth (SURVEY 8d seed 0), "
+                    f"{args.ns} static + {args.nd} dynamic Gaussians, {args.width}x{args.height}, "
+                    "render() lean mode fwd+bwd incl. spline prep, decoder, camera gradient")
+        if args.deblur_steps > 0:
+            wl = DeblurWorkload(dev, stat, dyn, scam, args.width, args.height, shard, args.views)
+            ddt, dmed = timed(wl.step, args.deblur_steps, 3, world, dist)
+            deblur = {"blurry_views_per_s": round(args.views * args.deblur_steps / ddt, 3),
+                      "renders_per_s": round(n_units * args.deblur_steps / ddt, 2),
+                      "ms_per_iteration": round(ddt / args.deblur_steps * 1e3, 3),
+                      "event_median_ms_per_iteration": round(dmed, 3), "views_per_iteration": args.views,
+                      "subframes_per_view": 9, "steps": args.deblur_steps,
+                      "what": "train.py:430-541 per iteration: per view 1 train-mode mid render + 8 latent renders "
+                              "(BLCE cameras + exposure offsets, HIP-graph replay), mean, backward, flat gradient buffer"}
+    else:
+        wl = DeblurWorkload(dev, stat, dyn, scam, args.width, args.height, shard, args.views)
+        profiler.enable(True)
+        dt, med_ms = timed(wl.step, args.steps, args.warmup, world, dist)
+        prof = profiler.summary()
+        profiler.enable(False)
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        renders = n_units * args.steps
+        last["out"] = next(iter(wl.mids.values())) if wl.mids else render(cam, stat, dyn, None, bg)
+        workload = (f"K=9 deblur iteration (train.py:430-541): {args.views} blurry views x (1 train-mode mid render + 8 "
+                    f"latent renders, BLCE cameras + exposure offsets), seesaw-synth {args.ns} static + {args.nd} "
+                    f"dynamic Gaussians, {args.width}x{args.height}, fwd+bwd, {n_units} (view, sub-frame) units "
+                    f"sharded over {world} ranks; value counts all {n_units} renders of a step")
 
-    # workload statistics for the roofline: intersections I and pixels P of this rank's render
+    # workload statistics for the roofline: intersections I and pixels P of this rank's last render
     from mobgs_amd import rendering
     I = rendering.last_stats.get("n_isects", 0)
-    P = args.width * args.height
+    out = last["out"]
     n_vis = int((out["radii"] > 0).sum())
     ms_per_step = dt / args.steps * 1e3
-    value = world * args.steps / dt  # every rank completes one render fwd+bwd per step
+    value = renders / dt
 
     result = {
         "metric": "train-step renders/sec (fwd+bwd, 1352x1014, 300k Gaussians)",
@@ -185,17 +331,19 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
+        "event_median_ms_per_step": round(med_ms, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if world == 1 else "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic" if not share else "synthetic (FUNCTIONAL CHECK: ranks share one GPU, not a measurement)",
-        "config": {"workload": "BASELINE config #2: seesaw-synth (SURVEY 8d seed 0), "
-                               f"{args.ns} static + {args.nd} dynamic Gaussians, {args.width}x{args.height}, "
-                               "render() lean mode fwd+bwd incl. spline prep, decoder, camera gradient",
-                   "gaussians": args.ns + args.nd, "visible": n_vis, "intersections": I, "pixels": P,
-                   "subframes_per_step": world, "parallelism": f"subframe-shard x{world}" if world > 1 else "single"},
+        "config": {"workload": workload, "gaussians": args.ns + args.nd, "visible": n_vis, "intersections": I,
+                   "pixels": P, "subframes_per_step": 1 if world == 1 else n_units,
+                   "renders_per_step": 1 if world == 1 else n_units,
+                   "parallelism": f"subframe-shard x{world}" if world > 1 else "single"},
     }
+    if deblur is not None:
+        result["deblur"] = deblur
     if rank == 0:
         rb = prof.get("raster_bwd")
         if rb:
@@ -204,32 +352,43 @@ def main():
             # + 4 (last_id) read
             alg_bytes = 132.0 * I + 52.0 * P
             achieved = alg_bytes / (rb["avg_ms"] * 1e-3) / 1e9
-            traffic = valu_insts = None
-            pmc = os.path.join(ROOT, "profiles", "r01_raster_bwd_pmc.json")
+            roof = {"kernel": "raster_bwd_kernel<10>", "bound": "hbm", "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_kernel_ms": round(rb["avg_ms"], 4), "algorithmic_bytes": alg_bytes, "calls": rb["calls"]}
+            # counter-derived figures are attached only when the committed PMC summary was collected with exactly
+            # these kernel sources (scripts/prof_pmc.sh writes profiles/r02_raster_bwd_pmc.json with their hash)
+            pmc = os.path.join(ROOT, "profiles", "r02_raster_bwd_pmc.json")
             if os.path.exists(pmc):
                 try:
                     counters = json.load(open(pmc))
-                    traffic = counters.get("hbm_bytes_per_launch")
-                    valu_insts = counters.get("valu_wave_insts_per_launch")
+                    if counters.get("source_sha") == source_sha():
+                        roof["traffic"] = counters.get("hbm_bytes_per_launch")
+                        pairs = counters.get("pixel_splat_pairs_per_launch")
+                        vi = counters.get("valu_wave_insts_per_launch")
+                        if pairs:
+                            roof["pixel_splat_pairs_per_s"] = round(pairs / (rb["avg_ms"] * 1e-3), 1)
+                        if vi:
+                            # VALU lane-operations/s against the fp32 vector peak counted the same way
+                            # (157.3 TFLOP/s = 78.6 T lane-ops/s of FMA)
+                            lane_ops = vi * 64.0 / (rb["avg_ms"] * 1e-3)
+                            roof["valu"] = {"wave_insts": vi, "lane_ops_per_s": round(lane_ops, 1),
+                                            "frac_of_fp32_vector_issue_peak": round(lane_ops / (F32_VECTOR_PEAK_TF
+                                                                                                 * 1e12 / 2), 4)}
+                    else:
+                        roof["traffic_note"] = "profiles/r02_raster_bwd_pmc.json is from other kernel sources: ignored"
                 except Exception:  # noqa: BLE001
-                    traffic = valu_insts = None
-            result["roofline"] = {"kernel": "raster_bwd_kernel<10>", "bound": "hbm", "achieved": round(achieved, 2),
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                                  "traffic": traffic, "avg_kernel_ms": round(rb["avg_ms"], 4),
-                                  "algorithmic_bytes": alg_bytes, "calls": rb["calls"]}
-            if valu_insts:
-                # what actually bounds the kernel: VALU issue.  A wave64 VALU instruction holds
-                # one of the 1024 SIMDs for 4 cycles; counted instructions (SQ_INSTS_VALU, committed PMC pass) x 4 /
-                # 1024 / 2.4 GHz peak clock against the live kernel time (the chip sustains ~2.2 GHz here, so the
-                # true occupancy of the issue slots is ~9 % higher than this figure)
-                floor_ms = valu_insts * 4.0 / 1024.0 / 2.4e9 * 1e3
-                result["roofline"]["valu_issue"] = {"wave_insts": valu_insts, "floor_ms_at_2.4GHz": round(floor_ms, 4),
-                                                    "frac": round(floor_ms / rb["avg_ms"], 4)}
+                    pass
+            result["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(*raw, scam, args.width, args.height, args.cpu_reps)
             except Exception as exc:  # noqa: BLE001
                 result["cpu_baseline"] = {"error": str(exc)}
+            if not args.no_cpu_torch:
+                try:
+                    result["cpu_baseline"]["torch_reference_config1"] = cpu_torch_reference(args.width, args.height)
+                except Exception as exc:  # noqa: BLE001
+                    result["cpu_baseline"]["torch_reference_config1"] = {"error": str(exc)}
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

@@ -1,40 +1,114 @@
-"""Multi-GPU sharding of the K latent sub-frame renders of one blurry training view (one process per GPU,
+"""Multi-GPU sharding of the K latent sub-frame renders of blurry training views (one process per GPU,
 torch.distributed over RCCL/xGMI; backend "nccl" IS RCCL on ROCm, "gloo" on CPU for tests).
 
-The reference is single-GPU: train.py:502-541 renders the K = 9 latent sharp frames of a blurry view one after
-the other and averages them, `pred = mean_k(render_k) + 1e-10`.  The sub-frames only depend on the (replicated)
-Gaussians and on their own camera / exposure offset, so they shard with exactly two exchange steps
-(SURVEY.md section 8e):
+The reference is single-GPU: train.py:441-541 renders, for every view of the batch, the mid frame in train mode and
+the other K - 1 = 8 latent sharp frames one after the other and averages them, `pred = mean_k(render_k) + 1e-10`.
+The sub-frames only depend on the (replicated) Gaussians and on their own camera / exposure offset, so the
+(view, sub-frame) units shard with exactly two exchange steps per training iteration:
 
-  forward   all_reduce(SUM) of the rank-local partial image sum  [3,H,W] fp32 (16.4 MB at 1352x1014)
-            -> every rank holds the identical blurry prediction and computes the identical loss;
-  backward  dL/dpred is already replicated, so the all-reduce back-propagates as the identity (no traffic);
-            each rank back-propagates its own sub-frames, then ONE flat all_reduce(SUM) over all parameter
-            gradients (<= 57 floats per Gaussian) gives every rank the full gradient.
+  forward   all_reduce(SUM) of the rank-local partial image sums, one [V,3,H,W] fp32 tensor for the V views of the
+            batch (16.4 MB per view at 1352x1014) -> every rank holds the identical blurry predictions and computes
+            the identical photometric loss;
+  backward  dL/dpred is already replicated, so that all-reduce back-propagates as the identity (no traffic); each
+            rank back-propagates through its own sub-frames, then ONE in-place all_reduce(SUM) of a persistent flat
+            buffer that holds every parameter gradient (<= 57 floats per Gaussian, decoder, BLCE) AND the mid-frame
+            densification statistics (means2d.grad [N,2] and radii [N] of each view's mid render, train.py:634-648,
+            which only the rank that rendered the mid frame has) gives every rank the full gradient and statistics.
+
+Which loss terms may be formed where (the SUM counts every rank's backward once):
+  * terms that are functions of the all-reduced prediction (L1 / SSIM, train.py:621-628): on EVERY rank, unscaled --
+    each rank's backward reaches only its own sub-frames;
+  * terms on the outputs of one sub-frame render (depth / mask losses on the mid render, train.py:651-655): only the
+    rank that rendered that unit has them (`owns()`), unscaled;
+  * terms every rank can form identically from replicated data alone (regularisers on parameters): scale them with
+    `replicated_term()` (1 / world) or form them on one rank only, otherwise the SUM counts them world times.
 
 Full replicas of the parameters live on every rank (300k x 57 floats = 68 MB, trivial next to 288 GB HBM).
 """
 from __future__ import annotations
 
-from typing import Callable, Iterable, List, Optional, Sequence
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 
+def _all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
+    """In-place SUM.  A gloo group gets device tensors staged through the host (functional tests of the N > 1 path on
+    a one-GPU box; the RCCL path reduces in place on the device)."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
 class _SumAcrossRanks(torch.autograd.Function):
     """y = sum_r x_r (all-reduce).  The caller's loss is a function of y that is IDENTICAL on every rank, so the
-    gradient of that single loss w.r.t. this rank's x_r is dL/dy itself: backward is the identity."""
+    gradient of that single loss w.r.t. this rank's x_r is dL/dy itself: backward is the identity.
+    donate=True: x is a fresh temporary nobody else reads (the stacked partial sums) -- reduced in place, no copy."""
 
     @staticmethod
-    def forward(ctx, x, group):
-        y = x.contiguous().clone()
-        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+    def forward(ctx, x, group, donate):
+        y = x.detach()
+        if not (donate and y.is_contiguous()):
+            y = y.clone(memory_format=torch.contiguous_format)
+        _all_reduce_sum(y, group)
+        if donate:
+            ctx.mark_dirty(x)
+            return x
         return y
 
     @staticmethod
     def backward(ctx, g):
-        return g, None
+        return g, None, None
+
+
+class FlatGradients:
+    """One persistent flat fp32 buffer; every parameter's .grad is a VIEW of it, so backward passes accumulate in
+    place and the exchange is a single in-place all-reduce (no torch.cat, no copy back).  `extra` reserves named
+    slots for per-step statistics that ride in the same message (name -> number of floats)."""
+
+    def __init__(self, params: Sequence[torch.Tensor], extra: Optional[Dict[str, int]] = None):
+        self.params = [p for p in params if p.requires_grad]
+        if any(p.dtype != torch.float32 for p in self.params):
+            raise NotImplementedError("FlatGradients holds fp32 parameters (the reference trains in fp32)")
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.extra_slices: Dict[str, slice] = {}
+        n = sum(p.numel() for p in self.params)
+        off = n
+        for name, k in (extra or {}).items():
+            self.extra_slices[name] = slice(off, off + int(k))
+            off += int(k)
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.views: List[torch.Tensor] = []
+        o = 0
+        for p in self.params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+
+    def zero(self) -> None:
+        """Start of an iteration: clear the buffer and (re-)attach the views as .grad."""
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def attached(self) -> bool:
+        return all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
+
+    def gather_stray(self) -> None:
+        """A .grad that was replaced by another tensor since zero() (an optimizer with set_to_none, a LeafGradSink
+        that installed its own buffer) is folded back into the flat buffer."""
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.add_(p.grad)
+                p.grad = v
+
+    def extra(self, name: str) -> torch.Tensor:
+        return self.flat[self.extra_slices[name]]
 
 
 class SubframeShard:
@@ -47,20 +121,34 @@ class SubframeShard:
 
     # ---- partition ----------------------------------------------------------------------------------
     def units(self, n_units: int) -> List[int]:
-        """Sub-frame indices this rank renders: u mod world == rank (round-robin keeps 9 units over 8 ranks at
-        ceil(9/8) = 2 on one rank, 1 elsewhere)."""
+        """Unit indices this rank renders: u mod world == rank (round-robin keeps 9 units over 8 ranks at
+        ceil(9/8) = 2 on one rank, 1 elsewhere; 18 units -- two views, the reference's batch -- at 3,3,2,...)."""
         return [u for u in range(n_units) if u % self.world == self.rank]
 
     def owner(self, unit: int) -> int:
         return unit % self.world
 
+    def owns(self, unit: int) -> bool:
+        return unit % self.world == self.rank
+
+    def view_units(self, n_views: int, n_sub: int) -> List[Tuple[int, int]]:
+        """(view, sub-frame) pairs of this rank for a batch of `n_views` views with `n_sub` sub-frames each; the
+        global unit index is view * n_sub + sub-frame."""
+        return [(u // n_sub, u % n_sub) for u in self.units(n_views * n_sub)]
+
+    def replicated_term(self, loss_term: torch.Tensor) -> torch.Tensor:
+        """Scale a loss term that EVERY rank forms identically from replicated data (not through the all-reduced
+        prediction, not on the outputs of one rank's render) so that the gradient SUM counts it once."""
+        return loss_term if self.world == 1 else loss_term / self.world
+
     # ---- forward exchange ---------------------------------------------------------------------------
-    def mean_of_subframes(self, local_sum: torch.Tensor, n_units: int) -> torch.Tensor:
-        """local_sum = sum of THIS rank's sub-frame renders -> mean over all n_units sub-frames (+1e-10, as
-        train.py:541), identical on every rank.  With one process and one unit it is the render itself."""
+    def mean_of_subframes(self, local_sum: torch.Tensor, n_units: int, donate: bool = False) -> torch.Tensor:
+        """local_sum = sum of THIS rank's sub-frame renders (any leading batch dimensions) -> mean over all n_units
+        sub-frames (+1e-10, as train.py:541), identical on every rank.  With one process and one unit it is the
+        render itself."""
         if self.world == 1:
             return local_sum if n_units == 1 else local_sum / n_units + 1e-10
-        total = _SumAcrossRanks.apply(local_sum, self.group)
+        total = _SumAcrossRanks.apply(local_sum, self.group, donate)
         return total / n_units + 1e-10
 
     def render_blurry_view(self, render_unit: Callable[[int], torch.Tensor], n_units: int,
@@ -79,24 +167,60 @@ class SubframeShard:
             local = torch.zeros_like(like)
         return self.mean_of_subframes(local, n_units)
 
+    def render_blurry_views(self, render_unit: Callable[[int, int], torch.Tensor], n_views: int, n_sub: int,
+                            like: torch.Tensor) -> torch.Tensor:
+        """Batch form (train.py:430-541 loops over the views of the batch): render_unit(view, k) -> [3,H,W].
+        ONE all-reduce for the whole batch: returns the blurry predictions [n_views,3,H,W] on every rank."""
+        sums: List[Optional[torch.Tensor]] = [None] * n_views
+        for v, k in self.view_units(n_views, n_sub):
+            img = render_unit(v, k)
+            sums[v] = img if sums[v] is None else sums[v] + img
+        local = torch.stack([s if s is not None else torch.zeros_like(like) for s in sums])
+        return self.mean_of_subframes(local, n_sub, donate=True)
+
     # ---- backward exchange --------------------------------------------------------------------------
-    def all_reduce_gradients(self, params: Sequence[torch.Tensor]) -> None:
-        """One flat all_reduce(SUM) over the .grad of every parameter (missing grads count as zero)."""
+    def all_reduce_gradients(self, params, async_op: bool = False):
+        """ONE all_reduce(SUM) over all parameter gradients.  `params`: a FlatGradients (in place on its persistent
+        buffer, statistics slots included) or a plain sequence of tensors (packed into a temporary flat buffer;
+        missing grads count as zero)."""
+        if isinstance(params, FlatGradients):
+            params.gather_stray()
+            if self.world == 1:
+                return None
+            return _all_reduce_sum(params.flat, self.group, async_op)
         if self.world == 1:
-            return
+            return None
         params = [p for p in params if p.requires_grad]
         if not params:
-            return
+            return None
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32)
                           for p in params])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        # the reduced gradients stay in the flat buffer: every .grad becomes a view of it (no copy back)
+        _all_reduce_sum(flat, self.group)
         off = 0
-        for p in params:
+        for p in params:  # the reduced gradients stay in the flat buffer: every .grad becomes a view of it
             n = p.numel()
             g = flat[off:off + n].view_as(p)
             p.grad = g if p.dtype == torch.float32 else g.to(p.dtype)
             off += n
+        return None
+
+    def put_densification_stats(self, bucket: FlatGradients, name: str, viewspace_grad: Optional[torch.Tensor],
+                                radii: Optional[torch.Tensor]) -> None:
+        """The rank that rendered a view's mid frame deposits `viewspace_points.grad` [.., N, 2] and `radii` [N]
+        (train.py:634-648 reads them for add_densification_stats) in the slot `name` (3 N floats) of the gradient
+        message; the other ranks leave zeros, so the SUM hands them to everyone."""
+        slot = bucket.extra(name)
+        n = slot.numel() // 3
+        if viewspace_grad is not None:
+            slot[:2 * n].copy_(viewspace_grad.reshape(-1)[:2 * n])
+        if radii is not None:
+            slot[2 * n:].copy_(radii.reshape(-1).to(torch.float32))
+
+    @staticmethod
+    def get_densification_stats(bucket: FlatGradients, name: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        slot = bucket.extra(name)
+        n = slot.numel() // 3
+        return slot[:2 * n].view(n, 2), slot[2 * n:].to(torch.int32)
 
 
 def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group=None) -> None:

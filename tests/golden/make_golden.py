@@ -341,6 +341,76 @@ def gen_blce(name, num_views=3, seed=8):
     save(name, **arrays)
 
 
+def gen_blurry_view(name, ns=700, nd=400, W=64, H=48, seed=31, num_views=2):
+    """One blurry training view as train.py:441-541 forms it, with the reference's own pieces: scene.blce.BLCE.forward
+    -> 9 latent c2w poses + exposure offsets; blceKernel.get_warped_cams' pose algebra (:150-157: R = c2w rotation,
+    T = translation of the inverse); gaussian_renderer.render() for the mid frame (train mode, the view's own camera)
+    and the 8 latent frames (warped camera, delta_exposure = exposure_time[k]); mean + 1e-10.  Back-propagated:
+    sum(pred * v) + sum(depth_mid * vd) + sum(d_alpha_mid * vd) -> gradients of every Gaussian leaf, the decoder and
+    the BLCE parameters of that view."""
+    gr = RH.ref_import("gaussian_renderer")
+    bl = RH.ref_import("scene.blce")
+    scam = SynthCamera().scaled(W, H)
+    w2c = small_w2c()
+    cam = PinholeCamera(W, H, scam.K, w2c, time=scam.time, max_time=scam.max_time)
+    stat, dyn = scene_params(ns, nd, scam, seed)
+    spc, dpc = ref_models(stat, dyn, seed)
+    bg = torch.tensor([0.1, 0.2, 0.3, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+    idx = 1
+    with RH.CudaToCpu():
+        torch.manual_seed(seed)
+        model = bl.BLCE(num_views=num_views, view_dim=32, num_warp=9, method="euler", adjoint=False)
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():  # decoders start at 1e-5 gain: give the latent poses a visible spread
+            for i in range(num_views):
+                for dec, sc in ((model.rot_decoder[i], 0.3), (model.trans_decoder[i], 0.02), (model.theta_decoder[i], 0.03)):
+                    dec.weight.copy_(sc * torch.randn(dec.weight.shape, generator=g))
+                    dec.bias.copy_(0.1 * sc * torch.randn(dec.bias.shape, generator=g))
+                model.wv_derivative[i].time_embedder.data = 0.5 * torch.randn(9, 8, generator=g)
+            model.view_embedder.data = torch.randn(num_views, 32, generator=g)
+            model.exposure_time_expo.data = torch.tensor([0.4, 0.3, 0.6])[:num_views]
+        img = torch.rand(3, H, W, generator=g)
+        blur = bl.compute_frequency_blur_feature(img)
+        c2w = torch.inverse(w2c)
+        warped_c2w, expo = model(c2w, blur, idx)
+        warped_w2c_full = torch.inverse(warped_c2w)
+        renders = []
+        mid = gr.render(cam, spc, dpc, None, bg, get_static=True, get_dynamic=True)
+        for k in range(9):
+            if k == 4:
+                renders.append(mid["render"])
+                continue
+            # get_cam (:160-163): Camera(R = c2w rotation, T = w2c translation) -> world_view_transform = [R^T | T]
+            R, T = warped_c2w[k, :3, :3], warped_w2c_full[k, :3, 3]
+            w2c_k = torch.eye(4)
+            w2c_k = torch.cat([torch.cat([R.transpose(0, 1), T[:, None]], dim=1), torch.tensor([[0.0, 0, 0, 1]])], dim=0)
+            cam_k = PinholeCamera(W, H, scam.K, w2c_k.detach(), time=scam.time, max_time=scam.max_time)
+            cam_k.world_view_transform = w2c_k.transpose(0, 1)  # differentiable pose (Camera keeps tensors, :109-146)
+            c2w_k = torch.inverse(w2c_k)
+            cam_k._ray = PinholeCamera.build_cam_ray_c2w(W, H, scam.K, c2w_k)
+            pkg = gr.render(cam_k, spc, dpc, None, bg, get_static=True, get_dynamic=True, delta_exposure=expo[k])
+            renders.append(pkg["render"])
+        pred = torch.mean(torch.stack(renders, dim=0), dim=0) + 1e-10
+    gq = torch.Generator().manual_seed(seed + 100)
+    v_pred = torch.randn(pred.shape, generator=gq)
+    v_depth = torch.randn(mid["depth"].shape, generator=gq)
+    ((pred * v_pred).sum() + (mid["depth"] * v_depth).sum() + (mid["d_alpha"] * v_depth).sum()).backward()
+    arrays = inputs_dict(stat, dyn, cam, w2c, spc, dpc, bg)
+    arrays.update({"in_image": np_(img), "in_idx": np.array([idx, num_views]), "out_pred": np_(pred),
+                   "out_mid_render": np_(mid["render"]), "out_mid_depth": np_(mid["depth"]),
+                   "out_mid_d_alpha": np_(mid["d_alpha"]), "out_warped_c2w": np_(warped_c2w), "out_exposure": np_(expo),
+                   "cot_v_pred": np_(v_pred), "cot_v_depth": np_(v_depth),
+                   "grad_viewspace_points": np_(mid["viewspace_points"].grad), "out_radii": np_(mid["radii"])})
+    for k, v in leafs(spc, dpc).items():
+        arrays["grad_" + k] = np_(v.grad) if v.grad is not None else None
+    for k, v in model.state_dict().items():
+        arrays["sd_" + k] = np_(v)
+    for k, p_ in model.named_parameters():
+        if p_.grad is not None and float(p_.grad.abs().max()) > 0:
+            arrays["bgrad_" + k] = np_(p_.grad)
+    save(name, **arrays)
+
+
 def gen_losses(name):
     lu = RH.ref_import("utils.loss_utils")
     iu = RH.ref_import("utils.image_utils")
@@ -563,6 +633,7 @@ def main():
     gen_deform("deform")
     gen_deform_mid("deform_mid")
     gen_blce("blce")
+    gen_blurry_view("blurry_view")
     gen_losses("losses")
     gen_densify("densify")
     gen_normals("normals")

@@ -1,0 +1,192 @@
+"""BASELINE config #4 on the GPU: one blurry training view = K = 9 latent sub-frame renders through BLCE-warped
+cameras, averaged (train.py:441-541).
+
+  * against tests/golden/blurry_view.npz (reference BLCE + reference render() x 9): blurry prediction, mid-frame
+    outputs, every Gaussian / decoder gradient, the BLCE parameter gradients, the mid-frame densification statistics,
+    with the BLCE forward/backward replayed as a HIP graph (asserted: no eager fallback);
+  * the (view, sub-frame) sharding with the REAL render: two processes (gloo) sharing this one GPU produce the
+    single-process predictions, gradients and statistics;
+  * the workload at its stated size (300 000 Gaussians, 1352x1014, K = 9): the batch helper equals nine separate
+    render() calls, and every parameter group receives a finite, non-zero gradient.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import close, leaf_map, load, scene_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _kernel_from_fixture(fx, dev):
+    from mobgs_amd.blce import blceKernel
+    idx, num_views = (int(v) for v in fx["in_idx"])
+    kern = blceKernel(num_views=num_views, num_warp=9, iteration=10000)
+    kern.model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("sd_")}, strict=True)
+    return kern.to(dev), idx
+
+
+def test_blurry_view_k9_blce_matches_reference_fixture(hip_device):
+    from mobgs_amd import blce as B
+    from mobgs_amd.deblur import render_blurry_batch
+    from mobgs_amd.distributed import SubframeShard
+    from mobgs_amd.ops import LeafGradSink
+    assert B.GRAPH_CAPTURE
+    fx = load("blurry_view")
+    dev = hip_device
+    cam, stat, dyn, bg, w2c = scene_from_fixture(fx, dev)
+    kern, idx = _kernel_from_fixture(fx, dev)
+    cam.uid = idx
+    cam.image = torch.from_numpy(fx["in_image"]).to(dev)
+    T = lambda k: torch.from_numpy(fx[k]).to(dev)  # noqa: E731
+    for rep in range(2):  # the second pass replays the captured graph
+        for p in list(leaf_map(stat, dyn).values()) + list(kern.model.parameters()):
+            p.grad = None
+        pred, mids = render_blurry_batch([cam], stat, dyn, bg, SubframeShard(1, 0), blce=kern, n_sub=9)
+        mid = mids[0]
+        with LeafGradSink(stat, dyn):
+            ((pred[0] * T("cot_v_pred")).sum() + (mid["depth"] * T("cot_v_depth")).sum()
+             + (mid["d_alpha"] * T("cot_v_depth")).sum()).backward()
+    g = kern._graphed.get(idx)
+    assert g is not None and g is not False, "BLCE must run as a captured HIP graph here (no eager fallback)"
+    # an alpha within an ulp of 1/255 is kept by one exp() and dropped by the other: <= 0.1 % of the pixels may move
+    # by one such blend step
+    close(pred[0], fx["out_pred"], 2e-5, 2e-5, "blurry prediction", flip_frac=1e-3, flip_atol=5e-3)
+    close(mid["render"], fx["out_mid_render"], 2e-5, 2e-5, "mid render", flip_frac=1e-3, flip_atol=5e-3)
+    close(mid["depth"], fx["out_mid_depth"], 2e-5, 2e-5 * float(np.abs(fx["out_mid_depth"]).max()), "mid depth")
+    close(mid["d_alpha"], fx["out_mid_d_alpha"], 2e-5, 2e-5, "mid d_alpha")
+    assert torch.equal(mid["radii"].cpu(), torch.from_numpy(fx["out_radii"]))
+    ref = fx["grad_viewspace_points"]
+    close(mid["viewspace_points"].grad, ref, 2e-3, 1e-4 * float(np.abs(ref).max()), "viewspace gradient",
+          flip_frac=5e-3, flip_atol=5e-3 * float(np.abs(ref).max()))
+    for k, leaf in leaf_map(stat, dyn).items():
+        ref = fx["grad_" + k]
+        sc = float(np.abs(ref).max())
+        close(leaf.grad, ref, 2e-3, 1e-4 * sc + 1e-8, f"grad {k}", flip_frac=5e-3, flip_atol=5e-3 * sc)
+    n = 0
+    for k, p in kern.model.named_parameters():
+        if "bgrad_" + k in fx:
+            ref = fx["bgrad_" + k]
+            close(p.grad, ref, 5e-3, 5e-4 * float(np.abs(ref).max()), f"BLCE grad {k}")
+            n += 1
+    assert n >= 20
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _iteration(dev, shard, fx_name="blurry_view", n_views=2):
+    """One sharded training iteration on the fixture scene (two views: the fixture's pose and a second one)."""
+    from mobgs_amd.camera import PinholeCamera
+    from mobgs_amd.deblur import render_blurry_batch
+    from mobgs_amd.distributed import FlatGradients
+    from mobgs_amd.ops import LeafGradSink
+    fx = load(fx_name)
+    cam, stat, dyn, bg, w2c = scene_from_fixture(fx, dev)
+    kern, idx = _kernel_from_fixture(fx, dev)
+    W, H = cam.image_width, cam.image_height
+    w2c_b = w2c.clone()
+    w2c_b[:3, 3] += torch.tensor([0.03, -0.01, 0.02], device=dev)
+    cams = [cam, PinholeCamera(W, H, cam.K, w2c_b, time=cam.time, max_time=cam.max_time, device=dev)][:n_views]
+    g = torch.Generator().manual_seed(3)
+    for i, c in enumerate(cams):
+        c.uid = i
+        c.image = torch.rand(3, H, W, generator=g).to(dev)
+    params = list(leaf_map(stat, dyn).values()) + list(kern.model.get_params())
+    n = stat.get_xyz.shape[0] + dyn.get_xyz.shape[0]
+    bucket = FlatGradients(params, extra={f"view{v}": 3 * n for v in range(n_views)})
+    v_pred = torch.randn(n_views, 3, H, W, generator=g).to(dev)
+    v_depth = torch.randn(1, H, W, generator=g).to(dev)
+    bucket.zero()
+    pred, mids = render_blurry_batch(cams, stat, dyn, bg, shard, blce=kern, n_sub=9)
+    reg = 1e-3 * sum((p ** 2).sum() for p in (stat._scaling, dyn._scaling))
+    loss = (pred * v_pred).sum() + shard.replicated_term(reg)
+    for v, pkg in mids.items():
+        loss = loss + (pkg["depth"] * v_depth).sum() + 0.5 * (pkg["d_alpha"] * v_depth).sum()
+    with LeafGradSink(stat, dyn):
+        loss.backward()
+    for v, pkg in mids.items():
+        shard.put_densification_stats(bucket, f"view{v}", pkg["viewspace_points"].grad, pkg["radii"])
+    shard.all_reduce_gradients(bucket)
+    return pred.detach().cpu(), bucket.flat.detach().cpu(), sorted(mids)
+
+
+def _shard_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mobgs_amd.distributed import SubframeShard
+        torch.cuda.set_device(0)
+        pred, flat, mids = _iteration(torch.device("cuda:0"), SubframeShard())
+        q.put((rank, pred.numpy(), flat.numpy(), mids))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_iteration_world2_on_one_gpu_equals_single_process(hip_device):
+    """Both ranks run the real HIP render on this GPU (collectives through gloo, staged via the host): 18 (view,
+    sub-frame) units split 9 / 9, mid frames of the two views on different ranks."""
+    import torch.multiprocessing as mp
+    from mobgs_amd.distributed import SubframeShard
+    ref_pred, ref_flat, _ = _iteration(hip_device, SubframeShard(1, 0))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    owners = sorted(v for _, _, _, mids in results for v in mids)
+    assert owners == [0, 1], "every view's mid frame is rendered by exactly one rank"
+    assert sorted(len(m) for _, _, _, m in results) == [1, 1], "... and the two mid frames land on different ranks"
+    sc = float(ref_flat.abs().max())
+    for rank, pred, flat, _ in results:
+        close(pred, ref_pred, 1e-5, 1e-5, f"rank {rank}: predictions")
+        # summation order differs (per-rank partial sums, then the reduction): fp32 round-off only
+        close(flat, ref_flat, 1e-3, 2e-5 * sc, f"rank {rank}: flat gradient + statistics buffer", flip_frac=2e-4,
+              flip_atol=1e-2 * sc)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_config4_workload_k9_300k_gaussians_1352x1014(hip_device):
+    import bench as B
+    from mobgs_amd.distributed import SubframeShard
+    from mobgs_amd.gaussian_renderer import render
+    dev = hip_device
+    W, H = 1352, 1014
+    scam, cam, stat, dyn, _ = B.build_scene(dev, 200_000, 100_000, W, H)
+    wl = B.DeblurWorkload(dev, stat, dyn, scam, W, H, SubframeShard(1, 0), n_views=1)
+    with torch.no_grad():  # spread the latent poses (the decoders start at 1e-5 gain)
+        g = torch.Generator().manual_seed(0)
+        m = wl.blce.model
+        for dec, s in ((m.rot_decoder[0], 0.3), (m.trans_decoder[0], 0.01), (m.theta_decoder[0], 0.02)):
+            dec.weight.copy_((s * torch.randn(dec.weight.shape, generator=g)).to(dev))
+    pred = wl.step()
+    pred2 = wl.step()  # HIP-graph replay of BLCE, arena sized from the previous frame
+    assert torch.equal(pred, pred2), "a step must be reproducible (no float atomics on the render path)"
+    g_blce = wl.blce._graphed.get(0)
+    assert g_blce is not None and g_blce is not False
+    # nine separate render() calls give the same mean
+    with torch.no_grad():
+        cams, expo = wl.blce.get_warped_cams(wl.cams[0], None, None)
+        frames = [render(wl.cams[0], stat, dyn, None, wl.bg)["render"] if k == 4 else
+                  render(cams[k], stat, dyn, None, wl.bg, delta_exposure=expo[k])["render"] for k in range(9)]
+        ref = torch.stack(frames).mean(0) + 1e-10
+    close(pred[0], ref, 1e-6, 1e-6, "mean of nine renders")
+    assert float((frames[0] - frames[8]).abs().max()) > 1e-2, "the latent frames must actually differ"
+    flat = wl.bucket.flat
+    assert torch.isfinite(flat).all()
+    for p in wl.params:
+        if p is stat._features_t:  # static colours are [features_dc, 0 * features_t]: its gradient is exactly zero
+            continue
+        assert p.grad is not None and float(p.grad.abs().max()) > 0, tuple(p.shape)
+    vs, radii = SubframeShard.get_densification_stats(wl.bucket, "view0")
+    assert int((radii > 0).sum()) > 250_000 and float(vs.abs().max()) > 0
