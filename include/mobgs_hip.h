@@ -354,6 +354,25 @@ int mobgs_prep_bwd(int Ns, int Nd, const float* times, const int64_t* d_ncp, con
                    float* g_s_scaling, float* g_s_rotation, float* g_s_opacity, float* g_s_fdc, float* g_s_ft,
                    float* g_d_control, float* g_d_scaling, float* g_d_rotation, float* g_d_omega,
                    float* g_d_opacity, float* g_d_fdc, float* g_d_ft, int accumulate, void* stream);
+/* The same two entry points for Gaussian sets whose ATTRIBUTES (scaling, rotation, omega, opacity, f_dc, f_t) are
+ * stored as IEEE binary16 (BASELINE config #5; no such mode exists in the reference, whose GaussianModel keeps
+ * fp32 nn.Parameters, scene/gaussian_model.py:1044-1090): the kernels read the halves from HBM and widen them in
+ * registers, arithmetic and outputs stay fp32.  xyz / control / trbf stay fp32.  mobgs_prep_bwd_f16 writes the
+ * attribute gradients as binary16 (what a half leaf's .grad must be); accumulation across renders in fp32 buffers
+ * goes through mobgs_prep_bwd, which does not read the attributes. */
+int mobgs_prep_fwd_f16(int Ns, int Nd, const float* times, const float* s_xyz, const uint16_t* s_scaling,
+                       const uint16_t* s_rotation, const uint16_t* s_opacity, const uint16_t* s_fdc,
+                       const uint16_t* s_ft, const float* d_control, const int64_t* d_ncp,
+                       const uint16_t* d_scaling, const uint16_t* d_rotation, const uint16_t* d_omega,
+                       const uint16_t* d_opacity, const uint16_t* d_fdc, const uint16_t* d_ft, const float* d_trbf,
+                       float* means, float* quats, float* scales, float* opacities, float* colors, void* stream);
+int mobgs_prep_bwd_f16(int Ns, int Nd, const float* times, const int64_t* d_ncp, const float* d_trbf,
+                       const float* scales, const float* opacities, const float* v_means, const float* v_quats,
+                       const float* v_scales, const float* v_opacities, const float* v_colors, float* g_s_xyz,
+                       uint16_t* g_s_scaling, uint16_t* g_s_rotation, uint16_t* g_s_opacity, uint16_t* g_s_fdc,
+                       uint16_t* g_s_ft, float* g_d_control, uint16_t* g_d_scaling, uint16_t* g_d_rotation,
+                       uint16_t* g_d_omega, uint16_t* g_d_opacity, uint16_t* g_d_fdc, uint16_t* g_d_ft,
+                       int accumulate, void* stream);
 
 /* ---- K9: colour decoder + expected-depth normalisation (replaces Sandwich.forward + gsplat's "ED" step) ---
  * /root/reference/helper_model.py:19-28; /root/reference/gaussian_renderer/__init__.py:216-227.

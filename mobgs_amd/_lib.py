@@ -60,6 +60,8 @@ _SIGS = {
     "mobgs_raster_layers_bwd": (c_int, [c_int] * 8 + [P] * 20 + [P]),  # incl. 7 host pointer arrays of length 3
     "mobgs_prep_fwd": (c_int, [c_int, c_int] + [P] * 21 + [P]),
     "mobgs_prep_bwd": (c_int, [c_int, c_int] + [P] * 23 + [c_int, P]),
+    "mobgs_prep_fwd_f16": (c_int, [c_int, c_int] + [P] * 21 + [P]),
+    "mobgs_prep_bwd_f16": (c_int, [c_int, c_int] + [P] * 23 + [c_int, P]),
     "mobgs_decoder_fwd": (c_int, [c_int, c_int, c_int, c_int] + [P] * 8 + [P]),
     "mobgs_decoder_bwd_blocks": (c_int, [c_int]),
     "mobgs_decoder_bwd": (c_int, [c_int, c_int, c_int, c_int] + [P] * 15 + [P]),
@@ -158,3 +160,17 @@ def f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+def attr_c(t: torch.Tensor, half: bool) -> torch.Tensor:
+    """A per-splat attribute array in the storage type the kernel was chosen for: contiguous, and float16 when
+    `half` (no copy when it already is -- the fp16-storage path never widens in HBM), float32 otherwise."""
+    want = torch.float16 if half else torch.float32
+    if t.dtype != want:
+        global attr_conversions
+        attr_conversions += 1
+        t = t.to(want)
+    return t.contiguous()
+
+
+attr_conversions = 0  # dtype conversions of attribute arrays on the way into a kernel (tests assert none happen)

@@ -15,9 +15,38 @@
 // times[0] = t_feat  = time + delta/max_time (unclamped; drives tfp = t_feat - trbf_center)
 // times[1] = t_curve = clamp(t_feat, 0, 1)    (drives the Hermite spline)
 // They are read from DEVICE memory so a BLCE exposure offset living on the GPU never forces a host sync.
+//
+// Attribute storage (BASELINE config #5, "fp16 Gaussian attributes"): the kernels are templated on the storage type
+// A of the per-splat ATTRIBUTES (scaling, rotation, omega, opacity, features_dc, features_t): float, or IEEE half
+// read straight from HBM and widened in registers (all arithmetic stays fp32; 80 -> 46 bytes per static splat,
+// 232 -> 188 per dynamic one).  Positions / spline control points / time centres stay fp32: a half cannot hold a
+// position in centimetres.  The backward kernel writes the attribute gradients in the type G the caller asks for
+// (half leaves need half .grad tensors; the multi-render accumulation buffers of LeafGradSink stay fp32).
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace mobgs {
+
+__device__ inline float ldf(const float* p, size_t i) { return p[i]; }
+__device__ inline float ldf(const __half* p, size_t i) { return __half2float(p[i]); }
+__device__ inline float4 ld4(const float* p, size_t i) { return reinterpret_cast<const float4*>(p)[i]; }
+__device__ inline float4 ld4(const __half* p, size_t i) {
+    const uint2 u = reinterpret_cast<const uint2*>(p)[i];  // 4 halves = 8 bytes
+    const __half2 a = *reinterpret_cast<const __half2*>(&u.x), b = *reinterpret_cast<const __half2*>(&u.y);
+    const float2 fa = __half22float2(a), fb = __half22float2(b);
+    return make_float4(fa.x, fa.y, fb.x, fb.y);
+}
+__device__ inline void stf(float* p, size_t i, float v) { p[i] = v; }
+__device__ inline void stf(__half* p, size_t i, float v) { p[i] = __float2half(v); }
+__device__ inline void st4(float* p, size_t i, float4 v) { reinterpret_cast<float4*>(p)[i] = v; }
+__device__ inline void st4(__half* p, size_t i, float4 v) {
+    const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+    uint2 u;
+    u.x = *reinterpret_cast<const unsigned*>(&a);
+    u.y = *reinterpret_cast<const unsigned*>(&b);
+    reinterpret_cast<uint2*>(p)[i] = u;
+}
 
 struct Hermite {
     int i0, i1, i2, i3;  // left, index, right, right-right knots
@@ -45,17 +74,18 @@ __device__ inline Hermite hermite_setup(float t, int n) {
     return H;
 }
 
+template <typename A>
 __global__ void __launch_bounds__(256)
 prep_fwd_kernel(int Ns, int Nd, const float* __restrict__ times,
                 // static
-                const float* __restrict__ s_xyz, const float* __restrict__ s_scaling,
-                const float* __restrict__ s_rotation, const float* __restrict__ s_opacity,
-                const float* __restrict__ s_fdc, const float* __restrict__ s_ft,
+                const float* __restrict__ s_xyz, const A* __restrict__ s_scaling,
+                const A* __restrict__ s_rotation, const A* __restrict__ s_opacity,
+                const A* __restrict__ s_fdc, const A* __restrict__ s_ft,
                 // dynamic
                 const float* __restrict__ d_control, const long long* __restrict__ d_ncp,
-                const float* __restrict__ d_scaling, const float* __restrict__ d_rotation,
-                const float* __restrict__ d_omega, const float* __restrict__ d_opacity,
-                const float* __restrict__ d_fdc, const float* __restrict__ d_ft, const float* __restrict__ d_trbf,
+                const A* __restrict__ d_scaling, const A* __restrict__ d_rotation,
+                const A* __restrict__ d_omega, const A* __restrict__ d_opacity,
+                const A* __restrict__ d_fdc, const A* __restrict__ d_ft, const float* __restrict__ d_trbf,
                 // out
                 float* __restrict__ means, float* __restrict__ quats, float* __restrict__ scales,
                 float* __restrict__ opac, float* __restrict__ colors) {
@@ -67,15 +97,15 @@ prep_fwd_kernel(int Ns, int Nd, const float* __restrict__ times,
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             m[k] = s_xyz[3 * i + k];
-            s[k] = __expf(s_scaling[3 * i + k]);
-            col[6 + k] = 0.0f * s_ft[3 * i + k];
+            s[k] = __expf(ldf(s_scaling, 3 * (size_t)i + k));
+            col[6 + k] = 0.0f * ldf(s_ft, 3 * (size_t)i + k);
         }
         // the reference normalises static rotations (get_rotation_stat); emit them raw, see header
-        const float4 r = reinterpret_cast<const float4*>(s_rotation)[i];
+        const float4 r = ld4(s_rotation, i);
         q[0] = r.x; q[1] = r.y; q[2] = r.z; q[3] = r.w;
-        o = 1.f / (1.f + __expf(-s_opacity[i]));
+        o = 1.f / (1.f + __expf(-ldf(s_opacity, i)));
 #pragma unroll
-        for (int k = 0; k < 6; ++k) col[k] = s_fdc[6 * i + k];
+        for (int k = 0; k < 6; ++k) col[k] = ldf(s_fdc, 6 * (size_t)i + k);
     } else {
         const int j = i - Ns;
         const float t_feat = times[0], t_curve = times[1];
@@ -89,15 +119,15 @@ prep_fwd_kernel(int Ns, int Nd, const float* __restrict__ times,
             const float m0 = H.left_edge ? (p2 - p1) : (p2 - p0) * 0.5f;
             const float m1 = H.right_edge ? (p2 - p1) : (p3 - p1) * 0.5f;
             m[k] = (H.h00 * p1 + H.h10 * m0 + H.h01 * p2 + H.h11 * m1) * 1e-2f;
-            s[k] = __expf(d_scaling[3 * j + k]);
-            col[6 + k] = tfp * d_ft[3 * j + k];
+            s[k] = __expf(ldf(d_scaling, 3 * (size_t)j + k));
+            col[6 + k] = tfp * ldf(d_ft, 3 * (size_t)j + k);
         }
-        const float4 r = reinterpret_cast<const float4*>(d_rotation)[j];
-        const float4 w = reinterpret_cast<const float4*>(d_omega)[j];
+        const float4 r = ld4(d_rotation, j);
+        const float4 w = ld4(d_omega, j);
         q[0] = r.x + tfp * w.x; q[1] = r.y + tfp * w.y; q[2] = r.z + tfp * w.z; q[3] = r.w + tfp * w.w;
-        o = 1.f / (1.f + __expf(-d_opacity[j]));
+        o = 1.f / (1.f + __expf(-ldf(d_opacity, j)));
 #pragma unroll
-        for (int k = 0; k < 6; ++k) col[k] = d_fdc[6 * j + k];
+        for (int k = 0; k < 6; ++k) col[k] = ldf(d_fdc, 6 * (size_t)j + k);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -112,7 +142,7 @@ prep_fwd_kernel(int Ns, int Nd, const float* __restrict__ times,
 
 // ACC: the leaf gradients are ADDED to what the buffers hold (several renders of one backward pass write into one
 // set of buffers, see mobgs_amd.ops.LeafGradSink) instead of overwriting them
-template <bool ACC>
+template <bool ACC, typename G>
 __global__ void __launch_bounds__(256)
 prep_bwd_kernel(int Ns, int Nd, const float* __restrict__ times, const long long* __restrict__ d_ncp,
                 const float* __restrict__ d_trbf,
@@ -123,12 +153,12 @@ prep_bwd_kernel(int Ns, int Nd, const float* __restrict__ times, const long long
                 const float* __restrict__ v_scales, const float* __restrict__ v_opac,
                 const float* __restrict__ v_colors,
                 // gradients of the leaves (static)
-                float* __restrict__ g_s_xyz, float* __restrict__ g_s_scaling, float* __restrict__ g_s_rotation,
-                float* __restrict__ g_s_opacity, float* __restrict__ g_s_fdc, float* __restrict__ g_s_ft,
+                float* __restrict__ g_s_xyz, G* __restrict__ g_s_scaling, G* __restrict__ g_s_rotation,
+                G* __restrict__ g_s_opacity, G* __restrict__ g_s_fdc, G* __restrict__ g_s_ft,
                 // gradients of the leaves (dynamic)
-                float* __restrict__ g_d_control, float* __restrict__ g_d_scaling, float* __restrict__ g_d_rotation,
-                float* __restrict__ g_d_omega, float* __restrict__ g_d_opacity, float* __restrict__ g_d_fdc,
-                float* __restrict__ g_d_ft) {
+                float* __restrict__ g_d_control, G* __restrict__ g_d_scaling, G* __restrict__ g_d_rotation,
+                G* __restrict__ g_d_omega, G* __restrict__ g_d_opacity, G* __restrict__ g_d_fdc,
+                G* __restrict__ g_d_ft) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = Ns + Nd;
     if (!ACC) {
@@ -167,20 +197,20 @@ prep_bwd_kernel(int Ns, int Nd, const float* __restrict__ times, const long long
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             g_s_xyz[3 * i + k] = (ACC ? g_s_xyz[3 * i + k] : 0.f) + vm[k];
-            g_s_scaling[3 * i + k] = (ACC ? g_s_scaling[3 * i + k] : 0.f) + vs[k];
-            g_s_ft[3 * i + k] = (ACC ? g_s_ft[3 * i + k] : 0.f) + 0.0f * vc[6 + k];
+            stf(g_s_scaling, 3 * (size_t)i + k, (ACC ? ldf(g_s_scaling, 3 * (size_t)i + k) : 0.f) + vs[k]);
+            stf(g_s_ft, 3 * (size_t)i + k, (ACC ? ldf(g_s_ft, 3 * (size_t)i + k) : 0.f) + 0.0f * vc[6 + k]);
         }
         {
             float4 q = make_float4(vq[0], vq[1], vq[2], vq[3]);
             if (ACC) {
-                const float4 o = reinterpret_cast<const float4*>(g_s_rotation)[i];
+                const float4 o = ld4(g_s_rotation, i);
                 q = make_float4(o.x + q.x, o.y + q.y, o.z + q.z, o.w + q.w);
             }
-            reinterpret_cast<float4*>(g_s_rotation)[i] = q;
+            st4(g_s_rotation, i, q);
         }
-        g_s_opacity[i] = (ACC ? g_s_opacity[i] : 0.f) + vo;
+        stf(g_s_opacity, i, (ACC ? ldf(g_s_opacity, i) : 0.f) + vo);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) g_s_fdc[6 * i + k] = (ACC ? g_s_fdc[6 * i + k] : 0.f) + vc[k];
+        for (int k = 0; k < 6; ++k) stf(g_s_fdc, 6 * (size_t)i + k, (ACC ? ldf(g_s_fdc, 6 * (size_t)i + k) : 0.f) + vc[k]);
     } else {
         const int j = i - Ns;
         const float tfp = times[0] - d_trbf[j];
@@ -219,30 +249,76 @@ prep_bwd_kernel(int Ns, int Nd, const float* __restrict__ times, const long long
                 gc[3 * H.i2 + k] = a2;
                 if (!H.right_edge) gc[3 * H.i3 + k] = a3;
             }
-            g_d_scaling[3 * j + k] = (ACC ? g_d_scaling[3 * j + k] : 0.f) + vs[k];
-            g_d_ft[3 * j + k] = (ACC ? g_d_ft[3 * j + k] : 0.f) + tfp * vc[6 + k];
+            stf(g_d_scaling, 3 * (size_t)j + k, (ACC ? ldf(g_d_scaling, 3 * (size_t)j + k) : 0.f) + vs[k]);
+            stf(g_d_ft, 3 * (size_t)j + k, (ACC ? ldf(g_d_ft, 3 * (size_t)j + k) : 0.f) + tfp * vc[6 + k]);
         }
         {
             float4 q = make_float4(vq[0], vq[1], vq[2], vq[3]);
             float4 w = make_float4(tfp * vq[0], tfp * vq[1], tfp * vq[2], tfp * vq[3]);
             if (ACC) {
-                const float4 o = reinterpret_cast<const float4*>(g_d_rotation)[j];
-                const float4 p = reinterpret_cast<const float4*>(g_d_omega)[j];
+                const float4 o = ld4(g_d_rotation, j);
+                const float4 p = ld4(g_d_omega, j);
                 q = make_float4(o.x + q.x, o.y + q.y, o.z + q.z, o.w + q.w);
                 w = make_float4(p.x + w.x, p.y + w.y, p.z + w.z, p.w + w.w);
             }
-            reinterpret_cast<float4*>(g_d_rotation)[j] = q;
-            reinterpret_cast<float4*>(g_d_omega)[j] = w;
+            st4(g_d_rotation, j, q);
+            st4(g_d_omega, j, w);
         }
-        g_d_opacity[j] = (ACC ? g_d_opacity[j] : 0.f) + vo;
+        stf(g_d_opacity, j, (ACC ? ldf(g_d_opacity, j) : 0.f) + vo);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) g_d_fdc[6 * j + k] = (ACC ? g_d_fdc[6 * j + k] : 0.f) + vc[k];
+        for (int k = 0; k < 6; ++k) stf(g_d_fdc, 6 * (size_t)j + k, (ACC ? ldf(g_d_fdc, 6 * (size_t)j + k) : 0.f) + vc[k]);
     }
 }
 
 }  // namespace mobgs
 
 using namespace mobgs;
+
+template <typename A>
+static int prep_fwd_launch(int Ns, int Nd, const float* times, const float* s_xyz, const A* s_scaling,
+                           const A* s_rotation, const A* s_opacity, const A* s_fdc, const A* s_ft,
+                           const float* d_control, const int64_t* d_ncp, const A* d_scaling, const A* d_rotation,
+                           const A* d_omega, const A* d_opacity, const A* d_fdc, const A* d_ft, const float* d_trbf,
+                           float* means, float* quats, float* scales, float* opacities, float* colors, void* stream,
+                           const char* who) {
+    if (Ns < 0 || Nd < 0) {
+        set_error("%s: bad sizes Ns=%d Nd=%d", who, Ns, Nd);
+        return MOBGS_E_INVALID;
+    }
+    const int N = Ns + Nd;
+    if (N == 0) return MOBGS_OK;
+    hipLaunchKernelGGL(prep_fwd_kernel<A>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, Ns, Nd, times,
+                       s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_control, (const long long*)d_ncp,
+                       d_scaling, d_rotation, d_omega, d_opacity, d_fdc, d_ft, d_trbf, means, quats, scales, opacities,
+                       colors);
+    return check_launch("prep_fwd_kernel");
+}
+
+template <typename G>
+static int prep_bwd_launch(int Ns, int Nd, const float* times, const int64_t* d_ncp, const float* d_trbf,
+                           const float* scales, const float* opacities, const float* v_means, const float* v_quats,
+                           const float* v_scales, const float* v_opacities, const float* v_colors, float* g_s_xyz,
+                           G* g_s_scaling, G* g_s_rotation, G* g_s_opacity, G* g_s_fdc, G* g_s_ft, float* g_d_control,
+                           G* g_d_scaling, G* g_d_rotation, G* g_d_omega, G* g_d_opacity, G* g_d_fdc, G* g_d_ft,
+                           int accumulate, void* stream, const char* who) {
+    if (Ns < 0 || Nd < 0) {
+        set_error("%s: bad sizes Ns=%d Nd=%d", who, Ns, Nd);
+        return MOBGS_E_INVALID;
+    }
+    const int N = Ns + Nd;
+    if (N == 0) return MOBGS_OK;
+    if (accumulate)
+        hipLaunchKernelGGL((prep_bwd_kernel<true, G>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, Ns, Nd,
+                           times, (const long long*)d_ncp, d_trbf, scales, opacities, v_means, v_quats, v_scales,
+                           v_opacities, v_colors, g_s_xyz, g_s_scaling, g_s_rotation, g_s_opacity, g_s_fdc, g_s_ft,
+                           g_d_control, g_d_scaling, g_d_rotation, g_d_omega, g_d_opacity, g_d_fdc, g_d_ft);
+    else
+        hipLaunchKernelGGL((prep_bwd_kernel<false, G>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, Ns,
+                           Nd, times, (const long long*)d_ncp, d_trbf, scales, opacities, v_means, v_quats, v_scales,
+                           v_opacities, v_colors, g_s_xyz, g_s_scaling, g_s_rotation, g_s_opacity, g_s_fdc, g_s_ft,
+                           g_d_control, g_d_scaling, g_d_rotation, g_d_omega, g_d_opacity, g_d_fdc, g_d_ft);
+    return check_launch("prep_bwd_kernel");
+}
 
 extern "C" {
 
@@ -252,16 +328,22 @@ int mobgs_prep_fwd(int Ns, int Nd, const float* times, const float* s_xyz, const
                    const float* d_omega, const float* d_opacity, const float* d_fdc, const float* d_ft,
                    const float* d_trbf, float* means, float* quats, float* scales, float* opacities, float* colors,
                    void* stream) {
-    if (Ns < 0 || Nd < 0) {
-        set_error("mobgs_prep_fwd: bad sizes Ns=%d Nd=%d", Ns, Nd);
-        return MOBGS_E_INVALID;
-    }
-    const int N = Ns + Nd;
-    if (N == 0) return MOBGS_OK;
-    hipLaunchKernelGGL(prep_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, Ns, Nd, times, s_xyz,
-                       s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_control, (const long long*)d_ncp, d_scaling,
-                       d_rotation, d_omega, d_opacity, d_fdc, d_ft, d_trbf, means, quats, scales, opacities, colors);
-    return check_launch("prep_fwd_kernel");
+    return prep_fwd_launch<float>(Ns, Nd, times, s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_control, d_ncp,
+                                  d_scaling, d_rotation, d_omega, d_opacity, d_fdc, d_ft, d_trbf, means, quats, scales,
+                                  opacities, colors, stream, "mobgs_prep_fwd");
+}
+
+int mobgs_prep_fwd_f16(int Ns, int Nd, const float* times, const float* s_xyz, const uint16_t* s_scaling,
+                       const uint16_t* s_rotation, const uint16_t* s_opacity, const uint16_t* s_fdc,
+                       const uint16_t* s_ft, const float* d_control, const int64_t* d_ncp, const uint16_t* d_scaling,
+                       const uint16_t* d_rotation, const uint16_t* d_omega, const uint16_t* d_opacity,
+                       const uint16_t* d_fdc, const uint16_t* d_ft, const float* d_trbf, float* means, float* quats,
+                       float* scales, float* opacities, float* colors, void* stream) {
+    auto H = [](const uint16_t* p) { return reinterpret_cast<const __half*>(p); };
+    return prep_fwd_launch<__half>(Ns, Nd, times, s_xyz, H(s_scaling), H(s_rotation), H(s_opacity), H(s_fdc), H(s_ft),
+                                   d_control, d_ncp, H(d_scaling), H(d_rotation), H(d_omega), H(d_opacity), H(d_fdc),
+                                   H(d_ft), d_trbf, means, quats, scales, opacities, colors, stream,
+                                   "mobgs_prep_fwd_f16");
 }
 
 int mobgs_prep_bwd(int Ns, int Nd, const float* times, const int64_t* d_ncp, const float* d_trbf,
@@ -270,23 +352,24 @@ int mobgs_prep_bwd(int Ns, int Nd, const float* times, const int64_t* d_ncp, con
                    float* g_s_scaling, float* g_s_rotation, float* g_s_opacity, float* g_s_fdc, float* g_s_ft,
                    float* g_d_control, float* g_d_scaling, float* g_d_rotation, float* g_d_omega, float* g_d_opacity,
                    float* g_d_fdc, float* g_d_ft, int accumulate, void* stream) {
-    if (Ns < 0 || Nd < 0) {
-        set_error("mobgs_prep_bwd: bad sizes Ns=%d Nd=%d", Ns, Nd);
-        return MOBGS_E_INVALID;
-    }
-    const int N = Ns + Nd;
-    if (N == 0) return MOBGS_OK;
-    if (accumulate)
-        hipLaunchKernelGGL(prep_bwd_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, Ns, Nd,
-                           times, (const long long*)d_ncp, d_trbf, scales, opacities, v_means, v_quats, v_scales,
-                           v_opacities, v_colors, g_s_xyz, g_s_scaling, g_s_rotation, g_s_opacity, g_s_fdc, g_s_ft,
-                           g_d_control, g_d_scaling, g_d_rotation, g_d_omega, g_d_opacity, g_d_fdc, g_d_ft);
-    else
-        hipLaunchKernelGGL(prep_bwd_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, Ns, Nd,
-                           times, (const long long*)d_ncp, d_trbf, scales, opacities, v_means, v_quats, v_scales,
-                           v_opacities, v_colors, g_s_xyz, g_s_scaling, g_s_rotation, g_s_opacity, g_s_fdc, g_s_ft,
-                           g_d_control, g_d_scaling, g_d_rotation, g_d_omega, g_d_opacity, g_d_fdc, g_d_ft);
-    return check_launch("prep_bwd_kernel");
+    return prep_bwd_launch<float>(Ns, Nd, times, d_ncp, d_trbf, scales, opacities, v_means, v_quats, v_scales,
+                                  v_opacities, v_colors, g_s_xyz, g_s_scaling, g_s_rotation, g_s_opacity, g_s_fdc,
+                                  g_s_ft, g_d_control, g_d_scaling, g_d_rotation, g_d_omega, g_d_opacity, g_d_fdc,
+                                  g_d_ft, accumulate, stream, "mobgs_prep_bwd");
+}
+
+int mobgs_prep_bwd_f16(int Ns, int Nd, const float* times, const int64_t* d_ncp, const float* d_trbf,
+                       const float* scales, const float* opacities, const float* v_means, const float* v_quats,
+                       const float* v_scales, const float* v_opacities, const float* v_colors, float* g_s_xyz,
+                       uint16_t* g_s_scaling, uint16_t* g_s_rotation, uint16_t* g_s_opacity, uint16_t* g_s_fdc,
+                       uint16_t* g_s_ft, float* g_d_control, uint16_t* g_d_scaling, uint16_t* g_d_rotation,
+                       uint16_t* g_d_omega, uint16_t* g_d_opacity, uint16_t* g_d_fdc, uint16_t* g_d_ft, int accumulate,
+                       void* stream) {
+    auto H = [](uint16_t* p) { return reinterpret_cast<__half*>(p); };
+    return prep_bwd_launch<__half>(Ns, Nd, times, d_ncp, d_trbf, scales, opacities, v_means, v_quats, v_scales,
+                                   v_opacities, v_colors, g_s_xyz, H(g_s_scaling), H(g_s_rotation), H(g_s_opacity),
+                                   H(g_s_fdc), H(g_s_ft), g_d_control, H(g_d_scaling), H(g_d_rotation), H(g_d_omega),
+                                   H(g_d_opacity), H(g_d_fdc), H(g_d_ft), accumulate, stream, "mobgs_prep_bwd_f16");
 }
 
 }  // extern "C"

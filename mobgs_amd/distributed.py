@@ -66,31 +66,40 @@ class _SumAcrossRanks(torch.autograd.Function):
 
 
 class FlatGradients:
-    """One persistent flat fp32 buffer; every parameter's .grad is a VIEW of it, so backward passes accumulate in
-    place and the exchange is a single in-place all-reduce (no torch.cat, no copy back).  `extra` reserves named
-    slots for per-step statistics that ride in the same message (name -> number of floats)."""
+    """One persistent flat buffer per parameter dtype (fp32; fp16 for attribute arrays stored in half precision);
+    every parameter's .grad is a VIEW of it, so backward passes accumulate in place and the exchange is an in-place
+    all-reduce per buffer (no torch.cat, no copy back).  `extra` reserves named fp32 slots for per-step statistics
+    that ride in the same message (name -> number of floats)."""
 
     def __init__(self, params: Sequence[torch.Tensor], extra: Optional[Dict[str, int]] = None):
         self.params = [p for p in params if p.requires_grad]
-        if any(p.dtype != torch.float32 for p in self.params):
-            raise NotImplementedError("FlatGradients holds fp32 parameters (the reference trains in fp32)")
+        if any(p.dtype not in (torch.float32, torch.float16) for p in self.params):
+            raise NotImplementedError("FlatGradients holds fp32 / fp16 parameters")
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.extra_slices: Dict[str, slice] = {}
-        n = sum(p.numel() for p in self.params)
-        off = n
+        sizes = {torch.float32: 0, torch.float16: 0}
+        for p in self.params:
+            sizes[p.dtype] += p.numel()
+        off = sizes[torch.float32]
         for name, k in (extra or {}).items():
             self.extra_slices[name] = slice(off, off + int(k))
             off += int(k)
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_half = torch.zeros(sizes[torch.float16], dtype=torch.float16, device=dev)
         self.views: List[torch.Tensor] = []
-        o = 0
+        o = {torch.float32: 0, torch.float16: 0}
         for p in self.params:
-            self.views.append(self.flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
+            buf = self.flat if p.dtype == torch.float32 else self.flat_half
+            self.views.append(buf[o[p.dtype]:o[p.dtype] + p.numel()].view_as(p))
+            o[p.dtype] += p.numel()
+
+    def buffers(self) -> List[torch.Tensor]:
+        return [b for b in (self.flat, self.flat_half) if b.numel()]
 
     def zero(self) -> None:
-        """Start of an iteration: clear the buffer and (re-)attach the views as .grad."""
-        self.flat.zero_()
+        """Start of an iteration: clear the buffers and (re-)attach the views as .grad."""
+        for b in self.buffers():
+            b.zero_()
         for p, v in zip(self.params, self.views):
             p.grad = v
 
@@ -187,7 +196,8 @@ class SubframeShard:
             params.gather_stray()
             if self.world == 1:
                 return None
-            return _all_reduce_sum(params.flat, self.group, async_op)
+            works = [_all_reduce_sum(b, self.group, async_op) for b in params.buffers()]
+            return works if async_op else None
         if self.world == 1:
             return None
         params = [p for p in params if p.requires_grad]

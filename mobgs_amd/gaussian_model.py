@@ -16,22 +16,29 @@ from .helper_model import Sandwich
 
 class GaussianParams:
     def __init__(self, params: Dict[str, torch.Tensor], dynamic: Optional[Dict[str, torch.Tensor]] = None,
-                 decoder: Optional[torch.nn.Module] = None, device="cpu", requires_grad: bool = False):
-        def P(t, grad=True):
+                 decoder: Optional[torch.nn.Module] = None, device="cpu", requires_grad: bool = False,
+                 attr_dtype: torch.dtype = torch.float32):
+        """attr_dtype=torch.float16: the per-splat ATTRIBUTES (scaling, rotation, omega, opacity, features) are kept
+        in half precision in HBM (BASELINE config #5; the render kernels widen them in registers).  Positions, spline
+        control points and time centres always stay fp32."""
+        def P(t, grad=True, attr=False):
             t = t.detach().clone().to(device)
+            if attr and t.is_floating_point():
+                t = t.to(attr_dtype)
             if grad and requires_grad and t.is_floating_point():
                 t.requires_grad_(True)
             return t
 
+        self.attr_dtype = attr_dtype
         self._xyz = P(params["xyz"])
-        self._scaling = P(params["scaling"])
-        self._rotation = P(params["rotation"])
-        self._opacity = P(params["opacity"])
-        self._features_dc = P(params["features_dc"])
-        self._features_t = P(params["features_t"])
+        self._scaling = P(params["scaling"], attr=True)
+        self._rotation = P(params["rotation"], attr=True)
+        self._opacity = P(params["opacity"], attr=True)
+        self._features_dc = P(params["features_dc"], attr=True)
+        self._features_t = P(params["features_t"], attr=True)
         n = self._xyz.shape[0]
         dyn = dynamic or {}
-        self._omega = P(dyn.get("omega", torch.zeros(n, 4)))
+        self._omega = P(dyn.get("omega", torch.zeros(n, 4)), attr=True)
         self._trbf_center = P(dyn.get("trbf_center", torch.zeros(n, 1)))
         self.control_xyz = P(dyn.get("control_xyz", (params["xyz"] * 100.0)[:, None, :].repeat(1, 12, 1)))
         self.current_control_num = P(dyn.get("current_control_num", torch.full((n, 1), 12, dtype=torch.int64)),

@@ -7,7 +7,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import check, f32c, ptr, stream
+from ._lib import attr_c, check, f32c, ptr, stream
 
 
 _LEAF_NAMES = ("s_xyz", "s_scaling", "s_rotation", "s_opacity", "s_fdc", "s_ft", "d_control", "d_scaling",
@@ -48,6 +48,8 @@ class LeafGradSink:
         if self.buffers is not None and exc[0] is None:
             for p, name in zip(self.leaves, _LEAF_NAMES):
                 g = self.buffers[name].view_as(p)
+                if g.dtype != p.dtype:  # fp16 attribute storage: accumulated in fp32, handed over in the leaf's dtype
+                    g = g.to(p.dtype)
                 if p.grad is None:
                     p.grad = g
                 else:
@@ -67,10 +69,15 @@ class PrepSplats(torch.autograd.Function):
         # the caller's tensor objects (a LeafGradSink recognises its leaves by identity)
         ctx.leaf_inputs = (s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_control, d_scaling, d_rotation,
                            d_omega, d_opacity, d_fdc, d_ft)
-        (times, s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_control, d_scaling, d_rotation, d_omega,
-         d_opacity, d_fdc, d_ft, d_trbf) = map(f32c, (times, s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_ft,
-                                                       d_control, d_scaling, d_rotation, d_omega, d_opacity, d_fdc,
-                                                       d_ft, d_trbf))
+        # fp16 attribute storage (BASELINE config #5): when every attribute leaf is float16 the kernel reads the halves
+        # directly; positions, control points and time centres are always fp32
+        attrs = (s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_scaling, d_rotation, d_omega, d_opacity, d_fdc, d_ft)
+        half = all(a.dtype == torch.float16 for a in attrs)
+        times, s_xyz, d_control, d_trbf = map(f32c, (times, s_xyz, d_control, d_trbf))
+        (s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_scaling, d_rotation, d_omega, d_opacity, d_fdc,
+         d_ft) = (attr_c(a, half) for a in attrs)
+        ctx.attr_dtypes = tuple(a.dtype for a in attrs)
+        ctx.half = half
         d_ncp = d_ncp.to(torch.int64).contiguous()
         Ns, Nd = s_xyz.shape[0], d_control.shape[0]
         N = Ns + Nd
@@ -80,10 +87,11 @@ class PrepSplats(torch.autograd.Function):
         scales = torch.empty(N, 3, dtype=torch.float32, device=dev)
         opac = torch.empty(N, dtype=torch.float32, device=dev)
         colors = torch.empty(N, 9, dtype=torch.float32, device=dev)
-        check(lib.mobgs_prep_fwd(Ns, Nd, ptr(times), ptr(s_xyz), ptr(s_scaling), ptr(s_rotation), ptr(s_opacity),
-                                 ptr(s_fdc), ptr(s_ft), ptr(d_control), ptr(d_ncp), ptr(d_scaling), ptr(d_rotation),
-                                 ptr(d_omega), ptr(d_opacity), ptr(d_fdc), ptr(d_ft), ptr(d_trbf), ptr(means),
-                                 ptr(quats), ptr(scales), ptr(opac), ptr(colors), stream()), "mobgs_prep_fwd")
+        fwd = lib.mobgs_prep_fwd_f16 if half else lib.mobgs_prep_fwd
+        check(fwd(Ns, Nd, ptr(times), ptr(s_xyz), ptr(s_scaling), ptr(s_rotation), ptr(s_opacity), ptr(s_fdc),
+                  ptr(s_ft), ptr(d_control), ptr(d_ncp), ptr(d_scaling), ptr(d_rotation), ptr(d_omega),
+                  ptr(d_opacity), ptr(d_fdc), ptr(d_ft), ptr(d_trbf), ptr(means), ptr(quats), ptr(scales), ptr(opac),
+                  ptr(colors), stream()), "mobgs_prep_fwd")
         ctx.save_for_backward(times, d_ncp, d_trbf, scales, opac)
         ctx.sizes = (Ns, Nd)
         return means, quats, scales, opac, colors
@@ -95,28 +103,39 @@ class PrepSplats(torch.autograd.Function):
         Ns, Nd = ctx.sizes
         dev = times.device
 
-        def E(*shape):
-            return torch.empty(*shape, dtype=torch.float32, device=dev)
-
         sink = _active_sink
         use_sink = sink is not None and getattr(ctx, "leaf_inputs", None) is not None and sink.accepts(ctx.leaf_inputs)
+        # attribute gradients: fp32 in the sink's accumulation buffers (cast once when the context exits), otherwise
+        # the dtype of the leaves (half leaves need half .grad tensors: written as such by the kernel)
+        g_half = ctx.half and not use_sink
+
+        def E(*shape, attr=False):
+            return torch.empty(*shape, dtype=torch.float16 if (attr and g_half) else torch.float32, device=dev)
+
         accumulate = 0
         if use_sink and sink.buffers is not None:
             g, accumulate = sink.buffers, 1
         else:
-            g = {"s_xyz": E(Ns, 3), "s_scaling": E(Ns, 3), "s_rotation": E(Ns, 4), "s_opacity": E(Ns, 1),
-                 "s_fdc": E(Ns, 6), "s_ft": E(Ns, 3), "d_control": E(Nd, 12, 3), "d_scaling": E(Nd, 3),
-                 "d_rotation": E(Nd, 4), "d_omega": E(Nd, 4), "d_opacity": E(Nd, 1), "d_fdc": E(Nd, 6),
-                 "d_ft": E(Nd, 3)}
+            g = {"s_xyz": E(Ns, 3), "s_scaling": E(Ns, 3, attr=True), "s_rotation": E(Ns, 4, attr=True),
+                 "s_opacity": E(Ns, 1, attr=True), "s_fdc": E(Ns, 6, attr=True), "s_ft": E(Ns, 3, attr=True),
+                 "d_control": E(Nd, 12, 3), "d_scaling": E(Nd, 3, attr=True), "d_rotation": E(Nd, 4, attr=True),
+                 "d_omega": E(Nd, 4, attr=True), "d_opacity": E(Nd, 1, attr=True), "d_fdc": E(Nd, 6, attr=True),
+                 "d_ft": E(Nd, 3, attr=True)}
             if use_sink:
                 sink.buffers = g
         c = [f32c(v) if v is not None else None for v in (v_means, v_quats, v_scales, v_opac, v_colors)]
-        check(lib.mobgs_prep_bwd(Ns, Nd, ptr(times), ptr(d_ncp), ptr(d_trbf), ptr(scales), ptr(opac), ptr(c[0]),
-                                 ptr(c[1]), ptr(c[2]), ptr(c[3]), ptr(c[4]), ptr(g["s_xyz"]), ptr(g["s_scaling"]),
-                                 ptr(g["s_rotation"]), ptr(g["s_opacity"]), ptr(g["s_fdc"]), ptr(g["s_ft"]),
-                                 ptr(g["d_control"]), ptr(g["d_scaling"]), ptr(g["d_rotation"]), ptr(g["d_omega"]),
-                                 ptr(g["d_opacity"]), ptr(g["d_fdc"]), ptr(g["d_ft"]), accumulate, stream()),
+        bwd = lib.mobgs_prep_bwd_f16 if g_half else lib.mobgs_prep_bwd
+        check(bwd(Ns, Nd, ptr(times), ptr(d_ncp), ptr(d_trbf), ptr(scales), ptr(opac), ptr(c[0]), ptr(c[1]), ptr(c[2]),
+                  ptr(c[3]), ptr(c[4]), ptr(g["s_xyz"]), ptr(g["s_scaling"]), ptr(g["s_rotation"]), ptr(g["s_opacity"]),
+                  ptr(g["s_fdc"]), ptr(g["s_ft"]), ptr(g["d_control"]), ptr(g["d_scaling"]), ptr(g["d_rotation"]),
+                  ptr(g["d_omega"]), ptr(g["d_opacity"]), ptr(g["d_fdc"]), ptr(g["d_ft"]), accumulate, stream()),
               "mobgs_prep_bwd")
+        if not use_sink and not g_half:  # mixed / other dtypes: autograd wants the leaf's dtype back
+            names = ("s_scaling", "s_rotation", "s_opacity", "s_fdc", "s_ft", "d_scaling", "d_rotation", "d_omega",
+                     "d_opacity", "d_fdc", "d_ft")
+            for n_, dt in zip(names, ctx.attr_dtypes):
+                if dt != torch.float32:
+                    g[n_] = g[n_].to(dt)
         if use_sink:
             return (None,) * 16
         return (None, g["s_xyz"], g["s_scaling"], g["s_rotation"], g["s_opacity"], g["s_fdc"], g["s_ft"],

@@ -1,0 +1,120 @@
+"""BASELINE config #5 on the GPU: Gaussian attributes stored as fp16 in HBM, read by the prep kernel as halves
+(no widened copy), 800 000 Gaussians, K = 9 deblur iteration.
+
+The reference has no fp16 mode (its GaussianModel keeps fp32 nn.Parameters), so there is no reference vector for it;
+what CAN be asserted exactly: widening a half is exact, so a render from half-stored attributes must equal, bit for
+bit, the fp32 render of the same values after rounding them to half; its gradients are the fp32 gradients rounded to
+half.  On top: PSNR against the un-rounded fp32 scene is reported, and the config's workload runs at its size.
+"""
+import pytest
+import torch
+
+from helpers import psnr
+
+pytestmark = pytest.mark.gpu
+
+ATTRS = ("_scaling", "_rotation", "_opacity", "_features_dc", "_features_t", "_omega")
+
+
+def _scene(dev, ns, nd, W, H, attr_dtype, seed=0, rounded=False):
+    """rounded=True: fp32 storage of the values a half-precision scene holds."""
+    from mobgs_amd.camera import PinholeCamera
+    from mobgs_amd.gaussian_model import GaussianParams
+    from mobgs_amd.helper_model import Sandwich
+    from mobgs_amd.synth import SynthCamera, dynamic_extras, gaussian_cloud
+    scam = SynthCamera().scaled(W, H) if (W, H) != (1352, 1014) else SynthCamera()
+    stat_p = gaussian_cloud(ns, scam, seed)
+    dyn_p = gaussian_cloud(nd, scam, seed + 1)
+    dyn_x = dynamic_extras(dyn_p["xyz"], seed)
+    if rounded:
+        for d in (stat_p, dyn_p):
+            for k in ("scaling", "rotation", "opacity", "features_dc", "features_t"):
+                d[k] = d[k].half().float()
+        dyn_x["omega"] = dyn_x["omega"].half().float()
+    torch.manual_seed(seed)
+    dec = Sandwich(9, 3).to(dev)
+    stat = GaussianParams(stat_p, None, dec, dev, requires_grad=True, attr_dtype=attr_dtype)
+    dyn = GaussianParams(dyn_p, dyn_x, dec, dev, requires_grad=True, attr_dtype=attr_dtype)
+    cam = PinholeCamera(W, H, scam.K, torch.eye(4), time=scam.time, max_time=scam.max_time, device=dev)
+    return scam, cam, stat, dyn
+
+
+def _fwd_bwd(cam, stat, dyn, dev, train_mode, sink):
+    from mobgs_amd.gaussian_renderer import render
+    from mobgs_amd.ops import LeafGradSink
+    import contextlib
+    W, H = cam.image_width, cam.image_height
+    g = torch.Generator().manual_seed(7)
+    v3, v1 = torch.randn(3, H, W, generator=g).to(dev), torch.randn(1, H, W, generator=g).to(dev)
+    out = render(cam, stat, dyn, None, torch.zeros(9, device=dev), get_static=train_mode, get_dynamic=train_mode)
+    outs, cots = [out["render"], out["depth"]], [v3, v1]
+    if train_mode:
+        outs += [out["d_alpha"], out["s_render"]]
+        cots += [v1, v3]
+    with (LeafGradSink(stat, dyn) if sink else contextlib.nullcontext()):
+        torch.autograd.backward(outs, cots)
+    return out
+
+
+@pytest.mark.parametrize("train_mode,sink", [(False, False), (True, True)])
+def test_half_storage_equals_fp32_render_of_the_rounded_values(hip_device, train_mode, sink):
+    from mobgs_amd import _lib
+    dev = hip_device
+    W, H, ns, nd = 320, 240, 20_000, 10_000
+    _, cam, s16, d16 = _scene(dev, ns, nd, W, H, torch.float16)
+    _, _, s32, d32 = _scene(dev, ns, nd, W, H, torch.float32, rounded=True)
+    for a in ATTRS:
+        assert getattr(s16, a).dtype == torch.float16 and getattr(d16, a).dtype == torch.float16
+        assert torch.equal(getattr(d16, a).float(), getattr(d32, a))
+    before = _lib.attr_conversions
+    o16 = _fwd_bwd(cam, s16, d16, dev, train_mode, sink)
+    assert _lib.attr_conversions == before, "the half attributes must reach the kernel as stored (no widened copy)"
+    o32 = _fwd_bwd(cam, s32, d32, dev, train_mode, sink)
+    assert torch.equal(o16["render"], o32["render"]) and torch.equal(o16["depth"], o32["depth"])
+    assert torch.equal(o16["radii"], o32["radii"])
+    for pc16, pc32 in ((s16, s32), (d16, d32)):
+        for a in ATTRS:
+            g16, g32 = getattr(pc16, a).grad, getattr(pc32, a).grad
+            if g32 is None:
+                assert g16 is None
+                continue
+            assert g16.dtype == torch.float16
+            # the fp32 gradient rounded to half (values beyond the half range saturate to inf in both)
+            assert torch.equal(g16, g32.half()), a
+        for a in ("_xyz", "control_xyz"):
+            g16, g32 = getattr(pc16, a).grad, getattr(pc32, a).grad
+            if g32 is not None:
+                assert g16.dtype == torch.float32 and torch.equal(g16, g32), a
+
+
+def test_config5_800k_k9_half_attributes(hip_device, capsys):
+    """800 000 Gaussians (533k static + 267k dynamic), 1352x1014, one K = 9 deblur iteration (1 view) with BLCE
+    cameras, attributes in half precision; PSNR of the half-storage render against the fp32 scene is reported."""
+    import bench as B
+    from mobgs_amd import _lib
+    from mobgs_amd.distributed import SubframeShard
+    from mobgs_amd.gaussian_renderer import render
+    dev = hip_device
+    W, H = 1352, 1014
+    scam, cam, s16, d16 = _scene(dev, 533_000, 267_000, W, H, torch.float16, seed=1)
+    _, _, s32, d32 = _scene(dev, 533_000, 267_000, W, H, torch.float32, seed=1)
+    bg = torch.zeros(9, device=dev)
+    with torch.no_grad():
+        img16 = render(cam, s16, d16, None, bg)["render"]
+        img32 = render(cam, s32, d32, None, bg)["render"]
+    p = psnr(img16.clamp(0, 1).cpu(), img32.clamp(0, 1).cpu())
+    with capsys.disabled():
+        print(f"\n[config #5] fp16-attribute render vs fp32 scene at 800k Gaussians: {p:.1f} dB")
+    assert p > 45.0
+    del s32, d32, img32
+    wl = B.DeblurWorkload(dev, s16, d16, scam, W, H, SubframeShard(1, 0), n_views=1)
+    before = _lib.attr_conversions
+    pred = wl.step()
+    pred = wl.step()
+    assert _lib.attr_conversions == before
+    assert torch.isfinite(pred).all()
+    assert wl.bucket.flat_half.numel() > 0 and wl.bucket.attached()
+    for b in wl.bucket.buffers():
+        assert torch.isfinite(b.float()).all()
+    assert float(wl.bucket.flat_half.float().abs().max()) > 0
+    assert int((wl.mids[0]["radii"] > 0).sum()) > 700_000
