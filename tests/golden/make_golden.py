@@ -168,6 +168,44 @@ def gen_get_flow(name, ns, nd, W, H, seed, delta):
     save(name, **arrays)
 
 
+def gen_get_flow_grad(name, ns, nd, W, H, seed, delta):
+    """get_flow() / get_flow_static() WITH gradients (train.py:570-579 back-propagates the flow loss through them):
+    fixed cotangents on all four outputs -> gradients of every leaf that receives one."""
+    gr = RH.ref_import("gaussian_renderer")
+    scam = SynthCamera().scaled(W, H)
+    w2c = small_w2c()
+    cam = PinholeCamera(W, H, scam.K, w2c, time=scam.time, max_time=scam.max_time)
+    stat, dyn = scene_params(ns, nd, scam, seed)
+    spc, dpc = ref_models(stat, dyn, seed)
+    bg = torch.zeros(9)
+    with RH.CudaToCpu():
+        e2m, m2e, img, alpha = gr.get_flow(cam, spc, dpc, None, bg, delta_exposure=torch.tensor(delta))
+    g = torch.Generator().manual_seed(seed + 100)
+    cots = [torch.randn(t.shape, generator=g) for t in (e2m, m2e, img, alpha)]
+    torch.autograd.backward([e2m, m2e, img, alpha], cots)
+    arrays = inputs_dict(stat, dyn, cam, w2c, spc, dpc, bg)
+    arrays.update({"opt": np.array([delta]), "out_exp2mid": np_(e2m), "out_mid2exp": np_(m2e),
+                   "out_latent_img": np_(img), "out_latent_alpha": np_(alpha)})
+    for n_, c in zip(("exp2mid", "mid2exp", "latent_img", "latent_alpha"), cots):
+        arrays["cot_" + n_] = np_(c)
+    for k, v in leafs(spc, dpc).items():
+        arrays["grad_" + k] = np_(v.grad) if v.grad is not None else None
+        v.grad = None
+    # get_flow_static
+    w2c_b = w2c.clone()
+    w2c_b[:3, 3] += torch.tensor([0.02, 0.01, -0.01])
+    cam_b = PinholeCamera(W, H, scam.K, w2c_b, time=scam.time, max_time=scam.max_time)
+    with RH.CudaToCpu():
+        flow_2d, flow_img = gr.get_flow_static(cam, cam_b, cam, spc, dpc, None, bg)
+    c2 = [torch.randn(t.shape, generator=g) for t in (flow_2d, flow_img)]
+    torch.autograd.backward([flow_2d, flow_img], c2)
+    arrays.update({"in_w2c_b": np_(w2c_b), "out_static_flow_2d": np_(flow_2d), "out_static_flow_img": np_(flow_img),
+                   "cot_static_flow_2d": np_(c2[0]), "cot_static_flow_img": np_(c2[1])})
+    for k, v in leafs(spc, dpc).items():
+        arrays["sgrad_" + k] = np_(v.grad) if v.grad is not None else None
+    save(name, **arrays)
+
+
 def gen_hermite(name):
     gr = RH.ref_import("gaussian_renderer")
     g = torch.Generator().manual_seed(11)
@@ -630,6 +668,7 @@ def main():
     gen_render("render_train_delta_flow", 900, 500, 80, 48, 1, True, True, 0.3, True, False)
     gen_render("render_train", 700, 400, 64, 48, 2, True, True, None, False, False)
     gen_get_flow("get_flow", 900, 500, 80, 48, 3, -0.4)
+    gen_get_flow_grad("get_flow_grad", 800, 450, 72, 48, 6, 0.3)
     gen_deform("deform")
     gen_deform_mid("deform_mid")
     gen_blce("blce")

@@ -75,6 +75,16 @@ def test_get_flow_matches_reference_fixture(hip_device):
     close(fimg, fx["out_static_flow_img"], 1e-5, 2e-4, "static flow image", flip_frac=2e-3, flip_atol=1.0)
 
 
+def test_get_flow_gradients_match_reference_fixture(hip_device):
+    """get_flow() / get_flow_static() forward AND backward against the reference's own autograd result (the only
+    reference check the 12-channel compositor backward, raster_bwd<12>, gets)."""
+    from test_oracle_cpu import _flow_grad_check
+    from mobgs_amd.gaussian_renderer import get_flow, get_flow_static
+    _flow_grad_check(load("get_flow_grad"), lambda cam, s, d, bg, dl: get_flow(cam, s, d, None, bg, delta_exposure=dl),
+                     lambda a, b, c, s, d, bg: get_flow_static(a, b, c, s, d, None, bg), hip_device, 2e-3, 2e-4,
+                     flip={"flip_frac": 2e-3, "flip_atol": 1.0})
+
+
 def test_hermite_wrapper_matches_reference_fixture(hip_device):
     from mobgs_amd.gaussian_renderer import interpolate_cubic_hermite
     fx = load("hermite")

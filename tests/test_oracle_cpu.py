@@ -213,6 +213,50 @@ def test_get_flow_restatement_matches_reference_fixture():
     close(fimg, fx["out_static_flow_img"], 1e-5, 1e-4, "static flow image")
 
 
+def _flow_grad_check(fx, get_flow_fn, get_flow_static_fn, device, rtol, atol_rel, flip=None):
+    """shared by the CPU (oracle) and GPU (HIP) tests of tests/golden/get_flow_grad.npz"""
+    from helpers import leaf_map
+    from mobgs_amd.camera import PinholeCamera
+    flip = flip or {}
+    cam, stat, dyn, bg, w2c = scene_from_fixture(fx, device=device, requires_grad=True)
+    T = lambda k: torch.from_numpy(fx[k]).to(device)  # noqa: E731
+    outs = get_flow_fn(cam, stat, dyn, bg, torch.tensor(float(fx["opt"][0]), device=device))
+    for got, key in zip(outs, ("out_exp2mid", "out_mid2exp", "out_latent_img", "out_latent_alpha")):
+        close(got, fx[key], 1e-5, 2e-4, key, **flip)
+    torch.autograd.backward(list(outs), [T(k) for k in ("cot_exp2mid", "cot_mid2exp", "cot_latent_img",
+                                                         "cot_latent_alpha")])
+    leaves = leaf_map(stat, dyn)
+    n = 0
+    for k, leaf in leaves.items():
+        if "grad_" + k in fx:
+            ref = fx["grad_" + k]
+            sc = float(np.abs(ref).max())
+            fl = {"flip_frac": flip["flip_frac"] * 5, "flip_atol": 0.05 * sc} if flip else {}
+            close(leaf.grad, ref, rtol, atol_rel * sc + 1e-9, f"get_flow grad {k}", **fl)
+            n += 1
+        else:
+            assert leaf.grad is None or float(leaf.grad.abs().max()) == 0.0, k
+        leaf.grad = None
+    assert n >= 14
+    cam_b = PinholeCamera(cam.image_width, cam.image_height, cam.K, T("in_w2c_b"), cam.time, cam.max_time,
+                          device=device)
+    f2d, fimg = get_flow_static_fn(cam, cam_b, cam, stat, dyn, bg)
+    close(f2d, fx["out_static_flow_2d"], 1e-5, 2e-4, "static flow_2d")
+    close(fimg, fx["out_static_flow_img"], 1e-5, 2e-4, "static flow image", **flip)
+    torch.autograd.backward([f2d, fimg], [T("cot_static_flow_2d"), T("cot_static_flow_img")])
+    for k in ("s__xyz", "s__scaling", "s__rotation", "s__opacity"):
+        ref = fx["sgrad_" + k]
+        sc = float(np.abs(ref).max())
+        fl = {"flip_frac": flip["flip_frac"] * 5, "flip_atol": 0.05 * sc} if flip else {}
+        close(leaves[k].grad, ref, rtol, atol_rel * sc + 1e-9, f"get_flow_static grad {k}", **fl)
+
+
+def test_get_flow_gradients_of_the_restatement_match_reference_fixture():
+    """get_flow()'s backward was never compared with the reference (the old fixture is no_grad)."""
+    _flow_grad_check(load("get_flow_grad"), lambda cam, s, d, bg, dl: R.get_flow(cam, s, d, bg, dl),
+                     lambda a, b, c, s, d, bg: R.get_flow_static(a, b, c, s), "cpu", 1e-4, 1e-5)
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/gaussian_renderer"), reason="reference tree not present")
 def test_render_restatement_matches_reference_live():
     """When /root/reference is present (build container), run its render() directly on a fresh scene."""
