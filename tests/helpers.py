@@ -109,3 +109,34 @@ def check_deform_fixture_grads(fx, get_plane_grad, what=""):
                       f"{what}grad plane {li}.{pi} samples", flip_frac=0.02, flip_atol=0.02 * sc)
                 assert abs(float(flat.double().abs().sum()) - a_ref) <= 1e-4 * a_ref, (li, pi)
                 assert abs(float(flat.double().sum()) - s_ref) <= 1e-4 * a_ref, (li, pi)
+
+
+def close_image_with_blend_flips(img, ref, alphas_ref, colors_absmax, depth_spread, tight_atol, what, flip_frac=2e-3,
+                                 n_colour_channels=None):
+    """Image comparison whose discrete-decision allowance is DERIVED, not guessed.  Two fp32 implementations of
+    alpha = o exp(-sigma) disagree in the last bit, so a splat sitting on the 1/255 skip threshold is blended by one
+    and skipped by the other (the 1e-4 transmittance stop moves a pixel by <= 1e-4 of the colour range).  The pixel
+    then moves by at most w (|c| + |pixel|) with w = alpha T <= 1/255 in a colour channel, and an expected-depth
+    channel (accumulated depth / alpha) by at most w spread / alpha_pixel.  `flip_frac` of the elements may use that
+    bound (x 2: the flip can also cascade into the next splat's weight), everything else must meet `tight_atol`.
+    -> (number of flipped elements, their largest error): logged by the callers."""
+    img = torch.as_tensor(img).detach().cpu().double()
+    ref = torch.as_tensor(ref).detach().cpu().double()
+    assert img.shape == ref.shape, f"{what}: shape {tuple(img.shape)} vs {tuple(ref.shape)}"
+    a = torch.as_tensor(alphas_ref).detach().cpu().double().reshape(ref.shape[:-1] + (1,))
+    C = ref.shape[-1]
+    nc = C if n_colour_channels is None else n_colour_channels
+    w = 1.0 / 255.0 * 1.001
+    bound = torch.empty_like(ref)
+    bound[..., :nc] = 2.0 * w * (colors_absmax + ref[..., :nc].abs())
+    if nc < C:
+        bound[..., nc:] = 2.0 * w * depth_spread / a.clamp_min(1.0 / 255.0)
+    err = (img - ref).abs()
+    bad = err > tight_atol
+    nbad = int(bad.sum())
+    msg = f"{what}: {nbad}/{bad.numel()} beyond {tight_atol:.1e}, max err {float(err.max()):.3e}"
+    assert nbad <= flip_frac * bad.numel(), msg
+    over = bad & (err > bound)
+    assert not bool(over.any()), msg + f"; {int(over.sum())} exceed the one-blend-step bound, worst " \
+        f"{float((err / bound)[over].max()):.2f}x"
+    return nbad, (float(err[bad].max()) if nbad else 0.0)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import close, psnr
+from helpers import close, close_image_with_blend_flips, psnr
 from mobgs_amd.synth import SynthCamera, splat_inputs
 
 pytestmark = pytest.mark.gpu
@@ -53,7 +53,14 @@ def test_fullsize_forward_backward_against_c_oracle(hip_device, scene300k):
     assert np.abs(rad - ref_rad)[both].max(initial=0) <= 1
     ref = torch.from_numpy(r["render"])
     scale = float(ref.abs().max())
-    close(img, ref, 0, 3e-5 * scale, "image", flip_frac=2e-3, flip_atol=scale / 50)
+    # SURVEY's criterion (max |dpixel| <= 2e-5 of the range) for every pixel except those where an alpha-threshold
+    # decision flips; those are bounded by the flipped splat's own weight (helpers.close_image_with_blend_flips)
+    vis_depth = meta["depths"][meta["radii"] > 0]
+    nflip, worst = close_image_with_blend_flips(img, ref, r["alphas"], float(s["colors"].abs().max()),
+                                                float(vis_depth.max() - vis_depth.min()), 3e-5 * scale, "image",
+                                                flip_frac=2e-3, n_colour_channels=9)
+    print(f"\n[fullsize] image: {nflip} of {ref.numel()} elements beyond 3e-5 x range (largest {worst:.2e}); all "
+          "within the one-blend-step bound")
     target = (ref[..., :9] / scale + 0.05 * torch.randn(ref[..., :9].shape, generator=g))
     assert abs(psnr(img[..., :9].cpu() / scale, target) - psnr(ref[..., :9] / scale, target)) <= 1e-4
     for k, ck in [("means", "v_means"), ("quats", "v_quats"), ("scales", "v_scales"), ("opacities", "v_opacities"),
