@@ -19,9 +19,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in _host;
  *   - the caller owns every buffer (outputs and scratch); the library never allocates device memory; its only
- *     mutable state is the thread-local last-error string, two process-wide scheduling hints
- *     (mobgs_set_heavy_tile_len, mobgs_hint_longest_list) and one testing switch (mobgs_set_quadrant_culling) that
- *     change how work is distributed or skipped, never a result;
+ *     mutable state is the thread-local last-error string -- scheduling policy and testing switches travel with
+ *     each call (MobgsTuning), so calls are re-entrant across streams, devices and threads;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises, except
  *     mobgs_project_and_bin (one documented read-back);
  *   - return value: 0 on success, negative MOBGS_E_* on failure (mobgs_last_error() gives the text);
@@ -52,6 +51,22 @@ extern "C" {
 #define MOBGS_MAX_CHANNELS 32
 
 /* Library identification.  Returns e.g. "mobgs_hip 0.1 gfx950". */
+/* Per-call policy of the binning / compositing entry points.  The library keeps NO mutable state: what used to be
+ * process-wide setters travels with each call (host pointer, may be NULL = all defaults; a negative field = default).
+ *   heavy_tile_len     scheduling: a tile whose list has at least this many entries (at most an eighth of the tiles)
+ *                      is composited by a whole workgroup, one 8x8 quadrant per wave.  Default 1024; 0 = never.
+ *   longest_list_hint  the longest per-tile list the caller expects (e.g. the previous frame's stats[2]): >= 2048
+ *                      makes mobgs_isect_offsets rank through LDS first (dense image regions).  Default 0.
+ *   quadrant_culling   testing aid, default 1: the compositors skip, per list entry, the 8x8 quadrants of the tile
+ *                      the splat cannot reach (work that is predicated off at every pixel); 0 evaluates everything
+ *                      -- results are identical. */
+typedef struct MobgsTuning {
+    int32_t heavy_tile_len;
+    int32_t longest_list_hint;
+    int32_t quadrant_culling;
+    int32_t reserved;
+} MobgsTuning;
+
 const char* mobgs_version(void);
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* mobgs_last_error(void);
@@ -100,7 +115,7 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
  *      tile_order [mobgs_tile_order_len(C*n_tiles)] (may be NULL) the schedule of the compositing kernels, 4
  *                slots per workgroup: tile ids by descending list length (1024 length classes; longest lists
  *                first, lists of similar length share a workgroup), -1 = unused slot.  Tiles whose list is at
- *                least mobgs_get_heavy_tile_len() long (at most an eighth of the tiles) appear as id | 1<<30 in
+ *                least MobgsTuning.heavy_tile_len long (at most an eighth of the tiles) appear as id | 1<<30 in
  *                the 4 slots of one workgroup, whose 4 waves then composite one 8x8 quadrant each.  A schedule
  *                only -- images do not depend on it; the compositing entry points accept NULL for raster order.
  *      stats int64[3] = {I_box, I_listed, longest per-tile list}; the caller reads them back to size the list
@@ -112,20 +127,13 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
  * scratch: mobgs_isect_scratch_bytes(C*N, C*n_tiles, capacity) bytes. */
 size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity);
 size_t mobgs_tile_order_len(int n_tiles);  /* int32 entries of tile_order */
-void mobgs_set_heavy_tile_len(int len);    /* scheduling policy, default 1024; 0 = never split a tile */
-/* Testing aid, default on: the compositors skip, per list entry, the 8x8 quadrants of the tile the splat cannot
- * reach (work that is predicated off at every pixel); 0 evaluates everything -- results are identical. */
-void mobgs_set_quadrant_culling(int on);
-int mobgs_get_quadrant_culling(void);
-void mobgs_hint_longest_list(int len);     /* longest list expected (e.g. last frame's): >= 2048 makes the next
-                                              mobgs_isect_offsets rank through LDS first (dense image regions) */
-int mobgs_get_heavy_tile_len(void);
 size_t mobgs_keep_scan_len(int capacity); /* int32 entries of keep_scan for `capacity` box intersections */
 int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
                         const int32_t* tiles_per_gauss, const float* means2d, const int32_t* radii,
                         const float* conics, const float* opacities, int opac_per_camera,
                         int32_t* cum_tiles, int32_t* keep_scan, int32_t* tile_offsets, int32_t* tile_order,
-                        int64_t capacity_listed, int64_t* stats, void* scratch, void* stream);
+                        int64_t capacity_listed, int64_t* stats, void* scratch, const MobgsTuning* tuning,
+                        void* stream);
 
 /* ---- K3b/K4: emit + per-tile depth sort (replaces isect_tiles pass 2 + CUB DeviceRadixSort) ------------
  * Writes, per tile, its listed splats ordered by (float depth bits ascending, flat id ascending) -- the order a
@@ -167,7 +175,7 @@ int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, 
                           float* conics, int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* tile_offsets,
                           int32_t* tile_order, int64_t* stats_dev, int capacity_box, int32_t* keep_scan, void* scratch,
                           int64_t capacity_listed, int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
-                          int64_t* stats_host, void* stream);
+                          int64_t* stats_host, const MobgsTuning* tuning, void* stream);
 
 /* mobgs_project_and_bin WITHOUT the host synchronisation: every stage is enqueued, the three counts are copied
  * asynchronously into stats_host_pinned (page-locked host memory, valid once the caller has waited on an event
@@ -194,7 +202,7 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
                                       int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
                                       int64_t max_tile_len_hint, int64_t* stats_host_pinned, int64_t stats_seq,
                                       const float* pack_colors, int colors_per_camera, int pack_channels,
-                                      float* pack_records, void* stream);
+                                      float* pack_records, const MobgsTuning* tuning, void* stream);
 
 /* ---- K6: rasterise forward (replaces gsplat rasterize_to_pixels fwd) -----------------------------------
  * colors   : [C,N,channels] (colors_per_camera=1) or [N,channels] (0); NULL: `records` are already packed (by
@@ -212,7 +220,8 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
                      const float* opacities, int opac_per_camera, const float* extra,
                      const float* backgrounds, const int32_t* radii, const int32_t* tile_offsets,
                      const int32_t* tile_order, const int32_t* flatten_ids, float* records, float* render,
-                     float* alphas, int32_t* last_ids, uint8_t* isect_reach, void* stream);
+                     float* alphas, int32_t* last_ids, uint8_t* isect_reach, const MobgsTuning* tuning,
+                     void* stream);
 
 /* ---- K7: rasterise backward (replaces gsplat rasterize_to_pixels bwd) ----------------------------------
  * Deterministic two-stage gradient reduction, no floating-point atomics:
@@ -228,7 +237,8 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
                      const float* means2d, const int32_t* cum_tiles, const int32_t* keep_scan,
                      const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
                      const float* render_alphas, const int32_t* last_ids, const float* v_render,
-                     const float* v_alphas, float* grad_slots, const uint8_t* isect_reach, void* stream);
+                     const float* v_alphas, float* grad_slots, const uint8_t* isect_reach,
+                     const MobgsTuning* tuning, void* stream);
 int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int32_t* cum_tiles,
                             const int32_t* keep_scan, const float* grad_slots, float* v_means2d, float* v_conics, float* v_opacities,
                             float* v_colors, float* v_extra, void* stream);
@@ -319,13 +329,13 @@ int mobgs_normals_bwd(int H, int W, float fx, float fy, float cx, float cy, floa
 int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_total, int width, int height,
                            const float* records, const float* backgrounds, const int32_t* tile_offsets,
                            const int32_t* tile_order, const int32_t* flatten_ids, float* render, float* alphas,
-                           int32_t* last_ids, uint8_t* isect_reach, void* stream);
+                           int32_t* last_ids, uint8_t* isect_reach, const MobgsTuning* tuning, void* stream);
 int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_total, int width, int height,
                            const float* records, const float* backgrounds, const int32_t* radii,
                            const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
                            const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
                            const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
-                           const uint8_t* isect_reach, void* stream);
+                           const uint8_t* isect_reach, const MobgsTuning* tuning, void* stream);
 
 /* 1 if raster kernels are compiled for `total_channels` (colour channels + optional extra channel). */
 int mobgs_raster_channels_supported(int total_channels);

@@ -15,6 +15,19 @@ from .build import LIB_PATH, build_extension, is_stale
 
 _lib: Optional[ctypes.CDLL] = None
 
+
+class MobgsTuning(ctypes.Structure):
+    """include/mobgs_hip.h MobgsTuning: per-call policy (-1 = library default).  The library keeps no state; a
+    caller-side instance (mobgs_amd.rendering.tuning) is passed by pointer with every call that consults it."""
+    _fields_ = [("heavy_tile_len", ctypes.c_int32), ("longest_list_hint", ctypes.c_int32),
+                ("quadrant_culling", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+    def __init__(self, heavy_tile_len=-1, longest_list_hint=-1, quadrant_culling=-1):
+        super().__init__(heavy_tile_len, longest_list_hint, quadrant_culling, 0)
+
+    def ref(self):
+        return ctypes.cast(ctypes.pointer(self), c_void_p)
+
 P = c_void_p
 _SIGS = {
     "mobgs_version": (c_char_p, []),
@@ -29,23 +42,20 @@ _SIGS = {
     "mobgs_isect_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "mobgs_keep_scan_len": (c_size_t, [c_int]),
     "mobgs_tile_order_len": (c_size_t, [c_int]),
-    "mobgs_set_heavy_tile_len": (None, [c_int]),
-    "mobgs_set_quadrant_culling": (None, [c_int]),
-    "mobgs_get_quadrant_culling": (c_int, []),
-    "mobgs_get_heavy_tile_len": (c_int, []),
-    "mobgs_hint_longest_list": (None, [c_int]),
-    "mobgs_isect_offsets": (c_int, [c_int] * 8 + [P] * 5 + [c_int] + [P] * 4 + [c_int64] + [P] * 2 + [P]),
+    "mobgs_isect_offsets": (c_int, [c_int] * 8 + [P] * 5 + [c_int] + [P] * 4 + [c_int64] + [P] * 2 + [P, P]),
     "mobgs_isect_emit_sort": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int64, c_int64] + [P] * 7 + [P]),
     "mobgs_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, P, P,
-                                 P, P, P, P, P]),
-    "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int] + [P] * 15 + [P]),
+                                 P, P, P, P, P, P]),
+    "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int] + [P] * 15 + [P, P]),
     "mobgs_raster_bwd_reduce": (c_int, [c_int, c_int, c_int, c_int] + [P] * 8 + [P]),
     "mobgs_project_and_bin": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
-                                      c_float, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, P, P, P]),
+                                      c_float, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, P, P, P,
+                                      P]),
     "mobgs_isect_emit_sort_speculative": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int64, c_int64] + [P] * 8 + [P]),
     "mobgs_project_and_bin_speculative": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float,
                                                   c_float, c_float, c_float, c_int, P, P, P, P, P, P, P, P, P, c_int,
-                                                  P, P, c_int64, P, P, P, c_int64, P, c_int64, P, c_int, c_int, P, P]),
+                                                  P, P, c_int64, P, P, P, c_int64, P, c_int64, P, c_int, c_int, P, P,
+                                                  P]),
     "mobgs_densify_stats": (c_int, [c_int, P, c_int, P, P, P, P, P, P]),
     "mobgs_densify_select": (c_int, [c_int, c_int, P, P, P, c_float, c_float, P, P, P]),
     "mobgs_mask_indices": (c_int, [c_int, P, c_int, P, P, P]),
@@ -53,8 +63,8 @@ _SIGS = {
     "mobgs_split_children": (c_int, [c_int, c_int, c_int, P, P, P, P, P]),
     "mobgs_normals_fwd": (c_int, [c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P]),
     "mobgs_normals_bwd": (c_int, [c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P, P]),
-    "mobgs_raster_class_fwd": (c_int, [c_int] * 7 + [P] * 9 + [P]),
-    "mobgs_raster_class_bwd": (c_int, [c_int] * 7 + [P] * 14 + [P]),
+    "mobgs_raster_class_fwd": (c_int, [c_int] * 7 + [P] * 9 + [P, P]),
+    "mobgs_raster_class_bwd": (c_int, [c_int] * 7 + [P] * 14 + [P, P]),
     "mobgs_pack_records": (c_int, [c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P]),
     "mobgs_raster_layers_fwd": (c_int, [c_int] * 7 + [P] * 8 + [P]),
     "mobgs_raster_layers_bwd": (c_int, [c_int] * 8 + [P] * 20 + [P]),  # incl. 7 host pointer arrays of length 3

@@ -172,7 +172,13 @@ int isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width, int he
                          const int32_t* tiles_per_gauss, const float* means2d, const int32_t* radii, const float* conics,
                          const float* opacities, int opac_per_camera, int32_t* cum_tiles, int32_t* keep_scan,
                          int32_t* tile_offsets, int32_t* tile_order, int64_t capacity_listed, int64_t* stats,
-                         void* scratch, bool scratch_zeroed, int64_t* stats_mirror, int64_t stats_seq, void* stream);
+                         void* scratch, bool scratch_zeroed, int64_t* stats_mirror, int64_t stats_seq,
+                         const MobgsTuning* tuning, void* stream);
+
+// per-call policy (include/mobgs_hip.h MobgsTuning): NULL or a negative field = the library default
+inline int tuning_heavy_len(const MobgsTuning* t) { return (t && t->heavy_tile_len >= 0) ? t->heavy_tile_len : 1024; }
+inline int tuning_list_hint(const MobgsTuning* t) { return (t && t->longest_list_hint >= 0) ? t->longest_list_hint : 0; }
+inline int tuning_all_reach(const MobgsTuning* t) { return (t && t->quadrant_culling == 0) ? 1 : 0; }
 void isect_zeroed_region(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity, int32_t** ptr, size_t* count);
 
 // bit q = 2 * qy + qx set <=> the splat may reach alpha >= 1/255 at a pixel centre of the 8x8 quadrant (qx, qy) of

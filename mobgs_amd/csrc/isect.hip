@@ -916,11 +916,9 @@ __global__ void __launch_bounds__(THREADS) tile_sort_kernel(int n_tiles_total, i
 
 using namespace mobgs;
 
-// list length from which a tile is composited by a whole workgroup (scheduling policy, see tile_scan_kernel)
-static int g_heavy_len = 1024;
-// longest list of the previous frame as told by the orchestrator (mobgs_project_and_bin_speculative): selects the
-// dense variant of bin_kernel
-static int g_dense_hint = 0;
+// MobgsTuning.heavy_tile_len: list length from which a tile is composited by a whole workgroup (scheduling policy,
+// see tile_scan_kernel); MobgsTuning.longest_list_hint: longest list the caller expects (e.g. the previous frame's):
+// selects the dense variant of bin_kernel.  Both travel with the call -- the library keeps no mutable state.
 constexpr int DENSE_LIST_LEN = 2048;
 constexpr int DENSE_MAX_TILES = 8192;  // 32 KiB of LDS
 
@@ -952,10 +950,6 @@ struct IsectScratch {
 
 size_t mobgs_tile_order_len(int n_tiles) { return sched_slots((size_t)n_tiles); }
 
-void mobgs_set_heavy_tile_len(int len) { g_heavy_len = len < 0 ? 0 : len; }
-void mobgs_hint_longest_list(int len) { g_dense_hint = len < 0 ? 0 : len; }
-int mobgs_get_heavy_tile_len(void) { return g_heavy_len; }
-
 size_t mobgs_keep_scan_len(int capacity) { return keep_scan_len((size_t)capacity); }
 
 size_t mobgs_isect_scratch_bytes(int n_gauss, int n_tiles, int capacity) {
@@ -967,11 +961,11 @@ int mobgs_isect_offsets(int C, int N, int tile_w, int tile_h, int width, int hei
                         const int32_t* tiles_per_gauss, const float* means2d, const int32_t* radii,
                         const float* conics, const float* opacities, int opac_per_camera, int32_t* cum_tiles,
                         int32_t* keep_scan, int32_t* tile_offsets, int32_t* tile_order, int64_t capacity_listed,
-                        int64_t* stats, void* scratch, void* stream) {
+                        int64_t* stats, void* scratch, const MobgsTuning* tuning, void* stream) {
     return mobgs::isect_offsets_launch(C, N, tile_w, tile_h, width, height, cull, capacity, tiles_per_gauss, means2d, radii,
                                        conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order,
                                        capacity_listed, stats, scratch, /*scratch_zeroed=*/false, /*stats_mirror=*/nullptr,
-                                       /*stats_seq=*/0, stream);
+                                       /*stats_seq=*/0, tuning, stream);
 }
 
 }  // extern "C"
@@ -988,7 +982,8 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
                                 const float* conics, const float* opacities, int opac_per_camera, int32_t* cum_tiles,
                                 int32_t* keep_scan, int32_t* tile_offsets, int32_t* tile_order, int64_t capacity_listed,
                                 int64_t* stats, void* scratch, bool scratch_zeroed, int64_t* stats_mirror,
-                                int64_t stats_seq, void* stream) {
+                                int64_t stats_seq, const MobgsTuning* tuning, void* stream) {
+    const int heavy_len = tuning_heavy_len(tuning), dense_hint = tuning_list_hint(tuning);
     const long long ng = (long long)C * N;
     const long long nt = (long long)C * tile_w * tile_h;
     if (C <= 0 || N < 0 || capacity < 1 || ng >= (1ll << 31) - 1 || nt >= (1ll << 31) - 1) {
@@ -1009,7 +1004,7 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
         hipMemsetAsync(keep_scan, 0, 2 * sizeof(int32_t), st);  // base and first local of chunk 0
         hipMemsetAsync(stats, 0, 3 * sizeof(int64_t), st);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
-                           stats, tile_order, (int64_t)capacity, (int64_t)0, (int32_t*)nullptr, 0, g_heavy_len,
+                           stats, tile_order, (int64_t)capacity, (int64_t)0, (int32_t*)nullptr, 0, heavy_len,
                            stats_mirror, stats_seq);
         return check_launch("isect_offsets(empty)");
     }
@@ -1019,8 +1014,8 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
     // keep flags, per-tile ranks and keep_scan over the first min(I_box, capacity) intersections (the caller
     // re-runs with a larger buffer when stats[0] > capacity); stats[1] = I_listed
     const int n_chunks = (capacity >> KEEP_CHUNK_LOG2) + 1;
-    // dense variant: long lists last frame (g_dense_hint, set by the orchestrator) and one int per tile fits in LDS
-    if (g_dense_hint >= DENSE_LIST_LEN && nt <= DENSE_MAX_TILES)
+    // dense variant: long lists expected (the caller's hint) and one int per tile fits in LDS
+    if (dense_hint >= DENSE_LIST_LEN && nt <= DENSE_MAX_TILES)
         hipLaunchKernelGGL(bin_kernel<true>, dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n, N,
                            tile_w, tile_h, width, height, cull, capacity, cum_tiles, means2d, radii, conics, opacities,
                            opac_per_camera, L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan,
@@ -1030,7 +1025,7 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
                            height, cull, capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera,
                            L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
-                       stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, g_heavy_len,
+                       stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, heavy_len,
                        stats_mirror, stats_seq);
     return check_launch("isect_offsets");
 }

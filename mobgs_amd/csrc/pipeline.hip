@@ -21,7 +21,7 @@ int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, 
                           int64_t* stats_dev,
                           int capacity_box, int32_t* keep_scan, void* scratch, int64_t capacity_listed,
                           int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids, int64_t* stats_host,
-                          void* stream) {
+                          const MobgsTuning* tuning, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
     int rc = mobgs_project_fwd(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
@@ -29,7 +29,7 @@ int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, 
     if (rc != MOBGS_OK) return rc;
     rc = mobgs_isect_offsets(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d, radii,
                              conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order, /*capacity_listed (checked on the host)*/ 0,
-                             stats_dev, scratch,
+                             stats_dev, scratch, tuning,
                              stream);
     if (rc != MOBGS_OK) return rc;
     // the pipeline's one host synchronisation (upstream gsplat has the same one): {I_box, I_listed, longest list}
@@ -63,7 +63,7 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
                                       int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
                                       int64_t max_tile_len_hint, int64_t* stats_host_pinned, int64_t stats_seq,
                                       const float* pack_colors, int colors_per_camera, int pack_channels,
-                                      float* pack_records, void* stream) {
+                                      float* pack_records, const MobgsTuning* tuning, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
     if (!stats_host_pinned || capacity_listed < 1) {
@@ -91,7 +91,9 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
                                        radius_clip, radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, zero_n, pack,
                                        stream);
     if (rc != MOBGS_OK) return rc;
-    mobgs_hint_longest_list((int)(max_tile_len_hint > 0x7fffffff ? 0x7fffffff : max_tile_len_hint));
+    // the binning variant follows the caller's expectation of the longest list (max_tile_len_hint)
+    MobgsTuning tn = tuning ? *tuning : MobgsTuning{-1, -1, -1, 0};
+    tn.longest_list_hint = (int32_t)(max_tile_len_hint > 0x7fffffff ? 0x7fffffff : max_tile_len_hint);
     void* mirror = nullptr;
     if (hipHostGetDevicePointer(&mirror, stats_host_pinned, 0) != hipSuccess) {
         (void)hipGetLastError();
@@ -100,7 +102,7 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
     rc = mobgs::isect_offsets_launch(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d, radii,
                                      conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order,
                                      capacity_listed, stats_dev, scratch, fuse_zero, (int64_t*)mirror,
-                                     mirror ? stats_seq : 0, stream);
+                                     mirror ? stats_seq : 0, &tn, stream);
     if (rc != MOBGS_OK) return rc;
     if (!mirror) {
         hipError_t e = hipMemcpyAsync(stats_host_pinned, stats_dev, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st);

@@ -14,7 +14,7 @@
 //     {x, y, conic a b c, opacity, colour[..]} into a per-wave LDS slab and re-read as broadcasts;
 //   * while a batch is staged every lane also works out which of the four quadrants ITS splat can reach at all
 //     (quadrant_reach_mask, common.h); evaluation and blend of the others are skipped by scalar branches -- ~40 % of
-//     the (entry, quadrant) pairs of a typical list, bit-identical results (mobgs_set_quadrant_culling(0) turns it
+//     the (entry, quadrant) pairs of a typical list, bit-identical results (MobgsTuning.quadrant_culling = 0 turns it
 //     off for the test that proves it);
 //   * backward reduces the 6+D per-splat gradient components across the wave with a halving butterfly
 //     (log-depth, D+6 -> 1 value per lane) and writes ONE 64-byte gradient record per (tile, splat) into a
@@ -59,7 +59,7 @@ __device__ inline void wave_lds_fence() {
 // class test per batch, not a trip through the blend loop.
 struct ClassSel {
     int sel, N, Ns;
-    int all_reach;  // testing aid (mobgs_set_quadrant_culling(0)): treat every quadrant as reachable
+    int all_reach;  // testing aid (MobgsTuning.quadrant_culling = 0): treat every quadrant as reachable
     __device__ __forceinline__ bool keeps(int flat_id) const { return sel == 0 || (((flat_id % N) < Ns) == (sel == 1)); }
 };
 
@@ -808,14 +808,10 @@ inline int dispatch_channels(int D, F&& f) {
 
 using namespace mobgs;
 
-// testing aid: 0 = the compositors evaluate every quadrant of every entry (the per-quadrant reach masks only skip
-// work that is predicated off at every pixel, so results must not change)
-static int g_all_reach = 0;
+// MobgsTuning.quadrant_culling = 0 (testing aid): the compositors evaluate every quadrant of every entry (the
+// per-quadrant reach masks only skip work that is predicated off at every pixel, so results must not change)
 
 extern "C" {
-
-void mobgs_set_quadrant_culling(int on) { g_all_reach = on ? 0 : 1; }
-int mobgs_get_quadrant_culling(void) { return g_all_reach ? 0 : 1; }
 
 int mobgs_raster_channels_supported(int D) {
     return D == 1 || D == 2 || D == 3 || D == 4 || D == 9 || D == 10 || D == 12 || D == 16 || D == 26;
@@ -841,8 +837,9 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
                      int opac_per_camera, const float* extra, const float* backgrounds, const int32_t* radii,
                      const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
                      float* records, float* render, float* alphas, int32_t* last_ids, uint8_t* isect_reach,
-                     void* stream) {
+                     const MobgsTuning* tuning, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    const int g_all_reach = tuning_all_reach(tuning);
     const int D = channels + (extra ? 1 : 0);
     if (C <= 0 || N < 0 || channels < 0 || D < 1 || width <= 0 || height <= 0) {
         set_error("mobgs_raster_fwd: bad sizes C=%d N=%d channels=%d W=%d H=%d", C, N, channels, width, height);
@@ -876,8 +873,9 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
                      const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
                      const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
                      const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
-                     const uint8_t* isect_reach, void* stream) {
+                     const uint8_t* isect_reach, const MobgsTuning* tuning, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    const int g_all_reach = tuning_all_reach(tuning);
     (void)means2d;
     const int D = channels + (has_extra ? 1 : 0);
     if (C <= 0 || N < 0 || D < 1) {
@@ -907,7 +905,8 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
 int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_total, int width, int height,
                            const float* records, const float* backgrounds, const int32_t* tile_offsets,
                            const int32_t* tile_order, const int32_t* flatten_ids, float* render, float* alphas,
-                           int32_t* last_ids, uint8_t* isect_reach, void* stream) {
+                           int32_t* last_ids, uint8_t* isect_reach, const MobgsTuning* tuning, void* stream) {
+    const int g_all_reach = tuning_all_reach(tuning);
     if (C <= 0 || N <= 0 || Ns < 0 || Ns > N || (class_sel != 1 && class_sel != 2) || channels_total != 10) {
         set_error("mobgs_raster_class_fwd: unsupported arguments (C=%d N=%d Ns=%d class=%d D=%d)", C, N, Ns, class_sel,
                   channels_total);
@@ -928,7 +927,8 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
                            const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
                            const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
                            const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
-                           const uint8_t* isect_reach, void* stream) {
+                           const uint8_t* isect_reach, const MobgsTuning* tuning, void* stream) {
+    const int g_all_reach = tuning_all_reach(tuning);
     if (C <= 0 || N <= 0 || Ns < 0 || Ns > N || (class_sel != 1 && class_sel != 2) || channels_total != 10) {
         set_error("mobgs_raster_class_bwd: unsupported arguments");
         return MOBGS_E_UNSUPPORTED;

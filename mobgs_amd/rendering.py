@@ -230,6 +230,20 @@ class _PendingCounts:
 
 
 _tile_culling = True
+# Caller-side policy handed to the library with every call (include/mobgs_hip.h MobgsTuning; the library itself keeps
+# no state).  tuning.heavy_tile_len / tuning.quadrant_culling may be changed by tests and experiments.
+tuning = _lib.MobgsTuning()
+
+
+def _tuning_with_hint(key):
+    """`tuning` plus the longest list the previous frame on this device had (selects the dense binning variant)."""
+    t = _lib.MobgsTuning(tuning.heavy_tile_len, _len_hint.get(key, 0), tuning.quadrant_culling)
+    _tuning_keepalive.append(t)
+    del _tuning_keepalive[:-8]
+    return t.ref()
+
+
+_tuning_keepalive = []
 # True: the projection/binning call does not wait for the intersection counts (see TileLists); False: it does
 SPECULATIVE_BINNING = True
 _len_hint = {}  # device index -> longest per-tile list of the previous frame (selects the sort variant)
@@ -275,7 +289,7 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Ten
                                       ptr(tiles_per_gauss), ptr(means2d), ptr(radii), ptr(conics), ptr(opac),
                                       1 if opac.dim() == 2 else 0, ptr(tl.cum_tiles), ptr(tl.keep_scan),
                                       ptr(tl.tile_offsets), ptr(tl.tile_order), 0, ptr(stats), ptr(scratch),
-                                      stream()),
+                                      _tuning_with_hint(key), stream()),
               "mobgs_isect_offsets")
         n_box, n_isects, max_len = (int(v) for v in stats.tolist())  # the pipeline's one host sync (as in gsplat)
         if n_box <= cap:
@@ -283,7 +297,7 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Ten
         cap = int(n_box * 1.25) + 1024  # first call on a denser scene: grow and redo (rare)
     _capacity[key] = cap
     last_stats.update(n_isects=n_isects, n_box=n_box, max_tile_len=max_len, n_tiles=nt)
-    lib.mobgs_hint_longest_list(max_len)  # next frame: dense-region variant of the binning when lists are long
+    _len_hint[key] = max_len  # next frame: dense-region variant of the binning when lists are long
     flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
     isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev) if want_isect_ids else None
     tl._set_counts(n_box, n_isects, max_len, flatten_ids, isect_ids)
@@ -345,7 +359,7 @@ class _Rasterize(torch.autograd.Function):
                                            colors_per_camera, ptr(opacities), opac_per_camera, ptr(extra), ptr(bg),
                                            ptr(radii), ptr(tl.tile_offsets), ptr(tl.tile_order),
                                            ptr(tl.flatten_arena), ptr(records), ptr(render), ptr(alphas),
-                                           ptr(last_ids), ptr(reach), stream()), "mobgs_raster_fwd")
+                                           ptr(last_ids), ptr(reach), tuning.ref(), stream()), "mobgs_raster_fwd")
                 # speculative lists whose arena was too small get rebuilt by resolve(): composite again.  A caller that
                 # wants to enqueue more work before waiting for the counts sets tl.defer and does this itself.
                 if tl.defer or not tl.resolve():
@@ -381,7 +395,7 @@ class _Rasterize(torch.autograd.Function):
                                        ptr(radii), ptr(means2d), ptr(tl.cum_tiles), ptr(tl.keep_scan),
                                        ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas),
                                        ptr(last_ids),
-                                       ptr(v_render), ptr(v_alphas), ptr(slots), ptr(reach), stream()),
+                                       ptr(v_render), ptr(v_alphas), ptr(slots), ptr(reach), tuning.ref(), stream()),
                   "mobgs_raster_bwd")
         check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(tl.cum_tiles), ptr(tl.keep_scan),
                                           ptr(slots),
@@ -540,7 +554,8 @@ class _RasterizeClasses(torch.autograd.Function):
                         reach = torch.empty(tl.flatten_arena.numel(), dtype=torch.uint8, device=dev)
                     check(lib.mobgs_raster_class_fwd(C, N, Ns, cls, D, width, height, ptr(records), ptr(bg),
                                                      ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_arena),
-                                                     ptr(render), ptr(alphas), ptr(last), ptr(reach), stream()),
+                                                     ptr(render), ptr(alphas), ptr(last), ptr(reach), tuning.ref(),
+                                                     stream()),
                           "mobgs_raster_class_fwd")
                     if not tl.resolve():
                         break
@@ -585,7 +600,8 @@ class _RasterizeClasses(torch.autograd.Function):
                 check(lib.mobgs_raster_class_bwd(C, N, Ns, cls, D, width, height, ptr(records), ptr(bg), ptr(radii),
                                                  ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(tl.tile_offsets),
                                                  ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas), ptr(last),
-                                                 ptr(v_render), ptr(v_alpha), ptr(slots), ptr(reach), stream()),
+                                                 ptr(v_render), ptr(v_alpha), ptr(slots), ptr(reach), tuning.ref(),
+                                                 stream()),
                       "mobgs_raster_class_bwd")
         v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
         v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
@@ -663,7 +679,7 @@ class _ProjectAndBin(torch.autograd.Function):
                     _len_hint.get(key, 0), ctypes.c_void_p(row.data_ptr()), seq,
                     ptr(pack_colors) if records is not None else None,
                     1 if (records is not None and pack_colors.dim() == 3) else 0,
-                    pack_colors.shape[-1] if records is not None else 0, ptr(records), stream())
+                    pack_colors.shape[-1] if records is not None else 0, ptr(records), tuning.ref(), stream())
                 if rc not in (0, 1):
                     check(rc, "mobgs_project_and_bin_speculative")
                 tl.records = records
@@ -683,7 +699,8 @@ class _ProjectAndBin(torch.autograd.Function):
                                            radius_clip, int(_tile_culling), ptr(radii), ptr(means2d), ptr(depths),
                                            ptr(conics), ptr(tiles_per_gauss), ptr(cum_tiles), ptr(tile_offsets),
                                            ptr(tile_order), ptr(stats_dev), cap_box, ptr(keep_scan), ptr(scratch), cap_listed,
-                                           ptr(flatten_ids), ptr(sort_keys), ptr(isect_ids), stats_host, stream())
+                                           ptr(flatten_ids), ptr(sort_keys), ptr(isect_ids), stats_host,
+                                           _tuning_with_hint(key), stream())
             if rc != -4:  # MOBGS_E_CAPACITY: grow the arena (first call on a denser scene) and redo
                 check(rc, "mobgs_project_and_bin")
                 break

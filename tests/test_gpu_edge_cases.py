@@ -81,8 +81,8 @@ def test_two_cameras_with_heavy_tiles(hip_device):
     vm2[0, 0, 3] += 0.15
     viewmats = torch.cat([s["viewmats"], vm2], 0)
     Ks = torch.cat([s["Ks"], s["Ks"]], 0)
-    old = lib.mobgs_get_heavy_tile_len()
-    lib.mobgs_set_heavy_tile_len(32)
+    old = rendering.tuning.heavy_tile_len
+    rendering.tuning.heavy_tile_len = 32
     try:
         both = rendering.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], viewmats, Ks,
                                        w, h, packed=False, render_mode="RGB+ED")
@@ -90,7 +90,7 @@ def test_two_cameras_with_heavy_tiles(hip_device):
                                            viewmats[c:c + 1], Ks[c:c + 1], w, h, packed=False, render_mode="RGB+ED")
                    for c in range(2)]
     finally:
-        lib.mobgs_set_heavy_tile_len(old)
+        rendering.tuning.heavy_tile_len = old
     for c in range(2):
         assert torch.equal(both[0][c], singles[c][0][0]) and torch.equal(both[1][c], singles[c][1][0])
 

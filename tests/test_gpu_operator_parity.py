@@ -196,7 +196,7 @@ def test_tile_culling_is_bit_exact(hip_device, mode, channels):
 def test_quadrant_reach_masks_change_nothing(hip_device, mode, channels, tile_cull):
     """Inside the compositors every list entry carries a 4-bit mask of the 8x8 quadrants its splat can reach; the
     other quadrants are not evaluated.  That only removes work that is predicated off at every pixel, so with the
-    masks switched off (mobgs_set_quadrant_culling(0): everything is evaluated) images, alphas AND gradients must
+    masks switched off (MobgsTuning.quadrant_culling = 0: everything is evaluated) images, alphas AND gradients must
     be bit-identical -- skipped terms are exact zeros added to the same sums in the same order.  Small, thin and
     rotated splats stress the conservative margin of the reach test; with tile culling off the lists also hold
     entries that reach no quadrant at all."""
@@ -212,8 +212,7 @@ def test_quadrant_reach_masks_change_nothing(hip_device, mode, channels, tile_cu
     rendering.set_tile_culling(tile_cull)
     try:
         for masks in (1, 0):
-            lib.mobgs_set_quadrant_culling(masks)
-            assert lib.mobgs_get_quadrant_culling() == masks
+            rendering.tuning.quadrant_culling = masks
             t = {k: v.to(hip_device).clone().requires_grad_(k in names) for k, v in s.items()}
             img, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
                                          t["viewmats"], t["Ks"], w, h, packed=False, render_mode=mode)
@@ -222,7 +221,7 @@ def test_quadrant_reach_masks_change_nothing(hip_device, mode, channels, tile_cu
             ((img * v_img).sum() + (a * a).sum()).backward()
             res[masks] = (img.detach().cpu(), a.detach().cpu(), {k: t[k].grad.cpu() for k in names})
     finally:
-        lib.mobgs_set_quadrant_culling(1)
+        rendering.tuning.quadrant_culling = -1
         rendering.set_tile_culling(True)
     assert torch.equal(res[1][0], res[0][0]), "image differs"
     assert torch.equal(res[1][1], res[0][1]), "alpha differs"
@@ -440,10 +439,10 @@ def test_heavy_tiles_are_split_over_a_workgroup(hip_device):
     s = _clustered_scene(n, w, h, 41)
     names = ["means", "quats", "scales", "opacities", "colors", "viewmats"]
     res = {}
-    old = lib.mobgs_get_heavy_tile_len()
+    old = rendering.tuning.heavy_tile_len
     try:
         for mode in ("heavy", "light", "raster"):
-            lib.mobgs_set_heavy_tile_len(48 if mode == "heavy" else 0)
+            rendering.tuning.heavy_tile_len = 48 if mode == "heavy" else 0
             rendering.TILE_SCHEDULE = mode != "raster"
             t = {k: v.to(hip_device).clone().requires_grad_(k in names) for k, v in s.items()}
             sp = rendering.SharedProjection(t["means"], t["quats"], t["scales"], t["opacities"], t["viewmats"],
@@ -469,7 +468,7 @@ def test_heavy_tiles_are_split_over_a_workgroup(hip_device):
                 assert int(lens[heavy_tiles].min()) >= int(lens[light_tiles].max()) - (int(lens.max()) // 1023 + 1)
                 assert int(lens[heavy_tiles].min()) >= 48 - (int(lens.max()) // 1023 + 1)
     finally:
-        lib.mobgs_set_heavy_tile_len(old)
+        rendering.tuning.heavy_tile_len = old
         rendering.TILE_SCHEDULE = True
     for other in ("light", "raster"):
         assert torch.equal(res["heavy"][0], res[other][0]) and torch.equal(res["heavy"][1], res[other][1]), other
