@@ -18,6 +18,7 @@ from (K, c2w) on first use instead of 9 x 33 MB eagerly per view (SURVEY.md sect
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Callable, List, Optional
 
 import numpy as np
@@ -193,6 +194,29 @@ class WarpedCamera:
 # True: the per-view BLCE forward / backward is captured once per view in a HIP graph and replayed (see
 # blceKernel._view_fn); False: eager launches
 GRAPH_CAPTURE = True
+# True: a failed capture raises instead of falling back to eager launches with a warning (benchmarks / tests that
+# must not silently measure the eager path)
+REQUIRE_GRAPH = False
+
+
+class _Flight:
+    """One replay of a view's BLCE graph whose backward pass has not run yet."""
+    __slots__ = ("done", "__weakref__")
+
+    def __init__(self):
+        self.done = False
+
+
+class _ReplayGuard(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c2w, flight):
+        ctx.flight = flight
+        return c2w.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.flight.done = True
+        return g, None
 
 
 class _ViewModule(nn.Module):
@@ -225,6 +249,8 @@ class blceKernel(nn.Module):
         self._blur_cache = {}
         self._c2w_cache = {}
         self._graphed = {}
+        self._graph_ptrs = {}
+        self._inflight = {}
 
     @staticmethod
     def _w2c_of(cam) -> torch.Tensor:
@@ -257,17 +283,44 @@ class blceKernel(nn.Module):
         if not (GRAPH_CAPTURE and Rt.is_cuda and torch.is_grad_enabled()):
             return self.model(Rt, bf, idx_view)
         fn = self._graphed.get(idx_view)
+        ptrs = None
+        if fn is not False:
+            # the graph holds the parameters' ADDRESSES: a model.to(...) / re-allocation since capture invalidates it
+            ptrs = tuple(p.data_ptr() for p in self._view_params(idx_view))
+            if fn is not None and self._graph_ptrs.get(idx_view) != ptrs:
+                fn = None
         if fn is None:
             try:
                 fn = torch.cuda.make_graphed_callables(_ViewModule(self.model, idx_view), (Rt.clone(), bf.clone()))
             except RuntimeError as e:  # capture unsupported in this setup: say so once and run eagerly from now on
+                if REQUIRE_GRAPH:
+                    raise
                 import warnings
                 warnings.warn(f"mobgs_amd.blce: HIP graph capture failed ({e}); running BLCE eagerly")
                 fn = False
             self._graphed[idx_view] = fn
+            self._graph_ptrs[idx_view] = ptrs
         if fn is False:
             return self.model(Rt, bf, idx_view)
-        return fn(Rt, bf)
+        # The replay writes its outputs, saved activations and input gradients into the graph's static buffers.  A
+        # second forward of the same view while the first one's autograd graph is still alive (the same uid twice in
+        # a batch, an evaluation between forward and backward) would overwrite them: such a call runs eagerly.
+        live = self._inflight.get(idx_view)
+        flight = live() if live is not None else None
+        if flight is not None and not flight.done:
+            return self.model(Rt, bf, idx_view)
+        c2w, expo = fn(Rt, bf)
+        flight = _Flight()
+        self._inflight[idx_view] = weakref.ref(flight)
+        # private copies, not the static output buffers; the copy's autograd node owns `flight`, so the weak reference
+        # dies with the autograd graph of this replay and `done` is set when its backward has run
+        return _ReplayGuard.apply(c2w, flight), expo.clone()
+
+    def _view_params(self, idx_view):
+        m = self.model
+        mods = [getattr(m, n)[idx_view] for n in ("view_encoder", "Rt_encoder", "wv_derivative", "rot_decoder",
+                                                  "trans_decoder", "theta_decoder", "blur_feature_encoder")]
+        return [m.view_embedder] + [p for mod in mods for p in mod.parameters()]
 
     def get_warped_cams(self, cam=None, fwd_cam=None, bwd_cam=None):
         dev = next(self.model.parameters()).device

@@ -383,3 +383,46 @@ def kernel_times(net, pts, scales, rots, times, cots, steps, timer):
         N, ptr(pts), ptr(t1), ptr(aabb), ptrs, ra, rb, ptr(g_feat), gptrs, ptr(v_pts), ptr(v_times), stream()),
         "hexplane_bwd"), steps)
     return out
+
+
+# ---- init-time geometry helpers train.py imports from scene.deformation (train.py:101,113) ------------------------
+def _lift_pixels(depth: torch.Tensor, K_inv: torch.Tensor) -> torch.Tensor:
+    """depth [B,H,W] -> camera-frame points [B,3,H*W]: depth * K^-1 [u, v, 1]^T at INTEGER pixel coordinates
+    (/root/reference/scene/deformation.py:484-506)."""
+    B, H, W = depth.shape
+    v, u = torch.meshgrid(torch.arange(H, device=depth.device, dtype=depth.dtype),
+                          torch.arange(W, device=depth.device, dtype=depth.dtype), indexing="ij")
+    pix = torch.stack([u, v, torch.ones_like(u)], dim=0).reshape(1, 3, H * W)
+    return torch.bmm(K_inv, pix.expand(B, 3, H * W)) * depth.reshape(B, 1, H * W)
+
+
+def _camera_to_world(w2c: torch.Tensor, cam_pts: torch.Tensor) -> torch.Tensor:
+    R, t = w2c[:, :, 0:3], w2c[:, :, 3:4]
+    Rt = R.transpose(1, 2)
+    return torch.bmm(Rt, cam_pts) - torch.bmm(Rt, t)
+
+
+def points_from_DRTK(depth, w2c1, intrinsics):
+    """World coordinates of every pixel of a depth map (/root/reference/scene/deformation.py:758-782).
+    depth [B,1,H,W], w2c1 [B,3,4], intrinsics [B,3,3] -> [B,3,H*W]."""
+    return _camera_to_world(w2c1, _lift_pixels(depth[:, 0], torch.inverse(intrinsics)))
+
+
+def inverse_warp_rt1_rt2(img, depth, w2c1, w2c2, intrinsics, intrinsics_inv, padding_mode="zeros", ret_grid=False):
+    """Sample `img` (seen by camera 2) at the re-projection of camera 1's depth map
+    (/root/reference/scene/deformation.py:640-699).  img [B,C,H,W], depth [B,1,H,W], w2c1 / w2c2 [B,3,4]."""
+    d = depth[:, 0]
+    B, H, W = d.shape
+    world = _camera_to_world(w2c1, _lift_pixels(d, intrinsics_inv))
+    c2 = torch.bmm(w2c2[:, :, 0:3], world) + w2c2[:, :, 3:4]
+    z = c2[:, 2:3, :]
+    z = torch.where(z.abs() < 1e-6, torch.full_like(z, 1e-6), z)
+    p2 = torch.bmm(intrinsics, c2 / z)
+    x = 2 * p2[:, 0] / (W - 1) - 1
+    y = 2 * p2[:, 1] / (H - 1) - 1
+    if padding_mode == "zeros":  # anything off-image samples well outside: no blend of image and padding
+        x = torch.where(((x > 1) | (x < -1)).detach(), torch.full_like(x, 2.0), x)
+        y = torch.where(((y > 1) | (y < -1)).detach(), torch.full_like(y, 2.0), y)
+    grid = torch.stack([x, y], dim=2).view(B, H, W, 2)
+    out = F.grid_sample(img, grid, padding_mode=padding_mode, align_corners=True)
+    return (out, grid) if ret_grid else out

@@ -82,6 +82,27 @@ class RenderResult(dict):
         self._materialise()
         return dict(self)
 
+    # dict(out), {**out}, out | other go through PyDict_Merge, which reads the storage of a dict SUBCLASS directly
+    # unless the subclass overrides __iter__ (then it uses keys() + __getitem__): overriding it is what keeps the
+    # pending marker from leaking through those paths.
+    def __iter__(self):
+        return dict.__iter__(self)
+
+    def keys(self):
+        return dict.keys(self)
+
+    def pop(self, key, *default):
+        if key in self:
+            self[key]  # materialise its group first
+        return dict.pop(self, key, *default)
+
+    def setdefault(self, key, default=None):
+        return self[key] if key in self else dict.setdefault(self, key, default)
+
+    def __reduce__(self):  # pickling / copy.copy / copy.deepcopy: a plain dict of materialised values
+        self._materialise()
+        return (dict, (dict(dict.items(self)),))
+
 
 def _device_of(pc):
     return pc.get_xyz.device
@@ -182,7 +203,9 @@ def _keep_grad(t: torch.Tensor) -> None:
     def hook(g):
         target = ref()
         if target is not None:
-            target.grad = g
+            # accumulate across backward passes like retain_grad() does (train.py calls photo_loss.backward(
+            # retain_graph=True) and then loss.backward(), :629,:678); the first pass keeps the tensor itself
+            target.grad = g if target.grad is None else target.grad + g
 
     t.register_hook(hook)
 

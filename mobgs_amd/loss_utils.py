@@ -64,8 +64,10 @@ def l1_loss(network_output, gt, mask=None):
         channel = gt.shape[1]
         mask = mask.expand(-1, channel, -1, -1)
         return torch.abs((network_output - gt) * mask).sum() / (mask.sum() + 1e-8)
-    _, l1, hw = _sums(network_output, gt)
-    return l1.sum() / (l1.numel() * hw)
+    # the reference's l1_loss is a plain abs().mean() that differentiates both arguments and takes any shape
+    # (utils/loss_utils.py:233-239); the fused SSIM+L1 kernel is for image pairs whose second member is a constant.
+    # An L1 alone (e.g. the depth term, train.py:651) does not need the 11x11 window pass either: torch.
+    return torch.abs(network_output - gt).mean()
 
 
 def ssim(img1, img2, window_size=11, size_average=True):

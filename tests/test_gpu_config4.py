@@ -190,3 +190,52 @@ def test_config4_workload_k9_300k_gaussians_1352x1014(hip_device):
         assert p.grad is not None and float(p.grad.abs().max()) > 0, tuple(p.shape)
     vs, radii = SubframeShard.get_densification_stats(wl.bucket, "view0")
     assert int((radii > 0).sum()) > 250_000 and float(vs.abs().max()) > 0
+
+
+def test_blce_graph_replay_is_guarded_against_reentry_and_reallocation(hip_device):
+    """a second forward of the same view before the first one's backward must not overwrite the replay's
+    static buffers (it runs eagerly); outputs are private copies; moved parameters trigger a re-capture."""
+    fx = load("blurry_view")
+    dev = hip_device
+    cam, stat, dyn, bg, w2c = scene_from_fixture(fx, dev)
+    kern, idx = _kernel_from_fixture(fx, dev)
+    cam.uid = idx
+    cam.image = torch.from_numpy(fx["in_image"]).to(dev)
+    g = torch.Generator().manual_seed(0)
+    v = torch.randn(9, 4, 4, generator=g).to(dev)
+
+    def poses(cams):
+        return torch.stack([c.world_view_transform for c in cams])
+
+    def grads():
+        out = {k: p.grad.clone() for k, p in kern.model.named_parameters() if p.grad is not None}
+        kern.optimizer.zero_grad(set_to_none=True)
+        return out
+
+    cams0, _ = kern.get_warped_cams(cam)          # capture + first replay
+    (poses(cams0) * v).sum().backward()
+    ref = grads()
+    assert kern._graphed[idx] not in (None, False)
+    # two forwards, then both backwards (the second forward must not disturb the first one's saved activations)
+    cams1, _ = kern.get_warped_cams(cam)
+    first = poses(cams1).detach().clone()
+    cams2, _ = kern.get_warped_cams(cam)
+    assert torch.equal(poses(cams1).detach(), first), "outputs of a replay must be private copies"
+    (poses(cams1) * v).sum().backward()
+    g1 = grads()
+    (poses(cams2) * v).sum().backward()
+    g2 = grads()
+    for k in ref:
+        sc = float(ref[k].abs().max()) + 1e-12
+        close(g1[k], ref[k], 1e-4, 1e-5 * sc, f"first of two overlapping forwards: {k}")
+        close(g2[k], ref[k], 1e-4, 1e-5 * sc, f"second of two overlapping forwards: {k}")
+    # parameters re-allocated (model moved): the stale graph is dropped and a new one captured
+    old = kern._graphed[idx]
+    for p in kern.model.parameters():
+        p.data = p.data.clone()
+    cams3, _ = kern.get_warped_cams(cam)
+    (poses(cams3) * v).sum().backward()
+    g3 = grads()
+    assert kern._graphed[idx] is not old and kern._graphed[idx] not in (None, False)
+    for k in ref:
+        close(g3[k], ref[k], 1e-4, 1e-5 * (float(ref[k].abs().max()) + 1e-12), f"after re-allocation: {k}")
