@@ -41,6 +41,19 @@ KERNEL(add, "v_add_f32 %0, %0, %1")
 KERNEL(mov, "v_mov_b32 %0, %1")
 KERNEL(max, "v_max_f32 %0, %0, %1")
 KERNEL(cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+KERNEL(cnd_sgpr, "v_cndmask_b32 %0, %0, %1, s[10:11]")
+KERNEL(cmp_vcc, "v_cmp_lt_f32 vcc, %0, %1")
+KERNEL(cmp_sgpr, "v_cmp_lt_f32 s[10:11], %0, %1")
+KERNEL(min, "v_min_f32 %0, %0, %1")
+KERNEL(med3, "v_med3_f32 %0, %0, %1, %2")
+KERNEL(and_b32, "v_and_b32 %0, %0, %1")
+KERNEL(add_u32, "v_add_u32 %0, %0, %1")
+KERNEL(lshl, "v_lshlrev_b32 %0, 1, %0")
+KERNEL(cvt, "v_cvt_f32_i32 %0, %0")
+KERNEL(fmac, "v_fmac_f32 %0, %1, %2")
+KERNEL(mul_neg, "v_mul_f32 %0, -%0, %1")
+KERNEL(dpp_add, "v_add_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+KERNEL(readlane, "v_readlane_b32 s12, %0, 3")
 KERNEL(exp, "v_exp_f32 %0, %0")
 KERNEL(rcp, "v_rcp_f32 %0, %0")
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -92,6 +105,7 @@ void run(const char* name, K kern, int waves_per_simd, bool packed) {
     const double med = (double)h[n_waves / 2], mx = (double)h[n_waves - 1];
     const double instr_per_wave = (double)iters * UNROLL * CHAINS;
     const double cpi = med / (instr_per_wave * waves_per_simd);
+    const double cpi_max = mx / (instr_per_wave * waves_per_simd);
     // readcyclecounter on gfx9 = s_memtime: constant 100 MHz reference clock on this part if it is NOT the shader
     // clock -- print both interpretations' inputs: ticks and wall time
     const double wall_cyc_24 = ms * 1e-3 * 2.4e9;
@@ -106,7 +120,22 @@ int main() {
     for (int w : {1, 2, 4, 8}) {
         run("fma", k_fma, w, false);
     }
-    for (int w : {2, 8}) {
+    for (int w : {4}) {
+        run("cnd_sgpr", k_cnd_sgpr, w, false);
+        run("cmp_vcc", k_cmp_vcc, w, false);
+        run("cmp_sgpr", k_cmp_sgpr, w, false);
+        run("min", k_min, w, false);
+        run("med3", k_med3, w, false);
+        run("and_b32", k_and_b32, w, false);
+        run("add_u32", k_add_u32, w, false);
+        run("lshl", k_lshl, w, false);
+        run("cvt", k_cvt, w, false);
+        run("fmac", k_fmac, w, false);
+        run("mul_neg", k_mul_neg, w, false);
+        run("dpp_add", k_dpp_add, w, false);
+        run("readlane", k_readlane, w, false);
+    }
+    for (int w : {2, 4}) {
         run("mul", k_mul, w, false);
         run("add", k_add, w, false);
         run("mov", k_mov, w, false);
