@@ -291,7 +291,7 @@ def main():
                     "render() lean mode fwd+bwd incl. spline prep, decoder, camera gradient")
         if args.deblur_steps > 0:
             wl = DeblurWorkload(dev, stat, dyn, scam, args.width, args.height, shard, args.views)
-            ddt, dmed = timed(wl.step, args.deblur_steps, 3, world, dist)
+            ddt, dmed = timed(wl.step, args.deblur_steps, 4, world, dist)
             deblur = {"blurry_views_per_s": round(args.views * args.deblur_steps / ddt, 3),
                       "renders_per_s": round(n_units * args.deblur_steps / ddt, 2),
                       "ms_per_iteration": round(ddt / args.deblur_steps * 1e3, 3),

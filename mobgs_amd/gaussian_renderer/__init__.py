@@ -199,13 +199,15 @@ def _keep_grad(t: torch.Tensor) -> None:
     if not t.requires_grad:
         return
     ref = weakref.ref(t)
+    seen = []  # reading .grad of a non-leaf that has none yet warns: remember whether a pass has stored one
 
     def hook(g):
         target = ref()
         if target is not None:
             # accumulate across backward passes like retain_grad() does (train.py calls photo_loss.backward(
             # retain_graph=True) and then loss.backward(), :629,:678); the first pass keeps the tensor itself
-            target.grad = g if target.grad is None else target.grad + g
+            target.grad = target.grad + g if seen else g
+            seen.append(True)
 
     t.register_hook(hook)
 
