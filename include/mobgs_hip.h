@@ -413,8 +413,12 @@ int mobgs_decoder_bwd(int P, int CF, int has_depth, int width, const float* feat
  *   axis of the pair, rb of the second) -- the host permutes the reference's [1,32,rb,ra] parameters.
  * ra_host / rb_host: HOST int32[18].   aabb: device [2,3] = {xyz_max, xyz_min} (the reference's convention).
  * mobgs_hexplane_fwd : pts [N,3], times [N]  ->  feat [N,96]
- * mobgs_hexplane_bwd : v_feat [N,96] -> gplanes (ACCUMULATED with float atomics; zero them first),
- *                      v_pts [N,3] (ADDED to its current content), v_times [N] (written)
+ * mobgs_hexplane_bwd : v_feat [N,96] -> gplanes (ACCUMULATED; zero them first), v_pts [N,3] (ADDED to its current
+ *                      content), v_times [N] (written).  The (point, plane) contributions are counting-sorted by
+ *                      plane cell (integer atomics) and runs of equal cells are summed in registers before they
+ *                      leave as float atomics, instead of torch's one global float atomic per (point, plane, tap,
+ *                      channel) (grid_sampler_2d_backward).  scratch: mobgs_hexplane_bwd_scratch_bytes(N, ra, rb)
+ *                      bytes, 16-byte aligned (per-cell counters + entry lists of 144 B per point and plane).
  * mobgs_deform_mlp_fwd: feat + pts/scales/rots [N,3]/[N,3]/[N,4] -> out_pts, out_scales, out_rots (MFMA fp32).
  *   Weights K-major: W0t [96,128], b0 [128], W1t [3,128,128], b1 [3,128], W2t [3,128,32] (7/3/4 real columns,
  *   zero padded), b2 [3,32]; head order: position, scale, rotation.
@@ -436,7 +440,8 @@ int mobgs_hexplane_fwd(int N, const float* pts, const float* times, const float*
 int mobgs_hexplane_bwd(int N, const float* pts, const float* times, const float* aabb,
                        const float* const* planes_host, const int32_t* ra_host, const int32_t* rb_host,
                        const float* v_feat, float* const* gplanes_host, float* v_pts, float* v_times,
-                       void* stream);
+                       void* scratch, void* stream);
+size_t mobgs_hexplane_bwd_scratch_bytes(int N, const int32_t* ra_host, const int32_t* rb_host);
 int mobgs_deform_mlp_fwd(int N, const float* feat, const float* pts, const float* scales, const float* rots,
                          const float* W0t, const float* b0, const float* W1t, const float* b1, const float* W2t,
                          const float* b2, float* out_pts, float* out_scales, float* out_rots, float* o_raw,

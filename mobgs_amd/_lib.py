@@ -79,7 +79,8 @@ _SIGS = {
     "mobgs_ssim_l1_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P]),
     "mobgs_ssim_l1_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P]),
     "mobgs_hexplane_fwd": (c_int, [c_int] + [P] * 7 + [P]),
-    "mobgs_hexplane_bwd": (c_int, [c_int] + [P] * 10 + [P]),
+    "mobgs_hexplane_bwd": (c_int, [c_int] + [P] * 11 + [P]),
+    "mobgs_hexplane_bwd_scratch_bytes": (c_size_t, [c_int, P, P]),
     "mobgs_deform_mlp_fwd": (c_int, [c_int] + [P] * 14 + [P]),
     "mobgs_deform_mlp_bwd_blocks": (c_int, [c_int]),
     "mobgs_deform_mlp_grad_floats": (c_size_t, []),

@@ -13,7 +13,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 # MOBGS_LIB: load another build of the same library instead (A/B timing of kernel variants on one GPU box)
 LIB_PATH = Path(os.environ["MOBGS_LIB"]).resolve() if os.environ.get("MOBGS_LIB") else CSRC / "libmobgs_hip.so"
-SOURCES = ["project.hip", "isect.hip", "raster.hip", "raster_layers.hip", "pipeline.hip", "prep.hip", "decoder.hip", "deform.hip", "deform_bwd.hip", "loss.hip", "densify.hip", "normals.hip"]
+SOURCES = ["project.hip", "isect.hip", "raster.hip", "raster_layers.hip", "pipeline.hip", "prep.hip", "decoder.hip", "deform.hip", "deform_bwd.hip", "hexplane_bwd.hip", "loss.hip", "densify.hip", "normals.hip"]
 ARCH = "gfx950"
 # Per-file extra flags.  -fno-slp-vectorize: the SLP vectoriser pairs independent fp32 FMAs into v_pk_fma_f32,
 # which on gfx950 issues at half rate (no gain) and needs v_mov shuffles to build the 64-bit operand pairs:
@@ -42,7 +42,7 @@ def is_stale() -> bool:
     if not LIB_PATH.exists():
         return True
     t = LIB_PATH.stat().st_mtime
-    deps = sources() + [CSRC / "common.h", CSRC.parent.parent / "include" / "mobgs_hip.h"]
+    deps = sources() + [CSRC / "common.h", CSRC / "hexplane.h", CSRC.parent.parent / "include" / "mobgs_hip.h"]
     return any(d.exists() and d.stat().st_mtime > t for d in deps)
 
 
@@ -57,7 +57,7 @@ def build_extension(force: bool = False, verbose: bool = False) -> Path:
         obj = src.with_suffix(".o")
         objs.append(obj)
         if not force and obj.exists() and obj.stat().st_mtime > max(
-                src.stat().st_mtime, (CSRC / "common.h").stat().st_mtime,
+                src.stat().st_mtime, (CSRC / "common.h").stat().st_mtime, (CSRC / "hexplane.h").stat().st_mtime,
                 (CSRC.parent.parent / "include" / "mobgs_hip.h").stat().st_mtime):
             continue
         cmd = [hipcc, *flags, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]

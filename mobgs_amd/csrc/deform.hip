@@ -18,62 +18,9 @@
 #include <atomic>
 
 #include "common.h"
+#include "hexplane.h"
 
 namespace mobgs {
-
-struct PlaneSet {
-    const float* p[18];  // [level*6 + plane], channels-last [rb][ra][32]
-    int ra[18];          // width  = resolution of the FIRST axis of the pair
-    int rb[18];          // height = resolution of the SECOND axis of the pair
-};
-struct PlaneGradSet {
-    float* p[18];
-};
-
-__constant__ const int kAxisA[6] = {0, 0, 0, 1, 1, 2};
-__constant__ const int kAxisB[6] = {1, 2, 3, 2, 3, 3};
-
-struct Tap {
-    int o00, o01, o10, o11;  // element offsets of the 4 taps (channel 0)
-    float wx, wy;            // fractional parts
-    float gx, gy;            // d(ix)/d(coord), d(iy)/d(coord): 0 when the coordinate was clipped to the border
-};
-
-__device__ inline Tap make_tap(float x, float y, int ra, int rb) {
-    // grid_sample, align_corners=True, padding_mode='border' (PyTorch clip_coordinates)
-    Tap t;
-    float ix = (x + 1.f) * 0.5f * (float)(ra - 1);
-    float iy = (y + 1.f) * 0.5f * (float)(rb - 1);
-    // clip_coordinates_set_grad: the borders themselves count as out of bounds (gradient 0 for ix <= 0, ix >= ra-1)
-    t.gx = (ix > 0.f && ix < (float)(ra - 1)) ? 0.5f * (float)(ra - 1) : 0.f;
-    t.gy = (iy > 0.f && iy < (float)(rb - 1)) ? 0.5f * (float)(rb - 1) : 0.f;
-    ix = fminf(fmaxf(ix, 0.f), (float)(ra - 1));
-    iy = fminf(fmaxf(iy, 0.f), (float)(rb - 1));
-    const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy;
-    const int x1 = min(x0 + 1, ra - 1), y1 = min(y0 + 1, rb - 1);
-    t.wx = ix - fx;
-    t.wy = iy - fy;
-    t.o00 = (y0 * ra + x0) * 32;
-    t.o01 = (y0 * ra + x1) * 32;
-    t.o10 = (y1 * ra + x0) * 32;
-    t.o11 = (y1 * ra + x1) * 32;
-    return t;
-}
-
-__device__ inline void normalized_query(const float* __restrict__ pts, const float* __restrict__ times,
-                                        const float* __restrict__ aabb, int n, float q[4], float dq[3]) {
-    // aabb[0] = xyz_max, aabb[1] = xyz_min (the reference's axis-inverted convention, hexplane.py:156-163)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float a0 = aabb[k], a1 = aabb[3 + k];
-        const float s = 2.0f / (a1 - a0);
-        const float v = (pts[3 * n + k] - a0) * s - 1.0f;
-        q[k] = fminf(fmaxf(v, -1.f), 1.f);
-        dq[k] = (v >= -1.f && v <= 1.f) ? s : 0.f;
-    }
-    q[3] = times[n];
-}
 
 __global__ void __launch_bounds__(256)
 hexplane_fwd_kernel(int N, const float* __restrict__ pts, const float* __restrict__ times,
@@ -98,71 +45,6 @@ hexplane_fwd_kernel(int N, const float* __restrict__ pts, const float* __restric
                 prod *= s;
             }
             feat[(size_t)n * 96 + l * 32 + c] = prod;
-        }
-    }
-}
-
-__device__ inline float half_wave_sum(float v) {
-    // sum over the 32 lanes of a half-wave (the 32 channels of one point)
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));
-    v += __shfl_xor(v, 16, 64);
-    return v;
-}
-
-// v_feat [N,96] -> plane gradients (channels-last, float atomics: the same plane cell is hit by many points),
-// v_pts [N,3] (ADDED to what is there), v_times [N] (written)
-__global__ void __launch_bounds__(256)
-hexplane_bwd_kernel(int N, const float* __restrict__ pts, const float* __restrict__ times,
-                    const float* __restrict__ aabb, PlaneSet planes, const float* __restrict__ v_feat,
-                    PlaneGradSet gplanes, float* __restrict__ v_pts, float* __restrict__ v_times) {
-    const int c = threadIdx.x & 31;
-    const int half = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int nhalf = (gridDim.x * blockDim.x) >> 5;
-    for (int n = half; n < N; n += nhalf) {
-        float q[4], dq[3];
-        normalized_query(pts, times, aabb, n, q, dq);
-        float vq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int l = 0; l < 3; ++l) {
-            float s[6], dsx[6], dsy[6];
-            Tap taps[6];
-#pragma unroll
-            for (int p = 0; p < 6; ++p) {
-                const int id = l * 6 + p;
-                taps[p] = make_tap(q[kAxisA[p]], q[kAxisB[p]], planes.ra[id], planes.rb[id]);
-                const Tap& t = taps[p];
-                const float* g = planes.p[id] + c;
-                const float v00 = g[t.o00], v01 = g[t.o01], v10 = g[t.o10], v11 = g[t.o11];
-                s[p] = (v00 * (1.f - t.wx) + v01 * t.wx) * (1.f - t.wy) + (v10 * (1.f - t.wx) + v11 * t.wx) * t.wy;
-                dsx[p] = ((v01 - v00) * (1.f - t.wy) + (v11 - v10) * t.wy) * t.gx;
-                dsy[p] = ((v10 - v00) * (1.f - t.wx) + (v11 - v01) * t.wx) * t.gy;
-            }
-            const float v = v_feat[(size_t)n * 96 + l * 32 + c];
-#pragma unroll
-            for (int p = 0; p < 6; ++p) {
-                float others = v;
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-                    if (r != p) others *= s[r];
-                const Tap& t = taps[p];
-                float* g = gplanes.p[l * 6 + p] + c;
-                atomicAdd(g + t.o00, others * (1.f - t.wx) * (1.f - t.wy));
-                atomicAdd(g + t.o01, others * t.wx * (1.f - t.wy));
-                atomicAdd(g + t.o10, others * (1.f - t.wx) * t.wy);
-                atomicAdd(g + t.o11, others * t.wx * t.wy);
-                vq[kAxisA[p]] += others * dsx[p];
-                vq[kAxisB[p]] += others * dsy[p];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vq[k] = half_wave_sum(vq[k]);
-        if (c == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v_pts[3 * n + k] += vq[k] * dq[k];
-            v_times[n] = vq[3];
         }
     }
 }
@@ -339,24 +221,6 @@ int mobgs_hexplane_fwd(int N, const float* pts, const float* times, const float*
     hipLaunchKernelGGL(hexplane_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, pts, times, aabb, ps,
                        feat);
     return check_launch("hexplane_fwd_kernel");
-}
-
-int mobgs_hexplane_bwd(int N, const float* pts, const float* times, const float* aabb,
-                       const float* const* planes_host, const int32_t* ra_host, const int32_t* rb_host,
-                       const float* v_feat, float* const* gplanes_host, float* v_pts, float* v_times, void* stream) {
-    PlaneSet ps;
-    if (N < 0 || fill_planes(ps, planes_host, ra_host, rb_host) != MOBGS_OK) {
-        set_error("mobgs_hexplane_bwd: bad arguments");
-        return MOBGS_E_INVALID;
-    }
-    PlaneGradSet gs;
-    for (int i = 0; i < 18; ++i) gs.p[i] = gplanes_host[i];
-    if (N == 0) return MOBGS_OK;
-    int grid = (N + 7) / 8;
-    if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(hexplane_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, pts, times, aabb, ps,
-                       v_feat, gs, v_pts, v_times);
-    return check_launch("hexplane_bwd_kernel");
 }
 
 int mobgs_deform_mlp_fwd(int N, const float* feat, const float* pts, const float* scales, const float* rots,

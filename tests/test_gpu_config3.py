@@ -186,7 +186,7 @@ def test_config3_deformed_dynamic_splats_through_the_rasterizer(hip_device):
         close(a.grad, b.grad, 2e-3, 1e-4 * sc, "grad " + name, flip_frac=2e-3, flip_atol=0.5 * sc)
     for k, w in _weights_of(net).items():
         sc = float(W[k].grad.abs().max())
-        close(w.grad, W[k].grad, 5e-3, 2e-3 * sc, "grad " + k, flip_frac=0.05, flip_atol=0.03 * sc)
+        close(w.grad, W[k].grad, 5e-3, 5e-3 * sc, "grad " + k, flip_frac=0.05, flip_atol=0.03 * sc)
     for li, level in enumerate(net.deformation_net.grid.grids):
         for pi, pl in enumerate(level):
             b = planes[li][pi].grad
