@@ -42,7 +42,8 @@ struct CellMap {
     int lbase[18];
     int hot_total;  // cells of all hot planes (0: no LDS table, everything through global atomics)
 };
-constexpr int PB = 256;            // points per workgroup of the count / pass-1 kernels
+constexpr int PB = 512;            // points per workgroup of the count / pass-1 kernels
+constexpr int WG = 1024;           // threads of those workgroups
 constexpr int HOT_MAX = 24 * 1024; // LDS table entries (96 KB)
 
 __device__ inline int cell_of(const CellMap& cm, const PlaneSet& planes, int id, const float q[4]) {
@@ -98,14 +99,14 @@ struct BwdScratch {
 };
 
 // ---- count: entries per cell -----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(WG)
 hex_count_kernel(int N, const float* __restrict__ pts, const float* __restrict__ times, const float* __restrict__ aabb,
                  PlaneSet planes, CellMap cm, int* __restrict__ count) {
     extern __shared__ int hot[];
-    for (int i = threadIdx.x; i < cm.hot_total; i += 512) hot[i] = 0;
+    for (int i = threadIdx.x; i < cm.hot_total; i += WG) hot[i] = 0;
     __syncthreads();
     const int n0 = blockIdx.x * PB;
-    for (int t = threadIdx.x; t < PB * 18; t += 512) {  // one (point, plane) pair per step
+    for (int t = threadIdx.x; t < PB * 18; t += WG) {  // one (point, plane) pair per step
         const int n = n0 + t / 18, id = t % 18;
         if (n >= N) break;
         float q[4], dq[3];
@@ -117,7 +118,7 @@ hex_count_kernel(int N, const float* __restrict__ pts, const float* __restrict__
             atomicAdd(&count[cm.base[id] + cell], 1);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < cm.hot_total; i += 512) {
+    for (int i = threadIdx.x; i < cm.hot_total; i += WG) {
         const int v = hot[i];
         if (v) atomicAdd(&count[hot_global_cell(cm, i)], v);
     }
@@ -191,7 +192,7 @@ __device__ inline float half_wave_sum(float v) {
 }
 
 // ---- pass 1: per-point rows into the region lists; point / time gradients ---------------------------------------
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(WG)
 hex_pass1_kernel(int N, const float* __restrict__ pts, const float* __restrict__ times, const float* __restrict__ aabb,
                  PlaneSet planes, CellMap cm, const float* __restrict__ v_feat, const int* __restrict__ start,
                  int* __restrict__ cursor, EntryHeader* __restrict__ hdr, float* __restrict__ rows,
@@ -200,9 +201,9 @@ hex_pass1_kernel(int N, const float* __restrict__ pts, const float* __restrict__
     const int c = threadIdx.x & 31;
     const int n0 = blockIdx.x * PB;
     if (cm.hot_total > 0) {
-        for (int i = threadIdx.x; i < cm.hot_total; i += 512) hot[i] = 0;
+        for (int i = threadIdx.x; i < cm.hot_total; i += WG) hot[i] = 0;
         __syncthreads();
-        for (int t = threadIdx.x; t < PB * 18; t += 512) {
+        for (int t = threadIdx.x; t < PB * 18; t += WG) {
             const int n = n0 + t / 18, id = t % 18;
             if (n >= N) break;
             if (cm.lbase[id] < 0) continue;
@@ -211,7 +212,7 @@ hex_pass1_kernel(int N, const float* __restrict__ pts, const float* __restrict__
             atomicAdd(&hot[cm.lbase[id] + cell_of(cm, planes, id, q)], 1);
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < cm.hot_total; i += 512) {  // one returning global atomic per touched cell
+        for (int i = threadIdx.x; i < cm.hot_total; i += WG) {  // one returning global atomic per touched cell
             const int v = hot[i];
             if (v) {
                 const int gc = hot_global_cell(cm, i);
@@ -220,7 +221,7 @@ hex_pass1_kernel(int N, const float* __restrict__ pts, const float* __restrict__
         }
         __syncthreads();
     }
-    for (int n = n0 + (threadIdx.x >> 5); n < min(n0 + PB, N); n += 16) {
+    for (int n = n0 + (threadIdx.x >> 5); n < min(n0 + PB, N); n += WG / 32) {
         float q[4], dq[3];
         normalized_query(pts, times, aabb, n, q, dq);
         // lane id (< 18) reserves the slot of plane id in the list of its base cell: one returning integer atomic
@@ -417,12 +418,12 @@ int mobgs_hexplane_bwd(int N, const float* pts, const float* times, const float*
     static std::atomic<unsigned long long> done_c{0}, done_p{0};
     allow_lds(reinterpret_cast<const void*>(hex_count_kernel), (int)sizeof(int) * HOT_MAX, done_c);
     allow_lds(reinterpret_cast<const void*>(hex_pass1_kernel), (int)sizeof(int) * HOT_MAX, done_p);
-    hipLaunchKernelGGL(hex_count_kernel, dim3(n_blocks), dim3(512), hot_bytes, st, N, pts, times, aabb, ps, cm, S.count);
+    hipLaunchKernelGGL(hex_count_kernel, dim3(n_blocks), dim3(WG), hot_bytes, st, N, pts, times, aabb, ps, cm, S.count);
     const int nb = (cm.total + 1023) / 1024;
     hipLaunchKernelGGL(hex_scan_blocks_kernel, dim3(nb), dim3(1024), 0, st, cm.total, S.count, S.block_sums);
     hipLaunchKernelGGL(hex_scan_top_kernel, dim3(1), dim3(1024), 0, st, nb, S.block_sums);
     hipLaunchKernelGGL(hex_scan_final_kernel, dim3(nb), dim3(1024), 0, st, cm.total, S.count, S.block_sums, S.start);
-    hipLaunchKernelGGL(hex_pass1_kernel, dim3(n_blocks), dim3(512), hot_bytes, st, N, pts, times, aabb, ps, cm, v_feat,
+    hipLaunchKernelGGL(hex_pass1_kernel, dim3(n_blocks), dim3(WG), hot_bytes, st, N, pts, times, aabb, ps, cm, v_feat,
                        S.start, S.cursor, S.hdr, S.rows, v_pts, v_times);
     const int n_half = (n_entries + SLICE - 1) / SLICE;
     hipLaunchKernelGGL(hex_pass2_kernel, dim3((n_half + 7) / 8), dim3(256), 0, st, n_entries, ps, cm, gs, S.hdr, S.rows);
