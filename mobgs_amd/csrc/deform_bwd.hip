@@ -1,4 +1,5 @@
-// Backward pass of the deformation MLP + update rules (BASELINE config #3) for gfx950, fp32 MFMA.
+// The deformation MLP + update rules (BASELINE config #3) for gfx950 on fp32 MFMA: backward pass (below), and the
+// forward pass in the same workgroup tiling (deform_mlp_fwd_kernel, further down).
 //
 // Differentiates what deform.hip's deform_mlp_fwd_kernel computes, i.e.
 //   /root/reference/scene/deformation.py:56-73,158-199   Linear(96,128); three heads ReLU-Linear(128,128)-ReLU-
@@ -65,12 +66,12 @@ __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (
 // (LDS ~100, L2 ~300-500 cycles) is exposed every U MFMAs.
 template <int K>
 __device__ __forceinline__ void gemm_tile(const float (*A)[LDB], int row0, const float* __restrict__ B, int ldb,
-                                          int col0, int lane, f32x16& acc) {
+                                          int col0, int lane, f32x16& acc, int acol0 = 0) {
     constexpr int U = GEMM_U;      // k-steps per group
     constexpr int G = K / 2 / U;   // groups; processed two at a time (ping / pong register sets)
     static_assert(G % 2 == 0, "K/2 must be a multiple of twice the group size");
     const int r = lane & 31, kh = lane >> 5;
-    const float* ap = &A[row0 + r][kh];
+    const float* ap = &A[row0 + r][acol0 + kh];
     const float* bp = B + (size_t)kh * ldb + col0 + r;
     float a0[U], b0[U], a1[U], b1[U];
 #pragma unroll
@@ -421,6 +422,116 @@ deform_mlp_bwd_kernel(int N, int n_tiles, const float* __restrict__ feat, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward: the same workgroup tiling (8 waves, 64 points, pipelined operand fetch) instead of round 1's one-wave-per-
+// 32-points kernel (31 % of the fp32 MFMA peak: every MFMA waited for its own L2 fetch).  The 128 -> {7,3,4} output
+// layers have only 64 x 32 outputs per tile: the eight waves split their K = 128 into quarters (wave (cb, hf): rows of
+// half hf, k in [32 cb, 32 cb + 32)), leave the four partial tiles in LDS and the workgroup sums them in fixed order.
+struct FwdLds {
+    float F[TP][LDB];        // features; reused for the partial output tiles of the heads
+    float A1[TP][LDB];       // relu(hidden)
+    float A2[TP][LDB];       // relu(z1) of the current head
+    float PO[4][TP][LDO];    // partial head outputs per K-quarter
+    float O[TP][16];         // the 14 raw head outputs
+};
+
+__global__ void __launch_bounds__(512)
+deform_mlp_fwd_kernel(int N, int n_tiles, const float* __restrict__ feat, const float* __restrict__ pts,
+                      const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ W0t,
+                      const float* __restrict__ b0, const float* __restrict__ W1t, const float* __restrict__ b1,
+                      const float* __restrict__ W2t, const float* __restrict__ b2, float* __restrict__ out_pts,
+                      float* __restrict__ out_scales, float* __restrict__ out_rots, float* __restrict__ o_raw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    FwdLds& S = *reinterpret_cast<FwdLds*>(lds_raw);
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int r = lane & 31;
+    const int cb = wv & 3, hf = wv >> 2, col0 = 32 * cb, prow0 = 32 * hf;
+    const int nout[3] = {7, 3, 4}, ooff[3] = {0, 7, 10};
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row0 = tile * TP;
+        for (int idx = tid; idx < TP * 96; idx += 512) {
+            const int p = idx / 96, k = idx - p * 96;
+            S.F[p][k] = (row0 + p < N) ? feat[(size_t)(row0 + p) * 96 + k] : 0.f;
+        }
+        __syncthreads();
+        {
+            f32x16 acc;
+            zero(acc);
+            gemm_tile<96>(S.F, prow0, W0t, 128, col0, lane, acc);
+            const float bias = b0[col0 + r];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S.A1[prow0 + acc_row(i, lane)][col0 + r] = fmaxf(acc[i] + bias, 0.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            {
+                f32x16 acc;
+                zero(acc);
+                gemm_tile<128>(S.A1, prow0, W1t + (size_t)h * 128 * 128, 128, col0, lane, acc);
+                const float bias = b1[h * 128 + col0 + r];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S.A2[prow0 + acc_row(i, lane)][col0 + r] = fmaxf(acc[i] + bias, 0.f);
+            }
+            __syncthreads();
+            {
+                f32x16 acc;
+                zero(acc);
+                gemm_tile<32>(S.A2, prow0, W2t + (size_t)h * 128 * 32 + (size_t)col0 * 32, 32, 0, lane, acc, col0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S.PO[cb][prow0 + acc_row(i, lane)][r] = acc[i];
+            }
+            __syncthreads();
+            for (int idx = tid; idx < TP * 8; idx += 512) {
+                const int p = idx >> 3, o = idx & 7;
+                if (o < nout[h])
+                    S.O[p][ooff[h] + o] = ((S.PO[0][p][o] + S.PO[1][p][o]) + (S.PO[2][p][o] + S.PO[3][p][o])) +
+                                          b2[h * 32 + o];
+            }
+            // (the next head's first barrier orders these reads of PO / writes of O before anything overwrites them)
+        }
+        __syncthreads();
+        // update rules, one lane per point
+        if (tid < TP && row0 + tid < N) {
+            const int n = row0 + tid;
+            float o[14];
+#pragma unroll
+            for (int k = 0; k < 14; ++k) o[k] = S.O[tid][k];
+            if (o_raw) {  // what the backward pass needs of the forward: the 14 raw head outputs (64 B per point)
+#pragma unroll
+                for (int k = 0; k < 14; ++k) o_raw[(size_t)n * 16 + k] = o[k];
+            }
+            // points: R(quat2mat5(dx[3:7])) (p + dx[0:3])
+            const float px = pts[3 * n] + o[0], py = pts[3 * n + 1] + o[1], pz = pts[3 * n + 2] + o[2];
+            const float inv5 = 1.f / sqrtf(1.f + o[3] * o[3] + o[4] * o[4] + o[5] * o[5] + o[6] * o[6]);
+            const float w = inv5, x = o[3] * inv5, y = o[4] * inv5, z = o[5] * inv5;
+            const float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
+            const float wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
+            out_pts[3 * n] = (w2 + x2 - y2 - z2) * px + (2.f * xy - 2.f * wz) * py + (2.f * wy + 2.f * xz) * pz;
+            out_pts[3 * n + 1] = (2.f * wz + 2.f * xy) * px + (w2 - x2 + y2 - z2) * py + (2.f * yz - 2.f * wx) * pz;
+            out_pts[3 * n + 2] = (2.f * xz - 2.f * wy) * px + (2.f * wx + 2.f * yz) * py + (w2 - x2 - y2 + z2) * pz;
+            // scales: + clamp(ds, +-log 100)
+            const float L = 4.605170185988092f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out_scales[3 * n + k] = scales[3 * n + k] + fminf(fmaxf(o[7 + k], -L), L);
+            // rotations: normalize((rot + dr) (x) dx[3:7])
+            const float a0 = rots[4 * n] + o[10], a1 = rots[4 * n + 1] + o[11], a2 = rots[4 * n + 2] + o[12],
+                        a3 = rots[4 * n + 3] + o[13];
+            const float b0q = o[3], b1q = o[4], b2q = o[5], b3q = o[6];
+            const float qw = a0 * b0q - a1 * b1q - a2 * b2q - a3 * b3q;
+            const float qx = a0 * b1q + a1 * b0q + a2 * b3q - a3 * b2q;
+            const float qy = a0 * b2q - a1 * b3q + a2 * b0q + a3 * b1q;
+            const float qz = a0 * b3q + a1 * b2q - a2 * b1q + a3 * b0q;
+            const float invn = 1.f / sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+            out_rots[4 * n] = qw * invn;
+            out_rots[4 * n + 1] = qx * invn;
+            out_rots[4 * n + 2] = qy * invn;
+            out_rots[4 * n + 3] = qz * invn;
+        }
+        __syncthreads();
+    }
+}
+
 // out[i] = sum over the workgroups' partials, in workgroup order
 __global__ void __launch_bounds__(256) mlp_grad_reduce_kernel(int n_part, const float* __restrict__ partials,
                                                               float* __restrict__ out) {
@@ -453,6 +564,24 @@ static void allow_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned lo
 using namespace mobgs;
 
 extern "C" {
+
+int mobgs_deform_mlp_fwd(int N, const float* feat, const float* pts, const float* scales, const float* rots,
+                         const float* W0t, const float* b0, const float* W1t, const float* b1, const float* W2t,
+                         const float* b2, float* out_pts, float* out_scales, float* out_rots, float* o_raw,
+                         void* stream) {
+    if (N < 0) {
+        set_error("mobgs_deform_mlp_fwd: bad N=%d", N);
+        return MOBGS_E_INVALID;
+    }
+    if (N == 0) return MOBGS_OK;
+    static std::atomic<unsigned long long> attr_done{0};
+    allow_dynamic_lds(reinterpret_cast<const void*>(deform_mlp_fwd_kernel), (int)sizeof(FwdLds), attr_done);
+    const int tiles = (N + TP - 1) / TP;
+    const int grid = tiles < 256 ? tiles : 256;
+    hipLaunchKernelGGL(deform_mlp_fwd_kernel, dim3(grid), dim3(512), sizeof(FwdLds), (hipStream_t)stream, N, tiles, feat,
+                       pts, scales, rots, W0t, b0, W1t, b1, W2t, b2, out_pts, out_scales, out_rots, o_raw);
+    return check_launch("deform_mlp_fwd_kernel");
+}
 
 int mobgs_deform_mlp_bwd_blocks(int N) {
     const int tiles = (N + TP - 1) / TP;
