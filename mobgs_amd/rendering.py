@@ -183,8 +183,15 @@ class _PendingCounts:
         self.caps, self.arenas, self.rebuild_args = caps, arenas, rebuild_args
 
     def __del__(self):
+        # dropped without finish() (exception, unused result): the device may still be about to write this slot, so
+        # it goes back to the pool only when its sequence word has arrived; otherwise it is simply retired
         if self.slot is not None and _stats_slots is not None:
-            _stats_slots.give(self.slot)
+            try:
+                arrived = self.event is not None and self.event.query() or int(self.row.numpy()[3]) == self.seq
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                arrived = False
+            if arrived:
+                _stats_slots.give(self.slot)
             self.slot = None
 
     def _wait(self):
@@ -195,14 +202,23 @@ class _PendingCounts:
         # recorded, so nothing sits between the binning kernels and what was enqueued behind them)
         import time
         word = self.row.numpy()
-        deadline = None
+        if int(word[3]) == self.seq:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mobgs: render() cannot be captured into a HIP graph (the host reads the intersection "
+                               "counts of the frame between binning and the end of the forward pass)")
+        t0 = time.monotonic()
+        spins = 0
         while int(word[3]) != self.seq:
-            if deadline is None:
-                deadline = time.monotonic() + 10.0
-            elif time.monotonic() > deadline:
+            spins += 1
+            if spins < 20000:      # the counts are normally there within ~0.2 ms: spin (a sleep costs 50+ us)
+                continue
+            dt = time.monotonic() - t0
+            if dt > 10.0:
                 torch.cuda.synchronize()
                 if int(word[3]) != self.seq:
                     raise RuntimeError("mobgs: the intersection counts never arrived (device fault?)")
+            time.sleep(50e-6 if dt < 0.05 else 1e-3)  # long wait (queue full of other work): stop burning a core
 
     def finish(self, tl) -> bool:
         self._wait()
