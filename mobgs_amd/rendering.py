@@ -185,14 +185,18 @@ class _PendingCounts:
     def __del__(self):
         # dropped without finish() (exception, unused result): the device may still be about to write this slot, so
         # it goes back to the pool only when its sequence word has arrived; otherwise it is simply retired
-        if self.slot is not None and _stats_slots is not None:
-            try:
-                arrived = self.event is not None and self.event.query() or int(self.row.numpy()[3]) == self.seq
-            except Exception:  # noqa: BLE001  (interpreter shutdown)
-                arrived = False
-            if arrived:
-                _stats_slots.give(self.slot)
-            self.slot = None
+        if self.slot is None or _stats_slots is None:
+            return
+        import sys
+        if sys is None or sys.is_finalizing():  # interpreter shutdown: torch / HIP may already be torn down
+            return
+        try:
+            arrived = int(self.row.numpy()[3]) == self.seq if self.event is None else bool(self.event.query())
+        except Exception:  # noqa: BLE001
+            arrived = False
+        if arrived:
+            _stats_slots.give(self.slot)
+        self.slot = None
 
     def _wait(self):
         if self.event is not None:
