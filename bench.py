@@ -189,6 +189,47 @@ class DeblurWorkload:
         return pred
 
 
+class DynamicWorkload:
+    """BASELINE config #3 (secondary object of the N = 1 line): `deform_network` (HexPlane [64,64,64,12] x [1,2,4] +
+    MLP heads, arguments/stereo/seesaw.py) moves the dynamic Gaussians' position / scale / rotation, the result is
+    rasterised together with the static set (RGB+ED, 9 channels) and fixed cotangents are back-propagated to the
+    deformation network's planes and weights and to the Gaussian inputs."""
+
+    def __init__(self, dev, raw, scam, width, height, seed=0):
+        from mobgs_amd.deformation import SeesawArgs, deform_network
+        stat_p, dyn_p, _ = raw
+        torch.manual_seed(seed)
+        self.net = deform_network(SeesawArgs()).to(dev)
+        lo, hi = dyn_p["xyz"].min(0).values, dyn_p["xyz"].max(0).values
+        self.net.deformation_net.set_aabb(hi.tolist(), lo.tolist())
+        with torch.no_grad():
+            for pl in self.net.deformation_net.grid.planes():
+                pl.uniform_(0.5, 1.0)
+        T = lambda t: t.to(dev)  # noqa: E731
+        self.s = {"means": T(stat_p["xyz"]), "scales": T(torch.exp(stat_p["scaling"])), "quats": T(stat_p["rotation"])}
+        self.leaves = [T(dyn_p[k]).requires_grad_(True) for k in ("xyz", "scaling", "rotation")]
+        self.opac = T(torch.sigmoid(torch.cat([stat_p["opacity"], dyn_p["opacity"]])).squeeze(-1))
+        self.cols = T(torch.cat([torch.cat([stat_p["features_dc"], stat_p["features_t"]], 1),
+                                 torch.cat([dyn_p["features_dc"], dyn_p["features_t"]], 1)]))
+        self.times = torch.full((dyn_p["xyz"].shape[0], 1), scam.time, device=dev)
+        self.K, self.vm = T(scam.K)[None], torch.eye(4, device=dev)[None]
+        self.W, self.H = width, height
+        g = torch.Generator().manual_seed(seed + 5)
+        self.v = torch.randn(1, height, width, 10, generator=g).to(dev)
+        self.bg = torch.zeros(1, 9, device=dev)
+        self.params = list(self.net.parameters())
+
+    def step(self):
+        from mobgs_amd.rendering import rasterization
+        for p in self.params + self.leaves:
+            p.grad = None
+        d_pts, d_scl, d_rot = self.net(*self.leaves, self.times)
+        img, _, _ = rasterization(torch.cat([self.s["means"], d_pts]), torch.cat([self.s["quats"], d_rot]),
+                                  torch.cat([self.s["scales"], torch.exp(d_scl)]), self.opac, self.cols, self.vm, self.K,
+                                  self.W, self.H, packed=False, backgrounds=self.bg, render_mode="RGB+ED")
+        torch.autograd.backward([img], [self.v])
+
+
 def timed(step, steps, warmup, world, dist):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize; per-step HIP events on the current
     stream give the median next to the wall-clock mean."""
@@ -223,6 +264,7 @@ def main():
     ap.add_argument("--height", type=int, default=1014)
     ap.add_argument("--views", type=int, default=2, help="views per training iteration in the deblur step")
     ap.add_argument("--deblur-steps", type=int, default=10, help="N=1: steps of the secondary deblur leg (0: skip)")
+    ap.add_argument("--dynamic-steps", type=int, default=20, help="N=1: steps of the secondary config #3 leg (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-torch", action="store_true", help="skip the PyTorch-CPU config #1 render (tens of s)")
     ap.add_argument("--cpu-reps", type=int, default=2)
@@ -279,12 +321,15 @@ def main():
 
     P = args.width * args.height
     n_units = args.views * 9
-    deblur = None
+    deblur = dynamic = None
     if world == 1:
         profiler.enable(True)
         dt, med_ms = timed(lean_step, args.steps, args.warmup, world, dist)
         prof = profiler.summary()
         profiler.enable(False)
+        from mobgs_amd import rendering
+        I = rendering.last_stats.get("n_isects", 0)  # of the PRIMARY workload (the secondary legs render too)
+        n_vis = int((last["out"]["radii"] > 0).sum())
         renders = args.steps
         workload = ("BASELINE config #2: seesaw-synth (SURVEY 8d seed 0), "
                     f"{args.ns} static + {args.nd} dynamic Gaussians, {args.width}x{args.height}, "
@@ -299,6 +344,14 @@ def main():
                       "subframes_per_view": 9, "steps": args.deblur_steps,
                       "what": "train.py:430-541 per iteration: per view 1 train-mode mid render + 8 latent renders "
                               "(BLCE cameras + exposure offsets, HIP-graph replay), mean, backward, flat gradient buffer"}
+        if args.dynamic_steps > 0:
+            dw = DynamicWorkload(dev, raw, scam, args.width, args.height)
+            xdt, xmed = timed(dw.step, args.dynamic_steps, 3, world, dist)
+            dynamic = {"steps_per_s": round(args.dynamic_steps / xdt, 2),
+                       "ms_per_step": round(xdt / args.dynamic_steps * 1e3, 4), "event_median_ms_per_step": round(xmed, 4),
+                       "what": "BASELINE config #3: deform_network (seesaw HexPlane + MLP heads, HIP fwd + bwd) on the "
+                               f"{args.nd} dynamic Gaussians -> rasterization of all {args.ns + args.nd} (RGB+ED) -> "
+                               "backward to the network's planes / weights and the Gaussian inputs"}
     else:
         wl = DeblurWorkload(dev, stat, dyn, scam, args.width, args.height, shard, args.views)
         profiler.enable(True)
@@ -310,16 +363,15 @@ def main():
         dt = float(t.item())
         renders = n_units * args.steps
         last["out"] = next(iter(wl.mids.values())) if wl.mids else render(cam, stat, dyn, None, bg)
+        from mobgs_amd import rendering
+        I = rendering.last_stats.get("n_isects", 0)
+        n_vis = int((last["out"]["radii"] > 0).sum())
         workload = (f"K=9 deblur iteration (train.py:430-541): {args.views} blurry views x (1 train-mode mid render + 8 "
                     f"latent renders, BLCE cameras + exposure offsets), seesaw-synth {args.ns} static + {args.nd} "
                     f"dynamic Gaussians, {args.width}x{args.height}, fwd+bwd, {n_units} (view, sub-frame) units "
                     f"sharded over {world} ranks; value counts all {n_units} renders of a step")
 
-    # workload statistics for the roofline: intersections I and pixels P of this rank's last render
-    from mobgs_amd import rendering
-    I = rendering.last_stats.get("n_isects", 0)
-    out = last["out"]
-    n_vis = int((out["radii"] > 0).sum())
+    # workload statistics for the roofline: intersections I and pixels P of this rank's render (taken above)
     ms_per_step = dt / args.steps * 1e3
     value = renders / dt
 
@@ -344,6 +396,8 @@ def main():
     }
     if deblur is not None:
         result["deblur"] = deblur
+    if dynamic is not None:
+        result["dynamic_config3"] = dynamic
     if rank == 0:
         rb = prof.get("raster_bwd")
         if rb:
