@@ -266,10 +266,18 @@ def _tuning_with_hint(key):
 _tuning_keepalive = []
 # True: the projection/binning call does not wait for the intersection counts (see TileLists); False: it does
 SPECULATIVE_BINNING = True
-_len_hint = {}  # device index -> longest per-tile list of the previous frame (selects the sort variant)
+_len_hint = {}  # workload key -> longest per-tile list of the previous frame (selects the sort variant)
 # True: the compositing kernels take tiles heaviest-list-first (TileLists.tile_order); False: raster order
 TILE_SCHEDULE = os.environ.get("MOBGS_TILE_SCHEDULE", "1") != "0"
-_capacity = {}  # device index -> current capacity of the keep-flag buffer (grows geometrically, never shrinks)
+_capacity = {}  # workload key -> current capacity of the keep-flag buffer (grows geometrically, never shrinks)
+
+
+def _workload_key(dev, C, N, width, height):
+    """Arena sizes and list-length hints carry over from the previous frame OF THE SAME WORKLOAD: device, cameras,
+    splat count (in steps of 1/8 octave, so a scene that densifies keeps its arenas) and image size -- two scenes or
+    a full-set and a dynamic-only projection sharing a device do not fight over one entry."""
+    n_bucket = 0 if N <= 0 else int(8 * math.log2(N))
+    return (dev.index if dev.index is not None else -1, int(C), n_bucket, int(width), int(height))
 
 
 def set_tile_culling(flag: bool) -> None:
@@ -300,7 +308,7 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Ten
                      if TILE_SCHEDULE else None)
     stats = torch.empty(3, dtype=torch.int64, device=dev)
     opac = f32c(opacities)
-    key = dev.index if dev.index is not None else -1
+    key = _workload_key(dev, C, N, width, height)
     cap = max(_capacity.get(key, 0), 16 * (C * N) + 1024)
     while True:
         tl.keep_scan = torch.empty(lib.mobgs_keep_scan_len(cap), dtype=torch.int32, device=dev)
@@ -638,7 +646,7 @@ class _RasterizeClasses(torch.autograd.Function):
         return v_means2d, v_conics, v_colors, v_opac, v_extra, None, None, None, None, None, None, None, None
 
 
-_cap_listed = {}  # device index -> capacity of the listed-intersection buffers
+_cap_listed = {}  # workload key -> capacity of the listed-intersection buffers
 
 
 class _ProjectAndBin(torch.autograd.Function):
@@ -674,7 +682,7 @@ class _ProjectAndBin(torch.autograd.Function):
             pack_ch = pack_colors.shape[-1]
             if lib.mobgs_raster_channels_supported(pack_ch + 1):
                 records = torch.empty(C * N, lib.mobgs_record_stride(pack_ch + 1), dtype=torch.float32, device=dev)
-        key = dev.index if dev.index is not None else -1
+        key = _workload_key(dev, C, N, width, height)
         cap_box = max(_capacity.get(key, 0), 16 * (C * N) + 1024)
         cap_listed = max(_cap_listed.get(key, 0), cap_box // 2)
         while True:
