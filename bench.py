@@ -343,7 +343,7 @@ def main():
                       "event_median_ms_per_iteration": round(dmed, 3), "views_per_iteration": args.views,
                       "subframes_per_view": 9, "steps": args.deblur_steps,
                       "what": "train.py:430-541 per iteration: per view 1 train-mode mid render + 8 latent renders "
-                              "(BLCE cameras + exposure offsets, HIP-graph replay), mean, backward, flat gradient buffer"}
+                              "(BLCE cameras + exposure offsets from the fused BLCE kernels), mean, backward, flat gradient buffer"}
         if args.dynamic_steps > 0:
             dw = DynamicWorkload(dev, raw, scam, args.width, args.height)
             xdt, xmed = timed(dw.step, args.dynamic_steps, 3, world, dist)

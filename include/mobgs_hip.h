@@ -454,6 +454,22 @@ int mobgs_deform_mlp_bwd(int N, const float* feat, const float* pts, const float
                          const float* v_out_rots, float* v_feat, float* v_pts, float* v_rots, float* v_o,
                          float* partials, float* grads, void* stream);
 
+/* ---- K10b: BLCE of one view (latent camera poses of the K = 9 sub-frames), forward and backward ----------
+ * /root/reference/scene/blce.py:374-478 (BLCE.forward) + :150-152 (inverse of the warped poses), which the reference
+ * runs as ~180 + ~350 tiny torch launches per view.  One single-wave kernel each way.
+ * params_host / grads_host: HOST arrays of 22 device pointers in the order documented in csrc/blce.hip (the
+ *   reference's parameter tensors of view `idx`: view_embedder table, Rt_encoder, view_encoder, blur_feature_encoder
+ *   0/2/4, wv_derivative.{time_embedder, w_linear, v_linear}, rot/trans/theta decoders; weight then bias).
+ * Rt [4,4] c2w of the view, blur_feature: device scalar.  c2w / w2c [9,4,4]: warped poses and their inverses.
+ * saved: mobgs_blce_saved_floats() floats kept for the backward pass (NULL when no gradient is needed).
+ * bwd: v_c2w / v_w2c [9,4,4] cotangents (either may be NULL); every gradient tensor is fully written (the
+ *   view_embedder table gets zeros outside row idx). */
+size_t mobgs_blce_saved_floats(void);
+int mobgs_blce_fwd(const float* const* params_host, int idx, const float* Rt, const float* blur_feature, float* c2w,
+                   float* w2c, float* saved, void* stream);
+int mobgs_blce_bwd(const float* const* params_host, float* const* grads_host, int idx, int num_views, const float* Rt,
+                   const float* saved, const float* v_c2w, const float* v_w2c, void* stream);
+
 /* ---- K11: fused photometric loss (L1 + SSIM), forward and backward -------------------------------------
  * /root/reference/utils/loss_utils.py:233-239 (l1_loss, mask=None), :251-260 + :351-381 (ssim: 11x11 Gaussian
  * window sigma 1.5, zero padding, per channel, mean over all elements); /root/reference/train.py:621-628.

@@ -191,8 +191,12 @@ class WarpedCamera:
         return self._ray
 
 
-# True: the per-view BLCE forward / backward is captured once per view in a HIP graph and replayed (see
-# blceKernel._view_fn); False: eager launches
+# True (default): the per-view BLCE forward / backward run as ONE hand-written HIP kernel each (csrc/blce.hip) on HIP
+# tensors.  False: the PyTorch module below (eager, or replayed as a HIP graph when GRAPH_CAPTURE is on) -- the
+# formulation the fused kernels are tested against.
+FUSED = True
+# True: the per-view BLCE forward / backward of the PyTorch path is captured once per view in a HIP graph and
+# replayed (see blceKernel._view_fn); False: eager launches
 GRAPH_CAPTURE = True
 # True: a failed capture raises instead of falling back to eager launches with a warning (benchmarks / tests that
 # must not silently measure the eager path)
@@ -217,6 +221,58 @@ class _ReplayGuard(torch.autograd.Function):
     def backward(ctx, g):
         ctx.flight.done = True
         return g, None
+
+
+def _view_param_list(model: "BLCE", i: int):
+    """The 22 parameter tensors of view i in the order csrc/blce.hip documents."""
+    bfe, wv = model.blur_feature_encoder[i], model.wv_derivative[i]
+    return [model.view_embedder, model.Rt_encoder[i].weight, model.Rt_encoder[i].bias, model.view_encoder[i].weight,
+            model.view_encoder[i].bias, bfe[0].weight, bfe[0].bias, bfe[2].weight, bfe[2].bias, bfe[4].weight,
+            bfe[4].bias, wv.time_embedder, wv.w_linear.weight, wv.w_linear.bias, wv.v_linear.weight, wv.v_linear.bias,
+            model.rot_decoder[i].weight, model.rot_decoder[i].bias, model.trans_decoder[i].weight,
+            model.trans_decoder[i].bias, model.theta_decoder[i].weight, model.theta_decoder[i].bias]
+
+
+class _FusedView(torch.autograd.Function):
+    """(Rt [4,4], blur feature, idx, 22 parameters) -> (warped c2w [9,4,4], warped w2c [9,4,4]) in one kernel launch;
+    backward: one launch that writes all 22 parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, Rt, bf, idx, num_views, *params):
+        import ctypes
+        from . import _lib
+        from ._lib import check, f32c, ptr, stream
+        lib = _lib.load()
+        Rt, bf = f32c(Rt), f32c(bf).reshape(1)
+        ps = [f32c(p.detach()) for p in params]
+        dev = Rt.device
+        c2w = torch.empty(9, 4, 4, dtype=torch.float32, device=dev)
+        w2c = torch.empty(9, 4, 4, dtype=torch.float32, device=dev)
+        need = any(ctx.needs_input_grad[4:])
+        saved = torch.empty(int(lib.mobgs_blce_saved_floats()), dtype=torch.float32, device=dev) if need else None
+        table = (ctypes.c_void_p * 22)(*[p.data_ptr() for p in ps])
+        check(lib.mobgs_blce_fwd(table, int(idx), ptr(Rt), ptr(bf), ptr(c2w), ptr(w2c), ptr(saved), stream()),
+              "mobgs_blce_fwd")
+        if need:
+            ctx.save_for_backward(Rt, saved, *ps)
+            ctx.idx, ctx.num_views = int(idx), int(num_views)
+        return c2w, w2c
+
+    @staticmethod
+    def backward(ctx, v_c2w, v_w2c):
+        import ctypes
+        from . import _lib
+        from ._lib import check, f32c, ptr, stream
+        lib = _lib.load()
+        Rt, saved, *ps = ctx.saved_tensors
+        grads = [torch.empty_like(p) for p in ps]
+        table = (ctypes.c_void_p * 22)(*[p.data_ptr() for p in ps])
+        gtable = (ctypes.c_void_p * 22)(*[g.data_ptr() for g in grads])
+        v_c2w = f32c(v_c2w) if v_c2w is not None else None
+        v_w2c = f32c(v_w2c) if v_w2c is not None else None
+        check(lib.mobgs_blce_bwd(table, gtable, ctx.idx, ctx.num_views, ptr(Rt), ptr(saved), ptr(v_c2w), ptr(v_w2c),
+                                 stream()), "mobgs_blce_bwd")
+        return (None, None, None, None, *grads)
 
 
 class _ViewModule(nn.Module):
@@ -249,6 +305,7 @@ class blceKernel(nn.Module):
         self._blur_cache = {}
         self._c2w_cache = {}
         self._graphed = {}
+        self._steps = {}
         self._graph_ptrs = {}
         self._inflight = {}
 
@@ -291,6 +348,7 @@ class blceKernel(nn.Module):
                 fn = None
         if fn is None:
             try:
+                torch.cuda.synchronize()  # capture starts from an idle device (one-time cost per view)
                 fn = torch.cuda.make_graphed_callables(_ViewModule(self.model, idx_view), (Rt.clone(), bf.clone()))
             except RuntimeError as e:  # capture unsupported in this setup: say so once and run eagerly from now on
                 if REQUIRE_GRAPH:
@@ -325,13 +383,25 @@ class blceKernel(nn.Module):
     def get_warped_cams(self, cam=None, fwd_cam=None, bwd_cam=None):
         dev = next(self.model.parameters()).device
         Rt = self.get_Rt_c2w(cam).to(dev)
-        warped_c2w, exposure_time = self._view_fn(cam.uid, Rt, self.blur_feature(cam).to(dev))
-        warped_w2c = torch.inverse(warped_c2w)
+        if FUSED and Rt.is_cuda and self.model.num_warp == 9:
+            m = self.model
+            warped_c2w, warped_w2c = _FusedView.apply(Rt, self.blur_feature(cam).to(dev), int(cam.uid), m.num_views,
+                                                      *_view_param_list(m, int(cam.uid)))
+            exposure_time = self._exposure_steps(dev) * m.exposure_time_expo[cam.uid]
+        else:
+            warped_c2w, exposure_time = self._view_fn(cam.uid, Rt, self.blur_feature(cam).to(dev))
+            warped_w2c = torch.inverse(warped_c2w)
         # unbind: ONE autograd node per stack (its backward is a single stack) instead of 2 x num_warp selects whose
         # backward each zero-fills and copies a [num_warp,4,4] tensor
         cams: List = [self.camera_factory(cam, w2c_i, c2w_i)
                       for w2c_i, c2w_i in zip(warped_w2c.unbind(0), warped_c2w.unbind(0))]
         return cams, exposure_time
+
+    def _exposure_steps(self, dev):
+        t = self._steps.get(str(dev))
+        if t is None:
+            t = self._steps[str(dev)] = torch.linspace(-1, 1, self.num_warp, device=dev)
+        return t
 
     def adjust_lr(self) -> None:
         for g in self.optimizer.param_groups:
