@@ -7,13 +7,16 @@ WV_Derivative (:234-275), BLCE (:311-478).  Module tree and parameter names are 
 `model.rot_decoder/.trans_decoder/.theta_decoder.<v>`), so `blce.pth` checkpoints load unchanged.
 
 This part of the path is a handful of 16..64-wide Linear layers on ONE vector per view (176 640 parameters for
-24 views) and an 8-step explicit Euler integration: latency-bound host-driven work with no kernel worth writing,
-kept in PyTorch on the HIP device.  `torchdiffeq.odeint(method=
-'euler')` on the integer grid 0..num_warp-1 is restated as the fixed-step loop it is (:278-309); `pytorch3d` and
-`einops` were imported but unused upstream.
+24 views) and an 8-step explicit Euler integration: ~530 launches of a few microseconds each in PyTorch, pure launch
+latency.  On a HIP device `blceKernel.get_warped_cams` therefore runs it as TWO single-wave kernels per view
+(csrc/blce.hip: forward incl. the pose inversion, backward with all 22 parameter gradients; `FUSED`).  The PyTorch
+module below is the same computation -- API-compatible with the reference, used on CPU, by `FUSED = False` (eagerly
+or replayed as a HIP graph) and as what the fused kernels are tested against.  `torchdiffeq.odeint(method='euler')`
+on the integer grid 0..num_warp-1 is restated as the fixed-step loop it is (:278-309); `pytorch3d` and `einops` were
+imported but unused upstream.
 
-What IS done differently for MI355X: the warped cameras carry their [1,6,H,W] ray map lazily -- it is built
-from (K, c2w) on first use instead of 9 x 33 MB eagerly per view.
+Also done differently for MI355X: the warped cameras carry their [1,6,H,W] ray map lazily -- it is built from
+(K, c2w) on first use instead of 9 x 33 MB eagerly per view.
 """
 from __future__ import annotations
 
