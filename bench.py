@@ -179,7 +179,7 @@ class DeblurWorkload:
             outs += [pkg["depth"], pkg["d_alpha"]]
             cots += [self.v_depth, self.v_alpha]
         if any(o.requires_grad for o in outs):
-            with LeafGradSink(self.stat, self.dyn):
+            with LeafGradSink(self.stat, self.dyn, extra=self.blce.model.get_params()):
                 torch.autograd.backward([o for o in outs if o.requires_grad],
                                         [c for o, c in zip(outs, cots) if o.requires_grad])
         for v, pkg in mids.items():

@@ -389,19 +389,23 @@ int mobgs_prep_bwd_f16(int Ns, int Nd, const float* times, const int64_t* d_ncp,
  * feat_hw [P,CF] channels-last compositor output (CF >= 9; channel 9 = accumulated depth when has_depth),
  * alphas [P], w1 [6,12], w2 [3,6]  ->  rgb [3,P] planar, depth [P].
  * Camera rays, one of:
- *   rays   [6,P] planar (the reference's cam_ray map, /root/reference/scene/cameras.py:132-146), raycam = NULL;
- *   rays = NULL, raycam = device float[16] {fx, fy, cx, cy, c2w row-major 3x4}, width = image width: the origin
- *          and the unit view direction through each pixel centre are generated in registers. */
+ *   rays   [6,P] planar (the reference's cam_ray map, /root/reference/scene/cameras.py:132-146), ray_* = NULL;
+ *   rays = NULL, ray_intr = device float[4] {fx, fy, cx, cy}, ray_c2w = device float[12] (the first three rows of
+ *          the row-major camera-to-world matrix: a [3,4] or a [4,4] array), width = image width: the origin and
+ *          the unit view direction through each pixel centre are generated in registers. */
 int mobgs_decoder_fwd(int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
-                      const float* rays, const float* raycam, const float* w1, const float* w2, float* rgb,
-                      float* depth, void* stream);
+                      const float* rays, const float* ray_intr, const float* ray_c2w, const float* w1,
+                      const float* w2, float* rgb, float* depth, void* stream);
 /* w_partial: scratch [mobgs_decoder_bwd_blocks(P), 102] floats.  v_depth / v_rays may be NULL.
- * g_c2w (float[12], may be NULL): gradient of the c2w entries of raycam (in-kernel-ray mode only). */
+ * g_c2w (may be NULL): gradient of ray_c2w (in-kernel-ray mode only), g_c2w_floats = 12 ([3,4]) or 16 ([4,4]: the
+ * fourth row is written as zeros).  accumulate_wgrad != 0: the weight gradients are added to g_w1 / g_w2 instead
+ * of overwriting them (fixed summation order either way). */
 int mobgs_decoder_bwd_blocks(int P);
 int mobgs_decoder_bwd(int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
-                      const float* rays, const float* raycam, const float* w1, const float* w2,
-                      const float* v_rgb, const float* v_depth, float* v_feat_hw, float* v_alphas, float* v_rays,
-                      float* w_partial, float* g_w1, float* g_w2, float* g_c2w, void* stream);
+                      const float* rays, const float* ray_intr, const float* ray_c2w, const float* w1,
+                      const float* w2, const float* v_rgb, const float* v_depth, float* v_feat_hw, float* v_alphas,
+                      float* v_rays, float* w_partial, float* g_w1, float* g_w2, float* g_c2w, int g_c2w_floats,
+                      int accumulate_wgrad, void* stream);
 
 /* ---- K10: deformation network (the API the reference exposes as scene.deformation.deform_network) -----
  * /root/reference/scene/hexplane.py:75-108,165-187 (HexPlane multi-resolution bilinear planes, product over the

@@ -180,8 +180,8 @@ class WarpedCamera:
         return torch.stack([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
 
     @property
-    def ray_c2w(self):  # differentiable: the decoder kernel reduces the ray gradient into these 12 entries
-        return self._c2w[:3, :]
+    def ray_c2w(self):  # differentiable: the decoder kernel reduces the ray gradient into its first 12 entries
+        return self._c2w  # the whole [4,4]: slicing rows would add a zero-fill + copy pair to every backward pass
 
     def __getattr__(self, name):  # everything else (K, time, max_time, image, uid, sizes, ...) comes from the source
         return getattr(self._src, name)
@@ -259,6 +259,7 @@ class _FusedView(torch.autograd.Function):
         if need:
             ctx.save_for_backward(Rt, saved, *ps)
             ctx.idx, ctx.num_views = int(idx), int(num_views)
+            ctx.param_inputs = tuple(params)  # the caller's Parameter objects (ops.LeafGradSink.add_into_grads)
         return c2w, w2c
 
     @staticmethod
@@ -275,6 +276,10 @@ class _FusedView(torch.autograd.Function):
         v_w2c = f32c(v_w2c) if v_w2c is not None else None
         check(lib.mobgs_blce_bwd(table, gtable, ctx.idx, ctx.num_views, ptr(Rt), ptr(saved), ptr(v_c2w), ptr(v_w2c),
                                  stream()), "mobgs_blce_bwd")
+        from .ops import active_sink
+        sink = active_sink()
+        if sink is not None and sink.add_into_grads(ctx.param_inputs, grads):  # one launch instead of 22 add_
+            return (None,) * (4 + len(grads))
         return (None, None, None, None, *grads)
 
 

@@ -9,8 +9,9 @@
 // Camera rays: the reference keeps a [1,6,H,W] map per camera (origin + unit view direction through each pixel
 // centre, /root/reference/scene/cameras.py:132-146) -- 33 MB at 1352x1014, rebuilt for each of the 9 BLCE-warped
 // cameras of a blurry view.  When the caller passes the pinhole parameters instead
-// (`raycam` = {fx, fy, cx, cy, c2w[3][4]}, `rays` = NULL) the rays are generated in registers and the backward
-// pass reduces their gradient straight into the 12 entries of c2w.
+// (`ray_intr` = {fx, fy, cx, cy}, `ray_c2w` = the first three rows of the row-major camera-to-world matrix, `rays` =
+// NULL) the rays are generated in registers and the backward pass reduces their gradient straight into the 12
+// entries of c2w.
 //
 // One thread per pixel; the 90 weights live in SGPRs (wave-uniform, scalar loads).  Reads the compositor's
 // channels-last image [H,W,10] (one 40-byte row per lane), the planar ray map [6,H,W] and writes planar rgb
@@ -40,11 +41,11 @@ struct RayCam {
     float fx, fy, cx, cy;
     float c2w[12];  // row-major 3x4: [R | t], camera -> world
 };
-__device__ inline RayCam load_raycam(const float* __restrict__ rc) {
+__device__ inline RayCam load_raycam(const float* __restrict__ intr, const float* __restrict__ c2w) {
     RayCam c;
-    c.fx = rc[0]; c.fy = rc[1]; c.cx = rc[2]; c.cy = rc[3];
+    c.fx = intr[0]; c.fy = intr[1]; c.cx = intr[2]; c.cy = intr[3];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) c.c2w[k] = rc[4 + k];
+    for (int k = 0; k < 12; ++k) c.c2w[k] = c2w[k];
     return c;
 }
 // origin + normalised direction of pixel p (row-major, width W); also returns the local direction and 1/|d|
@@ -67,11 +68,12 @@ __device__ inline void pixel_ray(const RayCam& c, int p, int W, float r[6], floa
 __global__ void __launch_bounds__(DEC_THREADS)
 decoder_fwd_kernel(int P, int CF, int has_depth, int width, const float* __restrict__ feat_hw,
                    const float* __restrict__ alphas, const float* __restrict__ rays,
-                   const float* __restrict__ raycam, const float* __restrict__ w1, const float* __restrict__ w2,
+                   const float* __restrict__ ray_intr, const float* __restrict__ ray_c2w,
+                   const float* __restrict__ w1, const float* __restrict__ w2,
                    float* __restrict__ rgb, float* __restrict__ depth) {
     const Weights W = load_weights(w1, w2);
     RayCam cam;
-    if (!rays) cam = load_raycam(raycam);
+    if (!rays) cam = load_raycam(ray_intr, ray_c2w);
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         const float* f = feat_hw + (size_t)p * CF;
         float x[12];
@@ -134,7 +136,8 @@ constexpr int NACC = 30;  // 18 (w2) + 12 (c2w)
 __global__ void __launch_bounds__(DEC_THREADS)
 decoder_bwd_kernel(int P, int CF, int has_depth, int width, const float* __restrict__ feat_hw,
                    const float* __restrict__ alphas, const float* __restrict__ rays,
-                   const float* __restrict__ raycam, int want_cam_grad, const float* __restrict__ w1,
+                   const float* __restrict__ ray_intr, const float* __restrict__ ray_c2w, int want_cam_grad,
+                   const float* __restrict__ w1,
                    const float* __restrict__ w2, const float* __restrict__ v_rgb, const float* __restrict__ v_depth,
                    float* __restrict__ v_feat_hw, float* __restrict__ v_alphas, float* __restrict__ v_rays,
                    float* __restrict__ w_partial) {
@@ -142,7 +145,7 @@ decoder_bwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
     __shared__ __attribute__((aligned(16))) float s_b[DEC_THREADS / 64][64][12];   // x[12] per pixel
     const Weights W = load_weights(w1, w2);
     RayCam cam;
-    if (!rays) cam = load_raycam(raycam);
+    if (!rays) cam = load_raycam(ray_intr, ray_c2w);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;  // MFMA operand coordinates of this lane
     float gw[NACC];
@@ -273,12 +276,18 @@ decoder_bwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
     }
 }
 
-// one workgroup per weight component: 90 workgroups x 256 threads sum the per-workgroup partial rows
+// one workgroup per weight component: 102 workgroups x 256 threads sum the per-workgroup partial rows in a fixed
+// order.  `accumulate`: the weight gradients are ADDED to g_w1 / g_w2 (several renders of one backward pass writing
+// into the same .grad).  Workgroups past the 102nd clear the fourth row of a 4 x 4 pose gradient.
 __global__ void __launch_bounds__(256) decoder_wgrad_reduce_kernel(int nblocks, const float* __restrict__ w_partial,
                                                                      float* __restrict__ g_w1,
                                                                      float* __restrict__ g_w2,
-                                                                     float* __restrict__ g_c2w) {
+                                                                     float* __restrict__ g_c2w, int accumulate) {
     const int k = blockIdx.x;
+    if (k >= NRED) {
+        if (threadIdx.x == 0) g_c2w[k - 90] = 0.f;
+        return;
+    }
     float s = 0.f;
     for (int b = threadIdx.x; b < nblocks; b += 256) s += w_partial[(size_t)b * NRED + k];
     s = wave_sum_f(s);
@@ -288,9 +297,9 @@ __global__ void __launch_bounds__(256) decoder_wgrad_reduce_kernel(int nblocks, 
     if (threadIdx.x == 0) {
         const float t = red[0] + red[1] + red[2] + red[3];
         if (k < 72)
-            g_w1[k] = t;
+            g_w1[k] = accumulate ? g_w1[k] + t : t;
         else if (k < 90)
-            g_w2[k - 72] = t;
+            g_w2[k - 72] = accumulate ? g_w2[k - 72] + t : t;
         else if (g_c2w)
             g_c2w[k - 90] = t;
     }
@@ -312,34 +321,37 @@ static int decoder_grid(int P) {
 int mobgs_decoder_bwd_blocks(int P) { return decoder_grid(P); }
 
 int mobgs_decoder_fwd(int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
-                      const float* rays, const float* raycam, const float* w1, const float* w2, float* rgb,
-                      float* depth, void* stream) {
-    if (P < 0 || CF < 9 + (has_depth ? 1 : 0) || (!rays && (!raycam || width <= 0))) {
-        set_error("mobgs_decoder_fwd: bad arguments P=%d CF=%d (rays or raycam+width required)", P, CF);
+                      const float* rays, const float* ray_intr, const float* ray_c2w, const float* w1,
+                      const float* w2, float* rgb, float* depth, void* stream) {
+    if (P < 0 || CF < 9 + (has_depth ? 1 : 0) || (!rays && (!ray_intr || !ray_c2w || width <= 0))) {
+        set_error("mobgs_decoder_fwd: bad arguments P=%d CF=%d (rays or ray_intr+ray_c2w+width required)", P, CF);
         return MOBGS_E_INVALID;
     }
     if (P == 0) return MOBGS_OK;
     int g = (P + DEC_THREADS - 1) / DEC_THREADS;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(decoder_fwd_kernel, dim3(g), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth, width,
-                       feat_hw, alphas, rays, raycam, w1, w2, rgb, depth);
+                       feat_hw, alphas, rays, ray_intr, ray_c2w, w1, w2, rgb, depth);
     return check_launch("decoder_fwd_kernel");
 }
 
 int mobgs_decoder_bwd(int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
-                      const float* rays, const float* raycam, const float* w1, const float* w2, const float* v_rgb,
-                      const float* v_depth, float* v_feat_hw, float* v_alphas, float* v_rays, float* w_partial,
-                      float* g_w1, float* g_w2, float* g_c2w, void* stream) {
-    if (P <= 0 || CF < 9 + (has_depth ? 1 : 0) || (!rays && (!raycam || width <= 0))) {
+                      const float* rays, const float* ray_intr, const float* ray_c2w, const float* w1,
+                      const float* w2, const float* v_rgb, const float* v_depth, float* v_feat_hw, float* v_alphas,
+                      float* v_rays, float* w_partial, float* g_w1, float* g_w2, float* g_c2w, int g_c2w_floats,
+                      int accumulate_wgrad, void* stream) {
+    if (P <= 0 || CF < 9 + (has_depth ? 1 : 0) || (!rays && (!ray_intr || !ray_c2w || width <= 0)) ||
+        (g_c2w && g_c2w_floats != 12 && g_c2w_floats != 16)) {
         set_error("mobgs_decoder_bwd: bad arguments P=%d CF=%d", P, CF);
         return MOBGS_E_INVALID;
     }
     const int g = decoder_grid(P);
     hipLaunchKernelGGL(decoder_bwd_kernel, dim3(g), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth, width,
-                       feat_hw, alphas, rays, raycam, g_c2w ? 1 : 0, w1, w2, v_rgb, v_depth, v_feat_hw, v_alphas,
-                       v_rays, w_partial);
-    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3(NRED), dim3(256), 0, (hipStream_t)stream, g, w_partial, g_w1,
-                       g_w2, g_c2w);
+                       feat_hw, alphas, rays, ray_intr, ray_c2w, g_c2w ? 1 : 0, w1, w2, v_rgb, v_depth, v_feat_hw,
+                       v_alphas, v_rays, w_partial);
+    const int nred = NRED + ((g_c2w && g_c2w_floats == 16) ? 4 : 0);
+    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3(nred), dim3(256), 0, (hipStream_t)stream, g, w_partial, g_w1,
+                       g_w2, g_c2w, accumulate_wgrad);
     return check_launch("decoder_bwd_kernel");
 }
 

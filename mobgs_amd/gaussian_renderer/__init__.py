@@ -111,6 +111,9 @@ def _device_of(pc):
 _time_cache = {}
 
 
+_subframe_times = {}
+
+
 def _times(cam, delta_exposure, dev):
     """[t_feat, t_curve] on the device.  No host->device copy on the hot path (a pageable H2D copy blocks the
     host until the stream drains, which serialises consecutive render() calls): constants are cached per value,
@@ -128,6 +131,19 @@ def _times(cam, delta_exposure, dev):
     if delta_exposure is None:
         return const(cam.time)
     if torch.is_tensor(delta_exposure) and delta_exposure.is_cuda:
+        # train.py hands over exposure_time[k], an element of the view's vector of K offsets: the K time pairs are
+        # computed with ONE set of (4) launches on the whole vector and the element's row is picked from the table
+        base = delta_exposure._base
+        if base is not None and base.dim() == 1 and delta_exposure.dim() == 0 and base.is_contiguous():
+            key = (id(base), float(cam.time), float(cam.max_time))
+            hit = _subframe_times.get(key)
+            if hit is None or hit[0]() is not base or hit[1] != base._version:
+                if len(_subframe_times) > 64:
+                    _subframe_times.clear()
+                t = const(cam.time)[0] + base.detach().to(torch.float32) / cam.max_time
+                hit = (weakref.ref(base), base._version, torch.stack([t, torch.clamp(t, 0.0, 1.0)], dim=1))
+                _subframe_times[key] = hit
+            return hit[2][delta_exposure.storage_offset() - base.storage_offset()]
         t = const(cam.time)[0] + delta_exposure.detach().to(torch.float32).reshape(()) / cam.max_time
         return torch.stack([t, torch.clamp(t, 0.0, 1.0)])
     d = float(delta_exposure)

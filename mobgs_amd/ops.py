@@ -25,27 +25,73 @@ class LeafGradSink:
     tensors into .grad one launch at a time (124 add_ kernels, 0.7 ms of device time per view at 300 k splats).
     Inside the context the prep backward kernel of every render adds its leaf gradients straight into this sink's
     buffers (the first one writes them), and on exit they become the leaves' .grad (or are added to an existing one)
-    -- the same sums in the same order.  Only renders whose inputs are exactly the sets' leaf tensors use the sink."""
+    -- the same sums in the same order.  Only renders whose inputs are exactly the sets' leaf tensors use the sink.
 
-    def __init__(self, stat_pc, dyn_pc):
+    When every leaf already HAS a float32 contiguous .grad on entry (the views of a distributed.FlatGradients buffer
+    after zero()), those tensors are the sink's buffers: the kernels add into .grad itself and nothing is left to do
+    on exit.  The colour decoder's two weight matrices (dyn_pc.rgbdecoder) are handled the same way by the decoder's
+    backward (one fixed-order reduction per render that adds into the buffer instead of 2 add_ launches per render),
+    and `extra` lists further parameters (the BLCE module's) whose custom backward may add into an existing .grad
+    with ONE multi-tensor launch (see `add_into_grads`)."""
+
+    def __init__(self, stat_pc, dyn_pc, extra=()):
         self.leaves = (stat_pc._xyz, stat_pc._scaling, stat_pc._rotation, stat_pc._opacity, stat_pc._features_dc,
                        stat_pc._features_t, dyn_pc.get_control_xyz, dyn_pc._scaling, dyn_pc._rotation, dyn_pc._omega,
                        dyn_pc._opacity, dyn_pc._features_dc, dyn_pc._features_t)
+        dec = getattr(dyn_pc, "rgbdecoder", None)
+        self.dec_leaves = (dec.mlp1.weight, dec.mlp2.weight) if dec is not None else ()
+        self.extra_ids = {id(p) for p in extra}
+        self._extra_keep = tuple(extra)  # keeps the ids valid
         self.buffers = None
+        self.dec_buffers = None
+        self.direct = False
+        self.dec_direct = False
         self._prev = None
 
     def accepts(self, inputs) -> bool:
         return all(a is b and a.is_leaf and a.requires_grad for a, b in zip(inputs, self.leaves))
 
+    @staticmethod
+    def _addable(p) -> bool:
+        g = p.grad
+        return g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape \
+            and not g.requires_grad
+
     def __enter__(self):
         global _active_sink
         self._prev, _active_sink = _active_sink, self
+        if all(self._addable(p) for p in self.leaves):
+            self.buffers = {name: p.grad for p, name in zip(self.leaves, _LEAF_NAMES)}
+            self.direct = True
+        if self.dec_leaves and all(self._addable(p) for p in self.dec_leaves):
+            self.dec_buffers = [p.grad for p in self.dec_leaves]
+            self.dec_direct = True
         return self
+
+    def decoder_buffers(self, w1, w2):
+        """-> (g_w1, g_w2, accumulate) for a decoder backward whose weights are this sink's, else None."""
+        if len(self.dec_leaves) != 2 or w1 is not self.dec_leaves[0] or w2 is not self.dec_leaves[1] or \
+                not (w1.requires_grad and w2.requires_grad):
+            return None
+        if self.dec_buffers is None:
+            self.dec_buffers = [torch.empty(p.shape, dtype=torch.float32, device=p.device) for p in self.dec_leaves]
+            return self.dec_buffers[0], self.dec_buffers[1], 0
+        return self.dec_buffers[0], self.dec_buffers[1], 1
+
+    def add_into_grads(self, params, grads) -> bool:
+        """Custom backward of `params` (all listed in `extra`, all with a float32 .grad): .grad += grads in one
+        multi-tensor launch; the caller then returns None for them.  False: not applicable, return them normally."""
+        if not params or not all(id(p) in self.extra_ids and self._addable(p) for p in params):
+            return False
+        torch._foreach_add_([p.grad for p in params], list(grads))
+        return True
 
     def __exit__(self, *exc):
         global _active_sink
         _active_sink = self._prev
-        if self.buffers is not None and exc[0] is None:
+        if exc[0] is not None:
+            return False
+        if self.buffers is not None and not self.direct:
             for p, name in zip(self.leaves, _LEAF_NAMES):
                 g = self.buffers[name].view_as(p)
                 if g.dtype != p.dtype:  # fp16 attribute storage: accumulated in fp32, handed over in the leaf's dtype
@@ -54,7 +100,18 @@ class LeafGradSink:
                     p.grad = g
                 else:
                     p.grad.add_(g)
+        if self.dec_buffers is not None and not self.dec_direct:
+            for p, g in zip(self.dec_leaves, self.dec_buffers):
+                g = g.to(p.dtype)
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
         return False
+
+
+def active_sink():
+    return _active_sink
 
 
 class PrepSplats(torch.autograd.Function):
@@ -143,9 +200,6 @@ class PrepSplats(torch.autograd.Function):
                 g["d_ft"], None)
 
 
-_raycam_cache = _lib.DerivedCache()
-
-
 class Decode(torch.autograd.Function):
     """Channels-last compositor image (+alpha) -> planar rgb [3,H,W] (+ expected depth [H,W]).
     Rays: either the reference's map `rays` [6,H,W], or (rays=None) the pinhole parameters `intr` = [fx,fy,cx,cy]
@@ -154,21 +208,25 @@ class Decode(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat_hw, alphas, rays, intr, c2w, w1, w2, has_depth: bool):
         lib = _lib.load()
+        ctx.set_materialize_grads(False)  # an unused depth output costs no zero image in backward
+        ctx.w_inputs = (w1, w2)  # the caller's tensor objects (a LeafGradSink recognises its weights by identity)
         feat_hw, w1, w2 = map(f32c, (feat_hw, w1, w2))
         H, W, CF = feat_hw.shape[-3:]
         P = H * W
         dev = feat_hw.device
         alphas_c = f32c(alphas) if alphas is not None else None
         rays_c = f32c(rays) if rays is not None else None
-        raycam = None
-        if rays_c is None:
-            raycam = _raycam_cache.get((intr, c2w), lambda: torch.cat([f32c(intr.detach()).reshape(4),
-                                                                       f32c(c2w.detach()).reshape(12)]))
+        intr_c = c2w_c = None
+        if rays_c is None:  # pinhole parameters: the kernel reads the 4 intrinsics and the first 12 pose entries
+            intr_c, c2w_c = f32c(intr.detach()), f32c(c2w.detach())
+            if intr_c.numel() != 4 or c2w_c.numel() not in (12, 16):
+                raise ValueError("decode: intr must be [fx, fy, cx, cy] and c2w a [3,4] or [4,4] camera-to-world matrix")
         rgb = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(H, W, dtype=torch.float32, device=dev) if has_depth else None
-        check(lib.mobgs_decoder_fwd(P, CF, int(has_depth), W, ptr(feat_hw), ptr(alphas_c), ptr(rays_c), ptr(raycam),
-                                    ptr(w1), ptr(w2), ptr(rgb), ptr(depth), stream()), "mobgs_decoder_fwd")
-        ctx.save_for_backward(feat_hw, alphas_c, rays_c, raycam, w1, w2)
+        check(lib.mobgs_decoder_fwd(P, CF, int(has_depth), W, ptr(feat_hw), ptr(alphas_c), ptr(rays_c), ptr(intr_c),
+                                    ptr(c2w_c), ptr(w1), ptr(w2), ptr(rgb), ptr(depth), stream()),
+              "mobgs_decoder_fwd")
+        ctx.save_for_backward(feat_hw, alphas_c, rays_c, intr_c, c2w_c, w1, w2)
         ctx.has_depth = has_depth
         ctx.rays_need_grad = rays is not None and ctx.needs_input_grad[2]
         ctx.c2w_needs_grad = rays is None and ctx.needs_input_grad[4]
@@ -180,7 +238,9 @@ class Decode(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_rgb, v_depth):
         lib = _lib.load()
-        feat_hw, alphas, rays, raycam, w1, w2 = ctx.saved_tensors
+        feat_hw, alphas, rays, intr, c2w, w1, w2 = ctx.saved_tensors
+        if v_rgb is None and v_depth is None:
+            return (None,) * 8
         H, W, CF = feat_hw.shape[-3:]
         P = H * W
         dev = feat_hw.device
@@ -190,22 +250,28 @@ class Decode(torch.autograd.Function):
         v_feat = torch.empty(ctx.feat_shape, dtype=torch.float32, device=dev)
         v_alphas = torch.empty(alphas.shape, dtype=torch.float32, device=dev) if has_depth else None
         v_rays = torch.empty_like(rays) if ctx.rays_need_grad else None
-        g_c2w = torch.empty(3, 4, dtype=torch.float32, device=dev) if ctx.c2w_needs_grad else None
+        g_c2w = torch.empty_like(c2w) if ctx.c2w_needs_grad else None  # [3,4] or [4,4] like the input
         nb = lib.mobgs_decoder_bwd_blocks(P)
         partial = torch.empty(nb, 102, dtype=torch.float32, device=dev)
-        g_w1 = torch.empty_like(w1)
-        g_w2 = torch.empty_like(w2)
-        check(lib.mobgs_decoder_bwd(P, CF, int(has_depth), W, ptr(feat_hw), ptr(alphas), ptr(rays), ptr(raycam),
-                                    ptr(w1), ptr(w2), ptr(v_rgb), ptr(v_depth), ptr(v_feat), ptr(v_alphas),
-                                    ptr(v_rays), ptr(partial), ptr(g_w1), ptr(g_w2), ptr(g_c2w), stream()),
+        sunk = _active_sink.decoder_buffers(*ctx.w_inputs) if _active_sink is not None else None
+        if sunk is not None:
+            g_w1, g_w2, accumulate = sunk
+        else:
+            g_w1, g_w2, accumulate = torch.empty_like(w1), torch.empty_like(w2), 0
+        check(lib.mobgs_decoder_bwd(P, CF, int(has_depth), W, ptr(feat_hw), ptr(alphas), ptr(rays), ptr(intr),
+                                    ptr(c2w), ptr(w1), ptr(w2), ptr(v_rgb), ptr(v_depth), ptr(v_feat), ptr(v_alphas),
+                                    ptr(v_rays), ptr(partial), ptr(g_w1), ptr(g_w2), ptr(g_c2w),
+                                    g_c2w.numel() if g_c2w is not None else 0, accumulate, stream()),
               "mobgs_decoder_bwd")
+        if sunk is not None:
+            return v_feat, v_alphas, v_rays, None, g_c2w, None, None, None
         return v_feat, v_alphas, v_rays, None, g_c2w, g_w1, g_w2, None
 
 
 def decode(feat_hw: Tensor, alphas: Optional[Tensor], rays, w1: Tensor, w2: Tensor, has_depth: bool):
     """feat_hw [..,H,W,CF>=9(+1)], alphas [..,H,W] or [..,H,W,1] -> rgb [3,H,W], depth [H,W]|None.
-    `rays`: the reference's cam_ray map [1,6,H,W], or a pair (intr [4] = fx,fy,cx,cy, c2w [3,4]) to have the kernel
-    generate the pinhole rays itself."""
+    `rays`: the reference's cam_ray map [1,6,H,W], or a pair (intr [4] = fx,fy,cx,cy, c2w [3,4] or [4,4]) to have
+    the kernel generate the pinhole rays itself."""
     H, W = feat_hw.shape[-3], feat_hw.shape[-2]
     if feat_hw.numel() != H * W * feat_hw.shape[-1]:
         raise NotImplementedError("decoder batch size must be 1 (as in every reference call)")

@@ -55,10 +55,12 @@ def test_blurry_view_k9_blce_matches_reference_fixture(hip_device, blce_mode):
     T = lambda k: torch.from_numpy(fx[k]).to(dev)  # noqa: E731
     for rep in range(2):  # the second pass replays the captured graph
         for p in list(leaf_map(stat, dyn).values()) + list(kern.model.parameters()):
-            p.grad = None
+            # second pass: zero gradients already in place (what distributed.FlatGradients.zero() leaves) -- every
+            # backward kernel then ADDS into .grad itself (leaves, decoder weights, BLCE parameters)
+            p.grad = None if rep == 0 else torch.zeros_like(p)
         pred, mids = render_blurry_batch([cam], stat, dyn, bg, SubframeShard(1, 0), blce=kern, n_sub=9)
         mid = mids[0]
-        with LeafGradSink(stat, dyn):
+        with LeafGradSink(stat, dyn, extra=kern.model.get_params()):
             ((pred[0] * T("cot_v_pred")).sum() + (mid["depth"] * T("cot_v_depth")).sum()
              + (mid["d_alpha"] * T("cot_v_depth")).sum()).backward()
     g = kern._graphed.get(idx)
@@ -118,7 +120,7 @@ def _iteration(dev, shard, fx_name="blurry_view", n_views=2):
     loss = (pred * v_pred).sum() + shard.replicated_term(reg)
     for v, pkg in mids.items():
         loss = loss + (pkg["depth"] * v_depth).sum() + 0.5 * (pkg["d_alpha"] * v_depth).sum()
-    with LeafGradSink(stat, dyn):
+    with LeafGradSink(stat, dyn, extra=kern.model.get_params()):
         loss.backward()
     for v, pkg in mids.items():
         shard.put_densification_stats(bucket, f"view{v}", pkg["viewspace_points"].grad, pkg["radii"])
