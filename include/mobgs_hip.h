@@ -53,8 +53,10 @@ extern "C" {
 /* Library identification.  Returns e.g. "mobgs_hip 0.1 gfx950". */
 /* Per-call policy of the binning / compositing entry points.  The library keeps NO mutable state: what used to be
  * process-wide setters travels with each call (host pointer, may be NULL = all defaults; a negative field = default).
- *   heavy_tile_len     scheduling: a tile whose list has at least this many entries (at most an eighth of the tiles)
- *                      is composited by a whole workgroup, one 8x8 quadrant per wave.  Default 1024; 0 = never.
+ *   heavy_tile_len     scheduling: a tile whose list has at least this many entries is composited by a whole
+ *                      workgroup, one 8x8 quadrant per wave -- for at most an eighth of the tiles, or, on grids of
+ *                      fewer than 4096 tiles, as many as bring the launch to 4096 waves (small images cannot fill
+ *                      the chip with one wave per tile).  Default 1024 (1 on grids below 4096 tiles); 0 = never.
  *   longest_list_hint  the longest per-tile list the caller expects (e.g. the previous frame's stats[2]): >= 2048
  *                      makes mobgs_isect_offsets rank through LDS first (dense image regions).  Default 0.
  *   quadrant_culling   testing aid, default 1: the compositors skip, per list entry, the 8x8 quadrants of the tile
@@ -115,7 +117,7 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
  *      tile_order [mobgs_tile_order_len(C*n_tiles)] (may be NULL) the schedule of the compositing kernels, 4
  *                slots per workgroup: tile ids by descending list length (1024 length classes; longest lists
  *                first, lists of similar length share a workgroup), -1 = unused slot.  Tiles whose list is at
- *                least MobgsTuning.heavy_tile_len long (at most an eighth of the tiles) appear as id | 1<<30 in
+ *                least MobgsTuning.heavy_tile_len long (capped, see there) appear as id | 1<<30 in
  *                the 4 slots of one workgroup, whose 4 waves then composite one 8x8 quadrant each.  A schedule
  *                only -- images do not depend on it; the compositing entry points accept NULL for raster order.
  *      stats int64[3] = {I_box, I_listed, longest per-tile list}; the caller reads them back to size the list

@@ -983,9 +983,10 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
                                 int32_t* keep_scan, int32_t* tile_offsets, int32_t* tile_order, int64_t capacity_listed,
                                 int64_t* stats, void* scratch, bool scratch_zeroed, int64_t* stats_mirror,
                                 int64_t stats_seq, const MobgsTuning* tuning, void* stream) {
-    const int heavy_len = tuning_heavy_len(tuning), dense_hint = tuning_list_hint(tuning);
     const long long ng = (long long)C * N;
     const long long nt = (long long)C * tile_w * tile_h;
+    const int heavy_len = tuning_heavy_len(tuning, (int)(nt < (1ll << 30) ? nt : (1ll << 30)));
+    const int dense_hint = tuning_list_hint(tuning);
     if (C <= 0 || N < 0 || capacity < 1 || ng >= (1ll << 31) - 1 || nt >= (1ll << 31) - 1) {
         set_error("mobgs_isect_offsets: bad sizes C=%d N=%d tiles=%dx%d capacity=%d", C, N, tile_w, tile_h, capacity);
         return MOBGS_E_INVALID;

@@ -180,7 +180,9 @@ def test_tile_culling_is_bit_exact(hip_device, mode, channels):
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     for k in names:  # same terms; the per-splat slot sum associates them differently once the zero slots are gone
         g = res[False][2][k]
-        _close(res[True][2][k], g, 1e-5, 1e-6 * float(g.abs().max()), f"grad[{k}] under culling")
+        # (1e-5 of the largest entry: on a grid this small every tile is composited quadrant-per-wave, and the four
+        # quadrant records of an entry are summed per splat in slot order, which culling changes)
+        _close(res[True][2][k], g, 1e-5, 1e-5 * float(g.abs().max()), f"grad[{k}] under culling")
     n_full, n_cull = res[False][3].numel(), res[True][3].numel()
     assert n_cull < 0.8 * n_full, (n_cull, n_full)
     # per tile: the culled list is a sub-sequence (same order) of the full list
@@ -252,11 +254,14 @@ def test_counts_reach_the_host_without_an_event(hip_device):
 def test_tile_schedule_is_a_permutation_and_changes_nothing(hip_device):
     """TileLists.tile_order: every tile exactly once, list lengths non-increasing up to the width of one length
     class; images and gradients are bit-identical with the schedule on or off (it only reorders workgroups)."""
-    from mobgs_amd import rendering
+    import sys
+    from mobgs_amd import _lib, rendering
     n, w, h = 6000, 200, 152
     s, _ = _scene(n, w, h, 21, 9)
     names = ["means", "quats", "scales", "opacities", "colors", "viewmats"]
     res = {}
+    old_heavy = rendering.tuning.heavy_tile_len
+    rendering.tuning.heavy_tile_len = 0  # a pure permutation: no workgroup-per-tile splitting (its own test below)
     for sched in (False, True):
         rendering.TILE_SCHEDULE = sched
         try:
@@ -273,10 +278,10 @@ def test_tile_schedule_is_a_permutation_and_changes_nothing(hip_device):
                 off = sp.tl.tile_offsets.cpu()
                 lens = (off[1:] - off[:-1])
                 slots = sp.tl.tile_order.cpu().long()
-                assert slots.numel() == lens.numel() + 3 * (lens.numel() // 8) + 4
+                assert slots.numel() == _lib.load().mobgs_tile_order_len(lens.numel()) >= lens.numel() + 4
                 used = slots[slots >= 0]
                 heavy = (used & (1 << 30)) != 0
-                assert not bool(heavy.any())  # no list of this scene reaches the default heavy length
+                assert not bool(heavy.any())
                 order = used
                 assert sorted(order.tolist()) == list(range(lens.numel()))
                 assert bool((slots[:lens.numel()] >= 0).all()) and bool((slots[lens.numel():] < 0).all())
@@ -288,6 +293,8 @@ def test_tile_schedule_is_a_permutation_and_changes_nothing(hip_device):
                 assert sp.tl.tile_order is None
         finally:
             rendering.TILE_SCHEDULE = True
+            if sched or sys.exc_info()[0] is not None:
+                rendering.tuning.heavy_tile_len = old_heavy
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     for k in res[False][2]:
         assert torch.equal(res[True][2][k], res[False][2][k]), k
@@ -441,8 +448,9 @@ def test_heavy_tiles_are_split_over_a_workgroup(hip_device):
     res = {}
     old = rendering.tuning.heavy_tile_len
     try:
-        for mode in ("heavy", "light", "raster"):
-            rendering.tuning.heavy_tile_len = 48 if mode == "heavy" else 0
+        thr = 48
+        for mode in ("light", "heavy", "raster"):
+            rendering.tuning.heavy_tile_len = thr if mode == "heavy" else 0
             rendering.TILE_SCHEDULE = mode != "raster"
             t = {k: v.to(hip_device).clone().requires_grad_(k in names) for k, v in s.items()}
             sp = rendering.SharedProjection(t["means"], t["quats"], t["scales"], t["opacities"], t["viewmats"],
@@ -452,6 +460,10 @@ def test_heavy_tiles_are_split_over_a_workgroup(hip_device):
             v_img = torch.randn(img.shape, generator=g).to(hip_device)
             ((img * v_img).sum() + a.sum()).backward()
             res[mode] = (img.detach().cpu(), a.detach().cpu(), {k: t[k].grad.cpu() for k in names if t[k].grad is not None})
+            if mode == "light":  # threshold for the heavy run: about the longest eighth of this scene's lists
+                off = sp.tl.tile_offsets.cpu()
+                lens = (off[1:] - off[:-1])
+                thr = max(48, int(lens.sort().values[-max(lens.numel() // 8, 1)]))
             if mode == "heavy":
                 off = sp.tl.tile_offsets.cpu()
                 lens = (off[1:] - off[:-1])
@@ -459,14 +471,16 @@ def test_heavy_tiles_are_split_over_a_workgroup(hip_device):
                 used = slots[slots >= 0]
                 hv = (used & (1 << 30)) != 0
                 n_heavy = int(hv.sum()) // 4
-                assert 0 < n_heavy <= lens.numel() // 8, n_heavy
+                nt = lens.numel()  # a grid this small may go heavy up to 4096 waves in total (include/mobgs_hip.h)
+                assert 0 < n_heavy <= max(nt // 8, min(nt, (4096 - nt) // 3)), n_heavy
+                assert 0 < int((~hv).sum()), "the scene must keep some light tiles for the checks below"
                 head = slots[:4 * n_heavy].reshape(n_heavy, 4)
                 assert bool((head == head[:, :1]).all()) and bool(((head & (1 << 30)) != 0).all())
                 heavy_tiles = (head[:, 0] & ~(1 << 30))
                 light_tiles = used[~hv]
                 assert sorted(heavy_tiles.tolist() + light_tiles.tolist()) == list(range(lens.numel()))
                 assert int(lens[heavy_tiles].min()) >= int(lens[light_tiles].max()) - (int(lens.max()) // 1023 + 1)
-                assert int(lens[heavy_tiles].min()) >= 48 - (int(lens.max()) // 1023 + 1)
+                assert int(lens[heavy_tiles].min()) >= thr - (int(lens.max()) // 1023 + 1)
     finally:
         rendering.tuning.heavy_tile_len = old
         rendering.TILE_SCHEDULE = True
@@ -508,3 +522,40 @@ def test_zero_cotangent_pixels_are_skipped_exactly(hip_device):
     zero = grads(torch.zeros_like(v_img), torch.zeros_like(v_a))
     for k in names:
         assert float(zero[k].abs().max()) == 0.0, k
+
+
+def test_small_grids_go_heavy_by_default(hip_device):
+    """A grid with fewer tiles than the chip has wave slots (512x288, the reference's training resolution: 576 tiles)
+    is scheduled workgroup-per-tile by default -- every non-empty tile, up to 4096 waves in total; images are
+    bit-identical to the one-wave-per-tile schedule, gradients equal up to the summation order of the quadrants."""
+    from mobgs_amd import rendering
+    n, w, h = 20000, 512, 288
+    s, _ = _scene(n, w, h, 33, 9)
+    names = ["means", "quats", "scales", "opacities", "colors", "viewmats"]
+    res = {}
+    old = rendering.tuning.heavy_tile_len
+    try:
+        for mode, knob in (("default", -1), ("light", 0)):
+            rendering.tuning.heavy_tile_len = knob
+            t = {k: v.to(hip_device).clone().requires_grad_(k in names) for k, v in s.items()}
+            sp = rendering.SharedProjection(t["means"], t["quats"], t["scales"], t["opacities"], t["viewmats"],
+                                            t["Ks"], w, h)
+            img, a = sp.composite(t["colors"])
+            g = torch.Generator().manual_seed(7)
+            ((img * torch.randn(img.shape, generator=g).to(hip_device)).sum() + a.sum()).backward()
+            res[mode] = (img.detach().cpu(), a.detach().cpu(), {k: t[k].grad.cpu() for k in names})
+            slots = sp.tl.tile_order.cpu().long()
+            used = slots[slots >= 0]
+            n_heavy = int(((used & (1 << 30)) != 0).sum()) // 4
+            off = sp.tl.tile_offsets.cpu()
+            lens = off[1:] - off[:-1]
+            if mode == "default":
+                assert lens.numel() == 32 * 18 and n_heavy == int((lens > 0).sum()) > 500, (n_heavy, lens.numel())
+            else:
+                assert n_heavy == 0
+    finally:
+        rendering.tuning.heavy_tile_len = old
+    assert torch.equal(res["default"][0], res["light"][0]) and torch.equal(res["default"][1], res["light"][1])
+    for k, ref in res["light"][2].items():
+        tol = 2e-5 * float(ref.abs().max()) + 1e-9
+        assert float((res["default"][2][k] - ref).abs().max()) <= tol, k
