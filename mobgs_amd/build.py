@@ -15,6 +15,9 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(os.environ["MOBGS_LIB"]).resolve() if os.environ.get("MOBGS_LIB") else CSRC / "libmobgs_hip.so"
 SOURCES = ["project.hip", "isect.hip", "raster.hip", "raster_layers.hip", "pipeline.hip", "prep.hip", "decoder.hip", "deform.hip", "deform_bwd.hip", "hexplane_bwd.hip", "blce.hip", "loss.hip", "densify.hip", "normals.hip"]
 ARCH = "gfx950"
+# host fast path (csrc/fastpath.cpp): a plain C++ torch extension, no device code, no link against libmobgs_hip.so
+FAST_SRC = CSRC / "fastpath.cpp"
+FAST_PATH = CSRC.parent / "_mobgs_fast.so"
 # Per-file extra flags.  -fno-slp-vectorize: the SLP vectoriser pairs independent fp32 FMAs into v_pk_fma_f32,
 # which on gfx950 issues at half rate (no gain) and needs v_mov shuffles to build the 64-bit operand pairs:
 # +6% renders/s on the compositing kernels without it (measured).
@@ -75,6 +78,39 @@ def build_extension(force: bool = False, verbose: bool = False) -> Path:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     return LIB_PATH
+
+
+def fastpath_is_stale() -> bool:
+    if not FAST_PATH.exists():
+        return True
+    t = FAST_PATH.stat().st_mtime
+    deps = [FAST_SRC, CSRC.parent.parent / "include" / "mobgs_hip.h"]
+    return any(d.exists() and d.stat().st_mtime > t for d in deps)
+
+
+def build_fastpath(force: bool = False, verbose: bool = False) -> Path:
+    """g++ -shared against the installed libtorch (~30 s).  Needs no GPU and no hipcc."""
+    if not force and not fastpath_is_stale():
+        return FAST_PATH
+    import sysconfig
+
+    import torch
+    import torch.utils.cpp_extension as ce
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("no C++ compiler found: cannot build the host fast path")
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [cxx, "-O2", "-std=c++17", "-shared", "-fPIC", str(FAST_SRC), "-o", str(FAST_PATH),
+           "-DTORCH_EXTENSION_NAME=_mobgs_fast", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           "-I" + sysconfig.get_paths()["include"], *["-I" + i for i in ce.include_paths()],
+           "-L" + libdir, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python", "-Wl,-rpath," + libdir,
+           "-Wno-unused-function"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"host fast path: compile failed:\n{r.stdout[-4000:]}")
+    return FAST_PATH
 
 
 if __name__ == "__main__":

@@ -1,0 +1,311 @@
+// Host fast path: the bodies of the hot autograd nodes (allocate outputs, gather pointers, ONE C-ABI call) in C++.
+//
+// At the reference's own operating point (512x288, a few ten thousand splats) a render() step is bound by the host,
+// not the device: the kernels of a forward + backward sum to ~0.33 ms while the Python bodies of the eight autograd
+// nodes -- ~45 torch.empty calls, ~145 pointer conversions and 17 ctypes calls with 20-40 arguments each -- take
+// ~0.45 ms.  This module runs the same bodies natively (at::empty ~0.3 us, no per-argument marshalling).  It launches
+// nothing itself: every function ends in the same include/mobgs_hip.h entry point the Python body calls, so the two
+// are interchangeable (tests/test_gpu_fastpath.py compares them bit for bit) and the Python bodies remain the
+// specification.
+//
+// No HIP or libmobgs_hip.so symbols at link time: bind() receives the entry points' addresses from the ctypes handle
+// (so MOBGS_LIB builds are honoured) and every call receives the raw current stream as an integer.
+#include <torch/extension.h>
+
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mobgs_hip.h"
+
+namespace {
+
+using at::Tensor;
+using OptT = c10::optional<Tensor>;
+
+struct Api {
+    decltype(&mobgs_last_error) last_error = nullptr;
+    decltype(&mobgs_record_stride) record_stride = nullptr;
+    decltype(&mobgs_prep_fwd) prep_fwd = nullptr;
+    decltype(&mobgs_prep_fwd_f16) prep_fwd_f16 = nullptr;
+    decltype(&mobgs_prep_bwd) prep_bwd = nullptr;
+    decltype(&mobgs_prep_bwd_f16) prep_bwd_f16 = nullptr;
+    decltype(&mobgs_raster_fwd) raster_fwd = nullptr;
+    decltype(&mobgs_raster_bwd) raster_bwd = nullptr;
+    decltype(&mobgs_raster_bwd_reduce) raster_bwd_reduce = nullptr;
+    decltype(&mobgs_decoder_fwd) decoder_fwd = nullptr;
+    decltype(&mobgs_decoder_bwd) decoder_bwd = nullptr;
+    decltype(&mobgs_decoder_bwd_blocks) decoder_bwd_blocks = nullptr;
+    decltype(&mobgs_project_bwd) project_bwd = nullptr;
+    decltype(&mobgs_project_bwd_scratch_floats) project_bwd_scratch_floats = nullptr;
+    bool bound = false;
+} api;
+
+template <typename F>
+void take(const std::unordered_map<std::string, uint64_t>& m, const char* name, F& slot) {
+    auto it = m.find(name);
+    if (it == m.end() || it->second == 0) throw std::runtime_error(std::string("mobgs fastpath: missing symbol ") + name);
+    slot = reinterpret_cast<F>(static_cast<uintptr_t>(it->second));
+}
+
+void bind(const std::unordered_map<std::string, uint64_t>& m) {
+    take(m, "mobgs_last_error", api.last_error);
+    take(m, "mobgs_record_stride", api.record_stride);
+    take(m, "mobgs_prep_fwd", api.prep_fwd);
+    take(m, "mobgs_prep_fwd_f16", api.prep_fwd_f16);
+    take(m, "mobgs_prep_bwd", api.prep_bwd);
+    take(m, "mobgs_prep_bwd_f16", api.prep_bwd_f16);
+    take(m, "mobgs_raster_fwd", api.raster_fwd);
+    take(m, "mobgs_raster_bwd", api.raster_bwd);
+    take(m, "mobgs_raster_bwd_reduce", api.raster_bwd_reduce);
+    take(m, "mobgs_decoder_fwd", api.decoder_fwd);
+    take(m, "mobgs_decoder_bwd", api.decoder_bwd);
+    take(m, "mobgs_decoder_bwd_blocks", api.decoder_bwd_blocks);
+    take(m, "mobgs_project_bwd", api.project_bwd);
+    take(m, "mobgs_project_bwd_scratch_floats", api.project_bwd_scratch_floats);
+    api.bound = true;
+}
+
+void check(int rc, const char* what) {
+    if (rc != 0) {
+        const char* msg = api.last_error ? api.last_error() : "";
+        throw std::runtime_error(std::string(what) + " failed (code " + std::to_string(rc) + "): " + msg);
+    }
+}
+
+// device pointer of a contiguous HIP tensor; the product path has no CPU fallback
+inline void* dp(const Tensor& t) {
+    if (!t.is_cuda()) throw std::runtime_error("mobgs_amd: tensors must live on a HIP device (device='cuda'); there is no CPU path");
+    if (!t.is_contiguous()) throw std::runtime_error("mobgs_amd: internal error, non-contiguous tensor passed to the C ABI");
+    return t.data_ptr();
+}
+inline void* dp(const OptT& t) { return (t.has_value() && t->defined()) ? dp(*t) : nullptr; }
+inline const float* fp(const Tensor& t) { return static_cast<const float*>(dp(t)); }
+inline const float* fp(const OptT& t) { return static_cast<const float*>(dp(t)); }
+inline float* fpw(const Tensor& t) { return static_cast<float*>(dp(t)); }
+inline float* fpw(const OptT& t) { return static_cast<float*>(dp(t)); }
+inline const int32_t* ip(const Tensor& t) { return static_cast<const int32_t*>(dp(t)); }
+inline const int32_t* ip(const OptT& t) { return static_cast<const int32_t*>(dp(t)); }
+
+// float32 + contiguous (no copy when already so)
+inline Tensor f32c(const Tensor& t) {
+    if (t.scalar_type() == at::kFloat && t.is_contiguous()) return t;
+    return t.to(at::kFloat).contiguous();
+}
+inline OptT f32c(const OptT& t) { return (t.has_value() && t->defined()) ? OptT(f32c(*t)) : OptT(); }
+
+inline void* sp(int64_t stream) { return reinterpret_cast<void*>(static_cast<uintptr_t>(stream)); }
+inline const MobgsTuning* tp(int64_t tuning) {
+    return reinterpret_cast<const MobgsTuning*>(static_cast<uintptr_t>(tuning));
+}
+
+// ---- ops.PrepSplats ------------------------------------------------------------------------------------------------
+// attrs: s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_scaling, d_rotation, d_omega, d_opacity, d_fdc, d_ft
+// -> (means, quats, scales, opac, colors, times, d_ncp, d_trbf, n_conversions); the last four are what backward saves
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, int64_t>
+prep_fwd(const Tensor& times_in, const Tensor& s_xyz_in, const Tensor& d_control_in, const Tensor& d_ncp_in,
+         const Tensor& d_trbf_in, const std::vector<Tensor>& attrs_in, bool half, int64_t stream) {
+    if (attrs_in.size() != 11) throw std::runtime_error("prep_fwd: 11 attribute arrays expected");
+    const Tensor times = f32c(times_in), s_xyz = f32c(s_xyz_in), d_control = f32c(d_control_in),
+                 d_trbf = f32c(d_trbf_in);
+    const Tensor d_ncp = (d_ncp_in.scalar_type() == at::kLong && d_ncp_in.is_contiguous())
+                             ? d_ncp_in : d_ncp_in.to(at::kLong).contiguous();
+    const auto want = half ? at::kHalf : at::kFloat;
+    int64_t conversions = 0;
+    Tensor a[11];
+    for (int i = 0; i < 11; ++i) {
+        a[i] = attrs_in[i];
+        if (a[i].scalar_type() != want) {
+            a[i] = a[i].to(want);
+            ++conversions;
+        }
+        if (!a[i].is_contiguous()) a[i] = a[i].contiguous();
+    }
+    const int64_t Ns = s_xyz.size(0), Nd = d_control.size(0), N = Ns + Nd;
+    const auto opt = times.options().dtype(at::kFloat);
+    Tensor means = at::empty({N, 3}, opt), quats = at::empty({N, 4}, opt), scales = at::empty({N, 3}, opt),
+           opac = at::empty({N}, opt), colors = at::empty({N, 9}, opt);
+    if (half) {
+        auto h = [](const Tensor& t) { return static_cast<const uint16_t*>(dp(t)); };
+        check(api.prep_fwd_f16((int)Ns, (int)Nd, fp(times), fp(s_xyz), h(a[0]), h(a[1]), h(a[2]), h(a[3]), h(a[4]),
+                               fp(d_control), static_cast<const int64_t*>(dp(d_ncp)), h(a[5]), h(a[6]), h(a[7]),
+                               h(a[8]), h(a[9]), h(a[10]), fp(d_trbf), fpw(means), fpw(quats), fpw(scales),
+                               fpw(opac), fpw(colors), sp(stream)),
+              "mobgs_prep_fwd");
+    } else {
+        check(api.prep_fwd((int)Ns, (int)Nd, fp(times), fp(s_xyz), fp(a[0]), fp(a[1]), fp(a[2]), fp(a[3]), fp(a[4]),
+                           fp(d_control), static_cast<const int64_t*>(dp(d_ncp)), fp(a[5]), fp(a[6]), fp(a[7]),
+                           fp(a[8]), fp(a[9]), fp(a[10]), fp(d_trbf), fpw(means), fpw(quats), fpw(scales), fpw(opac),
+                           fpw(colors), sp(stream)),
+              "mobgs_prep_fwd");
+    }
+    return {means, quats, scales, opac, colors, times, d_ncp, d_trbf, conversions};
+}
+
+// g: the 13 gradient buffers in ops._LEAF_NAMES order (a sink's), or empty -> allocated here (attribute gradients as
+// halves when g_half).  Returns the 13 buffers.
+std::vector<Tensor> prep_bwd(int64_t Ns, int64_t Nd, const Tensor& times, const Tensor& d_ncp, const Tensor& d_trbf,
+                             const Tensor& scales, const Tensor& opac, const OptT& v_means, const OptT& v_quats,
+                             const OptT& v_scales, const OptT& v_opac, const OptT& v_colors, std::vector<Tensor> g,
+                             bool g_half, int64_t accumulate, int64_t stream) {
+    if (g.empty()) {
+        const auto f = times.options().dtype(at::kFloat);
+        const auto a = times.options().dtype(g_half ? at::kHalf : at::kFloat);
+        g = {at::empty({Ns, 3}, f), at::empty({Ns, 3}, a), at::empty({Ns, 4}, a), at::empty({Ns, 1}, a),
+             at::empty({Ns, 6}, a), at::empty({Ns, 3}, a), at::empty({Nd, 12, 3}, f), at::empty({Nd, 3}, a),
+             at::empty({Nd, 4}, a), at::empty({Nd, 4}, a), at::empty({Nd, 1}, a), at::empty({Nd, 6}, a),
+             at::empty({Nd, 3}, a)};
+    } else if (g.size() != 13) {
+        throw std::runtime_error("prep_bwd: 13 gradient buffers expected");
+    }
+    const OptT c0 = f32c(v_means), c1 = f32c(v_quats), c2 = f32c(v_scales), c3 = f32c(v_opac), c4 = f32c(v_colors);
+    if (g_half) {
+        auto h = [](const Tensor& t) { return static_cast<uint16_t*>(dp(t)); };
+        check(api.prep_bwd_f16((int)Ns, (int)Nd, fp(times), static_cast<const int64_t*>(dp(d_ncp)), fp(d_trbf),
+                               fp(scales), fp(opac), fp(c0), fp(c1), fp(c2), fp(c3), fp(c4), fpw(g[0]), h(g[1]),
+                               h(g[2]), h(g[3]), h(g[4]), h(g[5]), fpw(g[6]), h(g[7]), h(g[8]), h(g[9]), h(g[10]),
+                               h(g[11]), h(g[12]), (int)accumulate, sp(stream)),
+              "mobgs_prep_bwd");
+    } else {
+        check(api.prep_bwd((int)Ns, (int)Nd, fp(times), static_cast<const int64_t*>(dp(d_ncp)), fp(d_trbf),
+                           fp(scales), fp(opac), fp(c0), fp(c1), fp(c2), fp(c3), fp(c4), fpw(g[0]), fpw(g[1]),
+                           fpw(g[2]), fpw(g[3]), fpw(g[4]), fpw(g[5]), fpw(g[6]), fpw(g[7]), fpw(g[8]), fpw(g[9]),
+                           fpw(g[10]), fpw(g[11]), fpw(g[12]), (int)accumulate, sp(stream)),
+              "mobgs_prep_bwd");
+    }
+    return g;
+}
+
+// ---- rendering._Rasterize ------------------------------------------------------------------------------------------
+// One compositing launch.  records / reach: pass the tensors to (re)use, or None to have them allocated.
+// -> (records, render [C,H,W,D], alphas [C,H,W], last_ids, reach)
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor>
+raster_fwd(int64_t C, int64_t N, int64_t channels, int64_t width, int64_t height, const Tensor& means2d,
+           const Tensor& conics, const OptT& colors, int64_t colors_per_camera, const Tensor& opacities,
+           int64_t opac_per_camera, const OptT& extra, const OptT& bg, const Tensor& radii, const Tensor& tile_offsets,
+           const OptT& tile_order, const Tensor& flatten_arena, const OptT& records_in, const OptT& reach_in,
+           int64_t tuning, int64_t stream) {
+    const bool has_extra = extra.has_value() && extra->defined();
+    const int64_t D = channels + (has_extra ? 1 : 0);
+    const auto f = means2d.options().dtype(at::kFloat);
+    Tensor records = (records_in.has_value() && records_in->defined())
+                         ? *records_in : at::empty({C * N, (int64_t)api.record_stride((int)D)}, f);
+    const int64_t arena = std::max<int64_t>(flatten_arena.numel(), 1);
+    Tensor reach = (reach_in.has_value() && reach_in->defined() && reach_in->numel() >= flatten_arena.numel())
+                       ? *reach_in : at::empty({arena}, f.dtype(at::kByte));
+    Tensor render = at::empty({C, height, width, D}, f), alphas = at::empty({C, height, width}, f),
+           last_ids = at::empty({C, height, width}, f.dtype(at::kInt));
+    check(api.raster_fwd((int)C, (int)N, (int)channels, (int)width, (int)height, fp(means2d), fp(conics), fp(colors),
+                         (int)colors_per_camera, fp(opacities), (int)opac_per_camera, fp(extra), fp(bg), ip(radii),
+                         ip(tile_offsets), ip(tile_order), ip(flatten_arena), fpw(records), fpw(render), fpw(alphas),
+                         static_cast<int32_t*>(dp(last_ids)), static_cast<uint8_t*>(dp(reach)), tp(tuning),
+                         sp(stream)),
+          "mobgs_raster_fwd");
+    return {records, render, alphas, last_ids, reach};
+}
+
+// -> zero-filled gradient slots [max(n_isects,1), stride] with the per-entry records written by the kernel
+Tensor raster_bwd(int64_t C, int64_t N, int64_t channels, int64_t has_extra, int64_t width, int64_t height,
+                  int64_t n_isects, const Tensor& records, const OptT& bg, const Tensor& radii, const Tensor& means2d,
+                  const Tensor& cum_tiles, const Tensor& keep_scan, const Tensor& tile_offsets, const OptT& tile_order,
+                  const Tensor& flatten_ids, const Tensor& alphas, const Tensor& last_ids, const Tensor& v_render_in,
+                  const OptT& v_alphas_in, const OptT& reach, int64_t tuning, int64_t stream) {
+    const Tensor v_render = f32c(v_render_in);
+    const OptT v_alphas = f32c(v_alphas_in);
+    Tensor slots = at::zeros({std::max<int64_t>(n_isects, 1), records.size(1)}, records.options());
+    check(api.raster_bwd((int)C, (int)N, (int)channels, (int)has_extra, (int)width, (int)height, fp(records), fp(bg),
+                         ip(radii), fp(means2d), ip(cum_tiles), ip(keep_scan), ip(tile_offsets), ip(tile_order),
+                         ip(flatten_ids), fp(alphas), ip(last_ids), fp(v_render), fp(v_alphas), fpw(slots),
+                         static_cast<const uint8_t*>(dp(reach)), tp(tuning), sp(stream)),
+          "mobgs_raster_bwd");
+    return slots;
+}
+
+// -> (v_means2d [C,N,2], v_conics [C,N,3], v_opac [C,N], v_colors [C,N,channels], v_extra [C,N] | None)
+std::tuple<Tensor, Tensor, Tensor, Tensor, OptT>
+raster_bwd_reduce(int64_t C, int64_t N, int64_t channels, int64_t has_extra, const Tensor& cum_tiles,
+                  const Tensor& keep_scan, const Tensor& slots, int64_t stream) {
+    const auto f = slots.options();
+    Tensor v_means2d = at::empty({C, N, 2}, f), v_conics = at::empty({C, N, 3}, f), v_opac = at::empty({C, N}, f),
+           v_colors = at::empty({C, N, channels}, f);
+    OptT v_extra = has_extra ? OptT(at::empty({C, N}, f)) : OptT();
+    check(api.raster_bwd_reduce((int)C, (int)N, (int)channels, (int)has_extra, ip(cum_tiles), ip(keep_scan), fp(slots),
+                                fpw(v_means2d), fpw(v_conics), fpw(v_opac), fpw(v_colors), fpw(v_extra), sp(stream)),
+          "mobgs_raster_bwd_reduce");
+    return {v_means2d, v_conics, v_opac, v_colors, v_extra};
+}
+
+// ---- ops.Decode ----------------------------------------------------------------------------------------------------
+// -> (rgb [3,H,W], depth [H,W] | None)
+std::tuple<Tensor, OptT> decoder_fwd(int64_t H, int64_t W, int64_t CF, bool has_depth, const Tensor& feat_hw,
+                                     const OptT& alphas, const OptT& rays, const OptT& intr, const OptT& c2w,
+                                     const Tensor& w1, const Tensor& w2, int64_t stream) {
+    const auto f = feat_hw.options();
+    Tensor rgb = at::empty({3, H, W}, f);
+    OptT depth = has_depth ? OptT(at::empty({H, W}, f)) : OptT();
+    check(api.decoder_fwd((int)(H * W), (int)CF, has_depth ? 1 : 0, (int)W, fp(feat_hw), fp(alphas), fp(rays),
+                          fp(intr), fp(c2w), fp(w1), fp(w2), fpw(rgb), fpw(depth), sp(stream)),
+          "mobgs_decoder_fwd");
+    return {rgb, depth};
+}
+
+// g_w1 / g_w2: a sink's buffers (accumulate as given) or None -> allocated here and overwritten.
+// -> (v_feat, v_alphas | None, v_rays | None, g_c2w | None, g_w1, g_w2)
+std::tuple<Tensor, OptT, OptT, OptT, Tensor, Tensor>
+decoder_bwd(int64_t H, int64_t W, int64_t CF, bool has_depth, const Tensor& feat_hw, const OptT& alphas,
+            const OptT& rays, const OptT& intr, const OptT& c2w, const Tensor& w1, const Tensor& w2,
+            const OptT& v_rgb_in, const OptT& v_depth_in, std::vector<int64_t> feat_shape, bool rays_need_grad,
+            bool c2w_needs_grad, const OptT& g_w1_in, const OptT& g_w2_in, int64_t accumulate, int64_t stream) {
+    const auto f = feat_hw.options();
+    const int64_t P = H * W;
+    Tensor v_rgb = (v_rgb_in.has_value() && v_rgb_in->defined()) ? f32c(*v_rgb_in) : at::zeros({3, H, W}, f);
+    OptT v_depth = has_depth ? f32c(v_depth_in) : OptT();
+    Tensor v_feat = at::empty(feat_shape, f);
+    OptT v_alphas = has_depth ? OptT(at::empty(alphas->sizes(), f)) : OptT();
+    OptT v_rays = rays_need_grad ? OptT(at::empty_like(*rays)) : OptT();
+    OptT g_c2w = c2w_needs_grad ? OptT(at::empty_like(*c2w)) : OptT();
+    Tensor partial = at::empty({(int64_t)api.decoder_bwd_blocks((int)P), 102}, f);
+    const bool sunk = g_w1_in.has_value() && g_w1_in->defined();
+    Tensor g_w1 = sunk ? *g_w1_in : at::empty_like(w1);
+    Tensor g_w2 = sunk ? *g_w2_in : at::empty_like(w2);
+    check(api.decoder_bwd((int)P, (int)CF, has_depth ? 1 : 0, (int)W, fp(feat_hw), fp(alphas), fp(rays), fp(intr),
+                          fp(c2w), fp(w1), fp(w2), fp(v_rgb), fp(v_depth), fpw(v_feat), fpw(v_alphas), fpw(v_rays),
+                          fpw(partial), fpw(g_w1), fpw(g_w2), fpw(g_c2w), g_c2w.has_value() ? (int)g_c2w->numel() : 0,
+                          sunk ? (int)accumulate : 0, sp(stream)),
+          "mobgs_decoder_bwd");
+    return {v_feat, v_alphas, v_rays, g_c2w, g_w1, g_w2};
+}
+
+// ---- rendering._Project.backward -----------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor, Tensor, Tensor>
+project_bwd(int64_t width, int64_t height, double eps2d, const Tensor& means, const Tensor& quats, const Tensor& scales,
+            const Tensor& viewmats, const Tensor& Ks, const Tensor& radii, const Tensor& conics, const OptT& v_means2d,
+            const OptT& v_depths, const OptT& v_conics, int64_t stream) {
+    const int64_t C = viewmats.size(0), N = means.size(0);
+    Tensor v_means = at::empty_like(means), v_quats = at::empty_like(quats), v_scales = at::empty_like(scales),
+           v_viewmats = at::empty_like(viewmats);
+    Tensor partial = at::empty({(int64_t)api.project_bwd_scratch_floats((int)C, (int)N)}, means.options());
+    const OptT g2 = f32c(v_means2d), gd = f32c(v_depths), gc = f32c(v_conics);
+    check(api.project_bwd((int)C, (int)N, fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), (int)width,
+                          (int)height, (float)eps2d, ip(radii), fp(conics), fp(g2), fp(gd), fp(gc), fpw(v_means),
+                          fpw(v_quats), fpw(v_scales), fpw(v_viewmats), fpw(partial), sp(stream)),
+          "mobgs_project_bwd");
+    return {v_means, v_quats, v_scales, v_viewmats};
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "mobgs_amd host fast path (see csrc/fastpath.cpp)";
+    m.def("bind", &bind);
+    m.def("prep_fwd", &prep_fwd);
+    m.def("prep_bwd", &prep_bwd);
+    m.def("raster_fwd", &raster_fwd);
+    m.def("raster_bwd", &raster_bwd);
+    m.def("raster_bwd_reduce", &raster_bwd_reduce);
+    m.def("decoder_fwd", &decoder_fwd);
+    m.def("decoder_bwd", &decoder_bwd);
+    m.def("project_bwd", &project_bwd);
+}

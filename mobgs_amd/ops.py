@@ -7,6 +7,8 @@ import torch
 from torch import Tensor
 
 from . import _lib
+from . import _fast
+from ._lib import stream_int  # noqa: E402
 from ._lib import attr_c, check, f32c, ptr, stream
 
 
@@ -130,11 +132,19 @@ class PrepSplats(torch.autograd.Function):
         # directly; positions, control points and time centres are always fp32
         attrs = (s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_scaling, d_rotation, d_omega, d_opacity, d_fdc, d_ft)
         half = all(a.dtype == torch.float16 for a in attrs)
+        ctx.attr_dtypes = tuple(a.dtype for a in attrs)
+        ctx.half = half
+        ctx.sizes = (s_xyz.shape[0], d_control.shape[0])
+        F = _fast.get()
+        if F is not None:  # the same body in C++ (csrc/fastpath.cpp)
+            (means, quats, scales, opac, colors, times, d_ncp, d_trbf, n_conv) = F.prep_fwd(
+                times, s_xyz, d_control, d_ncp, d_trbf, list(attrs), half, stream_int())
+            _lib.attr_conversions += n_conv
+            ctx.save_for_backward(times, d_ncp, d_trbf, scales, opac)
+            return means, quats, scales, opac, colors
         times, s_xyz, d_control, d_trbf = map(f32c, (times, s_xyz, d_control, d_trbf))
         (s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_scaling, d_rotation, d_omega, d_opacity, d_fdc,
          d_ft) = (attr_c(a, half) for a in attrs)
-        ctx.attr_dtypes = tuple(a.dtype for a in attrs)
-        ctx.half = half
         d_ncp = d_ncp.to(torch.int64).contiguous()
         Ns, Nd = s_xyz.shape[0], d_control.shape[0]
         N = Ns + Nd
@@ -150,7 +160,6 @@ class PrepSplats(torch.autograd.Function):
                   ptr(d_opacity), ptr(d_fdc), ptr(d_ft), ptr(d_trbf), ptr(means), ptr(quats), ptr(scales), ptr(opac),
                   ptr(colors), stream()), "mobgs_prep_fwd")
         ctx.save_for_backward(times, d_ncp, d_trbf, scales, opac)
-        ctx.sizes = (Ns, Nd)
         return means, quats, scales, opac, colors
 
     @staticmethod
@@ -170,7 +179,16 @@ class PrepSplats(torch.autograd.Function):
             return torch.empty(*shape, dtype=torch.float16 if (attr and g_half) else torch.float32, device=dev)
 
         accumulate = 0
-        if use_sink and sink.buffers is not None:
+        F = _fast.get()
+        if F is not None:
+            have = use_sink and sink.buffers is not None
+            out = F.prep_bwd(Ns, Nd, times, d_ncp, d_trbf, scales, opac, v_means, v_quats, v_scales, v_opac, v_colors,
+                             [sink.buffers[n_] for n_ in _LEAF_NAMES] if have else [], g_half, 1 if have else 0,
+                             stream_int())
+            g = sink.buffers if have else dict(zip(_LEAF_NAMES, out))
+            if use_sink:
+                sink.buffers = g
+        elif use_sink and sink.buffers is not None:
             g, accumulate = sink.buffers, 1
         else:
             g = {"s_xyz": E(Ns, 3), "s_scaling": E(Ns, 3, attr=True), "s_rotation": E(Ns, 4, attr=True),
@@ -180,13 +198,14 @@ class PrepSplats(torch.autograd.Function):
                  "d_ft": E(Nd, 3, attr=True)}
             if use_sink:
                 sink.buffers = g
-        c = [f32c(v) if v is not None else None for v in (v_means, v_quats, v_scales, v_opac, v_colors)]
-        bwd = lib.mobgs_prep_bwd_f16 if g_half else lib.mobgs_prep_bwd
-        check(bwd(Ns, Nd, ptr(times), ptr(d_ncp), ptr(d_trbf), ptr(scales), ptr(opac), ptr(c[0]), ptr(c[1]), ptr(c[2]),
-                  ptr(c[3]), ptr(c[4]), ptr(g["s_xyz"]), ptr(g["s_scaling"]), ptr(g["s_rotation"]), ptr(g["s_opacity"]),
-                  ptr(g["s_fdc"]), ptr(g["s_ft"]), ptr(g["d_control"]), ptr(g["d_scaling"]), ptr(g["d_rotation"]),
-                  ptr(g["d_omega"]), ptr(g["d_opacity"]), ptr(g["d_fdc"]), ptr(g["d_ft"]), accumulate, stream()),
-              "mobgs_prep_bwd")
+        if F is None:
+            c = [f32c(v) if v is not None else None for v in (v_means, v_quats, v_scales, v_opac, v_colors)]
+            bwd = lib.mobgs_prep_bwd_f16 if g_half else lib.mobgs_prep_bwd
+            check(bwd(Ns, Nd, ptr(times), ptr(d_ncp), ptr(d_trbf), ptr(scales), ptr(opac), ptr(c[0]), ptr(c[1]),
+                      ptr(c[2]), ptr(c[3]), ptr(c[4]), ptr(g["s_xyz"]), ptr(g["s_scaling"]), ptr(g["s_rotation"]),
+                      ptr(g["s_opacity"]), ptr(g["s_fdc"]), ptr(g["s_ft"]), ptr(g["d_control"]), ptr(g["d_scaling"]),
+                      ptr(g["d_rotation"]), ptr(g["d_omega"]), ptr(g["d_opacity"]), ptr(g["d_fdc"]), ptr(g["d_ft"]),
+                      accumulate, stream()), "mobgs_prep_bwd")
         if not use_sink and not g_half:  # mixed / other dtypes: autograd wants the leaf's dtype back
             names = ("s_scaling", "s_rotation", "s_opacity", "s_fdc", "s_ft", "d_scaling", "d_rotation", "d_omega",
                      "d_opacity", "d_fdc", "d_ft")
@@ -221,11 +240,16 @@ class Decode(torch.autograd.Function):
             intr_c, c2w_c = f32c(intr.detach()), f32c(c2w.detach())
             if intr_c.numel() != 4 or c2w_c.numel() not in (12, 16):
                 raise ValueError("decode: intr must be [fx, fy, cx, cy] and c2w a [3,4] or [4,4] camera-to-world matrix")
-        rgb = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-        depth = torch.empty(H, W, dtype=torch.float32, device=dev) if has_depth else None
-        check(lib.mobgs_decoder_fwd(P, CF, int(has_depth), W, ptr(feat_hw), ptr(alphas_c), ptr(rays_c), ptr(intr_c),
-                                    ptr(c2w_c), ptr(w1), ptr(w2), ptr(rgb), ptr(depth), stream()),
-              "mobgs_decoder_fwd")
+        F = _fast.get()
+        if F is not None:
+            rgb, depth = F.decoder_fwd(H, W, CF, bool(has_depth), feat_hw, alphas_c, rays_c, intr_c, c2w_c, w1, w2,
+                                       stream_int())
+        else:
+            rgb = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            depth = torch.empty(H, W, dtype=torch.float32, device=dev) if has_depth else None
+            check(lib.mobgs_decoder_fwd(P, CF, int(has_depth), W, ptr(feat_hw), ptr(alphas_c), ptr(rays_c),
+                                        ptr(intr_c), ptr(c2w_c), ptr(w1), ptr(w2), ptr(rgb), ptr(depth), stream()),
+                  "mobgs_decoder_fwd")
         ctx.save_for_backward(feat_hw, alphas_c, rays_c, intr_c, c2w_c, w1, w2)
         ctx.has_depth = has_depth
         ctx.rays_need_grad = rays is not None and ctx.needs_input_grad[2]
@@ -245,6 +269,17 @@ class Decode(torch.autograd.Function):
         P = H * W
         dev = feat_hw.device
         has_depth = ctx.has_depth
+        sunk = _active_sink.decoder_buffers(*ctx.w_inputs) if _active_sink is not None else None
+        F = _fast.get()
+        if F is not None:
+            v_feat, v_alphas, v_rays, g_c2w, g_w1, g_w2 = F.decoder_bwd(
+                H, W, CF, bool(has_depth), feat_hw, alphas, rays, intr, c2w, w1, w2, v_rgb, v_depth,
+                list(ctx.feat_shape), bool(ctx.rays_need_grad), bool(ctx.c2w_needs_grad),
+                sunk[0] if sunk is not None else None, sunk[1] if sunk is not None else None,
+                sunk[2] if sunk is not None else 0, stream_int())
+            if sunk is not None:
+                return v_feat, v_alphas, v_rays, None, g_c2w, None, None, None
+            return v_feat, v_alphas, v_rays, None, g_c2w, g_w1, g_w2, None
         v_rgb = f32c(v_rgb) if v_rgb is not None else torch.zeros(3, H, W, dtype=torch.float32, device=dev)
         v_depth = f32c(v_depth) if (has_depth and v_depth is not None) else None
         v_feat = torch.empty(ctx.feat_shape, dtype=torch.float32, device=dev)
@@ -253,7 +288,6 @@ class Decode(torch.autograd.Function):
         g_c2w = torch.empty_like(c2w) if ctx.c2w_needs_grad else None  # [3,4] or [4,4] like the input
         nb = lib.mobgs_decoder_bwd_blocks(P)
         partial = torch.empty(nb, 102, dtype=torch.float32, device=dev)
-        sunk = _active_sink.decoder_buffers(*ctx.w_inputs) if _active_sink is not None else None
         if sunk is not None:
             g_w1, g_w2, accumulate = sunk
         else:

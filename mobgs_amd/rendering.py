@@ -16,8 +16,8 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
-from . import _lib, profiler
-from ._lib import DerivedCache, check, f32c, ptr, stream
+from . import _fast, _lib, profiler
+from ._lib import DerivedCache, check, f32c, ptr, stream, stream_int
 
 TILE = 16
 # statistics of the most recent build_tile_lists() call (read by bench.py for the roofline line)
@@ -57,6 +57,12 @@ class _Project(torch.autograd.Function):
         lib = _lib_()
         means, quats, scales, viewmats, Ks, radii, conics = ctx.saved_tensors
         width, height, eps2d = ctx.dims
+        F = _fast.get()
+        if F is not None:  # the same body in C++ (csrc/fastpath.cpp)
+            v_means, v_quats, v_scales, v_viewmats = F.project_bwd(width, height, eps2d, means, quats, scales,
+                                                                   viewmats, Ks, radii, conics, v_means2d, v_depths,
+                                                                   v_conics, stream_int())
+            return v_means, v_quats, v_scales, v_viewmats, None, None, None, None, None, None, None
         C, N = viewmats.shape[0], means.shape[0]
         dev = means.device
         v_means = torch.empty_like(means)
@@ -371,23 +377,34 @@ class _Rasterize(torch.autograd.Function):
         # no pack launch (colors = NULL tells mobgs_raster_fwd so)
         if packed is not None and tuple(packed.shape) != (C * N, stride):
             packed = None
-        records = packed if packed is not None else torch.empty(C * N, stride, dtype=torch.float32, device=dev)
         colors_arg = None if packed is not None else colors
-        render = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
-        alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
-        last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
-        # per list entry: the quadrants of its tile the splat can reach -- computed by the forward kernel anyway,
-        # kept for the backward pass over the same lists
-        reach = torch.empty(max(tl.flatten_arena.numel(), 1), dtype=torch.uint8, device=dev)
+        F = _fast.get()
+        records, reach = packed, None
+        if F is None:
+            if records is None:
+                records = torch.empty(C * N, stride, dtype=torch.float32, device=dev)
+            render = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
+            alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
+            last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+            # per list entry: the quadrants of its tile the splat can reach -- computed by the forward kernel anyway,
+            # kept for the backward pass over the same lists
+            reach = torch.empty(max(tl.flatten_arena.numel(), 1), dtype=torch.uint8, device=dev)
         with profiler.region("raster_fwd"):
             while True:
-                if reach.numel() < tl.flatten_arena.numel():  # lists rebuilt into a larger arena
-                    reach = torch.empty(tl.flatten_arena.numel(), dtype=torch.uint8, device=dev)
-                check(lib.mobgs_raster_fwd(C, N, channels, width, height, ptr(means2d), ptr(conics), ptr(colors_arg),
-                                           colors_per_camera, ptr(opacities), opac_per_camera, ptr(extra), ptr(bg),
-                                           ptr(radii), ptr(tl.tile_offsets), ptr(tl.tile_order),
-                                           ptr(tl.flatten_arena), ptr(records), ptr(render), ptr(alphas),
-                                           ptr(last_ids), ptr(reach), tuning.ref(), stream()), "mobgs_raster_fwd")
+                if F is not None:  # allocations + the launch in C++ (csrc/fastpath.cpp); buffers are reused on a redo
+                    records, render, alphas, last_ids, reach = F.raster_fwd(
+                        C, N, channels, width, height, means2d, conics, colors_arg, colors_per_camera, opacities,
+                        opac_per_camera, extra, bg, radii, tl.tile_offsets, tl.tile_order, tl.flatten_arena, records,
+                        reach, tuning.address(), stream_int())
+                else:
+                    if reach.numel() < tl.flatten_arena.numel():  # lists rebuilt into a larger arena
+                        reach = torch.empty(tl.flatten_arena.numel(), dtype=torch.uint8, device=dev)
+                    check(lib.mobgs_raster_fwd(C, N, channels, width, height, ptr(means2d), ptr(conics),
+                                               ptr(colors_arg), colors_per_camera, ptr(opacities), opac_per_camera,
+                                               ptr(extra), ptr(bg), ptr(radii), ptr(tl.tile_offsets),
+                                               ptr(tl.tile_order), ptr(tl.flatten_arena), ptr(records), ptr(render),
+                                               ptr(alphas), ptr(last_ids), ptr(reach), tuning.ref(), stream()),
+                          "mobgs_raster_fwd")
                 # speculative lists whose arena was too small get rebuilt by resolve(): composite again.  A caller that
                 # wants to enqueue more work before waiting for the counts sets tl.defer and does this itself.
                 if tl.defer or not tl.resolve():
@@ -410,25 +427,33 @@ class _Rasterize(torch.autograd.Function):
         dev = records.device
         D = channels + (1 if has_extra else 0)
         stride = records.shape[1]
-        v_render = f32c(v_render)
-        v_alphas = f32c(v_alphas) if v_alphas is not None else None
-        slots = torch.zeros(max(tl.n_isects, 1), stride, dtype=torch.float32, device=dev)
-        v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
-        v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
-        v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
-        v_colors = torch.empty(C, N, channels, dtype=torch.float32, device=dev)
-        v_extra = torch.empty(C, N, dtype=torch.float32, device=dev) if has_extra else None
-        with profiler.region("raster_bwd"):
-            check(lib.mobgs_raster_bwd(C, N, channels, int(has_extra), width, height, ptr(records), ptr(bg),
-                                       ptr(radii), ptr(means2d), ptr(tl.cum_tiles), ptr(tl.keep_scan),
-                                       ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas),
-                                       ptr(last_ids),
-                                       ptr(v_render), ptr(v_alphas), ptr(slots), ptr(reach), tuning.ref(), stream()),
-                  "mobgs_raster_bwd")
-        check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(tl.cum_tiles), ptr(tl.keep_scan),
-                                          ptr(slots),
-                                          ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra),
-                                          stream()), "mobgs_raster_bwd_reduce")
+        F = _fast.get()
+        if F is not None:  # the same body in C++ (csrc/fastpath.cpp)
+            st = stream_int()
+            with profiler.region("raster_bwd"):
+                slots = F.raster_bwd(C, N, channels, int(has_extra), width, height, tl.n_isects, records, bg, radii,
+                                     means2d, tl.cum_tiles, tl.keep_scan, tl.tile_offsets, tl.tile_order,
+                                     tl.flatten_ids, alphas, last_ids, v_render, v_alphas, reach, tuning.address(), st)
+            v_means2d, v_conics, v_opac, v_colors, v_extra = F.raster_bwd_reduce(
+                C, N, channels, int(has_extra), tl.cum_tiles, tl.keep_scan, slots, st)
+        else:
+            v_render = f32c(v_render)
+            v_alphas = f32c(v_alphas) if v_alphas is not None else None
+            slots = torch.zeros(max(tl.n_isects, 1), stride, dtype=torch.float32, device=dev)
+            v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+            v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+            v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
+            v_colors = torch.empty(C, N, channels, dtype=torch.float32, device=dev)
+            v_extra = torch.empty(C, N, dtype=torch.float32, device=dev) if has_extra else None
+            with profiler.region("raster_bwd"):
+                check(lib.mobgs_raster_bwd(C, N, channels, int(has_extra), width, height, ptr(records), ptr(bg),
+                                           ptr(radii), ptr(means2d), ptr(tl.cum_tiles), ptr(tl.keep_scan),
+                                           ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas),
+                                           ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(slots), ptr(reach),
+                                           tuning.ref(), stream()), "mobgs_raster_bwd")
+            check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(tl.cum_tiles), ptr(tl.keep_scan),
+                                              ptr(slots), ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors),
+                                              ptr(v_extra), stream()), "mobgs_raster_bwd_reduce")
         if not colors_per_camera:
             v_colors = v_colors.sum(0) if C > 1 else v_colors[0]
         if not opac_per_camera:

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    torch.autograd.set_multithreading_enabled(False)  # backward on the calling thread
     from mobgs_amd import rendering
     rendering.tuning.heavy_tile_len = a.heavy
     scam, cam, stat, dyn, _ = bench.build_scene(dev, a.ns, a.nd, a.width, a.height)

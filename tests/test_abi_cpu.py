@@ -78,3 +78,18 @@ def test_render_cluster_argument_raises_like_the_reference():
     from mobgs_amd.gaussian_renderer import render
     with pytest.raises(NameError):
         render(None, None, None, None, None, cluster=1)
+
+
+def test_host_fast_path_builds_loads_and_binds():
+    """csrc/fastpath.cpp (the autograd-node bodies in C++) compiles against the installed libtorch with g++, loads,
+    and binds every C-ABI entry point it calls from the ctypes handle."""
+    from mobgs_amd import _fast
+    _fast.reset(True)
+    try:
+        m = _fast.get()
+        assert m is not None, _fast.load_error
+        for name in ("prep_fwd", "prep_bwd", "raster_fwd", "raster_bwd", "raster_bwd_reduce", "decoder_fwd",
+                     "decoder_bwd", "project_bwd"):
+            assert callable(getattr(m, name))
+    finally:
+        _fast.reset(None)
