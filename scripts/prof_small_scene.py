@@ -25,11 +25,17 @@ def main():
     ap.add_argument("--cprofile", action="store_true")
     ap.add_argument("--heavy", type=int, default=-1, help="rendering.tuning.heavy_tile_len (-1: library default)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dense", action="store_true", help="experiment: force the dense-region binning variant")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.autograd.set_multithreading_enabled(False)  # backward on the calling thread
     from mobgs_amd import rendering
     rendering.tuning.heavy_tile_len = a.heavy
+    if a.dense:
+        class _Hint(dict):
+            def get(self, k, d=None):
+                return 4096
+        rendering._len_hint = _Hint()
     scam, cam, stat, dyn, _ = bench.build_scene(dev, a.ns, a.nd, a.width, a.height)
     bg = torch.zeros(9, device=dev)
     g = torch.Generator().manual_seed(100)

@@ -14,11 +14,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--views", type=int, default=2)
     ap.add_argument("--stacks", action="store_true")
+    ap.add_argument("--ns", type=int, default=200_000)
+    ap.add_argument("--nd", type=int, default=100_000)
+    ap.add_argument("--width", type=int, default=1352)
+    ap.add_argument("--height", type=int, default=1014)
+    ap.add_argument("--host", action="store_true", help="also list the ops by host (self CPU) time")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     from mobgs_amd.distributed import SubframeShard
-    scam, cam, stat, dyn, raw = bench.build_scene(dev, 200_000, 100_000, 1352, 1014)
-    wl = bench.DeblurWorkload(dev, stat, dyn, scam, 1352, 1014, SubframeShard(), a.views)
+    torch.autograd.set_multithreading_enabled(False)
+    scam, cam, stat, dyn, raw = bench.build_scene(dev, a.ns, a.nd, a.width, a.height)
+    wl = bench.DeblurWorkload(dev, stat, dyn, scam, a.width, a.height, SubframeShard(), a.views)
     for _ in range(4):
         wl.step()
     torch.cuda.synchronize()
@@ -29,6 +35,8 @@ def main():
         torch.cuda.synchronize()
     print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=45,
                                                               max_name_column_width=60))
+    if a.host:
+        print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40, max_name_column_width=60))
     print("\n--- PyTorch ops that launch device work (everything except this package's autograd nodes) ---")
     tot = 0.0
     for e in sorted(prof.key_averages(group_by_input_shape=True), key=lambda e: -e.self_device_time_total):
