@@ -40,6 +40,11 @@ struct Api {
     decltype(&mobgs_decoder_bwd_blocks) decoder_bwd_blocks = nullptr;
     decltype(&mobgs_project_bwd) project_bwd = nullptr;
     decltype(&mobgs_project_bwd_scratch_floats) project_bwd_scratch_floats = nullptr;
+    decltype(&mobgs_project_and_bin_speculative) project_and_bin_speculative = nullptr;
+    decltype(&mobgs_tile_order_len) tile_order_len = nullptr;
+    decltype(&mobgs_keep_scan_len) keep_scan_len = nullptr;
+    decltype(&mobgs_isect_scratch_bytes) isect_scratch_bytes = nullptr;
+    decltype(&mobgs_raster_channels_supported) raster_channels_supported = nullptr;
     bool bound = false;
 } api;
 
@@ -65,6 +70,11 @@ void bind(const std::unordered_map<std::string, uint64_t>& m) {
     take(m, "mobgs_decoder_bwd_blocks", api.decoder_bwd_blocks);
     take(m, "mobgs_project_bwd", api.project_bwd);
     take(m, "mobgs_project_bwd_scratch_floats", api.project_bwd_scratch_floats);
+    take(m, "mobgs_project_and_bin_speculative", api.project_and_bin_speculative);
+    take(m, "mobgs_tile_order_len", api.tile_order_len);
+    take(m, "mobgs_keep_scan_len", api.keep_scan_len);
+    take(m, "mobgs_isect_scratch_bytes", api.isect_scratch_bytes);
+    take(m, "mobgs_raster_channels_supported", api.raster_channels_supported);
     api.bound = true;
 }
 
@@ -295,6 +305,56 @@ project_bwd(int64_t width, int64_t height, double eps2d, const Tensor& means, co
     return {v_means, v_quats, v_scales, v_viewmats};
 }
 
+// ---- rendering._ProjectAndBin.forward, speculative binning ---------------------------------------------------------
+// Allocates every output / arena and makes the ONE orchestrator call.  -> (rc, [radii, means2d, depths, conics,
+// tiles_per_gauss, cum_tiles, tile_offsets, keep_scan, flatten_ids], tile_order | None, isect_ids | None,
+// records | None).  rc: 0 = counts arrive through the polled pinned row, 1 = by asynchronous copy (record an event).
+std::tuple<int64_t, std::vector<Tensor>, OptT, OptT, OptT>
+project_and_bin_speculative(const Tensor& means, const Tensor& quats, const Tensor& scales, const Tensor& viewmats,
+                            const Tensor& Ks, const Tensor& opac, int64_t width, int64_t height, double eps2d,
+                            double near_plane, double far_plane, double radius_clip, int64_t cull,
+                            bool want_isect_ids, bool tile_schedule, const OptT& pack_colors, int64_t cap_box,
+                            int64_t cap_listed, int64_t len_hint, int64_t stats_row, int64_t seq, int64_t tuning,
+                            int64_t stream) {
+    const int64_t C = viewmats.size(0), N = means.size(0);
+    const int64_t tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, nt = C * tile_w * tile_h;
+    const auto f = means.options().dtype(at::kFloat);
+    const auto i32 = f.dtype(at::kInt);
+    const auto i64 = f.dtype(at::kLong);
+    Tensor radii = at::empty({C, N}, i32), means2d = at::empty({C, N, 2}, f), depths = at::empty({C, N}, f),
+           conics = at::empty({C, N, 3}, f), tiles_per_gauss = at::empty({C, N}, i32),
+           cum_tiles = at::empty({C * N + 1}, i32), tile_offsets = at::empty({nt + 1}, i32),
+           stats_dev = at::empty({3}, i64);
+    OptT tile_order = tile_schedule ? OptT(at::empty({(int64_t)api.tile_order_len((int)nt)}, i32)) : OptT();
+    OptT records;
+    int64_t pack_ch = 0;
+    if (pack_colors.has_value() && pack_colors->defined()) {
+        pack_ch = pack_colors->size(-1);
+        if (api.raster_channels_supported((int)pack_ch + 1))
+            records = at::empty({C * N, (int64_t)api.record_stride((int)pack_ch + 1)}, f);
+    }
+    Tensor keep_scan = at::empty({(int64_t)api.keep_scan_len((int)cap_box)}, i32);
+    Tensor scratch = at::empty({(int64_t)api.isect_scratch_bytes((int)(C * N), (int)nt, (int)cap_box)},
+                               f.dtype(at::kByte));
+    Tensor flatten_ids = at::empty({cap_listed}, i32), sort_keys = at::empty({cap_listed}, i64);
+    OptT isect_ids = want_isect_ids ? OptT(at::empty({cap_listed}, i64)) : OptT();
+    const bool pack = records.has_value();
+    const int rc = api.project_and_bin_speculative(
+        (int)C, (int)N, fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), fp(opac), opac.dim() == 2 ? 1 : 0,
+        (int)width, (int)height, (float)eps2d, (float)near_plane, (float)far_plane, (float)radius_clip, (int)cull,
+        static_cast<int32_t*>(dp(radii)), fpw(means2d), fpw(depths), fpw(conics),
+        static_cast<int32_t*>(dp(tiles_per_gauss)), static_cast<int32_t*>(dp(cum_tiles)),
+        static_cast<int32_t*>(dp(tile_offsets)), static_cast<int32_t*>(dp(tile_order)),
+        static_cast<int64_t*>(dp(stats_dev)), (int)cap_box, static_cast<int32_t*>(dp(keep_scan)), dp(scratch),
+        cap_listed, static_cast<int32_t*>(dp(flatten_ids)), static_cast<uint64_t*>(dp(sort_keys)),
+        static_cast<uint64_t*>(dp(isect_ids)), len_hint,
+        reinterpret_cast<int64_t*>(static_cast<uintptr_t>(stats_row)), seq, pack ? fp(*pack_colors) : nullptr,
+        (pack && pack_colors->dim() == 3) ? 1 : 0, pack ? (int)pack_ch : 0, fpw(records), tp(tuning), sp(stream));
+    if (rc != 0 && rc != 1) check(rc, "mobgs_project_and_bin_speculative");
+    return {rc, {radii, means2d, depths, conics, tiles_per_gauss, cum_tiles, tile_offsets, keep_scan, flatten_ids},
+            tile_order, isect_ids, records};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -308,4 +368,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("decoder_fwd", &decoder_fwd);
     m.def("decoder_bwd", &decoder_bwd);
     m.def("project_bwd", &project_bwd);
+    m.def("project_and_bin_speculative", &project_and_bin_speculative);
 }

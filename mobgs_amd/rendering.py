@@ -160,14 +160,17 @@ class _StatsSlots:
     def __init__(self, n=256):
         self.block = torch.zeros(n, 4, dtype=torch.int64, pin_memory=True)
         self.view = self.block.numpy()  # same memory: polled without going through the dispatcher
+        self.base = self.block.data_ptr()
         self.free = list(range(n))
         self.seq = 0
 
     def take(self):
+        """-> (row: numpy view of 4 int64, slot index | None, host address of the row, owner keeping it alive)"""
         if self.free:
             i = self.free.pop()
-            return self.block[i], i
-        return torch.zeros(4, dtype=torch.int64, pin_memory=True), None
+            return self.view[i], i, self.base + 32 * i, self.block
+        extra = torch.zeros(4, dtype=torch.int64, pin_memory=True)  # pool exhausted: a one-off pinned row
+        return extra.numpy(), None, extra.data_ptr(), extra
 
     def next_seq(self) -> int:
         self.seq += 1
@@ -184,9 +187,10 @@ _stats_slots = None
 class _PendingCounts:
     """The read-back half of a speculative mobgs_project_and_bin_speculative call."""
 
-    def __init__(self, row, slot, event, caps, arenas, rebuild_args, seq=0):
-        self.row, self.slot, self.event, self.seq = row, slot, event, seq
+    def __init__(self, row, slot, event, caps, arenas, rebuild_args, seq=0, owner=None):
+        self.row, self.slot, self.event, self.seq = row, slot, event, seq  # row: numpy view of the pinned words
         self.caps, self.arenas, self.rebuild_args = caps, arenas, rebuild_args
+        self.owner = owner  # the pinned tensor behind `row`
 
     def __del__(self):
         # dropped without finish() (exception, unused result): the device may still be about to write this slot, so
@@ -197,7 +201,7 @@ class _PendingCounts:
         if sys is None or sys.is_finalizing():  # interpreter shutdown: torch / HIP may already be torn down
             return
         try:
-            arrived = int(self.row.numpy()[3]) == self.seq if self.event is None else bool(self.event.query())
+            arrived = int(self.row[3]) == self.seq if self.event is None else bool(self.event.query())
         except Exception:  # noqa: BLE001
             arrived = False
         if arrived:
@@ -211,7 +215,7 @@ class _PendingCounts:
         # the device stores the counts and then the sequence number into the pinned row: poll it (no event was
         # recorded, so nothing sits between the binning kernels and what was enqueued behind them)
         import time
-        word = self.row.numpy()
+        word = self.row
         if int(word[3]) == self.seq:
             return
         if torch.cuda.is_current_stream_capturing():
@@ -232,7 +236,7 @@ class _PendingCounts:
 
     def finish(self, tl) -> bool:
         self._wait()
-        n_box, n_isects, max_len = (int(v) for v in self.row.tolist()[:3])
+        n_box, n_isects, max_len = (int(v) for v in self.row[:3])
         _stats_slots.give(self.slot)
         self.slot = None
         key, cap_box, cap_listed = self.caps
@@ -688,6 +692,41 @@ class _ProjectAndBin(torch.autograd.Function):
         dev = means.device
         tile_w, tile_h = math.ceil(width / TILE), math.ceil(height / TILE)
         nt = C * tile_w * tile_h
+        F = _fast.get() if SPECULATIVE_BINNING else None
+        if F is not None:  # allocations + the orchestrator call in C++ (csrc/fastpath.cpp)
+            global _stats_slots
+            if _stats_slots is None:
+                _stats_slots = _StatsSlots()
+            tl.records = None
+            pack = f32c(pack_colors) if pack_colors is not None else None
+            key = _workload_key(dev, C, N, width, height)
+            cap_box = max(_capacity.get(key, 0), 16 * (C * N) + 1024)
+            cap_listed = max(_cap_listed.get(key, 0), cap_box // 2)
+            row, slot, row_addr, owner = _stats_slots.take()
+            seq = _stats_slots.next_seq()
+            row[3] = 0
+            rc, outs, tile_order, isect_ids, records = F.project_and_bin_speculative(
+                means, quats, scales, viewmats, Ks, opac, width, height, eps2d, near_plane, far_plane, radius_clip,
+                int(_tile_culling), bool(want_isect_ids), bool(TILE_SCHEDULE), pack, cap_box, cap_listed,
+                _len_hint.get(key, 0), row_addr, seq, tuning.address(), stream_int())
+            radii, means2d, depths, conics, tiles_per_gauss, cum_tiles, tile_offsets, keep_scan, flatten_ids = outs
+            tl.records = records
+            event = None
+            if rc == 1:  # counts by asynchronous copy: wait on an event (0: poll the sequence word)
+                event = torch.cuda.Event()
+                event.record()
+            tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
+            tl.cum_tiles, tl.keep_scan, tl.tile_offsets, tl.tile_order = cum_tiles, keep_scan, tile_offsets, tile_order
+            tl.flatten_arena = flatten_ids
+            tl._pending = _PendingCounts(row, slot, event, (key, cap_box, cap_listed), (flatten_ids, isect_ids),
+                                         (means2d, radii, depths, conics, opac, tiles_per_gauss, width, height,
+                                          want_isect_ids), seq, owner)
+            _capacity[key], _cap_listed[key] = cap_box, cap_listed
+            ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics)
+            ctx.dims = (width, height, eps2d)
+            ctx.mark_non_differentiable(radii, tiles_per_gauss)
+            ctx.set_materialize_grads(False)
+            return radii, means2d, depths, conics, tiles_per_gauss
         radii = torch.empty(C, N, dtype=torch.int32, device=dev)
         means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
         depths = torch.empty(C, N, dtype=torch.float32, device=dev)
@@ -717,10 +756,9 @@ class _ProjectAndBin(torch.autograd.Function):
             sort_keys = torch.empty(cap_listed, dtype=torch.int64, device=dev)
             isect_ids = torch.empty(cap_listed, dtype=torch.int64, device=dev) if want_isect_ids else None
             if SPECULATIVE_BINNING:
-                global _stats_slots
                 if _stats_slots is None:
                     _stats_slots = _StatsSlots()
-                row, slot = _stats_slots.take()
+                row, slot, row_addr, owner = _stats_slots.take()
                 seq = _stats_slots.next_seq()
                 row[3] = 0
                 rc = lib.mobgs_project_and_bin_speculative(
@@ -729,7 +767,7 @@ class _ProjectAndBin(torch.autograd.Function):
                     int(_tile_culling), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(tiles_per_gauss),
                     ptr(cum_tiles), ptr(tile_offsets), ptr(tile_order), ptr(stats_dev), cap_box, ptr(keep_scan),
                     ptr(scratch), cap_listed, ptr(flatten_ids), ptr(sort_keys), ptr(isect_ids),
-                    _len_hint.get(key, 0), ctypes.c_void_p(row.data_ptr()), seq,
+                    _len_hint.get(key, 0), ctypes.c_void_p(row_addr), seq,
                     ptr(pack_colors) if records is not None else None,
                     1 if (records is not None and pack_colors.dim() == 3) else 0,
                     pack_colors.shape[-1] if records is not None else 0, ptr(records), tuning.ref(), stream())
@@ -745,7 +783,7 @@ class _ProjectAndBin(torch.autograd.Function):
                 tl.flatten_arena = flatten_ids
                 tl._pending = _PendingCounts(row, slot, event, (key, cap_box, cap_listed), (flatten_ids, isect_ids),
                                              (means2d, radii, depths, conics, opac, tiles_per_gauss, width, height,
-                                              want_isect_ids), seq)
+                                              want_isect_ids), seq, owner)
                 break
             rc = lib.mobgs_project_and_bin(C, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), ptr(opac),
                                            1 if opac.dim() == 2 else 0, width, height, eps2d, near_plane, far_plane,
