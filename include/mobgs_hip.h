@@ -54,11 +54,12 @@ extern "C" {
 /* Per-call policy of the binning / compositing entry points.  The library keeps NO mutable state: what used to be
  * process-wide setters travels with each call (host pointer, may be NULL = all defaults; a negative field = default).
  *   heavy_tile_len     scheduling: a tile whose list has at least this many entries is composited by a whole
- *                      workgroup, one 8x8 quadrant per wave -- for at most an eighth of the tiles, or, on grids of
- *                      fewer than 4096 tiles, as many as bring the launch to 4096 waves (small images cannot fill
- *                      the chip with one wave per tile).  Default 1024 (1 on grids below 4096 tiles); 0 = never.
- *   longest_list_hint  the longest per-tile list the caller expects (e.g. the previous frame's stats[2]): >= 2048
- *                      makes mobgs_isect_offsets rank through LDS first (dense image regions).  Default 0.
+ *                      workgroup, one 8x8 quadrant per wave -- for at most an eighth of the tiles, or all of them
+ *                      on grids of <= 1024 tiles (small images cannot fill the chip with one wave per tile).
+ *                      Default 1024 (1 on grids of <= 1024 tiles); 0 = never.
+ *   longest_list_hint  the longest per-tile list the caller expects (e.g. the previous frame's stats[2]).  Accepted
+ *                      for compatibility: mobgs_isect_offsets now ranks through LDS on every grid of <= 8192 tiles
+ *                      (it used to do so only with a hint >= 2048).  Default 0.
  *   quadrant_culling   testing aid, default 1: the compositors skip, per list entry, the 8x8 quadrants of the tile
  *                      the splat cannot reach (work that is predicated off at every pixel); 0 evaluates everything
  *                      -- results are identical. */

@@ -60,19 +60,15 @@ __host__ __device__ inline TileRect tile_rect(float mx, float my, int radius, in
 // tile_order has sched_slots(n_tiles) entries, 4 per workgroup of the compositing kernels: a tile id, a tile id |
 // SCHED_HEAVY (in all 4 slots of one workgroup: the 4 waves share that tile, one 8x8 quadrant each) or -1 (unused).
 // At most an eighth of the tiles (the longest) are scheduled heavy: when more lists than that are long, long is
-// the norm and no single list is the critical path.  Small images are the exception: with fewer tiles than the chip
-// has wave slots worth filling (SCHED_FILL_WAVES = 4 per SIMD) one wave per tile leaves most of it idle and every
-// list is a critical path, so as many tiles as fit into that many waves may be heavy there -- all 576 of them at
-// 512x288, the reference's own training resolution (raster_fwd 128 -> 66 us, raster_bwd 215 -> 117 us on a
-// 30 k-splat scene).
+// the norm and no single list is the critical path.  Small images are the exception: with no more tiles than the
+// chip has SIMDs (1024) one wave per tile leaves SIMDs idle, exposes every latency and makes every list a critical
+// path, so ALL tiles may be heavy there -- 576 at 512x288, the reference's own training resolution (raster_fwd 128 ->
+// 66 us, raster_bwd 215 -> 113 us on a 30 k-splat scene; a 920-tile grid still gains 1.34x per step, a 1400-tile
+// grid already loses 2 %: four waves per tile pay the per-entry overhead four times).
 constexpr int SCHED_HEAVY = 1 << 30;
-constexpr size_t SCHED_FILL_WAVES = 4096;
+constexpr size_t SCHED_SMALL_GRID = 1024;
 __host__ __device__ inline size_t sched_max_heavy(size_t n_tiles) {
-    const size_t eighth = n_tiles / 8;
-    if (n_tiles >= SCHED_FILL_WAVES) return eighth;
-    size_t fill = (SCHED_FILL_WAVES - n_tiles) / 3;
-    if (fill > n_tiles) fill = n_tiles;
-    return fill > eighth ? fill : eighth;
+    return n_tiles <= SCHED_SMALL_GRID ? n_tiles : n_tiles / 8;
 }
 __host__ __device__ inline size_t sched_slots(size_t n_tiles) { return n_tiles + 3 * sched_max_heavy(n_tiles) + 4; }
 
@@ -187,11 +183,10 @@ int isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width, int he
                          const MobgsTuning* tuning, void* stream);
 
 // per-call policy (include/mobgs_hip.h MobgsTuning): NULL or a negative field = the library default
-// default: lists of >= 1024 entries; on grids too small to fill the chip every non-empty list qualifies (the cap
-// sched_max_heavy then picks the longest ones)
+// default: lists of >= 1024 entries; on grids too small to fill the chip every non-empty list qualifies
 inline int tuning_heavy_len(const MobgsTuning* t, int n_tiles) {
     if (t && t->heavy_tile_len >= 0) return t->heavy_tile_len;
-    return (size_t)n_tiles < SCHED_FILL_WAVES ? 1 : 1024;
+    return (size_t)n_tiles <= SCHED_SMALL_GRID ? 1 : 1024;
 }
 inline int tuning_list_hint(const MobgsTuning* t) { return (t && t->longest_list_hint >= 0) ? t->longest_list_hint : 0; }
 inline int tuning_all_reach(const MobgsTuning* t) { return (t && t->quadrant_culling == 0) ? 1 : 0; }

@@ -174,11 +174,11 @@ static_assert(SCAN_BLOCK == KEEP_CHUNK, "one workgroup per keep_scan chunk");
 // chunk_cnt, so that pass B is a pure streaming scatter that reads 12 bytes per listed entry instead of 16 per
 // bounding-box intersection.
 //
-// DENSE variant (chosen when the previous frame had long lists): a dense image region sends thousands of rank
-// atomics to the same few counters, which serialise in L2 (bin 73 -> 249 us on scripts/heavy_tail.py).  The
-// workgroup first ranks its kept intersections per tile in LDS (one int per tile, dynamic shared memory), then ONE
-// thread per touched tile reserves the workgroup's range with a single global atomic: up to 20x fewer same-address
-// atomics there, ~10 % more work on uniform scenes (hence not the default).
+// DENSE variant (grids of up to DENSE_MAX_TILES tiles): a dense image region sends thousands of rank atomics to the
+// same few counters, which serialise in L2 (bin 73 -> 249 us on scripts/heavy_tail.py).  The workgroup first ranks
+// its kept intersections per tile in LDS (one int per tile, dynamic shared memory), then ONE thread per touched tile
+// reserves the workgroup's range with a single global atomic: up to 20x fewer same-address atomics there, and still
+// ahead on uniform scenes (fewer returning global atomics per chunk).
 template <bool DENSE>
 __global__ void __launch_bounds__(SCAN_THREADS)
 bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
@@ -917,11 +917,9 @@ __global__ void __launch_bounds__(THREADS) tile_sort_kernel(int n_tiles_total, i
 using namespace mobgs;
 
 // MobgsTuning.heavy_tile_len: list length from which a tile is composited by a whole workgroup (scheduling policy,
-// see tile_scan_kernel); MobgsTuning.longest_list_hint: longest list the caller expects (e.g. the previous frame's):
-// selects the dense variant of bin_kernel.  Both travel with the call -- the library keeps no mutable state.
-constexpr int DENSE_LIST_LEN = 2048;
+// see tile_scan_kernel); MobgsTuning.longest_list_hint: longest list the caller expects (no longer consulted here).
+// Both travel with the call -- the library keeps no mutable state.
 constexpr int DENSE_MAX_TILES = 8192;  // 32 KiB of LDS
-constexpr int DENSE_SMALL_GRID = 1024;
 
 extern "C" {
 
@@ -1016,9 +1014,11 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
     // keep flags, per-tile ranks and keep_scan over the first min(I_box, capacity) intersections (the caller
     // re-runs with a larger buffer when stats[0] > capacity); stats[1] = I_listed
     const int n_chunks = (capacity >> KEEP_CHUNK_LOG2) + 1;
-    // dense variant: long lists expected (the caller's hint) and one int per tile fits in LDS -- or a grid so small
-    // that every 2048-intersection chunk hits each tile several times anyway (512x288: 576 tiles, bin 47 -> 33 us)
-    if ((dense_hint >= DENSE_LIST_LEN || nt <= DENSE_SMALL_GRID) && nt <= DENSE_MAX_TILES)
+    // LDS-ranked variant whenever one int per tile fits in LDS: measured faster at every grid size that qualifies
+    // (scripts/ab/sweep_dense.sh: 576 tiles 47 -> 33 us, 1100 tiles 48 -> 40, 2040 tiles 50 -> 46, 5440 tiles 66.6 ->
+    // 65.3), several times faster on dense image regions (long lists); larger grids keep the direct atomics
+    (void)dense_hint;
+    if (nt <= DENSE_MAX_TILES)
         hipLaunchKernelGGL(bin_kernel<true>, dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n, N,
                            tile_w, tile_h, width, height, cull, capacity, cum_tiles, means2d, radii, conics, opacities,
                            opac_per_camera, L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan,
