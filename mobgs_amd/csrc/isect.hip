@@ -698,7 +698,7 @@ __device__ inline int radix_sort_long(const uint64_t* __restrict__ seg, int n, R
 }
 
 // ---------------------------------------------------------------------------------------------------
-// short lists (n <= 512): one WAVE per tile, the bitonic network in registers.
+// short lists (n <= 512 / 1024 / 2048, see tile_sort_short_kernel): one WAVE per tile, the bitonic network in registers.
 //
 // Element i of the (virtually +inf padded) list lives in lane i / EPL, register i % EPL.  Compare-exchange steps
 // with distance < EPL stay inside a lane (register pairs); the others exchange whole registers with lane ^ (j / EPL)
@@ -761,7 +761,9 @@ __device__ __forceinline__ void sort_tile_in_wave(const uint64_t* __restrict__ s
     }
 }
 
-constexpr int WAVE_SORT_MAX = 512;
+// lists of up to 64 * MAXEPL entries sort in registers; three builds of the kernel (MAXEPL = 8 / 16 / 32 keys per lane:
+// 512 / 1024 / 2048 entries) because the register count of the longest network sets the occupancy of all of them
+// (MAXEPL 16: 76 VGPRs, 32: 138 VGPRs = 3 waves per SIMD)
 constexpr int SHORT_SORT_LDS_KEYS = 2048;  // 16 KiB: longer lists belong to the long-list launch (or sort in global memory)
 
 // A workgroup sorts one list of any length: bitonic network in LDS when it fits, in place in global memory else.
@@ -790,8 +792,14 @@ __device__ __forceinline__ void sort_tile_by_block(uint64_t* lds_keys, int lds_c
 }
 
 // All lists of up to n_max entries in ONE launch: four tiles per workgroup; each wave sorts its tile in registers
-// when the list has <= 512 entries (nearly all of them), and the workgroup then takes the longer ones among its four
+// when the list has <= 64 * MAXEPL entries (nearly all of them), and the workgroup then takes the longer ones among
+// its four
 // tiles together, one after the other (LDS network).
+// MAXEPL is chosen from the longest list expected: longer lists than it covers go one at a time through the
+// workgroup's LDS network, which is several times slower per list (800 k splats, mean list 810: 105 us with MAXEPL 8,
+// 56 us with 16; 1.5 M splats, mean 1500: 226 us with 16, 129 us with 32), while a build wider than needed costs
+// occupancy (300 k splats: 27.2 / 28.7 / 28.9 us with 8 / 16 / 32).
+template <int MAXEPL>
 __global__ void __launch_bounds__(256) tile_sort_short_kernel(int n_tiles_total, int tile_bits,
                                                                 const int32_t* __restrict__ tile_offsets,
                                                                 uint64_t* __restrict__ sort_keys,
@@ -806,7 +814,8 @@ __global__ void __launch_bounds__(256) tile_sort_short_kernel(int n_tiles_total,
         s = tile_offsets[t];
         n = tile_offsets[t + 1] - s;
     }
-    if (n > 0 && n <= WAVE_SORT_MAX) {
+    constexpr int WAVE_MAX = 64 * MAXEPL;
+    if (n > 0 && n <= WAVE_MAX) {
         const uint64_t* seg = sort_keys + s;
         const int cam = t / tiles_per_cam, tl = t - cam * tiles_per_cam;
         const uint64_t hi_bits = (((uint64_t)cam << tile_bits) | (uint64_t)tl) << 32;
@@ -814,15 +823,19 @@ __global__ void __launch_bounds__(256) tile_sort_short_kernel(int n_tiles_total,
             sort_tile_in_wave<2>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
         else if (n <= 256)
             sort_tile_in_wave<4>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
-        else
+        else if (MAXEPL == 8 || n <= 512)
             sort_tile_in_wave<8>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
+        else if (MAXEPL == 16 || n <= 1024)
+            sort_tile_in_wave<16>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
+        else
+            sort_tile_in_wave<32>(seg, n, s, hi_bits, flatten_ids, isect_ids, lane);
     }
-    if (!__syncthreads_or(n > WAVE_SORT_MAX && n <= n_max)) return;
+    if (!__syncthreads_or(n > WAVE_MAX && n <= n_max)) return;
     for (int w = 0; w < 4; ++w) {
         const int t2 = blockIdx.x * 4 + w;
         if (t2 >= n_tiles_total) break;
         const int s2 = tile_offsets[t2], n2 = tile_offsets[t2 + 1] - s2;
-        if (n2 <= WAVE_SORT_MAX || n2 > n_max) continue;
+        if (n2 <= WAVE_MAX || n2 > n_max) continue;
         const int cam = t2 / tiles_per_cam, tl = t2 - cam * tiles_per_cam;
         const uint64_t hi_bits = (((uint64_t)cam << tile_bits) | (uint64_t)tl) << 32;
         sort_tile_by_block<256>(lds_keys, SHORT_SORT_LDS_KEYS, sort_keys + s2, n2, s2, hi_bits, flatten_ids, isect_ids);
@@ -1064,8 +1077,11 @@ static int emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t
     const int small_cap = SHORT_SORT_LDS_KEYS, big_cap = 16384;
     const bool split = max_tile_len > small_cap;
     const int nmax_small = split ? small_cap : 0x7fffffff;
-    hipLaunchKernelGGL(tile_sort_short_kernel, dim3((nt + 3) / 4), dim3(256), 0, st, nt, tile_bits, tile_offsets,
-                       sort_keys, flatten_ids, isect_ids, tiles_per_cam, nmax_small);
+    // (max_tile_len: the previous frame's longest list, or this frame's in the synchronous form)
+    auto sort_short = max_tile_len > 1024 ? tile_sort_short_kernel<32>
+                      : max_tile_len > 512 ? tile_sort_short_kernel<16> : tile_sort_short_kernel<8>;
+    hipLaunchKernelGGL(sort_short, dim3((nt + 3) / 4), dim3(256), 0, st, nt, tile_bits, tile_offsets, sort_keys,
+                       flatten_ids, isect_ids, tiles_per_cam, nmax_small);
     if (split) {
         int32_t* long_ids = L.tile_count;
         int32_t* long_count = L.tickets + 1;
