@@ -341,7 +341,9 @@ __device__ __forceinline__ float dpp_add_mirror_odd(float keep, float v) {  // b
     asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\ts_nop 1" : "+v"(keep) : "v"(v));
     return keep;
 }
-__device__ __forceinline__ float wave_reduce16_scatter(float (&v)[16]) {
+template <int N>
+__device__ __forceinline__ float wave_reduce16_scatter(float (&v)[N]) {
+    static_assert(N >= 16, "reduces v[0..15]");
     // the swaps exchange register halves IN PLACE; through the builtin the compiler copies one operand of every
     // swap first (7 v_mov + a 2-cycle bubble each), in assembly the sixteen sums are simply consumed where they lie
     asm volatile(
@@ -379,6 +381,18 @@ __device__ __forceinline__ float wave_reduce16_scatter(float (&v)[16]) {
     w = dpp_add<0xB1>(w);
     w = dpp_add<0x4E>(w);
     return w;
+}
+
+// One or two further components (NV = 17, 18: e.g. 9 features + 2 flow channels + depth) next to the sixteen above:
+// one permlane32 swap + add puts the bit-5 sums of e0 into lanes 0-31 and of e1 into lanes 32-63, four DPP adds
+// all-reduce every 16-lane row, one permlane16 swap of the register with itself + add folds the two rows of each
+// half: 8 instructions, against 80 for the generic 32-component reduction such a kernel used before.  Afterwards
+// lanes 0-31 hold the wave total of e0, lanes 32-63 that of e1.
+__device__ __forceinline__ float wave_reduce_pair(float e0, float e1) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(e0), __float_as_uint(e1), false, false);
+    float x = row_allreduce(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
 // One (pixel, splat) pair of the backward pass: rebuilds the transmittance in front of the splat, forms the
@@ -457,7 +471,10 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
     constexpr int NV = 6 + CD;
-    constexpr int NVP = NV <= 8 ? 8 : (NV <= 16 ? 16 : (NV <= 32 ? 32 : 64));
+    // per-lane gradient sums of one entry: 6 + CD components, padded to what the wave reduction handles -- a power of
+    // two, or sixteen plus 2 / plus 8 (NVX extra components reduced on their own, see below)
+    constexpr int NVX = (NV > 16 && NV <= 24) ? NV - 16 : 0;
+    constexpr int NVP = NV <= 8 ? 8 : (NV <= 16 ? 16 : (NVX ? (NVX <= 2 ? 18 : 24) : (NV <= 32 ? 32 : 64)));
     constexpr int PPL = NP;
     constexpr bool HEAVY = NP == 1;
     auto& slab = sh.slab;
@@ -608,21 +625,36 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                     float* dst = HEAVY ? &sh.part[wv][j][0] : grad_slots + (size_t)slot_of[wv][j] * RS;
                     dst[lane >> 2] = w;
                 }
-                continue;
-            }
-            wave_reduce_components<NVP>(g);
-            // lane 0 of each 16-lane row stores its NVP/4 consecutive components
-            constexpr int Q = NVP / 4;
-            const int base = (lane >> 5) * (NVP / 2) + ((lane >> 4) & 1) * Q;
-            if ((lane & 15) == 0 && base < RS) {
-                float* dst = HEAVY ? &sh.part[wv][j][base] : grad_slots + (size_t)slot_of[wv][j] * RS + base;
-                if constexpr (Q == 2) {
-                    *reinterpret_cast<float2*>(dst) = make_float2(g[0], g[1]);
+            } else if constexpr (NVX > 0) {
+                float* dst = HEAVY ? &sh.part[wv][j][0] : grad_slots + (size_t)slot_of[wv][j] * RS;
+                if constexpr (NVX <= 2) {
+                    const float x = wave_reduce_pair(g[16], g[17]);
+                    if ((lane & 31) == 0 && (lane >> 5) < NVX) dst[16 + (lane >> 5)] = x;
                 } else {
+                    float ext[8];
 #pragma unroll
-                    for (int q = 0; q < Q; q += 4)
-                        if (base + q < RS)
-                            *reinterpret_cast<float4*>(dst + q) = make_float4(g[q], g[q + 1], g[q + 2], g[q + 3]);
+                    for (int i = 0; i < 8; ++i) ext[i] = g[16 + i];
+                    wave_reduce_components<8>(ext);  // row r: components 16 + (r >> 1) * 4 + (r & 1) * 2 + {0, 1}
+                    const int base = 16 + (lane >> 5) * 4 + ((lane >> 4) & 1) * 2;
+                    if ((lane & 15) == 0 && base < RS) *reinterpret_cast<float2*>(dst + base) = make_float2(ext[0], ext[1]);
+                }
+                const float w = wave_reduce16_scatter(g);
+                if ((lane & 3) == 0) dst[lane >> 2] = w;
+            } else {
+                wave_reduce_components<NVP>(g);
+                // lane 0 of each 16-lane row stores its NVP/4 consecutive components
+                constexpr int Q = NVP / 4;
+                const int base = (lane >> 5) * (NVP / 2) + ((lane >> 4) & 1) * Q;
+                if ((lane & 15) == 0 && base < RS) {
+                    float* dst = HEAVY ? &sh.part[wv][j][base] : grad_slots + (size_t)slot_of[wv][j] * RS + base;
+                    if constexpr (Q == 2) {
+                        *reinterpret_cast<float2*>(dst) = make_float2(g[0], g[1]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < Q; q += 4)
+                            if (base + q < RS)
+                                *reinterpret_cast<float4*>(dst + q) = make_float4(g[q], g[q + 1], g[q + 2], g[q + 3]);
+                    }
                 }
             }
         }
@@ -653,7 +685,7 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
 }
 
 template <int CD, bool FILTER>
-__global__ void __launch_bounds__(64 * TILES_PER_WG) __attribute__((amdgpu_waves_per_eu(CD <= 10 ? 4 : 1)))
+__global__ void __launch_bounds__(64 * TILES_PER_WG) __attribute__((amdgpu_waves_per_eu(CD <= 10 ? 4 : (CD <= 16 ? 3 : 1))))
 raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
                   const float* __restrict__ records, const float* __restrict__ backgrounds,
                   const int32_t* __restrict__ radii, const int32_t* __restrict__ cum_tiles,

@@ -388,7 +388,7 @@ def _flow_mid_state(cam, stat_pc, dyn_pc, dev):
     return _R.SharedProjection(mid_m, mid_q, scales, opac, viewmat[None], cam.K[None], W, H)
 
 
-def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=None, _mid=None):
+def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=None, _mid=None, _defer_mid=False):
     """/root/reference/gaussian_renderer/__init__.py:318-492 ->
     (exp2mid_coord_map [1,H,W,2], mid2exp_coord_map [1,H,W,2], latent_img [3,H,W], latent_alpha [1,H,W])."""
     cam = viewpoint_camera
@@ -423,18 +423,34 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     e2m_img = img12[..., 9:11]
     pix = _pixel_grid(cam, W, H, e2m_img)
     exp2mid = pix + e2m_img
-    mid2exp = pix + splat(sp_mid, -e2m)
+    # get_flow_many splats the mid-exposure flows of several calls in one walk over the shared lists
+    mid2exp = (pix, e2m) if _defer_mid else pix + splat(sp_mid, -e2m)
     latent_img, _ = decode(img12, alphas, _rays_of(cam), w1, w2, False)  # reads the 9 feature channels only
     return exp2mid, mid2exp, latent_img, latent_alpha
 
 
 def get_flow_many(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposures):
     """[get_flow(..., delta_exposure=d) for d in delta_exposures] -- the 9 calls per view of train.py:570-579 -- with
-    the mid-exposure prep / projection / tile lists (which do not depend on d) built once and shared by all of them
-    (not in the reference; the results are identical)."""
-    mid = _flow_mid_state(viewpoint_camera, stat_pc, dyn_pc, _device_of(dyn_pc))
-    return [get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=d, _mid=mid)
+    the mid-exposure prep / projection / tile lists (which do not depend on d) built once and shared by all of them,
+    and the mid-to-exposure flow maps of up to 8 calls splatted in ONE walk over those lists (2 channels each: the
+    cost of a compositing pass is its alpha evaluations, not its channels -- nine 2-channel passes take 9 x 0.58 ms
+    forward + backward, one 16-channel pass ~1.5 ms).  Not in the reference; the images are identical (channels
+    accumulate independently), gradients equal up to summation order."""
+    cam = viewpoint_camera
+    mid = _flow_mid_state(cam, stat_pc, dyn_pc, _device_of(dyn_pc))
+    outs = [list(get_flow(cam, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=d, _mid=mid, _defer_mid=True))
             for d in delta_exposures]
+    W, H = int(cam.image_width), int(cam.image_height)
+    for g0 in range(0, len(outs), _FLOW_GROUP):
+        grp = outs[g0:g0 + _FLOW_GROUP]
+        cols = torch.cat([-o[1][1] for o in grp], dim=-1)  # [N, 2 * len(grp)]
+        img = _R.rasterize_to_pixels(mid.means2d, mid.conics, cols, mid.opacities, mid.radii, mid.tl, W, H)[0]
+        for i, o in enumerate(grp):
+            o[1] = o[1][0] + img[..., 2 * i:2 * i + 2]
+    return [tuple(o) for o in outs]
+
+
+_FLOW_GROUP = 8  # exposures per mid-list walk: 16 channels, the widest compositor build below the 26-channel one
 
 
 _ones_cache = {}
