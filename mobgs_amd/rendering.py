@@ -414,6 +414,7 @@ class _Rasterize(torch.autograd.Function):
                 if tl.defer or not tl.resolve():
                     break
         ctx.save_for_backward(records, bg, radii, means2d, alphas, last_ids, reach)
+        ctx.set_materialize_grads(False)  # an output nothing back-propagates through costs no zero image
         ctx.tl = tl
         ctx.arena = tl.flatten_arena  # the lists `reach` belongs to (a rebuild replaces the arena)
         ctx.meta = (C, N, channels, extra is not None, width, height, colors_per_camera, opac_per_camera)
@@ -431,6 +432,10 @@ class _Rasterize(torch.autograd.Function):
         dev = records.device
         D = channels + (1 if has_extra else 0)
         stride = records.shape[1]
+        if v_render is None and v_alphas is None:
+            return (None,) * 11
+        if v_render is None:  # only the alpha output was used
+            v_render = torch.zeros(C, height, width, D, dtype=torch.float32, device=dev)
         F = _fast.get()
         if F is not None:  # the same body in C++ (csrc/fastpath.cpp)
             st = stream_int()
