@@ -234,17 +234,21 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
  *     splat's tile rectangle].  grad_slots must be zero-filled by the caller (intersections that no pixel blended stay 0).
  *   stage 2 (mobgs_raster_bwd_reduce) sums each splat's contiguous slots into the dense gradients
  *     v_means2d [C,N,2], v_conics [C,N,3], v_opacities [C,N], v_colors [C,N,channels], v_extra [C,N] (NULL when
- *     there was no extra channel); all fully written. */
+ *     there was no extra channel); all fully written.
+ *   any_record (optional, both stages the same zero-initialised int32; NULL = off): stage 1 sets it when it writes
+ *     its first record, stage 2 reads no slot when it is still 0 -- a pass whose cotangents are all exactly zero (a
+ *     loss term with weight 0, e.g. lambda_flow_loss = 0 in arguments/stereo/seesaw.py) then costs no reduction. */
 int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int height,
                      const float* records, const float* backgrounds, const int32_t* radii,
                      const float* means2d, const int32_t* cum_tiles, const int32_t* keep_scan,
                      const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
                      const float* render_alphas, const int32_t* last_ids, const float* v_render,
                      const float* v_alphas, float* grad_slots, const uint8_t* isect_reach,
-                     const MobgsTuning* tuning, void* stream);
+                     int32_t* any_record, const MobgsTuning* tuning, void* stream);
 int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int32_t* cum_tiles,
-                            const int32_t* keep_scan, const float* grad_slots, float* v_means2d, float* v_conics, float* v_opacities,
-                            float* v_colors, float* v_extra, void* stream);
+                            const int32_t* keep_scan, const float* grad_slots, const int32_t* any_record,
+                            float* v_means2d, float* v_conics, float* v_opacities, float* v_colors, float* v_extra,
+                            void* stream);
 
 /* Packs the compositor's per-splat inputs into records [C*N, mobgs_record_stride(D)] (the first step of
  * mobgs_raster_fwd, exposed for mobgs_raster_layers_fwd). */

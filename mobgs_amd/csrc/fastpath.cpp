@@ -216,7 +216,8 @@ raster_fwd(int64_t C, int64_t N, int64_t channels, int64_t width, int64_t height
     return {records, render, alphas, last_ids, reach};
 }
 
-// -> zero-filled gradient slots [max(n_isects,1), stride] with the per-entry records written by the kernel
+// -> zero-filled gradient slots [max(n_isects,1) + 1, stride] with the per-entry records written by the kernel; the
+// first word of the extra last row is the any_record flag of include/mobgs_hip.h (zeroed by the same fill)
 Tensor raster_bwd(int64_t C, int64_t N, int64_t channels, int64_t has_extra, int64_t width, int64_t height,
                   int64_t n_isects, const Tensor& records, const OptT& bg, const Tensor& radii, const Tensor& means2d,
                   const Tensor& cum_tiles, const Tensor& keep_scan, const Tensor& tile_offsets, const OptT& tile_order,
@@ -224,11 +225,13 @@ Tensor raster_bwd(int64_t C, int64_t N, int64_t channels, int64_t has_extra, int
                   const OptT& v_alphas_in, const OptT& reach, int64_t tuning, int64_t stream) {
     const Tensor v_render = f32c(v_render_in);
     const OptT v_alphas = f32c(v_alphas_in);
-    Tensor slots = at::zeros({std::max<int64_t>(n_isects, 1), records.size(1)}, records.options());
+    const int64_t rows = std::max<int64_t>(n_isects, 1), stride = records.size(1);
+    Tensor slots = at::zeros({rows + 1, stride}, records.options());
+    int32_t* flag = reinterpret_cast<int32_t*>(fpw(slots) + rows * stride);
     check(api.raster_bwd((int)C, (int)N, (int)channels, (int)has_extra, (int)width, (int)height, fp(records), fp(bg),
                          ip(radii), fp(means2d), ip(cum_tiles), ip(keep_scan), ip(tile_offsets), ip(tile_order),
                          ip(flatten_ids), fp(alphas), ip(last_ids), fp(v_render), fp(v_alphas), fpw(slots),
-                         static_cast<const uint8_t*>(dp(reach)), tp(tuning), sp(stream)),
+                         static_cast<const uint8_t*>(dp(reach)), flag, tp(tuning), sp(stream)),
           "mobgs_raster_bwd");
     return slots;
 }
@@ -241,8 +244,10 @@ raster_bwd_reduce(int64_t C, int64_t N, int64_t channels, int64_t has_extra, con
     Tensor v_means2d = at::empty({C, N, 2}, f), v_conics = at::empty({C, N, 3}, f), v_opac = at::empty({C, N}, f),
            v_colors = at::empty({C, N, channels}, f);
     OptT v_extra = has_extra ? OptT(at::empty({C, N}, f)) : OptT();
+    const int32_t* flag = reinterpret_cast<const int32_t*>(fp(slots) + (slots.size(0) - 1) * slots.size(1));
     check(api.raster_bwd_reduce((int)C, (int)N, (int)channels, (int)has_extra, ip(cum_tiles), ip(keep_scan), fp(slots),
-                                fpw(v_means2d), fpw(v_conics), fpw(v_opac), fpw(v_colors), fpw(v_extra), sp(stream)),
+                                flag, fpw(v_means2d), fpw(v_conics), fpw(v_opac), fpw(v_colors), fpw(v_extra),
+                                sp(stream)),
           "mobgs_raster_bwd_reduce");
     return {v_means2d, v_conics, v_opac, v_colors, v_extra};
 }

@@ -467,7 +467,8 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                                               const int32_t* __restrict__ last_ids,
                                               const float* __restrict__ v_render, const float* __restrict__ v_alphas,
                                               float* __restrict__ grad_slots,
-                                              const uint8_t* __restrict__ isect_reach) {
+                                              const uint8_t* __restrict__ isect_reach,
+                                              int32_t* __restrict__ any_record) {
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
     constexpr int NV = 6 + CD;
@@ -543,6 +544,10 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
         top = max(max(sh.top[0], sh.top[1]), max(sh.top[2], sh.top[3]));
     }
     top = min(top, e - 1);
+    // tells stage 2 that there may be something to sum (see mobgs_raster_bwd): once per wave with a non-empty walk --
+    // when every cotangent of the pass is zero no pixel is valid, top stays below s and nobody sets it.  (Setting it
+    // at the first record instead cost 16 us of the 540: a branch per list entry.)
+    if (any_record && top >= s && lane == 0) *any_record = 1;
 
     for (int hi = top; hi >= s; hi -= 64) {
         int n = min(64, hi - s + 1);
@@ -694,7 +699,7 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
                   const int32_t* __restrict__ last_ids,
                   const float* __restrict__ v_render, const float* __restrict__ v_alphas,
                   float* __restrict__ grad_slots, const int32_t* __restrict__ tile_order, ClassSel cls,
-                  const uint8_t* __restrict__ isect_reach) {
+                  const uint8_t* __restrict__ isect_reach, int32_t* __restrict__ any_record) {
     __shared__ BwdShared<CD> sh;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
@@ -702,11 +707,11 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
     if (slot & SCHED_HEAVY)  // workgroup-uniform: all 4 slots of a heavy workgroup carry the flag
         composite_bwd<CD, 1, FILTER>(slot & ~SCHED_HEAVY, wv, wv, lane, sh, cls, tile_w, tile_h, width, height, records,
                                      backgrounds, radii, cum_tiles, keep_scan, tile_offsets, flatten_ids,
-                                     render_alphas, last_ids, v_render, v_alphas, grad_slots, isect_reach);
+                                     render_alphas, last_ids, v_render, v_alphas, grad_slots, isect_reach, any_record);
     else
         composite_bwd<CD, 4, FILTER>(slot, 0, wv, lane, sh, cls, tile_w, tile_h, width, height, records, backgrounds,
                                      radii, cum_tiles, keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids,
-                                     v_render, v_alphas, grad_slots, isect_reach);
+                                     v_render, v_alphas, grad_slots, isect_reach, any_record);
 }
 
 
@@ -718,11 +723,14 @@ __global__ void __launch_bounds__(256)
 slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, const int32_t* __restrict__ cum_tiles,
                    const int32_t* __restrict__ keep_scan, const float* __restrict__ grad_slots, float* __restrict__ v_means2d,
                    float* __restrict__ v_conics, float* __restrict__ v_opacities, float* __restrict__ v_colors,
-                   float* __restrict__ v_extra) {
+                   float* __restrict__ v_extra, const int32_t* __restrict__ any_record) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPG;
     const int comp = threadIdx.x % LPG;
     if (gid >= n_gauss) return;
-    const int a = keep_index(keep_scan, cum_tiles[gid]), b = keep_index(keep_scan, cum_tiles[gid + 1]);
+    // stage 1 wrote no record at all (every cotangent of the pass was zero): all sums are zero, read nothing
+    const bool none = any_record && *any_record == 0;
+    const int a = none ? 0 : keep_index(keep_scan, cum_tiles[gid]);
+    const int b = none ? 0 : keep_index(keep_scan, cum_tiles[gid + 1]);
     float acc = 0.f;
     if (comp < stride) {
         // 4 independent partial sums keep 4 loads in flight per lane (the loop is latency-bound otherwise);
@@ -763,14 +771,15 @@ __global__ void __launch_bounds__(256)
 slot_reduce16_kernel(int n_gauss, int channels, int has_extra, const int32_t* __restrict__ cum_tiles,
                      const int32_t* __restrict__ keep_scan, const float* __restrict__ grad_slots,
                      float* __restrict__ v_means2d, float* __restrict__ v_conics, float* __restrict__ v_opacities,
-                     float* __restrict__ v_colors, float* __restrict__ v_extra) {
+                     float* __restrict__ v_colors, float* __restrict__ v_extra,
+                     const int32_t* __restrict__ any_record) {
     constexpr int SUBS = LPS / 4;
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPS;
     const int l16 = threadIdx.x & (LPS - 1);
     const int q = l16 & 3, sub = l16 >> 2;
     const bool live = gid < n_gauss;
     int a = 0, b = 0;
-    if (live) {
+    if (live && !(any_record && *any_record == 0)) {  // (no record written by stage 1: every sum is zero)
         a = keep_index(keep_scan, cum_tiles[gid]);
         b = keep_index(keep_scan, cum_tiles[gid + 1]);
     }
@@ -905,7 +914,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
                      const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
                      const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
                      const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
-                     const uint8_t* isect_reach, const MobgsTuning* tuning, void* stream) {
+                     const uint8_t* isect_reach, int32_t* any_record, const MobgsTuning* tuning, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int g_all_reach = tuning_all_reach(tuning);
     (void)means2d;
@@ -924,7 +933,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
         hipLaunchKernelGGL((raster_bwd_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
                            tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan,
                            tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots,
-                           tile_order, ClassSel{0, 1, 0, g_all_reach}, isect_reach);
+                           tile_order, ClassSel{0, 1, 0, g_all_reach}, isect_reach, any_record);
     });
     if (rc != MOBGS_OK) {
         set_error("mobgs_raster_bwd: %d total channels not compiled in", D);
@@ -972,13 +981,14 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
     hipLaunchKernelGGL((raster_bwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream, nt,
                        n_groups, tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan,
                        tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots, tile_order,
-                       ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach);
+                       ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach, (int32_t*)nullptr);
     return check_launch("raster_bwd_kernel(class)");
 }
 
 int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int32_t* cum_tiles,
-                            const int32_t* keep_scan, const float* grad_slots, float* v_means2d, float* v_conics, float* v_opacities,
-                            float* v_colors, float* v_extra, void* stream) {
+                            const int32_t* keep_scan, const float* grad_slots, const int32_t* any_record,
+                            float* v_means2d, float* v_conics, float* v_opacities, float* v_colors, float* v_extra,
+                            void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int D = channels + (has_extra ? 1 : 0);
     if (C <= 0 || N < 0 || D < 1) {
@@ -991,19 +1001,19 @@ int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int
         if (stride <= 8) {
             hipLaunchKernelGGL(slot_reduce_kernel<8>, dim3((n * 8 + 255) / 256), dim3(256), 0, st, n, channels,
                                has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities, v_colors,
-                               v_extra);
+                               v_extra, any_record);
         } else if (stride == 16) {
             hipLaunchKernelGGL(slot_reduce16_kernel<8>, dim3((int)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
-                               v_colors, v_extra);
+                               v_colors, v_extra, any_record);
         } else if (stride <= 16) {
             hipLaunchKernelGGL(slot_reduce_kernel<16>, dim3((int)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
-                               v_colors, v_extra);
+                               v_colors, v_extra, any_record);
         } else {
             hipLaunchKernelGGL(slot_reduce_kernel<32>, dim3((int)(((size_t)n * 32 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
-                               v_colors, v_extra);
+                               v_colors, v_extra, any_record);
         }
     }
     return check_launch("slot_reduce_kernel");

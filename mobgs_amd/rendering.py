@@ -9,6 +9,7 @@ include/mobgs_hip.h.  Options the reference never uses raise NotImplementedError
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import os
 from typing import Dict, Optional, Tuple
@@ -448,7 +449,10 @@ class _Rasterize(torch.autograd.Function):
         else:
             v_render = f32c(v_render)
             v_alphas = f32c(v_alphas) if v_alphas is not None else None
-            slots = torch.zeros(max(tl.n_isects, 1), stride, dtype=torch.float32, device=dev)
+            # one extra row: its first word is the any_record flag of include/mobgs_hip.h (zeroed by the same fill)
+            rows = max(tl.n_isects, 1)
+            slots = torch.zeros(rows + 1, stride, dtype=torch.float32, device=dev)
+            flag = ctypes.c_void_p(slots.data_ptr() + 4 * rows * stride)
             v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
             v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
             v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
@@ -459,10 +463,10 @@ class _Rasterize(torch.autograd.Function):
                                            ptr(radii), ptr(means2d), ptr(tl.cum_tiles), ptr(tl.keep_scan),
                                            ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas),
                                            ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(slots), ptr(reach),
-                                           tuning.ref(), stream()), "mobgs_raster_bwd")
+                                           flag, tuning.ref(), stream()), "mobgs_raster_bwd")
             check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(tl.cum_tiles), ptr(tl.keep_scan),
-                                              ptr(slots), ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors),
-                                              ptr(v_extra), stream()), "mobgs_raster_bwd_reduce")
+                                              ptr(slots), flag, ptr(v_means2d), ptr(v_conics), ptr(v_opac),
+                                              ptr(v_colors), ptr(v_extra), stream()), "mobgs_raster_bwd_reduce")
         if not colors_per_camera:
             v_colors = v_colors.sum(0) if C > 1 else v_colors[0]
         if not opac_per_camera:
@@ -670,7 +674,7 @@ class _RasterizeClasses(torch.autograd.Function):
         v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
         v_colors = torch.empty(C, N, channels, dtype=torch.float32, device=dev)
         v_extra = torch.empty(C, N, dtype=torch.float32, device=dev)
-        check(lib.mobgs_raster_bwd_reduce(C, N, channels, 1, ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(slots),
+        check(lib.mobgs_raster_bwd_reduce(C, N, channels, 1, ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(slots), None,
                                           ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra),
                                           stream()), "mobgs_raster_bwd_reduce")
         if not colors_per_camera:

@@ -559,3 +559,28 @@ def test_small_grids_go_heavy_by_default(hip_device):
     for k, ref in res["light"][2].items():
         tol = 2e-5 * float(ref.abs().max()) + 1e-9
         assert float((res["default"][2][k] - ref).abs().max()) <= tol, k
+
+
+@pytest.mark.parametrize("channels", [9, 2])
+def test_zero_cotangents_give_exact_zero_gradients(hip_device, channels):
+    """A compositing pass whose cotangents are all exactly zero (a loss term with weight 0) writes no gradient record;
+    the per-splat reduction then reads no slot (any_record flag, include/mobgs_hip.h) and every gradient is an exact
+    zero -- while a single non-zero cotangent pixel brings back the ordinary result."""
+    from mobgs_amd.rendering import rasterization
+    n, w, h = 5000, 200, 152
+    s, _ = _scene(n, w, h, 17, channels)
+    names = ["means", "quats", "scales", "opacities", "colors"]
+    res = {}
+    for mode in ("zero", "one_pixel"):
+        t = {k: v.to(hip_device).clone().requires_grad_(k in names) for k, v in s.items()}
+        img, a, _ = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], t["viewmats"],
+                                  t["Ks"], w, h, packed=False, render_mode="RGB")
+        v = torch.zeros_like(img)
+        if mode == "one_pixel":
+            v[0, h // 2, w // 2, 0] = 1.0
+        torch.autograd.backward([img, a], [v, torch.zeros_like(a)])
+        res[mode] = {k: t[k].grad.cpu() for k in names}
+    for k, g in res["zero"].items():
+        assert float(g.abs().max()) == 0.0, k
+    assert float(res["one_pixel"]["colors"].abs().max()) > 0.0
+    assert float(res["one_pixel"]["means"].abs().max()) > 0.0
