@@ -445,8 +445,10 @@ def get_flow_many(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_expos
         grp = outs[g0:g0 + _FLOW_GROUP]
         cols = torch.cat([-o[1][1] for o in grp], dim=-1)  # [N, 2 * len(grp)]
         img = _R.rasterize_to_pixels(mid.means2d, mid.conics, cols, mid.opacities, mid.radii, mid.tl, W, H)[0]
-        for i, o in enumerate(grp):
-            o[1] = o[1][0] + img[..., 2 * i:2 * i + 2]
+        # split, not slices: its backward is ONE concatenation of the 2-channel cotangents instead of a zero image, a
+        # strided copy and an add per call
+        for o, part in zip(grp, img.split(2, dim=-1)):
+            o[1] = o[1][0] + part
     return [tuple(o) for o in outs]
 
 

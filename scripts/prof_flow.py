@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--zero-weight", action="store_true")
     ap.add_argument("--separate", action="store_true")
     ap.add_argument("--no-sink", action="store_true", help="plain loss.backward() without ops.LeafGradSink")
+    ap.add_argument("--torch-ops", action="store_true", help="list the PyTorch ops of one step that launch device work")
     ap.add_argument("--ns", type=int, default=200_000)
     ap.add_argument("--nd", type=int, default=100_000)
     ap.add_argument("--width", type=int, default=1352)
@@ -57,6 +58,17 @@ def main():
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
+    if a.torch_ops:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        tot = 0.0
+        for e in sorted(prof.key_averages(group_by_input_shape=True), key=lambda e: -e.self_device_time_total):
+            if e.self_device_time_total > 0 and (e.key.startswith(("aten::", "Memcpy", "Memset"))):
+                tot += e.self_device_time_total
+                print(f"{e.key[:40]:40s} n={e.count:4d} dev={e.self_device_time_total:9.1f}us  {str(e.input_shapes)[:110]}")
+        print(f"total {tot:.1f} us")
     print(f"9 x get_flow fwd+bwd: {(time.perf_counter() - t0) / a.steps * 1e3:.3f} ms per view "
           f"({'zero' if a.zero_weight else 'random'} cotangents, {'separate calls' if a.separate else 'get_flow_many'})")
 
