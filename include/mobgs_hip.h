@@ -331,8 +331,10 @@ int mobgs_normals_bwd(int H, int W, float fx, float fy, float cx, float cy, floa
  * of the WHOLE set: entries of the other class are dropped as each 64-entry batch is staged.  Every splat belongs
  * to exactly one class, so the two passes together blend each (tile, splat) pair once and their backward passes
  * write disjoint records of ONE grad_slots buffer (zero-filled [I_listed, stride]), reduced by one
- * mobgs_raster_bwd_reduce.  10 total channels (9 features + depth); records from mobgs_pack_records; last_ids index
- * the whole set's lists. */
+ * mobgs_raster_bwd_reduce.  channels_total = 10 (9 features + depth), or 1 (one colour channel, no extra: the
+ * dynamic-only coverage of get_flow(), /root/reference/gaussian_renderer/__init__.py:477-490, where only the alpha
+ * output matters); records from mobgs_pack_records; last_ids index the whole set's lists; any_record as in
+ * mobgs_raster_bwd. */
 int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_total, int width, int height,
                            const float* records, const float* backgrounds, const int32_t* tile_offsets,
                            const int32_t* tile_order, const int32_t* flatten_ids, float* render, float* alphas,
@@ -342,7 +344,7 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
                            const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
                            const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
                            const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
-                           const uint8_t* isect_reach, const MobgsTuning* tuning, void* stream);
+                           const uint8_t* isect_reach, int32_t* any_record, const MobgsTuning* tuning, void* stream);
 
 /* 1 if raster kernels are compiled for `total_channels` (colour channels + optional extra channel). */
 int mobgs_raster_channels_supported(int total_channels);

@@ -67,7 +67,7 @@ _SIGS = {
     "mobgs_normals_fwd": (c_int, [c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P]),
     "mobgs_normals_bwd": (c_int, [c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P, P]),
     "mobgs_raster_class_fwd": (c_int, [c_int] * 7 + [P] * 9 + [P, P]),
-    "mobgs_raster_class_bwd": (c_int, [c_int] * 7 + [P] * 14 + [P, P]),
+    "mobgs_raster_class_bwd": (c_int, [c_int] * 7 + [P] * 15 + [P, P]),
     "mobgs_pack_records": (c_int, [c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P]),
     "mobgs_raster_layers_fwd": (c_int, [c_int] * 7 + [P] * 8 + [P]),
     "mobgs_raster_layers_bwd": (c_int, [c_int] * 8 + [P] * 20 + [P]),  # incl. 7 host pointer arrays of length 3

@@ -942,13 +942,15 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
     return check_launch("raster_bwd_kernel");
 }
 
-// class-restricted passes over the lists of the whole set (10 total channels: the render() configuration)
+// class-restricted passes over the lists of the whole set: 10 total channels (the render() configuration) or 1 (the
+// dynamic-only coverage of get_flow(): only the alpha output matters there)
 int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_total, int width, int height,
                            const float* records, const float* backgrounds, const int32_t* tile_offsets,
                            const int32_t* tile_order, const int32_t* flatten_ids, float* render, float* alphas,
                            int32_t* last_ids, uint8_t* isect_reach, const MobgsTuning* tuning, void* stream) {
     const int g_all_reach = tuning_all_reach(tuning);
-    if (C <= 0 || N <= 0 || Ns < 0 || Ns > N || (class_sel != 1 && class_sel != 2) || channels_total != 10) {
+    if (C <= 0 || N <= 0 || Ns < 0 || Ns > N || (class_sel != 1 && class_sel != 2) ||
+        (channels_total != 10 && channels_total != 1)) {
         set_error("mobgs_raster_class_fwd: unsupported arguments (C=%d N=%d Ns=%d class=%d D=%d)", C, N, Ns, class_sel,
                   channels_total);
         return MOBGS_E_UNSUPPORTED;
@@ -957,9 +959,14 @@ int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_tot
     const int nt = C * tile_w * tile_h;
     const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
-    hipLaunchKernelGGL((raster_fwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream, nt,
-                       n_groups, tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render,
-                       alphas, last_ids, tile_order, ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach);
+    if (channels_total == 10)
+        hipLaunchKernelGGL((raster_fwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream,
+                           nt, n_groups, tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids,
+                           render, alphas, last_ids, tile_order, ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach);
+    else
+        hipLaunchKernelGGL((raster_fwd_kernel<1, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream,
+                           nt, n_groups, tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids,
+                           render, alphas, last_ids, tile_order, ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach);
     return check_launch("raster_fwd_kernel(class)");
 }
 
@@ -968,9 +975,10 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
                            const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
                            const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
                            const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
-                           const uint8_t* isect_reach, const MobgsTuning* tuning, void* stream) {
+                           const uint8_t* isect_reach, int32_t* any_record, const MobgsTuning* tuning, void* stream) {
     const int g_all_reach = tuning_all_reach(tuning);
-    if (C <= 0 || N <= 0 || Ns < 0 || Ns > N || (class_sel != 1 && class_sel != 2) || channels_total != 10) {
+    if (C <= 0 || N <= 0 || Ns < 0 || Ns > N || (class_sel != 1 && class_sel != 2) ||
+        (channels_total != 10 && channels_total != 1)) {
         set_error("mobgs_raster_class_bwd: unsupported arguments");
         return MOBGS_E_UNSUPPORTED;
     }
@@ -978,10 +986,16 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
     const int nt = C * tile_w * tile_h;
     const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
-    hipLaunchKernelGGL((raster_bwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream, nt,
-                       n_groups, tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan,
-                       tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots, tile_order,
-                       ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach, (int32_t*)nullptr);
+    if (channels_total == 10)
+        hipLaunchKernelGGL((raster_bwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream,
+                           nt, n_groups, tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles,
+                           keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas,
+                           grad_slots, tile_order, ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach, any_record);
+    else
+        hipLaunchKernelGGL((raster_bwd_kernel<1, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream,
+                           nt, n_groups, tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles,
+                           keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas,
+                           grad_slots, tile_order, ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach, any_record);
     return check_launch("raster_bwd_kernel(class)");
 }
 

@@ -409,13 +409,11 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     def splat(sp, colors):
         return _R.rasterize_to_pixels(sp.means2d, sp.conics, colors, opac, sp.radii, sp.tl, W, H)[0]
 
-    # dynamic-only coverage (:477-490): its own (smaller) projection and lists, without a host synchronisation
-    dyn_sl = slice(Ns, None)
-    sp_dyn = _R.SharedProjection(exp_m[dyn_sl], exp_q[dyn_sl], scales[dyn_sl], opac[dyn_sl], viewmat[None], K[None],
-                                 W, H)
-    ones = _ones_column(exp_c.shape[0] - Ns, dev)
-    latent_alpha = _R.rasterize_to_pixels(sp_dyn.means2d, sp_dyn.conics, ones, opac[dyn_sl], sp_dyn.radii, sp_dyn.tl,
-                                          W, H, backgrounds=bg[0:1][None])[0][..., 0]
+    # dynamic-only coverage (:477-490: a rasterization of the dynamic splats alone with a ones colour): a
+    # class-restricted walk over the exposure-time lists of the whole set -- the same image without projecting,
+    # binning and sorting the dynamic third a second time; sum_i w_i + T_final * bg = (1 - T) + T * bg
+    a_dyn = sp_exp.class_alpha(Ns, 2)
+    latent_alpha = a_dyn + (1.0 - a_dyn) * bg[0]
     e2m = (sp_mid.means2d - sp_exp.means2d).squeeze(0)
     # the exposure-time lists are walked ONCE for the 9 colour features and the 2 flow channels (the reference: one
     # rasterization each, :436-452 and :461-476; channels accumulate independently, so the images are identical)
@@ -453,19 +451,6 @@ def get_flow_many(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_expos
 
 
 _FLOW_GROUP = 8  # exposures per mid-list walk: 16 channels, the widest compositor build below the 26-channel one
-
-
-_ones_cache = {}
-
-
-def _ones_column(n, dev):
-    key = (n, str(dev))
-    t = _ones_cache.get(key)
-    if t is None:
-        if len(_ones_cache) > 8:
-            _ones_cache.clear()
-        t = _ones_cache[key] = torch.ones(n, 1, device=dev)
-    return t
 
 
 def get_flow_static(source_camera, target_camera, splat_camera, stat_pc, dyn_pc, pipe, bg_color):

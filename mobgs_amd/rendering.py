@@ -477,6 +477,99 @@ class _Rasterize(torch.autograd.Function):
         return v_means2d, v_conics, v_colors, v_opac, v_extra, v_bg, None, None, None, None, None
 
 
+class _RasterizeClassAlpha(torch.autograd.Function):
+    """Coverage (alpha = 1 - final transmittance) of ONE class of a projected set -- the first Ns splats (class_sel 1)
+    or the rest (2) -- over the tile lists of the WHOLE set: what a rasterization of that subset alone with a ones
+    colour returns as alpha, without projecting, binning and sorting the subset a second time
+    (/root/reference/gaussian_renderer/__init__.py:477-490 does exactly that for the dynamic splats in get_flow()).
+    mobgs_raster_class_fwd/bwd with one channel; -> alphas [C,H,W]."""
+
+    @staticmethod
+    def forward(ctx, means2d, conics, opacities, radii, tl: TileLists, width, height, Ns, class_sel):
+        lib = _lib_()
+        C, N = radii.shape
+        dev = means2d.device
+        means2d, conics, opacities = map(f32c, (means2d, conics, opacities))
+        ones = _ones_colors(N, dev)
+        stride = lib.mobgs_record_stride(1)
+        records = torch.empty(C * N, stride, dtype=torch.float32, device=dev)
+        check(lib.mobgs_pack_records(C, N, 1, ptr(means2d), ptr(conics), ptr(ones), 0, ptr(opacities),
+                                     1 if opacities.dim() == 2 else 0, None, ptr(radii), ptr(records), stream()),
+              "mobgs_pack_records")
+        render = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
+        alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
+        last = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+        reach = torch.empty(max(tl.flatten_arena.numel(), 1), dtype=torch.uint8, device=dev)
+        while True:
+            if reach.numel() < tl.flatten_arena.numel():  # lists rebuilt into a larger arena
+                reach = torch.empty(tl.flatten_arena.numel(), dtype=torch.uint8, device=dev)
+            check(lib.mobgs_raster_class_fwd(C, N, Ns, class_sel, 1, width, height, ptr(records), None,
+                                             ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_arena),
+                                             ptr(render), ptr(alphas), ptr(last), ptr(reach), tuning.ref(), stream()),
+                  "mobgs_raster_class_fwd")
+            if tl.defer or not tl.resolve():
+                break
+        ctx.save_for_backward(records, radii, alphas, last, reach)
+        ctx.tl, ctx.arena = tl, tl.flatten_arena
+        ctx.meta = (C, N, width, height, opacities.dim() == 2, Ns, class_sel)
+        return alphas
+
+    @staticmethod
+    def backward(ctx, v_alphas):
+        lib = _lib_()
+        C, N, width, height, opac_per_camera, Ns, class_sel = ctx.meta
+        records, radii, alphas, last, reach = ctx.saved_tensors
+        tl = ctx.tl
+        dev = records.device
+        if v_alphas is None:
+            return (None,) * 9
+        if tl.flatten_arena is not ctx.arena:  # lists rebuilt after this forward ran: recompute the masks
+            reach = None
+        stride = records.shape[1]
+        rows = max(tl.n_isects, 1)
+        slots = torch.zeros(rows + 1, stride, dtype=torch.float32, device=dev)  # last row: the any_record flag
+        flag = ctypes.c_void_p(slots.data_ptr() + 4 * rows * stride)
+        v_render = _zero_image(C, height, width, dev)
+        check(lib.mobgs_raster_class_bwd(C, N, Ns, class_sel, 1, width, height, ptr(records), None, ptr(radii),
+                                         ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(tl.tile_offsets),
+                                         ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas), ptr(last),
+                                         ptr(v_render), ptr(f32c(v_alphas)), ptr(slots), ptr(reach), flag,
+                                         tuning.ref(), stream()), "mobgs_raster_class_bwd")
+        v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
+        v_colors = torch.empty(C, N, 1, dtype=torch.float32, device=dev)
+        check(lib.mobgs_raster_bwd_reduce(C, N, 1, 0, ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(slots), flag,
+                                          ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), None, stream()),
+              "mobgs_raster_bwd_reduce")
+        if not opac_per_camera:
+            v_opac = v_opac.sum(0) if C > 1 else v_opac[0]
+        return v_means2d, v_conics, v_opac, None, None, None, None, None, None
+
+
+_const_cache = {}
+
+
+def _ones_colors(n, dev):
+    key = ("ones", n, str(dev))
+    t = _const_cache.get(key)
+    if t is None:
+        if len(_const_cache) > 16:
+            _const_cache.clear()
+        t = _const_cache[key] = torch.ones(n, 1, dtype=torch.float32, device=dev)
+    return t
+
+
+def _zero_image(C, h, w, dev):
+    key = ("zeros", C, h, w, str(dev))
+    t = _const_cache.get(key)
+    if t is None:
+        if len(_const_cache) > 16:
+            _const_cache.clear()
+        t = _const_cache[key] = torch.zeros(C, h, w, 1, dtype=torch.float32, device=dev)
+    return t
+
+
 def _ptr3(tensors):
     import ctypes
     return (ctypes.c_void_p * 3)(*[None if t is None else t.data_ptr() for t in tensors])
@@ -666,8 +759,8 @@ class _RasterizeClasses(torch.autograd.Function):
                 check(lib.mobgs_raster_class_bwd(C, N, Ns, cls, D, width, height, ptr(records), ptr(bg), ptr(radii),
                                                  ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(tl.tile_offsets),
                                                  ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas), ptr(last),
-                                                 ptr(v_render), ptr(v_alpha), ptr(slots), ptr(reach), tuning.ref(),
-                                                 stream()),
+                                                 ptr(v_render), ptr(v_alpha), ptr(slots), ptr(reach), None,
+                                                 tuning.ref(), stream()),
                       "mobgs_raster_class_bwd")
         v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
         v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
@@ -886,6 +979,12 @@ class SharedProjection:
         on = [(mask >> layer) & 1 for layer in range(3)]
         return ([outs[2 * layer] if on[layer] else None for layer in range(3)],
                 [outs[2 * layer + 1] if on[layer] else None for layer in range(3)])
+
+    def class_alpha(self, Ns, class_sel):
+        """Coverage [C,H,W] of the first Ns splats (class_sel = 1) or of the rest (2) composited on their own, from
+        the lists of the whole set (see _RasterizeClassAlpha)."""
+        return _RasterizeClassAlpha.apply(self.means2d, self.conics, self.opacities, self.radii, self.tl, self.width,
+                                          self.height, int(Ns), int(class_sel))
 
     def meta(self):
         tl = self.tl
