@@ -11,8 +11,9 @@ N = 1   one step = one full `render()` forward + backward of BASELINE config #2:
         SURVEY.md section 8d (200k static + 100k dynamic Gaussians, 1352x1014, lean mode as eval.py:125), i.e. per-splat
         prep (Hermite spline, activations) -> projection -> tile lists + per-tile depth sort -> 10-channel compositing
         -> expected depth + colour decoder, and the backward pass to every Gaussian leaf, the decoder weights and the
-        camera matrix.  `value` = renders/s.  The same line carries, as the secondary object `deblur`, the K = 9
-        blurry-view throughput on this one GPU (the N > 1 step below with world = 1).
+        camera matrix.  `value` = renders/s.  The same line carries, as secondary objects, `deblur` (the K = 9
+        blurry-view throughput on this one GPU: the N > 1 step below with world = 1), `dynamic_config3` (BASELINE
+        config #3) and `get_flow` (the nine get_flow() calls train.py issues per view, :570-579).
 N > 1   one step = one training iteration's blurry-view part (train.py:430-541) for a batch of 2 views (the
         reference's batch_size, arguments/stereo/default.py): per view 1 train-mode mid render + 8 latent renders
         through BLCE-warped cameras with exposure offsets, K = 9; the 18 (view, sub-frame) units are sharded
@@ -189,6 +190,30 @@ class DeblurWorkload:
         return pred
 
 
+class FlowWorkload:
+    """The nine get_flow() calls train.py issues per view and iteration (:570-579, exposure offsets (k - 4) / 4),
+    forward + backward, through get_flow_many; `zero` = the cotangents of lambda_flow_loss = 0 (arguments/stereo/
+    seesaw.py: the flow loss is formed and back-propagated with weight 0)."""
+
+    def __init__(self, dev, stat, dyn, cam, width, height, zero, seed=100):
+        g = torch.Generator().manual_seed(seed)
+        mk = (lambda *s: torch.zeros(*s, device=dev)) if zero else (lambda *s: torch.randn(*s, generator=g).to(dev))
+        self.v2, self.v3, self.v1 = mk(1, height, width, 2), mk(3, height, width), mk(1, height, width)
+        self.stat, self.dyn, self.cam = stat, dyn, cam
+        self.bg = torch.zeros(9, device=dev)
+        self.deltas = [(k - 4) / 4.0 for k in range(9)]
+        self.params = leaves(stat, dyn)
+
+    def step(self):
+        from mobgs_amd.gaussian_renderer import get_flow_many
+        from mobgs_amd.ops import LeafGradSink
+        for p in self.params:
+            p.grad = None
+        outs = get_flow_many(self.cam, self.stat, self.dyn, None, self.bg, self.deltas)
+        with LeafGradSink(self.stat, self.dyn):
+            torch.autograd.backward([t for o in outs for t in o], [self.v2, self.v2, self.v3, self.v1] * 9)
+
+
 class DynamicWorkload:
     """BASELINE config #3 (secondary object of the N = 1 line): `deform_network` (HexPlane [64,64,64,12] x [1,2,4] +
     MLP heads, arguments/stereo/seesaw.py) moves the dynamic Gaussians' position / scale / rotation, the result is
@@ -265,6 +290,7 @@ def main():
     ap.add_argument("--views", type=int, default=2, help="views per training iteration in the deblur step")
     ap.add_argument("--deblur-steps", type=int, default=10, help="N=1: steps of the secondary deblur leg (0: skip)")
     ap.add_argument("--dynamic-steps", type=int, default=20, help="N=1: steps of the secondary config #3 leg (0: skip)")
+    ap.add_argument("--flow-steps", type=int, default=4, help="N=1: steps of the secondary get_flow leg (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-torch", action="store_true", help="skip the PyTorch-CPU config #1 render (tens of s)")
     ap.add_argument("--cpu-reps", type=int, default=2)
@@ -321,7 +347,7 @@ def main():
 
     P = args.width * args.height
     n_units = args.views * 9
-    deblur = dynamic = None
+    deblur = dynamic = flows = None
     if world == 1:
         profiler.enable(True)
         dt, med_ms = timed(lean_step, args.steps, args.warmup, world, dist)
@@ -352,6 +378,14 @@ def main():
                        "what": "BASELINE config #3: deform_network (seesaw HexPlane + MLP heads, HIP fwd + bwd) on the "
                                f"{args.nd} dynamic Gaussians -> rasterization of all {args.ns + args.nd} (RGB+ED) -> "
                                "backward to the network's planes / weights and the Gaussian inputs"}
+        if args.flow_steps > 0:
+            flows = {"what": "train.py:570-579: the nine get_flow() calls of one view (9 features + 2 flow channels + "
+                             "dynamic coverage per call, mid-exposure state shared through get_flow_many), fwd + bwd"}
+            for name, zero in (("ms_per_view", False), ("ms_per_view_zero_weight", True)):
+                fw = FlowWorkload(dev, stat, dyn, cam, args.width, args.height, zero)
+                fdt, _ = timed(fw.step, args.flow_steps, 2, world, dist)
+                flows[name] = round(fdt / args.flow_steps * 1e3, 3)
+            flows["zero_weight_note"] = "cotangents exactly zero: lambda_flow_loss = 0 (arguments/stereo/seesaw.py)"
     else:
         wl = DeblurWorkload(dev, stat, dyn, scam, args.width, args.height, shard, args.views)
         profiler.enable(True)
@@ -398,6 +432,8 @@ def main():
         result["deblur"] = deblur
     if dynamic is not None:
         result["dynamic_config3"] = dynamic
+    if flows is not None:
+        result["get_flow"] = flows
     if rank == 0:
         rb = prof.get("raster_bwd")
         if rb:
