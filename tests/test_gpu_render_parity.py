@@ -216,7 +216,7 @@ def test_get_flow_many_equals_separate_calls(hip_device):
     get_flow calls, summed gradients equal up to fp32 accumulation order."""
     from mobgs_amd.gaussian_renderer import get_flow, get_flow_many
     fx = load("get_flow")
-    deltas = [-0.4, 0.1, 0.3]
+    deltas = [(k - 4) / 4.0 for k in range(9)]  # train.py:571-573; nine calls: one 16-channel walk + one 2-channel
     res = {}
     for many in (False, True):
         cam, stat, dyn, bg, _ = scene_from_fixture(fx, device=hip_device)
