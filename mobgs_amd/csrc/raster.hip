@@ -235,6 +235,9 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
                 const float nT = T[k] * (1.f - ev.alpha);
                 const bool blend = ev.pass && nT > T_STOP;   // never for a finished pixel (nT < 0)
                 const bool stop = ev.pass && !(nT > T_STOP);
+                // (skipping the channel FMAs when no pixel of the quadrant passes -- as the backward pass does -- was
+                // measured: +9 us per launch, the ballot + branch per evaluation costs more than the ~16 instructions
+                // it saves on the few empty quadrants the reach masks let through)
                 const float w = blend ? ev.alpha * T[k] : 0.f;
 #pragma unroll
                 for (int c = 0; c < CD; ++c) acc[k][c] = __fmaf_rn(rec[6 + c], w, acc[k][c]);
