@@ -763,6 +763,56 @@ slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, const i
         v_extra[g] = acc;
 }
 
+// Wide records (stride 20 .. 32 floats: the 12- and 16-channel passes of get_flow): 8 lanes per splat, lane q < stride / 4
+// sums 16-byte quarter q of every slot of the splat, four slots in flight per lane -- a quarter of the waves and a
+// quarter of the load instructions of the one-float-per-lane kernel above (stride 20: 74 -> 41 us at 300 k splats).
+// Fixed association order -> deterministic.
+__global__ void __launch_bounds__(256)
+slot_reduce_wide_kernel(int n_gauss, int channels, int has_extra, int rq, const int32_t* __restrict__ cum_tiles,
+                        const int32_t* __restrict__ keep_scan, const float* __restrict__ grad_slots,
+                        float* __restrict__ v_means2d, float* __restrict__ v_conics, float* __restrict__ v_opacities,
+                        float* __restrict__ v_colors, float* __restrict__ v_extra,
+                        const int32_t* __restrict__ any_record) {
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int q = threadIdx.x & 7;
+    if (gid >= n_gauss || q >= rq) return;
+    const bool none = any_record && *any_record == 0;  // stage 1 wrote no record: all sums are zero
+    const int a = none ? 0 : keep_index(keep_scan, cum_tiles[gid]);
+    const int b = none ? 0 : keep_index(keep_scan, cum_tiles[gid + 1]);
+    const float4* p = reinterpret_cast<const float4*>(grad_slots) + q;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    int k = a;
+    for (; k + 4 <= b; k += 4) {
+        const float4 u0 = p[(size_t)k * rq], u1 = p[(size_t)(k + 1) * rq], u2 = p[(size_t)(k + 2) * rq],
+                     u3 = p[(size_t)(k + 3) * rq];
+        s0.x += u0.x; s0.y += u0.y; s0.z += u0.z; s0.w += u0.w;
+        s1.x += u1.x; s1.y += u1.y; s1.z += u1.z; s1.w += u1.w;
+        s2.x += u2.x; s2.y += u2.y; s2.z += u2.z; s2.w += u2.w;
+        s3.x += u3.x; s3.y += u3.y; s3.z += u3.z; s3.w += u3.w;
+    }
+    for (; k < b; ++k) {
+        const float4 u = p[(size_t)k * rq];
+        s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+    }
+    const float acc[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                          (s0.w + s1.w) + (s2.w + s3.w)};
+    const size_t g = (size_t)gid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int comp = 4 * q + i;
+        if (comp < 2)
+            v_means2d[2 * g + comp] = acc[i];
+        else if (comp < 5)
+            v_conics[3 * g + (comp - 2)] = acc[i];
+        else if (comp == 5)
+            v_opacities[g] = acc[i];
+        else if (comp - 6 < channels)
+            v_colors[g * channels + (comp - 6)] = acc[i];
+        else if (has_extra && comp - 6 == channels)
+            v_extra[g] = acc[i];
+    }
+}
+
 // 64-byte records (stride 16, the render() configuration): LPS lanes per splat, every lane loads 16 BYTES -- quarter
 // q = lane & 3 of slot k + sub-group -- so one load instruction of a group covers LPS / 4 slots (the kernel is
 // latency-bound: 4x the bytes in flight of a one-float-per-lane loop), two such loads in flight per lane; the
@@ -1027,6 +1077,10 @@ int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int
             hipLaunchKernelGGL(slot_reduce_kernel<16>, dim3((int)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
                                v_colors, v_extra, any_record);
+        } else if (stride <= 32 && (stride & 3) == 0) {
+            hipLaunchKernelGGL(slot_reduce_wide_kernel, dim3((int)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, st, n,
+                               channels, has_extra, stride / 4, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics,
+                               v_opacities, v_colors, v_extra, any_record);
         } else {
             hipLaunchKernelGGL(slot_reduce_kernel<32>, dim3((int)(((size_t)n * 32 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
