@@ -763,18 +763,19 @@ slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, const i
         v_extra[g] = acc;
 }
 
-// Wide records (stride 20 .. 32 floats: the 12- and 16-channel passes of get_flow): 8 lanes per splat, lane q < stride / 4
-// sums 16-byte quarter q of every slot of the splat, four slots in flight per lane -- a quarter of the waves and a
-// quarter of the load instructions of the one-float-per-lane kernel above (stride 20: 74 -> 41 us at 300 k splats).
-// Fixed association order -> deterministic.
+// Records read as 16-byte quarters (strides 8, 12, 20 .. 32 floats: the 1-, 2-, 12- and 16-channel passes of get_flow):
+// LPS lanes per splat, lane q < stride / 4 sums quarter q of every slot of the splat, four slots in flight per lane -- a
+// quarter of the waves and of the load instructions of the one-float-per-lane kernel above (stride 20: 74 -> 40 us,
+// stride 8: 25 -> 20 us at 300 k splats).  Fixed association order -> deterministic.
+template <int LPS>
 __global__ void __launch_bounds__(256)
 slot_reduce_wide_kernel(int n_gauss, int channels, int has_extra, int rq, const int32_t* __restrict__ cum_tiles,
                         const int32_t* __restrict__ keep_scan, const float* __restrict__ grad_slots,
                         float* __restrict__ v_means2d, float* __restrict__ v_conics, float* __restrict__ v_opacities,
                         float* __restrict__ v_colors, float* __restrict__ v_extra,
                         const int32_t* __restrict__ any_record) {
-    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-    const int q = threadIdx.x & 7;
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPS;
+    const int q = threadIdx.x % LPS;
     if (gid >= n_gauss || q >= rq) return;
     const bool none = any_record && *any_record == 0;  // stage 1 wrote no record: all sums are zero
     const int a = none ? 0 : keep_index(keep_scan, cum_tiles[gid]);
@@ -1065,10 +1066,18 @@ int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int
     const int stride = record_stride(D);
     const int n = C * N;
     if (n > 0) {
-        if (stride <= 8) {
+        if (stride == 8) {
+            hipLaunchKernelGGL(slot_reduce_wide_kernel<2>, dim3((int)(((size_t)n * 2 + 255) / 256)), dim3(256), 0, st, n,
+                               channels, has_extra, 2, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics,
+                               v_opacities, v_colors, v_extra, any_record);
+        } else if (stride < 8) {
             hipLaunchKernelGGL(slot_reduce_kernel<8>, dim3((n * 8 + 255) / 256), dim3(256), 0, st, n, channels,
                                has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities, v_colors,
                                v_extra, any_record);
+        } else if (stride == 12) {
+            hipLaunchKernelGGL(slot_reduce_wide_kernel<4>, dim3((int)(((size_t)n * 4 + 255) / 256)), dim3(256), 0, st, n,
+                               channels, has_extra, 3, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics,
+                               v_opacities, v_colors, v_extra, any_record);
         } else if (stride == 16) {
             hipLaunchKernelGGL(slot_reduce16_kernel<8>, dim3((int)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
@@ -1078,7 +1087,7 @@ int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int
                                channels, has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
                                v_colors, v_extra, any_record);
         } else if (stride <= 32 && (stride & 3) == 0) {
-            hipLaunchKernelGGL(slot_reduce_wide_kernel, dim3((int)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, st, n,
+            hipLaunchKernelGGL(slot_reduce_wide_kernel<8>, dim3((int)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, stride / 4, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics,
                                v_opacities, v_colors, v_extra, any_record);
         } else {
