@@ -1078,7 +1078,7 @@ int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const int
             hipLaunchKernelGGL(slot_reduce_wide_kernel<4>, dim3((int)(((size_t)n * 4 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, 3, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics,
                                v_opacities, v_colors, v_extra, any_record);
-        } else if (stride == 16) {
+        } else if (stride == 16) {  // (slot_reduce_wide_kernel<4> measures the same here: 29.0 vs 28.7 us)
             hipLaunchKernelGGL(slot_reduce16_kernel<8>, dim3((int)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
                                v_colors, v_extra, any_record);
