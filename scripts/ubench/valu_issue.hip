@@ -77,6 +77,29 @@ __global__ void __launch_bounds__(512) k_pk_fma(float* out, long long* cyc, int 
     if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
 
+// 64-bit moves: would two registers per instruction halve the cost of clearing an accumulator block?
+#define KERNEL64(name, body)                                                                                  \
+    __global__ void __launch_bounds__(512) k_##name(float* out, long long* cyc, int iters, float c0) {        \
+        v2f a[CHAINS];                                                                                        \
+        for (int i = 0; i < CHAINS; ++i) a[i] = v2f{threadIdx.x * 1e-3f + i, (float)i};                       \
+        v2f b = {c0, c0 * 2.f};                                                                               \
+        __syncthreads();                                                                                      \
+        const long long t0 = __builtin_readcyclecounter();                                                    \
+        for (int it = 0; it < iters; ++it) {                                                                  \
+            _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                                              \
+                _Pragma("unroll") for (int i = 0; i < CHAINS; ++i) asm volatile(body : "+v"(a[i]) : "v"(b));  \
+            }                                                                                                 \
+        }                                                                                                     \
+        const long long t1 = __builtin_readcyclecounter();                                                    \
+        float s = 0;                                                                                          \
+        for (int i = 0; i < CHAINS; ++i) s += a[i].x + a[i].y;                                                \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                       \
+        if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;             \
+    }
+KERNEL64(mov_b64, "v_mov_b64 %0, %1")
+KERNEL64(pk_mov, "v_pk_mov_b32 %0, %1, %1")
+KERNEL64(pk_add, "v_pk_add_f32 %0, %0, %1")
+
 template <typename K>
 void run(const char* name, K kern, int waves_per_simd, bool packed) {
     // one workgroup per CU with 4 * W waves (<= 8 per SIMD would need 2048 threads: use W <= 2 per block and more blocks)
@@ -144,6 +167,9 @@ int main() {
         run("exp", k_exp, w, false);
         run("rcp", k_rcp, w, false);
         run("pk_fma", k_pk_fma, w, true);
+        run("mov_b64", k_mov_b64, w, true);
+        run("pk_mov", k_pk_mov, w, true);
+        run("pk_add", k_pk_add, w, true);
     }
     return 0;
 }
