@@ -23,6 +23,13 @@ FAST_PATH = CSRC.parent / "_mobgs_fast.so"
 # +6% renders/s on the compositing kernels without it (measured).
 NOSLP_FILES = os.environ.get("MOBGS_NOSLP_FILES", "raster.hip,raster_layers.hip").split(",")
 EXTRA_FLAGS = {f: ["-fno-slp-vectorize"] for f in NOSLP_FILES if f}
+# project.hip: no implicit FMA contraction.  radii (= ceil(3 sqrt(lambda_max))), tile rectangles and the cull tests
+# are integer / boolean functions of float expressions; with the compiler free to fuse a * b + c differently from the
+# written order, one splat in ~8000 of an extreme scene (near-plane, 6x scales) landed on the other side of an integer
+# boundary than the oracles, which evaluate the expressions as written (scripts/soak_parity.py).  The kernels are
+# HBM-bound: no measurable cost.
+EXTRA_FLAGS.setdefault("project.hip", [])
+EXTRA_FLAGS["project.hip"] = EXTRA_FLAGS["project.hip"] + ["-ffp-contract=off"]
 for _f in ("raster.hip", "raster_layers.hip"):  # experiment hook: extra flags for the compositing kernels
     EXTRA_FLAGS.setdefault(_f, [])
     EXTRA_FLAGS[_f] = EXTRA_FLAGS[_f] + os.environ.get("MOBGS_RASTER_EXTRA_FLAGS", "").split()

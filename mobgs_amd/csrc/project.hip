@@ -46,7 +46,10 @@ __device__ inline Cam load_cam(const float* __restrict__ viewmats, const float* 
 
 // rotation matrix of the NORMALISED quaternion (w,x,y,z); row-major
 __device__ inline void quat_to_rotmat(const float q[4], float R[9]) {
-    const float inv = rsqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    // 1 / sqrt in the oracles' order and with correctly rounded operations (v_rsq_f32 is ~1 ulp: the last bit of the
+    // rotation decided the radius = ceil(3 sqrt(lambda_max)) of one splat in ~8000 of an extreme scene differently from
+    // the oracles, scripts/soak_parity.py; upstream's own CUDA rsqrtf cannot be reproduced bit for bit either way)
+    const float inv = 1.f / sqrtf(q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + q[0] * q[0]);
     const float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
     const float x2 = x * x, y2 = y * y, z2 = z * z;
     const float xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
@@ -358,7 +361,7 @@ project_bwd_kernel(int N, const float* __restrict__ means, const float* __restri
 #pragma unroll
         for (int k = 0; k < 3; ++k) vs[k] = Rq[k] * vM[k] + Rq[3 + k] * vM[3 + k] + Rq[6 + k] * vM[6 + k];
         // --- Rq = rot(normalize(q))
-        const float inv = rsqrtf(qraw[0] * qraw[0] + qraw[1] * qraw[1] + qraw[2] * qraw[2] + qraw[3] * qraw[3]);
+        const float inv = 1.f / sqrtf(qraw[1] * qraw[1] + qraw[2] * qraw[2] + qraw[3] * qraw[3] + qraw[0] * qraw[0]);
         const float w = qraw[0] * inv, x = qraw[1] * inv, y = qraw[2] * inv, z = qraw[3] * inv;
         float vn[4];
         vn[0] = 2.f * (-z * vRq[1] + y * vRq[2] + z * vRq[3] - x * vRq[5] - y * vRq[6] + x * vRq[7]);

@@ -79,8 +79,16 @@ def test_half_storage_equals_fp32_render_of_the_rounded_values(hip_device, train
                 assert g16 is None
                 continue
             assert g16.dtype == torch.float16
-            # the fp32 gradient rounded to half (values beyond the half range saturate to inf in both)
-            assert torch.equal(g16, g32.half()), a
+            # the fp32 gradient rounded to half (values beyond the half range saturate to inf in both).  The two
+            # kernel instantiations may contract an a * b + c differently: an fp32 value one ulp off that sits on a
+            # half rounding boundary lands on the neighbouring half -- allowed for a handful of entries, one half
+            # spacing apart
+            h = g32.half()
+            off = g16 != h
+            assert int(off.sum()) <= max(2, off.numel() // 5000), (a, int(off.sum()))
+            if bool(off.any()):
+                d = (g16.float() - h.float()).abs()[off]
+                assert bool((d <= 2.0 ** -9 * h.float().abs()[off] + 1e-7).all()), a
         for a in ("_xyz", "control_xyz"):
             g16, g32 = getattr(pc16, a).grad, getattr(pc32, a).grad
             if g32 is not None:

@@ -557,7 +557,7 @@ def test_small_grids_go_heavy_by_default(hip_device):
         rendering.tuning.heavy_tile_len = old
     assert torch.equal(res["default"][0], res["light"][0]) and torch.equal(res["default"][1], res["light"][1])
     for k, ref in res["light"][2].items():
-        tol = 2e-5 * float(ref.abs().max()) + 1e-9
+        tol = 1e-4 * float(ref.abs().max()) + 1e-9  # fp32 sums of the same terms in another order
         assert float((res["default"][2][k] - ref).abs().max()) <= tol, k
 
 

@@ -1,0 +1,20 @@
+"""Randomised regimes the fixed-seed parity tests do not visit (scripts/soak_parity.py): tiny / huge / thin splats,
+opacities at the 1/255 and 0.999 edges, splats at the near plane, equal depths, rotated cameras, ragged image sizes,
+1..11 channels, every render mode, with and without background -- against the C oracle.  radii and per-tile lists
+must be bit-equal; images and gradients within the flip-aware tolerances."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+def test_random_regimes_against_the_c_oracle(hip_device, seed):
+    import soak_parity
+    failed, msgs = soak_parity.soak(60, seed, hip_device, verbose=False)
+    assert failed == 0, "\n".join(msgs)
