@@ -97,13 +97,13 @@ prep_fwd_kernel(int Ns, int Nd, const float* __restrict__ times,
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             m[k] = s_xyz[3 * i + k];
-            s[k] = __expf(ldf(s_scaling, 3 * (size_t)i + k));
+            s[k] = expf(ldf(s_scaling, 3 * (size_t)i + k));  // (accurate exp: the scale decides the integer radius)
             col[6 + k] = 0.0f * ldf(s_ft, 3 * (size_t)i + k);
         }
         // the reference normalises static rotations (get_rotation_stat); emit them raw, see header
         const float4 r = ld4(s_rotation, i);
         q[0] = r.x; q[1] = r.y; q[2] = r.z; q[3] = r.w;
-        o = 1.f / (1.f + __expf(-ldf(s_opacity, i)));
+        o = 1.f / (1.f + expf(-ldf(s_opacity, i)));
 #pragma unroll
         for (int k = 0; k < 6; ++k) col[k] = ldf(s_fdc, 6 * (size_t)i + k);
     } else {
@@ -119,13 +119,13 @@ prep_fwd_kernel(int Ns, int Nd, const float* __restrict__ times,
             const float m0 = H.left_edge ? (p2 - p1) : (p2 - p0) * 0.5f;
             const float m1 = H.right_edge ? (p2 - p1) : (p3 - p1) * 0.5f;
             m[k] = (H.h00 * p1 + H.h10 * m0 + H.h01 * p2 + H.h11 * m1) * 1e-2f;
-            s[k] = __expf(ldf(d_scaling, 3 * (size_t)j + k));
+            s[k] = expf(ldf(d_scaling, 3 * (size_t)j + k));
             col[6 + k] = tfp * ldf(d_ft, 3 * (size_t)j + k);
         }
         const float4 r = ld4(d_rotation, j);
         const float4 w = ld4(d_omega, j);
         q[0] = r.x + tfp * w.x; q[1] = r.y + tfp * w.y; q[2] = r.z + tfp * w.z; q[3] = r.w + tfp * w.w;
-        o = 1.f / (1.f + __expf(-ldf(d_opacity, j)));
+        o = 1.f / (1.f + expf(-ldf(d_opacity, j)));
 #pragma unroll
         for (int k = 0; k < 6; ++k) col[k] = ldf(d_fdc, 6 * (size_t)j + k);
     }

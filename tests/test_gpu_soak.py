@@ -18,3 +18,12 @@ def test_random_regimes_against_the_c_oracle(hip_device, seed):
     import soak_parity
     failed, msgs = soak_parity.soak(60, seed, hip_device, verbose=False)
     assert failed == 0, "\n".join(msgs)
+
+
+def test_random_render_calls_against_the_torch_restatement(hip_device):
+    """render() (boundary B1) in random regimes (scripts/soak_render.py): camera times on and between the spline's
+    knots, exposure offsets pushing the time outside [0, 1], 4..12 control points, lean and train mode, random
+    backgrounds and cameras -- against oracle/render_torch.py."""
+    import soak_render
+    failed, msgs = soak_render.soak(14, 3, hip_device, verbose=False)
+    assert failed == 0, "\n".join(msgs)
