@@ -1,0 +1,187 @@
+"""Randomised soak of the per-pixel / per-point side kernels against their CPU restatements:
+  loss     fused L1 + SSIM (csrc/loss.hip) vs oracle/loss_torch.py -- image sizes from 1x1 up, smaller than the 11x11
+           window, ragged against the kernel's tiles, batches, constant images
+  normals  normals from depth (csrc/normals.hip) vs oracle/normals_torch.py -- sizes from 3x3 up, skewed intrinsics
+  deform   deform_network (HexPlane + MLP heads, csrc/deform*.hip, hexplane_bwd.hip) vs oracle/deform_torch.py -- point
+           counts around the 64-point tiles (1, 63, 64, 65, ...), points outside the bounding box, times 0 / 1
+GPU box only:   python scripts/soak_misc.py [--cases 30] [--only loss|normals|deform]"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _off(a, b, rtol, atol):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs()
+    return float((err > atol + rtol * b.abs()).double().mean()), float(err.max()) if err.numel() else 0.0
+
+
+def loss_case(rng, i, dev):
+    from mobgs_amd.loss_utils import l1_loss, photometric_loss, ssim
+    from oracle import loss_torch as L
+    B = int(rng.choice([1, 1, 2, 3]))
+    H = int(rng.choice([1, 2, 7, 10, 11, 12, 31, 64, 97, 130]))
+    W = int(rng.choice([1, 3, 8, 11, 16, 33, 65, 128, 201]))
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    kind = str(rng.choice(["rand", "const", "close"]))
+    gt = torch.rand(B, 3, H, W, generator=g)
+    img = {"rand": torch.rand(B, 3, H, W, generator=g), "const": torch.full((B, 3, H, W), 0.37),
+           "close": (gt + 0.01 * torch.randn(B, 3, H, W, generator=g)).clamp(0, 1)}[kind]
+    desc = f"loss case {i}: {B}x3x{H}x{W} {kind}"
+    probs = []
+    a = img.clone().requires_grad_(True)
+    ref = L.l1_loss(a, gt) + 0.2 * (1.0 - L.ssim(a, gt))
+    ref.backward()
+    b = img.clone().to(dev).requires_grad_(True)
+    out = photometric_loss(b, gt.to(dev), 0.2)
+    out.backward()
+    if abs(float(out.detach()) - float(ref.detach())) > 2e-6 + 1e-5 * abs(float(ref)):
+        probs.append(f"loss {float(out):.8f} vs {float(ref):.8f}")
+    sc = float(a.grad.abs().max()) + 1e-30
+    f, e = _off(b.grad, a.grad, 1e-3, 2e-5 * sc)
+    if f > 0 or not torch.isfinite(b.grad).all():
+        probs.append(f"grad: {f:.2e} off, max {e:.2e} (scale {sc:.2e})")
+    s2 = ssim(img.to(dev), gt.to(dev), size_average=False)
+    r2 = L.ssim(img, gt, size_average=False)
+    if float((s2.cpu() - r2).abs().max()) > 2e-5:
+        probs.append(f"ssim per image off by {float((s2.cpu() - r2).abs().max()):.2e}")
+    if abs(float(l1_loss(img.to(dev), gt.to(dev))) - float(L.l1_loss(img, gt))) > 1e-6:
+        probs.append("l1 differs")
+    return desc, probs
+
+
+def normals_case(rng, i, dev):
+    from mobgs_amd.main_utils import get_normals
+    from oracle import normals_torch as N
+    H = int(rng.choice([3, 4, 17, 64, 99, 200]))
+    W = int(rng.choice([3, 5, 16, 65, 130, 333]))
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    fx, fy = float(rng.uniform(50, 1500)), float(rng.uniform(50, 1500))
+    cx, cy, skew = float(rng.uniform(0, W)), float(rng.uniform(0, H)), float(rng.choice([0.0, 0.0, 0.3]))
+    center = bool(rng.random() < 0.7)
+    z = 1.0 + 4.0 * torch.rand(1, H, W, generator=g)
+    if rng.random() < 0.3:
+        z = torch.full((1, H, W), 2.5)  # a fronto-parallel plane: every normal is (0, 0, +-1)
+    cot = torch.randn(1, 3, H, W, generator=g)
+    desc = f"normals case {i}: {H}x{W} f=({fx:.0f},{fy:.0f}) skew={skew} center={center}"
+    meta = types.SimpleNamespace(scale_factor_x=fx, scale_factor_y=fy, principal_point_x=cx, principal_point_y=cy,
+                                 skew=skew, use_center=center)
+    a = z.clone().requires_grad_(True)
+    ref = N.get_normals(a, fx, fy, cx, cy, skew, 0.5 if center else 0.0)
+    (ref * cot).sum().backward()
+    b = z.clone().to(dev).requires_grad_(True)
+    out = get_normals(b, meta)
+    (out * cot.to(dev)).sum().backward()
+    probs = []
+    if out.shape != ref.shape:
+        return desc, [f"shape {tuple(out.shape)} vs {tuple(ref.shape)}"]
+    e = float((out.cpu() - ref).abs().max())
+    if e > 2e-5 or not torch.isfinite(out).all():
+        probs.append(f"normals off by {e:.2e}")
+    sc = float(a.grad.abs().max()) + 1e-30
+    f, e = _off(b.grad, a.grad, 2e-3, 1e-4 * sc)
+    if f > 1e-3 or not torch.isfinite(b.grad).all():
+        probs.append(f"depth gradient: {f:.2e} off, max {e:.2e} (scale {sc:.2e})")
+    return desc, probs
+
+
+def deform_case(rng, i, dev):
+    import test_gpu_config3 as T3
+    from oracle import deform_torch as D
+    n = int(rng.choice([1, 2, 63, 64, 65, 127, 129, 1000, 4097]))
+    base = int(rng.choice([8, 16, 32]))
+    seed = int(rng.integers(1 << 20))
+    net = T3._make_net(dev, base, seed)
+    g = torch.Generator().manual_seed(seed + 5)
+    with torch.no_grad():
+        for pl in net.deformation_net.grid.planes():
+            pl.copy_(0.5 + 0.5 * torch.rand(tuple(pl.shape), generator=g))
+        for p in net.deformation_net.get_mlp_parameters():
+            p.mul_(2.0)
+    net.deformation_net.set_aabb([1.0, 1.2, 0.8], [-1.0, -0.9, -1.1])
+    spread = float(rng.choice([0.5, 1.0, 1.6]))  # 1.6: a good part of the points lies outside the box (border taps)
+    pts = (torch.rand(n, 3, generator=g) * 2 - 1) * spread
+    if rng.random() < 0.3 and n > 3:
+        pts[:3] = torch.tensor([[1.0, 1.2, 0.8], [-1.0, -0.9, -1.1], [0.0, 0.0, 0.0]])  # corners, centre
+    scales, rots = torch.randn(n, 3, generator=g), torch.randn(n, 4, generator=g)
+    tval = float(rng.choice([0.0, 1.0, rng.random()]))
+    times = torch.full((n, 1), tval)
+    cot = [torch.randn(n, k, generator=g) for k in (3, 3, 4)]
+    desc = f"deform case {i}: n={n} planes {base} spread {spread} t={tval:.3f}"
+    leaves_cpu = [t.clone().requires_grad_(True) for t in (pts, scales, rots)]
+    W, planes, aabb = T3._oracle_copy(net)
+    ref = D.deform_forward(*leaves_cpu, times, aabb, planes, W)
+    torch.autograd.backward(ref, cot)
+    leaves = [t.clone().to(dev).requires_grad_(True) for t in (pts, scales, rots)]
+    out = net(*leaves, times.to(dev))
+    torch.autograd.backward(out, [c.to(dev) for c in cot])
+    probs = []
+    for a, b, name in zip(out, ref, ("pts", "scales", "rots")):
+        f, e = _off(a, b, 2e-5, 5e-5 * max(1.0, float(b.detach().abs().max())))
+        if f > 0 or not torch.isfinite(a).all():
+            probs.append(f"{name}: {f:.2e} off, max {e:.2e}")
+    few = n <= 130
+    # a hidden unit whose pre-activation is zero to within fp32 rounding takes the other ReLU branch in one of the two
+    # implementations: that ONE point's contribution (~ scale / n of every weight / plane gradient it touches -- all of
+    # the first layer's, through the heads' W^T) moves; small n makes it visible
+    one_point = 8.0 / n
+    for a, b, name in zip(leaves, leaves_cpu, ("pts", "scales", "rots")):
+        sc = float(b.grad.abs().max()) + 1e-30
+        f, e = _off(a.grad, b.grad, 1e-3, 1e-4 * sc)
+        if (f > (0.05 if few else 2e-3)) or e > 0.6 * sc or not torch.isfinite(a.grad).all():
+            probs.append(f"grad {name}: {f:.2e} off, max {e:.2e} (scale {sc:.2e})")
+    for k, w in T3._weights_of(net).items():
+        sc = float(W[k].grad.abs().max()) + 1e-30
+        f, e = _off(w.grad, W[k].grad, 2e-3, 2e-4 * sc)
+        if (f > 0.05 and e > one_point * sc) or e > max(0.05, one_point) * sc or not torch.isfinite(w.grad).all():
+            probs.append(f"grad {k}: {f:.2e} off, max {e:.2e} (scale {sc:.2e})")
+    for li, level in enumerate(net.deformation_net.grid.grids):
+        for pi, pl in enumerate(level):
+            r = planes[li][pi].grad
+            sc = float(r.abs().max()) + 1e-30
+            f, e = _off(pl.grad, r, 2e-3, 2e-4 * sc)
+            if (f > 0.02 and e > one_point * sc) or e > 0.5 * sc or not torch.isfinite(pl.grad).all():
+                probs.append(f"grad plane {li}.{pi}: {f:.2e} off, max {e:.2e} (scale {sc:.2e})")
+    return desc, probs
+
+
+CASES = {"loss": loss_case, "normals": normals_case, "deform": deform_case}
+
+
+def soak(which, cases, seed, dev, verbose=True):
+    rng = np.random.default_rng(seed)
+    failed, msgs = 0, []
+    for i in range(cases):
+        try:
+            desc, probs = CASES[which](rng, i, dev)
+        except Exception as exc:  # noqa: BLE001
+            desc, probs = f"{which} case {i}", [f"exception {type(exc).__name__}: {exc}"]
+        if probs:
+            failed += 1
+            msgs.append(desc + ": " + "; ".join(probs))
+            if verbose:
+                print(msgs[-1])
+    if verbose:
+        print(f"{which}: {cases - failed}/{cases} cases clean")
+    return failed, msgs
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=30)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    bad = 0
+    for which in CASES:
+        if a.only in (None, which):
+            bad += soak(which, a.cases, a.seed, torch.device("cuda:0"))[0]
+    sys.exit(1 if bad else 0)

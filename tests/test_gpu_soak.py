@@ -27,3 +27,14 @@ def test_random_render_calls_against_the_torch_restatement(hip_device):
     import soak_render
     failed, msgs = soak_render.soak(14, 3, hip_device, verbose=False)
     assert failed == 0, "\n".join(msgs)
+
+
+@pytest.mark.parametrize("which", ["loss", "normals", "deform"])
+def test_random_side_kernel_regimes(hip_device, which):
+    """scripts/soak_misc.py: fused L1 + SSIM on images from 1x1 up (smaller than the 11x11 window, ragged against the
+    kernel's tiles, batches, constant images), normals from depth on 3x3.. images with skewed intrinsics,
+    deform_network with point counts around its 64-point tiles, points outside the bounding box and times 0 / 1 --
+    against the CPU restatements."""
+    import soak_misc
+    failed, msgs = soak_misc.soak(which, 16, 1, hip_device, verbose=False)
+    assert failed == 0, "\n".join(msgs)
