@@ -4,6 +4,8 @@
   normals  normals from depth (csrc/normals.hip) vs oracle/normals_torch.py -- sizes from 3x3 up, skewed intrinsics
   deform   deform_network (HexPlane + MLP heads, csrc/deform*.hip, hexplane_bwd.hip) vs oracle/deform_torch.py -- point
            counts around the 64-point tiles (1, 63, 64, 65, ...), points outside the bounding box, times 0 / 1
+  blce     the fused BLCE kernels (csrc/blce.hip) vs the PyTorch module -- random parameters of three amplitudes, view
+           counts 1..24, random poses
 GPU box only:   python scripts/soak_misc.py [--cases 30] [--only loss|normals|deform]"""
 import argparse
 import os
@@ -153,7 +155,70 @@ def deform_case(rng, i, dev):
     return desc, probs
 
 
-CASES = {"loss": loss_case, "normals": normals_case, "deform": deform_case}
+def blce_case(rng, i, dev):
+    """csrc/blce.hip (one kernel each way) against the PyTorch BLCE module on the same random parameters, view index,
+    pose and image statistic: warped poses, their inverses, exposure offsets and all parameter gradients."""
+    import math
+    from mobgs_amd import blce as B
+    from mobgs_amd.camera import PinholeCamera
+    V = int(rng.choice([1, 2, 5, 24]))
+    idx = int(rng.integers(0, V))
+    seed = int(rng.integers(1 << 30))
+    torch.manual_seed(seed)
+    kern = B.blceKernel(num_views=V, num_warp=9, iteration=1000).to(dev)
+    g = torch.Generator().manual_seed(seed + 1)
+    # (amplitude 0.6 makes the 8 Euler steps blow up -- poses of 1e6, gradients of 1e10 -- and the comparison
+    # meaningless: both sides are then dominated by their conditioning)
+    amp = float(rng.choice([0.02, 0.1, 0.25]))
+    with torch.no_grad():
+        for p in kern.model.parameters():
+            if p.requires_grad:
+                p.copy_((amp * torch.randn(p.shape, generator=g)).to(dev))
+    ang = float(rng.uniform(-1.0, 1.0))
+    w2c = torch.eye(4)
+    w2c[:3, :3] = torch.tensor([[math.cos(ang), -math.sin(ang), 0], [math.sin(ang), math.cos(ang), 0], [0, 0, 1.0]])
+    w2c[:3, 3] = torch.tensor([float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2)), float(rng.uniform(-1, 3))])
+    W, H = 64, 48
+    K = torch.tensor([[60.0, 0, 32], [0, 60.0, 24], [0, 0, 1]])
+    cam = PinholeCamera(W, H, K, w2c, time=0.5, max_time=23, device=dev)
+    cam.uid = idx
+    cam.image = torch.rand(3, H, W, generator=g).to(dev)
+    v_w2c, v_c2w = torch.randn(9, 4, 4, generator=g).to(dev), torch.randn(9, 4, 4, generator=g).to(dev)
+    desc = f"blce case {i}: views={V} idx={idx} amplitude {amp}"
+    res = {}
+    old, old_graph = B.FUSED, B.GRAPH_CAPTURE
+    B.GRAPH_CAPTURE = False
+    try:
+        for mode in ("fused", "torch"):
+            B.FUSED = mode == "fused"
+            kern.optimizer.zero_grad(set_to_none=True)
+            cams, expo = kern.get_warped_cams(cam)
+            w = torch.stack([c.world_view_transform.transpose(0, 1) for c in cams])
+            c = torch.stack([torch.cat([c_.R, c_.camera_center[:, None]], dim=1) for c_ in cams])
+            ((w * v_w2c).sum() + (c * v_c2w[:, :3, :]).sum()).backward()
+            res[mode] = (w.detach().cpu(), c.detach().cpu(), expo.detach().cpu(),
+                         {k: p.grad.detach().cpu() for k, p in kern.model.named_parameters() if p.grad is not None})
+    finally:
+        B.FUSED, B.GRAPH_CAPTURE = old, old_graph
+    probs = []
+    for j, nm in ((0, "w2c"), (1, "c2w"), (2, "exposure")):
+        # (random weights of amplitude 0.25 through 8 Euler steps: condition numbers of 1e2..1e3)
+        f, e = _off(res["fused"][j], res["torch"][j], 2e-4, 2e-4 * max(1.0, float(res["torch"][j].abs().max())))
+        if f > 0 or not torch.isfinite(res["fused"][j]).all():
+            probs.append(f"{nm}: max {e:.2e}")
+    if set(res["fused"][3]) != set(res["torch"][3]):
+        probs.append("different sets of parameter gradients")
+    for k, ref in res["torch"][3].items():
+        if k not in res["fused"][3]:
+            continue
+        sc = float(ref.abs().max()) + 1e-12
+        f, e = _off(res["fused"][3][k], ref, 2e-3, 2e-4 * sc)
+        if f > 0.02 or e > 0.05 * sc or not torch.isfinite(res["fused"][3][k]).all():
+            probs.append(f"grad {k}: {f:.2e} off, max {e:.2e} (scale {sc:.2e})")
+    return desc, probs
+
+
+CASES = {"loss": loss_case, "normals": normals_case, "deform": deform_case, "blce": blce_case}
 
 
 def soak(which, cases, seed, dev, verbose=True):

@@ -104,12 +104,80 @@ def run_case(rng, i, dev):
     return desc, problems
 
 
-def soak(cases, seed, dev, verbose=True):
+def run_flow_case(rng, i, dev):
+    """get_flow() / get_flow_many() against oracle/render_torch.get_flow: all four outputs and the leaf gradients."""
+    from mobgs_amd.gaussian_renderer import get_flow, get_flow_many
+    W = int(rng.choice([40, 97, 160]))
+    H = int(rng.choice([24, 64, 88]))
+    ns, nd = int(rng.choice([1, 30, 800])), int(rng.choice([1, 40, 600]))
+    seed = int(rng.integers(1 << 30))
+    scam = SynthCamera().scaled(W, H)
+    stat_p, dyn_p = gaussian_cloud(ns, scam, seed), gaussian_cloud(nd, scam, seed + 1)
+    dyn_x = dynamic_extras(dyn_p["xyz"], seed)
+    max_time = int(rng.choice([7, 23]))
+    t = float(rng.choice([0.0, 1.0, rng.random()]))
+    deltas = [float(rng.uniform(-1.0, 1.0)), 0.0][: int(rng.integers(1, 3))]
+    many = bool(rng.random() < 0.5)
+    g = torch.Generator().manual_seed(seed + 5)
+    bg0 = torch.rand(9, generator=g) if rng.random() < 0.5 else torch.zeros(9)
+    cots = [(torch.randn(1, H, W, 2, generator=g), torch.randn(1, H, W, 2, generator=g),
+             torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g)) for _ in deltas]
+    torch.manual_seed(seed)
+    dec = Sandwich(9, 3)
+    res = {}
+    for name, device in (("hip", dev), ("oracle", torch.device("cpu"))):
+        d = Sandwich(9, 3)
+        d.load_state_dict(dec.state_dict())
+        d = d.to(device)
+        stat = GaussianParams(stat_p, None, d, device, requires_grad=True)
+        dyn = GaussianParams(dyn_p, dyn_x, d, device, requires_grad=True)
+        cam = PinholeCamera(W, H, scam.K, torch.eye(4), t, max_time, device=device)
+        bg = bg0.to(device)
+        if name == "hip":
+            outs = get_flow_many(cam, stat, dyn, None, bg, deltas) if many else \
+                [get_flow(cam, stat, dyn, None, bg, delta_exposure=dl) for dl in deltas]
+        else:
+            outs = [R.get_flow(cam, stat, dyn, bg, torch.tensor(dl)) for dl in deltas]
+        torch.autograd.backward([o for out in outs for o in out],
+                                [c.to(device) for cs in cots for c in cs])
+        grads = {}
+        for pc, tag in ((stat, "s"), (dyn, "d")):
+            for a in LEAVES:
+                p = getattr(pc, a, None)
+                if p is not None and getattr(p, "grad", None) is not None:
+                    grads[tag + a] = p.grad.detach().cpu()
+        res[name] = ([o.detach().cpu() for out in outs for o in out], grads)
+    desc = f"flow case {i}: ns={ns} nd={nd} {W}x{H} t={t:.3f} deltas={deltas} many={many}"
+    problems = []
+    for j, (a, b) in enumerate(zip(res["hip"][0], res["oracle"][0])):
+        if a.shape != b.shape:
+            problems.append(f"output {j}: shape {tuple(a.shape)} vs {tuple(b.shape)}")
+            continue
+        err = (a.double() - b.double()).abs()
+        sc = max(1.0, float(b.abs().max()))
+        frac = float((err > 5e-5 * sc).double().mean())
+        if frac > 5e-3 or not torch.isfinite(a).all():
+            problems.append(f"output {j % 4}: {frac:.2e} of the pixels off, max {float(err.max()):.2e}")
+    for k, ref in res["oracle"][1].items():
+        got = res["hip"][1].get(k)
+        if got is None:
+            problems.append(f"grad {k} missing")
+            continue
+        sc = float(ref.abs().max())
+        err = (got.double() - ref.double()).abs()
+        frac = float((err > 2e-3 * ref.abs().double() + 3e-4 * sc + 1e-7).double().mean())
+        few = ref.numel() <= 400
+        if (frac > 1e-2 and not (few and float(err.max()) <= 5e-2 * sc)) or not torch.isfinite(got).all():
+            problems.append(f"grad {k}: {frac:.2e} off, max {float(err.max()):.2e} (scale {sc:.2e})")
+    return desc, problems
+
+
+def soak(cases, seed, dev, verbose=True, flow=False):
     rng = np.random.default_rng(seed)
     failed, msgs = 0, []
     for i in range(cases):
         try:
-            desc, problems = run_case(rng, i, dev)
+            desc, problems = (run_flow_case if flow else run_case)(rng, i, dev)
         except Exception as exc:  # noqa: BLE001
             desc, problems = f"case {i}", [f"exception {type(exc).__name__}: {exc}"]
         if problems:
@@ -126,6 +194,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--flow", action="store_true", help="get_flow() / get_flow_many() instead of render()")
     a = ap.parse_args()
-    failed, _ = soak(a.cases, a.seed, torch.device("cuda:0"))
+    failed, _ = soak(a.cases, a.seed, torch.device("cuda:0"), flow=a.flow)
     sys.exit(1 if failed else 0)

@@ -29,12 +29,21 @@ def test_random_render_calls_against_the_torch_restatement(hip_device):
     assert failed == 0, "\n".join(msgs)
 
 
-@pytest.mark.parametrize("which", ["loss", "normals", "deform"])
+@pytest.mark.parametrize("which", ["loss", "normals", "deform", "blce"])
 def test_random_side_kernel_regimes(hip_device, which):
     """scripts/soak_misc.py: fused L1 + SSIM on images from 1x1 up (smaller than the 11x11 window, ragged against the
     kernel's tiles, batches, constant images), normals from depth on 3x3.. images with skewed intrinsics,
-    deform_network with point counts around its 64-point tiles, points outside the bounding box and times 0 / 1 --
-    against the CPU restatements."""
+    deform_network with point counts around its 64-point tiles, points outside the bounding box and times 0 / 1, the
+    fused BLCE kernels with random parameters / view counts / poses -- against the CPU restatements (BLCE: the PyTorch
+    module)."""
     import soak_misc
     failed, msgs = soak_misc.soak(which, 16, 1, hip_device, verbose=False)
+    assert failed == 0, "\n".join(msgs)
+
+
+def test_random_get_flow_calls_against_the_torch_restatement(hip_device):
+    """get_flow() and get_flow_many() in random regimes (scripts/soak_render.py --flow): all four outputs and the
+    leaf gradients against oracle/render_torch.get_flow."""
+    import soak_render
+    failed, msgs = soak_render.soak(8, 5, hip_device, verbose=False, flow=True)
     assert failed == 0, "\n".join(msgs)
