@@ -58,6 +58,30 @@ def make_case(rng, idx):
     return dict(w=w, h=h, n=n, channels=channels, mode=mode, regime=regime, s=s, bg=bg, X=X, idx=idx)
 
 
+def make_large_case(rng, idx):
+    """Full-size scenes whose per-tile lists reach hundreds to tens of thousands of entries: every sort build (register
+    networks of 512 / 1024 / 2048 keys, the LDS radix sort, the in-place global sort), heavy tiles, long walks."""
+    w, h = [(1352, 1014), (800, 600), (512, 288)][int(rng.integers(3))]
+    n = int(rng.choice([60_000, 150_000, 300_000]))
+    channels = int(rng.choice([3, 9]))
+    mode = str(rng.choice(["RGB", "RGB+ED"]))
+    cam = SynthCamera().scaled(w, h) if (w, h) != (1352, 1014) else SynthCamera()
+    s = splat_inputs(n, cam, int(rng.integers(1 << 30)), channels)
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    regime = str(rng.choice(["plain", "big", "clustered", "clustered_big"]))
+    if "big" in regime:
+        s["scales"] = s["scales"] * float(rng.choice([2.0, 3.5]))
+    if "clustered" in regime:  # a third of the splats pulled into a small image region: lists of thousands of entries
+        k = n // 3
+        z = s["means"][:k, 2:3]
+        c = torch.tensor([float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.2, 0.2))])
+        s["means"] = s["means"].clone()
+        s["means"][:k, :2] = (c + 0.05 * torch.randn(k, 2, generator=g)) * z
+    X = channels + (1 if mode == "RGB+ED" else 0)
+    bg = torch.rand(1, channels, generator=g) if rng.random() < 0.5 else None
+    return dict(w=w, h=h, n=n, channels=channels, mode=mode, regime=regime, s=s, bg=bg, X=X, idx=idx)
+
+
 def frac_off(a, b, rtol, atol):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     err = np.abs(a - b)
@@ -85,6 +109,10 @@ def run_case(c, dev):
     finally:
         rendering.set_tile_culling(True)
     problems = []
+    if c["n"] > 20000:
+        off = meta["isect_offsets"].cpu().numpy().reshape(-1)
+        lens = np.diff(np.concatenate([off, [meta["flatten_ids"].numel()]]))
+        c["longest"] = int(lens.max())
     if not np.array_equal(meta["radii"].cpu().numpy(), ref["radii"]):
         problems.append("radii differ")
     if "flatten_ids" in ref and not np.array_equal(meta["flatten_ids"].cpu().numpy(), ref["flatten_ids"]):
@@ -113,12 +141,12 @@ def run_case(c, dev):
     return problems, stats
 
 
-def soak(cases, seed, dev, verbose=True):
+def soak(cases, seed, dev, verbose=True, large=False):
     """-> (number of failing cases, messages)."""
     rng = np.random.default_rng(seed)
     worst, failed, msgs = {}, 0, []
     for i in range(cases):
-        c = make_case(rng, i)
+        c = (make_large_case if large else make_case)(rng, i)
         try:
             problems, stats = run_case(c, dev)
         except Exception as exc:  # noqa: BLE001
@@ -126,9 +154,13 @@ def soak(cases, seed, dev, verbose=True):
         for k, (f, e) in stats.items():
             if k not in worst or f > worst[k][0]:
                 worst[k] = (f, e, i)
+        if verbose and large:
+            print(f"  large case {i}: n={c['n']} {c['w']}x{c['h']} {c['regime']} longest list {c.get('longest', '-')}"
+                  f" -> {'FAIL' if problems else 'ok'}", flush=True)
         if problems:
             failed += 1
             msgs.append(f"case {i}: n={c['n']} {c['w']}x{c['h']} ch={c['channels']} {c['mode']} {c['regime']} "
+                        f"longest list {c.get('longest', '-')} "
                         f"bg={'y' if c['bg'] is not None else 'n'}: " + "; ".join(problems))
             if verbose:
                 print(msgs[-1])
@@ -143,8 +175,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=120)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--large", action="store_true", help="full-size scenes with long per-tile lists (seconds per case)")
     a = ap.parse_args()
-    failed, _ = soak(a.cases, a.seed, torch.device("cuda:0"))
+    failed, _ = soak(a.cases, a.seed, torch.device("cuda:0"), large=a.large)
     sys.exit(1 if failed else 0)
 
 

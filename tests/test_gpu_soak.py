@@ -47,3 +47,12 @@ def test_random_get_flow_calls_against_the_torch_restatement(hip_device):
     import soak_render
     failed, msgs = soak_render.soak(8, 5, hip_device, verbose=False, flow=True)
     assert failed == 0, "\n".join(msgs)
+
+
+def test_random_full_size_scenes_with_long_lists(hip_device):
+    """scripts/soak_parity.py --large: 60 k .. 300 k splats at 512x288 .. 1352x1014, enlarged and clustered so that
+    per-tile lists reach thousands to tens of thousands of entries (every sort build, heavy tiles): lists bit-equal
+    to the C oracle's, images and gradients within tolerance."""
+    import soak_parity
+    failed, msgs = soak_parity.soak(6, 2, hip_device, verbose=False, large=True)
+    assert failed == 0, "\n".join(msgs)
