@@ -51,11 +51,23 @@ def make_case(rng, idx):
         vm[:3, :3] = torch.tensor([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
         vm[:3, 3] = torch.tensor([float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.3, 0.5))])
         s["viewmats"] = vm[None]
+    C = 1
+    if rng.random() < 0.25:  # several cameras in one call (B2 supports it; the reference always passes one)
+        C = int(rng.integers(2, 4))
+        vms = []
+        for _ in range(C):
+            ang = float(rng.uniform(-0.2, 0.2))
+            vm = torch.eye(4)
+            vm[:3, :3] = torch.tensor([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
+            vm[:3, 3] = torch.tensor([float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.1, 0.1)), float(rng.uniform(-0.2, 0.3))])
+            vms.append(vm)
+        s["viewmats"] = torch.stack(vms)
+        s["Ks"] = s["Ks"].expand(C, 3, 3).contiguous()
     X = (0 if mode in ("D", "ED") else channels) + (1 if mode in ("RGB+D", "RGB+ED", "D", "ED") else 0)
-    bg = torch.rand(1, X if mode in ("D", "ED") else channels, generator=g) if rng.random() < 0.5 else None
+    bg = torch.rand(C, X if mode in ("D", "ED") else channels, generator=g) if rng.random() < 0.5 else None
     if mode in ("D", "ED"):
         bg = None if bg is None else bg[:, :1]
-    return dict(w=w, h=h, n=n, channels=channels, mode=mode, regime=regime, s=s, bg=bg, X=X, idx=idx)
+    return dict(w=w, h=h, n=n, channels=channels, mode=mode, regime=regime, s=s, bg=bg, X=X, idx=idx, C=C)
 
 
 def make_large_case(rng, idx):
@@ -92,8 +104,9 @@ def frac_off(a, b, rtol, atol):
 def run_case(c, dev):
     s, w, h, mode, bg = c["s"], c["w"], c["h"], c["mode"], c["bg"]
     g = torch.Generator().manual_seed(1000 + c["idx"])
-    v_img = torch.randn(1, h, w, c["X"], generator=g)
-    v_a = torch.randn(1, h, w, 1, generator=g)
+    C = c.get("C", 1)
+    v_img = torch.randn(C, h, w, c["X"], generator=g)
+    v_a = torch.randn(C, h, w, 1, generator=g)
     ref = Cc.rasterization_fwd_bwd(*(s[k].numpy() for k in ["means", "quats", "scales", "opacities", "colors",
                                                             "viewmats", "Ks"]), w, h,
                                    backgrounds=None if bg is None else bg.numpy(), render_mode=mode,
