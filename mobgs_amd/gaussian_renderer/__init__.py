@@ -384,8 +384,10 @@ def _flow_mid_state(cam, stat_pc, dyn_pc, dev):
     not depend on delta_exposure."""
     W, H = int(cam.image_width), int(cam.image_height)
     viewmat = cam.world_view_transform.transpose(0, 1)
-    mid_m, mid_q, scales, opac, _ = _prep(stat_pc, dyn_pc, _times(cam, None, dev))
-    return _R.SharedProjection(mid_m, mid_q, scales, opac, viewmat[None], cam.K[None], W, H)
+    mid_m, mid_q, scales, opac, cols = _prep(stat_pc, dyn_pc, _times(cam, None, dev))
+    sp = _R.SharedProjection(mid_m, mid_q, scales, opac, viewmat[None], cam.K[None], W, H)
+    sp.flow_cols = cols  # the colour features at the mid time (get_flow_many: the call with exposure offset 0)
+    return sp
 
 
 def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=None, _mid=None, _defer_mid=False):
@@ -436,11 +438,20 @@ def get_flow_many(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_expos
     accumulate independently), gradients equal up to summation order."""
     cam = viewpoint_camera
     mid = _flow_mid_state(cam, stat_pc, dyn_pc, _device_of(dyn_pc))
-    outs = [list(get_flow(cam, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=d, _mid=mid, _defer_mid=True))
-            for d in delta_exposures]
     W, H = int(cam.image_width), int(cam.image_height)
-    for g0 in range(0, len(outs), _FLOW_GROUP):
-        grp = outs[g0:g0 + _FLOW_GROUP]
+    outs = []
+    for d in delta_exposures:
+        if not torch.is_tensor(d) and float(d) == 0.0:
+            # the mid exposure itself (train.py's fifth call): the exposure-time state IS the mid state, both flows
+            # are identically zero (their gradients cancel term by term), so the call needs no projection, binning,
+            # flow channels or flow splat of its own -- one 10-channel walk over the shared lists
+            outs.append(_flow_at_mid(cam, mid, stat_pc.get_xyz.shape[0], dyn_pc, bg_color, W, H))
+        else:
+            outs.append(list(get_flow(cam, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=d, _mid=mid,
+                                      _defer_mid=True)))
+    pending = [o for o in outs if isinstance(o[1], tuple)]
+    for g0 in range(0, len(pending), _FLOW_GROUP):
+        grp = pending[g0:g0 + _FLOW_GROUP]
         cols = torch.cat([-o[1][1] for o in grp], dim=-1)  # [N, 2 * len(grp)]
         img = _R.rasterize_to_pixels(mid.means2d, mid.conics, cols, mid.opacities, mid.radii, mid.tl, W, H)[0]
         # split, not slices: its backward is ONE concatenation of the 2-channel cotangents instead of a zero image, a
@@ -448,6 +459,33 @@ def get_flow_many(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_expos
         for o, part in zip(grp, img.split(2, dim=-1)):
             o[1] = o[1][0] + part
     return [tuple(o) for o in outs]
+
+
+def _flow_at_mid(cam, mid, Ns, dyn_pc, bg_color, W, H):
+    """get_flow(delta_exposure = 0) from the shared mid-exposure state: [exp2mid, mid2exp, latent_img, latent_alpha]."""
+    bg1 = _bg9(bg_color)
+    w1, w2 = _decoder_weights(dyn_pc)
+    a_dyn = mid.class_alpha(Ns, 2)
+    latent_alpha = a_dyn + (1.0 - a_dyn) * bg1[0][0]
+    img10, alphas = mid.composite(mid.flow_cols, bg1)
+    pix = _pixel_grid(cam, W, H, img10)
+    latent_img, _ = decode(img10, alphas, _rays_of(cam), w1, w2, False)
+    grid = pix.unsqueeze(0)  # [1,H,W,2] like pix + image
+    # part of the autograd graph like the other calls' maps (a caller may hand them to autograd.backward directly);
+    # their gradient is identically zero
+    return [_ZeroGradCopy.apply(grid, mid.means2d), _ZeroGradCopy.apply(grid, mid.means2d), latent_img, latent_alpha]
+
+
+class _ZeroGradCopy(torch.autograd.Function):
+    """A copy of `value` that belongs to `anchor`'s autograd graph and passes no gradient on."""
+
+    @staticmethod
+    def forward(ctx, value, anchor):
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None
 
 
 _FLOW_GROUP = 8  # exposures per mid-list walk: 16 channels, the widest compositor build below the 26-channel one
