@@ -22,7 +22,7 @@ import torch
 
 from .. import rendering as _R
 from .._lib import DerivedCache
-from ..ops import PrepSplats, decode
+from ..ops import PrepSplats, decode, decode_with_channels
 from . import network_gui  # noqa: F401  (train.py imports it from here)
 
 __all__ = ["render", "get_flow", "get_flow_many", "get_flow_static", "interpolate_cubic_hermite", "network_gui"]
@@ -420,12 +420,12 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     # the exposure-time lists are walked ONCE for the 9 colour features and the 2 flow channels (the reference: one
     # rasterization each, :436-452 and :461-476; channels accumulate independently, so the images are identical)
     img12, alphas = sp_exp.composite(torch.cat([exp_c, e2m], dim=-1), _bg11(bg1))  # [1,H,W, 9 + 2 + depth]
-    e2m_img = img12[..., 9:11]
+    # the decoder reads the 9 feature channels; the 2 flow channels leave through the same autograd node
+    latent_img, e2m_img = decode_with_channels(img12, alphas, _rays_of(cam), w1, w2, 9, 2)
     pix = _pixel_grid(cam, W, H, e2m_img)
-    exp2mid = pix + e2m_img
+    exp2mid = pix + e2m_img[None]
     # get_flow_many splats the mid-exposure flows of several calls in one walk over the shared lists
     mid2exp = (pix, e2m) if _defer_mid else pix + splat(sp_mid, -e2m)
-    latent_img, _ = decode(img12, alphas, _rays_of(cam), w1, w2, False)  # reads the 9 feature channels only
     return exp2mid, mid2exp, latent_img, latent_alpha
 
 

@@ -302,6 +302,47 @@ class Decode(torch.autograd.Function):
         return v_feat, v_alphas, v_rays, None, g_c2w, g_w1, g_w2, None
 
 
+class DecodeWithChannels(torch.autograd.Function):
+    """Decode (no depth) of an image that carries `n` further channels from `c0` on, which are handed out as a
+    tensor of their own [..., n].  Slicing them off the image in PyTorch costs every backward pass a zero image of the
+    image's size, a strided copy and an add with the decoder's gradient; here the decoder's gradient buffer (zero in
+    the channels it does not read) simply receives their cotangent.  get_flow(): 9 features + 2 flow channels."""
+
+    @staticmethod
+    def forward(ctx, feat_hw, alphas, rays, intr, c2w, w1, w2, c0: int, n: int):
+        rgb, _ = Decode.forward(ctx, feat_hw, alphas, rays, intr, c2w, w1, w2, False)
+        ctx.chan = (int(c0), int(n))
+        return rgb, feat_hw[..., c0:c0 + n].contiguous()
+
+    @staticmethod
+    def backward(ctx, v_rgb, v_chan):
+        c0, n = ctx.chan
+        if v_rgb is None and v_chan is None:
+            return (None,) * 9
+        if v_rgb is None:  # only the extra channels were used
+            v_feat = torch.zeros(ctx.feat_shape, dtype=torch.float32, device=v_chan.device)
+            v_feat[..., c0:c0 + n].copy_(v_chan)
+            return (v_feat,) + (None,) * 8
+        g = Decode.backward(ctx, v_rgb, None)
+        if v_chan is not None:
+            g[0][..., c0:c0 + n].copy_(v_chan)
+        return tuple(g[:7]) + (None, None)
+
+
+def decode_with_channels(feat_hw: Tensor, alphas: Optional[Tensor], rays, w1: Tensor, w2: Tensor, c0: int, n: int):
+    """decode(..., has_depth=False) + feat_hw[..., c0:c0+n] as a tensor of its own (see DecodeWithChannels):
+    -> (rgb [3,H,W], channels [H,W,n])."""
+    H, W = feat_hw.shape[-3], feat_hw.shape[-2]
+    if feat_hw.numel() != H * W * feat_hw.shape[-1]:
+        raise NotImplementedError("decoder batch size must be 1 (as in every reference call)")
+    if alphas is not None:
+        alphas = alphas.reshape(H, W)
+    feat = feat_hw.reshape(H, W, feat_hw.shape[-1])
+    if isinstance(rays, (tuple, list)):
+        return DecodeWithChannels.apply(feat, alphas, None, rays[0], rays[1], w1, w2, c0, n)
+    return DecodeWithChannels.apply(feat, alphas, rays.reshape(6, H, W), None, None, w1, w2, c0, n)
+
+
 def decode(feat_hw: Tensor, alphas: Optional[Tensor], rays, w1: Tensor, w2: Tensor, has_depth: bool):
     """feat_hw [..,H,W,CF>=9(+1)], alphas [..,H,W] or [..,H,W,1] -> rgb [3,H,W], depth [H,W]|None.
     `rays`: the reference's cam_ray map [1,6,H,W], or a pair (intr [4] = fx,fy,cx,cy, c2w [3,4] or [4,4]) to have
