@@ -281,8 +281,8 @@ def timed(step, steps, warmup, world, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--ns", type=int, default=200_000)
     ap.add_argument("--nd", type=int, default=100_000)
     ap.add_argument("--width", type=int, default=1352)
