@@ -136,11 +136,17 @@ def cpu_torch_reference(width, height, ns=10_000):
 
 
 def source_sha():
-    """Identity of the compositor / binning sources a committed PMC summary was collected with."""
+    """Identity of the compositor / binning sources a committed PMC summary was collected with: their code with
+    comments and blank lines removed (a reworded comment does not make the counters stale)."""
+    import re
     h = hashlib.sha256()
     for f in ("raster.hip", "isect.hip", "common.h"):
-        with open(os.path.join(ROOT, "mobgs_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, "mobgs_amd", "csrc", f), "r", encoding="utf-8") as fh:
+            text = fh.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        code = "\n".join(line.rstrip() for line in text.splitlines() if line.strip())
+        h.update(code.encode())
     return h.hexdigest()[:16]
 
 
