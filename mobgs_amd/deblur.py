@@ -20,13 +20,37 @@ from .distributed import SubframeShard
 from .gaussian_renderer import render
 
 
+def get_flow_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor, shard: SubframeShard, n_sub: int = 9,
+                   exposure_max_delta: float = 1.0, pipe=None) -> Dict[Tuple[int, int], tuple]:
+    """The n_sub get_flow() calls per view of train.py:564-579 (exposure offsets exposure_max_delta * (k - half) /
+    half), for the (view, sub-frame) units THIS rank owns: {(view, k): (exp2mid, mid2exp, latent_img, latent_alpha)}.
+    The units are dealt round-robin like the renders, rotated by the number of render units so that the ranks the
+    renders left with one unit fewer take the surplus here; a rank's calls of one view share the mid-exposure state
+    (get_flow_many).  The flow loss is a sum of per-sub-frame terms: the owner of a unit forms the unit's term, the
+    gradient SUM of all_reduce_gradients() then counts every term once -- and because those terms also read the
+    blurry prediction, the prediction's exchange must reduce its backward (render_blurry_batch(...,
+    rank_local_terms=True)) and terms all ranks form identically on it go through shard.replicated_term()."""
+    from .gaussian_renderer import get_flow_many
+    V, half = len(cams), n_sub // 2
+    mine = shard.view_units(V, n_sub, offset=V * n_sub)
+    out: Dict[Tuple[int, int], tuple] = {}
+    for v in sorted({v for v, _ in mine}):
+        ks = [k for vv, k in mine if vv == v]
+        deltas = [exposure_max_delta * (k - half) / half for k in ks]
+        for k, res in zip(ks, get_flow_many(cams[v], stat_pc, dyn_pc, pipe, bg_color, deltas)):
+            out[(v, k)] = res
+    return out
+
+
 def render_blurry_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor, shard: SubframeShard,
                         blce=None, n_sub: int = 9, exposures: Optional[Sequence[Sequence]] = None,
-                        train_mode_mid: bool = True, pipe=None) -> Tuple[torch.Tensor, Dict[int, dict]]:
+                        train_mode_mid: bool = True, pipe=None,
+                        rank_local_terms: bool = False) -> Tuple[torch.Tensor, Dict[int, dict]]:
     """cams: the batch's view cameras.  blce: a mobgs_amd.blce.blceKernel (None: every sub-frame uses the view's own
     camera and `exposures[v][k]` / 0 as exposure offset -- the reference before `start_warp`).
     -> (pred [V,3,H,W] on every rank, {view index: result dict of its mid (train-mode) render} for the mid frames this
-    rank rendered)."""
+    rank rendered).  rank_local_terms: some loss term on `pred` is formed by one rank only (get_flow_batch): the
+    exchange then all-reduces its backward too."""
     V = len(cams)
     half = n_sub // 2
     mine = shard.view_units(V, n_sub)
@@ -59,7 +83,7 @@ def render_blurry_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor,
     if not mine:  # more ranks than units: contribute zeros (image size from the first camera)
         c = cams[0]
         like = torch.zeros(3, int(c.image_height), int(c.image_width), device=bg_color.device)
-        return shard.render_blurry_views(unit, V, n_sub, like=like), mids
+        return shard.render_blurry_views(unit, V, n_sub, like=like, reduce_backward=rank_local_terms), mids
     # the image shape is known after the first unit; render_blurry_views only needs `like` for views this rank has no
     # unit of, so hand it a lazily-filled zero image
     first_v, first_k = mine[0]
@@ -69,4 +93,5 @@ def render_blurry_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor,
     def unit_cached(v, k):
         return cache.pop((v, k)) if (v, k) in cache else unit(v, k)
 
-    return shard.render_blurry_views(unit_cached, V, n_sub, like=torch.zeros_like(img0)), mids
+    return shard.render_blurry_views(unit_cached, V, n_sub, like=torch.zeros_like(img0),
+                                     reduce_backward=rank_local_terms), mids

@@ -45,12 +45,16 @@ def _all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
 
 
 class _SumAcrossRanks(torch.autograd.Function):
-    """y = sum_r x_r (all-reduce).  The caller's loss is a function of y that is IDENTICAL on every rank, so the
-    gradient of that single loss w.r.t. this rank's x_r is dL/dy itself: backward is the identity.
+    """y = sum_r x_r (all-reduce).  reduce_backward=False: the caller's loss is a function of y that is IDENTICAL on
+    every rank, so the gradient of that single loss w.r.t. this rank's x_r is dL/dy itself -- backward is the identity.
+    reduce_backward=True: the ranks put DIFFERENT terms on y (each the loss terms of the units it owns, e.g. the
+    flow losses of its get_flow calls, which read the blurry prediction): the gradient of the total w.r.t. x_r is the
+    SUM over ranks of their dL_r/dy -- backward all-reduces.
     donate=True: x is a fresh temporary nobody else reads (the stacked partial sums) -- reduced in place, no copy."""
 
     @staticmethod
-    def forward(ctx, x, group, donate):
+    def forward(ctx, x, group, donate, reduce_backward=False):
+        ctx.group, ctx.reduce_backward = group, bool(reduce_backward)
         y = x.detach()
         if not (donate and y.is_contiguous()):
             y = y.clone(memory_format=torch.contiguous_format)
@@ -62,7 +66,10 @@ class _SumAcrossRanks(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g, None, None
+        if ctx.reduce_backward:
+            g = g.contiguous().clone()
+            _all_reduce_sum(g, ctx.group)
+        return g, None, None, None
 
 
 class FlatGradients:
@@ -129,21 +136,23 @@ class SubframeShard:
         self.world, self.rank, self.group = int(world_size), int(rank), group
 
     # ---- partition ----------------------------------------------------------------------------------
-    def units(self, n_units: int) -> List[int]:
-        """Unit indices this rank renders: u mod world == rank (round-robin keeps 9 units over 8 ranks at
-        ceil(9/8) = 2 on one rank, 1 elsewhere; 18 units -- two views, the reference's batch -- at 3,3,2,...)."""
-        return [u for u in range(n_units) if u % self.world == self.rank]
+    def units(self, n_units: int, offset: int = 0) -> List[int]:
+        """Unit indices this rank renders: (u + offset) mod world == rank (round-robin keeps 9 units over 8 ranks at
+        ceil(9/8) = 2 on one rank, 1 elsewhere; 18 units -- two views, the reference's batch -- at 3,3,2,...).
+        `offset` rotates the assignment: a second family of units (the get_flow calls of the same batch) started at
+        offset = number of units of the first hands ITS surplus to the ranks the first family left short."""
+        return [u for u in range(n_units) if (u + offset) % self.world == self.rank]
 
-    def owner(self, unit: int) -> int:
-        return unit % self.world
+    def owner(self, unit: int, offset: int = 0) -> int:
+        return (unit + offset) % self.world
 
-    def owns(self, unit: int) -> bool:
-        return unit % self.world == self.rank
+    def owns(self, unit: int, offset: int = 0) -> bool:
+        return (unit + offset) % self.world == self.rank
 
-    def view_units(self, n_views: int, n_sub: int) -> List[Tuple[int, int]]:
+    def view_units(self, n_views: int, n_sub: int, offset: int = 0) -> List[Tuple[int, int]]:
         """(view, sub-frame) pairs of this rank for a batch of `n_views` views with `n_sub` sub-frames each; the
         global unit index is view * n_sub + sub-frame."""
-        return [(u // n_sub, u % n_sub) for u in self.units(n_views * n_sub)]
+        return [(u // n_sub, u % n_sub) for u in self.units(n_views * n_sub, offset)]
 
     def replicated_term(self, loss_term: torch.Tensor) -> torch.Tensor:
         """Scale a loss term that EVERY rank forms identically from replicated data (not through the all-reduced
@@ -151,13 +160,15 @@ class SubframeShard:
         return loss_term if self.world == 1 else loss_term / self.world
 
     # ---- forward exchange ---------------------------------------------------------------------------
-    def mean_of_subframes(self, local_sum: torch.Tensor, n_units: int, donate: bool = False) -> torch.Tensor:
+    def mean_of_subframes(self, local_sum: torch.Tensor, n_units: int, donate: bool = False,
+                          reduce_backward: bool = False) -> torch.Tensor:
         """local_sum = sum of THIS rank's sub-frame renders (any leading batch dimensions) -> mean over all n_units
         sub-frames (+1e-10, as train.py:541), identical on every rank.  With one process and one unit it is the
-        render itself."""
+        render itself.  reduce_backward: see _SumAcrossRanks -- needed as soon as some loss term on the prediction
+        exists on ONE rank only (then every term all ranks form identically on it goes through replicated_term())."""
         if self.world == 1:
             return local_sum if n_units == 1 else local_sum / n_units + 1e-10
-        total = _SumAcrossRanks.apply(local_sum, self.group, donate)
+        total = _SumAcrossRanks.apply(local_sum, self.group, donate, reduce_backward)
         return total / n_units + 1e-10
 
     def render_blurry_view(self, render_unit: Callable[[int], torch.Tensor], n_units: int,
@@ -177,7 +188,7 @@ class SubframeShard:
         return self.mean_of_subframes(local, n_units)
 
     def render_blurry_views(self, render_unit: Callable[[int, int], torch.Tensor], n_views: int, n_sub: int,
-                            like: torch.Tensor) -> torch.Tensor:
+                            like: torch.Tensor, reduce_backward: bool = False) -> torch.Tensor:
         """Batch form (train.py:430-541 loops over the views of the batch): render_unit(view, k) -> [3,H,W].
         ONE all-reduce for the whole batch: returns the blurry predictions [n_views,3,H,W] on every rank."""
         sums: List[Optional[torch.Tensor]] = [None] * n_views
@@ -185,7 +196,7 @@ class SubframeShard:
             img = render_unit(v, k)
             sums[v] = img if sums[v] is None else sums[v] + img
         local = torch.stack([s if s is not None else torch.zeros_like(like) for s in sums])
-        return self.mean_of_subframes(local, n_sub, donate=True)
+        return self.mean_of_subframes(local, n_sub, donate=True, reduce_backward=reduce_backward)
 
     # ---- backward exchange --------------------------------------------------------------------------
     def all_reduce_gradients(self, params, async_op: bool = False):

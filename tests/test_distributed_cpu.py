@@ -191,3 +191,83 @@ def test_view_unit_partition():
     assert sorted(pairs) == [(v, k) for v in range(2) for k in range(9)]
     assert sorted(len(sh.view_units(2, 9)) for sh in s) == [2, 2, 2, 2, 2, 2, 3, 3]
     assert s[4].owns(4) and s[5].owns(13)  # the two mid frames land on different ranks
+
+
+# ---- rank-local loss terms on the prediction (the flow losses of sharded get_flow units) -----------------------------
+def _toy_flow(params, v, k):
+    """stand-in for one get_flow() result of view v, sub-frame k"""
+    w, b = params
+    grid = torch.linspace(-1, 1, 6 * 8).reshape(1, 6, 8)
+    return torch.sin(w[0] * grid * (k + 1) + b) * (1.0 + 0.1 * v)
+
+
+def _flow_term(pred_v, flow):
+    return 0.05 * ((pred_v.mean(0, keepdim=True) - flow).abs()).mean()  # reads the prediction AND the unit's flow
+
+
+def _flow_single():
+    torch.manual_seed(0)
+    w = torch.randn(2, requires_grad=True)
+    b = torch.randn(1, requires_grad=True)
+    pred = torch.stack([torch.stack([_toy_unit((w, b), v, k) for k in range(K)]).mean(0) + 1e-10 for v in range(V)])
+    loss = (pred - 0.3).abs().mean()
+    for v in range(V):
+        for k in range(K):
+            loss = loss + _flow_term(pred[v], _toy_flow((w, b), v, k))
+    loss.backward()
+    return w.grad.clone(), b.grad.clone()
+
+
+def _flow_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        w = torch.randn(2, requires_grad=True)
+        b = torch.randn(1, requires_grad=True)
+        shard = SubframeShard()
+        bucket = FlatGradients([w, b])
+        bucket.zero()
+        pred = shard.render_blurry_views(lambda v, k: _toy_unit((w, b), v, k), V, K, like=torch.zeros(3, 6, 8),
+                                         reduce_backward=True)
+        loss = shard.replicated_term((pred - 0.3).abs().mean())      # every rank forms it: 1 / world
+        mine = shard.view_units(V, K, offset=V * K)                  # the flow units of this rank
+        for v, k in mine:
+            loss = loss + _flow_term(pred[v], _toy_flow((w, b), v, k))   # owner only
+        loss.backward()
+        shard.all_reduce_gradients(bucket)
+        q.put((rank, w.grad.clone(), b.grad.clone(), mine))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_local_terms_on_the_prediction_need_the_backward_reduction():
+    """Flow losses of sharded get_flow units read the blurry prediction: with reduce_backward=True on the prediction's
+    exchange (and the replicated photometric term through replicated_term) the summed gradients equal the
+    single-process ones; the flow units are dealt with the rotated partition."""
+    ref_w, ref_b = _flow_single()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(u for _, _, _, mine in results for u in mine) == [(v, k) for v in range(V) for k in range(K)]
+    for rank, gw, gb, _ in results:
+        assert torch.allclose(gw, ref_w, atol=1e-6) and torch.allclose(gb, ref_b, atol=1e-6), \
+            f"rank {rank}: {gw} vs {ref_w}, {gb} vs {ref_b}"
+
+
+def test_rotated_partition_balances_two_unit_families():
+    """18 render units + 18 flow units over 8 ranks: rotating the second family by the size of the first gives every
+    rank 4 or 5 units in total instead of 6 on two ranks."""
+    s = [SubframeShard(8, r) for r in range(8)]
+    renders = [len(sh.view_units(2, 9)) for sh in s]
+    flows = [len(sh.view_units(2, 9, offset=18)) for sh in s]
+    assert sorted(renders) == [2, 2, 2, 2, 2, 2, 3, 3] and sorted(flows) == [2, 2, 2, 2, 2, 2, 3, 3]
+    assert sorted(a + b for a, b in zip(renders, flows)) == [4, 4, 4, 4, 5, 5, 5, 5]
+    assert sorted(p for sh in s for p in sh.view_units(2, 9, offset=18)) == [(v, k) for v in range(2) for k in range(9)]

@@ -92,8 +92,10 @@ def test_blurry_view_k9_blce_matches_reference_fixture(hip_device, blce_mode):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def _iteration(dev, shard, fx_name="blurry_view", n_views=2):
-    """One sharded training iteration on the fixture scene (two views: the fixture's pose and a second one)."""
+def _iteration(dev, shard, fx_name="blurry_view", n_views=2, with_flows=False):
+    """One sharded training iteration on the fixture scene (two views: the fixture's pose and a second one).
+    with_flows: the get_flow calls of the batch are sharded too (deblur.get_flow_batch) and each unit's owner adds a
+    flow term that reads the unit's outputs AND the blurry prediction."""
     from mobgs_amd.camera import PinholeCamera
     from mobgs_amd.deblur import render_blurry_batch
     from mobgs_amd.distributed import FlatGradients
@@ -115,9 +117,18 @@ def _iteration(dev, shard, fx_name="blurry_view", n_views=2):
     v_pred = torch.randn(n_views, 3, H, W, generator=g).to(dev)
     v_depth = torch.randn(1, H, W, generator=g).to(dev)
     bucket.zero()
-    pred, mids = render_blurry_batch(cams, stat, dyn, bg, shard, blce=kern, n_sub=9)
+    pred, mids = render_blurry_batch(cams, stat, dyn, bg, shard, blce=kern, n_sub=9, rank_local_terms=with_flows)
     reg = 1e-3 * sum((p ** 2).sum() for p in (stat._scaling, dyn._scaling))
-    loss = (pred * v_pred).sum() + shard.replicated_term(reg)
+    photo = (pred * v_pred).sum()
+    # with rank-local terms on the prediction its exchange reduces the backward pass too, so the term every rank forms
+    # identically on it counts 1 / world per rank
+    loss = (shard.replicated_term(photo) if with_flows else photo) + shard.replicated_term(reg)
+    if with_flows:
+        from mobgs_amd.deblur import get_flow_batch
+        flows = get_flow_batch(cams, stat, dyn, bg, shard, n_sub=9)
+        for (v, k), (e2m, m2e, limg, lalpha) in sorted(flows.items()):
+            wk = 0.1 * (k + 1)
+            loss = loss + wk * ((limg * pred[v]).mean() + 1e-3 * (e2m - m2e).abs().mean() + (lalpha * v_depth).mean())
     for v, pkg in mids.items():
         loss = loss + (pkg["depth"] * v_depth).sum() + 0.5 * (pkg["d_alpha"] * v_depth).sum()
     with LeafGradSink(stat, dyn, extra=kern.model.get_params()):
@@ -128,32 +139,34 @@ def _iteration(dev, shard, fx_name="blurry_view", n_views=2):
     return pred.detach().cpu(), bucket.flat.detach().cpu(), sorted(mids)
 
 
-def _shard_worker(rank, world, port, q):
+def _shard_worker(rank, world, port, q, with_flows=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from mobgs_amd.distributed import SubframeShard
         torch.cuda.set_device(0)
-        pred, flat, mids = _iteration(torch.device("cuda:0"), SubframeShard())
+        pred, flat, mids = _iteration(torch.device("cuda:0"), SubframeShard(), with_flows=with_flows)
         q.put((rank, pred.numpy(), flat.numpy(), mids))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_iteration_world2_on_one_gpu_equals_single_process(hip_device):
+@pytest.mark.parametrize("with_flows", [False, True])
+def test_sharded_iteration_world2_on_one_gpu_equals_single_process(hip_device, with_flows):
     """Both ranks run the real HIP render on this GPU (collectives through gloo, staged via the host): 18 (view,
-    sub-frame) units split 9 / 9, mid frames of the two views on different ranks."""
+    sub-frame) units split 9 / 9, mid frames of the two views on different ranks.  with_flows: the 18 get_flow units
+    are sharded as well, their owners' loss terms read the blurry prediction (backward-reduced exchange)."""
     import torch.multiprocessing as mp
     from mobgs_amd.distributed import SubframeShard
-    ref_pred, ref_flat, _ = _iteration(hip_device, SubframeShard(1, 0))
+    ref_pred, ref_flat, _ = _iteration(hip_device, SubframeShard(1, 0), with_flows=with_flows)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q, with_flows)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]
