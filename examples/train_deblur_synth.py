@@ -1,0 +1,138 @@
+#!/usr/bin/env python
+"""A miniature of the reference's DEBLUR training iteration (train.py:430-700) on a synthetic scene, end to end on the
+MI355X path and, under torchrun, sharded over GPUs:
+
+  per view of the batch   blcekernel.get_warped_cams -> K = 9 latent renders (mid frame in train mode) -> mean = blurry
+                          prediction (mobgs_amd.deblur.render_blurry_batch: ONE all-reduce for the batch)
+                          K get_flow() calls (mobgs_amd.deblur.get_flow_batch, sharded like the renders)
+  loss                    photometric (L1 + 0.2 D-SSIM, fused) on the prediction, depth / mask terms on the mid render,
+                          a flow term per sub-frame (latent image vs. prediction, the two coordinate maps), a
+                          regulariser on the scales
+  backward                ops.LeafGradSink + distributed.FlatGradients, ONE in-place gradient all-reduce that also carries
+                          the mid-frame densification statistics
+  step                    Adam on both Gaussian sets, the decoder and the BLCE parameters; densification statistics
+
+    python examples/train_deblur_synth.py [--iters 60]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 examples/train_deblur_synth.py
+
+The "ground truth" blurry views are K-frame averages of the same scene with perturbed colours seen through jittered
+cameras, so the loss has somewhere to go.  Used by tests/test_gpu_train_loop.py as an integration test.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+torch.autograd.set_multithreading_enabled(False)
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mobgs_amd.blce import blceKernel  # noqa: E402
+from mobgs_amd.camera import PinholeCamera  # noqa: E402
+from mobgs_amd.deblur import get_flow_batch, render_blurry_batch  # noqa: E402
+from mobgs_amd.densify import TrainableGaussians  # noqa: E402
+from mobgs_amd.distributed import FlatGradients, SubframeShard  # noqa: E402
+from mobgs_amd.gaussian_renderer import render  # noqa: E402
+from mobgs_amd.helper_model import Sandwich  # noqa: E402
+from mobgs_amd.loss_utils import l1_loss, photometric_loss  # noqa: E402
+from mobgs_amd.ops import LeafGradSink  # noqa: E402
+from mobgs_amd.synth import SynthCamera, dynamic_extras, gaussian_cloud  # noqa: E402
+from train_synth import Opt  # noqa: E402  (examples/ is on sys.path when run as a script or from the test)
+
+K = 9
+
+
+def view_pose(i):
+    w2c = torch.eye(4)
+    w2c[:3, 3] = torch.tensor([0.04 * i, -0.02 * i, 0.03 * i])
+    return w2c
+
+
+def train(dev="cuda:0", iters=40, ns=4000, nd=2000, width=256, height=192, n_views=2, seed=0, lambda_flow=1e-2,
+          shard=None, log=None):
+    shard = shard or SubframeShard()
+    scam = SynthCamera().scaled(width, height)
+    torch.manual_seed(seed)
+    dec = Sandwich(9, 3).to(dev)
+    sp, dp = gaussian_cloud(ns, scam, seed), gaussian_cloud(nd, scam, seed + 1)
+    dx = dynamic_extras(dp["xyz"], seed)
+    stat = TrainableGaussians(sp, None, dec, device=dev)
+    dyn = TrainableGaussians(dp, dx, dec, device=dev)
+    bg = torch.zeros(9, device=dev)
+    g = torch.Generator().manual_seed(seed + 100)
+    cams = []
+    for i in range(n_views):
+        c = PinholeCamera(width, height, scam.K, view_pose(i), time=(5.0 + 6 * i) / 23.0, max_time=23, device=dev)
+        c.uid = i
+        cams.append(c)
+    # blurry targets: mean of K renders of a colour-shifted copy of the scene at spread-out exposure offsets
+    with torch.no_grad():
+        tsp = dict(sp, features_dc=sp["features_dc"] + 0.4 * torch.randn(sp["features_dc"].shape, generator=g))
+        tdp = dict(dp, features_dc=dp["features_dc"] + 0.4 * torch.randn(dp["features_dc"].shape, generator=g))
+        tstat, tdyn = TrainableGaussians(tsp, None, dec, device=dev), TrainableGaussians(tdp, dx, dec, device=dev)
+        targets, depths = [], []
+        for c in cams:
+            outs = [render(c, tstat, tdyn, None, bg, delta_exposure=float(d))
+                    for d in torch.linspace(-0.6, 0.6, K)]
+            targets.append(torch.stack([o["render"] for o in outs]).mean(0).clamp(0, 1))
+            depths.append(outs[K // 2]["depth"].detach())
+            c.image = targets[-1]  # BLCE's blur statistic reads the (blurry) input image of the view
+    torch.manual_seed(seed + 1)
+    blce = blceKernel(num_views=n_views, num_warp=K, iteration=max(iters, 1)).to(dev)
+    opt = Opt()
+    stat.training_setup(opt)
+    dyn.training_setup(opt)
+    dyn.optimizer.param_groups = [gr for gr in dyn.optimizer.param_groups if gr["name"] != "decoder"]
+    params = [p for gr in stat.optimizer.param_groups + dyn.optimizer.param_groups for p in gr["params"]] \
+        + list(blce.model.get_params())
+    n_all = ns + nd
+    bucket = FlatGradients(params, extra={f"view{v}": 3 * n_all for v in range(n_views)})
+    history = []
+    for it in range(1, iters + 1):
+        bucket.zero()
+        pred, mids = render_blurry_batch(cams, stat, dyn, bg, shard, blce=blce, n_sub=K, rank_local_terms=True)
+        flows = get_flow_batch(cams, stat, dyn, bg, shard, n_sub=K)
+        gt = torch.stack(targets)
+        photo = photometric_loss(pred, gt, opt.lambda_dssim)
+        loss = shard.replicated_term(photo)                      # every rank forms it on the replicated prediction
+        for v, pkg in mids.items():                              # the rank that rendered the mid frame
+            loss = loss + 0.05 * l1_loss(pkg["depth"], depths[v]) + 0.01 * pkg["d_alpha"].mean()
+        for (v, k), (e2m, m2e, limg, lalpha) in flows.items():   # the owner of the flow unit
+            loss = loss + lambda_flow / K * (l1_loss(limg, pred[v]) + 1e-3 * (e2m - m2e).abs().mean()
+                                             + 0.1 * lalpha.mean())
+        loss = loss + shard.replicated_term(1e-4 * ((stat._scaling ** 2).mean() + (dyn._scaling ** 2).mean()))
+        with LeafGradSink(stat, dyn, extra=blce.model.get_params()):
+            loss.backward()
+        for v, pkg in mids.items():
+            shard.put_densification_stats(bucket, f"view{v}", pkg["viewspace_points"].grad, pkg["radii"])
+        shard.all_reduce_gradients(bucket)
+        with torch.no_grad():
+            for v in range(n_views):
+                grad2d, radii = shard.get_densification_stats(bucket, f"view{v}")
+                vis = radii > 0
+                stat.add_densification_stats(grad2d[:ns], vis[:ns], radii=radii[:ns])
+                dyn.add_densification_stats(grad2d[ns:], vis[ns:], radii=radii[ns:])
+        stat.optimizer.step()
+        dyn.optimizer.step()
+        blce.optimizer.step()
+        history.append(float(photo.detach()))
+        if log and (it % log == 0 or it == 1) and shard.rank == 0:
+            print(f"it {it:4d}  photometric {history[-1]:.5f}")
+    return history, stat, dyn, blce, bucket
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=60)
+    ap.add_argument("--ns", type=int, default=20000)
+    ap.add_argument("--nd", type=int, default=10000)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--height", type=int, default=288)
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    train(dev=f"cuda:{local}", iters=a.iters, ns=a.ns, nd=a.nd, width=a.width, height=a.height, log=10)
