@@ -160,6 +160,24 @@ __device__ inline int owner_in(const Cum& cum, int lo, int hi, int j) {
     return lo;
 }
 
+// The same answer found by a whole wave: every lane probes one of 64 evenly spaced candidates per round, the ballot of
+// "cum[probe] <= j" (a prefix of ones, cum is non-decreasing) narrows [lo, hi) 64-fold -- 4 dependent global loads for
+// 300 k splats where the binary search above needs 18.  bin_kernel's two chunk-boundary searches sit at the head of
+// every workgroup's dependency chain (2 x 18 L2 round trips before the first useful load).  All lanes must be
+// active and call it with the same arguments.
+__device__ inline int owner_in_wave(const int32_t* __restrict__ cum, int lo, int hi, int j) {
+    const int lane = threadIdx.x & 63;
+    while (hi - lo > 1) {
+        const int step = (hi - lo + 63) >> 6;
+        const int probe = lo + (lane + 1) * step;
+        const bool le = probe < hi && cum[probe] <= j;
+        const int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(le));
+        lo += c * step;
+        hi = min(hi, lo + step);
+    }
+    return lo;
+}
+
 // stride of the per-tile list counters (1 = packed; giving each counter its own 128-byte line was measured: no gain
 // for the atomics of a dense image region, +12 us in tile_scan)
 constexpr int TC_STRIDE = 1;
@@ -202,8 +220,8 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
         return;
     }
     const int end = min(I, start + SCAN_BLOCK);
-    const int g_lo = owner_in(cum, 0, n_gauss, start);
-    const int g_hi = owner_in(cum, g_lo, n_gauss, end - 1);
+    const int g_lo = owner_in_wave(cum, 0, n_gauss, start);
+    const int g_hi = owner_in_wave(cum, g_lo, n_gauss, end - 1);
     const int span = g_hi - g_lo + 1;
     const bool cached = span <= OWNER_LDS;
     if (cached) {
