@@ -168,6 +168,10 @@ class SubframeShard:
         exists on ONE rank only (then every term all ranks form identically on it goes through replicated_term())."""
         if self.world == 1:
             return local_sum if n_units == 1 else local_sum / n_units + 1e-10
+        if reduce_backward and not local_sum.requires_grad:
+            # a rank without a render unit (more ranks than units) still forms loss terms on the prediction and must
+            # take part in the backward all-reduce: give the exchange node an input that requires grad
+            local_sum = local_sum.detach().requires_grad_(True).clone()  # (a non-leaf: `donate` reduces in place)
         total = _SumAcrossRanks.apply(local_sum, self.group, donate, reduce_backward)
         return total / n_units + 1e-10
 

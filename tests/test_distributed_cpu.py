@@ -262,6 +262,55 @@ def test_rank_local_terms_on_the_prediction_need_the_backward_reduction():
             f"rank {rank}: {gw} vs {ref_w}, {gb} vs {ref_b}"
 
 
+def _idle_rank_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        w = torch.randn(2, requires_grad=True)
+        b = torch.randn(1, requires_grad=True)
+        shard = SubframeShard()
+        bucket = FlatGradients([w, b])
+        bucket.zero()
+        # ONE render unit over three ranks: ranks 1 and 2 render nothing, yet own flow units that read the prediction
+        pred = shard.render_blurry_views(lambda v, k: _toy_unit((w, b), v, k), 1, 1, like=torch.zeros(3, 6, 8),
+                                         reduce_backward=True)
+        loss = shard.replicated_term((pred - 0.3).abs().mean())
+        for k in range(3):
+            if shard.owns(k, offset=1):
+                loss = loss + _flow_term(pred[0], _toy_flow((w, b), 0, k))
+        loss.backward()
+        shard.all_reduce_gradients(bucket)
+        q.put((rank, w.grad.clone(), b.grad.clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_without_render_unit_still_joins_the_backward_reduction():
+    """world 3, one render unit: the ranks that contribute a zero image hold loss terms on the prediction; the
+    exchange node must exist in their graphs too (else the owner's backward all-reduce waits for ever)."""
+    torch.manual_seed(0)
+    w = torch.randn(2, requires_grad=True)
+    b = torch.randn(1, requires_grad=True)
+    pred = torch.stack([_toy_unit((w, b), 0, 0) + 1e-10])
+    loss = (pred - 0.3).abs().mean()
+    for k in range(3):
+        loss = loss + _flow_term(pred[0], _toy_flow((w, b), 0, k))
+    loss.backward()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_idle_rank_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, gw, gb in results:
+        assert torch.allclose(gw, w.grad, atol=1e-6) and torch.allclose(gb, b.grad, atol=1e-6), (rank, gw, w.grad)
+
+
 def test_rotated_partition_balances_two_unit_families():
     """18 render units + 18 flow units over 8 ranks: rotating the second family by the size of the first gives every
     rank 4 or 5 units in total instead of 6 on two ranks."""
