@@ -21,6 +21,10 @@
 namespace mobgs {
 
 constexpr int DEC_THREADS = 256;
+#ifndef MOBGS_DEC_W1_ROWS
+#define MOBGS_DEC_W1_ROWS 2
+#endif
+constexpr int W1_ROWS = MOBGS_DEC_W1_ROWS;  // rows of the first layer held in SGPRs at a time (see reload_here)
 constexpr int NRED = 102;  // per-workgroup partial row: 72 (w1) + 18 (w2) + 12 (c2w) gradients
 
 struct Weights {
@@ -35,6 +39,20 @@ __device__ inline Weights load_weights(const float* __restrict__ w1, const float
 #pragma unroll
     for (int k = 0; k < 18; ++k) W.w2[k] = w2[k];
     return W;
+}
+
+// The 90 weights + the camera + the kernel's pointers do not fit the SGPR file: kept live across the pixel loop, the
+// register allocator parks the excess in VGPR lanes and every iteration pays ~190 v_readlane_b32 (half-rate VALU) to get
+// them back -- as many issue slots as the arithmetic.  Instead each use re-reads its weights with scalar loads from a
+// pointer the optimiser cannot see through (so the loads stay inside the loop, next to their use): they hit the scalar
+// cache and issue on the scalar unit, off the VALU.
+typedef const float __attribute__((address_space(4))) * ConstWeights;  // constant address space: scalar loads
+__device__ __forceinline__ ConstWeights reload_here(const float* p) {
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+s"(v));
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (ConstWeights)(((unsigned long long)hi << 32) | lo);
 }
 
 struct RayCam {
@@ -71,7 +89,6 @@ decoder_fwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
                    const float* __restrict__ ray_intr, const float* __restrict__ ray_c2w,
                    const float* __restrict__ w1, const float* __restrict__ w2,
                    float* __restrict__ rgb, float* __restrict__ depth) {
-    const Weights W = load_weights(w1, w2);
     RayCam cam;
     if (!rays) cam = load_raycam(ray_intr, ray_c2w);
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
@@ -88,17 +105,22 @@ decoder_fwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
         }
         float h[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            float s = 0.f;
+        for (int jg = 0; jg < 6 / W1_ROWS; ++jg) {  // W1_ROWS rows of W1 in SGPRs at a time
+            const ConstWeights w1a = reload_here(w1 + 12 * W1_ROWS * jg);
 #pragma unroll
-            for (int c = 0; c < 12; ++c) s = __fmaf_rn(W.w1[12 * j + c], x[c], s);
-            h[j] = fmaxf(s, 0.f);
+            for (int jj = 0; jj < W1_ROWS; ++jj) {
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 12; ++c) s = __fmaf_rn(w1a[12 * jj + c], x[c], s);
+                h[W1_ROWS * jg + jj] = fmaxf(s, 0.f);
+            }
         }
+        const ConstWeights w2a = reload_here(w2);
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             float y = 0.f;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) y = __fmaf_rn(W.w2[6 * o + j], h[j], y);
+            for (int j = 0; j < 6; ++j) y = __fmaf_rn(w2a[6 * o + j], h[j], y);
             const float z = f[o] + y;
             rgb[(size_t)o * P + p] = 1.f / (1.f + __expf(-z));
         }
@@ -133,6 +155,10 @@ __device__ __forceinline__ void dec_wave_fence() {
 // the 90 weights + camera + pointers exceed the SGPR file and are partly spilled to VGPR lanes -- 87 us, because the
 // register allocator then keeps the uniform values in VGPRs and the occupancy halves.)
 constexpr int NACC = 30;  // 18 (w2) + 12 (c2w)
+// RAY_MAP: the rays come from the [6,P] map (else from the pinhole parameters, in registers).  A template parameter, not
+// a run-time branch: with both paths in one kernel the wait for the map's loads is placed on the joined path and, the
+// vector-memory counter being in order, drains the prefetch of the next iteration with it.
+template <bool RAY_MAP>
 __global__ void __launch_bounds__(DEC_THREADS)
 decoder_bwd_kernel(int P, int CF, int has_depth, int width, const float* __restrict__ feat_hw,
                    const float* __restrict__ alphas, const float* __restrict__ rays,
@@ -143,9 +169,8 @@ decoder_bwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
                    float* __restrict__ w_partial) {
     __shared__ __attribute__((aligned(16))) float s_a[DEC_THREADS / 64][64][8];    // vh[6] (+2 zeros) per pixel
     __shared__ __attribute__((aligned(16))) float s_b[DEC_THREADS / 64][64][12];   // x[12] per pixel
-    const Weights W = load_weights(w1, w2);
     RayCam cam;
-    if (!rays) cam = load_raycam(ray_intr, ray_c2w);
+    if (!RAY_MAP) cam = load_raycam(ray_intr, ray_c2w);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;  // MFMA operand coordinates of this lane
     float gw[NACC];
@@ -155,20 +180,46 @@ decoder_bwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
     const int stride = gridDim.x * blockDim.x;
     const int p0 = blockIdx.x * blockDim.x + threadIdx.x;
     const int iters = (P - (blockIdx.x * blockDim.x + wv * 64) + stride - 1) / stride;  // wave-uniform trip count
+    // Software pipeline: the kernel moves 104 B per pixel with 4 waves per SIMD and one dependent chain per iteration
+    // (loads -> 300 instructions -> stores -> LDS -> 16 MFMAs), i.e. it is bound by bytes in flight, not by issue: the
+    // per-pixel inputs of iteration it + 1 are requested before iteration it is evaluated.
+    struct PixelIn {
+        float f[10], v_rgb[3], alpha, v_depth;
+    };
+    // (every load unconditional, from clamped addresses: a branch around a load puts the register shuffle of the
+    // merged value -- and with it the wait for the load -- right behind the load)
+    const float* alpha_src = has_depth ? alphas : feat_hw;
+    const float* vdepth_src = (has_depth && v_depth) ? v_depth : feat_hw;
+    const int depth_ch = has_depth ? 9 : 0;
+    auto fetch = [&](int p, PixelIn& in) {
+        p = min(p, P - 1);
+        const float* f = feat_hw + (size_t)p * CF;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) in.f[k] = f[k];
+        in.f[9] = f[depth_ch];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) in.v_rgb[o] = v_rgb[(size_t)o * P + p];
+        in.alpha = alpha_src[has_depth ? p : 0];
+        in.v_depth = vdepth_src[(has_depth && v_depth) ? p : 0];
+    };
+    PixelIn next;
+    fetch(p0, next);
     for (int it = 0; it < iters; ++it) {
         const int p = p0 + it * stride;
         const bool live = p < P;
+        const PixelIn in = next;
+        fetch(p + stride, next);
         float x[12], vh[6];
 #pragma unroll
         for (int k = 0; k < 12; ++k) x[k] = 0.f;
 #pragma unroll
         for (int k = 0; k < 6; ++k) vh[k] = 0.f;
         if (live) {
-            const float* f = feat_hw + (size_t)p * CF;
+            const float* f = in.f;
             float loc[2] = {0.f, 0.f}, inv_n = 0.f;
 #pragma unroll
             for (int k = 0; k < 6; ++k) x[k] = f[3 + k];
-            if (rays) {
+            if constexpr (RAY_MAP) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) x[6 + k] = rays[(size_t)k * P + p];
             } else {
@@ -176,38 +227,46 @@ decoder_bwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
             }
             float h[6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                float s = 0.f;
+            for (int jg = 0; jg < 6 / W1_ROWS; ++jg) {
+                const ConstWeights w1a = reload_here(w1 + 12 * W1_ROWS * jg);
 #pragma unroll
-                for (int c = 0; c < 12; ++c) s = __fmaf_rn(W.w1[12 * j + c], x[c], s);
-                h[j] = fmaxf(s, 0.f);
+                for (int jj = 0; jj < W1_ROWS; ++jj) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) s = __fmaf_rn(w1a[12 * jj + c], x[c], s);
+                    h[W1_ROWS * jg + jj] = fmaxf(s, 0.f);
+                }
             }
+            const ConstWeights w2a = reload_here(w2);
             float vy[3];
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
                 float y = 0.f;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) y = __fmaf_rn(W.w2[6 * o + j], h[j], y);
+                for (int j = 0; j < 6; ++j) y = __fmaf_rn(w2a[6 * o + j], h[j], y);
                 const float sg = 1.f / (1.f + __expf(-(f[o] + y)));
-                vy[o] = v_rgb[(size_t)o * P + p] * sg * (1.f - sg);
+                vy[o] = in.v_rgb[o] * sg * (1.f - sg);
             }
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 float s = 0.f;
 #pragma unroll
                 for (int o = 0; o < 3; ++o) {
-                    s = __fmaf_rn(W.w2[6 * o + j], vy[o], s);
+                    s = __fmaf_rn(w2a[6 * o + j], vy[o], s);
                     gw[6 * o + j] = __fmaf_rn(vy[o], h[j], gw[6 * o + j]);
                 }
                 vh[j] = h[j] > 0.f ? s : 0.f;
             }
             float vx[12];
 #pragma unroll
-            for (int c = 0; c < 12; ++c) {
-                float s = 0.f;
+            for (int c = 0; c < 12; ++c) vx[c] = 0.f;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) s = __fmaf_rn(W.w1[12 * j + c], vh[j], s);
-                vx[c] = s;
+            for (int jg = 0; jg < 6 / W1_ROWS; ++jg) {  // (j ascending per component, as one chain of FMAs)
+                const ConstWeights w1b = reload_here(w1 + 12 * W1_ROWS * jg);
+#pragma unroll
+                for (int jj = 0; jj < W1_ROWS; ++jj)
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) vx[c] = __fmaf_rn(w1b[12 * jj + c], vh[W1_ROWS * jg + jj], vx[c]);
             }
             float* vf = v_feat_hw + (size_t)p * CF;
 #pragma unroll
@@ -215,9 +274,9 @@ decoder_bwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
 #pragma unroll
             for (int k = 0; k < 6; ++k) vf[3 + k] = vx[k];
             if (has_depth) {
-                const float a = alphas[p];
+                const float a = in.alpha;
                 const float ac = fmaxf(a, 1e-10f);
-                const float g = v_depth ? v_depth[p] : 0.f;
+                const float g = v_depth ? in.v_depth : 0.f;
                 vf[9] = g / ac;
                 v_alphas[p] = a > 1e-10f ? -g * f[9] / (ac * ac) : 0.f;
             }
@@ -226,7 +285,7 @@ decoder_bwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
 #pragma unroll
                 for (int k = 0; k < 6; ++k) v_rays[(size_t)k * P + p] = vx[6 + k];
             }
-            if (!rays && want_cam_grad) {
+            if (!RAY_MAP && want_cam_grad) {
                 // origin = t; dir = d / |d| with d = R loc + [third column]: v_d = (v_dir - dir <dir, v_dir>) / |d|
                 const float dotp = x[9] * vx[9] + x[10] * vx[10] + x[11] * vx[11];
 #pragma unroll
@@ -312,7 +371,7 @@ using namespace mobgs;
 extern "C" {
 
 static int decoder_grid(int P) {
-    int g = (P + DEC_THREADS * 3 - 1) / (DEC_THREADS * 3);  // ~3 pixels per thread (measured optimum, 2..8 within 10 %)
+    int g = (P + DEC_THREADS * 3 - 1) / (DEC_THREADS * 3);  // ~3 pixels per thread (measured optimum, 3..12 within 4 %)
     if (g < 1) g = 1;
     if (g > 4096) g = 4096;
     return g;
@@ -346,7 +405,8 @@ int mobgs_decoder_bwd(int P, int CF, int has_depth, int width, const float* feat
         return MOBGS_E_INVALID;
     }
     const int g = decoder_grid(P);
-    hipLaunchKernelGGL(decoder_bwd_kernel, dim3(g), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth, width,
+    hipLaunchKernelGGL(rays ? decoder_bwd_kernel<true> : decoder_bwd_kernel<false>, dim3(g), dim3(DEC_THREADS), 0,
+                       (hipStream_t)stream, P, CF, has_depth, width,
                        feat_hw, alphas, rays, ray_intr, ray_c2w, g_c2w ? 1 : 0, w1, w2, v_rgb, v_depth, v_feat_hw,
                        v_alphas, v_rays, w_partial);
     const int nred = NRED + ((g_c2w && g_c2w_floats == 16) ? 4 : 0);
