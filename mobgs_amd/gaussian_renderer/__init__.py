@@ -452,7 +452,7 @@ def get_flow_many(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_expos
     pending = [o for o in outs if isinstance(o[1], tuple)]
     for g0 in range(0, len(pending), _FLOW_GROUP):
         grp = pending[g0:g0 + _FLOW_GROUP]
-        cols = torch.cat([-o[1][1] for o in grp], dim=-1)  # [N, 2 * len(grp)]
+        cols = -torch.cat([o[1][1] for o in grp], dim=-1)  # [N, 2 * len(grp)]  (one negation, not one per call)
         img = _R.rasterize_to_pixels(mid.means2d, mid.conics, cols, mid.opacities, mid.radii, mid.tl, W, H)[0]
         # split, not slices: its backward is ONE concatenation of the 2-channel cotangents instead of a zero image, a
         # strided copy and an add per call
