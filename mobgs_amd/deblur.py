@@ -8,7 +8,7 @@ it re-uses the train-mode render, :507-509) and averages: `pred = mean(rendered_
 `render_blurry_batch` does the same for the (view, sub-frame) units THIS rank owns (mobgs_amd.distributed) and
 exchanges the partial sums once for the whole batch.  With world = 1 it is exactly the reference's loop.
 bench.py times it (the "K-sub-frame deblur throughput" of BASELINE.json), tests/test_gpu_config4.py checks it against
-the oracle, examples/train_synth.py trains with it.
+the oracle, examples/train_deblur_synth.py trains with it.
 """
 from __future__ import annotations
 
