@@ -94,17 +94,18 @@ __device__ inline float min_sigma_over_tile(float mx, float my, float ca, float 
     if (mx >= x0 && mx <= x1 && my >= y0 && my <= y1) return 0.f;
     float best = 3.0e38f;
     const float ex[2] = {x0, x1}, ey[2] = {y0, y1};
+    const float sx = cb / cc, sy = cb / ca;  // two divisions for the four edges (as quadrant_reach_mask below)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         {  // vertical edge px = ex[k]: optimum dy = -cb dx / cc
             const float dx = mx - ex[k];
-            const float py = fminf(fmaxf(my + cb * dx / cc, y0), y1);
+            const float py = fminf(fmaxf(my + sx * dx, y0), y1);
             const float dy = my - py;
             best = fminf(best, 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy);
         }
         {  // horizontal edge py = ey[k]
             const float dy = my - ey[k];
-            const float px = fminf(fmaxf(mx + cb * dy / ca, x0), x1);
+            const float px = fminf(fmaxf(mx + sy * dy, x0), x1);
             const float dx = mx - px;
             best = fminf(best, 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy);
         }
