@@ -134,7 +134,10 @@ def run_case(c, dev):
     stats = {}
     f, e = frac_off(img.detach().cpu().numpy(), ref["render"], 0, 2e-5 * scale)
     stats["image"] = (f, e / scale)
-    if f > 5e-3 or e > scale * (1.0 / 255 if mode not in ("ED", "RGB+ED") else 1e9) * 1.5:
+    # a blend decision at the 1/255 threshold that falls the other way moves a pixel by alpha * T * |colour| <= |colour| / 255
+    # -- of the SPLAT's colour, which may exceed the image's range (seed 4242 case 28: colour 3.2, pixel off by 1.26e-2)
+    flip = max(scale, float(s["colors"].abs().max())) / 255
+    if f > 5e-3 or e > (flip if mode not in ("ED", "RGB+ED") else 1e9) * 1.5:
         problems.append(f"image: {f:.2e} of the pixels off, max {e:.3e} (scale {scale:.2e})")
     f, e = frac_off(a.detach().cpu().numpy()[..., 0], ref["alphas"], 0, 2e-5)
     stats["alpha"] = (f, e)
