@@ -115,12 +115,17 @@ __device__ inline int lookback_exclusive(uint64_t* status, int chunk, int aggreg
     return s_excl;
 }
 
-// cum[i] = sum of in[0..i), cum[n] = total (also stats_slot); n > 0
+// cum[i] = sum of in[0..i), cum[n] = total (also stats_slot); n > 0.
+// chunk_owner[m] (m < owner_slots) = the element whose interval [cum[i], cum[i+1]) holds position m * KEEP_CHUNK, for
+// every such position below the total: bin_kernel's workgroup m starts from it instead of searching cum (a chain of
+// dependent loads of data another XCD has just written, at the head of every workgroup).
 __global__ void __launch_bounds__(SCAN_THREADS) scan_lookback_kernel(int n, const int32_t* __restrict__ in,
                                                                        int32_t* __restrict__ cum,
                                                                        int32_t* __restrict__ counter,
                                                                        uint64_t* __restrict__ status,
-                                                                       int64_t* __restrict__ stats_slot) {
+                                                                       int64_t* __restrict__ stats_slot,
+                                                                       int32_t* __restrict__ chunk_owner,
+                                                                       int owner_slots) {
     const int chunk = take_ticket(counter);
     const int base = chunk * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
     int v[SCAN_ITEMS];
@@ -136,6 +141,12 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_lookback_kernel(int n, cons
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         if (base + k < n) cum[base + k] = run;
+        if (v[k] > 0) {  // chunk starts inside [run, run + v[k]): none or one, more only for splats over > 2048 tiles
+            const unsigned m1 = ((unsigned)run + (unsigned)v[k] - 1u) >> KEEP_CHUNK_LOG2;
+            for (unsigned m = ((unsigned)run + (unsigned)KEEP_CHUNK - 1u) >> KEEP_CHUNK_LOG2;
+                 m <= m1 && m < (unsigned)owner_slots; ++m)
+                chunk_owner[m] = base + k;
+        }
         run += v[k];
     }
     if (base <= n - 1 && n - 1 < base + SCAN_ITEMS) {  // the thread that owns the last element
@@ -204,7 +215,7 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
            const float* __restrict__ conics, const float* __restrict__ opacities, int opac_per_camera,
            int32_t* __restrict__ chunk_cnt, int32_t* __restrict__ owner, int32_t* __restrict__ tile_of_j,
            int32_t* __restrict__ rank_of_j, int32_t* __restrict__ tile_count, int32_t* __restrict__ keep_scan,
-           int n_tiles_total) {
+           int n_tiles_total, const int32_t* __restrict__ chunk_owner) {
     __shared__ int s_cum[OWNER_LDS + 1];
     extern __shared__ int s_tile[];  // DENSE: per-tile count of this workgroup, then the base of its range
     const int chunk = blockIdx.x;
@@ -220,8 +231,11 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
         return;
     }
     const int end = min(I, start + SCAN_BLOCK);
-    const int g_lo = owner_in_wave(cum, 0, n_gauss, start);
-    const int g_hi = owner_in_wave(cum, g_lo, n_gauss, end - 1);
+    // owner of the chunk's first intersection: left by the scan.  Upper end of the owner range: the owner of the NEXT
+    // chunk's first intersection when there is one (>= the owner of this chunk's last, which is all the searches
+    // below need: cum[g_hi + 1] > every j of the chunk), else -- one workgroup per launch -- a wave-wide search
+    const int g_lo = chunk_owner[chunk];
+    const int g_hi = end < I ? chunk_owner[chunk + 1] : owner_in_wave(cum, g_lo, n_gauss, end - 1);
     const int span = g_hi - g_lo + 1;
     const bool cached = span <= OWNER_LDS;
     if (cached) {
@@ -962,7 +976,8 @@ extern "C" {
 //   [tile_count nt * TC_STRIDE | ticket (+3 pad) | status 2*(nb1+1)]  <- zeroed by one memset
 //   [owner cap | tile cap | rank cap | chunk_cnt (cap >> 11) + 1]
 struct IsectScratch {
-    int32_t *tile_count, *tickets, *chunk_cnt, *owner, *tile_of_j, *rank_of_j;
+    int32_t *tile_count, *tickets, *chunk_cnt, *owner, *tile_of_j, *rank_of_j, *chunk_owner;
+    int owner_slots;
     uint64_t* status1;
     size_t zeroed_ints, total_ints;
     int nb1;
@@ -978,7 +993,9 @@ struct IsectScratch {
         tile_of_j = owner + capacity;
         rank_of_j = tile_of_j + capacity;
         chunk_cnt = rank_of_j + capacity;
-        total_ints = zeroed_ints + 3 * capacity + (capacity >> KEEP_CHUNK_LOG2) + 1;
+        owner_slots = (int)(capacity >> KEEP_CHUNK_LOG2) + 2;
+        chunk_owner = chunk_cnt + (capacity >> KEEP_CHUNK_LOG2) + 1;
+        total_ints = zeroed_ints + 3 * capacity + (capacity >> KEEP_CHUNK_LOG2) + 1 + (size_t)owner_slots;
     }
 };
 
@@ -1045,7 +1062,7 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
     }
     // bounding-box counts -> cum_tiles; stats[0] = I_box
     hipLaunchKernelGGL(scan_lookback_kernel, dim3(L.nb1), dim3(SCAN_THREADS), 0, st, n, tiles_per_gauss, cum_tiles,
-                       L.tickets, L.status1, stats);
+                       L.tickets, L.status1, stats, L.chunk_owner, L.owner_slots);
     // keep flags, per-tile ranks and keep_scan over the first min(I_box, capacity) intersections (the caller
     // re-runs with a larger buffer when stats[0] > capacity); stats[1] = I_listed
     const int n_chunks = (capacity >> KEEP_CHUNK_LOG2) + 1;
@@ -1057,11 +1074,12 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
         hipLaunchKernelGGL(bin_kernel<true>, dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n, N,
                            tile_w, tile_h, width, height, cull, capacity, cum_tiles, means2d, radii, conics, opacities,
                            opac_per_camera, L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan,
-                           (int)nt);
+                           (int)nt, L.chunk_owner);
     else
         hipLaunchKernelGGL(bin_kernel<false>, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h, width,
                            height, cull, capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera,
-                           L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt);
+                           L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt,
+                           L.chunk_owner);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
                        stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, heavy_len,
                        stats_mirror, stats_seq);
