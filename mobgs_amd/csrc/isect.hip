@@ -192,6 +192,14 @@ __device__ inline int owner_in_wave(const int32_t* __restrict__ cum, int lo, int
 // stride of the per-tile list counters (1 = packed; giving each counter its own 128-byte line was measured: no gain
 // for the atomics of a dense image region, +12 us in tile_scan)
 constexpr int TC_STRIDE = 1;
+// The rank counters exist TC_COPIES times ([copy][tile]); workgroup (chunk) c of bin_kernel uses copy c mod TC_COPIES.
+// Device-scope atomics on one address are served one after the other at the memory side of the chip (~120 ns each:
+// the L2s of the eight XCDs are not coherent with each other); every tile counter receives one atomic from almost
+// every chunk that touches the tile -- ~200 per counter at 300 k splats, 150 at 30 k -- and that queue was 42 % /
+// 62 % of bin_kernel (ablated build: 59.1 -> 34.4 us, 29.8 -> 11.3 us).  With the copies a counter's queue is 8 x
+// shorter; tile_scan_kernel sums the copies into the list lengths and leaves every (copy, tile) pair's first
+// position in tile_base, which is what emit_kernel adds the rank to.  Ranks only have to be distinct inside a list.
+constexpr int TC_COPIES = 8;
 constexpr int OWNER_LDS = 4096;  // cum_tiles entries of the chunk's owner range cached in LDS
 static_assert(SCAN_BLOCK == KEEP_CHUNK, "one workgroup per keep_scan chunk");
 
@@ -220,6 +228,7 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
     extern __shared__ int s_tile[];  // DENSE: per-tile count of this workgroup, then the base of its range
     const int chunk = blockIdx.x;
     int32_t* kchunk = keep_scan + (size_t)chunk * (KEEP_CHUNK + 1);
+    tile_count += (size_t)(chunk & (TC_COPIES - 1)) * n_tiles_total;  // this workgroup's copy of the counters
     const int I = min(cum[n_gauss], capacity);
     const int start = chunk * SCAN_BLOCK;
     if (start >= I) {
@@ -350,8 +359,17 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
 // that one very long list does not become the critical path of the launch.  Only a schedule: images are
 // bit-identical for any permutation / heavy marking, gradients equal up to the summation order of the quadrants.
 constexpr int ORDER_BUCKETS = 1024;
+constexpr int ORDER_LDS_TILES = 8192;  // list lengths the order workgroup keeps in LDS (32 KiB); beyond: re-read
 constexpr int TSCAN_THREADS = 1024;
+__device__ __forceinline__ int tile_total(const int32_t* __restrict__ tile_count, int nt, int i) {
+    int v = 0;
+#pragma unroll
+    for (int c = 0; c < TC_COPIES; ++c) v += tile_count[(size_t)c * nt + i];
+    return v;
+}
+
 __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const int32_t* __restrict__ tile_count,
+                                                                    int32_t* __restrict__ tile_base,
                                                                     int32_t* __restrict__ tile_offsets,
                                                                     int64_t* __restrict__ stats,
                                                                     int32_t* __restrict__ tile_order,
@@ -361,6 +379,8 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
                                                                     int64_t stats_seq) {
     __shared__ int smax[TSCAN_THREADS / 64];
     __shared__ int hist[ORDER_BUCKETS];
+    __shared__ int s_len[ORDER_LDS_TILES];  // list lengths (sum over the counter copies) of the order workgroup
+    auto length_of = [&](int i) { return i < ORDER_LDS_TILES ? s_len[i] : tile_total(tile_count, nt, i); };
     // workgroup 1: chunk totals -> chunk bases of keep_scan (bin_kernel left each chunk's total in its base
     // word); stats[1] = I_listed.  Workgroup 0 does the per-tile work below at the same time.
     if (blockIdx.x == 1) {
@@ -382,12 +402,29 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
     int carry = 0, mx = 0;
     for (int start = 0; start < nt; start += TSCAN_THREADS) {
         const int i = start + threadIdx.x;
-        const int v = (i < nt) ? tile_count[i * TC_STRIDE] : 0;
+        int cnt[TC_COPIES];
+        int v = 0;
+#pragma unroll
+        for (int c = 0; c < TC_COPIES; ++c) {
+            cnt[c] = (i < nt) ? tile_count[(size_t)c * nt + i] : 0;
+            v += cnt[c];
+        }
         mx = max(mx, v);
-        if (order_wg) continue;  // only needs the longest list
+        if (order_wg) {  // only needs the longest list here; keeps the lengths for its two passes below
+            if (i < ORDER_LDS_TILES) s_len[i] = v;
+            continue;
+        }
         int total;
         const int inc = block_incl_scan_w<TSCAN_THREADS / 64>(v, &total);
-        if (i < nt) tile_offsets[i] = carry + inc - v;
+        if (i < nt) {
+            int at = carry + inc - v;
+            tile_offsets[i] = at;
+#pragma unroll
+            for (int c = 0; c < TC_COPIES; ++c) {  // first position of the entries ranked through copy c
+                tile_base[(size_t)c * nt + i] = at;
+                at += cnt[c];
+            }
+        }
         carry += total;
     }
 #pragma unroll
@@ -431,7 +468,7 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
     static_assert(ORDER_BUCKETS == TSCAN_THREADS, "one histogram bin per thread");
     hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < nt; i += TSCAN_THREADS) atomicAdd(&hist[bucket(tile_count[i * TC_STRIDE])], 1);
+    for (int i = threadIdx.x; i < nt; i += TSCAN_THREADS) atomicAdd(&hist[bucket(length_of(i))], 1);
     __syncthreads();
     {
         const int mine = hist[threadIdx.x];
@@ -458,7 +495,7 @@ __global__ void __launch_bounds__(TSCAN_THREADS) tile_scan_kernel(int nt, const 
     __syncthreads();
     const int n_heavy = s_heavy;
     for (int i = threadIdx.x; i < nt; i += TSCAN_THREADS) {
-        const int pos = atomicAdd(&hist[bucket(tile_count[i * TC_STRIDE])], 1);
+        const int pos = atomicAdd(&hist[bucket(length_of(i))], 1);
         if (pos < n_heavy) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) tile_order[4 * pos + q] = i | SCHED_HEAVY;
@@ -475,7 +512,7 @@ __global__ void __launch_bounds__(1024) emit_kernel(const int32_t* __restrict__ 
                                                      const int32_t* __restrict__ tile_of_j,
                                                      const int32_t* __restrict__ rank_of_j,
                                                      const float* __restrict__ depths,
-                                                     const int32_t* __restrict__ tile_offsets,
+                                                     const int32_t* __restrict__ tile_base, int nt,
                                                      uint64_t* __restrict__ sort_keys, int capacity,
                                                      const int64_t* __restrict__ stats, int64_t capacity_listed) {
     // speculative launch (stats != NULL): nothing to do when the arena was too small (see tile_scan_kernel)
@@ -488,7 +525,8 @@ __global__ void __launch_bounds__(1024) emit_kernel(const int32_t* __restrict__ 
             const int j = (chunk << KEEP_CHUNK_LOG2) + l;
             const int g = owner[j];
             const uint32_t db = __float_as_uint(depths[g]);
-            sort_keys[(size_t)tile_offsets[tile_of_j[j]] + rank_of_j[j]] = ((uint64_t)db << 32) | (uint32_t)g;
+            const int32_t* base = tile_base + (size_t)(chunk & (TC_COPIES - 1)) * nt;  // the copy bin_kernel ranked in
+            sort_keys[(size_t)base[tile_of_j[j]] + rank_of_j[j]] = ((uint64_t)db << 32) | (uint32_t)g;
         }
     }
 }
@@ -973,17 +1011,17 @@ constexpr int DENSE_MAX_TILES = 8192;  // 32 KiB of LDS
 extern "C" {
 
 // Layout of the scratch buffer shared by mobgs_isect_offsets and mobgs_isect_emit_sort (int32 units):
-//   [tile_count nt * TC_STRIDE | ticket (+3 pad) | status 2*(nb1+1)]  <- zeroed by one memset
+//   [tile_count TC_COPIES * nt | ticket (+3 pad) | status 2*(nb1+1)]  <- zeroed by one memset
 //   [owner cap | tile cap | rank cap | chunk_cnt (cap >> 11) + 1]
 struct IsectScratch {
-    int32_t *tile_count, *tickets, *chunk_cnt, *owner, *tile_of_j, *rank_of_j, *chunk_owner;
+    int32_t *tile_count, *tickets, *chunk_cnt, *owner, *tile_of_j, *rank_of_j, *chunk_owner, *tile_base;
     int owner_slots;
     uint64_t* status1;
     size_t zeroed_ints, total_ints;
     int nb1;
     IsectScratch(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity) {
         nb1 = (int)((n_gauss + SCAN_BLOCK - 1) / SCAN_BLOCK);
-        const size_t nt_pad = (n_tiles * TC_STRIDE + 1) & ~(size_t)1;  // keeps the 64-bit status words 8-byte aligned
+        const size_t nt_pad = (n_tiles * TC_STRIDE * TC_COPIES + 1) & ~(size_t)1;  // (64-bit status words stay 8-byte aligned)
         int32_t* p = (int32_t*)scratch;
         tile_count = p;
         tickets = p + nt_pad;
@@ -995,7 +1033,9 @@ struct IsectScratch {
         chunk_cnt = rank_of_j + capacity;
         owner_slots = (int)(capacity >> KEEP_CHUNK_LOG2) + 2;
         chunk_owner = chunk_cnt + (capacity >> KEEP_CHUNK_LOG2) + 1;
-        total_ints = zeroed_ints + 3 * capacity + (capacity >> KEEP_CHUNK_LOG2) + 1 + (size_t)owner_slots;
+        tile_base = chunk_owner + owner_slots;
+        total_ints = zeroed_ints + 3 * capacity + (capacity >> KEEP_CHUNK_LOG2) + 1 + (size_t)owner_slots +
+                     n_tiles * TC_COPIES;
     }
 };
 
@@ -1055,7 +1095,7 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
         hipMemsetAsync(cum_tiles, 0, sizeof(int32_t), st);
         hipMemsetAsync(keep_scan, 0, 2 * sizeof(int32_t), st);  // base and first local of chunk 0
         hipMemsetAsync(stats, 0, 3 * sizeof(int64_t), st);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, L.tile_base, tile_offsets,
                            stats, tile_order, (int64_t)capacity, (int64_t)0, (int32_t*)nullptr, 0, heavy_len,
                            stats_mirror, stats_seq);
         return check_launch("isect_offsets(empty)");
@@ -1080,7 +1120,7 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
                            height, cull, capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera,
                            L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt,
                            L.chunk_owner);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, tile_offsets,
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, L.tile_base, tile_offsets,
                        stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, heavy_len,
                        stats_mirror, stats_seq);
     return check_launch("isect_offsets");
@@ -1105,7 +1145,7 @@ static int emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t
     // the compacted (owner, tile, rank) arrays pass A left in the scratch buffer of mobgs_isect_offsets
     const IsectScratch L(const_cast<void*>(offsets_scratch), (size_t)n, (size_t)nt, (size_t)capacity);
     hipLaunchKernelGGL(emit_kernel, dim3(4096), dim3(1024), 0, st, cum_tiles + n, L.chunk_cnt, L.owner, L.tile_of_j,
-                       L.rank_of_j, depths, tile_offsets, sort_keys, capacity, stats_dev, capacity_listed);
+                       L.rank_of_j, depths, L.tile_base, nt, sort_keys, capacity, stats_dev, capacity_listed);
     // gsplat: tile_n_bits = floor(log2(n_tiles)) + 1
     int tile_bits = 0;
     while ((1ll << tile_bits) <= (long long)tiles_per_cam) ++tile_bits;
