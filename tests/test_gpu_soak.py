@@ -56,3 +56,33 @@ def test_random_full_size_scenes_with_long_lists(hip_device):
     import soak_parity
     failed, msgs = soak_parity.soak(6, 2, hip_device, verbose=False, large=True)
     assert failed == 0, "\n".join(msgs)
+
+
+@pytest.mark.parametrize("w,h,C", [(2064, 1040, 1), (1100, 720, 3)])
+def test_grids_beyond_8192_tiles_match_the_c_oracle(hip_device, w, h, C):
+    """129 x 65 = 8385 tiles (and 3 cameras x 69 x 45 = 9315): more tiles than the LDS-ranked binning and the schedule
+    workgroup's LDS table hold, i.e. the direct-atomics form of bin_kernel over the eight counter copies and the
+    re-reading form of the tile order.  Lists bit-equal to the C oracle (tile culling off), image / gradients within
+    the soak's tolerances."""
+    import math
+
+    import numpy as np
+    import soak_parity
+    from mobgs_amd.synth import SynthCamera, splat_inputs
+    rng = np.random.default_rng(5)
+    cam = SynthCamera().scaled(w, h)
+    s = splat_inputs(7000, cam, 11, 3)
+    if C > 1:
+        vms = []
+        for i in range(C):
+            ang = 0.1 * (i - 1)
+            vm = torch.eye(4)
+            vm[:3, :3] = torch.tensor([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
+            vm[:3, 3] = torch.tensor([0.05 * i, -0.02 * i, 0.1 * i])
+            vms.append(vm)
+        s["viewmats"] = torch.stack(vms)
+        s["Ks"] = s["Ks"].expand(C, 3, 3).contiguous()
+    case = dict(w=w, h=h, n=7000, channels=3, mode="RGB+ED", regime="plain", s=s,
+                bg=torch.rand(C, 3, generator=torch.Generator().manual_seed(3)), X=4, idx=int(rng.integers(1000)), C=C)
+    problems, _ = soak_parity.run_case(case, hip_device)
+    assert not problems, problems
