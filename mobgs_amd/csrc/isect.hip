@@ -34,6 +34,7 @@ namespace mobgs {
 // back / invalidate the whole XCD L2 on every access (measured: 10x slower kernels).
 // ---------------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 512;  // x 4 items: shorter per-thread chains than 256 x 8 (-6 us in bin), same 2048-element chunks
+                                   // (1024 x 4 = 4096-element chunks, fewer counter atomics per entry: bin 49 -> 61 us)
 constexpr int SCAN_ITEMS = 4;
 constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;  // 2048 elements per workgroup
 
