@@ -11,6 +11,24 @@ import torch.multiprocessing as mp
 from mobgs_amd.distributed import FlatGradients, SubframeShard
 
 
+def _plain(obj):
+    """Tensors -> numpy arrays before they go through the queue: a torch tensor travels as a shared-memory handle the
+    receiver has to fetch from the SENDER, and a worker that has already exited resets that connection."""
+    if torch.is_tensor(obj):
+        return ("__tensor__", obj.detach().cpu().numpy())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_plain(o) for o in obj)
+    return obj
+
+
+def _tensors(obj):
+    if isinstance(obj, tuple) and len(obj) == 2 and isinstance(obj[0], str) and obj[0] == "__tensor__":
+        return torch.from_numpy(obj[1])
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_tensors(o) for o in obj)
+    return obj
+
+
 def _toy_render(params, k):
     """A differentiable stand-in for render(warped_cam[k], delta_exposure[k])["render"]: [3,6,8]."""
     w, b = params
@@ -46,7 +64,7 @@ def _worker(rank, world, port, K, q):
         if loss.requires_grad:  # a rank that owns no sub-frame (world > K) has nothing to back-propagate ...
             loss.backward()
         shard.all_reduce_gradients([w, b])  # ... but still takes part in the gradient all-reduce
-        q.put((rank, pred.detach(), w.grad.clone(), b.grad.clone()))
+        q.put(_plain((rank, pred.detach(), w.grad.clone(), b.grad.clone())))
     finally:
         dist.destroy_process_group()
 
@@ -68,7 +86,7 @@ def test_subframe_sharding_world2_matches_single_process(K):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, K, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in procs]
+    results = [_tensors(q.get(timeout=120)) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -156,8 +174,8 @@ def _iteration_worker(rank, world, port, q):
             shard.put_densification_stats(bucket, f"view{v}", m2d.grad, torch.full((NSPLAT,), 3 + v, dtype=torch.int32))
         shard.all_reduce_gradients(bucket)
         stats = [shard.get_densification_stats(bucket, f"view{v}") for v in range(V)]
-        q.put((rank, pred.detach(), w.grad.clone(), b.grad.clone(), [s[0].clone() for s in stats],
-               [s[1].clone() for s in stats]))
+        q.put(_plain((rank, pred.detach(), w.grad.clone(), b.grad.clone(), [s[0].clone() for s in stats],
+                      [s[1].clone() for s in stats])))
     finally:
         dist.destroy_process_group()
 
@@ -172,7 +190,7 @@ def test_training_iteration_world2_counts_every_loss_term_once():
     procs = [ctx.Process(target=_iteration_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in procs]
+    results = [_tensors(q.get(timeout=120)) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -236,7 +254,7 @@ def _flow_worker(rank, world, port, q):
             loss = loss + _flow_term(pred[v], _toy_flow((w, b), v, k))   # owner only
         loss.backward()
         shard.all_reduce_gradients(bucket)
-        q.put((rank, w.grad.clone(), b.grad.clone(), mine))
+        q.put(_plain((rank, w.grad.clone(), b.grad.clone(), mine)))
     finally:
         dist.destroy_process_group()
 
@@ -252,7 +270,7 @@ def test_rank_local_terms_on_the_prediction_need_the_backward_reduction():
     procs = [ctx.Process(target=_flow_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in procs]
+    results = [_tensors(q.get(timeout=120)) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -281,7 +299,7 @@ def _idle_rank_worker(rank, world, port, q):
                 loss = loss + _flow_term(pred[0], _toy_flow((w, b), 0, k))
         loss.backward()
         shard.all_reduce_gradients(bucket)
-        q.put((rank, w.grad.clone(), b.grad.clone()))
+        q.put(_plain((rank, w.grad.clone(), b.grad.clone())))
     finally:
         dist.destroy_process_group()
 
@@ -303,7 +321,7 @@ def test_rank_without_render_unit_still_joins_the_backward_reduction():
     procs = [ctx.Process(target=_idle_rank_worker, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in procs]
+    results = [_tensors(q.get(timeout=120)) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
