@@ -62,12 +62,16 @@ extern "C" {
  *                      (it used to do so only with a hint >= 2048).  Default 0.
  *   quadrant_culling   testing aid, default 1: the compositors skip, per list entry, the 8x8 quadrants of the tile
  *                      the splat cannot reach (work that is predicated off at every pixel); 0 evaluates everything
- *                      -- results are identical. */
+ *                      -- results are identical.
+ *   block_walk         forward compositor of the plain passes with <= 10 total channels, default 1: sixteen
+ *                      independent 4x4-pixel workers per wave, each walking the entries that can reach ITS block
+ *                      (raster.hip, "block-walk formulation"); 0 = the one-entry-at-a-time quadrant kernel.  Images,
+ *                      alphas and last_ids are bit-identical either way. */
 typedef struct MobgsTuning {
     int32_t heavy_tile_len;
     int32_t longest_list_hint;
     int32_t quadrant_culling;
-    int32_t reserved;
+    int32_t block_walk;
 } MobgsTuning;
 
 const char* mobgs_version(void);

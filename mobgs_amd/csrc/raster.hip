@@ -290,6 +290,219 @@ raster_fwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
 }
 
 // ---------------------------------------------------------------------------------------------------
+// forward, block-walk formulation (round 3): sixteen independent 4x4-pixel workers per wave
+// ---------------------------------------------------------------------------------------------------
+// The kernel above evaluates a list entry at a whole 8x8 quadrant as soon as one of its pixels may pass the alpha
+// test: on the benchmark lists 47 % of those lane-evaluations are live (profiles/r03/live_lane_stats.json), 69 % at
+// 4x4-block granularity.  A wave cannot branch per 16 lanes, and gfx950 does not skip a 32-lane pass whose EXEC bits
+// are all zero (scripts/ubench/exec_skip.hip: 1.93 cycles per v_fma whatever the mask) -- so finer culling needs lanes
+// that work on DIFFERENT entries at the same time.  The forward pass has no cross-lane reduction, which makes that
+// cheap here:
+//   * worker j = the four lanes {j, j + 16, j + 32, j + 48}; it owns the 4x4 block (j & 3, j >> 2) of the tile, lane
+//     a = lane >> 4 the four pixels of block row a (contiguous in x: 4 * CD contiguous floats per lane on the way out);
+//   * a batch of 64 entries is staged as before (lane = entry); each lane also computes the 16-bit mask of blocks ITS
+//     splat can reach (block_reach_mask16: per block a lower bound of sigma from its value and gradient at the block
+//     centre -- convexity --, 10 VALU per block, lane-parallel over the 64 entries of the batch);
+//   * sixteen ballots transpose the 64 x 16 bit matrix: worker j gets the 64-bit set of batch entries reaching its
+//     block, and walks it with v_ffbl -- its own record read from the LDS slab each step (records padded to 80 bytes:
+//     16 lanes of one ds_read_b128 group then hit distinct bank groups unless their entry indices agree mod 16);
+//   * a lane leaves the walk when its four pixels are finished; the batch ends when every worker's set is empty.
+// Every pixel still sees exactly the entries that can pass its alpha test, in list order, through the same
+// instruction sequence: images are bit-identical to the quadrant kernel's.
+// bit 4 * by + bx: the splat may reach alpha >= 1/255 at a pixel centre of the 4x4 block (bx, by) of tile (tx, ty).
+// sigma is convex (the conic is positive definite), so over the block's pixel centres c + d, |d_x|, |d_y| <= 1.5:
+//   sigma(c + d) >= sigma(c) + <grad sigma(c), d> >= sigma(c) - 1.5 (|g_x| + |g_y|),  g = (a dx + b dy, b dx + c dy).
+// Conservative by construction plus the margin of reach_threshold(); tightened by the exact per-quadrant test.
+__device__ inline unsigned block_reach_mask16(float mx, float my, float ca, float cb, float cc, float op, int tx,
+                                              int ty) {
+    const float thr = reach_threshold(op);
+    if (thr < 0.f) return 0u;
+    if (!(ca > 0.f && cc > 0.f && ca * cc - cb * cb > 0.f)) return 0xFFFFu;
+    const float xc = (float)(tx * MOBGS_TILE) + 2.f, yc = (float)(ty * MOBGS_TILE) + 2.f;  // centre of block (0, 0)
+    unsigned m = 0u;
+#pragma unroll
+    for (int by = 0; by < 4; ++by) {
+        const float dy = my - (yc + (float)(4 * by));
+#pragma unroll
+        for (int bx = 0; bx < 4; ++bx) {
+            const float dx = mx - (xc + (float)(4 * bx));
+            const float gx = ca * dx + cb * dy, gy = cb * dx + cc * dy;
+            const float lb = 0.5f * (dx * gx + dy * gy) - 1.5f * (fabsf(gx) + fabsf(gy));
+            if (lb <= thr) m |= 1u << (4 * by + bx);
+        }
+    }
+    const unsigned q = quadrant_reach_mask(mx, my, ca, cb, cc, op, tx, ty);
+    return m & (((q & 1u) ? 0x0033u : 0u) | ((q & 2u) ? 0x00CCu : 0u) | ((q & 4u) ? 0x3300u : 0u) |
+                ((q & 8u) ? 0xCC00u : 0u));
+}
+
+#ifndef F2_WAVES
+#define F2_WAVES 4
+#endif
+template <int CD>
+__global__ void __launch_bounds__(64 * TILES_PER_WG) __attribute__((amdgpu_waves_per_eu(CD <= 10 ? F2_WAVES : 1)))
+raster_fwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
+                         const float* __restrict__ records, const float* __restrict__ backgrounds,
+                         const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+                         float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
+                         const int32_t* __restrict__ tile_order, int all_reach, uint8_t* __restrict__ isect_reach) {
+    constexpr int RS = (6 + CD + 3) & ~3;
+    constexpr int RQ = RS / 4;
+    constexpr int RQP = RQ + 1;  // padded record: 16-byte quarters per slab row
+    __shared__ float4 slab[TILES_PER_WG][64][RQP];
+    __shared__ float4 hslab[TILES_PER_WG][64][RQ];   // heavy tiles keep the one-quadrant-per-wave walk
+    __shared__ int hidx[1][64];
+    __shared__ unsigned hreach[TILES_PER_WG][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
+    if (slot < 0) return;
+    if (slot & SCHED_HEAVY) {
+        composite_fwd<CD, 1, false>(slot & ~SCHED_HEAVY, wv, wv, lane, hslab, hidx, hreach, ClassSel{0, 1, 0, all_reach},
+                                    tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids,
+                                    render, alphas, last_ids, isect_reach);
+        return;
+    }
+    const int tile = slot;
+    const int tiles_per_cam = tile_w * tile_h;
+    const int cam = tile / tiles_per_cam;
+    const int tl = tile - cam * tiles_per_cam;
+    const int ty = tl / tile_w, tx = tl - ty * tile_w;
+    const int j = lane & 15, a = lane >> 4;
+    const int pyi = ty * MOBGS_TILE + 4 * (j >> 2) + a;
+    const int pxi0 = tx * MOBGS_TILE + 4 * (j & 3);
+    const float py = (float)pyi + 0.5f;
+    float px[4], T[4], acc[4][CD];
+    int last[4];
+    bool any_inside = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        px[k] = (float)(pxi0 + k) + 0.5f;
+        const bool inside = pxi0 + k < width && pyi < height;
+        any_inside = any_inside || inside;
+        T[k] = inside ? 1.f : -1.f;  // T < 0: the pixel takes no more splats (see composite_fwd)
+        last[k] = 0;
+#pragma unroll
+        for (int c = 0; c < CD; ++c) acc[k][c] = 0.f;
+    }
+    bool done = !any_inside;
+
+    const int s = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
+    const int e = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
+
+    constexpr int PQ = RQ < 2 ? RQ : 2;  // prefetched quarters of the next batch: position, conic, opacity
+    float4 pre[PQ];
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int pre_g = -1;
+    if (s + lane < e) {
+        pre_g = flatten_ids[s + lane];
+        const float4* r = reinterpret_cast<const float4*>(records + (size_t)pre_g * RS);
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) pre[q] = r[q];
+    }
+    for (int b = s; b < e; b += 64) {
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+        wave_lds_fence();
+        unsigned m16 = 0u;
+        {
+            float4 rest[RQ > PQ ? RQ - PQ : 1];
+            if (RQ > PQ && pre_g >= 0) {
+                const float4* r = reinterpret_cast<const float4*>(records + (size_t)pre_g * RS);
+#pragma unroll
+                for (int q = PQ; q < RQ; ++q) rest[q - PQ] = r[q];
+            }
+            if (pre_g >= 0) {
+                m16 = all_reach ? 0xFFFFu
+                                : block_reach_mask16(pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, tx, ty);
+                if (isect_reach) {  // the backward pass walks quadrants: a quadrant is reachable iff one of its blocks is
+                    const unsigned q = ((m16 & 0x0033u) ? 1u : 0u) | ((m16 & 0x00CCu) ? 2u : 0u) |
+                                       ((m16 & 0x3300u) ? 4u : 0u) | ((m16 & 0xCC00u) ? 8u : 0u);
+                    isect_reach[b + lane] = (uint8_t)q;
+                }
+#pragma unroll
+                for (int q = 0; q < PQ; ++q) slab[wv][lane][q] = pre[q];
+#pragma unroll
+                for (int q = PQ; q < RQ; ++q) slab[wv][lane][q] = rest[q - PQ];
+            }
+        }
+        wave_lds_fence();
+        pre_g = -1;
+        if (b + 64 + lane < e) {
+            pre_g = flatten_ids[b + 64 + lane];
+            const float4* r = reinterpret_cast<const float4*>(records + (size_t)pre_g * RS);
+#pragma unroll
+            for (int q = 0; q < PQ; ++q) pre[q] = r[q];
+        }
+        // transpose: worker j's set of batch entries
+        unsigned mlo = 0u, mhi = 0u;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64((m16 >> jj) & 1u);
+            if (j == jj) {
+                mlo = (unsigned)bal;
+                mhi = (unsigned)(bal >> 32);
+            }
+        }
+        if (done) mlo = mhi = 0u;
+        while (true) {
+            const bool has = (mlo | mhi) != 0u;
+            if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;
+            if (has) {
+                int i;
+                if (mlo != 0u) {
+                    i = __builtin_ctz(mlo);
+                    mlo &= mlo - 1u;
+                } else {
+                    i = 32 + __builtin_ctz(mhi);
+                    mhi &= mhi - 1u;
+                }
+                const int list_idx = b + i;
+                float rec[RS];
+#pragma unroll
+                for (int q = 0; q < RQ; ++q) {
+                    const float4 v = slab[wv][i][q];
+                    rec[4 * q] = v.x;
+                    rec[4 * q + 1] = v.y;
+                    rec[4 * q + 2] = v.z;
+                    rec[4 * q + 3] = v.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const Eval ev = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px[k], py);
+                    const float nT = T[k] * (1.f - ev.alpha);
+                    const bool blend = ev.pass && nT > T_STOP;   // never for a finished pixel (nT < 0)
+                    const bool stop = ev.pass && !(nT > T_STOP);
+                    const float w = blend ? ev.alpha * T[k] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < CD; ++c) acc[k][c] = __fmaf_rn(rec[6 + c], w, acc[k][c]);
+                    T[k] = blend ? nT : (stop ? -fabsf(T[k]) : T[k]);
+                    last[k] = blend ? list_idx : last[k];
+                }
+                if (!(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) > 0.f)) {  // all four pixels finished
+                    done = true;
+                    mlo = mhi = 0u;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!(pxi0 + k < width && pyi < height)) continue;
+        const float Tk = fabsf(T[k]);
+        const size_t pix = ((size_t)cam * height + pyi) * width + pxi0 + k;
+        alphas[pix] = 1.f - Tk;
+        last_ids[pix] = last[k];
+        float* out = render + pix * CD;
+#pragma unroll
+        for (int c = 0; c < CD; ++c) {
+            float v = acc[k][c];
+            if (backgrounds) v = __fmaf_rn(Tk, backgrounds[cam * CD + c], v);
+            out[c] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // backward, stage 1: per-(tile, splat) gradient records
 // ---------------------------------------------------------------------------------------------------
 // Wave-wide sum of NVP per-lane values with the cross-lane hardware of gfx950, no LDS traffic, no selects:
@@ -541,9 +754,21 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
         T[k] = Tf[k];
         tvab[k] = Tf[k] * (va[k] - bgdot[k]);
     }
-    // highest list index any pixel of the tile blended
+    // highest list index any pixel of pixel slot k (= one 8x8 quadrant) blended: entries behind it cannot contribute
+    // to that quadrant and are not even evaluated there (on the benchmark lists 21 % of the entries lie behind every
+    // quadrant's last blended entry -- scripts/live_lane_stats.py)
+    int topk[PPL];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
+    for (int k = 0; k < PPL; ++k) {
+        int t = binf[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t = max(t, __shfl_xor(t, off, 64));
+        topk[k] = __builtin_amdgcn_readfirstlane(t);
+    }
+    // ... and of the whole tile
+    top = topk[0];
+#pragma unroll
+    for (int k = 1; k < PPL; ++k) top = max(top, topk[k]);
     if (HEAVY) {  // all 4 quadrant waves walk the same batches
         if (lane == 0) sh.top[wv] = top;
         __syncthreads();
@@ -591,8 +816,10 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
         unsigned long long reach[PPL];
         {
             const unsigned rm = lane < n ? sh.reach_of[wv][lane] : 0u;
+            const int my_idx = FILTER ? (lane < n ? sh.idx_of[wv][lane] : 0x7fffffff) : hi - lane;
 #pragma unroll
-            for (int k = 0; k < PPL; ++k) reach[k] = __builtin_amdgcn_ballot_w64((rm >> (HEAVY ? quad : k)) & 1u);
+            for (int k = 0; k < PPL; ++k)
+                reach[k] = __builtin_amdgcn_ballot_w64(((rm >> (HEAVY ? quad : k)) & 1u) != 0u && my_idx <= topk[k]);
         }
         unsigned long long rem = reach[0];
 #pragma unroll
@@ -987,8 +1214,14 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
     }
     const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
+    const int block_walk = tuning_block_walk(tuning);
     const int rc = dispatch_channels(D, [&](auto cd) {
         constexpr int CD = decltype(cd)::value;
+        if (block_walk && CD <= 10)
+            hipLaunchKernelGGL((raster_fwd_blocks_kernel<CD>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
+                               tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render,
+                               alphas, last_ids, tile_order, g_all_reach, isect_reach);
+        else
         hipLaunchKernelGGL((raster_fwd_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
                            tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render,
                            alphas, last_ids, tile_order, ClassSel{0, 1, 0, g_all_reach}, isect_reach);

@@ -262,13 +262,14 @@ class _PendingCounts:
 
 _tile_culling = True
 # Caller-side policy handed to the library with every call (include/mobgs_hip.h MobgsTuning; the library itself keeps
-# no state).  tuning.heavy_tile_len / tuning.quadrant_culling may be changed by tests and experiments.
+# no state).  tuning.heavy_tile_len / tuning.quadrant_culling / tuning.block_walk may be changed by tests and
+# experiments.
 tuning = _lib.MobgsTuning()
 
 
 def _tuning_with_hint(key):
     """`tuning` plus the longest list the previous frame on this device had (selects the dense binning variant)."""
-    t = _lib.MobgsTuning(tuning.heavy_tile_len, _len_hint.get(key, 0), tuning.quadrant_culling)
+    t = _lib.MobgsTuning(tuning.heavy_tile_len, _len_hint.get(key, 0), tuning.quadrant_culling, tuning.block_walk)
     _tuning_keepalive.append(t)
     del _tuning_keepalive[:-8]
     return t.ref()

@@ -194,6 +194,50 @@ def test_tile_culling_is_bit_exact(hip_device, mode, channels):
         assert all(x in it for x in sub), f"tile {tile}: not a sub-sequence"
 
 
+@pytest.mark.parametrize("mode,channels,tile_cull,size", [("RGB+ED", 9, True, (232, 168)), ("RGB", 3, True, (232, 168)),
+                                                           ("RGB+ED", 9, False, (232, 168)),
+                                                           ("RGB+ED", 9, True, (1101, 613)), ("D", 0, True, (333, 250))])
+def test_block_walk_equals_quadrant_kernel(hip_device, mode, channels, tile_cull, size):
+    """Round 3: the plain forward passes run the block-walk compositor (sixteen independent 4x4-pixel workers per wave,
+    each walking only the entries that can reach its block, MobgsTuning.block_walk = 1).  A worker skips an entry only
+    when a conservative bound says no pixel centre of its block can pass the alpha test, so every pixel blends exactly
+    the same entries in the same order through the same instructions: images, alphas, last ids -- and therefore all
+    gradients, which the backward pass derives from them and from the per-entry quadrant masks the forward leaves
+    behind -- must be bit-identical to the quadrant kernel's (block_walk = 0).  The small grids run with heavy_tile_len
+    = 0 (one wave per tile, as on large images; by default every tile of such a grid goes to a whole workgroup, the
+    path both kernels share), 1101x613 is a large ragged image with the default schedule."""
+    from mobgs_amd import rendering
+    from mobgs_amd.rendering import rasterization
+    w, h = size
+    n = 8000 if w < 1000 else 60000
+    s, _ = _scene(n, w, h, 23, max(channels, 1))
+    g0 = torch.Generator().manual_seed(6)
+    s["scales"] = s["scales"] * torch.exp(torch.randn(s["scales"].shape, generator=g0) * 0.9)  # needles and blobs
+    names = ["means", "quats", "scales", "opacities", "colors", "viewmats"]
+    res = {}
+    rendering.set_tile_culling(tile_cull)
+    try:
+        for bw in (1, 0):
+            rendering.tuning.block_walk = bw
+            rendering.tuning.heavy_tile_len = 0 if w < 1000 else -1   # small grids: one wave per tile all the same
+            t = {k: v.to(hip_device).clone().requires_grad_(k in names) for k, v in s.items()}
+            img, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                                         t["viewmats"], t["Ks"], w, h, packed=False, render_mode=mode)
+            g = torch.Generator().manual_seed(7)
+            v_img = torch.randn(img.shape, generator=g).to(hip_device)
+            ((img * v_img).sum() + (a * a).sum()).backward()
+            res[bw] = (img.detach().cpu(), a.detach().cpu(),
+                       {k: t[k].grad.cpu() for k in names if t[k].grad is not None})
+    finally:
+        rendering.tuning.block_walk = -1
+        rendering.tuning.heavy_tile_len = -1
+        rendering.set_tile_culling(True)
+    assert torch.equal(res[1][0], res[0][0]), "image differs"
+    assert torch.equal(res[1][1], res[0][1]), "alpha differs"
+    for k in res[0][2]:
+        assert torch.equal(res[1][2][k], res[0][2][k]), f"grad[{k}] differs"
+
+
 @pytest.mark.parametrize("mode,channels,tile_cull", [("RGB+ED", 9, True), ("RGB", 3, True), ("RGB+ED", 9, False)])
 def test_quadrant_reach_masks_change_nothing(hip_device, mode, channels, tile_cull):
     """Inside the compositors every list entry carries a 4-bit mask of the 8x8 quadrants its splat can reach; the
