@@ -66,12 +66,19 @@ extern "C" {
  *   block_walk         forward compositor of the plain passes with <= 10 total channels, default 1: sixteen
  *                      independent 4x4-pixel workers per wave, each walking the entries that can reach ITS block
  *                      (raster.hip, "block-walk formulation"); 0 = the one-entry-at-a-time quadrant kernel.  Images,
- *                      alphas and last_ids are bit-identical either way. */
+ *                      alphas and last_ids are bit-identical either way.
+ *   bwd_block_walk     experimental, default 0: 1 runs the same sixteen-worker formulation in the backward pass of the
+ *                      7..10-channel plain passes (partial gradient records of the blocks combined in an LDS accumulator
+ *                      under an integer claim).  Measured 9 % SLOWER than the quadrant kernel on the benchmark lists
+ *                       -- kept as the A/B arm; gradients agree to summation order.
+ *   reserved           must be 0 (or the struct zero-/minus-one-initialised). */
 typedef struct MobgsTuning {
     int32_t heavy_tile_len;
     int32_t longest_list_hint;
     int32_t quadrant_culling;
     int32_t block_walk;
+    int32_t bwd_block_walk;
+    int32_t reserved[3];
 } MobgsTuning;
 
 const char* mobgs_version(void);

@@ -20,10 +20,11 @@ class MobgsTuning(ctypes.Structure):
     """include/mobgs_hip.h MobgsTuning: per-call policy (-1 = library default).  The library keeps no state; a
     caller-side instance (mobgs_amd.rendering.tuning) is passed by pointer with every call that consults it."""
     _fields_ = [("heavy_tile_len", ctypes.c_int32), ("longest_list_hint", ctypes.c_int32),
-                ("quadrant_culling", ctypes.c_int32), ("block_walk", ctypes.c_int32)]
+                ("quadrant_culling", ctypes.c_int32), ("block_walk", ctypes.c_int32),
+                ("bwd_block_walk", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
 
-    def __init__(self, heavy_tile_len=-1, longest_list_hint=-1, quadrant_culling=-1, block_walk=-1):
-        super().__init__(heavy_tile_len, longest_list_hint, quadrant_culling, block_walk)
+    def __init__(self, heavy_tile_len=-1, longest_list_hint=-1, quadrant_culling=-1, block_walk=-1, bwd_block_walk=-1):
+        super().__init__(heavy_tile_len, longest_list_hint, quadrant_culling, block_walk, bwd_block_walk)
 
     def ref(self):
         return ctypes.cast(ctypes.pointer(self), c_void_p)

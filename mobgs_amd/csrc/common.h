@@ -192,6 +192,7 @@ inline int tuning_heavy_len(const MobgsTuning* t, int n_tiles) {
 inline int tuning_list_hint(const MobgsTuning* t) { return (t && t->longest_list_hint >= 0) ? t->longest_list_hint : 0; }
 inline int tuning_all_reach(const MobgsTuning* t) { return (t && t->quadrant_culling == 0) ? 1 : 0; }
 inline int tuning_block_walk(const MobgsTuning* t) { return (t && t->block_walk == 0) ? 0 : 1; }
+inline int tuning_bwd_block_walk(const MobgsTuning* t) { return (t && t->bwd_block_walk == 1) ? 1 : 0; }
 void isect_zeroed_region(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity, int32_t** ptr, size_t* count);
 
 // bit q = 2 * qy + qx set <=> the splat may reach alpha >= 1/255 at a pixel centre of the 8x8 quadrant (qx, qy) of

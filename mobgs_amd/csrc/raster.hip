@@ -339,27 +339,30 @@ __device__ inline unsigned block_reach_mask16(float mx, float my, float ca, floa
 #ifndef F2_WAVES
 #define F2_WAVES 4
 #endif
-template <int CD>
-__global__ void __launch_bounds__(64 * TILES_PER_WG) __attribute__((amdgpu_waves_per_eu(CD <= 10 ? F2_WAVES : 1)))
+// FILTER: a class-restricted pass (ClassSel) -- entries of the other class simply get an empty block mask; list indices
+// stay those of the combined list.
+template <int CD, bool FILTER>
+__global__ void __launch_bounds__(64 * TILES_PER_WG) __attribute__((amdgpu_waves_per_eu(CD <= 10 ? F2_WAVES : (CD <= 12 ? 3 : 2))))
 raster_fwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
                          const float* __restrict__ records, const float* __restrict__ backgrounds,
                          const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
                          float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
-                         const int32_t* __restrict__ tile_order, int all_reach, uint8_t* __restrict__ isect_reach) {
+                         const int32_t* __restrict__ tile_order, ClassSel cls, uint8_t* __restrict__ isect_reach) {
+    const int all_reach = cls.all_reach;
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
     constexpr int RQP = RQ + 1;  // padded record: 16-byte quarters per slab row
     __shared__ float4 slab[TILES_PER_WG][64][RQP];
     __shared__ float4 hslab[TILES_PER_WG][64][RQ];   // heavy tiles keep the one-quadrant-per-wave walk
-    __shared__ int hidx[1][64];
+    __shared__ int hidx[FILTER ? TILES_PER_WG : 1][64];
     __shared__ unsigned hreach[TILES_PER_WG][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
     if (slot < 0) return;
     if (slot & SCHED_HEAVY) {
-        composite_fwd<CD, 1, false>(slot & ~SCHED_HEAVY, wv, wv, lane, hslab, hidx, hreach, ClassSel{0, 1, 0, all_reach},
-                                    tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids,
-                                    render, alphas, last_ids, isect_reach);
+        composite_fwd<CD, 1, FILTER>(slot & ~SCHED_HEAVY, wv, wv, lane, hslab, hidx, hreach, cls, tile_w, tile_h, width,
+                                     height, records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids,
+                                     isect_reach);
         return;
     }
     const int tile = slot;
@@ -406,6 +409,8 @@ raster_fwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
         unsigned m16 = 0u;
         {
             float4 rest[RQ > PQ ? RQ - PQ : 1];
+#pragma unroll
+            for (int q = 0; q < (RQ > PQ ? RQ - PQ : 1); ++q) rest[q] = make_float4(0.f, 0.f, 0.f, 0.f);  // (keeps it in registers)
             if (RQ > PQ && pre_g >= 0) {
                 const float4* r = reinterpret_cast<const float4*>(records + (size_t)pre_g * RS);
 #pragma unroll
@@ -414,6 +419,7 @@ raster_fwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
             if (pre_g >= 0) {
                 m16 = all_reach ? 0xFFFFu
                                 : block_reach_mask16(pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, tx, ty);
+                if (FILTER && !cls.keeps(pre_g)) m16 = 0u;
                 if (isect_reach) {  // the backward pass walks quadrants: a quadrant is reachable iff one of its blocks is
                     const unsigned q = ((m16 & 0x0033u) ? 1u : 0u) | ((m16 & 0x00CCu) ? 2u : 0u) |
                                        ((m16 & 0x3300u) ? 4u : 0u) | ((m16 & 0xCC00u) ? 8u : 0u);
@@ -558,6 +564,37 @@ __device__ __forceinline__ float dpp_add_ror8_hi(float keep, float v) {  // lane
 __device__ __forceinline__ float dpp_add_mirror_odd(float keep, float v) {  // banks 1, 3: v + v[half-row mirror]
     asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\ts_nop 1" : "+v"(keep) : "v"(v));
     return keep;
+}
+// the two swap stages alone: afterwards lane l holds, in v[0..3], components 4 (l >> 4) + {0..3} summed over the four
+// lanes {l & 15, (l & 15) + 16, + 32, + 48} -- the lanes of one block-walk worker
+template <int N>
+__device__ __forceinline__ void wave_reduce16_columns(float (&v)[N]) {
+    static_assert(N >= 16, "reduces v[0..15]");
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %8\n\t"
+        "v_permlane32_swap_b32 %1, %9\n\t"
+        "v_permlane32_swap_b32 %2, %10\n\t"
+        "v_permlane32_swap_b32 %3, %11\n\t"
+        "v_permlane32_swap_b32 %4, %12\n\t"
+        "v_permlane32_swap_b32 %5, %13\n\t"
+        "v_permlane32_swap_b32 %6, %14\n\t"
+        "v_permlane32_swap_b32 %7, %15\n\t"
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+          "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += v[i + 8];
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %4\n\t"
+        "v_permlane16_swap_b32 %1, %5\n\t"
+        "v_permlane16_swap_b32 %2, %6\n\t"
+        "v_permlane16_swap_b32 %3, %7\n\t"
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += v[i + 4];
 }
 template <int N>
 __device__ __forceinline__ float wave_reduce16_scatter(float (&v)[N]) {
@@ -983,6 +1020,264 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
 
 
 // ---------------------------------------------------------------------------------------------------
+// backward, block-walk formulation (round 3): the sixteen 4x4-pixel workers of raster_fwd_blocks_kernel, back to front
+// ---------------------------------------------------------------------------------------------------
+// Same lane layout and per-worker entry sets as the forward block walk.  What the backward pass adds is the sum of the
+// 6 + CD gradient components of an entry over all pixels of the tile -- with sixteen workers on sixteen different
+// entries there is no wave-wide reduction to amortise:
+//   * a lane accumulates its four pixels in registers (the first one WRITES the sixteen sums: no zero fill);
+//   * the two swap stages of the wave reduction (v_permlane32_swap / v_permlane16_swap, 24 VALU) sum over the four lanes
+//     of every worker at once and leave lane (r, j) with components 4 r .. 4 r + 3 of worker j's partial record -- one
+//     float4 per lane, no DPP stage, no select;
+//   * the partial records of the <= 16 blocks of a (tile, entry) pair meet in a per-wave LDS accumulator (64 entries x
+//     64 bytes per batch): read - add - write of one float4 per lane.  Two workers can be at the same entry in the same
+//     step (neighbouring blocks walk similar lists), and LDS float atomics are no way out (ds_add_f32: ~170 cycles per
+//     wave instruction, scripts/ubench/lds_atomic.hip): colliding workers are serialised with an INTEGER claim -- every
+//     pending worker ds_min_u32's its index into the entry's claim word, the smallest wins the round, adds, releases the
+//     word; the others retry.  Fixed winner => fixed summation order => bit-reproducible gradients, as before;
+//   * after a batch lane i flushes entry i's accumulated record to its gradient slot (if anything was added) and
+//     clears it.
+// A worker stops evaluating entries behind the last one any of ITS sixteen pixels blended.
+template <int CD>
+struct BwdBlocksShared {
+    static constexpr int RS = (6 + CD + 3) & ~3;
+    float4 slab[TILES_PER_WG][64][RS / 4 + 1];   // records of the batch, padded to spread the ds_read_b128 bank groups
+    float4 acc[TILES_PER_WG][64][RS / 4];        // per-entry gradient records of the batch
+    unsigned claim[TILES_PER_WG][64];
+    int slot_of[TILES_PER_WG][64];
+};
+
+template <int CD>
+__device__ __forceinline__ void composite_bwd_blocks(int tile, int wv, int lane, BwdBlocksShared<CD>& sh, int all_reach,
+                                                     int tile_w, int tile_h, int width, int height,
+                                                     const float* __restrict__ records,
+                                                     const float* __restrict__ backgrounds,
+                                                     const int32_t* __restrict__ radii,
+                                                     const int32_t* __restrict__ cum_tiles,
+                                                     const int32_t* __restrict__ keep_scan,
+                                                     const int32_t* __restrict__ tile_offsets,
+                                                     const int32_t* __restrict__ flatten_ids,
+                                                     const float* __restrict__ render_alphas,
+                                                     const int32_t* __restrict__ last_ids,
+                                                     const float* __restrict__ v_render,
+                                                     const float* __restrict__ v_alphas, float* __restrict__ grad_slots,
+                                                     int32_t* __restrict__ any_record) {
+    constexpr int RS = (6 + CD + 3) & ~3;
+    constexpr int RQ = RS / 4;
+    static_assert(RS == 16, "block-walk backward: 16-float records");
+    const int tiles_per_cam = tile_w * tile_h;
+    const int cam = tile / tiles_per_cam;
+    const int tl = tile - cam * tiles_per_cam;
+    const int ty = tl / tile_w, tx = tl - ty * tile_w;
+    const int s = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
+    const int e = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
+    if (e <= s) return;
+
+    const int j = lane & 15, r = lane >> 4;
+    const int pyi = ty * MOBGS_TILE + 4 * (j >> 2) + r;
+    const int pxi0 = tx * MOBGS_TILE + 4 * (j & 3);
+    const float py = (float)pyi + 0.5f;
+    float px[4], T[4], behind[4], tvab[4], vo[4][CD];
+    int binf[4];
+    int top_w = -1;  // last list index any pixel of this lane blended
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        px[k] = (float)(pxi0 + k) + 0.5f;
+        const bool inside = pxi0 + k < width && pyi < height;
+        binf[k] = -1;
+        float Tf = 1.f, va = 0.f, bgdot = 0.f;
+        behind[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CD; ++c) vo[k][c] = 0.f;
+        if (inside) {
+            const size_t pix = ((size_t)cam * height + pyi) * width + pxi0 + k;
+            binf[k] = last_ids[pix];
+            Tf = 1.f - render_alphas[pix];
+            va = v_alphas ? v_alphas[pix] : 0.f;
+            const float* vr = v_render + pix * CD;
+#pragma unroll
+            for (int c = 0; c < CD; ++c) vo[k][c] = vr[c];
+            if (backgrounds) {
+#pragma unroll
+                for (int c = 0; c < CD; ++c) bgdot = __fmaf_rn(backgrounds[cam * CD + c], vo[k][c], bgdot);
+            }
+            bool nz = va != 0.f;  // all-zero cotangents: the pixel contributes to no gradient (see composite_bwd)
+#pragma unroll
+            for (int c = 0; c < CD; ++c) nz = nz || (vo[k][c] != 0.f);
+            if (!nz) binf[k] = -1;
+            top_w = max(top_w, binf[k]);
+        }
+        T[k] = Tf;
+        tvab[k] = Tf * (va - bgdot);
+    }
+    // ... of this worker (lanes j, j + 16, j + 32, j + 48) ...
+    top_w = max(top_w, __shfl_xor(top_w, 16, 64));
+    top_w = max(top_w, __shfl_xor(top_w, 32, 64));
+    // ... and of the tile
+    int top = top_w;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
+    top = min(__builtin_amdgcn_readfirstlane(top), e - 1);
+    if (top < s) return;
+    if (any_record && lane == 0) *any_record = 1;
+
+    // clear this wave's accumulators and claim words
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) sh.acc[wv][lane][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    sh.claim[wv][lane] = 0xFFFFFFFFu;
+
+    for (int hi = top; hi >= s; hi -= 64) {
+        const int n = min(64, hi - s + 1);
+        wave_lds_fence();
+        unsigned m16 = 0u;
+        if (lane < n) {
+            const int g = flatten_ids[hi - lane];
+            const float4* rp = reinterpret_cast<const float4*>(records + (size_t)g * RS);
+            const float4 r0 = rp[0], r1 = rp[1];
+            sh.slab[wv][lane][0] = r0;
+            sh.slab[wv][lane][1] = r1;
+#pragma unroll
+            for (int q = 2; q < RQ; ++q) sh.slab[wv][lane][q] = rp[q];
+            m16 = all_reach ? 0xFFFFu : block_reach_mask16(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty);
+            const TileRect tr = tile_rect(r0.x, r0.y, radii[g], tile_w, tile_h);
+            sh.slot_of[wv][lane] = keep_index(keep_scan, cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0));
+        }
+        wave_lds_fence();
+        // worker j's set of batch entries (bit i = entry hi - i: ascending bits walk back to front), cut at the last
+        // entry one of its pixels blended
+        unsigned mlo = 0u, mhi = 0u;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64((m16 >> jj) & 1u);
+            if (j == jj) {
+                mlo = (unsigned)bal;
+                mhi = (unsigned)(bal >> 32);
+            }
+        }
+        {
+            const int cut = hi - top_w;  // entries i < cut lie behind the worker's last blended entry
+            if (cut >= 64) {
+                mlo = mhi = 0u;
+            } else if (cut >= 32) {
+                mlo = 0u;
+                mhi &= ~0u << (cut - 32);
+            } else if (cut > 0) {
+                mlo &= ~0u << cut;
+            }
+        }
+        while (true) {
+            const bool has = (mlo | mhi) != 0u;
+            if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;
+            if (has) {
+                int i;
+                if (mlo != 0u) {
+                    i = __builtin_ctz(mlo);
+                    mlo &= mlo - 1u;
+                } else {
+                    i = 32 + __builtin_ctz(mhi);
+                    mhi &= mhi - 1u;
+                }
+                const int idx = hi - i;
+                float rec[RS];
+#pragma unroll
+                for (int q = 0; q < RQ; ++q) {
+                    const float4 v = sh.slab[wv][i][q];
+                    rec[4 * q] = v.x;
+                    rec[4 * q + 1] = v.y;
+                    rec[4 * q + 2] = v.z;
+                    rec[4 * q + 3] = v.w;
+                }
+                float g[16];
+                {
+                    const Eval ev = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px[0], py);
+                    blend_bwd<CD, RS, 16, true>(rec, ev, ev.pass && idx <= binf[0], T[0], behind[0], tvab[0], vo[0], g);
+                }
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+                    const Eval ev = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px[k], py);
+                    blend_bwd<CD, RS, 16, false>(rec, ev, ev.pass && idx <= binf[k], T[k], behind[k], tvab[k], vo[k], g);
+                }
+                // NOTE: the swaps below exchange registers between ALL lanes of the wave; lanes outside this branch
+                // hold garbage in g, which only ever reaches the columns of their own (idle) workers
+                wave_reduce16_columns(g);
+                float4 part = make_float4(g[0], g[1], g[2], g[3]);
+                bool pending = true;
+                while (true) {
+                    if (pending && r == 0) atomicMin(&sh.claim[wv][i], (unsigned)j);
+                    const unsigned w = sh.claim[wv][i];
+                    const bool go = pending && w == (unsigned)j;
+                    if (go) {
+                        float4 a4 = sh.acc[wv][i][r];
+                        a4.x += part.x;
+                        a4.y += part.y;
+                        a4.z += part.z;
+                        a4.w += part.w;
+                        sh.acc[wv][i][r] = a4;
+                        if (r == 0) sh.claim[wv][i] = 0xFFFFFFFFu;
+                    }
+                    pending = pending && !go;
+                    if (__builtin_amdgcn_ballot_w64(pending) == 0ull) break;
+                }
+            }
+        }
+        // flush: lane i owns entry hi - i of the batch
+        wave_lds_fence();
+        if (lane < n) {
+            float4 a4[RQ];
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                a4[q] = sh.acc[wv][lane][q];
+                any = any || a4[q].x != 0.f || a4[q].y != 0.f || a4[q].z != 0.f || a4[q].w != 0.f;
+            }
+            if (any) {
+                float4* dst = reinterpret_cast<float4*>(grad_slots + (size_t)sh.slot_of[wv][lane] * RS);
+#pragma unroll
+                for (int q = 0; q < RQ; ++q) {
+                    dst[q] = a4[q];
+                    sh.acc[wv][lane][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    }
+}
+
+template <int CD>
+__global__ void __launch_bounds__(64 * TILES_PER_WG) __attribute__((amdgpu_waves_per_eu(4)))
+raster_bwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
+                         const float* __restrict__ records, const float* __restrict__ backgrounds,
+                         const int32_t* __restrict__ radii, const int32_t* __restrict__ cum_tiles,
+                         const int32_t* __restrict__ keep_scan, const int32_t* __restrict__ tile_offsets,
+                         const int32_t* __restrict__ flatten_ids, const float* __restrict__ render_alphas,
+                         const int32_t* __restrict__ last_ids, const float* __restrict__ v_render,
+                         const float* __restrict__ v_alphas, float* __restrict__ grad_slots,
+                         const int32_t* __restrict__ tile_order, int all_reach,
+                         const uint8_t* __restrict__ isect_reach, int32_t* __restrict__ any_record) {
+    // heavy tiles (a whole workgroup per tile) keep the quadrant walk; the two never meet in one workgroup
+    constexpr size_t LDS_BYTES = sizeof(BwdShared<CD>) > sizeof(BwdBlocksShared<CD>) ? sizeof(BwdShared<CD>)
+                                                                                     : sizeof(BwdBlocksShared<CD>);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
+    const bool heavy = slot >= 0 && (slot & SCHED_HEAVY);  // workgroup-uniform: all 4 slots carry the flag
+    if (heavy) {
+        auto& sh = *reinterpret_cast<BwdShared<CD>*>(lds);
+        if (threadIdx.x < 16) sh.zero16[threadIdx.x] = 0.f;
+        __syncthreads();
+        composite_bwd<CD, 1, false>(slot & ~SCHED_HEAVY, wv, wv, lane, sh, ClassSel{0, 1, 0, all_reach}, tile_w, tile_h,
+                                    width, height, records, backgrounds, radii, cum_tiles, keep_scan, tile_offsets,
+                                    flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots, isect_reach,
+                                    any_record);
+        return;
+    }
+    if (slot < 0) return;
+    composite_bwd_blocks<CD>(slot, wv, lane, *reinterpret_cast<BwdBlocksShared<CD>*>(lds), all_reach, tile_w, tile_h,
+                             width, height, records, backgrounds, radii, cum_tiles, keep_scan, tile_offsets,
+                             flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots, any_record);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
 // backward, stage 2: per-splat sum of its slots -> dense gradient tensors
 // ---------------------------------------------------------------------------------------------------
 template <int LPG>  // lanes per splat, >= record stride
@@ -1217,10 +1512,10 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
     const int block_walk = tuning_block_walk(tuning);
     const int rc = dispatch_channels(D, [&](auto cd) {
         constexpr int CD = decltype(cd)::value;
-        if (block_walk && CD <= 10)
-            hipLaunchKernelGGL((raster_fwd_blocks_kernel<CD>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
-                               tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render,
-                               alphas, last_ids, tile_order, g_all_reach, isect_reach);
+        if (block_walk && CD <= 16)
+            hipLaunchKernelGGL((raster_fwd_blocks_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt,
+                               n_groups, tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids,
+                               render, alphas, last_ids, tile_order, ClassSel{0, 1, 0, g_all_reach}, isect_reach);
         else
         hipLaunchKernelGGL((raster_fwd_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
                            tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render,
@@ -1252,8 +1547,18 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
     const int stride = record_stride(D);
     const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
+    const int bwd_blocks = tuning_bwd_block_walk(tuning);
     const int rc = dispatch_channels(D, [&](auto cd) {
         constexpr int CD = decltype(cd)::value;
+        if constexpr (CD >= 7 && CD <= 10) {
+            if (bwd_blocks) {
+                hipLaunchKernelGGL((raster_bwd_blocks_kernel<CD>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt,
+                                   n_groups, tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles,
+                                   keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas,
+                                   grad_slots, tile_order, g_all_reach, isect_reach, any_record);
+                return;
+            }
+        }
         hipLaunchKernelGGL((raster_bwd_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
                            tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan,
                            tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots,
@@ -1283,14 +1588,26 @@ int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_tot
     const int nt = C * tile_w * tile_h;
     const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
-    if (channels_total == 10)
-        hipLaunchKernelGGL((raster_fwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream,
-                           nt, n_groups, tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids,
-                           render, alphas, last_ids, tile_order, ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach);
+    const ClassSel cls{class_sel, N, Ns, g_all_reach};
+    const dim3 g3(grid), b3(64 * TILES_PER_WG);
+    hipStream_t st = (hipStream_t)stream;
+    if (tuning_block_walk(tuning)) {
+        if (channels_total == 10)
+            hipLaunchKernelGGL((raster_fwd_blocks_kernel<10, true>), g3, b3, 0, st, nt, n_groups, tile_w, tile_h, width,
+                               height, records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids,
+                               tile_order, cls, isect_reach);
+        else
+            hipLaunchKernelGGL((raster_fwd_blocks_kernel<1, true>), g3, b3, 0, st, nt, n_groups, tile_w, tile_h, width,
+                               height, records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids,
+                               tile_order, cls, isect_reach);
+    } else if (channels_total == 10)
+        hipLaunchKernelGGL((raster_fwd_kernel<10, true>), g3, b3, 0, st, nt, n_groups, tile_w, tile_h, width, height,
+                           records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids, tile_order, cls,
+                           isect_reach);
     else
-        hipLaunchKernelGGL((raster_fwd_kernel<1, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream,
-                           nt, n_groups, tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids,
-                           render, alphas, last_ids, tile_order, ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach);
+        hipLaunchKernelGGL((raster_fwd_kernel<1, true>), g3, b3, 0, st, nt, n_groups, tile_w, tile_h, width, height,
+                           records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids, tile_order, cls,
+                           isect_reach);
     return check_launch("raster_fwd_kernel(class)");
 }
 

@@ -269,7 +269,8 @@ tuning = _lib.MobgsTuning()
 
 def _tuning_with_hint(key):
     """`tuning` plus the longest list the previous frame on this device had (selects the dense binning variant)."""
-    t = _lib.MobgsTuning(tuning.heavy_tile_len, _len_hint.get(key, 0), tuning.quadrant_culling, tuning.block_walk)
+    t = _lib.MobgsTuning(tuning.heavy_tile_len, _len_hint.get(key, 0), tuning.quadrant_culling, tuning.block_walk,
+                          tuning.bwd_block_walk)
     _tuning_keepalive.append(t)
     del _tuning_keepalive[:-8]
     return t.ref()

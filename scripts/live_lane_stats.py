@@ -123,8 +123,23 @@ def workers(live, b4):
             cnt = torch.zeros(int(nb.sum().item()), Wn, dtype=torch.long, device=dev)
             cnt.index_add_(0, bid, blk.long())
             r[f"steps_sync{B}"] = int(cnt.max(1).values.sum().item())
-            if B == 64:  # one batch of slack: a worker may run ahead into the next batch
-                c2 = cnt.clone()
+            if B == 64:
+                # run-ahead: with NB batch buffers a worker that finished batch n goes on into batch n + 1 as soon as it
+                # is staged, and batch n + 1 is staged once batch n + 1 - NB is complete (all workers past it)
+                nbmax = int(nb.max().item())
+                dense = torch.zeros(nt, nbmax, Wn, dtype=torch.long, device=dev)
+                tix = tile_of.new_tensor(torch.arange(nt, device=dev)).repeat_interleave(nb)
+                bix = torch.arange(int(nb.sum().item()), device=dev) - base.repeat_interleave(nb)
+                dense[tix, bix] = cnt
+                for NB in (2, 3, 4):
+                    fin = torch.zeros(nt, Wn, dtype=torch.long, device=dev)      # f_w[n - 1]
+                    done_at = []                                                   # F[n]
+                    for n_ in range(nbmax):
+                        staged = done_at[n_ - NB] if n_ - NB >= 0 else torch.zeros(nt, dtype=torch.long, device=dev)
+                        start = torch.maximum(fin, staged[:, None])
+                        fin = start + dense[:, n_]
+                        done_at.append(fin.max(1).values)
+                    r[f"steps_runahead_{NB}buffers"] = int(done_at[-1].sum().item()) if done_at else 0
         pt = torch.zeros(nt, Wn, dtype=torch.long, device=dev)
         pt.index_add_(0, tile_of, blk.long())
         r["steps_tile"] = int(pt.max(1).values.sum().item())

@@ -238,6 +238,42 @@ def test_block_walk_equals_quadrant_kernel(hip_device, mode, channels, tile_cull
         assert torch.equal(res[1][2][k], res[0][2][k]), f"grad[{k}] differs"
 
 
+@pytest.mark.parametrize("size", [(232, 168), (1101, 613)])
+def test_backward_block_walk_matches_quadrant_kernel(hip_device, size):
+    """The experimental backward block walk (MobgsTuning.bwd_block_walk = 1: sixteen 4x4-pixel workers per wave, partial
+    records combined in LDS under an integer claim) blends exactly the pairs the quadrant kernel blends; only the order
+    in which a (tile, splat) record's terms are summed differs.  Gradients therefore agree to fp32 summation noise --
+    bounded here by 2e-4 of each tensor's largest entry plus 1e-4 relative (the quaternion gradient amplifies the
+    record's rounding through the projection backward: 7.5e-5 of the maximum observed) -- and repeat bit for bit run to run."""
+    from mobgs_amd import rendering
+    from mobgs_amd.rendering import rasterization
+    w, h = size
+    n = 8000 if w < 1000 else 60000
+    s, _ = _scene(n, w, h, 29, 9)
+    names = ["means", "quats", "scales", "opacities", "colors", "viewmats"]
+    res = {}
+    try:
+        for tag, bw in (("quad", 0), ("blocks", 1), ("blocks2", 1)):
+            rendering.tuning.bwd_block_walk = bw
+            rendering.tuning.heavy_tile_len = 0 if w < 1000 else -1
+            t = {k: v.to(hip_device).clone().requires_grad_(k in names) for k, v in s.items()}
+            img, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                                         t["viewmats"], t["Ks"], w, h, packed=False, render_mode="RGB+ED")
+            g = torch.Generator().manual_seed(7)
+            v_img = torch.randn(img.shape, generator=g).to(hip_device)
+            ((img * v_img).sum() + (a * a).sum()).backward()
+            res[tag] = {k: t[k].grad.cpu() for k in names}
+    finally:
+        rendering.tuning.bwd_block_walk = -1
+        rendering.tuning.heavy_tile_len = -1
+    for k in names:
+        assert torch.equal(res["blocks"][k], res["blocks2"][k]), f"grad[{k}] not reproducible"
+        ref = res["quad"][k].double()
+        err = (res["blocks"][k].double() - ref).abs()
+        tol = 2e-4 * float(ref.abs().max()) + 1e-4 * ref.abs()
+        assert bool((err <= tol).all()), f"grad[{k}]: max err {float(err.max()):.3e} vs max {float(ref.abs().max()):.3e}"
+
+
 @pytest.mark.parametrize("mode,channels,tile_cull", [("RGB+ED", 9, True), ("RGB", 3, True), ("RGB+ED", 9, False)])
 def test_quadrant_reach_masks_change_nothing(hip_device, mode, channels, tile_cull):
     """Inside the compositors every list entry carries a 4-bit mask of the 8x8 quadrants its splat can reach; the
