@@ -489,8 +489,8 @@ int mobgs_deform_mlp_bwd(int N, const float* feat, const float* pts, const float
  * bwd: v_c2w / v_w2c [9,4,4] cotangents (either may be NULL); every gradient tensor is fully written (the
  *   view_embedder table gets zeros outside row idx). */
 size_t mobgs_blce_saved_floats(void);
-int mobgs_blce_fwd(const float* const* params_host, int idx, const float* Rt, const float* blur_feature, float* c2w,
-                   float* w2c, float* saved, void* stream);
+int mobgs_blce_fwd(const float* const* params_host, int idx, int num_views, const float* Rt,
+                   const float* blur_feature, float* c2w, float* w2c, float* saved, void* stream);
 int mobgs_blce_bwd(const float* const* params_host, float* const* grads_host, int idx, int num_views, const float* Rt,
                    const float* saved, const float* v_c2w, const float* v_w2c, void* stream);
 

@@ -87,7 +87,7 @@ _SIGS = {
     "mobgs_hexplane_bwd_scratch_bytes": (c_size_t, [c_int, P, P]),
     "mobgs_deform_mlp_fwd": (c_int, [c_int] + [P] * 14 + [P]),
     "mobgs_blce_saved_floats": (c_size_t, []),
-    "mobgs_blce_fwd": (c_int, [P, c_int, P, P, P, P, P, P]),
+    "mobgs_blce_fwd": (c_int, [P, c_int, c_int, P, P, P, P, P, P]),
     "mobgs_blce_bwd": (c_int, [P, P, c_int, c_int, P, P, P, P, P]),
     "mobgs_deform_mlp_bwd_blocks": (c_int, [c_int]),
     "mobgs_deform_mlp_grad_floats": (c_size_t, []),

@@ -236,6 +236,21 @@ def _view_param_list(model: "BLCE", i: int):
             model.trans_decoder[i].bias, model.theta_decoder[i].weight, model.theta_decoder[i].bias]
 
 
+def _fused_shapes_ok(m) -> bool:
+    """csrc/blce.hip hard-codes the reference's default sizes (view_dim 32, 10 blur frequencies, time_dim 8,
+    blur_feat_dim 32, num_warp 9: strides 12 / 21 / 32 / 56 / 64 of its 22 parameter tensors).  `blceopt.view_dim` is a
+    config option of the reference (train.py:260): any other shape takes the PyTorch / HIP-graph path instead of
+    reading the parameters with the wrong strides."""
+    try:
+        wv = m.wv_derivative[0]
+        return (m.num_warp == 9 and m.num_freqs == 10 and tuple(m.view_embedder.shape[1:]) == (32,)
+                and tuple(wv.time_embedder.shape) == (9, 8) and wv.w_linear.in_features == 56
+                and wv.w_linear.out_features == 16 and m.blur_feature_encoder[0][0].in_features == 21
+                and m.Rt_encoder[0].in_features == 12 and m.view_encoder[0].in_features == 64)
+    except (AttributeError, IndexError):
+        return False
+
+
 class _FusedView(torch.autograd.Function):
     """(Rt [4,4], blur feature, idx, 22 parameters) -> (warped c2w [9,4,4], warped w2c [9,4,4]) in one kernel launch;
     backward: one launch that writes all 22 parameter gradients."""
@@ -254,8 +269,8 @@ class _FusedView(torch.autograd.Function):
         need = any(ctx.needs_input_grad[4:])
         saved = torch.empty(int(lib.mobgs_blce_saved_floats()), dtype=torch.float32, device=dev) if need else None
         table = (ctypes.c_void_p * 22)(*[p.data_ptr() for p in ps])
-        check(lib.mobgs_blce_fwd(table, int(idx), ptr(Rt), ptr(bf), ptr(c2w), ptr(w2c), ptr(saved), stream()),
-              "mobgs_blce_fwd")
+        check(lib.mobgs_blce_fwd(table, int(idx), int(num_views), ptr(Rt), ptr(bf), ptr(c2w), ptr(w2c), ptr(saved),
+                                 stream()), "mobgs_blce_fwd")
         if need:
             ctx.save_for_backward(Rt, saved, *ps)
             ctx.idx, ctx.num_views = int(idx), int(num_views)
@@ -391,8 +406,10 @@ class blceKernel(nn.Module):
     def get_warped_cams(self, cam=None, fwd_cam=None, bwd_cam=None):
         dev = next(self.model.parameters()).device
         Rt = self.get_Rt_c2w(cam).to(dev)
-        if FUSED and Rt.is_cuda and self.model.num_warp == 9:
+        if FUSED and Rt.is_cuda and _fused_shapes_ok(self.model):
             m = self.model
+            if not 0 <= int(cam.uid) < m.num_views:  # the PyTorch path raises here too (ModuleList / Parameter index)
+                raise IndexError(f"BLCE: camera uid {int(cam.uid)} outside the {m.num_views} views of the model")
             warped_c2w, warped_w2c = _FusedView.apply(Rt, self.blur_feature(cam).to(dev), int(cam.uid), m.num_views,
                                                       *_view_param_list(m, int(cam.uid)))
             exposure_time = self._exposure_steps(dev) * m.exposure_time_expo[cam.uid]

@@ -35,6 +35,28 @@ for _f in ("raster.hip", "raster_layers.hip"):  # experiment hook: extra flags f
     EXTRA_FLAGS[_f] = EXTRA_FLAGS[_f] + os.environ.get("MOBGS_RASTER_EXTRA_FLAGS", "").split()
 
 
+class _BuildLock:
+    """One builder at a time per output file (several ranks of one node start together and all find the same stale
+    .so): an exclusive flock on <target>.lock; the artefact itself is written to a temporary name and moved into place
+    with os.replace, so a concurrent loader sees the old file or the new one, never a half-written one."""
+
+    def __init__(self, target: Path):
+        self.path = str(target) + ".lock"
+        self.fd = None
+
+    def __enter__(self):
+        import fcntl
+        self.fd = os.open(self.path, os.O_CREAT | os.O_RDWR, 0o644)
+        fcntl.flock(self.fd, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.fd, fcntl.LOCK_UN)
+        os.close(self.fd)
+        return False
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -59,6 +81,13 @@ def is_stale() -> bool:
 def build_extension(force: bool = False, verbose: bool = False) -> Path:
     if not force and not is_stale():
         return LIB_PATH
+    with _BuildLock(LIB_PATH):
+        if not force and not is_stale():  # another process built it while this one waited for the lock
+            return LIB_PATH
+        return _build_extension_locked(force, verbose)
+
+
+def _build_extension_locked(force: bool, verbose: bool) -> Path:
     objs = []
     hipcc = _hipcc()
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
@@ -80,10 +109,12 @@ def build_extension(force: bool = False, verbose: bool = False) -> Path:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB_PATH)]
+    tmp = LIB_PATH.with_name(LIB_PATH.name + f".tmp{os.getpid()}")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *map(str, objs), "-o", str(tmp)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
@@ -99,6 +130,13 @@ def build_fastpath(force: bool = False, verbose: bool = False) -> Path:
     """g++ -shared against the installed libtorch (~30 s).  Needs no GPU and no hipcc."""
     if not force and not fastpath_is_stale():
         return FAST_PATH
+    with _BuildLock(FAST_PATH):
+        if not force and not fastpath_is_stale():
+            return FAST_PATH
+        return _build_fastpath_locked(verbose)
+
+
+def _build_fastpath_locked(verbose: bool) -> Path:
     import sysconfig
 
     import torch
@@ -107,7 +145,8 @@ def build_fastpath(force: bool = False, verbose: bool = False) -> Path:
     if not cxx:
         raise RuntimeError("no C++ compiler found: cannot build the host fast path")
     libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
-    cmd = [cxx, "-O2", "-std=c++17", "-shared", "-fPIC", str(FAST_SRC), "-o", str(FAST_PATH),
+    tmp = FAST_PATH.with_name(FAST_PATH.name + f".tmp{os.getpid()}")
+    cmd = [cxx, "-O2", "-std=c++17", "-shared", "-fPIC", str(FAST_SRC), "-o", str(tmp),
            "-DTORCH_EXTENSION_NAME=_mobgs_fast", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
            "-I" + sysconfig.get_paths()["include"], *["-I" + i for i in ce.include_paths()],
            "-L" + libdir, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python", "-Wl,-rpath," + libdir,
@@ -117,6 +156,7 @@ def build_fastpath(force: bool = False, verbose: bool = False) -> Path:
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"host fast path: compile failed:\n{r.stdout[-4000:]}")
+    os.replace(tmp, FAST_PATH)
     return FAST_PATH
 
 

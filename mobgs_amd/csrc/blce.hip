@@ -434,10 +434,14 @@ extern "C" {
 
 size_t mobgs_blce_saved_floats(void) { return (size_t)S_TOTAL; }
 
-int mobgs_blce_fwd(const float* const* params_host, int idx, const float* Rt, const float* blur_feature, float* c2w,
-                   float* w2c, float* saved, void* stream) {
-    if (!params_host || !Rt || !blur_feature || !c2w || !w2c || idx < 0) {
+int mobgs_blce_fwd(const float* const* params_host, int idx, int num_views, const float* Rt,
+                   const float* blur_feature, float* c2w, float* w2c, float* saved, void* stream) {
+    if (!params_host || !Rt || !blur_feature || !c2w || !w2c) {
         set_error("mobgs_blce_fwd: bad arguments");
+        return MOBGS_E_INVALID;
+    }
+    if (idx < 0 || idx >= num_views) {  // view_embedder has num_views rows
+        set_error("mobgs_blce_fwd: view index %d outside [0, %d)", idx, num_views);
         return MOBGS_E_INVALID;
     }
     BlceParams P;

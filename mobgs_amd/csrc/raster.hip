@@ -1512,7 +1512,10 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
     const int block_walk = tuning_block_walk(tuning);
     const int rc = dispatch_channels(D, [&](auto cd) {
         constexpr int CD = decltype(cd)::value;
-        if (block_walk && CD <= 16)
+        // measured (profiles/r03): the block walk wins where a pixel's blend is wide -- 10 channels 256 -> 218 us, 12
+        // channels 280 -> 255 us -- and loses where the per-step bookkeeping dominates (1 channel 86 -> 90 us) or the
+        // accumulators leave two waves per SIMD (16 channels 313 -> 335 us)
+        if (block_walk && CD >= 7 && CD <= 12)
             hipLaunchKernelGGL((raster_fwd_blocks_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt,
                                n_groups, tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids,
                                render, alphas, last_ids, tile_order, ClassSel{0, 1, 0, g_all_reach}, isect_reach);
@@ -1591,16 +1594,11 @@ int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_tot
     const ClassSel cls{class_sel, N, Ns, g_all_reach};
     const dim3 g3(grid), b3(64 * TILES_PER_WG);
     hipStream_t st = (hipStream_t)stream;
-    if (tuning_block_walk(tuning)) {
-        if (channels_total == 10)
-            hipLaunchKernelGGL((raster_fwd_blocks_kernel<10, true>), g3, b3, 0, st, nt, n_groups, tile_w, tile_h, width,
-                               height, records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids,
-                               tile_order, cls, isect_reach);
-        else
-            hipLaunchKernelGGL((raster_fwd_blocks_kernel<1, true>), g3, b3, 0, st, nt, n_groups, tile_w, tile_h, width,
-                               height, records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids,
-                               tile_order, cls, isect_reach);
-    } else if (channels_total == 10)
+    if (tuning_block_walk(tuning) && channels_total == 10)  // (the 1-channel coverage pass: 86 us vs 90 us, see above)
+        hipLaunchKernelGGL((raster_fwd_blocks_kernel<10, true>), g3, b3, 0, st, nt, n_groups, tile_w, tile_h, width,
+                           height, records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids,
+                           tile_order, cls, isect_reach);
+    else if (channels_total == 10)
         hipLaunchKernelGGL((raster_fwd_kernel<10, true>), g3, b3, 0, st, nt, n_groups, tile_w, tile_h, width, height,
                            records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids, tile_order, cls,
                            isect_reach);

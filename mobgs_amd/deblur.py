@@ -61,7 +61,12 @@ def render_blurry_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor,
     def latent(v):
         if v not in warped:
             if blce is not None:
-                warped[v] = blce.get_warped_cams(cams[v], None, None)  # train.py:472 (fwd/bwd cams are unused there)
+                wc, expo = blce.get_warped_cams(cams[v], None, None)  # train.py:472 (fwd/bwd cams are unused there)
+                if exposures is not None:
+                    # the caller's offsets override BLCE's: train.py:503-506 renders the warped cameras with
+                    # delta_exposure = 0 while start_warp < iteration <= start_warp_dynamic
+                    expo = exposures[v]
+                warped[v] = (wc, expo)
             else:
                 e = exposures[v] if exposures is not None else [0] * n_sub
                 warped[v] = ([cams[v]] * n_sub, e)

@@ -146,11 +146,20 @@ def _pack_weights(W, dev):
 _pack_memo = {}
 
 
+def invalidate_packed_weights() -> None:
+    """Forget the re-laid-out MLP weights.  Needed only after edits autograd's version counter does not see -- writes
+    through `p.data` (`p.data.copy_()`, manual EMA / weight surgery, old-style optimizers): in-place ops on the
+    parameter itself (every torch.optim step, load_state_dict, `with torch.no_grad(): p.mul_()`) bump `_version`
+    and re-pack automatically, and a re-allocated `.data` changes the storage pointer that is part of the key."""
+    _pack_memo.clear()
+
+
 def _packed(weights, W, dev):
     """_pack_weights, rebuilt only when a weight tensor was replaced or modified in place (optimizer step):
-    ~25 small launches saved per call."""
+    ~25 small launches saved per call.  Keyed on identity, storage pointer and autograd version of every weight; see
+    invalidate_packed_weights() for the one kind of edit that escapes all three."""
     key = tuple(id(w) for w in weights)
-    ver = tuple(w._version for w in weights)
+    ver = tuple((w._version, w.data_ptr()) for w in weights)
     hit = _pack_memo.get(key)
     if hit is not None and hit[0] == ver and all(a() is b for a, b in zip(hit[1], weights)):
         return hit[2]

@@ -40,8 +40,18 @@ def _all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
         h = t.detach().cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
         t.copy_(h)
-        return None
+        return _DoneWork() if async_op else None  # synchronous here; callers of async_op get a handle all the same
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+class _DoneWork:
+    """A completed `Work`: what the host-staged gloo path hands to callers that asked for async_op=True."""
+
+    def wait(self, timeout=None):
+        return True
+
+    def is_completed(self):
+        return True
 
 
 class _SumAcrossRanks(torch.autograd.Function):
@@ -56,7 +66,8 @@ class _SumAcrossRanks(torch.autograd.Function):
     def forward(ctx, x, group, donate, reduce_backward=False):
         ctx.group, ctx.reduce_backward = group, bool(reduce_backward)
         y = x.detach()
-        if not (donate and y.is_contiguous()):
+        donate = bool(donate) and y.is_contiguous()  # a strided temporary cannot be reduced in place: reduce a copy
+        if not donate:
             y = y.clone(memory_format=torch.contiguous_format)
         _all_reduce_sum(y, group)
         if donate:

@@ -57,3 +57,12 @@ def test_get_warped_cams_contract():
     assert kern.model.rot_decoder[0].weight.grad is not None
     kern.optimizer.step()
     kern.adjust_lr()
+
+
+def test_fused_kernel_is_gated_on_the_shapes_it_hard_codes():
+    """csrc/blce.hip reads the 22 parameter tensors of a view with the strides of the reference's default sizes;
+    `blceopt.view_dim` is a config option (train.py:260).  Any other shape must take the PyTorch path."""
+    from mobgs_amd.blce import _fused_shapes_ok
+    assert _fused_shapes_ok(BLCE(num_views=3, view_dim=32, num_warp=9))
+    assert not _fused_shapes_ok(BLCE(num_views=3, view_dim=64, num_warp=9))
+    assert not _fused_shapes_ok(BLCE(num_views=3, view_dim=32, num_warp=5))

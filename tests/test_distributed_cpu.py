@@ -338,3 +338,35 @@ def test_rotated_partition_balances_two_unit_families():
     assert sorted(renders) == [2, 2, 2, 2, 2, 2, 3, 3] and sorted(flows) == [2, 2, 2, 2, 2, 2, 3, 3]
     assert sorted(a + b for a, b in zip(renders, flows)) == [4, 4, 4, 4, 5, 5, 5, 5]
     assert sorted(p for sh in s for p in sh.view_units(2, 9, offset=18)) == [(v, k) for v in range(2) for k in range(9)]
+
+
+def _donate_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mobgs_amd.distributed import _SumAcrossRanks, _all_reduce_sum
+        base = torch.arange(24, dtype=torch.float32).reshape(4, 6) * (rank + 1)
+        strided = base.t()  # non-contiguous temporary
+        y = _SumAcrossRanks.apply(strided, None, True, False)
+        work = _all_reduce_sum(torch.ones(3), None, async_op=True)
+        work.wait()
+        q.put(_plain((rank, y.contiguous())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_donated_strided_input_is_still_reduced():
+    """mean_of_subframes(..., donate=True) with a non-contiguous input used to all-reduce a clone and hand
+    back the un-reduced original."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_donate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = [_tensors(q.get(timeout=120)) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    want = (torch.arange(24, dtype=torch.float32).reshape(4, 6) * 3).t()
+    for rank, y in outs:
+        assert torch.equal(y, want.contiguous()), f"rank {rank}"
