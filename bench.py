@@ -150,6 +150,130 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_raster_bwd_pmc.json")
+
+
+def _rocprof_child(extra, tag, child_args):
+    """Run `python bench.py <child_args>` under rocprofv3 with `extra` options in a scratch directory; -> that directory
+    (None when rocprofv3 is not installed or the run failed).  Counter passes never carry tracing flags."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix=f"mobgs_{tag}_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = [exe, *extra, "--output-format", "csv", "-d", out, "-o", tag, "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), *child_args]
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    except Exception:  # noqa: BLE001
+        return None
+    return out if r.returncode == 0 else None
+
+
+def _find(root, suffix):
+    for d, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(suffix):
+                return os.path.join(d, f)
+    return None
+
+
+def kernel_breakdown(args, N, Ns, Nd, I, I_box, P):
+    """Per-kernel time of the lean step from a rocprofv3 --kernel-trace --stats pass over a child run of this script
+    (40 steps of the same workload; the kernels of one process cannot be timed one by one with events from Python:
+    most of them are launched inside single C-ABI calls) -> {kernel: {avg_us, calls_per_step, bytes, GB/s, frac}} with
+    the ALGORITHMIC bytes of DESIGN.md section 4 per launch.  Times under the profiler run ~2 % slow (clock)."""
+    import csv
+    steps = 40
+    out = _rocprof_child(["--kernel-trace", "--stats"], "kb", ["--steps", str(steps), "--warmup", "10",
+                         "--breakdown-child", "--ns", str(args.ns), "--nd", str(args.nd), "--width", str(args.width),
+                         "--height", str(args.height)])
+    f = _find(out, "kernel_stats.csv") if out else None
+    if not f:
+        return None
+    algo = [  # (name as reported, substring of the kernel name, algorithmic bytes per launch)
+        ("prep_fwd", "prep_fwd_kernel", 124.0 * Ns + 252.0 * Nd),
+        ("prep_bwd", "prep_bwd_kernel", 124.0 * Ns + 252.0 * Nd + 80.0 * N),
+        ("project_fwd(+records)", "project_fwd_kernel", 140.0 * N),
+        ("project_bwd", "project_bwd_kernel", 140.0 * N),
+        ("scan_lookback", "scan_lookback", 8.0 * N),
+        ("bin", "bin_kernel", 16.0 * I_box + 12.0 * I),
+        ("tile_scan", "tile_scan_kernel", None),
+        ("emit", "emit_kernel", 20.0 * I),
+        ("tile_sort", "tile_sort", 16.0 * I),
+        ("raster_fwd", "raster_fwd", 68.0 * I + 48.0 * P),
+        ("raster_bwd", "raster_bwd", 132.0 * I + 52.0 * P),
+        ("slot_reduce", "slot_reduce", 64.0 * I + 64.0 * N),
+        ("slot_zero_fill", "FillFunctor", 64.0 * I),
+        ("decoder_fwd", "decoder_fwd_kernel", 84.0 * P),
+        ("decoder_bwd", "decoder_bwd_kernel", 132.0 * P),
+    ]
+    rows = list(csv.DictReader(open(f)))
+    total_ns = sum(float(r["TotalDurationNs"]) for r in rows)
+    calls0 = steps + 10
+    res, seen = {}, 0.0
+    for name, pat, nbytes in algo:
+        hit = [r for r in rows if pat in r["Name"]]
+        if not hit:
+            continue
+        tot = sum(float(r["TotalDurationNs"]) for r in hit)
+        calls = sum(int(r["Calls"]) for r in hit)
+        seen += tot
+        avg_us = tot / calls / 1e3
+        e = {"avg_us": round(avg_us, 2), "launches_per_step": round(calls / calls0, 2)}
+        if nbytes:
+            gbs = nbytes / (avg_us * 1e-6) / 1e9
+            e.update(bytes=nbytes, GBps=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+        res[name] = e
+    res["_all_kernels_us_per_step"] = round(total_ns / calls0 / 1e3, 1)
+    res["_other_kernels_us_per_step"] = round((total_ns - seen) / calls0 / 1e3, 1)
+    res["_source"] = f"rocprofv3 --kernel-trace --stats over a {steps}-step child run of this script (same workload)"
+    import shutil
+    shutil.rmtree(out, ignore_errors=True)
+    return res
+
+
+def collect_pmc(args, I, P):
+    """bench.py --pmc: re-collect the counters behind roofline.traffic / roofline.valu for raster_bwd -- three separate
+    rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU: MI355X_MICROARCH.md, "rocprofv3 PMC slots"; no
+    tracing flags) over a short child run -- and store them with the hash of the kernel sources in
+    profiles/r03_raster_bwd_pmc.json.  Correction rule (measured, DESIGN section 5: scripts/ubench/fetch_calib.hip):
+    FETCH_SIZE counts a 16-byte-per-lane coalesced stream at 0.5x and 64-byte record gathers / stores at 1.0x."""
+    import csv
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+        out = _rocprof_child(["--pmc", ctr], ctr.lower(), ["--steps", "10", "--warmup", "2", "--breakdown-child",
+                             "--ns", str(args.ns), "--nd", str(args.nd), "--width", str(args.width), "--height",
+                             str(args.height)])
+        f = _find(out, "counter_collection.csv") if out else None
+        if not f:
+            return {"error": f"no counter file for {ctr}"}
+        tot, n = 0.0, 0
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == ctr and "raster_bwd" in row["Kernel_Name"]:
+                tot += float(row["Counter_Value"])
+                n += 1
+        vals[ctr] = tot / max(1, n)
+        import shutil
+        shutil.rmtree(out, ignore_errors=True)
+    fetch, write = vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
+    stream = 52.0 * P
+    alg = 132.0 * I + 52.0 * P
+    d = {"source_sha": source_sha(), "kernel": "raster_bwd_kernel<10, false>",
+         "source": "bench.py --pmc: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU (three separate passes over "
+                   "bench.py --steps 10 --warmup 2 --breakdown-child)",
+         "FETCH_SIZE_KiB_per_launch_raw": vals["FETCH_SIZE"], "WRITE_SIZE_KiB_per_launch_raw": vals["WRITE_SIZE"],
+         "hbm_bytes_per_launch": fetch + 0.5 * stream + write, "hbm_bytes_per_launch_lower_estimate": fetch + write,
+         "algorithmic_bytes": alg, "valu_wave_insts_per_launch": vals["SQ_INSTS_VALU"],
+         "traffic_over_algorithmic": [round((fetch + write) / alg, 3), round((fetch + 0.5 * stream + write) / alg, 3)]}
+    os.makedirs(os.path.dirname(PMC_JSON), exist_ok=True)
+    json.dump(d, open(PMC_JSON, "w"), indent=1)
+    return d
+
+
 class DeblurWorkload:
     """The blurry-view part of one training iteration for a batch of views (train.py:430-541), see module docstring."""
 
@@ -300,6 +424,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-torch", action="store_true", help="skip the PyTorch-CPU config #1 render (tens of s)")
     ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--train-steps", type=int, default=3, help="N=1: whole training iterations timed (0: skip)")
+    ap.add_argument("--repeat-steps", type=int, default=100,
+                    help="N=1: further lean steps after the K timed ones; their HIP-event median is reported as `repeat`")
+    ap.add_argument("--no-kernel-breakdown", action="store_true",
+                    help="skip the rocprofv3 child run behind roofline.streaming")
+    ap.add_argument("--pmc", action="store_true",
+                    help="re-collect roofline.traffic / roofline.valu (three rocprofv3 --pmc child runs) first")
+    ap.add_argument("--breakdown-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -353,14 +485,25 @@ def main():
 
     P = args.width * args.height
     n_units = args.views * 9
-    deblur = dynamic = flows = None
+    deblur = dynamic = flows = train_it = repeat = None
+    if args.breakdown_child:  # the profiled child of kernel_breakdown() / collect_pmc(): lean steps only, no output
+        for _ in range(args.steps + args.warmup):
+            lean_step()
+        torch.cuda.synchronize()
+        return
     if world == 1:
         profiler.enable(True)
         dt, med_ms = timed(lean_step, args.steps, args.warmup, world, dist)
         prof = profiler.summary()
         profiler.enable(False)
+        if args.repeat_steps > 0:  # the driver's K may be small: a longer run next to it (not `value`)
+            rdt, rmed = timed(lean_step, args.repeat_steps, 0, world, dist)
+            repeat = {"steps": args.repeat_steps, "ms_per_step": round(rdt / args.repeat_steps * 1e3, 4),
+                      "event_median_ms_per_step": round(rmed, 4),
+                      "renders_per_s": round(args.repeat_steps / rdt, 2)}
         from mobgs_amd import rendering
         I = rendering.last_stats.get("n_isects", 0)  # of the PRIMARY workload (the secondary legs render too)
+        I_box = rendering.last_stats.get("n_box", 0) or I
         n_vis = int((last["out"]["radii"] > 0).sum())
         renders = args.steps
         workload = ("BASELINE config #2: seesaw-synth (SURVEY 8d seed 0), "
@@ -392,6 +535,22 @@ def main():
                 fdt, _ = timed(fw.step, args.flow_steps, 2, world, dist)
                 flows[name] = round(fdt / args.flow_steps * 1e3, 3)
             flows["zero_weight_note"] = "cotangents exactly zero: lambda_flow_loss = 0 (arguments/stereo/seesaw.py)"
+        if args.train_steps > 0:
+            sys.path.insert(0, os.path.join(ROOT, "examples"))
+            import train_deblur_synth as TD
+            tr = TD.DeblurTrainer(str(dev), args.ns, args.nd, args.width, args.height, args.views, shard=shard,
+                                  iters=10000)
+            tdt, tmed = timed(tr.iteration, args.train_steps, 2, world, dist)
+            train_it = {"ms_per_iteration": round(tdt / args.train_steps * 1e3, 2),
+                        "event_median_ms_per_iteration": round(tmed, 2), "iterations_per_s": round(args.train_steps / tdt, 3),
+                        "steps": args.train_steps, "views_per_iteration": args.views,
+                        "what": "ONE whole training iteration (train.py:430-807) at the headline size: per view K = 9 "
+                                "latent renders through BLCE cameras (mid frame in train mode) + the 9 get_flow() calls, "
+                                "fused L1 + D-SSIM on the blurry prediction, depth / mask / normal (get_normals) terms on "
+                                "the mid render, a flow term per sub-frame, backward into the flat gradient buffer, "
+                                "densification statistics, Adam on both Gaussian sets + decoder + BLCE "
+                                "(examples/train_deblur_synth.py DeblurTrainer.iteration)"}
+            del tr
     else:
         wl = DeblurWorkload(dev, stat, dyn, scam, args.width, args.height, shard, args.views)
         profiler.enable(True)
@@ -405,6 +564,7 @@ def main():
         last["out"] = next(iter(wl.mids.values())) if wl.mids else render(cam, stat, dyn, None, bg)
         from mobgs_amd import rendering
         I = rendering.last_stats.get("n_isects", 0)
+        I_box = rendering.last_stats.get("n_box", 0) or I
         n_vis = int((last["out"]["radii"] > 0).sum())
         workload = (f"K=9 deblur iteration (train.py:430-541): {args.views} blurry views x (1 train-mode mid render + 8 "
                     f"latent renders, BLCE cameras + exposure offsets), seesaw-synth {args.ns} static + {args.nd} "
@@ -440,6 +600,10 @@ def main():
         result["dynamic_config3"] = dynamic
     if flows is not None:
         result["get_flow"] = flows
+    if train_it is not None:
+        result["train_iteration"] = train_it
+    if repeat is not None:
+        result["repeat"] = repeat
     if rank == 0:
         rb = prof.get("raster_bwd")
         if rb:
@@ -453,7 +617,9 @@ def main():
                     "avg_kernel_ms": round(rb["avg_ms"], 4), "algorithmic_bytes": alg_bytes, "calls": rb["calls"]}
             # counter-derived figures are attached only when the committed PMC summary was collected with exactly
             # these kernel sources (scripts/prof_pmc.sh writes profiles/r02_raster_bwd_pmc.json with their hash)
-            pmc = os.path.join(ROOT, "profiles", "r02_raster_bwd_pmc.json")
+            if args.pmc and world == 1:
+                roof["pmc_collected"] = "error" not in collect_pmc(args, I, P)
+            pmc = PMC_JSON
             if os.path.exists(pmc):
                 try:
                     counters = json.load(open(pmc))
@@ -471,9 +637,25 @@ def main():
                                             "frac_of_fp32_vector_issue_peak": round(lane_ops / (F32_VECTOR_PEAK_TF
                                                                                                  * 1e12 / 2), 4)}
                     else:
-                        roof["traffic_note"] = "profiles/r02_raster_bwd_pmc.json is from other kernel sources: ignored"
+                        roof["traffic_note"] = ("profiles/r03_raster_bwd_pmc.json is from other kernel sources: ignored "
+                                                "(python bench.py --pmc re-collects it)")
                 except Exception:  # noqa: BLE001
                     pass
+            if world == 1:
+                N = args.ns + args.nd
+                # algorithmic bytes of the whole lean step, with the build's culled lists (I) and with
+                # gsplat's bounding-box lists (I_box), against the step time
+                e2e = {}
+                for tag, ii in (("listed_I", I), ("bounding_box_I", I_box)):
+                    b = 244.0 * N + 224.0 * ii + 172.0 * P
+                    gbs = b / (ms_per_step * 1e-3) / 1e9
+                    e2e[tag] = {"intersections": ii, "bytes": b, "GBps": round(gbs, 1),
+                                "frac": round(gbs / HBM_PEAK_GBS, 4)}
+                roof["end_to_end"] = e2e
+                if not args.no_kernel_breakdown:
+                    kb = kernel_breakdown(args, N, args.ns, args.nd, I, I_box, P)
+                    if kb:
+                        roof["streaming"] = kb
             result["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -48,58 +48,82 @@ def view_pose(i):
     return w2c
 
 
-def train(dev="cuda:0", iters=40, ns=4000, nd=2000, width=256, height=192, n_views=2, seed=0, lambda_flow=1e-2,
-          shard=None, log=None):
-    shard = shard or SubframeShard()
-    scam = SynthCamera().scaled(width, height)
-    torch.manual_seed(seed)
-    dec = Sandwich(9, 3).to(dev)
-    sp, dp = gaussian_cloud(ns, scam, seed), gaussian_cloud(nd, scam, seed + 1)
-    dx = dynamic_extras(dp["xyz"], seed)
-    stat = TrainableGaussians(sp, None, dec, device=dev)
-    dyn = TrainableGaussians(dp, dx, dec, device=dev)
-    bg = torch.zeros(9, device=dev)
-    g = torch.Generator().manual_seed(seed + 100)
-    cams = []
-    for i in range(n_views):
-        c = PinholeCamera(width, height, scam.K, view_pose(i), time=(5.0 + 6 * i) / 23.0, max_time=23, device=dev)
-        c.uid = i
-        cams.append(c)
-    # blurry targets: mean of K renders of a colour-shifted copy of the scene at spread-out exposure offsets
-    with torch.no_grad():
-        tsp = dict(sp, features_dc=sp["features_dc"] + 0.4 * torch.randn(sp["features_dc"].shape, generator=g))
-        tdp = dict(dp, features_dc=dp["features_dc"] + 0.4 * torch.randn(dp["features_dc"].shape, generator=g))
-        tstat, tdyn = TrainableGaussians(tsp, None, dec, device=dev), TrainableGaussians(tdp, dx, dec, device=dev)
-        targets, depths = [], []
-        for c in cams:
-            outs = [render(c, tstat, tdyn, None, bg, delta_exposure=float(d))
-                    for d in torch.linspace(-0.6, 0.6, K)]
-            targets.append(torch.stack([o["render"] for o in outs]).mean(0).clamp(0, 1))
-            depths.append(outs[K // 2]["depth"].detach())
-            c.image = targets[-1]  # BLCE's blur statistic reads the (blurry) input image of the view
-    torch.manual_seed(seed + 1)
-    blce = blceKernel(num_views=n_views, num_warp=K, iteration=max(iters, 1)).to(dev)
-    opt = Opt()
-    stat.training_setup(opt)
-    dyn.training_setup(opt)
-    dyn.optimizer.param_groups = [gr for gr in dyn.optimizer.param_groups if gr["name"] != "decoder"]
-    params = [p for gr in stat.optimizer.param_groups + dyn.optimizer.param_groups for p in gr["params"]] \
-        + list(blce.model.get_params())
-    n_all = ns + nd
-    bucket = FlatGradients(params, extra={f"view{v}": 3 * n_all for v in range(n_views)})
-    history = []
-    for it in range(1, iters + 1):
+class _Intrinsics:
+    """The five numbers main_utils.get_normals reads from a dycheck camera (main_utils.py:95-141)."""
+
+    def __init__(self, K):
+        self.scale_factor_x, self.scale_factor_y = float(K[0, 0]), float(K[1, 1])
+        self.principal_point_x, self.principal_point_y = float(K[0, 2]), float(K[1, 2])
+        self.skew = float(K[0, 1])
+
+
+class DeblurTrainer:
+    """State of the miniature training loop; `iteration()` is ONE iteration of train.py:430-807 on this stack:
+    blurry views (K latent renders each, BLCE cameras) -> K get_flow() calls per view -> photometric + depth + mask +
+    normal + flow + scale terms -> backward into the flat gradient buffer -> (all-reduce) -> densification statistics ->
+    Adam on both Gaussian sets (incl. the decoder) and the BLCE parameters.  bench.py times it at full size."""
+
+    def __init__(self, dev="cuda:0", ns=4000, nd=2000, width=256, height=192, n_views=2, seed=0, lambda_flow=1e-2,
+                 shard=None, iters=40):
+        from mobgs_amd.main_utils import get_normals
+        self.get_normals = get_normals
+        self.shard = shard = shard or SubframeShard()
+        self.ns, self.nd, self.n_views, self.lambda_flow = ns, nd, n_views, lambda_flow
+        scam = SynthCamera().scaled(width, height)
+        torch.manual_seed(seed)
+        dec = Sandwich(9, 3).to(dev)
+        sp, dp = gaussian_cloud(ns, scam, seed), gaussian_cloud(nd, scam, seed + 1)
+        dx = dynamic_extras(dp["xyz"], seed)
+        self.stat = stat = TrainableGaussians(sp, None, dec, device=dev)
+        self.dyn = dyn = TrainableGaussians(dp, dx, dec, device=dev)
+        self.bg = bg = torch.zeros(9, device=dev)
+        g = torch.Generator().manual_seed(seed + 100)
+        self.cams = cams = []
+        for i in range(n_views):
+            c = PinholeCamera(width, height, scam.K, view_pose(i), time=(5.0 + 6 * i) / 23.0, max_time=23, device=dev)
+            c.uid = i
+            cams.append(c)
+        self.meta = _Intrinsics(scam.K)
+        # blurry targets: mean of K renders of a colour-shifted copy of the scene at spread-out exposure offsets
+        with torch.no_grad():
+            tsp = dict(sp, features_dc=sp["features_dc"] + 0.4 * torch.randn(sp["features_dc"].shape, generator=g))
+            tdp = dict(dp, features_dc=dp["features_dc"] + 0.4 * torch.randn(dp["features_dc"].shape, generator=g))
+            tstat, tdyn = TrainableGaussians(tsp, None, dec, device=dev), TrainableGaussians(tdp, dx, dec, device=dev)
+            self.targets, self.depths, self.normals = [], [], []
+            for c in cams:
+                outs = [render(c, tstat, tdyn, None, bg, delta_exposure=float(d))
+                        for d in torch.linspace(-0.6, 0.6, K)]
+                self.targets.append(torch.stack([o["render"] for o in outs]).mean(0).clamp(0, 1))
+                self.depths.append(outs[K // 2]["depth"].detach())
+                self.normals.append(get_normals(self.depths[-1] + 1e-6, self.meta).detach())
+                c.image = self.targets[-1]  # BLCE's blur statistic reads the (blurry) input image of the view
+            del tstat, tdyn
+        self.gt = torch.stack(self.targets)
+        torch.manual_seed(seed + 1)
+        self.blce = blceKernel(num_views=n_views, num_warp=K, iteration=max(iters, 1)).to(dev)
+        self.opt = opt = Opt()
+        stat.training_setup(opt)
+        dyn.training_setup(opt)
+        dyn.optimizer.param_groups = [gr for gr in dyn.optimizer.param_groups if gr["name"] != "decoder"]
+        params = [p for gr in stat.optimizer.param_groups + dyn.optimizer.param_groups for p in gr["params"]] \
+            + list(self.blce.model.get_params())
+        self.bucket = FlatGradients(params, extra={f"view{v}": 3 * (ns + nd) for v in range(n_views)})
+
+    def iteration(self) -> torch.Tensor:
+        shard, stat, dyn, blce, bucket, ns = self.shard, self.stat, self.dyn, self.blce, self.bucket, self.ns
         bucket.zero()
-        pred, mids = render_blurry_batch(cams, stat, dyn, bg, shard, blce=blce, n_sub=K, rank_local_terms=True)
-        flows = get_flow_batch(cams, stat, dyn, bg, shard, n_sub=K)
-        gt = torch.stack(targets)
-        photo = photometric_loss(pred, gt, opt.lambda_dssim)
+        pred, mids = render_blurry_batch(self.cams, stat, dyn, self.bg, shard, blce=blce, n_sub=K,
+                                         rank_local_terms=True)
+        flows = get_flow_batch(self.cams, stat, dyn, self.bg, shard, n_sub=K)
+        photo = photometric_loss(pred, self.gt, self.opt.lambda_dssim)
         loss = shard.replicated_term(photo)                      # every rank forms it on the replicated prediction
         for v, pkg in mids.items():                              # the rank that rendered the mid frame
-            loss = loss + 0.05 * l1_loss(pkg["depth"], depths[v]) + 0.01 * pkg["d_alpha"].mean()
+            normal = self.get_normals(pkg["depth"] + 1e-6, self.meta)   # train.py:590
+            loss = loss + 0.05 * l1_loss(pkg["depth"], self.depths[v]) + 0.01 * pkg["d_alpha"].mean() \
+                + 0.01 * l1_loss(normal, self.normals[v])
         for (v, k), (e2m, m2e, limg, lalpha) in flows.items():   # the owner of the flow unit
-            loss = loss + lambda_flow / K * (l1_loss(limg, pred[v]) + 1e-3 * (e2m - m2e).abs().mean()
-                                             + 0.1 * lalpha.mean())
+            loss = loss + self.lambda_flow / K * (l1_loss(limg, pred[v]) + 1e-3 * (e2m - m2e).abs().mean()
+                                                  + 0.1 * lalpha.mean())
         loss = loss + shard.replicated_term(1e-4 * ((stat._scaling ** 2).mean() + (dyn._scaling ** 2).mean()))
         with LeafGradSink(stat, dyn, extra=blce.model.get_params()):
             loss.backward()
@@ -107,7 +131,7 @@ def train(dev="cuda:0", iters=40, ns=4000, nd=2000, width=256, height=192, n_vie
             shard.put_densification_stats(bucket, f"view{v}", pkg["viewspace_points"].grad, pkg["radii"])
         shard.all_reduce_gradients(bucket)
         with torch.no_grad():
-            for v in range(n_views):
+            for v in range(self.n_views):
                 grad2d, radii = shard.get_densification_stats(bucket, f"view{v}")
                 vis = radii > 0
                 stat.add_densification_stats(grad2d[:ns], vis[:ns], radii=radii[:ns])
@@ -115,10 +139,18 @@ def train(dev="cuda:0", iters=40, ns=4000, nd=2000, width=256, height=192, n_vie
         stat.optimizer.step()
         dyn.optimizer.step()
         blce.optimizer.step()
-        history.append(float(photo.detach()))
-        if log and (it % log == 0 or it == 1) and shard.rank == 0:
+        return photo.detach()
+
+
+def train(dev="cuda:0", iters=40, ns=4000, nd=2000, width=256, height=192, n_views=2, seed=0, lambda_flow=1e-2,
+          shard=None, log=None):
+    t = DeblurTrainer(dev, ns, nd, width, height, n_views, seed, lambda_flow, shard, iters)
+    history = []
+    for it in range(1, iters + 1):
+        history.append(float(t.iteration()))
+        if log and (it % log == 0 or it == 1) and t.shard.rank == 0:
             print(f"it {it:4d}  photometric {history[-1]:.5f}")
-    return history, stat, dyn, blce, bucket
+    return history, t.stat, t.dyn, t.blce, t.bucket
 
 
 if __name__ == "__main__":
