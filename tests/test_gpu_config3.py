@@ -14,7 +14,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import check_deform_fixture_grads, close, load, mid_planes, psnr
+from helpers import (check_deform_fixture_grads, close, close_image_with_blend_flips, close_point_rows, load,
+                     mid_planes, psnr)
 
 pytestmark = pytest.mark.gpu
 
@@ -62,7 +63,7 @@ def test_deform_mid_size_planes_match_reference_fixture(hip_device):
     for name, t in (("pts", pts), ("scales", scales), ("rots", rots)):
         ref = fx["grad_" + name]
         sc = float(np.abs(ref).max())
-        close(t.grad, ref, 1e-3, 1e-4 * sc, f"grad {name}", flip_frac=1e-3, flip_atol=0.05 * sc)
+        close_point_rows(t.grad, ref, 1e-3, 1e-4 * sc, f"grad {name}", flip_rows=1e-3, share=0.25)  # observed: 1 row of 4000
     # ... and so does the row / column of the weight gradients that belongs to that unit (one point's contribution)
     for k, w in _weights_of(net).items():
         ref = fx["gw_" + k]
@@ -118,14 +119,16 @@ def test_deform_seesaw_planes_100k_points_match_oracle(hip_device):
         sc = float(b.grad.abs().max())
         # ReLU flips and bilinear-cell flips (a coordinate within rounding of a grid line takes the neighbour's slope:
         # the sample is continuous there, its derivative is not) change a point's gradient by its own magnitude
-        close(a.grad, b.grad, 1e-3, 1e-4 * sc, "grad " + name, flip_frac=1e-3, flip_atol=0.5 * sc)
+        close_point_rows(a.grad, b.grad, 1e-3, 1e-4 * sc, "grad " + name, flip_rows=1e-3, share=1.0)
     for k, w in _weights_of(net).items():
         sc = float(W[k].grad.abs().max())
-        close(w.grad, W[k].grad, 2e-3, 2e-4 * sc, "grad " + k, flip_frac=0.05, flip_atol=0.02 * sc)
+        close(w.grad, W[k].grad, 2e-3, 2e-4 * sc, "grad " + k, flip_frac=0.05, flip_atol=0.02 * sc)  # observed 3e-2 / 9e-3
     for li, level in enumerate(net.deformation_net.grid.grids):
         for pi, pl in enumerate(level):
             r = planes[li][pi].grad
             sc = float(r.abs().max())
+            # observed: 6e-3 of the entries, the worst 7.6e-2 of the plane's maximum (one point's 4 x 32 taps in a plane
+            # cell that few points share)
             close(pl.grad, r, 2e-3, 2e-4 * sc, f"grad plane {li}.{pi}", flip_frac=0.01, flip_atol=0.2 * sc)
 
 
@@ -178,17 +181,20 @@ def test_config3_deformed_dynamic_splats_through_the_rasterizer(hip_device):
     torch.autograd.backward([m_c, q_c, s_c], [torch.from_numpy(r[k]) for k in ("v_means", "v_quats", "v_scales")])
     ref = torch.from_numpy(r["render"])
     scale = float(ref.abs().max())
-    close(img, ref, 0, 3e-5 * scale, "image", flip_frac=2e-3, flip_atol=scale / 50)
+    vis_depth = meta["depths"][meta["radii"] > 0]
+    close_image_with_blend_flips(img, ref, r["alphas"], float(c.abs().max()),
+                                 float(vis_depth.max() - vis_depth.min()), 3e-5 * scale, "image", flip_frac=2e-4,
+                                 n_colour_channels=9)  # derived one-blend-step bound (was scale / 50); observed 1.5e-5
     target = ref[..., :9] / scale + 0.05 * torch.randn(ref[..., :9].shape, generator=g)
     assert abs(psnr(img[..., :9].cpu() / scale, target) - psnr(ref[..., :9] / scale, target)) <= 1e-4
     for a, b, name in zip(leaves, leaves_cpu, ("pts", "scales", "rots")):
         sc = float(b.grad.abs().max())
-        close(a.grad, b.grad, 2e-3, 1e-4 * sc, "grad " + name, flip_frac=2e-3, flip_atol=0.5 * sc)
+        close_point_rows(a.grad, b.grad, 2e-3, 1e-4 * sc, "grad " + name, flip_rows=2e-4, share=1.0)  # observed 2e-5
     for k, w in _weights_of(net).items():
         sc = float(W[k].grad.abs().max())
-        close(w.grad, W[k].grad, 5e-3, 5e-3 * sc, "grad " + k, flip_frac=0.05, flip_atol=0.03 * sc)
+        close(w.grad, W[k].grad, 5e-3, 5e-3 * sc, "grad " + k, flip_frac=5e-3, flip_atol=0.01 * sc)  # observed: none
     for li, level in enumerate(net.deformation_net.grid.grids):
         for pi, pl in enumerate(level):
             b = planes[li][pi].grad
             sc = float(b.abs().max())
-            close(pl.grad, b, 5e-3, 5e-4 * sc, f"grad plane {li}.{pi}", flip_frac=0.01, flip_atol=0.2 * sc)
+            close(pl.grad, b, 5e-3, 5e-4 * sc, f"grad plane {li}.{pi}", flip_frac=1e-3, flip_atol=0.02 * sc)  # observed: none

@@ -48,7 +48,10 @@ def test_fullsize_forward_backward_against_c_oracle(hip_device, scene300k):
     rad = meta["radii"].cpu().numpy().astype(np.int64)
     ref_rad = r["radii"].astype(np.int64)
     differ = rad != ref_rad
-    assert differ.sum() <= 30, int(differ.sum())
+    # observed: 0 of 300 000 since project.hip evaluates the expressions as written (-ffp-contract=off, round 2); a
+    # regression of the kind the soak found (1 splat in 8000) would show as ~40
+    print(f"\n[fullsize] radii differing from the C oracle: {int(differ.sum())} of {rad.size}")
+    assert differ.sum() == 0, int(differ.sum())
     both = differ & (rad > 0) & (ref_rad > 0)
     assert np.abs(rad - ref_rad)[both].max(initial=0) <= 1
     ref = torch.from_numpy(r["render"])
@@ -58,7 +61,7 @@ def test_fullsize_forward_backward_against_c_oracle(hip_device, scene300k):
     vis_depth = meta["depths"][meta["radii"] > 0]
     nflip, worst = close_image_with_blend_flips(img, ref, r["alphas"], float(s["colors"].abs().max()),
                                                 float(vis_depth.max() - vis_depth.min()), 3e-5 * scale, "image",
-                                                flip_frac=2e-3, n_colour_channels=9)
+                                                flip_frac=2e-4, n_colour_channels=9)  # observed 2e-6 .. 6e-5
     print(f"\n[fullsize] image: {nflip} of {ref.numel()} elements beyond 3e-5 x range (largest {worst:.2e}); all "
           "within the one-blend-step bound")
     target = (ref[..., :9] / scale + 0.05 * torch.randn(ref[..., :9].shape, generator=g))
@@ -67,7 +70,10 @@ def test_fullsize_forward_backward_against_c_oracle(hip_device, scene300k):
                   ("colors", "v_colors"), ("viewmats", "v_viewmats")]:
         refg = torch.from_numpy(r[ck])
         sc = float(refg.abs().max())
-        close(t[k].grad, refg, 2e-3, 1e-4 * sc, f"grad[{k}]", flip_frac=1e-3, flip_atol=0.05 * sc)
+        # observed: no entry beyond rtol 1e-3 + 1e-4 max, largest error 9e-5 of the maximum.  A flipped blend decision
+        # moves the gradients of the splats of ONE pixel by at most that pixel's share: allowed for 1e-5 of the entries
+        # (3 - 27 of them) up to 5e-3 of the maximum
+        close(t[k].grad, refg, 1e-3, 1e-4 * sc, f"grad[{k}]", flip_frac=1e-5, flip_atol=5e-3 * sc)
 
 
 def test_fullsize_lists_are_sorted_and_complete(hip_device, scene300k):
@@ -113,6 +119,61 @@ def test_fp16_attribute_storage(hip_device, scene300k):
     p = psnr(img.cpu(), ref.cpu())
     print(f"fp16-attribute render vs fp32: {p:.1f} dB")
     assert p > 40.0
+
+
+def test_800k_fp32_twin_of_config5_against_c_oracle(hip_device, capsys):
+    """BASELINE config #5's scene (800 000 Gaussians, seed 1) in fp32 through rasterization(), forward AND backward,
+    against the C oracle (the 800 k scene had only been compared with itself).  Same criteria as the
+    300 k test: radii, image within 3e-5 of the range except blend flips inside the derived one-step bound, |dPSNR| <=
+    1e-4 dB, gradients rtol 1e-3 + 1e-4 of the maximum."""
+    import bench as B
+    from oracle import gsplat_cpu as Cc
+    from oracle import render_torch as R
+    from mobgs_amd.rendering import rasterization
+    from mobgs_amd.synth import SynthCamera, dynamic_extras, gaussian_cloud
+    ns, nd = 533_000, 267_000
+    scam = SynthCamera()
+    sp, dp = gaussian_cloud(ns, scam, 1), gaussian_cloud(nd, scam, 2)
+    dx = dynamic_extras(dp["xyz"], 1)
+    ctrl = R.hermite(dx["control_xyz"], torch.tensor(scam.time), dx["current_control_num"]) * 1e-2
+    tfp = scam.time - dx["trbf_center"]
+    s = {"means": torch.cat([sp["xyz"], ctrl]), "quats": torch.cat([sp["rotation"], dp["rotation"] + tfp * dx["omega"]]),
+         "scales": torch.exp(torch.cat([sp["scaling"], dp["scaling"]])),
+         "opacities": torch.sigmoid(torch.cat([sp["opacity"], dp["opacity"]])).squeeze(-1),
+         "colors": torch.cat([torch.cat([sp["features_dc"], 0 * sp["features_t"]], 1),
+                              torch.cat([dp["features_dc"], tfp * dp["features_t"]], 1)]),
+         "viewmats": torch.eye(4)[None], "Ks": scam.K[None]}
+    names = ["means", "quats", "scales", "opacities", "colors", "viewmats"]
+    g = torch.Generator().manual_seed(101)
+    v_img = torch.randn(1, H, W, 10, generator=g)
+    t = {k: v.to(hip_device).clone().requires_grad_(k in names) for k, v in s.items()}
+    img, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], t["viewmats"],
+                                 t["Ks"], W, H, packed=False, backgrounds=torch.zeros(1, 9, device=hip_device),
+                                 render_mode="RGB+ED")
+    (img * v_img.to(hip_device)).sum().backward()
+    r = Cc.rasterization_fwd_bwd(*(s[k].numpy() for k in ["means", "quats", "scales", "opacities", "colors",
+                                                          "viewmats", "Ks"]), W, H,
+                                 backgrounds=np.zeros((1, 9), np.float32), render_mode="RGB+ED",
+                                 v_render=v_img.numpy())
+    rad = meta["radii"].cpu().numpy().astype(np.int64)
+    differ = rad != r["radii"].astype(np.int64)
+    ref = torch.from_numpy(r["render"])
+    scale = float(ref.abs().max())
+    vis_depth = meta["depths"][meta["radii"] > 0]
+    nflip, worst = close_image_with_blend_flips(img, ref, r["alphas"], float(s["colors"].abs().max()),
+                                                float(vis_depth.max() - vis_depth.min()), 3e-5 * scale,
+                                                "image (800k)", flip_frac=2e-4, n_colour_channels=9)
+    with capsys.disabled():
+        print(f"\n[800k fp32] radii differing: {int(differ.sum())} of {rad.size}; image: {nflip} of {ref.numel()} "
+              f"elements beyond 3e-5 x range (largest {worst:.2e}); visible {int((rad > 0).sum())}")
+    assert differ.sum() == 0, int(differ.sum())
+    target = (ref[..., :9] / scale + 0.05 * torch.randn(ref[..., :9].shape, generator=g))
+    assert abs(psnr(img[..., :9].cpu() / scale, target) - psnr(ref[..., :9] / scale, target)) <= 1e-4
+    for k, ck in [("means", "v_means"), ("quats", "v_quats"), ("scales", "v_scales"), ("opacities", "v_opacities"),
+                  ("colors", "v_colors"), ("viewmats", "v_viewmats")]:
+        refg = torch.from_numpy(r[ck])
+        sc = float(refg.abs().max())
+        close(t[k].grad, refg, 1e-3, 1e-4 * sc, f"grad[{k}] (800k)", flip_frac=1e-5, flip_atol=5e-3 * sc)
 
 
 def test_800k_gaussians_config5_scale(hip_device):

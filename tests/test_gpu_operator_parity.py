@@ -34,6 +34,9 @@ def _close(a, b, rtol, atol, what, flip_frac=0.0, flip_atol=0.0):
     bad = err > tol
     nbad = int(bad.sum())
     msg = f"{what}: {nbad}/{bad.numel()} off, max err {err.max():.3e} (ref max {b.abs().max():.3e})"
+    from helpers import observe
+    observe(what, nbad, bad.numel(), float(err.max()) if err.numel() else 0.0, flip_frac, flip_atol,
+            float(b.abs().max()) if b.numel() else 0.0)
     assert nbad <= flip_frac * bad.numel(), msg
     if nbad:
         assert float(err.max()) <= flip_atol, msg
@@ -450,7 +453,9 @@ def test_two_cameras_forward_backward(hip_device):
     for key in ("radii", "tiles_per_gauss", "flatten_ids", "isect_offsets", "isect_ids"):
         assert torch.equal(out[2][key].cpu(), ref[2][key]), key
     scale = float(ref[0].abs().max())
-    close_ = lambda a, b, what, tol: _close(a, b, 0, tol, what, flip_frac=2e-3, flip_atol=scale / 50)  # noqa: E731
+    # one blend step: 2 w (|c| + |pixel|), w <= 1/255 (was a flat scale / 50); observed: no flipped element
+    step = 2.0 * (1.001 / 255.0) * 2.0 * scale
+    close_ = lambda a, b, what, tol: _close(a, b, 0, tol, what, flip_frac=5e-4, flip_atol=step)  # noqa: E731
     close_(out[0], ref[0], "image", 3e-5 * scale)
     close_(out[1], ref[1], "alpha", 3e-5)
     for k in names:

@@ -33,7 +33,10 @@ def test_render_matches_reference_fixture(hip_device, name):
             assert np.array_equal(got.numpy(), ref), k
         elif k in IMG_KEYS:
             scale = max(1.0, float(np.abs(ref).max()))
-            close(got, ref, 0, 3e-5 * scale, f"out[{k}]", flip_frac=2e-3, flip_atol=scale / 100)
+            # a flipped blend decision moves a feature / alpha / depth pixel by <= 2 w (|c| + |pixel|), w <= 1/255:
+            # ~ scale / 64 before the decoder (whose two layers are contractions here); observed: no flip at all in
+            # the three fixtures, allowed for 2e-4 of the elements (<= 6 of them)
+            close(got, ref, 0, 3e-5 * scale, f"out[{k}]", flip_frac=2e-4, flip_atol=scale / 100)
         else:
             close(got, ref, 2e-5, 1e-5 * max(1.0, float(np.abs(ref).max())), f"out[{k}]")
     # north-star criterion: PSNR of the decoded image against a common target within 1e-4 dB
@@ -63,16 +66,22 @@ def test_get_flow_matches_reference_fixture(hip_device):
     with torch.no_grad():
         e2m, m2e, img, alpha = get_flow(cam, stat, dyn, None, bg,
                                         delta_exposure=torch.tensor(float(fx["opt"][0]), device=hip_device))
+    from helpers import flow_flip_bound
     for got, key, atol in ((e2m, "out_exp2mid", 2e-4), (m2e, "out_mid2exp", 2e-4), (img, "out_latent_img", 3e-5),
                            (alpha, "out_latent_alpha", 3e-5)):
         assert tuple(got.shape) == fx[key].shape
-        close(got, fx[key], 1e-5, atol, key, flip_frac=2e-3, flip_atol=1.0)
+        # flow maps: one blend step of the splatted flow (derived, helpers.flow_flip_bound: ~0.05 px here, was a flat
+        # 1.0 px); decoded image / coverage: 2 / 255.  Observed: no flipped element; allowed for 2e-4 of them
+        fb = flow_flip_bound(fx[key]) if "2" in key.split("_")[1] else 2.0 / 255.0
+        close(got, fx[key], 1e-5, atol, key, flip_frac=2e-4, flip_atol=fb)
     cam_b = PinholeCamera(cam.image_width, cam.image_height, cam.K, torch.from_numpy(fx["in_w2c_b"]), cam.time,
                           cam.max_time, device=hip_device)
     with torch.no_grad():
         f2d, fimg = get_flow_static(cam, cam_b, cam, stat, dyn, None, bg)
     close(f2d, fx["out_static_flow_2d"], 1e-5, 2e-4, "static flow_2d")
-    close(fimg, fx["out_static_flow_img"], 1e-5, 2e-4, "static flow image", flip_frac=2e-3, flip_atol=1.0)
+    fmax = float(np.abs(fx["out_static_flow_2d"]).max())
+    close(fimg, fx["out_static_flow_img"], 1e-5, 2e-4, "static flow image", flip_frac=2e-4,
+          flip_atol=2.0 * (1.001 / 255.0) * 2.0 * fmax)  # one blend step of a splatted per-splat flow <= fmax
 
 
 def test_get_flow_gradients_match_reference_fixture(hip_device):
@@ -82,7 +91,7 @@ def test_get_flow_gradients_match_reference_fixture(hip_device):
     from mobgs_amd.gaussian_renderer import get_flow, get_flow_static
     _flow_grad_check(load("get_flow_grad"), lambda cam, s, d, bg, dl: get_flow(cam, s, d, None, bg, delta_exposure=dl),
                      lambda a, b, c, s, d, bg: get_flow_static(a, b, c, s, d, None, bg), hip_device, 2e-3, 2e-4,
-                     flip={"flip_frac": 2e-3, "flip_atol": 1.0})
+                     flip={"flip_frac": 2e-4, "flip_atol": "derived"})
 
 
 def test_hermite_wrapper_matches_reference_fixture(hip_device):
