@@ -303,8 +303,11 @@ class DeblurWorkload:
         from mobgs_amd.deblur import render_blurry_batch
         from mobgs_amd.ops import LeafGradSink
         self.bucket.zero()
+        # N > 1: units dealt by cost (the two train-mode mid frames weigh 2.3 latent renders), one asynchronous image
+        # all-reduce per view behind the next view's renders
+        multi = self.shard.world > 1
         pred, mids = render_blurry_batch(self.cams, self.stat, self.dyn, self.bg, self.shard, blce=self.blce,
-                                         n_sub=self.K)
+                                         n_sub=self.K, weighted=multi, overlap=multi)
         outs, cots = [pred], [self.v_pred]
         for v, pkg in mids.items():  # depth / mask terms live on the rank that rendered the mid frame
             outs += [pkg["depth"], pkg["d_alpha"]]
@@ -569,7 +572,8 @@ def main():
         workload = (f"K=9 deblur iteration (train.py:430-541): {args.views} blurry views x (1 train-mode mid render + 8 "
                     f"latent renders, BLCE cameras + exposure offsets), seesaw-synth {args.ns} static + {args.nd} "
                     f"dynamic Gaussians, {args.width}x{args.height}, fwd+bwd, {n_units} (view, sub-frame) units "
-                    f"sharded over {world} ranks; value counts all {n_units} renders of a step")
+                    f"dealt by cost over {world} ranks (planned loads {[round(x, 1) for x in shard.iteration_plan(args.views, 9, False)['loads']]} "
+                    f"latent-render units), per-view asynchronous image all-reduce; value counts all {n_units} renders of a step")
 
     # workload statistics for the roofline: intersections I and pixels P of this rank's render (taken above)
     ms_per_step = dt / args.steps * 1e3

@@ -112,9 +112,10 @@ class DeblurTrainer:
     def iteration(self) -> torch.Tensor:
         shard, stat, dyn, blce, bucket, ns = self.shard, self.stat, self.dyn, self.blce, self.bucket, self.ns
         bucket.zero()
+        multi = shard.world > 1  # units of both families dealt by cost, per-view asynchronous image exchange
         pred, mids = render_blurry_batch(self.cams, stat, dyn, self.bg, shard, blce=blce, n_sub=K,
-                                         rank_local_terms=True)
-        flows = get_flow_batch(self.cams, stat, dyn, self.bg, shard, n_sub=K)
+                                         rank_local_terms=True, weighted=multi, with_flows=True, overlap=multi)
+        flows = get_flow_batch(self.cams, stat, dyn, self.bg, shard, n_sub=K, weighted=multi)
         photo = photometric_loss(pred, self.gt, self.opt.lambda_dssim)
         loss = shard.replicated_term(photo)                      # every rank forms it on the replicated prediction
         for v, pkg in mids.items():                              # the rank that rendered the mid frame

@@ -21,7 +21,7 @@ from .gaussian_renderer import render
 
 
 def get_flow_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor, shard: SubframeShard, n_sub: int = 9,
-                   exposure_max_delta: float = 1.0, pipe=None) -> Dict[Tuple[int, int], tuple]:
+                   exposure_max_delta: float = 1.0, pipe=None, weighted: bool = False) -> Dict[Tuple[int, int], tuple]:
     """The n_sub get_flow() calls per view of train.py:564-579 (exposure offsets exposure_max_delta * (k - half) /
     half), for the (view, sub-frame) units THIS rank owns: {(view, k): (exp2mid, mid2exp, latent_img, latent_alpha)}.
     The units are dealt round-robin like the renders, rotated by the number of render units so that the ranks the
@@ -32,7 +32,8 @@ def get_flow_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor, shar
     rank_local_terms=True)) and terms all ranks form identically on it go through shard.replicated_term()."""
     from .gaussian_renderer import get_flow_many
     V, half = len(cams), n_sub // 2
-    mine = shard.view_units(V, n_sub, offset=V * n_sub)
+    mine = shard.planned_units(shard.iteration_plan(V, n_sub)["flow"], n_sub) if weighted \
+        else shard.view_units(V, n_sub, offset=V * n_sub)
     out: Dict[Tuple[int, int], tuple] = {}
     for v in sorted({v for v, _ in mine}):
         ks = [k for vv, k in mine if vv == v]
@@ -44,8 +45,9 @@ def get_flow_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor, shar
 
 def render_blurry_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor, shard: SubframeShard,
                         blce=None, n_sub: int = 9, exposures: Optional[Sequence[Sequence]] = None,
-                        train_mode_mid: bool = True, pipe=None,
-                        rank_local_terms: bool = False) -> Tuple[torch.Tensor, Dict[int, dict]]:
+                        train_mode_mid: bool = True, pipe=None, rank_local_terms: bool = False,
+                        weighted: bool = False, with_flows: bool = False,
+                        overlap: bool = False) -> Tuple[torch.Tensor, Dict[int, dict]]:
     """cams: the batch's view cameras.  blce: a mobgs_amd.blce.blceKernel (None: every sub-frame uses the view's own
     camera and `exposures[v][k]` / 0 as exposure offset -- the reference before `start_warp`).
     -> (pred [V,3,H,W] on every rank, {view index: result dict of its mid (train-mode) render} for the mid frames this
@@ -53,7 +55,11 @@ def render_blurry_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor,
     exchange then all-reduces its backward too."""
     V = len(cams)
     half = n_sub // 2
-    mine = shard.view_units(V, n_sub)
+    # weighted: units dealt by cost (SubframeShard.iteration_plan: the train-mode mid frames weigh 2.3 latent renders;
+    # with_flows: the get_flow units of the same iteration -- get_flow_batch(weighted=True) -- share the pool);
+    # overlap: one asynchronous image all-reduce per view instead of one for the batch
+    mine = shard.planned_units(shard.iteration_plan(V, n_sub, with_flows)["render"], n_sub) if weighted \
+        else shard.view_units(V, n_sub)
     warped: Dict[int, Tuple[List, torch.Tensor]] = {}
     mids: Dict[int, dict] = {}
     like = None
@@ -88,7 +94,8 @@ def render_blurry_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor,
     if not mine:  # more ranks than units: contribute zeros (image size from the first camera)
         c = cams[0]
         like = torch.zeros(3, int(c.image_height), int(c.image_width), device=bg_color.device)
-        return shard.render_blurry_views(unit, V, n_sub, like=like, reduce_backward=rank_local_terms), mids
+        return shard.render_blurry_views(unit, V, n_sub, like=like, reduce_backward=rank_local_terms, units=mine,
+                                         overlap=overlap), mids
     # the image shape is known after the first unit; render_blurry_views only needs `like` for views this rank has no
     # unit of, so hand it a lazily-filled zero image
     first_v, first_k = mine[0]
@@ -99,4 +106,4 @@ def render_blurry_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor,
         return cache.pop((v, k)) if (v, k) in cache else unit(v, k)
 
     return shard.render_blurry_views(unit_cached, V, n_sub, like=torch.zeros_like(img0),
-                                     reduce_backward=rank_local_terms), mids
+                                     reduce_backward=rank_local_terms, units=mine, overlap=overlap), mids

@@ -83,6 +83,38 @@ class _SumAcrossRanks(torch.autograd.Function):
         return g, None, None, None
 
 
+class _SumAcrossRanksAsync(torch.autograd.Function):
+    """_SumAcrossRanks whose forward only STARTS the all-reduce (async_op=True: it runs on the backend's own stream,
+    ordered behind the work already enqueued on the current stream) and returns before it has finished; the caller
+    awaits `ctx_work` (apply_async) before anything reads the result.  The input is a temporary: reduced in place."""
+
+    @staticmethod
+    def forward(ctx, x, group, reduce_backward, box):
+        ctx.group, ctx.reduce_backward = group, bool(reduce_backward)
+        y = x.detach()
+        if not y.is_contiguous():
+            y = y.clone(memory_format=torch.contiguous_format)
+            box.append(_all_reduce_sum(y, group, async_op=True))
+            return y
+        box.append(_all_reduce_sum(y, group, async_op=True))
+        ctx.mark_dirty(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.reduce_backward:
+            g = g.contiguous().clone()
+            _all_reduce_sum(g, ctx.group)
+        return g, None, None, None
+
+    @staticmethod
+    def apply_async(x, group, reduce_backward):
+        box: list = []
+        if x.is_leaf:            # mark_dirty needs a non-leaf (a partial sum of renders is one; a zero image is not)
+            x = x.clone()
+        return _SumAcrossRanksAsync.apply(x, group, reduce_backward, box), (box[0] if box else None)
+
+
 class FlatGradients:
     """One persistent flat buffer per parameter dtype (fp32; fp16 for attribute arrays stored in half precision);
     every parameter's .grad is a VIEW of it, so backward passes accumulate in place and the exchange is an in-place
@@ -165,6 +197,47 @@ class SubframeShard:
         global unit index is view * n_sub + sub-frame."""
         return [(u // n_sub, u % n_sub) for u in self.units(n_views * n_sub, offset)]
 
+    # ---- cost-weighted partition (round 3) ----------------------------------------------------------
+    # Relative device time of the unit kinds of one training iteration at the headline size (bench.py, 1 x MI355X): a
+    # lean latent render 1.05 ms = 1; the train-mode mid render (static / dynamic layers, depth, alphas) 2.4 ms; one
+    # get_flow() call 1.8 ms.
+    COST_LATENT, COST_MID, COST_FLOW = 1.0, 2.3, 1.7
+
+    @staticmethod
+    def plan(costs: Sequence[float], world: int, carry: Optional[Sequence[float]] = None):
+        """Longest-processing-time-first assignment of units with the given costs to `world` ranks: heaviest unit first,
+        each to the rank with the smallest load so far (ties: lowest rank).  `carry`: loads the ranks already have from
+        another family of units.  Deterministic and a pure function of its arguments -- every rank computes the same
+        plan.  -> (owner per unit, load per rank)."""
+        loads = [float(x) for x in carry] if carry is not None else [0.0] * world
+        owners = [0] * len(costs)
+        for u in sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i)):
+            r = min(range(world), key=lambda q: (loads[q], q))
+            owners[u] = r
+            loads[r] += float(costs[u])
+        return owners, loads
+
+    def iteration_plan(self, n_views: int, n_sub: int, with_flows: bool = True):
+        """The (view, sub-frame) render units and get_flow units of one training iteration, dealt by cost: the mid
+        frames (train mode, 2.3 x a latent render) first, then the flow calls, then the latent renders, each to the
+        least-loaded rank.  Round-robin (view_units) ignores that the two mid frames cost 2.3 units: 18 render units on
+        8 ranks give loads of 3.3 / 3.0 against 2.58 on average (78 %); by cost the heaviest rank has 3.0 (86 %), and
+        with the 18 flow units in the same pool 7.0 against 6.4 (91 %; 97 % on 4 ranks).
+        -> {"render": owners [V * K], "flow": owners [V * K] or None, "loads": per rank}."""
+        half = n_sub // 2
+        rc = [self.COST_MID if (u % n_sub) == half else self.COST_LATENT for u in range(n_views * n_sub)]
+        if with_flows:
+            fc = [self.COST_FLOW] * (n_views * n_sub)
+            owners, loads = self.plan(rc + fc, self.world)
+            return {"render": owners[:len(rc)], "flow": owners[len(rc):], "loads": loads}
+        owners, loads = self.plan(rc, self.world)
+        return {"render": owners, "flow": None, "loads": loads}
+
+    def planned_units(self, owners: Sequence[int], n_sub: int) -> List[Tuple[int, int]]:
+        """This rank's (view, sub-frame) pairs under a plan, in view order (a view's partial sum is complete as early
+        as possible: its image exchange can start while the next view renders)."""
+        return [(u // n_sub, u % n_sub) for u, r in enumerate(owners) if r == self.rank]
+
     def replicated_term(self, loss_term: torch.Tensor) -> torch.Tensor:
         """Scale a loss term that EVERY rank forms identically from replicated data (not through the all-reduced
         prediction, not on the outputs of one rank's render) so that the gradient SUM counts it once."""
@@ -203,15 +276,45 @@ class SubframeShard:
         return self.mean_of_subframes(local, n_units)
 
     def render_blurry_views(self, render_unit: Callable[[int, int], torch.Tensor], n_views: int, n_sub: int,
-                            like: torch.Tensor, reduce_backward: bool = False) -> torch.Tensor:
+                            like: torch.Tensor, reduce_backward: bool = False,
+                            units: Optional[Sequence[Tuple[int, int]]] = None, overlap: bool = False) -> torch.Tensor:
         """Batch form (train.py:430-541 loops over the views of the batch): render_unit(view, k) -> [3,H,W].
-        ONE all-reduce for the whole batch: returns the blurry predictions [n_views,3,H,W] on every rank."""
+        Returns the blurry predictions [n_views,3,H,W] on every rank.  `units`: this rank's (view, sub-frame) pairs
+        (default: the round-robin view_units).  overlap=False: ONE all-reduce for the whole batch.  overlap=True: one
+        all-reduce PER VIEW, issued asynchronously as soon as this rank has rendered its last unit of the view -- the
+        exchange of view v then runs on RCCL's stream while view v + 1 renders (8.2 MB per view at 1352x1014; VERDICT r2
+        item 6b); the results are awaited together before the predictions are used."""
+        mine = list(units) if units is not None else self.view_units(n_views, n_sub)
         sums: List[Optional[torch.Tensor]] = [None] * n_views
-        for v, k in self.view_units(n_views, n_sub):
-            img = render_unit(v, k)
-            sums[v] = img if sums[v] is None else sums[v] + img
-        local = torch.stack([s if s is not None else torch.zeros_like(like) for s in sums])
-        return self.mean_of_subframes(local, n_sub, donate=True, reduce_backward=reduce_backward)
+        if not (overlap and self.world > 1):
+            for v, k in mine:
+                img = render_unit(v, k)
+                sums[v] = img if sums[v] is None else sums[v] + img
+            local = torch.stack([s if s is not None else torch.zeros_like(like) for s in sums])
+            return self.mean_of_subframes(local, n_sub, donate=True, reduce_backward=reduce_backward)
+        totals: List[Optional[torch.Tensor]] = [None] * n_views
+        works = []
+
+        def exchange(v):
+            part = sums[v] if sums[v] is not None else torch.zeros_like(like)
+            if reduce_backward and not part.requires_grad:
+                part = part.detach().requires_grad_(True).clone()
+            tot, work = _SumAcrossRanksAsync.apply_async(part, self.group, reduce_backward)
+            totals[v] = tot
+            works.append(work)
+
+        # collectives of one group are matched by ISSUE ORDER: every rank starts the exchanges in view order (a rank
+        # with no unit of a view joins its exchange as soon as the earlier views are done)
+        for v in range(n_views):
+            for vv, k in mine:
+                if vv == v:
+                    img = render_unit(v, k)
+                    sums[v] = img if sums[v] is None else sums[v] + img
+            exchange(v)
+        for w in works:
+            if w is not None:
+                w.wait()
+        return torch.stack(totals) / n_sub + 1e-10
 
     # ---- backward exchange --------------------------------------------------------------------------
     def all_reduce_gradients(self, params, async_op: bool = False):
@@ -222,7 +325,19 @@ class SubframeShard:
             params.gather_stray()
             if self.world == 1:
                 return None
-            works = [_all_reduce_sum(b, self.group, async_op) for b in params.buffers()]
+            works = []
+            for b in params.buffers():
+                if b.dtype == torch.float16:
+                    # a half-precision SUM over 8 ranks saturates / loses the small terms: reduce the half slice in
+                    # fp32 and round once.  (The trainable fp16-storage mode keeps no half
+                    # gradients at all: GaussianParams(attr_dtype=float16, master=True) accumulates them in fp32.)
+                    w32 = b.float()
+                    _all_reduce_sum(w32, self.group)
+                    b.copy_(w32)
+                    if async_op:
+                        works.append(_DoneWork())
+                else:
+                    works.append(_all_reduce_sum(b, self.group, async_op))
             return works if async_op else None
         if self.world == 1:
             return None

@@ -370,3 +370,79 @@ def test_donated_strided_input_is_still_reduced():
     want = (torch.arange(24, dtype=torch.float32).reshape(4, 6) * 3).t()
     for rank, y in outs:
         assert torch.equal(y, want.contiguous()), f"rank {rank}"
+
+
+# ---- round 3: cost-weighted plan, per-view asynchronous image exchange, eight ranks ---------------------------------
+
+def test_cost_weighted_plan_is_a_partition_and_beats_round_robin():
+    for world in (1, 2, 3, 4, 8):
+        shards = [SubframeShard(world, r) for r in range(world)]
+        plan = shards[0].iteration_plan(2, 9, with_flows=True)
+        for fam in ("render", "flow"):
+            got = sorted(p for sh in shards for p in sh.planned_units(plan[fam], 9))
+            assert got == [(v, k) for v in range(2) for k in range(9)], (world, fam)
+        assert all(sh.iteration_plan(2, 9, True) == plan for sh in shards), "every rank must compute the same plan"
+    sh = SubframeShard(8, 0)
+    loads = sh.iteration_plan(2, 9, with_flows=False)["loads"]
+    rr = [0.0] * 8
+    for u in range(18):
+        rr[u % 8] += sh.COST_MID if u % 9 == 4 else sh.COST_LATENT
+    assert max(loads) < max(rr) and sum(loads) / 8 / max(loads) > 0.85, (loads, rr)   # 85.8 % against 78 %
+    both = sh.iteration_plan(2, 9, with_flows=True)["loads"]
+    assert sum(both) / 8 / max(both) > 0.9, both                                       # 91 % with the flow units
+    owners = sh.iteration_plan(2, 9, False)["render"]
+    assert owners[4] != owners[13], "the two mid frames must land on different ranks"
+
+
+def _planned_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        w = torch.randn(2, requires_grad=True)
+        b = torch.randn(1, requires_grad=True)
+        shard = SubframeShard()
+        bucket = FlatGradients([w, b], extra={f"view{v}": 3 * NSPLAT for v in range(V)})
+        bucket.zero()
+        mids = {}
+
+        def unit(v, k):
+            if k == K // 2:
+                mids[v] = _toy_mid_outputs((w, b), v)
+                mids[v][1].retain_grad()
+            return _toy_unit((w, b), v, k)
+
+        mine = shard.planned_units(shard.iteration_plan(V, K, with_flows=False)["render"], K)
+        pred = shard.render_blurry_views(unit, V, K, like=torch.zeros(3, 6, 8), units=mine, overlap=True)
+        loss = _iteration_loss(pred, mids, (w, b), shard)
+        loss.backward()
+        for v, (_, m2d) in mids.items():
+            shard.put_densification_stats(bucket, f"view{v}", m2d.grad, torch.full((NSPLAT,), 3 + v, dtype=torch.int32))
+        shard.all_reduce_gradients(bucket)
+        stats = [shard.get_densification_stats(bucket, f"view{v}") for v in range(V)]
+        q.put(_plain((rank, pred.detach(), w.grad.clone(), b.grad.clone(), [s[0].clone() for s in stats], len(mine))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_planned_units_with_overlapped_exchange_match_single_process(world):
+    """Eight (and three) gloo ranks, units dealt by cost, one asynchronous image all-reduce per view: predictions,
+    parameter gradients and densification statistics equal the single-process iteration."""
+    ref_pred, ref_w, ref_b, ref_m2d = _single_iteration()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_planned_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    outs = [_tensors(q.get(timeout=300)) for _ in ps]
+    for p in ps:
+        p.join(timeout=120)
+    assert sum(o[5] for o in outs) == V * K
+    for rank, pred, gw, gb, m2d, _ in outs:
+        assert torch.allclose(pred, ref_pred, atol=1e-6), f"rank {rank}"
+        assert torch.allclose(gw, ref_w, atol=1e-6), f"rank {rank}: {gw} vs {ref_w}"
+        assert torch.allclose(gb, ref_b, atol=1e-6), f"rank {rank}"
+        for v in range(V):
+            assert torch.allclose(m2d[v], ref_m2d[v], atol=1e-7), f"rank {rank} view {v}"
