@@ -67,7 +67,8 @@ def build_scene(dev, ns, nd, width, height, seed=0):
 
 
 def leaves(stat, dyn):
-    ls = list(stat.leaf_tensors(False).values()) + list(dyn.leaf_tensors(True).values())
+    """The tensors an optimiser / flat gradient buffer holds: the leaves, or the fp32 masters of half-stored ones."""
+    ls = list(stat.trainable_tensors(False).values()) + list(dyn.trainable_tensors(True).values())
     return ls + list(dyn.rgbdecoder.parameters())
 
 

@@ -87,3 +87,28 @@ class GaussianParams:
         names = ["_scaling", "_rotation", "_opacity", "_features_dc", "_features_t"]
         names += ["control_xyz", "_omega"] if dynamic else ["_xyz"]
         return {k: getattr(self, k) for k in names}
+
+    # ---- training with half-precision attribute storage (BASELINE config #5) ---------------------------------------
+    def enable_fp32_masters(self, dynamic: bool) -> Dict[str, torch.Tensor]:
+        """For attr_dtype=float16 sets that are TRAINED: every half-stored leaf gets an fp32 master copy (`leaf.master`,
+        a leaf tensor requiring grad).  The render kernels keep reading the halves; inside an ops.LeafGradSink the prep
+        backward accumulates the attribute gradients in fp32 straight into `master.grad` (no half gradient exists, so
+        nothing saturates at 65504 and a cross-rank SUM runs in fp32: distributed.FlatGradients over trainable_tensors());
+        the optimiser steps the masters (fp32 Adam moments) and sync_half() rounds them into the stored halves -- the
+        usual master-weight scheme, with the fp16 copy being what the kernels stream.  -> trainable_tensors(dynamic)."""
+        for k, t in self.leaf_tensors(dynamic).items():
+            if t.dtype == torch.float16 and getattr(t, "master", None) is None:
+                t.master = t.detach().float().requires_grad_(True)
+        return self.trainable_tensors(dynamic)
+
+    def trainable_tensors(self, dynamic: bool) -> Dict[str, torch.Tensor]:
+        """What an optimiser / a flat gradient buffer should hold: the fp32 master of a half-stored leaf, else the leaf."""
+        return {k: (getattr(t, "master", None) if getattr(t, "master", None) is not None else t)
+                for k, t in self.leaf_tensors(dynamic).items()}
+
+    @torch.no_grad()
+    def sync_half(self, dynamic: bool) -> None:
+        """After optimizer.step(): round the masters into the stored halves (one multi-tensor copy)."""
+        pairs = [(t, t.master) for t in self.leaf_tensors(dynamic).values() if getattr(t, "master", None) is not None]
+        if pairs:
+            torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])

@@ -54,8 +54,15 @@ class LeafGradSink:
         return all(a is b and a.is_leaf and a.requires_grad for a, b in zip(inputs, self.leaves))
 
     @staticmethod
+    def _target(p):
+        """Where a leaf's gradient lives: its fp32 master when it is a half-stored attribute with one
+        (GaussianParams.enable_fp32_masters), else the leaf itself."""
+        m = getattr(p, "master", None)
+        return p if m is None else m
+
+    @staticmethod
     def _addable(p) -> bool:
-        g = p.grad
+        g = LeafGradSink._target(p).grad
         return g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape \
             and not g.requires_grad
 
@@ -63,7 +70,7 @@ class LeafGradSink:
         global _active_sink
         self._prev, _active_sink = _active_sink, self
         if all(self._addable(p) for p in self.leaves):
-            self.buffers = {name: p.grad for p, name in zip(self.leaves, _LEAF_NAMES)}
+            self.buffers = {name: self._target(p).grad for p, name in zip(self.leaves, _LEAF_NAMES)}
             self.direct = True
         if self.dec_leaves and all(self._addable(p) for p in self.dec_leaves):
             self.dec_buffers = [p.grad for p in self.dec_leaves]
@@ -96,7 +103,8 @@ class LeafGradSink:
         if self.buffers is not None and not self.direct:
             for p, name in zip(self.leaves, _LEAF_NAMES):
                 g = self.buffers[name].view_as(p)
-                if g.dtype != p.dtype:  # fp16 attribute storage: accumulated in fp32, handed over in the leaf's dtype
+                p = self._target(p)     # a half-stored leaf with an fp32 master: the gradient stays fp32, on the master
+                if g.dtype != p.dtype:  # fp16 attribute storage without masters: handed over in the leaf's dtype
                     g = g.to(p.dtype)
                 if p.grad is None:
                     p.grad = g

@@ -106,6 +106,8 @@ def test_config5_800k_k9_half_attributes(hip_device, capsys):
     W, H = 1352, 1014
     scam, cam, s16, d16 = _scene(dev, 533_000, 267_000, W, H, torch.float16, seed=1)
     _, _, s32, d32 = _scene(dev, 533_000, 267_000, W, H, torch.float32, seed=1)
+    s16.enable_fp32_masters(False)   # the trainable form of half storage: fp32 masters hold the gradients
+    d16.enable_fp32_masters(True)
     bg = torch.zeros(9, device=dev)
     with torch.no_grad():
         img16 = render(cam, s16, d16, None, bg)["render"]
@@ -121,8 +123,71 @@ def test_config5_800k_k9_half_attributes(hip_device, capsys):
     pred = wl.step()
     assert _lib.attr_conversions == before
     assert torch.isfinite(pred).all()
-    assert wl.bucket.flat_half.numel() > 0 and wl.bucket.attached()
+    # every gradient of the iteration -- attribute gradients included -- lives in the fp32 flat buffer (what a
+    # multi-GPU run all-reduces); no half gradient buffer exists
+    assert wl.bucket.flat_half.numel() == 0 and wl.bucket.attached()
     for b in wl.bucket.buffers():
-        assert torch.isfinite(b.float()).all()
-    assert float(wl.bucket.flat_half.float().abs().max()) > 0
+        assert b.dtype == torch.float32 and torch.isfinite(b).all()
+    assert float(s16._scaling.master.grad.abs().max()) > 0 and s16._scaling.grad is None
     assert int((wl.mids[0]["radii"] > 0).sum()) > 700_000
+
+
+def test_fp16_storage_training_tracks_fp32(hip_device, capsys):
+    """config #5 must be TRAINABLE.  Half-stored attributes with fp32 masters
+    (GaussianParams.enable_fp32_masters): the kernels stream the halves, ops.LeafGradSink accumulates the attribute
+    gradients in fp32 straight into the masters' .grad (no half gradient anywhere: nothing can saturate at 65504),
+    Adam keeps fp32 moments and sync_half() rounds the masters into the stored halves.  200 Adam steps on a synthetic
+    scene: the loss and the PSNR against the target follow the all-fp32 run."""
+    from mobgs_amd.gaussian_renderer import render
+    from mobgs_amd.ops import LeafGradSink
+    dev = hip_device
+    W, H, ns, nd = 256, 192, 6000, 3000
+    bg = torch.zeros(9, device=dev)
+    # target: the same cloud with shifted colours / opacities
+    _, cam, ts, td = _scene(dev, ns, nd, W, H, torch.float32, seed=3)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(11)
+        for pc in (ts, td):
+            pc._features_dc.add_(0.5 * torch.randn(pc._features_dc.shape, generator=g).to(dev))
+            pc._opacity.add_(0.5 * torch.randn(pc._opacity.shape, generator=g).to(dev))
+        target = render(cam, ts, td, None, bg)["render"].clamp(0, 1)
+
+    def run(dtype):
+        _, _, stat, dyn = _scene(dev, ns, nd, W, H, dtype, seed=3)
+        if dtype == torch.float16:
+            params = list(stat.enable_fp32_masters(False).values()) + list(dyn.enable_fp32_masters(True).values())
+        else:
+            params = list(stat.leaf_tensors(False).values()) + list(dyn.leaf_tensors(True).values())
+        assert all(p.dtype == torch.float32 and p.requires_grad for p in params)
+        opt = torch.optim.Adam(params, lr=5e-3, eps=1e-15)
+        losses = []
+        for it in range(200):
+            opt.zero_grad(set_to_none=True)
+            out = render(cam, stat, dyn, None, bg)
+            loss = (out["render"] - target).abs().mean()
+            with LeafGradSink(stat, dyn):
+                loss.backward()
+            if it in (0, 100, 199):
+                for p in params:
+                    assert p.grad is not None and p.grad.dtype == torch.float32 and bool(torch.isfinite(p.grad).all())
+                if dtype == torch.float16:
+                    assert all(getattr(stat, a).grad is None and getattr(dyn, a).grad is None for a in ATTRS), \
+                        "no half gradient may exist in master mode"
+            opt.step()
+            if dtype == torch.float16:
+                stat.sync_half(False)
+                dyn.sync_half(True)
+            losses.append(float(loss.detach()))
+        with torch.no_grad():
+            final = render(cam, stat, dyn, None, bg)["render"].clamp(0, 1)
+        return losses, psnr(final.cpu(), target.cpu()), stat
+
+    l32, p32, _ = run(torch.float32)
+    l16, p16, s16 = run(torch.float16)
+    with capsys.disabled():
+        print(f"\n[config #5 training] 200 Adam steps: fp32 loss {l32[0]:.4f} -> {l32[-1]:.4f} (PSNR {p32:.2f} dB); fp16 storage "
+              f"+ fp32 masters {l16[0]:.4f} -> {l16[-1]:.4f} (PSNR {p16:.2f} dB)")
+    assert s16._scaling.dtype == torch.float16 and torch.equal(s16._scaling, s16._scaling.master.half())
+    assert l32[-1] < 0.6 * l32[0], "the fp32 run must actually train"
+    assert abs(l16[-1] - l32[-1]) <= 0.03 * l32[-1] + 1e-4, (l16[-1], l32[-1])
+    assert abs(p16 - p32) <= 0.3, (p16, p32)
