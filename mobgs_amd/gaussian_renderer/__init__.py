@@ -128,6 +128,11 @@ def _times(cam, delta_exposure, dev):
             _time_cache[key] = v
         return v
 
+    st = getattr(cam, "static_times", None)
+    if st is not None and delta_exposure is None:
+        # a camera whose time lives in a device buffer [t, clamp(t, 0, 1)] that its owner rewrites in place
+        # (mobgs_amd.graphed: a captured HIP graph must read the time from memory, not from a constant baked at capture)
+        return st
     if delta_exposure is None:
         return const(cam.time)
     if torch.is_tensor(delta_exposure) and delta_exposure.is_cuda:

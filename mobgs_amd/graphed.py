@@ -1,0 +1,144 @@
+"""A whole render() training step -- forward, loss cotangents, backward -- captured ONCE into a HIP graph and replayed.
+
+The reference's own operating point is small: 512x288 images and ~30 k Gaussians at the start of training
+(/root/reference/scene/dataset_readers.py:1448-1460, arguments/stereo/seesaw.py:13-14), ~81 rasterizations per blurry
+view (train.py:441-584).  At that size a render() forward + backward is seventeen kernels of a few microseconds each and
+the step is bound by launch overheads.  `GraphedRenderStep` removes the host from the loop:
+
+    step = GraphedRenderStep(stat_pc, dyn_pc, width, height, K, bg)
+    out = step(w2c, time, v_render, v_depth)    # copies the camera / cotangents into static buffers, replays the graph
+    step.check()                                # after a synchronisation: did every arena fit?  (else: step.recapture())
+
+What makes render() capturable (rendering.StaticCapacity): the intersection counts are not read back mid-forward;
+count-sized buffers take their capacity, fixed from a warm-up frame times a margin; the kernels read true extents from
+device memory as they always did.  Arena overflow cannot be repaired inside a graph: the kernels then see empty lists,
+`check()` reports it from the pinned count rows and `recapture()` re-records with the larger sizes it has learnt.
+Outputs and gradients are bit-identical to the eager step (tests/test_gpu_graphed.py).
+Each replay OVERWRITES the leaves' .grad (static tensors owned by the graph) with the step's gradients.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import rendering as _R
+from .camera import PinholeCamera
+from .gaussian_renderer import render
+
+
+class _StaticCamera(PinholeCamera):
+    """A PinholeCamera whose pose and time live in ONE device buffer that is rewritten in place between replays
+    (one 184-byte host-to-device copy from a pinned staging row per call)."""
+
+    def __init__(self, width, height, K, device):
+        super().__init__(width, height, K, torch.eye(4), time=0.0, max_time=1, device=device)
+        self.buf = torch.zeros(46, dtype=torch.float32, device=device)
+        self.stage = torch.zeros(46, dtype=torch.float32, pin_memory=True)
+        self._w2c = self.buf[0:16].view(4, 4)
+        self.world_view_transform = self.buf[16:32].view(4, 4)   # the reference stores the transpose
+        self.ray_c2w = self.buf[32:44].view(3, 4)
+        self.static_times = self.buf[44:46]                       # [t, clamp(t, 0, 1)]
+        self.set(torch.eye(4), 0.0)
+
+    @torch.no_grad()
+    def make_state(self, w2c: torch.Tensor, time: float) -> torch.Tensor:
+        """The 46 floats of a pose + time, computed ONCE per training view with the same device arithmetic as
+        PinholeCamera.__init__ (torch.inverse on the device: a replay is then bit-identical to an eager render() with a
+        PinholeCamera of this pose).  Binding a cached state costs one 184-byte device copy per step."""
+        dev = self.buf.device
+        w = w2c.detach().to(dev, torch.float32)
+        t = float(time)
+        tt = torch.tensor([t, min(max(t, 0.0), 1.0)], dtype=torch.float32).to(dev)
+        return torch.cat([w.reshape(-1), w.t().reshape(-1), torch.inverse(w)[:3, :].reshape(-1), tt])
+
+    @torch.no_grad()
+    def bind(self, state: torch.Tensor, time: float = None):
+        self.buf.copy_(state)
+        if time is not None:
+            self.time = float(time)
+
+    def set(self, w2c: torch.Tensor, time: float):
+        self.bind(self.make_state(w2c, time), time)
+
+
+class GraphedRenderStep:
+    def __init__(self, stat_pc, dyn_pc, width: int, height: int, K: torch.Tensor, bg_color: torch.Tensor,
+                 margin: float = 1.5, warmup: int = 3):
+        self.stat, self.dyn = stat_pc, dyn_pc
+        self.dev = dyn_pc.get_xyz.device
+        self.W, self.H = int(width), int(height)
+        self.cam = _StaticCamera(self.W, self.H, K, self.dev)
+        self.bg = bg_color.to(self.dev)
+        self.v_render = torch.zeros(3, self.H, self.W, device=self.dev)
+        self.v_depth = torch.zeros(1, self.H, self.W, device=self.dev)
+        self.margin, self.warmup = float(margin), int(warmup)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.static: Optional[_R.StaticCapacity] = None
+        self.out: Dict[str, torch.Tensor] = {}
+        self.params = list(stat_pc.leaf_tensors(False).values()) + list(dyn_pc.leaf_tensors(True).values()) \
+            + list(dyn_pc.rgbdecoder.parameters())
+
+    # ---- eager body (also the warm-up that teaches the capacities) ---------------------------------------------
+    def _body(self):
+        out = render(self.cam, self.stat, self.dyn, None, self.bg)
+        torch.autograd.backward([out["render"], out["depth"]], [self.v_render, self.v_depth])
+        return out
+
+    def zero_grad(self):
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.zero_()
+
+    def capture(self, w2c: torch.Tensor, time: float):
+        """Warm up eagerly at this camera (sizes the arenas), then record forward + backward into one graph."""
+        self.cam.set(w2c, time)
+        prev_mt = torch.autograd.is_multithreading_enabled()
+        torch.autograd.set_multithreading_enabled(False)  # backward on the capturing thread / stream
+        try:
+            for p in self.params:
+                p.grad = None
+            for _ in range(self.warmup):
+                self._body()
+            torch.cuda.synchronize()
+            for p in self.params:
+                p.grad = None  # the capture allocates the .grad tensors from the graph's private pool
+            self.static = _R.StaticCapacity(self.margin)
+            self.graph = torch.cuda.CUDAGraph()
+            with self.static, torch.cuda.graph(self.graph):
+                out = self._body()
+            self.out = {"render": out["render"], "depth": out["depth"], "radii": out["radii"]}
+        finally:
+            torch.autograd.set_multithreading_enabled(prev_mt)
+        return self
+
+    def __call__(self, w2c: Optional[torch.Tensor] = None, time: Optional[float] = None,
+                 v_render: Optional[torch.Tensor] = None, v_depth: Optional[torch.Tensor] = None,
+                 state: Optional[torch.Tensor] = None):
+        """Replay at a new camera / time / cotangents (None: keep the previous ones; `state`: a camera_state() computed
+        once per training view -- the cheap way to change the camera every step).  The leaves' .grad tensors are
+        OVERWRITTEN with this step's gradients (the capture began with .grad = None, so the recorded backward assigns
+        rather than accumulates).  -> {"render", "depth", "radii"}: static tensors, overwritten by the next call."""
+        if self.graph is None:
+            self.capture(w2c if w2c is not None else torch.eye(4), time or 0.0)
+        if state is not None:      # a cached camera_state(): one small device copy
+            self.cam.bind(state)
+        elif w2c is not None or time is not None:
+            self.cam.set(w2c if w2c is not None else self.cam._w2c.clone(), self.cam.time if time is None else time)
+        if v_render is not None:
+            self.v_render.copy_(v_render)
+        if v_depth is not None:
+            self.v_depth.copy_(v_depth)
+        self.graph.replay()
+        return self.out
+
+    def camera_state(self, w2c: torch.Tensor, time: float) -> torch.Tensor:
+        return self.cam.make_state(w2c, time)
+
+    def check(self) -> bool:
+        """After a synchronisation: True when every arena of the replayed frames fitted."""
+        return self.static.check() if self.static is not None else True
+
+    def recapture(self, w2c: torch.Tensor, time: float):
+        self.graph, self.static = None, None
+        return self.capture(w2c, time)

@@ -244,6 +244,7 @@ class _PendingCounts:
         if n_box <= cap_box and n_isects <= cap_listed:
             tl._set_counts(n_box, n_isects, max_len, *self.arenas)
             _len_hint[key] = max_len
+            _last_counts[key] = (n_box, n_isects)
             last_stats.update(n_isects=n_isects, n_box=n_box, max_tile_len=max_len,
                               n_tiles=tl.C * tl.tile_w * tl.tile_h)
             return False
@@ -277,6 +278,67 @@ def _tuning_with_hint(key):
 
 
 _tuning_keepalive = []
+
+
+class StaticCapacity:
+    """Context: speculative binning WITHOUT the count read-back (round 3: HIP-graph capture of a whole render step).
+
+    Outside this context the host reads the frame's three counts {I_box, I_listed, longest list} mid-forward, to size
+    count-dependent views and to redo the binning when an arena overflowed -- a host read no graph can contain.  Inside,
+    every count-sized buffer takes its CAPACITY instead (the kernels read the true extents from device memory anyway:
+    tile offsets, keep-scan bases, a tile schedule padded with -1), the counts still land in a pinned row, and nobody
+    waits for them: `check()` -- after the work has completed -- tells whether any arena was too small (the kernels then
+    saw EMPTY lists and the frame's outputs are invalid: grow and redo / re-capture).  Capacities are fixed at entry:
+    the previous frame's counts of the same workload times `margin`."""
+
+    def __init__(self, margin: float = 1.5, max_calls: int = 64):
+        self.margin = float(margin)
+        self.rows = []   # (pinned row, owner tensor, cap_box, cap_listed, key)
+        self._prev = None
+        # landing rows of the calls issued inside the context, page-locked BEFORE anything is captured (a pinned
+        # allocation is not a legal call while a stream is capturing)
+        self.pool = torch.zeros(max_calls, 4, dtype=torch.int64, pin_memory=True)
+        self.pool_np = self.pool.numpy()
+
+    def take_row(self):
+        i = len(self.rows)
+        if i >= self.pool.shape[0]:
+            raise RuntimeError("StaticCapacity: more binning calls than landing rows (max_calls)")
+        return self.pool_np[i], self.pool.data_ptr() + 32 * i
+
+    def __enter__(self):
+        global _static
+        self._prev, _static = _static, self
+        return self
+
+    def __exit__(self, *exc):
+        global _static
+        _static = self._prev
+        return False
+
+    def caps(self, key, C, N):
+        box = max(_capacity.get(key, 0), 16 * (C * N) + 1024)
+        listed = max(_cap_listed.get(key, 0), box // 2)
+        seen_box, seen_listed = _last_counts.get(key, (0, 0))
+        if seen_box:
+            box = max(int(seen_box * self.margin) + 1024, 4096)
+            listed = max(int(seen_listed * self.margin) + 1024, 4096)
+        hint = int(_len_hint.get(key, 0) * self.margin)
+        return box, listed, hint
+
+    def check(self) -> bool:
+        """True when every binning call issued under this context fitted its arenas (call after a synchronisation)."""
+        ok = True
+        for row, _, cap_box, cap_listed, key in self.rows:
+            n_box, n_isects, max_len = (int(v) for v in row[:3])
+            _last_counts[key] = (max(n_box, _last_counts.get(key, (0, 0))[0]), max(n_isects, _last_counts.get(key, (0, 0))[1]))
+            _len_hint[key] = max(max_len, _len_hint.get(key, 0))
+            ok = ok and n_box <= cap_box and n_isects <= cap_listed
+        return ok
+
+
+_static = None
+_last_counts = {}  # workload key -> (I_box, I_listed) of the most recent resolved frame
 # True: the projection/binning call does not wait for the intersection counts (see TileLists); False: it does
 SPECULATIVE_BINNING = True
 _len_hint = {}  # workload key -> longest per-tile list of the previous frame (selects the sort variant)
@@ -806,26 +868,37 @@ class _ProjectAndBin(torch.autograd.Function):
             key = _workload_key(dev, C, N, width, height)
             cap_box = max(_capacity.get(key, 0), 16 * (C * N) + 1024)
             cap_listed = max(_cap_listed.get(key, 0), cap_box // 2)
-            row, slot, row_addr, owner = _stats_slots.take()
+            len_hint = _len_hint.get(key, 0)
+            if _static is not None:  # fixed capacities, no read-back (StaticCapacity)
+                cap_box, cap_listed, len_hint = _static.caps(key, C, N)
+                row, row_addr = _static.take_row()  # this call's own landing row (kept for the context's lifetime)
+                slot, owner = None, _static.pool
+            else:
+                row, slot, row_addr, owner = _stats_slots.take()
             seq = _stats_slots.next_seq()
             row[3] = 0
             rc, outs, tile_order, isect_ids, records = F.project_and_bin_speculative(
                 means, quats, scales, viewmats, Ks, opac, width, height, eps2d, near_plane, far_plane, radius_clip,
                 int(_tile_culling), bool(want_isect_ids), bool(TILE_SCHEDULE), pack, cap_box, cap_listed,
-                _len_hint.get(key, 0), row_addr, seq, tuning.address(), stream_int())
+                len_hint, row_addr, seq, tuning.address(), stream_int())
             radii, means2d, depths, conics, tiles_per_gauss, cum_tiles, tile_offsets, keep_scan, flatten_ids = outs
             tl.records = records
             event = None
-            if rc == 1:  # counts by asynchronous copy: wait on an event (0: poll the sequence word)
+            if rc == 1 and _static is None:  # counts by asynchronous copy: wait on an event (0: poll the sequence word)
                 event = torch.cuda.Event()
                 event.record()
             tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
             tl.cum_tiles, tl.keep_scan, tl.tile_offsets, tl.tile_order = cum_tiles, keep_scan, tile_offsets, tile_order
             tl.flatten_arena = flatten_ids
-            tl._pending = _PendingCounts(row, slot, event, (key, cap_box, cap_listed), (flatten_ids, isect_ids),
-                                         (means2d, radii, depths, conics, opac, tiles_per_gauss, width, height,
-                                          want_isect_ids), seq, owner)
-            _capacity[key], _cap_listed[key] = cap_box, cap_listed
+            if _static is not None:
+                _static.rows.append((row, owner, cap_box, cap_listed, key))
+                tl._pending = None
+                tl._set_counts(cap_box, cap_listed, len_hint, flatten_ids, isect_ids)
+            else:
+                tl._pending = _PendingCounts(row, slot, event, (key, cap_box, cap_listed), (flatten_ids, isect_ids),
+                                             (means2d, radii, depths, conics, opac, tiles_per_gauss, width, height,
+                                              want_isect_ids), seq, owner)
+                _capacity[key], _cap_listed[key] = cap_box, cap_listed
             ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics)
             ctx.dims = (width, height, eps2d)
             ctx.mark_non_differentiable(radii, tiles_per_gauss)
