@@ -36,6 +36,7 @@ from mobgs_amd.gaussian_renderer import render  # noqa: E402
 from mobgs_amd.helper_model import Sandwich  # noqa: E402
 from mobgs_amd.loss_utils import l1_loss, photometric_loss  # noqa: E402
 from mobgs_amd.ops import LeafGradSink  # noqa: E402
+from mobgs_amd.optim import fused_adam_step  # noqa: E402
 from mobgs_amd.synth import SynthCamera, dynamic_extras, gaussian_cloud  # noqa: E402
 from train_synth import Opt  # noqa: E402  (examples/ is on sys.path when run as a script or from the test)
 
@@ -137,9 +138,9 @@ class DeblurTrainer:
                 vis = radii > 0
                 stat.add_densification_stats(grad2d[:ns], vis[:ns], radii=radii[:ns])
                 dyn.add_densification_stats(grad2d[ns:], vis[ns:], radii=radii[ns:])
-        stat.optimizer.step()
-        dyn.optimizer.step()
-        blce.optimizer.step()
+        # train.py:790-807 steps the three optimisers one after the other (~26 one-tensor groups x 8 launches); here
+        # ONE launch performs the same Adam update on all of them (mobgs_amd.optim)
+        fused_adam_step([stat.optimizer, dyn.optimizer, blce.optimizer])
         return photo.detach()
 
 

@@ -507,6 +507,27 @@ int mobgs_ssim_l1_fwd(int C, int H, int W, const float* img1, const float* img2,
 int mobgs_ssim_l1_bwd(int C, int H, int W, const float* img1, const float* img2, const float* dmaps,
                       const float* scales, float* v_img1, void* stream);
 
+/* ---- K14: one Adam step over MANY parameter tensors in one launch ------------------------------------------------
+ * The reference steps three torch.optim.Adam optimisers per iteration (train.py:790-807: static Gaussians, dynamic
+ * Gaussians + decoder, blur kernel), ~14 one-tensor parameter groups each: ~26 groups x 8 multi-tensor launches =
+ * 3.3 ms of device time per iteration at 300 k Gaussians for 0.48 GB of traffic.  One launch over all of them:
+ *   m = m + (1 - beta1) (g - m);  v = beta2 v + (1 - beta2) g^2;  p = p - step_size * m / (sqrt(v) / bias2_sqrt + eps)
+ * (torch.optim.Adam, amsgrad = False, weight_decay = 0, maximize = False; step_size = lr / (1 - beta1^t) and
+ * bias2_sqrt = sqrt(1 - beta2^t) are computed by the caller per tensor, as torch does on the host; the betas arrive as
+ * doubles and 1 - beta is formed in double before it is rounded to fp32, again as torch does: 1.f - 0.999f is off by 1e-5).
+ * tensors_host: HOST array of n_tensors descriptors (device pointers, fp32, contiguous); n_tensors <= 64. */
+typedef struct MobgsAdamTensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+    float step_size;
+    float bias2_sqrt;
+} MobgsAdamTensor;
+int mobgs_adam_step(int n_tensors, const MobgsAdamTensor* tensors_host, double beta1, double beta2, double eps,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

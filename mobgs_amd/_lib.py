@@ -88,6 +88,7 @@ _SIGS = {
     "mobgs_deform_mlp_fwd": (c_int, [c_int] + [P] * 14 + [P]),
     "mobgs_blce_saved_floats": (c_size_t, []),
     "mobgs_blce_fwd": (c_int, [P, c_int, c_int, P, P, P, P, P, P]),
+    "mobgs_adam_step": (c_int, [c_int, P, ctypes.c_double, ctypes.c_double, ctypes.c_double, P]),
     "mobgs_blce_bwd": (c_int, [P, P, c_int, c_int, P, P, P, P, P]),
     "mobgs_deform_mlp_bwd_blocks": (c_int, [c_int]),
     "mobgs_deform_mlp_grad_floats": (c_size_t, []),

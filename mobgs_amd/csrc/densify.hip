@@ -148,9 +148,65 @@ split_children_kernel(int n_children, int first, int n_split, const float* __res
 
 }  // namespace mobgs
 
+// ---- one Adam step over up to 64 tensors (include/mobgs_hip.h K14) -------------------------------------------------
+struct AdamTable {
+    MobgsAdamTensor t[64];
+};
+// grid (blocks over the longest tensor, tensor): 16 bytes per lane and stream; tensors shorter than the grid exit at once
+__global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, float w1, float beta2, float w2, float eps) {
+    const MobgsAdamTensor T = tab.t[blockIdx.y];
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= T.n) return;
+    auto one = [&](float& p, float g, float& m, float& v) {
+        m = m + w1 * (g - m);                  // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * beta2 + w2 * g * g;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        const float denom = sqrtf(v) / T.bias2_sqrt + eps;
+        p = p - T.step_size * (m / denom);     // param.addcdiv_(exp_avg, denom, value = -step_size)
+    };
+    if (i0 + 4 <= T.n && ((((uintptr_t)T.param | (uintptr_t)T.grad | (uintptr_t)T.exp_avg | (uintptr_t)T.exp_avg_sq) & 15) == 0)) {
+        float4 p = *reinterpret_cast<float4*>(T.param + i0);
+        const float4 g = *reinterpret_cast<const float4*>(T.grad + i0);
+        float4 m = *reinterpret_cast<float4*>(T.exp_avg + i0);
+        float4 v = *reinterpret_cast<float4*>(T.exp_avg_sq + i0);
+        one(p.x, g.x, m.x, v.x);
+        one(p.y, g.y, m.y, v.y);
+        one(p.z, g.z, m.z, v.z);
+        one(p.w, g.w, m.w, v.w);
+        *reinterpret_cast<float4*>(T.param + i0) = p;
+        *reinterpret_cast<float4*>(T.exp_avg + i0) = m;
+        *reinterpret_cast<float4*>(T.exp_avg_sq + i0) = v;
+    } else {
+        for (int64_t i = i0; i < T.n && i < i0 + 4; ++i) one(T.param[i], T.grad[i], T.exp_avg[i], T.exp_avg_sq[i]);
+    }
+}
+
 using namespace mobgs;
 
 extern "C" {
+
+int mobgs_adam_step(int n_tensors, const MobgsAdamTensor* tensors_host, double beta1, double beta2, double eps,
+                    void* stream) {
+    if (n_tensors < 0 || n_tensors > 64 || (n_tensors > 0 && !tensors_host)) {
+        set_error("mobgs_adam_step: n_tensors = %d (0..64)", n_tensors);
+        return MOBGS_E_INVALID;
+    }
+    if (n_tensors == 0) return MOBGS_OK;
+    AdamTable tab;
+    int64_t longest = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        tab.t[i] = tensors_host[i];
+        if (!tab.t[i].param || !tab.t[i].grad || !tab.t[i].exp_avg || !tab.t[i].exp_avg_sq || tab.t[i].n < 0) {
+            set_error("mobgs_adam_step: tensor %d has a NULL pointer or a negative size", i);
+            return MOBGS_E_INVALID;
+        }
+        longest = tab.t[i].n > longest ? tab.t[i].n : longest;
+    }
+    if (longest == 0) return MOBGS_OK;
+    const int64_t blocks = (longest + 1023) / 1024;
+    hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)blocks, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream,
+                       tab, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps);
+    return check_launch("adam_step_kernel");
+}
 
 int mobgs_densify_stats(int n, const float* viewspace_grad, int grad_stride, const uint8_t* visible,
                         const int32_t* radii, float* xyz_gradient_accum, float* denom, float* max_radii2D,

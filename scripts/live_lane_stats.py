@@ -186,6 +186,36 @@ for name, live in (("alpha_only", passed), ("forward", live_fwd), ("backward", l
         "walk_steps_8x8_wave": int(q8.sum().item()),
         "independent_workers": workers(live, b4),
     }
+# ---- what the forward block walk actually visits: the conservative per-block masks of block_reach_mask16 (linear
+# ---- lower bound of sigma over the block + margin), cut at the block's last live entry, against the exact live blocks
+def lin_masks():
+    thr = torch.log(255.0 * op)
+    thr = thr + 0.05 + 0.02 * thr
+    ok_op = (op * 255.0 >= 1.0)
+    m = torch.zeros(I, 16, dtype=torch.bool, device=dev)
+    for by in range(4):
+        for bx in range(4):
+            cx = (tx * 16).float() + 2.0 + 4 * bx
+            cy = (ty * 16).float() + 2.0 + 4 * by
+            dx, dy = m2[:, 0] - cx, m2[:, 1] - cy
+            gx = con[:, 0] * dx + con[:, 1] * dy
+            gy = con[:, 1] * dx + con[:, 2] * dy
+            lb = 0.5 * (dx * gx + dy * gy) - 1.5 * (gx.abs() + gy.abs())
+            m[:, 4 * by + bx] = (lb <= thr) & ok_op
+    return m
+
+
+ml = lin_masks()
+b4f = block_any(live_fwd, 4, 4).reshape(-1, 16)
+pos_in_tile = torch.arange(I, device=dev) - offs[tile_of]
+last_live = torch.full((nt, 16), -1, dtype=torch.long, device=dev)
+idx = pos_in_tile[:, None].expand(-1, 16).clone()
+idx[~b4f] = -1
+last_live.scatter_reduce_(0, tile_of[:, None].expand(-1, 16), idx, reduce="amax", include_self=True)
+visited = ml & (pos_in_tile[:, None] <= last_live[tile_of])
+out["forward_block_walk"] = {"exact_live_pairs": int(b4f.sum().item()), "linear_bound_pairs": int(ml.sum().item()),
+                             "visited_pairs(bound, cut at the block's last live entry)": int(visited.sum().item()),
+                             "workers": workers(live_fwd, visited)["16x(4x4)"]}
 print(json.dumps(out, indent=1))
 if args.out:
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
