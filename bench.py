@@ -539,6 +539,16 @@ def main():
                 fdt, _ = timed(fw.step, args.flow_steps, 2, world, dist)
                 flows[name] = round(fdt / args.flow_steps * 1e3, 3)
             flows["zero_weight_note"] = "cotangents exactly zero: lambda_flow_loss = 0 (arguments/stereo/seesaw.py)"
+            # what the same nine calls cost when the caller does not ask for gradients at all -- the one-line change
+            # INTEGRATION.md suggests for configurations with lambda_flow_loss = 0 (autograd cannot know the weight is 0)
+            from mobgs_amd.gaussian_renderer import get_flow_many
+            fw = FlowWorkload(dev, stat, dyn, cam, args.width, args.height, True)
+
+            def fwd_only():
+                with torch.no_grad():
+                    get_flow_many(fw.cam, fw.stat, fw.dyn, None, fw.bg, fw.deltas)
+            fdt, _ = timed(fwd_only, args.flow_steps, 2, world, dist)
+            flows["ms_per_view_no_grad"] = round(fdt / args.flow_steps * 1e3, 3)
         if args.train_steps > 0:
             sys.path.insert(0, os.path.join(ROOT, "examples"))
             import train_deblur_synth as TD

@@ -419,8 +419,7 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     # dynamic-only coverage (:477-490: a rasterization of the dynamic splats alone with a ones colour): a
     # class-restricted walk over the exposure-time lists of the whole set -- the same image without projecting,
     # binning and sorting the dynamic third a second time; sum_i w_i + T_final * bg = (1 - T) + T * bg
-    a_dyn = sp_exp.class_alpha(Ns, 2)
-    latent_alpha = a_dyn + (1.0 - a_dyn) * bg[0]
+    latent_alpha = sp_exp.class_alpha(Ns, 2, background=bg1[:, :1])
     e2m = (sp_mid.means2d - sp_exp.means2d).squeeze(0)
     # the exposure-time lists are walked ONCE for the 9 colour features and the 2 flow channels (the reference: one
     # rasterization each, :436-452 and :461-476; channels accumulate independently, so the images are identical)
@@ -461,8 +460,10 @@ def get_flow_many(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_expos
         img = _R.rasterize_to_pixels(mid.means2d, mid.conics, cols, mid.opacities, mid.radii, mid.tl, W, H)[0]
         # split, not slices: its backward is ONE concatenation of the 2-channel cotangents instead of a zero image, a
         # strided copy and an add per call
-        for o, part in zip(grp, img.split(2, dim=-1)):
-            o[1] = o[1][0] + part
+        # one broadcast add of the pixel grid for the whole group (was one add per call); the maps are then views
+        tot = img.unflatten(-1, (len(grp), 2)) + grp[0][1][0][:, :, None, :]
+        for o, part in zip(grp, tot.unbind(-2)):
+            o[1] = part
     return [tuple(o) for o in outs]
 
 
@@ -470,8 +471,7 @@ def _flow_at_mid(cam, mid, Ns, dyn_pc, bg_color, W, H):
     """get_flow(delta_exposure = 0) from the shared mid-exposure state: [exp2mid, mid2exp, latent_img, latent_alpha]."""
     bg1 = _bg9(bg_color)
     w1, w2 = _decoder_weights(dyn_pc)
-    a_dyn = mid.class_alpha(Ns, 2)
-    latent_alpha = a_dyn + (1.0 - a_dyn) * bg1[0][0]
+    latent_alpha = mid.class_alpha(Ns, 2, background=bg1[:, :1])
     img10, alphas = mid.composite(mid.flow_cols, bg1)
     pix = _pixel_grid(cam, W, H, img10)
     latent_img, _ = decode(img10, alphas, _rays_of(cam), w1, w2, False)

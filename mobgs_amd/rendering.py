@@ -549,7 +549,7 @@ class _RasterizeClassAlpha(torch.autograd.Function):
     mobgs_raster_class_fwd/bwd with one channel; -> alphas [C,H,W]."""
 
     @staticmethod
-    def forward(ctx, means2d, conics, opacities, radii, tl: TileLists, width, height, Ns, class_sel):
+    def forward(ctx, means2d, conics, opacities, radii, tl: TileLists, width, height, Ns, class_sel, background=None):
         lib = _lib_()
         C, N = radii.shape
         dev = means2d.device
@@ -560,6 +560,9 @@ class _RasterizeClassAlpha(torch.autograd.Function):
         check(lib.mobgs_pack_records(C, N, 1, ptr(means2d), ptr(conics), ptr(ones), 0, ptr(opacities),
                                      1 if opacities.dim() == 2 else 0, None, ptr(radii), ptr(records), stream()),
               "mobgs_pack_records")
+        # background [C,1] (optional): the ones-colour render (1 - T) + T * bg -- what get_flow() calls latent_alpha,
+        # /root/reference/gaussian_renderer/__init__.py:477-490 -- leaves the kernel directly (no rsub / mul / add glue)
+        bg = f32c(background).reshape(C, 1) if background is not None else None
         render = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
         alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
         last = torch.empty(C, height, width, dtype=torch.int32, device=dev)
@@ -567,37 +570,40 @@ class _RasterizeClassAlpha(torch.autograd.Function):
         while True:
             if reach.numel() < tl.flatten_arena.numel():  # lists rebuilt into a larger arena
                 reach = torch.empty(tl.flatten_arena.numel(), dtype=torch.uint8, device=dev)
-            check(lib.mobgs_raster_class_fwd(C, N, Ns, class_sel, 1, width, height, ptr(records), None,
+            check(lib.mobgs_raster_class_fwd(C, N, Ns, class_sel, 1, width, height, ptr(records), ptr(bg),
                                              ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_arena),
                                              ptr(render), ptr(alphas), ptr(last), ptr(reach), tuning.ref(), stream()),
                   "mobgs_raster_class_fwd")
             if tl.defer or not tl.resolve():
                 break
-        ctx.save_for_backward(records, radii, alphas, last, reach)
+        ctx.save_for_backward(records, radii, alphas, last, reach, bg)
         ctx.tl, ctx.arena = tl, tl.flatten_arena
         ctx.meta = (C, N, width, height, opacities.dim() == 2, Ns, class_sel)
-        return alphas
+        return alphas if bg is None else render.squeeze(-1)
 
     @staticmethod
     def backward(ctx, v_alphas):
         lib = _lib_()
         C, N, width, height, opac_per_camera, Ns, class_sel = ctx.meta
-        records, radii, alphas, last, reach = ctx.saved_tensors
+        records, radii, alphas, last, reach, bg = ctx.saved_tensors
         tl = ctx.tl
         dev = records.device
         if v_alphas is None:
-            return (None,) * 9
+            return (None,) * 10
         if tl.flatten_arena is not ctx.arena:  # lists rebuilt after this forward ran: recompute the masks
             reach = None
         stride = records.shape[1]
         rows = max(tl.n_isects, 1)
         slots = torch.zeros(rows + 1, stride, dtype=torch.float32, device=dev)  # last row: the any_record flag
         flag = ctypes.c_void_p(slots.data_ptr() + 4 * rows * stride)
-        v_render = _zero_image(C, height, width, dev)
-        check(lib.mobgs_raster_class_bwd(C, N, Ns, class_sel, 1, width, height, ptr(records), None, ptr(radii),
+        if bg is None:   # the cotangent belongs to the alpha output
+            v_render, v_a = _zero_image(C, height, width, dev), f32c(v_alphas)
+        else:            # ... to the 1-channel render output (background folded in by the kernel)
+            v_render, v_a = f32c(v_alphas).reshape(C, height, width, 1), None
+        check(lib.mobgs_raster_class_bwd(C, N, Ns, class_sel, 1, width, height, ptr(records), ptr(bg), ptr(radii),
                                          ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(tl.tile_offsets),
                                          ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas), ptr(last),
-                                         ptr(v_render), ptr(f32c(v_alphas)), ptr(slots), ptr(reach), flag,
+                                         ptr(v_render), ptr(v_a), ptr(slots), ptr(reach), flag,
                                          tuning.ref(), stream()), "mobgs_raster_class_bwd")
         v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
         v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
@@ -608,7 +614,7 @@ class _RasterizeClassAlpha(torch.autograd.Function):
               "mobgs_raster_bwd_reduce")
         if not opac_per_camera:
             v_opac = v_opac.sum(0) if C > 1 else v_opac[0]
-        return v_means2d, v_conics, v_opac, None, None, None, None, None, None
+        return v_means2d, v_conics, v_opac, None, None, None, None, None, None, None
 
 
 _const_cache = {}
@@ -1055,11 +1061,12 @@ class SharedProjection:
         return ([outs[2 * layer] if on[layer] else None for layer in range(3)],
                 [outs[2 * layer + 1] if on[layer] else None for layer in range(3)])
 
-    def class_alpha(self, Ns, class_sel):
+    def class_alpha(self, Ns, class_sel, background=None):
         """Coverage [C,H,W] of the first Ns splats (class_sel = 1) or of the rest (2) composited on their own, from
-        the lists of the whole set (see _RasterizeClassAlpha)."""
+        the lists of the whole set (see _RasterizeClassAlpha).  background [C,1] / [1]: the ones-colour render over
+        that background instead, (1 - T) + T * bg."""
         return _RasterizeClassAlpha.apply(self.means2d, self.conics, self.opacities, self.radii, self.tl, self.width,
-                                          self.height, int(Ns), int(class_sel))
+                                          self.height, int(Ns), int(class_sel), background)
 
     def meta(self):
         tl = self.tl
