@@ -2,7 +2,7 @@
 pat=$1; shift
 for v in "$@"; do
   n=kab_${v}_$RANDOM
-  MOBGS_LIB=$GRAFT_REPO_ROOT/scripts/ab/lib$v.so scripts/prof.sh $n python $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-cpu-torch --deblur-steps 0 --dynamic-steps 0 --flow-steps 0 > /dev/null 2>&1
+  MOBGS_LIB=$GRAFT_REPO_ROOT/scripts/ab/lib$v.so scripts/prof.sh $n python $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-cpu-torch --deblur-steps 0 --dynamic-steps 0 --flow-steps 0 --train-steps 0 --repeat-steps 0 --no-kernel-breakdown > /dev/null 2>&1
   python - $v $GRAFT_REPO_ROOT/gpurun_out/$n/kernel_stats.csv "$pat" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[2])):
