@@ -419,8 +419,12 @@ raster_fwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
             if (pre_g >= 0) {
                 m16 = all_reach ? 0xFFFFu
                                 : block_reach_mask16(pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, tx, ty);
-                if (FILTER && !cls.keeps(pre_g)) m16 = 0u;
-                if (isect_reach) {  // the backward pass walks quadrants: a quadrant is reachable iff one of its blocks is
+                const bool kept = !FILTER || cls.keeps(pre_g);
+                if (!kept) m16 = 0u;
+                // the backward pass walks quadrants: a quadrant is reachable iff one of its blocks is.  Class-restricted
+                // passes of one render share ONE byte array (each pass owns the bytes of its class): never touch the
+                // other class's entries
+                if (isect_reach && kept) {
                     const unsigned q = ((m16 & 0x0033u) ? 1u : 0u) | ((m16 & 0x00CCu) ? 2u : 0u) |
                                        ((m16 & 0x3300u) ? 4u : 0u) | ((m16 & 0xCC00u) ? 8u : 0u);
                     isect_reach[b + lane] = (uint8_t)q;

@@ -192,7 +192,15 @@ def main():
     ap.add_argument("--cases", type=int, default=120)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--large", action="store_true", help="full-size scenes with long per-tile lists (seconds per case)")
+    ap.add_argument("--no-heavy", action="store_true",
+                    help="one wave per tile on every grid (MobgsTuning.heavy_tile_len = 0): small images then run the "
+                         "block-walk compositors instead of the whole-workgroup path both formulations share")
+    ap.add_argument("--bwd-blocks", action="store_true", help="the experimental backward block walk")
     a = ap.parse_args()
+    if a.no_heavy:
+        rendering.tuning.heavy_tile_len = 0
+    if a.bwd_blocks:
+        rendering.tuning.bwd_block_walk = 1
     failed, _ = soak(a.cases, a.seed, torch.device("cuda:0"), large=a.large)
     sys.exit(1 if failed else 0)
 

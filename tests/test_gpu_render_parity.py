@@ -264,3 +264,37 @@ def test_leaf_grad_sink_equals_autograd_accumulation(hip_device):
     assert set(res[True]) == set(res[False])
     for k, g in res[False].items():
         close(res[True][k], g, 1e-6, 1e-7 * float(g.abs().max()) + 1e-12, f"grad[{k}]")
+
+
+def test_train_mode_render_block_walk_equals_quadrant_kernel(hip_device):
+    """Regression (round 3, found by scripts/soak_render.py): the static-only and dynamic-only passes of a train-mode
+    render() share ONE array of per-entry reach bytes, each pass owning the bytes of its class.  The class-restricted
+    block-walk forward used to write (zero) bytes for the OTHER class's entries too, wiping what the first pass had
+    left there -- the backward pass of that class then skipped everything and its gradients came out zero.  With the
+    block walk on and off, every output and every leaf gradient of a train-mode render must agree bit for bit."""
+    import bench as B
+    from mobgs_amd import rendering
+    from mobgs_amd.gaussian_renderer import render
+    dev = hip_device
+    W, H = 232, 120
+    res = {}
+    try:
+        for bw in (1, 0):
+            rendering.tuning.block_walk = bw
+            rendering.tuning.heavy_tile_len = 0   # one wave per tile: the block-walk path on this small grid
+            scam, cam, stat, dyn, _ = B.build_scene(dev, 300, 200, W, H, seed=5)
+            g = torch.Generator().manual_seed(3)
+            v3, v1 = torch.randn(3, H, W, generator=g).to(dev), torch.randn(1, H, W, generator=g).to(dev)
+            out = render(cam, stat, dyn, None, torch.zeros(9, device=dev), get_static=True, get_dynamic=True)
+            outs = [out[k] for k in ("render", "depth", "s_render", "d_render", "d_alpha", "s_alpha", "d_depth")]
+            cots = [v3, v1, v3, v3, v1, v1, v1]
+            torch.autograd.backward(outs, cots)
+            res[bw] = ([o.detach().clone() for o in outs], [p.grad.clone() for p in B.leaves(stat, dyn)])
+    finally:
+        rendering.tuning.block_walk = -1
+        rendering.tuning.heavy_tile_len = -1
+    for i, (a, b) in enumerate(zip(res[1][0], res[0][0])):
+        assert torch.equal(a, b), f"output {i}"
+    assert float(res[1][1][0].abs().max()) > 0, "the static set must receive a gradient"
+    for i, (a, b) in enumerate(zip(res[1][1], res[0][1])):
+        assert torch.equal(a, b), f"gradient of leaf {i}"
