@@ -1000,6 +1000,157 @@ __global__ void __launch_bounds__(THREADS) tile_sort_kernel(int n_tiles_total, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// huge lists (n > 16384; round 3): sorted chunks + parallel merge passes
+//
+// A list that does not fit the LDS radix sort used to be sorted in place in global memory by ONE workgroup (a barrier
+// after each of ~150 network steps): 7.8 ms for a 197 k-entry list, 67 % of the whole step on a scene with 70 % of the
+// splats in 2 % of the screen (scripts/heavy_tail.py 0.7 0.02).  Now every 16384-entry chunk of such a list is radix-
+// sorted in LDS by its own workgroup (the keys written back in place), and log2(#chunks) merge passes double the run
+// length: a pass cuts every list into 4096-key output blocks, a workgroup finds its block's two input ranges with a
+// merge-path search (two binary searches over global memory), stages them in LDS and its 256 threads merge 16 keys
+// each (their own merge-path split in LDS).  The 64-bit keys are unique (flat id in the low half), so the merge needs no
+// tie rule.  Passes ping-pong between the key arena and a scratch region that is dead after emit (owner / tile / rank
+// triples: 12 bytes per bounding-box intersection); the number of passes a frame needs is only known on the device
+// (a word holding the largest chunk count), so a fixed number is launched and the surplus ones return at once.
+// ---------------------------------------------------------------------------------------------------
+constexpr int MERGE_BLOCK = 4096;
+
+// number of elements the first d outputs of merge(A, B) take from A (keys unique)
+__device__ inline int merge_path(const uint64_t* __restrict__ A, int lenA, const uint64_t* __restrict__ B, int lenB, int d) {
+    int lo = max(0, d - lenB), hi = min(d, lenA);
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (A[mid] < B[d - 1 - mid]) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(1024) huge_chunk_sort_kernel(const int32_t* __restrict__ tile_offsets,
+                                                               uint64_t* __restrict__ sort_keys,
+                                                               const int32_t* __restrict__ long_ids,
+                                                               const int32_t* __restrict__ long_count,
+                                                               int32_t* __restrict__ max_chunks) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_keys[];
+    RadixShared& rs = *reinterpret_cast<RadixShared*>(lds_keys);
+    const int n_long = *long_count;
+    int base = 0;  // chunks of the huge lists before this one: work is dealt over ALL lists' chunks, not per list
+    for (int h = 0; h < n_long; ++h) {
+        const int t = long_ids[h];
+        const int s = tile_offsets[t], n = tile_offsets[t + 1] - s;
+        if (n <= RADIX_CAP) continue;
+        const int nch = (n + RADIX_CAP - 1) / RADIX_CAP;
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(max_chunks, nch);
+        const int first = ((int)blockIdx.x - base % (int)gridDim.x + (int)gridDim.x) % (int)gridDim.x;
+        base += nch;
+        for (int c = first; c < nch; c += gridDim.x) {
+            uint64_t* seg = sort_keys + s + (size_t)c * RADIX_CAP;
+            const int m = min(RADIX_CAP, n - c * RADIX_CAP);
+            const int cur = radix_sort_long(seg, m, rs);
+            if (cur >= 0) {
+                uint64_t k[RADIX_CAP / 1024];
+#pragma unroll
+                for (int r = 0; r < RADIX_CAP / 1024; ++r) {
+                    const int i = threadIdx.x + 1024 * r;
+                    k[r] = i < m ? seg[rs.perm[cur][i]] : 0ull;
+                }
+                __syncthreads();  // every gather done before the segment is overwritten
+#pragma unroll
+                for (int r = 0; r < RADIX_CAP / 1024; ++r) {
+                    const int i = threadIdx.x + 1024 * r;
+                    if (i < m) seg[i] = k[r];
+                }
+            } else {  // long runs of equal depth: the network on the full keys
+                __syncthreads();
+                for (int i = threadIdx.x; i < m; i += 1024) lds_keys[i] = seg[i];
+                __syncthreads();
+                bitonic_sort_lds<1024>(lds_keys, m);
+                for (int i = threadIdx.x; i < m; i += 1024) seg[i] = lds_keys[i];
+            }
+            __syncthreads();  // the LDS state is reused by the next chunk
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) huge_merge_kernel(int pass, const int32_t* __restrict__ tile_offsets,
+                                                         uint64_t* __restrict__ keys, uint64_t* __restrict__ tmp,
+                                                         const int32_t* __restrict__ long_ids,
+                                                         const int32_t* __restrict__ long_count,
+                                                         const int32_t* __restrict__ max_chunks) {
+    if ((1 << pass) >= *max_chunks) return;  // every huge list is one sorted run already
+    const uint64_t* src = (pass & 1) ? tmp : keys;
+    uint64_t* dst = (pass & 1) ? keys : tmp;
+    __shared__ uint64_t buf[MERGE_BLOCK];
+    __shared__ int sp[2];
+    const int R = RADIX_CAP << pass;  // run length entering this pass
+    const int n_long = *long_count;
+    int base = 0;  // output blocks of the huge lists before this one (work dealt over all of them)
+    for (int h = 0; h < n_long; ++h) {
+        const int t = long_ids[h];
+        const int s = tile_offsets[t], n = tile_offsets[t + 1] - s;
+        if (n <= RADIX_CAP) continue;
+        const int nblk = (n + MERGE_BLOCK - 1) / MERGE_BLOCK;
+        const int first = ((int)blockIdx.x - base % (int)gridDim.x + (int)gridDim.x) % (int)gridDim.x;
+        base += nblk;
+        for (int b = first; b < nblk; b += gridDim.x) {
+            const int o0 = b * MERGE_BLOCK, o1 = min(n, o0 + MERGE_BLOCK), cnt = o1 - o0;
+            const int a0 = (o0 / (2 * R)) * (2 * R);  // MERGE_BLOCK divides R: a block never straddles two pairs
+            const int a1 = min(n, a0 + R), b1 = min(n, a0 + 2 * R);
+            const int lenA = a1 - a0, lenB = b1 - a1;
+            const uint64_t* A = src + s + a0;
+            const uint64_t* B = src + s + a1;
+            if (threadIdx.x < 2) sp[threadIdx.x] = merge_path(A, lenA, B, lenB, (threadIdx.x ? o1 : o0) - a0);
+            __syncthreads();
+            const int ia0 = sp[0], ia1 = sp[1];
+            const int ib0 = (o0 - a0) - ia0;
+            const int na = ia1 - ia0, nb = cnt - na;
+            for (int i = threadIdx.x; i < cnt; i += 256) buf[i] = i < na ? A[ia0 + i] : B[ib0 + (i - na)];
+            __syncthreads();
+            const int dd = 16 * threadIdx.x;
+            if (dd < cnt) {
+                int ja = merge_path(buf, na, buf + na, nb, dd), jb = dd - ja;
+                uint64_t* out = dst + s + o0 + dd;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (dd + k < cnt) {
+                        const bool take_a = jb >= nb || (ja < na && buf[ja] < buf[na + jb]);
+                        out[k] = take_a ? buf[ja++] : buf[na + jb++];
+                    }
+                }
+            }
+            __syncthreads();  // buf / sp are reused by the next block
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) huge_finish_kernel(int tile_bits, int tiles_per_cam,
+                                                          const int32_t* __restrict__ tile_offsets,
+                                                          const uint64_t* __restrict__ keys,
+                                                          const uint64_t* __restrict__ tmp,
+                                                          int32_t* __restrict__ flatten_ids,
+                                                          uint64_t* __restrict__ isect_ids,
+                                                          const int32_t* __restrict__ long_ids,
+                                                          const int32_t* __restrict__ long_count,
+                                                          const int32_t* __restrict__ max_chunks) {
+    int passes = 0;
+    while ((1 << passes) < *max_chunks) ++passes;
+    const uint64_t* src = (passes & 1) ? tmp : keys;  // where the last pass left the lists
+    const int n_long = *long_count;
+    for (int h = 0; h < n_long; ++h) {
+        const int t = long_ids[h];
+        const int s = tile_offsets[t], n = tile_offsets[t + 1] - s;
+        if (n <= RADIX_CAP) continue;
+        const int cam = t / tiles_per_cam, tl = t - cam * tiles_per_cam;
+        const uint64_t hi_bits = (((uint64_t)cam << tile_bits) | (uint64_t)tl) << 32;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+            const uint64_t k = src[s + i];
+            flatten_ids[s + i] = (int32_t)(uint32_t)k;
+            if (isect_ids) isect_ids[s + i] = hi_bits | (k >> 32);
+        }
+    }
+}
+
 }  // namespace mobgs
 
 using namespace mobgs;
@@ -1169,9 +1320,28 @@ static int emit_sort(int C, int N, int tile_w, int tile_h, int capacity, int64_t
         hipLaunchKernelGGL(long_lists_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, nt, tile_offsets, small_cap,
                            long_ids, long_count);
         static_assert(sizeof(RadixShared) <= 160 * 1024, "radix sort state must fit the LDS of a CU");
+        // Lists beyond the LDS radix sort (> 16384 entries): chunks + merge passes (see huge_chunk_sort_kernel) when the
+        // previous frame's longest list says they are near -- and the dead (owner, tile, rank) triples of pass A, 12
+        // bytes per bounding-box intersection, can hold a second copy of the keys; otherwise such a list takes the old
+        // one-workgroup network in global memory (correct, slow; the next frame's hint then selects this path).
+        const int64_t listed_cap = stats_dev ? capacity_listed : n_isects;
+        const bool huge = max_tile_len > (3 * (int64_t)big_cap) / 4 && 8 * listed_cap <= 12 * (int64_t)capacity;
         hipLaunchKernelGGL(tile_sort_kernel<1024>, dim3(nt < 256 ? nt : 256), dim3(1024), sizeof(RadixShared), st,
                            nt, big_cap, tile_bits, tile_offsets, sort_keys, flatten_ids, isect_ids, tiles_per_cam,
-                           small_cap + 1, 0x7fffffff, long_ids, long_count);
+                           small_cap + 1, huge ? big_cap : 0x7fffffff, long_ids, long_count);
+        if (huge) {
+            int32_t* max_chunks = L.tickets + 2;  // zeroed with the frame's counters
+            uint64_t* tmp = reinterpret_cast<uint64_t*>(L.owner);
+            hipLaunchKernelGGL(huge_chunk_sort_kernel, dim3(256), dim3(1024), sizeof(RadixShared), st, tile_offsets,
+                               sort_keys, long_ids, long_count, max_chunks);
+            int passes = 0;  // enough for one list holding every listed intersection
+            while (((int64_t)big_cap << passes) < listed_cap) ++passes;
+            for (int p = 0; p < passes; ++p)
+                hipLaunchKernelGGL(huge_merge_kernel, dim3(256), dim3(256), 0, st, p, tile_offsets, sort_keys, tmp,
+                                   long_ids, long_count, max_chunks);
+            hipLaunchKernelGGL(huge_finish_kernel, dim3(256), dim3(256), 0, st, tile_bits, tiles_per_cam, tile_offsets,
+                               sort_keys, tmp, flatten_ids, isect_ids, long_ids, long_count, max_chunks);
+        }
     }
     return check_launch("isect_emit_sort");
 }

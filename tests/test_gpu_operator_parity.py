@@ -384,12 +384,14 @@ def test_tile_schedule_is_a_permutation_and_changes_nothing(hip_device):
 
 
 @pytest.mark.parametrize("n,w,h,scale,quant", [(3000, 48, 32, 8.0, 4), (12000, 64, 48, 3.0, 4),
-                                               (12000, 64, 48, 3.0, 2048), (40000, 64, 48, 3.0, 4)])
+                                               (12000, 64, 48, 3.0, 2048), (40000, 64, 48, 3.0, 4),
+                                               (70000, 64, 48, 3.0, 2048), (150000, 96, 64, 2.5, 65536)])
 def test_long_tile_lists_sort_exactly(hip_device, n, w, h, scale, quant):
     """Few tiles, many big splats: per-tile lists of several hundred to > 4096 entries exercise the multi-chunk
     LDS network, the radix sort of the 1024-thread variant -- with short runs of equal depth (quant 2048: tie fix-up
-    by flat id) and with runs of hundreds (quant 4: falls back to the network on the full keys) -- and (last case)
-    the global-memory fallback; order must be upstream's."""
+    by flat id) and with runs of hundreds (quant 4: falls back to the network on the full keys) -- and, from the
+    fourth case on, lists beyond the LDS sort (> 16384 entries; round 3: radix-sorted 16384-entry chunks + merge-path
+    passes, 3 to 10 chunks per list here, with and without long runs of equal depth); order must be upstream's."""
     from mobgs_amd import rendering
     from mobgs_amd.rendering import rasterization
     from oracle import gsplat_cpu as Cc
