@@ -278,7 +278,8 @@ def collect_pmc(args, I, P):
 class DeblurWorkload:
     """The blurry-view part of one training iteration for a batch of views (train.py:430-541), see module docstring."""
 
-    def __init__(self, dev, stat, dyn, scam, width, height, shard, n_views=2, n_sub=9, seed=100):
+    def __init__(self, dev, stat, dyn, scam, width, height, shard, n_views=2, n_sub=9, seed=100, batched=True):
+        self.batched = batched
         from mobgs_amd.blce import blceKernel
         from mobgs_amd.distributed import FlatGradients
         self.dev, self.stat, self.dyn, self.shard, self.V, self.K = dev, stat, dyn, shard, n_views, n_sub
@@ -308,7 +309,7 @@ class DeblurWorkload:
         # all-reduce per view behind the next view's renders
         multi = self.shard.world > 1
         pred, mids = render_blurry_batch(self.cams, self.stat, self.dyn, self.bg, self.shard, blce=self.blce,
-                                         n_sub=self.K, weighted=multi, overlap=multi)
+                                         n_sub=self.K, weighted=multi, overlap=multi, batched_latent=self.batched)
         outs, cots = [pred], [self.v_pred]
         for v, pkg in mids.items():  # depth / mask terms live on the rank that rendered the mid frame
             outs += [pkg["depth"], pkg["d_alpha"]]
@@ -521,7 +522,7 @@ def main():
                     "render() lean mode fwd+bwd incl. spline prep, decoder, camera gradient")
         if args.deblur_steps > 0:
             wl = DeblurWorkload(dev, stat, dyn, scam, args.width, args.height, shard, args.views)
-            ddt, dmed = timed(wl.step, args.deblur_steps, 4, world, dist)
+            ddt, dmed = timed(wl.step, args.deblur_steps, 10, world, dist)  # (the C = 8 batches size their arenas first)
             deblur = {"blurry_views_per_s": round(args.views * args.deblur_steps / ddt, 3),
                       "renders_per_s": round(n_units * args.deblur_steps / ddt, 2),
                       "ms_per_iteration": round(ddt / args.deblur_steps * 1e3, 3),
@@ -573,6 +574,8 @@ def main():
             del tr
     else:
         wl = DeblurWorkload(dev, stat, dyn, scam, args.width, args.height, shard, args.views)
+        for _ in range(min(args.prewarm, 8)):   # set-up: arena sizing of this rank's batches (see the N = 1 branch)
+            wl.step()
         profiler.enable(True)
         dt, med_ms = timed(wl.step, args.steps, args.warmup, world, dist)
         prof = profiler.summary()
@@ -603,7 +606,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "prewarm_steps": args.prewarm if world == 1 else 0,
+        "prewarm_steps": args.prewarm if world == 1 else min(args.prewarm, 8),
         "ms_per_step": round(ms_per_step, 4),
         "event_median_ms_per_step": round(med_ms, 4),
         "higher_is_better": True,

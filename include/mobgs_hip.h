@@ -71,6 +71,10 @@ extern "C" {
  *                      7..10-channel plain passes (partial gradient records of the blocks combined in an LDS accumulator
  *                      under an integer claim).  Measured 9 % SLOWER than the quadrant kernel on the benchmark lists
  *                       -- kept as the A/B arm; gradients agree to summation order.
+ *   geometry_per_camera  layout flag of mobgs_project_and_bin / _speculative (round 3), default 0: 1 = `means` is
+ *                      [C,N,3] and `quats` [C,N,4] -- every camera sees its OWN positions / rotations of the N splats
+ *                      (the K sub-frames of one blurry view: same Gaussians at K exposure times through K cameras,
+ *                      projected, binned, sorted and composited as ONE C = K batch); scales / opacities stay [N,..].
  *   reserved           must be 0 (or the struct zero-/minus-one-initialised). */
 typedef struct MobgsTuning {
     int32_t heavy_tile_len;
@@ -78,7 +82,8 @@ typedef struct MobgsTuning {
     int32_t quadrant_culling;
     int32_t block_walk;
     int32_t bwd_block_walk;
-    int32_t reserved[3];
+    int32_t geometry_per_camera;
+    int32_t reserved[2];
 } MobgsTuning;
 
 const char* mobgs_version(void);
@@ -108,6 +113,13 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
                       const int32_t* radii, const float* conics, const float* v_means2d,
                       const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
                       float* v_scales, float* v_viewmats, float* v_viewmats_partial, void* stream);
+/* The same with geometry_per_camera (see MobgsTuning): means / v_means [C,N,3] and quats / v_quats [C,N,4] when the
+ * flag is 1 (every camera's rows written once, nothing summed over cameras), v_scales [N,3] summed over cameras. */
+int mobgs_project_bwd_ex(int C, int N, int geometry_per_camera, const float* means, const float* quats,
+                         const float* scales, const float* viewmats, const float* Ks, int width, int height,
+                         float eps2d, const int32_t* radii, const float* conics, const float* v_means2d,
+                         const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
+                         float* v_scales, float* v_viewmats, float* v_viewmats_partial, void* stream);
 
 /* ---- K3a: intersection offsets (replaces isect_tiles pass 1 + cumsum + isect_offset_encode) ------------
  * in : tiles_per_gauss [C*N] (bounding-box tile counts from mobgs_project_fwd), means2d, radii, conics,

@@ -21,10 +21,13 @@ class MobgsTuning(ctypes.Structure):
     caller-side instance (mobgs_amd.rendering.tuning) is passed by pointer with every call that consults it."""
     _fields_ = [("heavy_tile_len", ctypes.c_int32), ("longest_list_hint", ctypes.c_int32),
                 ("quadrant_culling", ctypes.c_int32), ("block_walk", ctypes.c_int32),
-                ("bwd_block_walk", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+                ("bwd_block_walk", ctypes.c_int32), ("geometry_per_camera", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 2)]
 
-    def __init__(self, heavy_tile_len=-1, longest_list_hint=-1, quadrant_culling=-1, block_walk=-1, bwd_block_walk=-1):
-        super().__init__(heavy_tile_len, longest_list_hint, quadrant_culling, block_walk, bwd_block_walk)
+    def __init__(self, heavy_tile_len=-1, longest_list_hint=-1, quadrant_culling=-1, block_walk=-1, bwd_block_walk=-1,
+                 geometry_per_camera=0):
+        super().__init__(heavy_tile_len, longest_list_hint, quadrant_culling, block_walk, bwd_block_walk,
+                         geometry_per_camera)
 
     def ref(self):
         return ctypes.cast(ctypes.pointer(self), c_void_p)
@@ -43,6 +46,8 @@ _SIGS = {
     "mobgs_project_bwd_scratch_floats": (c_size_t, [c_int, c_int]),
     "mobgs_project_bwd": (c_int, [c_int, c_int, P, P, P, P, P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P,
                                   P, P]),
+    "mobgs_project_bwd_ex": (c_int, [c_int, c_int, c_int, P, P, P, P, P, c_int, c_int, c_float, P, P, P, P, P, P, P,
+                                     P, P, P, P]),
     "mobgs_isect_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "mobgs_keep_scan_len": (c_size_t, [c_int]),
     "mobgs_tile_order_len": (c_size_t, [c_int]),

@@ -173,7 +173,8 @@ struct PackArgs {
 int project_fwd_launch(int C, int N, const float* means, const float* quats, const float* scales, const float* viewmats,
                        const float* Ks, int width, int height, float eps2d, float near_plane, float far_plane,
                        float radius_clip, int32_t* radii, float* means2d, float* depths, float* conics,
-                       int32_t* tiles_per_gauss, int32_t* zero_ptr, size_t zero_n, PackArgs pack, void* stream);
+                       int32_t* tiles_per_gauss, int32_t* zero_ptr, size_t zero_n, PackArgs pack, void* stream,
+                       int geometry_per_camera = 0);
 // mobgs_isect_offsets; scratch_zeroed: the counters were cleared by the caller; stats_mirror: device-visible host
 // address that receives a copy of stats[0..2] (or NULL) and then, in word 3, stats_seq (when non-zero)
 int isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
@@ -193,6 +194,7 @@ inline int tuning_list_hint(const MobgsTuning* t) { return (t && t->longest_list
 inline int tuning_all_reach(const MobgsTuning* t) { return (t && t->quadrant_culling == 0) ? 1 : 0; }
 inline int tuning_block_walk(const MobgsTuning* t) { return (t && t->block_walk == 0) ? 0 : 1; }
 inline int tuning_bwd_block_walk(const MobgsTuning* t) { return (t && t->bwd_block_walk == 1) ? 1 : 0; }
+inline int tuning_geometry_per_camera(const MobgsTuning* t) { return (t && t->geometry_per_camera == 1) ? 1 : 0; }
 void isect_zeroed_region(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity, int32_t** ptr, size_t* count);
 
 // bit q = 2 * qy + qx set <=> the splat may reach alpha >= 1/255 at a pixel centre of the 8x8 quadrant (qx, qy) of

@@ -39,6 +39,7 @@ struct Api {
     decltype(&mobgs_decoder_bwd) decoder_bwd = nullptr;
     decltype(&mobgs_decoder_bwd_blocks) decoder_bwd_blocks = nullptr;
     decltype(&mobgs_project_bwd) project_bwd = nullptr;
+    decltype(&mobgs_project_bwd_ex) project_bwd_ex = nullptr;
     decltype(&mobgs_project_bwd_scratch_floats) project_bwd_scratch_floats = nullptr;
     decltype(&mobgs_project_and_bin_speculative) project_and_bin_speculative = nullptr;
     decltype(&mobgs_tile_order_len) tile_order_len = nullptr;
@@ -69,6 +70,7 @@ void bind(const std::unordered_map<std::string, uint64_t>& m) {
     take(m, "mobgs_decoder_bwd", api.decoder_bwd);
     take(m, "mobgs_decoder_bwd_blocks", api.decoder_bwd_blocks);
     take(m, "mobgs_project_bwd", api.project_bwd);
+    take(m, "mobgs_project_bwd_ex", api.project_bwd_ex);
     take(m, "mobgs_project_bwd_scratch_floats", api.project_bwd_scratch_floats);
     take(m, "mobgs_project_and_bin_speculative", api.project_and_bin_speculative);
     take(m, "mobgs_tile_order_len", api.tile_order_len);
@@ -298,14 +300,16 @@ std::tuple<Tensor, Tensor, Tensor, Tensor>
 project_bwd(int64_t width, int64_t height, double eps2d, const Tensor& means, const Tensor& quats, const Tensor& scales,
             const Tensor& viewmats, const Tensor& Ks, const Tensor& radii, const Tensor& conics, const OptT& v_means2d,
             const OptT& v_depths, const OptT& v_conics, int64_t stream) {
-    const int64_t C = viewmats.size(0), N = means.size(0);
+    // means [N,3] / quats [N,4] shared by the cameras, or [C,N,3] / [C,N,4] (MobgsTuning.geometry_per_camera)
+    const int64_t C = viewmats.size(0), N = means.size(-2);
+    const int per_cam = means.dim() == 3 ? 1 : 0;
     Tensor v_means = at::empty_like(means), v_quats = at::empty_like(quats), v_scales = at::empty_like(scales),
            v_viewmats = at::empty_like(viewmats);
     Tensor partial = at::empty({(int64_t)api.project_bwd_scratch_floats((int)C, (int)N)}, means.options());
     const OptT g2 = f32c(v_means2d), gd = f32c(v_depths), gc = f32c(v_conics);
-    check(api.project_bwd((int)C, (int)N, fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), (int)width,
-                          (int)height, (float)eps2d, ip(radii), fp(conics), fp(g2), fp(gd), fp(gc), fpw(v_means),
-                          fpw(v_quats), fpw(v_scales), fpw(v_viewmats), fpw(partial), sp(stream)),
+    check(api.project_bwd_ex((int)C, (int)N, per_cam, fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), (int)width,
+                             (int)height, (float)eps2d, ip(radii), fp(conics), fp(g2), fp(gd), fp(gc), fpw(v_means),
+                             fpw(v_quats), fpw(v_scales), fpw(v_viewmats), fpw(partial), sp(stream)),
           "mobgs_project_bwd");
     return {v_means, v_quats, v_scales, v_viewmats};
 }
@@ -321,7 +325,7 @@ project_and_bin_speculative(const Tensor& means, const Tensor& quats, const Tens
                             bool want_isect_ids, bool tile_schedule, const OptT& pack_colors, int64_t cap_box,
                             int64_t cap_listed, int64_t len_hint, int64_t stats_row, int64_t seq, int64_t tuning,
                             int64_t stream) {
-    const int64_t C = viewmats.size(0), N = means.size(0);
+    const int64_t C = viewmats.size(0), N = means.size(-2);  // means [N,3] or, with geometry_per_camera, [C,N,3]
     const int64_t tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, nt = C * tile_w * tile_h;
     const auto f = means.options().dtype(at::kFloat);
     const auto i32 = f.dtype(at::kInt);

@@ -24,8 +24,9 @@ int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, 
                           const MobgsTuning* tuning, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
-    int rc = mobgs_project_fwd(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
-                               radius_clip, radii, means2d, depths, conics, tiles_per_gauss, stream);
+    int rc = mobgs::project_fwd_launch(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                               radius_clip, radii, means2d, depths, conics, tiles_per_gauss, nullptr, 0, PackArgs{nullptr, nullptr, nullptr, 0, 0, 0, 0}, stream,
+                                       tuning_geometry_per_camera(tuning));
     if (rc != MOBGS_OK) return rc;
     rc = mobgs_isect_offsets(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d, radii,
                              conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order, /*capacity_listed (checked on the host)*/ 0,
@@ -89,10 +90,10 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
     }
     int rc = mobgs::project_fwd_launch(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
                                        radius_clip, radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, zero_n, pack,
-                                       stream);
+                                       stream, tuning_geometry_per_camera(tuning));
     if (rc != MOBGS_OK) return rc;
     // the binning variant follows the caller's expectation of the longest list (max_tile_len_hint)
-    MobgsTuning tn = tuning ? *tuning : MobgsTuning{-1, -1, -1, 0};
+    MobgsTuning tn = tuning ? *tuning : MobgsTuning{-1, -1, -1, -1, -1, 0, {0, 0}};
     tn.longest_list_hint = (int32_t)(max_tile_len_hint > 0x7fffffff ? 0x7fffffff : max_tile_len_hint);
     void* mirror = nullptr;
     if (hipHostGetDevicePointer(&mirror, stats_host_pinned, 0) != hipSuccess) {

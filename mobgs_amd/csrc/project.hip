@@ -123,9 +123,12 @@ project_fwd_kernel(int N, const float* __restrict__ means, const float* __restri
                    float far_plane, float radius_clip, int tile_w, int tile_h,
                    int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
                    float* __restrict__ conics, int32_t* __restrict__ tiles_per_gauss, int32_t* __restrict__ zero_ptr,
-                   unsigned zero_n, PackArgs pack) {
+                   unsigned zero_n, PackArgs pack, int geom_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
+    // geometry_per_camera: camera c reads rows [c N, c N + N) of means / quats (geom_stride = N), else the shared rows
+    means += (size_t)3 * c * geom_stride;
+    quats += (size_t)4 * c * geom_stride;
     // side job for the orchestrator: clear the binning counters (saves a memset launch on the critical path)
     if (zero_ptr && c == 0)
         for (unsigned z = (unsigned)i; z < zero_n; z += gridDim.x * blockDim.x) zero_ptr[z] = 0;
@@ -224,7 +227,7 @@ project_bwd_kernel(int N, const float* __restrict__ means, const float* __restri
                    const float* __restrict__ v_means2d, const float* __restrict__ v_depths,
                    const float* __restrict__ v_conics, float* __restrict__ v_means,
                    float* __restrict__ v_quats, float* __restrict__ v_scales,
-                   float* __restrict__ v_view_partial, int accumulate) {
+                   float* __restrict__ v_view_partial, int accumulate, int accumulate_scales) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     const Cam cam = load_cam(viewmats, Ks, c);
@@ -389,14 +392,17 @@ project_bwd_kernel(int N, const float* __restrict__ means, const float* __restri
             a.z += vq[2];
             a.w += vq[3];
             reinterpret_cast<float4*>(v_quats)[i] = a;
-            v_scales[3 * i] += vs[0];
-            v_scales[3 * i + 1] += vs[1];
-            v_scales[3 * i + 2] += vs[2];
         } else {
             v_means[3 * i] = vm[0];
             v_means[3 * i + 1] = vm[1];
             v_means[3 * i + 2] = vm[2];
             reinterpret_cast<float4*>(v_quats)[i] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+        }
+        if (accumulate_scales) {  // (geometry_per_camera: positions / rotations per camera, scales shared)
+            v_scales[3 * i] += vs[0];
+            v_scales[3 * i + 1] += vs[1];
+            v_scales[3 * i + 2] += vs[2];
+        } else {
             v_scales[3 * i] = vs[0];
             v_scales[3 * i + 1] = vs[1];
             v_scales[3 * i + 2] = vs[2];
@@ -466,7 +472,7 @@ int mobgs::project_fwd_launch(int C, int N, const float* means, const float* qua
                               const float* viewmats, const float* Ks, int width, int height, float eps2d,
                               float near_plane, float far_plane, float radius_clip, int32_t* radii, float* means2d,
                               float* depths, float* conics, int32_t* tiles_per_gauss, int32_t* zero_ptr, size_t zero_n,
-                              PackArgs pack, void* stream) {
+                              PackArgs pack, void* stream, int geometry_per_camera) {
     if (C <= 0 || N < 0 || width <= 0 || height <= 0) {
         set_error("mobgs_project_fwd: bad sizes C=%d N=%d W=%d H=%d", C, N, width, height);
         return MOBGS_E_INVALID;
@@ -479,7 +485,8 @@ int mobgs::project_fwd_launch(int C, int N, const float* means, const float* qua
     dim3 grid((N + 255) / 256, C);
     hipLaunchKernelGGL(project_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, means, quats, scales,
                        viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip, tile_w, tile_h,
-                       radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, (unsigned)zero_n, pack);
+                       radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, (unsigned)zero_n, pack,
+                       geometry_per_camera ? N : 0);
     return check_launch("project_fwd_kernel");
 }
 
@@ -492,6 +499,17 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
                       const int32_t* radii, const float* conics, const float* v_means2d, const float* v_depths,
                       const float* v_conics, float* v_means, float* v_quats, float* v_scales,
                       float* v_viewmats, float* v_viewmats_partial, void* stream) {
+    return mobgs_project_bwd_ex(C, N, 0, means, quats, scales, viewmats, Ks, width, height, eps2d, radii, conics,
+                                v_means2d, v_depths, v_conics, v_means, v_quats, v_scales, v_viewmats,
+                                v_viewmats_partial, stream);
+}
+
+int mobgs_project_bwd_ex(int C, int N, int geometry_per_camera, const float* means, const float* quats,
+                         const float* scales, const float* viewmats, const float* Ks, int width, int height,
+                         float eps2d, const int32_t* radii, const float* conics, const float* v_means2d,
+                         const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
+                         float* v_scales, float* v_viewmats, float* v_viewmats_partial, void* stream) {
+    const size_t gs = geometry_per_camera ? (size_t)N : 0;  // rows of means / quats (and their gradients) per camera
     if (C <= 0 || N < 0) {
         set_error("mobgs_project_bwd: bad sizes C=%d N=%d", C, N);
         return MOBGS_E_INVALID;
@@ -503,12 +521,14 @@ int mobgs_project_bwd(int C, int N, const float* means, const float* quats, cons
     const int nblocks = (N + 255) / 256;
     // one launch per camera so that the accumulation into v_means/v_quats/v_scales is race-free and ordered
     for (int c = 0; c < C; ++c) {
-        hipLaunchKernelGGL(project_bwd_kernel, dim3(nblocks, 1), dim3(256), 0, (hipStream_t)stream, N, means, quats,
-                           scales, viewmats + 16 * c, Ks + 9 * c, width, height, eps2d, radii + (size_t)c * N,
-                           conics + (size_t)3 * c * N, v_means2d ? v_means2d + (size_t)2 * c * N : nullptr,
+        hipLaunchKernelGGL(project_bwd_kernel, dim3(nblocks, 1), dim3(256), 0, (hipStream_t)stream, N,
+                           means + 3 * c * gs, quats + 4 * c * gs, scales, viewmats + 16 * c, Ks + 9 * c, width, height,
+                           eps2d, radii + (size_t)c * N, conics + (size_t)3 * c * N,
+                           v_means2d ? v_means2d + (size_t)2 * c * N : nullptr,
                            v_depths ? v_depths + (size_t)c * N : nullptr,
-                           v_conics ? v_conics + (size_t)3 * c * N : nullptr, v_means, v_quats, v_scales,
-                           v_viewmats_partial + (size_t)c * nblocks * 16, c > 0 ? 1 : 0);
+                           v_conics ? v_conics + (size_t)3 * c * N : nullptr, v_means + 3 * c * gs, v_quats + 4 * c * gs,
+                           v_scales, v_viewmats_partial + (size_t)c * nblocks * 16,
+                           (c > 0 && !geometry_per_camera) ? 1 : 0, c > 0 ? 1 : 0);
     }
     hipLaunchKernelGGL(viewmat_reduce_kernel, dim3(16 * C), dim3(256), 0, (hipStream_t)stream, nblocks,
                        v_viewmats_partial, v_viewmats);

@@ -46,8 +46,8 @@ def get_flow_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor, shar
 def render_blurry_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor, shard: SubframeShard,
                         blce=None, n_sub: int = 9, exposures: Optional[Sequence[Sequence]] = None,
                         train_mode_mid: bool = True, pipe=None, rank_local_terms: bool = False,
-                        weighted: bool = False, with_flows: bool = False,
-                        overlap: bool = False) -> Tuple[torch.Tensor, Dict[int, dict]]:
+                        weighted: bool = False, with_flows: bool = False, overlap: bool = False,
+                        batched_latent: bool = True) -> Tuple[torch.Tensor, Dict[int, dict]]:
     """cams: the batch's view cameras.  blce: a mobgs_amd.blce.blceKernel (None: every sub-frame uses the view's own
     camera and `exposures[v][k]` / 0 as exposure offset -- the reference before `start_warp`).
     -> (pred [V,3,H,W] on every rank, {view index: result dict of its mid (train-mode) render} for the mid frames this
@@ -78,18 +78,37 @@ def render_blurry_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor,
                 warped[v] = ([cams[v]] * n_sub, e)
         return warped[v]
 
+    # batched_latent: this rank's latent (non-mid) sub-frames of a view go through ONE render_many() call -- one
+    # projection / binning / sort / compositing pass over K' cameras with per-camera geometry instead of K' render()
+    # calls (gaussian_renderer.render_many: the win is at small image sizes, where a single render is latency-bound)
+    batch_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    def latent_batch(v):
+        from .gaussian_renderer import render_many
+        ks = [k for vv, k in mine if vv == v and k != half]
+        wc, expo = latent(v)
+        outs = render_many([wc[k] for k in ks], stat_pc, dyn_pc, pipe, bg_color, [expo[k] for k in ks])
+        for k, o in zip(ks, outs):
+            batch_cache[(v, k)] = o["render"]
+
     def unit(v, k):
         nonlocal like
         if k == half:
             pkg = render(cams[v], stat_pc, dyn_pc, pipe, bg_color, get_static=train_mode_mid,
                          get_dynamic=train_mode_mid)
             mids[v] = pkg
+            img = pkg["render"]
+        elif batched_latent:
+            if (v, k) not in batch_cache:
+                latent_batch(v)
+            img = batch_cache.pop((v, k))
         else:
             wc, expo = latent(v)
             d = expo[k]
-            pkg = render(wc[k], stat_pc, dyn_pc, pipe, bg_color, get_static=True, get_dynamic=True, delta_exposure=d)
-        like = pkg["render"]
-        return pkg["render"]
+            img = render(wc[k], stat_pc, dyn_pc, pipe, bg_color, get_static=True, get_dynamic=True,
+                         delta_exposure=d)["render"]
+        like = img
+        return img
 
     if not mine:  # more ranks than units: contribute zeros (image size from the first camera)
         c = cams[0]

@@ -25,7 +25,8 @@ from .._lib import DerivedCache
 from ..ops import PrepSplats, decode, decode_with_channels
 from . import network_gui  # noqa: F401  (train.py imports it from here)
 
-__all__ = ["render", "get_flow", "get_flow_many", "get_flow_static", "interpolate_cubic_hermite", "network_gui"]
+__all__ = ["render", "render_many", "get_flow", "get_flow_many", "get_flow_static", "interpolate_cubic_hermite",
+           "network_gui"]
 
 # True: the static-only / dynamic-only images of a train-mode render() come from one layered compositing pass over
 # the lists of the combined render (csrc/raster_layers.hip); False: one rasterization per set, call for call like
@@ -357,6 +358,63 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
         else:
             out.update(aux_images())
     return out
+
+
+_bgK_cache = {}  # K -> DerivedCache of the [K,9] background rows
+
+
+def render_many(viewpoint_cameras, stat_pc, dyn_pc, pipe, bg_color, delta_exposures=None):
+    """[render(cam_k, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=d_k) for k] in lean mode -- the K latent sub-frames
+    of one blurry view (train.py:502-518: same Gaussians at K exposure times through K warped cameras) -- as ONE batch of
+    C = K cameras: K per-splat preps, then ONE projection (every camera with its own positions / rotations / colours of
+    the N splats: MobgsTuning.geometry_per_camera), ONE binning + sort, ONE compositing pass forward and backward over
+    K x the tiles, K decodes.  Not in the reference (it renders the sub-frames one call at a time).  On large scenes a
+    single render already fills the chip and nothing is gained; at the reference's own operating point (512x288, ~30 k
+    splats: 576 tiles, every kernel at its launch floor) the sub-frames' renders stop being latency-bound.
+    Images are bit-identical to separate render() calls; gradients agree to summation order.
+    -> list of K dicts {"render" [3,H,W], "depth" [1,H,W], "radii" [N], "viewspace_points" [1,N,2], "visibility_filter"}."""
+    cams = list(viewpoint_cameras)
+    K = len(cams)
+    deltas = list(delta_exposures) if delta_exposures is not None else [None] * K
+    dev = _device_of(dyn_pc)
+    W, H = int(cams[0].image_width), int(cams[0].image_height)
+    if any((int(c.image_width), int(c.image_height)) != (W, H) for c in cams):
+        raise ValueError("render_many: all cameras must share one image size")
+    bg1 = _bg9(bg_color)
+    bgK = _bgK_cache.setdefault(K, DerivedCache()).get((bg1,), lambda: bg1.expand(K, 9).contiguous())
+    w1, w2 = _decoder_weights(dyn_pc)
+    preps = [_prep(stat_pc, dyn_pc, _times(c, d, dev)) for c, d in zip(cams, deltas)]
+    means = torch.stack([p[0] for p in preps])
+    quats = torch.stack([p[1] for p in preps])
+    cols = torch.stack([p[4] for p in preps])
+    scales, opac = preps[0][2], preps[0][3]   # activations of time-independent leaves: identical for every k
+    viewmats = torch.stack([c.world_view_transform.transpose(0, 1) for c in cams])
+    Ks = torch.stack([c.K for c in cams])
+    sp = _R.SharedProjection(means, quats, scales, opac, viewmats, Ks, W, H, pack_colors=cols)
+
+    def composite_and_decode():
+        img, alphas = sp.composite(cols, bgK)                  # [K,H,W,10], [K,H,W,1]
+        # unbind: ONE autograd node whose backward stacks the K cotangents (a select per k would zero-fill and copy
+        # the whole batch K times)
+        return [decode(i, a, _rays_of(c), w1, w2, True) for i, a, c in zip(img.unbind(0), alphas.unbind(0), cams)]
+
+    rebuilds = sp.tl.rebuilds
+    sp.tl.defer = True
+    try:
+        decoded = composite_and_decode()
+    finally:
+        sp.tl.defer = False
+    sp.tl.resolve()
+    if sp.tl.rebuilds != rebuilds:   # arena too small (first frame / scene grew): lists were rebuilt, do it again
+        decoded = composite_and_decode()
+    info = sp.meta()
+    _keep_grad(info["means2d"])
+    outs = []
+    for k, (rendered, depth) in enumerate(decoded):
+        radii = info["radii"][k]
+        outs.append({"render": rendered, "depth": depth.unsqueeze(0), "radii": radii,
+                     "viewspace_points": info["means2d"], "viewspace_index": k, "visibility_filter": radii > 0})
+    return outs
 
 
 def _raster_acc(raster, sl, colors, bgs):

@@ -64,7 +64,7 @@ class _Project(torch.autograd.Function):
                                                                    viewmats, Ks, radii, conics, v_means2d, v_depths,
                                                                    v_conics, stream_int())
             return v_means, v_quats, v_scales, v_viewmats, None, None, None, None, None, None, None
-        C, N = viewmats.shape[0], means.shape[0]
+        C, N = viewmats.shape[0], means.shape[-2]
         dev = means.device
         v_means = torch.empty_like(means)
         v_quats = torch.empty_like(quats)
@@ -74,10 +74,10 @@ class _Project(torch.autograd.Function):
         g2 = f32c(v_means2d) if v_means2d is not None else None
         gd = f32c(v_depths) if v_depths is not None else None
         gc = f32c(v_conics) if v_conics is not None else None
-        check(lib.mobgs_project_bwd(C, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
-                                    eps2d, ptr(radii), ptr(conics), ptr(g2), ptr(gd), ptr(gc), ptr(v_means),
-                                    ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(partial), stream()),
-              "mobgs_project_bwd")
+        check(lib.mobgs_project_bwd_ex(C, N, 1 if means.dim() == 3 else 0, ptr(means), ptr(quats), ptr(scales),
+                                       ptr(viewmats), ptr(Ks), width, height, eps2d, ptr(radii), ptr(conics), ptr(g2),
+                                       ptr(gd), ptr(gc), ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_viewmats),
+                                       ptr(partial), stream()), "mobgs_project_bwd")
         return v_means, v_quats, v_scales, v_viewmats, None, None, None, None, None, None, None
 
 
@@ -860,10 +860,22 @@ class _ProjectAndBin(torch.autograd.Function):
         import ctypes
         lib = _lib_()
         means, quats, scales, viewmats, Ks, opac = map(f32c, (means, quats, scales, viewmats, Ks, opacities))
-        C, N = viewmats.shape[0], means.shape[0]
+        C, N = viewmats.shape[0], means.shape[-2]
         dev = means.device
         tile_w, tile_h = math.ceil(width / TILE), math.ceil(height / TILE)
         nt = C * tile_w * tile_h
+        # means [C,N,3] / quats [C,N,4]: every camera has its own positions / rotations of the N splats (the K sub-frames
+        # of a blurry view as ONE batch; MobgsTuning.geometry_per_camera).  Speculative path only.
+        per_cam = means.dim() == 3
+        if per_cam:
+            if not (quats.dim() == 3 and means.shape[0] == C and quats.shape[0] == C and SPECULATIVE_BINNING):
+                raise ValueError("per-camera geometry: means [C,N,3] and quats [C,N,4] with C = number of cameras")
+            call_tuning = _lib.MobgsTuning(tuning.heavy_tile_len, tuning.longest_list_hint, tuning.quadrant_culling,
+                                           tuning.block_walk, tuning.bwd_block_walk, 1)
+            _tuning_keepalive.append(call_tuning)
+            del _tuning_keepalive[:-8]
+        else:
+            call_tuning = tuning
         F = _fast.get() if SPECULATIVE_BINNING else None
         if F is not None:  # allocations + the orchestrator call in C++ (csrc/fastpath.cpp)
             global _stats_slots
@@ -886,7 +898,7 @@ class _ProjectAndBin(torch.autograd.Function):
             rc, outs, tile_order, isect_ids, records = F.project_and_bin_speculative(
                 means, quats, scales, viewmats, Ks, opac, width, height, eps2d, near_plane, far_plane, radius_clip,
                 int(_tile_culling), bool(want_isect_ids), bool(TILE_SCHEDULE), pack, cap_box, cap_listed,
-                len_hint, row_addr, seq, tuning.address(), stream_int())
+                len_hint, row_addr, seq, call_tuning.address(), stream_int())
             radii, means2d, depths, conics, tiles_per_gauss, cum_tiles, tile_offsets, keep_scan, flatten_ids = outs
             tl.records = records
             event = None
@@ -953,7 +965,7 @@ class _ProjectAndBin(torch.autograd.Function):
                     _len_hint.get(key, 0), ctypes.c_void_p(row_addr), seq,
                     ptr(pack_colors) if records is not None else None,
                     1 if (records is not None and pack_colors.dim() == 3) else 0,
-                    pack_colors.shape[-1] if records is not None else 0, ptr(records), tuning.ref(), stream())
+                    pack_colors.shape[-1] if records is not None else 0, ptr(records), call_tuning.ref(), stream())
                 if rc not in (0, 1):
                     check(rc, "mobgs_project_and_bin_speculative")
                 tl.records = records
@@ -1013,7 +1025,7 @@ class SharedProjection:
         projection kernel then writes the compositor's packed records itself (one launch and one pass over the
         projection outputs fewer); passing other colours later simply packs again."""
         self.width, self.height = int(width), int(height)
-        self.C, self.N = viewmats.shape[0], means.shape[0]
+        self.C, self.N = viewmats.shape[0], means.shape[-2]
         self.opacities = opacities
         self.tl = TileLists()
         (self.radii, self.means2d, self.depths, self.conics, self.tiles_per_gauss) = _ProjectAndBin.apply(
