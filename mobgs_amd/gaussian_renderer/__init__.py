@@ -501,16 +501,27 @@ def get_flow_many(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_expos
     cam = viewpoint_camera
     mid = _flow_mid_state(cam, stat_pc, dyn_pc, _device_of(dyn_pc))
     W, H = int(cam.image_width), int(cam.image_height)
-    outs = []
-    for d in delta_exposures:
+    outs = [None] * len(delta_exposures)
+    off_mid = []
+    for i, d in enumerate(delta_exposures):
         if not torch.is_tensor(d) and float(d) == 0.0:
             # the mid exposure itself (train.py's fifth call): the exposure-time state IS the mid state, both flows
             # are identically zero (their gradients cancel term by term), so the call needs no projection, binning,
             # flow channels or flow splat of its own -- one 10-channel walk over the shared lists
-            outs.append(_flow_at_mid(cam, mid, stat_pc.get_xyz.shape[0], dyn_pc, bg_color, W, H))
+            outs[i] = _flow_at_mid(cam, mid, stat_pc.get_xyz.shape[0], dyn_pc, bg_color, W, H)
         else:
-            outs.append(list(get_flow(cam, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=d, _mid=mid,
-                                      _defer_mid=True)))
+            off_mid.append(i)
+    if BATCH_FLOW_EXPOSURES and len(off_mid) > 1:
+        # round 3: the exposure-time halves of all those calls as ONE batch of G "cameras" (the same pose G times,
+        # per-camera geometry: the splats at G exposure times) -- one projection, binning, sort, 12-channel compositing
+        # pass and coverage pass for all of them instead of G (see render_many)
+        for i, o in zip(off_mid, _get_flow_exposures(cam, stat_pc, dyn_pc, bg_color, [delta_exposures[i] for i in off_mid],
+                                                     mid)):
+            outs[i] = o
+    else:
+        for i in off_mid:
+            outs[i] = list(get_flow(cam, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=delta_exposures[i], _mid=mid,
+                                    _defer_mid=True))
     pending = [o for o in outs if isinstance(o[1], tuple)]
     for g0 in range(0, len(pending), _FLOW_GROUP):
         grp = pending[g0:g0 + _FLOW_GROUP]
@@ -523,6 +534,42 @@ def get_flow_many(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_expos
         for o, part in zip(grp, tot.unbind(-2)):
             o[1] = part
     return [tuple(o) for o in outs]
+
+
+BATCH_FLOW_EXPOSURES = True
+
+
+def _get_flow_exposures(cam, stat_pc, dyn_pc, bg_color, deltas, mid):
+    """[get_flow(cam, ..., delta_exposure=d, _mid=mid, _defer_mid=True) for d in deltas] with the exposure-time work of
+    all G calls batched: -> list of [exp2mid, (pix, e2m_g), latent_img, latent_alpha]."""
+    dev = _device_of(dyn_pc)
+    W, H = int(cam.image_width), int(cam.image_height)
+    G = len(deltas)
+    viewmat = cam.world_view_transform.transpose(0, 1)
+    bg1 = _bg9(bg_color)
+    w1, w2 = _decoder_weights(dyn_pc)
+    Ns = stat_pc.get_xyz.shape[0]
+    preps = [_prep(stat_pc, dyn_pc, _times(cam, d, dev)) for d in deltas]
+    means = torch.stack([p[0] for p in preps])
+    quats = torch.stack([p[1] for p in preps])
+    cols = torch.stack([p[4] for p in preps])                      # [G,N,9]
+    scales, opac = preps[0][2], preps[0][3]
+    sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None].expand(G, 4, 4), cam.K[None].expand(G, 3, 3), W, H)
+    bgG = _bgK_cache.setdefault(G, DerivedCache()).get((bg1,), lambda: bg1.expand(G, 9).contiguous())
+    bg11 = _bgK_cache.setdefault(("11", G), DerivedCache()).get(
+        (bg1,), lambda: torch.cat([bg1, bg1.new_zeros(1, 2)], dim=-1).expand(G, 11).contiguous())
+    latent_alpha = sp.class_alpha(Ns, 2, background=bgG[:, :1])    # [G,H,W]
+    e2m = mid.means2d - sp.means2d                                 # [G,N,2]
+    img12, alphas = sp.composite(torch.cat([cols, e2m], dim=-1), bg11)   # [G,H,W,12]
+    rays = _rays_of(cam)
+    outs = []
+    pix = None
+    for g, (i12, a, la) in enumerate(zip(img12.unbind(0), alphas.unbind(0), latent_alpha.unbind(0))):
+        latent_img, e2m_img = decode_with_channels(i12, a, rays, w1, w2, 9, 2)
+        if pix is None:
+            pix = _pixel_grid(cam, W, H, e2m_img)
+        outs.append([pix + e2m_img[None], (pix, e2m[g]), latent_img, la[None]])
+    return outs
 
 
 def _flow_at_mid(cam, mid, Ns, dyn_pc, bg_color, W, H):
