@@ -20,3 +20,16 @@ for (W, H, ns, nd, steps) in ((512, 288, 20_000, 10_000, 40), (1352, 1014, 200_0
         torch.cuda.synchronize()
         res[batched] = (time.perf_counter() - t0) / steps * 1e3
     print(f"{W}x{H} {ns}+{nd}: K=9 two-view iteration  separate renders {res[False]:.3f} ms   batched sub-frames {res[True]:.3f} ms")
+
+# ... and the WHOLE training iteration (train.py:430-807: both blurry views, 18 get_flow calls, losses, densification
+# statistics, Adam) at the reference's operating point
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+import train_deblur_synth as TD
+tr = TD.DeblurTrainer("cuda:0", 20_000, 10_000, 512, 288, 2, iters=10000)
+for _ in range(5):
+    tr.iteration()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(30):
+    tr.iteration()
+torch.cuda.synchronize()
+print(f"512x288 20000+10000: whole training iteration {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms")
