@@ -568,7 +568,7 @@ def main():
                         "what": "ONE whole training iteration (train.py:430-807) at the headline size: per view K = 9 "
                                 "latent renders through BLCE cameras (mid frame in train mode) + the 9 get_flow() calls, "
                                 "fused L1 + D-SSIM on the blurry prediction, depth / mask / normal (get_normals) terms on "
-                                "the mid render, a flow term per sub-frame, backward into the flat gradient buffer, "
+                                "the mid render, the flow-consistency term of train.py:651-671 (two grid_sample warps + masked L1, fused), backward into the flat gradient buffer, "
                                 "densification statistics, Adam on both Gaussian sets + decoder + BLCE "
                                 "(examples/train_deblur_synth.py DeblurTrainer.iteration)"}
             del tr

@@ -6,8 +6,9 @@ MI355X path and, under torchrun, sharded over GPUs:
                           prediction (mobgs_amd.deblur.render_blurry_batch: ONE all-reduce for the batch)
                           K get_flow() calls (mobgs_amd.deblur.get_flow_batch, sharded like the renders)
   loss                    photometric (L1 + 0.2 D-SSIM, fused) on the prediction, depth / mask terms on the mid render,
-                          a flow term per sub-frame (latent image vs. prediction, the two coordinate maps), a
-                          regulariser on the scales
+                          the flow-consistency term of train.py:651-671 on the get_flow outputs (both grid_sample
+                          warps + both masked L1 terms: mobgs_amd.loss_utils.flow_warp_loss, one fused kernel each
+                          way; sharded runs: a rank-local stand-in per flow unit), a regulariser on the scales
   backward                ops.LeafGradSink + distributed.FlatGradients, ONE in-place gradient all-reduce that also carries
                           the mid-frame densification statistics
   step                    Adam on both Gaussian sets, the decoder and the BLCE parameters; densification statistics
@@ -34,7 +35,7 @@ from mobgs_amd.densify import TrainableGaussians  # noqa: E402
 from mobgs_amd.distributed import FlatGradients, SubframeShard  # noqa: E402
 from mobgs_amd.gaussian_renderer import render  # noqa: E402
 from mobgs_amd.helper_model import Sandwich  # noqa: E402
-from mobgs_amd.loss_utils import l1_loss, photometric_loss  # noqa: E402
+from mobgs_amd.loss_utils import flow_warp_loss, l1_loss, photometric_loss  # noqa: E402
 from mobgs_amd.ops import LeafGradSink  # noqa: E402
 from mobgs_amd.optim import fused_adam_step  # noqa: E402
 from mobgs_amd.synth import SynthCamera, dynamic_extras, gaussian_cloud  # noqa: E402
@@ -123,9 +124,22 @@ class DeblurTrainer:
             normal = self.get_normals(pkg["depth"] + 1e-6, self.meta)   # train.py:590
             loss = loss + 0.05 * l1_loss(pkg["depth"], self.depths[v]) + 0.01 * pkg["d_alpha"].mean() \
                 + 0.01 * l1_loss(normal, self.normals[v])
-        for (v, k), (e2m, m2e, limg, lalpha) in flows.items():   # the owner of the flow unit
-            loss = loss + self.lambda_flow / K * (l1_loss(limg, pred[v]) + 1e-3 * (e2m - m2e).abs().mean()
-                                                  + 0.1 * lalpha.mean())
+        if not multi and self.lambda_flow != 0:
+            # train.py:608-617 + :651-671: the flow-consistency term on the tensors the reference concatenates --
+            # both grid_sample warps and both masked L1 terms in one forward and one backward kernel
+            views = range(self.n_views)
+            cat = lambda i: torch.stack([torch.cat([flows[(v, k)][i] for k in range(K)]) for v in views])  # noqa: E731
+            loss = loss + flow_warp_loss(torch.stack([mids[v]["render"] for v in views]),
+                                         torch.stack([torch.stack([flows[(v, k)][2] for k in range(K)]) for v in views]),
+                                         cat(0), cat(1), cat(3).unsqueeze(2),
+                                         torch.stack([mids[v]["d_alpha"].reshape(1, *pred.shape[-2:]) for v in views]),
+                                         self.lambda_flow)
+        else:
+            # flow units sharded over ranks: each owner forms a rank-local stand-in (the reference's term normalises
+            # over all (view, exposure) pairs and samples the view's mid render, which lives on one rank)
+            for (v, k), (e2m, m2e, limg, lalpha) in flows.items():
+                loss = loss + self.lambda_flow / K * (l1_loss(limg, pred[v]) + 1e-3 * (e2m - m2e).abs().mean()
+                                                      + 0.1 * lalpha.mean())
         loss = loss + shard.replicated_term(1e-4 * ((stat._scaling ** 2).mean() + (dyn._scaling ** 2).mean()))
         with LeafGradSink(stat, dyn, extra=blce.model.get_params()):
             loss.backward()

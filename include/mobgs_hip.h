@@ -519,7 +519,35 @@ int mobgs_ssim_l1_fwd(int C, int H, int W, const float* img1, const float* img2,
 int mobgs_ssim_l1_bwd(int C, int H, int W, const float* img1, const float* img2, const float* dmaps,
                       const float* scales, float* v_img1, void* stream);
 
-/* ---- K14: one Adam step over MANY parameter tensors in one launch ------------------------------------------------
+/* ---- K17: flow-consistency loss (the consumer of get_flow()'s outputs in a training iteration) ---------------------
+ * /root/reference/train.py:651-671 with utils/loss_utils.py:233-237 (masked l1_loss):
+ *   loss = l1(grid_sample(ori expanded over K, norm(exp2mid)), latent, mask = latent_alpha)
+ *        + l1(grid_sample(latent,             norm(mid2exp)), ori,    mask = d_alpha)
+ * norm(c) = 2 c / (size - 1) - 1 per axis; grid_sample bilinear, padding_mode = 'border', align_corners = False;
+ * l1(a, b, m) = sum |(a - b) m| / (3 sum(m) + 1e-8).  lambda_flow_loss is the caller's.
+ * ori [B,3,H,W]; latent [B,K,3,H,W]; exp2mid, mid2exp [B,K,H,W,2] PIXEL coordinates (what get_flow returns; the
+ * reference normalises them in place, this entry point leaves its inputs alone); latent_alpha [B,K,H,W]; d_alpha
+ * [B,H,W].  H, W >= 2.
+ * fwd: partial = scratch [mobgs_flow_warp_loss_blocks(B,H,W), 4]; sums [4] (kept for bwd) = {N1, S1, N2, S2};
+ *      loss [1].  Deterministic (fixed summation order).
+ * bwd: v_loss = device scalar.  g_ori [B,3,H,W] and g_latent [B,K,3,H,W] are ADDED to with float atomics (bilinear
+ *      scatter, as torch's grid_sampler_2d_backward: summation order not fixed) -- zero-fill them; g_exp2mid /
+ *      g_mid2exp [B,K,H,W,2], g_latent_alpha [B,K,H,W], g_d_alpha [B,H,W] are fully written.  Any may be NULL.
+ *      scratch: mobgs_flow_warp_loss_bwd_scratch_floats(B,K,H,W) floats (needed when g_ori or g_latent is wanted: the
+ *      images' gradients as TARGETS of the other term are written there and added at the end).
+ *      combine_taps != 0: coinciding taps of neighbouring pixels (next lane, next row) are merged in registers before
+ *      the atomics (same sums, a quarter of the atomics). */
+int mobgs_flow_warp_loss_blocks(int B, int H, int W);
+int mobgs_flow_warp_loss_fwd(int B, int K, int H, int W, const float* ori, const float* latent, const float* exp2mid,
+                             const float* mid2exp, const float* latent_alpha, const float* d_alpha, float* partial,
+                             float* sums, float* loss, void* stream);
+int mobgs_flow_warp_loss_bwd(int B, int K, int H, int W, const float* ori, const float* latent, const float* exp2mid,
+                             const float* mid2exp, const float* latent_alpha, const float* d_alpha, const float* sums,
+                             const float* v_loss, float* g_ori, float* g_latent, float* g_exp2mid, float* g_mid2exp,
+                             float* g_latent_alpha, float* g_d_alpha, float* scratch, int combine_taps, void* stream);
+size_t mobgs_flow_warp_loss_bwd_scratch_floats(int B, int K, int H, int W);
+
+/* ---- K16: one Adam step over MANY parameter tensors in one launch ------------------------------------------------
  * The reference steps three torch.optim.Adam optimisers per iteration (train.py:790-807: static Gaussians, dynamic
  * Gaussians + decoder, blur kernel), ~14 one-tensor parameter groups each: ~26 groups x 8 multi-tensor launches =
  * 3.3 ms of device time per iteration at 300 k Gaussians for 0.48 GB of traffic.  One launch over all of them:

@@ -87,6 +87,10 @@ _SIGS = {
     "mobgs_ssim_l1_blocks": (c_int, [c_int, c_int, c_int]),
     "mobgs_ssim_l1_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P]),
     "mobgs_ssim_l1_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P]),
+    "mobgs_flow_warp_loss_blocks": (c_int, [c_int, c_int, c_int]),
+    "mobgs_flow_warp_loss_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
+    "mobgs_flow_warp_loss_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P]),
+    "mobgs_flow_warp_loss_bwd_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mobgs_hexplane_fwd": (c_int, [c_int] + [P] * 7 + [P]),
     "mobgs_hexplane_bwd": (c_int, [c_int] + [P] * 11 + [P]),
     "mobgs_hexplane_bwd_scratch_bytes": (c_size_t, [c_int, P, P]),

@@ -13,7 +13,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 # MOBGS_LIB: load another build of the same library instead (A/B timing of kernel variants on one GPU box)
 LIB_PATH = Path(os.environ["MOBGS_LIB"]).resolve() if os.environ.get("MOBGS_LIB") else CSRC / "libmobgs_hip.so"
-SOURCES = ["project.hip", "isect.hip", "raster.hip", "raster_layers.hip", "pipeline.hip", "prep.hip", "decoder.hip", "deform.hip", "deform_bwd.hip", "hexplane_bwd.hip", "blce.hip", "loss.hip", "densify.hip", "normals.hip"]
+SOURCES = ["project.hip", "isect.hip", "raster.hip", "raster_layers.hip", "pipeline.hip", "prep.hip", "decoder.hip", "deform.hip", "deform_bwd.hip", "hexplane_bwd.hip", "blce.hip", "loss.hip", "flowloss.hip", "densify.hip", "normals.hip"]
 ARCH = "gfx950"
 # host fast path (csrc/fastpath.cpp): a plain C++ torch extension, no device code, no link against libmobgs_hip.so
 FAST_SRC = CSRC / "fastpath.cpp"

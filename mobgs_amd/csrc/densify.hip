@@ -148,7 +148,7 @@ split_children_kernel(int n_children, int first, int n_split, const float* __res
 
 }  // namespace mobgs
 
-// ---- one Adam step over up to 64 tensors (include/mobgs_hip.h K14) -------------------------------------------------
+// ---- one Adam step over up to 64 tensors (include/mobgs_hip.h K16) -------------------------------------------------
 struct AdamTable {
     MobgsAdamTensor t[64];
 };

@@ -6,7 +6,9 @@
 mirrors /root/reference/utils/loss_utils.py:233-239 (l1_loss), :351-381 (ssim, 11x11 Gaussian window sigma 1.5, zero
 padding), /root/reference/utils/image_utils.py:17-38 (psnr) and the combination of /root/reference/train.py:621-628.
 Gradients flow to the first argument (the rendered image); the second (ground truth) is treated as a constant, as
-in every reference call.  Masked L1 (used only by the flow loss, weight 0 in the shipped configs) stays in torch.
+in every reference call.  The masked L1 exists in the reference only inside the flow-consistency loss
+(train.py:651-671): `flow_warp_loss` below is that whole block -- coordinate normalisation, both grid_sample warps and
+both masked L1 terms -- as one forward and one backward kernel (csrc/flowloss.hip), differentiable in all six inputs.
 """
 from __future__ import annotations
 
@@ -90,6 +92,74 @@ def photometric_loss(image, gt, lambda_dssim=0.2):
     if lambda_dssim == 0:
         return ll1
     return ll1 + lambda_dssim * (1.0 - s.sum() / n)
+
+
+class _FlowWarpLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ori, latent, e2m, m2e, la, da, combine_taps):
+        lib = _lib.load()
+        ori, latent, e2m, m2e, la, da = (f32c(t) for t in (ori, latent, e2m, m2e, la, da))
+        B, K, _, H, W = latent.shape
+        dev = ori.device
+        partial = torch.empty(lib.mobgs_flow_warp_loss_blocks(B, H, W), 4, dtype=torch.float32, device=dev)
+        out = torch.empty(5, dtype=torch.float32, device=dev)  # sums[4], loss
+        check(lib.mobgs_flow_warp_loss_fwd(B, K, H, W, ptr(ori), ptr(latent), ptr(e2m), ptr(m2e), ptr(la), ptr(da),
+                                           ptr(partial), ptr(out), ptr(out[4:]), stream()), "mobgs_flow_warp_loss_fwd")
+        ctx.save_for_backward(ori, latent, e2m, m2e, la, da, out)
+        ctx.combine_taps = int(combine_taps)
+        return out[4]
+
+    @staticmethod
+    def backward(ctx, v):
+        lib = _lib.load()
+        ori, latent, e2m, m2e, la, da, out = ctx.saved_tensors
+        B, K, _, H, W = latent.shape
+        need = ctx.needs_input_grad
+        v = f32c(v).reshape(1)
+        g_ori = torch.zeros_like(ori) if need[0] else None          # scatter targets: accumulated with atomics
+        g_latent = torch.zeros_like(latent) if need[1] else None
+        g_e2m = torch.empty_like(e2m) if need[2] else None
+        g_m2e = torch.empty_like(m2e) if need[3] else None
+        g_la = torch.empty_like(la) if need[4] else None
+        g_da = torch.empty_like(da) if need[5] else None
+        scratch = None
+        if need[0] or need[1]:
+            scratch = torch.empty(lib.mobgs_flow_warp_loss_bwd_scratch_floats(B, K, H, W), dtype=torch.float32,
+                                  device=ori.device)
+        check(lib.mobgs_flow_warp_loss_bwd(B, K, H, W, ptr(ori), ptr(latent), ptr(e2m), ptr(m2e), ptr(la), ptr(da),
+                                           ptr(out), ptr(v), ptr(g_ori), ptr(g_latent), ptr(g_e2m), ptr(g_m2e),
+                                           ptr(g_la), ptr(g_da), ptr(scratch), ctx.combine_taps, stream()),
+              "mobgs_flow_warp_loss_bwd")
+        return g_ori, g_latent, g_e2m, g_m2e, g_la, g_da, None
+
+
+def flow_warp_loss(ori_image_tensor, latent_img_final_tensor, exp2mid_coord_final_tensor, mid2exp_coord_final_tensor,
+                   latent_alpha_final_tensor, d_alpha_tensor, lambda_flow_loss=1.0, combine_taps=True):
+    """The flow-consistency term of /root/reference/train.py:651-671 from the tensors of :608-617:
+
+        flow_loss = lambda_flow_loss * (l1(grid_sample(ori, norm(exp2mid)), latent, mask=latent_alpha)
+                                        + l1(grid_sample(latent, norm(mid2exp)), ori, mask=d_alpha))
+
+    ori [B,3,H,W]; latent [B,K,3,H,W]; exp2mid / mid2exp [B,K,H,W,2] pixel coordinates exactly as get_flow() returns
+    them (the reference normalises them in place before sampling; this function does not modify its arguments);
+    latent_alpha [B,K,1,H,W] (or [B,K,H,W]); d_alpha [B,1,H,W] (or [B,H,W]).  Differentiable in all six tensors.
+    lambda_flow_loss == 0 (the shipped seesaw / children configs): a zero that is part of no graph -- the reference
+    evaluates and back-propagates the whole block to multiply it by zero."""
+    B, K = latent_img_final_tensor.shape[:2]
+    H, W = ori_image_tensor.shape[-2:]
+    if latent_img_final_tensor.shape != (B, K, 3, H, W) or ori_image_tensor.shape != (B, 3, H, W):
+        raise ValueError("flow_warp_loss: ori [B,3,H,W] and latent [B,K,3,H,W] expected")
+    for name, t in (("exp2mid", exp2mid_coord_final_tensor), ("mid2exp", mid2exp_coord_final_tensor)):
+        if t.shape != (B, K, H, W, 2):
+            raise ValueError(f"flow_warp_loss: {name} coordinates must be [B,K,H,W,2], got {tuple(t.shape)}")
+    if latent_alpha_final_tensor.numel() != B * K * H * W or d_alpha_tensor.numel() != B * H * W:
+        raise ValueError("flow_warp_loss: latent_alpha [B,K,1,H,W] and d_alpha [B,1,H,W] expected")
+    if isinstance(lambda_flow_loss, (int, float)) and lambda_flow_loss == 0:
+        return ori_image_tensor.new_zeros(())
+    loss = _FlowWarpLoss.apply(ori_image_tensor, latent_img_final_tensor, exp2mid_coord_final_tensor,
+                               mid2exp_coord_final_tensor, latent_alpha_final_tensor.reshape(B, K, H, W),
+                               d_alpha_tensor.reshape(B, H, W), combine_taps)
+    return lambda_flow_loss * loss
 
 
 @torch.no_grad()

@@ -1,4 +1,4 @@
-"""One Adam step for several torch.optim.Adam optimisers in ONE kernel launch (include/mobgs_hip.h K14).
+"""One Adam step for several torch.optim.Adam optimisers in ONE kernel launch (include/mobgs_hip.h K16).
 
 The reference steps three optimisers per iteration (/root/reference/train.py:790-807); with one-tensor parameter groups
 (scene/gaussian_model.py:598-617) torch's multi-tensor path degenerates to ~8 launches per group: 3.3 ms per iteration at

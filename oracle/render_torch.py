@@ -223,3 +223,36 @@ def psnr(img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
     """/root/reference/utils/image_utils.py:17-31 (mask=None branch): per-image 20*log10(1/sqrt(mse))."""
     mse = ((img1 - img2) ** 2).reshape(img1.shape[0], -1).mean(1, keepdim=True)
     return (20 * torch.log10(1.0 / torch.sqrt(mse.float()))).mean().double()
+
+
+def masked_l1(network_output: torch.Tensor, gt: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """/root/reference/utils/loss_utils.py:233-237 (the mask branch of l1_loss)."""
+    mask = mask.expand(-1, gt.shape[1], -1, -1)
+    return torch.abs((network_output - gt) * mask).sum() / (mask.sum() + 1e-8)
+
+
+def flow_warp_loss(ori_image_tensor: torch.Tensor, latent_img_final_tensor: torch.Tensor,
+                   exp2mid_coord_final_tensor: torch.Tensor, mid2exp_coord_final_tensor: torch.Tensor,
+                   latent_alpha_final_tensor: torch.Tensor, d_alpha_tensor: torch.Tensor) -> torch.Tensor:
+    """/root/reference/train.py:651-671 without the lambda_flow_loss factor, statement by statement (the reference
+    normalises the coordinate tensors IN PLACE -- they are fresh torch.cat results there; here on clones).
+    ori [B,3,H,W]; latent [B,K,3,H,W]; coords [B,K,H,W,2] in pixels; latent_alpha [B,K,1,H,W]; d_alpha [B,1,H,W].
+    Parity anchor: these are the reference's own torch calls (F.grid_sample is the third-party piece, and it is torch
+    itself), evaluated on the CPU."""
+    K = latent_img_final_tensor.shape[1]
+    H, W = ori_image_tensor.shape[-2:]
+
+    def norm(coord):
+        x = coord[..., 0] / (W - 1)
+        y = coord[..., 1] / (H - 1)
+        return (2.0 * torch.stack([x, y], dim=-1) - 1.0).flatten(0, 1)
+
+    ori_k = ori_image_tensor.unsqueeze(1).expand(-1, K, -1, -1, -1).flatten(0, 1)
+    warped_exp2mid = F.grid_sample(ori_k, norm(exp2mid_coord_final_tensor), mode='bilinear', padding_mode='border',
+                                   align_corners=False).reshape(-1, K, 3, H, W)
+    warped_mid2exp = F.grid_sample(latent_img_final_tensor.flatten(0, 1), norm(mid2exp_coord_final_tensor),
+                                   mode='bilinear', padding_mode='border', align_corners=False).reshape(-1, K, 3, H, W)
+    return masked_l1(warped_exp2mid.flatten(0, 1), latent_img_final_tensor.flatten(0, 1),
+                     latent_alpha_final_tensor.flatten(0, 1)) \
+        + masked_l1(warped_mid2exp.flatten(0, 1), ori_k,
+                    d_alpha_tensor.unsqueeze(1).expand(-1, K, -1, -1, -1).flatten(0, 1))
