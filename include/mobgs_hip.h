@@ -416,6 +416,38 @@ int mobgs_prep_bwd_f16(int Ns, int Nd, const float* times, const int64_t* d_ncp,
                        uint16_t* g_d_omega, uint16_t* g_d_opacity, uint16_t* g_d_fdc, uint16_t* g_d_ft,
                        int accumulate, void* stream);
 
+/* The four entry points above for K time instants in ONE launch (the K sub-frames of a blurry view, train.py:502-518: the
+ * same Gaussians at K exposure times): times [K,2]; means [K,N,3], quats [K,N,4], colors [K,N,9] (row block k = instant
+ * k); scales [N,3] and opacities [N] do not depend on time and exist once.  Backward: v_means / v_quats / v_colors
+ * [K,...], v_scales / v_opacities once; the leaf gradients are the sums over the instants, accumulated in instant order
+ * (the result of K single-instant calls in a row, bit for bit).  K = 1 is the single-instant call. */
+int mobgs_prep_fwd_many(int K, int Ns, int Nd, const float* times, const float* s_xyz, const float* s_scaling,
+                        const float* s_rotation, const float* s_opacity, const float* s_fdc, const float* s_ft,
+                        const float* d_control, const int64_t* d_ncp, const float* d_scaling,
+                        const float* d_rotation, const float* d_omega, const float* d_opacity, const float* d_fdc,
+                        const float* d_ft, const float* d_trbf, float* means, float* quats, float* scales,
+                        float* opacities, float* colors, void* stream);
+int mobgs_prep_bwd_many(int K, int Ns, int Nd, const float* times, const int64_t* d_ncp, const float* d_trbf,
+                        const float* scales, const float* opacities, const float* v_means, const float* v_quats,
+                        const float* v_scales, const float* v_opacities, const float* v_colors, float* g_s_xyz,
+                        float* g_s_scaling, float* g_s_rotation, float* g_s_opacity, float* g_s_fdc, float* g_s_ft,
+                        float* g_d_control, float* g_d_scaling, float* g_d_rotation, float* g_d_omega,
+                        float* g_d_opacity, float* g_d_fdc, float* g_d_ft, int accumulate, void* stream);
+int mobgs_prep_fwd_many_f16(int K, int Ns, int Nd, const float* times, const float* s_xyz, const uint16_t* s_scaling,
+                            const uint16_t* s_rotation, const uint16_t* s_opacity, const uint16_t* s_fdc,
+                            const uint16_t* s_ft, const float* d_control, const int64_t* d_ncp,
+                            const uint16_t* d_scaling, const uint16_t* d_rotation, const uint16_t* d_omega,
+                            const uint16_t* d_opacity, const uint16_t* d_fdc, const uint16_t* d_ft,
+                            const float* d_trbf, float* means, float* quats, float* scales, float* opacities,
+                            float* colors, void* stream);
+int mobgs_prep_bwd_many_f16(int K, int Ns, int Nd, const float* times, const int64_t* d_ncp, const float* d_trbf,
+                            const float* scales, const float* opacities, const float* v_means, const float* v_quats,
+                            const float* v_scales, const float* v_opacities, const float* v_colors, float* g_s_xyz,
+                            uint16_t* g_s_scaling, uint16_t* g_s_rotation, uint16_t* g_s_opacity, uint16_t* g_s_fdc,
+                            uint16_t* g_s_ft, float* g_d_control, uint16_t* g_d_scaling, uint16_t* g_d_rotation,
+                            uint16_t* g_d_omega, uint16_t* g_d_opacity, uint16_t* g_d_fdc, uint16_t* g_d_ft,
+                            int accumulate, void* stream);
+
 /* ---- K9: colour decoder + expected-depth normalisation (replaces Sandwich.forward + gsplat's "ED" step) ---
  * /root/reference/helper_model.py:19-28; /root/reference/gaussian_renderer/__init__.py:216-227.
  * feat_hw [P,CF] channels-last compositor output (CF >= 9; channel 9 = accumulated depth when has_depth),

@@ -81,6 +81,10 @@ _SIGS = {
     "mobgs_prep_bwd": (c_int, [c_int, c_int] + [P] * 23 + [c_int, P]),
     "mobgs_prep_fwd_f16": (c_int, [c_int, c_int] + [P] * 21 + [P]),
     "mobgs_prep_bwd_f16": (c_int, [c_int, c_int] + [P] * 23 + [c_int, P]),
+    "mobgs_prep_fwd_many": (c_int, [c_int, c_int, c_int] + [P] * 21 + [P]),
+    "mobgs_prep_bwd_many": (c_int, [c_int, c_int, c_int] + [P] * 23 + [c_int, P]),
+    "mobgs_prep_fwd_many_f16": (c_int, [c_int, c_int, c_int] + [P] * 21 + [P]),
+    "mobgs_prep_bwd_many_f16": (c_int, [c_int, c_int, c_int] + [P] * 23 + [c_int, P]),
     "mobgs_decoder_fwd": (c_int, [c_int, c_int, c_int, c_int] + [P] * 9 + [P]),
     "mobgs_decoder_bwd_blocks": (c_int, [c_int]),
     "mobgs_decoder_bwd": (c_int, [c_int, c_int, c_int, c_int] + [P] * 16 + [c_int, c_int, P]),

@@ -28,10 +28,10 @@ using OptT = c10::optional<Tensor>;
 struct Api {
     decltype(&mobgs_last_error) last_error = nullptr;
     decltype(&mobgs_record_stride) record_stride = nullptr;
-    decltype(&mobgs_prep_fwd) prep_fwd = nullptr;
-    decltype(&mobgs_prep_fwd_f16) prep_fwd_f16 = nullptr;
-    decltype(&mobgs_prep_bwd) prep_bwd = nullptr;
-    decltype(&mobgs_prep_bwd_f16) prep_bwd_f16 = nullptr;
+    decltype(&mobgs_prep_fwd_many) prep_fwd = nullptr;
+    decltype(&mobgs_prep_fwd_many_f16) prep_fwd_f16 = nullptr;
+    decltype(&mobgs_prep_bwd_many) prep_bwd = nullptr;
+    decltype(&mobgs_prep_bwd_many_f16) prep_bwd_f16 = nullptr;
     decltype(&mobgs_raster_fwd) raster_fwd = nullptr;
     decltype(&mobgs_raster_bwd) raster_bwd = nullptr;
     decltype(&mobgs_raster_bwd_reduce) raster_bwd_reduce = nullptr;
@@ -59,10 +59,10 @@ void take(const std::unordered_map<std::string, uint64_t>& m, const char* name, 
 void bind(const std::unordered_map<std::string, uint64_t>& m) {
     take(m, "mobgs_last_error", api.last_error);
     take(m, "mobgs_record_stride", api.record_stride);
-    take(m, "mobgs_prep_fwd", api.prep_fwd);
-    take(m, "mobgs_prep_fwd_f16", api.prep_fwd_f16);
-    take(m, "mobgs_prep_bwd", api.prep_bwd);
-    take(m, "mobgs_prep_bwd_f16", api.prep_bwd_f16);
+    take(m, "mobgs_prep_fwd_many", api.prep_fwd);
+    take(m, "mobgs_prep_fwd_many_f16", api.prep_fwd_f16);
+    take(m, "mobgs_prep_bwd_many", api.prep_bwd);
+    take(m, "mobgs_prep_bwd_many_f16", api.prep_bwd_f16);
     take(m, "mobgs_raster_fwd", api.raster_fwd);
     take(m, "mobgs_raster_bwd", api.raster_bwd);
     take(m, "mobgs_raster_bwd_reduce", api.raster_bwd_reduce);
@@ -137,17 +137,22 @@ prep_fwd(const Tensor& times_in, const Tensor& s_xyz_in, const Tensor& d_control
     }
     const int64_t Ns = s_xyz.size(0), Nd = d_control.size(0), N = Ns + Nd;
     const auto opt = times.options().dtype(at::kFloat);
-    Tensor means = at::empty({N, 3}, opt), quats = at::empty({N, 4}, opt), scales = at::empty({N, 3}, opt),
-           opac = at::empty({N}, opt), colors = at::empty({N, 9}, opt);
+    // times [2]: one instant, outputs [N,*]; times [K,2]: K instants in one launch, means / quats / colors [K,N,*]
+    const bool many = times.dim() == 2;
+    const int64_t K = many ? times.size(0) : 1;
+    if (times.numel() != 2 * K || K < 1) throw std::runtime_error("prep_fwd: times must be [2] or [K,2]");
+    Tensor means = many ? at::empty({K, N, 3}, opt) : at::empty({N, 3}, opt),
+           quats = many ? at::empty({K, N, 4}, opt) : at::empty({N, 4}, opt), scales = at::empty({N, 3}, opt),
+           opac = at::empty({N}, opt), colors = many ? at::empty({K, N, 9}, opt) : at::empty({N, 9}, opt);
     if (half) {
         auto h = [](const Tensor& t) { return static_cast<const uint16_t*>(dp(t)); };
-        check(api.prep_fwd_f16((int)Ns, (int)Nd, fp(times), fp(s_xyz), h(a[0]), h(a[1]), h(a[2]), h(a[3]), h(a[4]),
+        check(api.prep_fwd_f16((int)K, (int)Ns, (int)Nd, fp(times), fp(s_xyz), h(a[0]), h(a[1]), h(a[2]), h(a[3]), h(a[4]),
                                fp(d_control), static_cast<const int64_t*>(dp(d_ncp)), h(a[5]), h(a[6]), h(a[7]),
                                h(a[8]), h(a[9]), h(a[10]), fp(d_trbf), fpw(means), fpw(quats), fpw(scales),
                                fpw(opac), fpw(colors), sp(stream)),
               "mobgs_prep_fwd");
     } else {
-        check(api.prep_fwd((int)Ns, (int)Nd, fp(times), fp(s_xyz), fp(a[0]), fp(a[1]), fp(a[2]), fp(a[3]), fp(a[4]),
+        check(api.prep_fwd((int)K, (int)Ns, (int)Nd, fp(times), fp(s_xyz), fp(a[0]), fp(a[1]), fp(a[2]), fp(a[3]), fp(a[4]),
                            fp(d_control), static_cast<const int64_t*>(dp(d_ncp)), fp(a[5]), fp(a[6]), fp(a[7]),
                            fp(a[8]), fp(a[9]), fp(a[10]), fp(d_trbf), fpw(means), fpw(quats), fpw(scales), fpw(opac),
                            fpw(colors), sp(stream)),
@@ -173,15 +178,16 @@ std::vector<Tensor> prep_bwd(int64_t Ns, int64_t Nd, const Tensor& times, const 
         throw std::runtime_error("prep_bwd: 13 gradient buffers expected");
     }
     const OptT c0 = f32c(v_means), c1 = f32c(v_quats), c2 = f32c(v_scales), c3 = f32c(v_opac), c4 = f32c(v_colors);
+    const int64_t K = times.dim() == 2 ? times.size(0) : 1;
     if (g_half) {
         auto h = [](const Tensor& t) { return static_cast<uint16_t*>(dp(t)); };
-        check(api.prep_bwd_f16((int)Ns, (int)Nd, fp(times), static_cast<const int64_t*>(dp(d_ncp)), fp(d_trbf),
+        check(api.prep_bwd_f16((int)K, (int)Ns, (int)Nd, fp(times), static_cast<const int64_t*>(dp(d_ncp)), fp(d_trbf),
                                fp(scales), fp(opac), fp(c0), fp(c1), fp(c2), fp(c3), fp(c4), fpw(g[0]), h(g[1]),
                                h(g[2]), h(g[3]), h(g[4]), h(g[5]), fpw(g[6]), h(g[7]), h(g[8]), h(g[9]), h(g[10]),
                                h(g[11]), h(g[12]), (int)accumulate, sp(stream)),
               "mobgs_prep_bwd");
     } else {
-        check(api.prep_bwd((int)Ns, (int)Nd, fp(times), static_cast<const int64_t*>(dp(d_ncp)), fp(d_trbf),
+        check(api.prep_bwd((int)K, (int)Ns, (int)Nd, fp(times), static_cast<const int64_t*>(dp(d_ncp)), fp(d_trbf),
                            fp(scales), fp(opac), fp(c0), fp(c1), fp(c2), fp(c3), fp(c4), fpw(g[0]), fpw(g[1]),
                            fpw(g[2]), fpw(g[3]), fpw(g[4]), fpw(g[5]), fpw(g[6]), fpw(g[7]), fpw(g[8]), fpw(g[9]),
                            fpw(g[10]), fpw(g[11]), fpw(g[12]), (int)accumulate, sp(stream)),

@@ -227,9 +227,17 @@ project_bwd_kernel(int N, const float* __restrict__ means, const float* __restri
                    const float* __restrict__ v_means2d, const float* __restrict__ v_depths,
                    const float* __restrict__ v_conics, float* __restrict__ v_means,
                    float* __restrict__ v_quats, float* __restrict__ v_scales,
-                   float* __restrict__ v_view_partial, int accumulate, int accumulate_scales) {
+                   float* __restrict__ v_view_partial, int accumulate, int accumulate_scales, size_t geom_stride,
+                   size_t scales_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
+    // cameras in parallel (grid.y = C > 1, per-camera geometry): camera c reads / writes its own rows of means, quats
+    // and their gradients, and its own copy of the shared scales' gradient (summed over the cameras afterwards)
+    means += 3 * c * geom_stride;
+    quats += 4 * c * geom_stride;
+    v_means += 3 * c * geom_stride;
+    v_quats += 4 * c * geom_stride;
+    v_scales += 3 * c * scales_stride;
     const Cam cam = load_cam(viewmats, Ks, c);
     float vR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float vt[3] = {0.f, 0.f, 0.f};
@@ -434,6 +442,16 @@ project_bwd_kernel(int N, const float* __restrict__ means, const float* __restri
     }
 }
 
+// out[i] = sum over the C per-camera copies part[c][i], in camera order (n floats)
+__global__ void __launch_bounds__(256) camera_sum_kernel(int C, size_t n, const float* __restrict__ part,
+                                                          float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = part[i];
+    for (int c = 1; c < C; ++c) acc += part[(size_t)c * n + i];
+    out[i] = acc;
+}
+
 // sums the per-workgroup partial rows: one workgroup per (camera, component), fixed order -> deterministic
 __global__ void __launch_bounds__(256) viewmat_reduce_kernel(int nblocks, const float* __restrict__ partial,
                                                                float* __restrict__ v_viewmats) {
@@ -492,7 +510,10 @@ int mobgs::project_fwd_launch(int C, int N, const float* means, const float* qua
 
 extern "C" {
 
-size_t mobgs_project_bwd_scratch_floats(int C, int N) { return (size_t)C * ((N + 255) / 256) * 16; }
+// [C, blocks, 16] camera-gradient partials, then (C > 1) [C, N, 3] per-camera copies of the scales' gradient
+size_t mobgs_project_bwd_scratch_floats(int C, int N) {
+    return (size_t)C * ((N + 255) / 256) * 16 + (C > 1 ? (size_t)C * N * 3 : 0);
+}
 
 int mobgs_project_bwd(int C, int N, const float* means, const float* quats, const float* scales,
                       const float* viewmats, const float* Ks, int width, int height, float eps2d,
@@ -519,6 +540,20 @@ int mobgs_project_bwd_ex(int C, int N, int geometry_per_camera, const float* mea
         return check_launch("project_bwd memset");
     }
     const int nblocks = (N + 255) / 256;
+    if (geometry_per_camera && C > 1) {
+        // ONE launch for all cameras (the K sub-frames of a blurry view: 8 launches of ~8 us at 30 k splats otherwise):
+        // only the scales' gradient is shared -- every camera writes its own copy, summed in camera order (the order of
+        // the sequential accumulation below: same bits)
+        float* scales_partial = v_viewmats_partial + (size_t)C * nblocks * 16;
+        hipLaunchKernelGGL(project_bwd_kernel, dim3(nblocks, C), dim3(256), 0, (hipStream_t)stream, N, means, quats, scales,
+                           viewmats, Ks, width, height, eps2d, radii, conics, v_means2d, v_depths, v_conics, v_means,
+                           v_quats, scales_partial, v_viewmats_partial, 0, 0, (size_t)N, (size_t)N);
+        hipLaunchKernelGGL(camera_sum_kernel, dim3((3 * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, C,
+                           (size_t)3 * N, scales_partial, v_scales);
+        hipLaunchKernelGGL(viewmat_reduce_kernel, dim3(16 * C), dim3(256), 0, (hipStream_t)stream, nblocks,
+                           v_viewmats_partial, v_viewmats);
+        return check_launch("project_bwd_kernel");
+    }
     // one launch per camera so that the accumulation into v_means/v_quats/v_scales is race-free and ordered
     for (int c = 0; c < C; ++c) {
         hipLaunchKernelGGL(project_bwd_kernel, dim3(nblocks, 1), dim3(256), 0, (hipStream_t)stream, N,
@@ -528,7 +563,7 @@ int mobgs_project_bwd_ex(int C, int N, int geometry_per_camera, const float* mea
                            v_depths ? v_depths + (size_t)c * N : nullptr,
                            v_conics ? v_conics + (size_t)3 * c * N : nullptr, v_means + 3 * c * gs, v_quats + 4 * c * gs,
                            v_scales, v_viewmats_partial + (size_t)c * nblocks * 16,
-                           (c > 0 && !geometry_per_camera) ? 1 : 0, c > 0 ? 1 : 0);
+                           (c > 0 && !geometry_per_camera) ? 1 : 0, c > 0 ? 1 : 0, (size_t)0, (size_t)0);
     }
     hipLaunchKernelGGL(viewmat_reduce_kernel, dim3(16 * C), dim3(256), 0, (hipStream_t)stream, nblocks,
                        v_viewmats_partial, v_viewmats);

@@ -366,7 +366,7 @@ _bgK_cache = {}  # K -> DerivedCache of the [K,9] background rows
 def render_many(viewpoint_cameras, stat_pc, dyn_pc, pipe, bg_color, delta_exposures=None):
     """[render(cam_k, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=d_k) for k] in lean mode -- the K latent sub-frames
     of one blurry view (train.py:502-518: same Gaussians at K exposure times through K warped cameras) -- as ONE batch of
-    C = K cameras: K per-splat preps, then ONE projection (every camera with its own positions / rotations / colours of
+    C = K cameras: ONE per-splat prep for the K instants, ONE projection (every camera with its own positions / rotations / colours of
     the N splats: MobgsTuning.geometry_per_camera), ONE binning + sort, ONE compositing pass forward and backward over
     K x the tiles, K decodes.  Not in the reference (it renders the sub-frames one call at a time).  On large scenes a
     single render already fills the chip and nothing is gained; at the reference's own operating point (512x288, ~30 k
@@ -383,11 +383,8 @@ def render_many(viewpoint_cameras, stat_pc, dyn_pc, pipe, bg_color, delta_exposu
     bg1 = _bg9(bg_color)
     bgK = _bgK_cache.setdefault(K, DerivedCache()).get((bg1,), lambda: bg1.expand(K, 9).contiguous())
     w1, w2 = _decoder_weights(dyn_pc)
-    preps = [_prep(stat_pc, dyn_pc, _times(c, d, dev)) for c, d in zip(cams, deltas)]
-    means = torch.stack([p[0] for p in preps])
-    quats = torch.stack([p[1] for p in preps])
-    cols = torch.stack([p[4] for p in preps])
-    scales, opac = preps[0][2], preps[0][3]   # activations of time-independent leaves: identical for every k
+    # the K instants in ONE prep launch (and one in the backward pass, which sums the leaf gradients in instant order)
+    means, quats, scales, opac, cols = _prep(stat_pc, dyn_pc, torch.stack([_times(c, d, dev) for c, d in zip(cams, deltas)]))
     viewmats = torch.stack([c.world_view_transform.transpose(0, 1) for c in cams])
     Ks = torch.stack([c.K for c in cams])
     sp = _R.SharedProjection(means, quats, scales, opac, viewmats, Ks, W, H, pack_colors=cols)
@@ -549,11 +546,7 @@ def _get_flow_exposures(cam, stat_pc, dyn_pc, bg_color, deltas, mid):
     bg1 = _bg9(bg_color)
     w1, w2 = _decoder_weights(dyn_pc)
     Ns = stat_pc.get_xyz.shape[0]
-    preps = [_prep(stat_pc, dyn_pc, _times(cam, d, dev)) for d in deltas]
-    means = torch.stack([p[0] for p in preps])
-    quats = torch.stack([p[1] for p in preps])
-    cols = torch.stack([p[4] for p in preps])                      # [G,N,9]
-    scales, opac = preps[0][2], preps[0][3]
+    means, quats, scales, opac, cols = _prep(stat_pc, dyn_pc, torch.stack([_times(cam, d, dev) for d in deltas]))  # cols [G,N,9]
     sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None].expand(G, 4, 4), cam.K[None].expand(G, 3, 3), W, H)
     bgG = _bgK_cache.setdefault(G, DerivedCache()).get((bg1,), lambda: bg1.expand(G, 9).contiguous())
     bg11 = _bgK_cache.setdefault(("11", G), DerivedCache()).get(
@@ -564,11 +557,13 @@ def _get_flow_exposures(cam, stat_pc, dyn_pc, bg_color, deltas, mid):
     rays = _rays_of(cam)
     outs = []
     pix = None
-    for g, (i12, a, la) in enumerate(zip(img12.unbind(0), alphas.unbind(0), latent_alpha.unbind(0))):
+    # (unbind, not e2m[g]: one autograd node whose backward stacks the G cotangents; a select per g zero-fills and copies
+    # the whole [G,N,2] array G times)
+    for i12, a, la, e2m_g in zip(img12.unbind(0), alphas.unbind(0), latent_alpha.unbind(0), e2m.unbind(0)):
         latent_img, e2m_img = decode_with_channels(i12, a, rays, w1, w2, 9, 2)
         if pix is None:
             pix = _pixel_grid(cam, W, H, e2m_img)
-        outs.append([pix + e2m_img[None], (pix, e2m[g]), latent_img, la[None]])
+        outs.append([pix + e2m_img[None], (pix, e2m_g), latent_img, la[None]])
     return outs
 
 

@@ -125,7 +125,9 @@ def active_sink():
 
 
 class PrepSplats(torch.autograd.Function):
-    """Leaves of the static + dynamic Gaussian sets -> concatenated operator-level inputs at one time instant.
+    """Leaves of the static + dynamic Gaussian sets -> concatenated operator-level inputs at one time instant
+    (times [2]) or at K instants in one launch (times [K,2]: means [K,N,3], quats [K,N,4], colors [K,N,9]; scales and
+    opacities do not depend on time and come once).
 
     Replaces /root/reference/gaussian_renderer/__init__.py:69-125,181-185 (see csrc/prep.hip)."""
 
@@ -157,13 +159,16 @@ class PrepSplats(torch.autograd.Function):
         Ns, Nd = s_xyz.shape[0], d_control.shape[0]
         N = Ns + Nd
         dev = times.device
-        means = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        quats = torch.empty(N, 4, dtype=torch.float32, device=dev)
+        # times [2]: one instant; times [K,2]: K instants in one launch, means / quats / colors get a leading K
+        lead = (times.shape[0],) if times.dim() == 2 else ()
+        K = lead[0] if lead else 1
+        means = torch.empty(*lead, N, 3, dtype=torch.float32, device=dev)
+        quats = torch.empty(*lead, N, 4, dtype=torch.float32, device=dev)
         scales = torch.empty(N, 3, dtype=torch.float32, device=dev)
         opac = torch.empty(N, dtype=torch.float32, device=dev)
-        colors = torch.empty(N, 9, dtype=torch.float32, device=dev)
-        fwd = lib.mobgs_prep_fwd_f16 if half else lib.mobgs_prep_fwd
-        check(fwd(Ns, Nd, ptr(times), ptr(s_xyz), ptr(s_scaling), ptr(s_rotation), ptr(s_opacity), ptr(s_fdc),
+        colors = torch.empty(*lead, N, 9, dtype=torch.float32, device=dev)
+        fwd = lib.mobgs_prep_fwd_many_f16 if half else lib.mobgs_prep_fwd_many
+        check(fwd(K, Ns, Nd, ptr(times), ptr(s_xyz), ptr(s_scaling), ptr(s_rotation), ptr(s_opacity), ptr(s_fdc),
                   ptr(s_ft), ptr(d_control), ptr(d_ncp), ptr(d_scaling), ptr(d_rotation), ptr(d_omega),
                   ptr(d_opacity), ptr(d_fdc), ptr(d_ft), ptr(d_trbf), ptr(means), ptr(quats), ptr(scales), ptr(opac),
                   ptr(colors), stream()), "mobgs_prep_fwd")
@@ -208,8 +213,8 @@ class PrepSplats(torch.autograd.Function):
                 sink.buffers = g
         if F is None:
             c = [f32c(v) if v is not None else None for v in (v_means, v_quats, v_scales, v_opac, v_colors)]
-            bwd = lib.mobgs_prep_bwd_f16 if g_half else lib.mobgs_prep_bwd
-            check(bwd(Ns, Nd, ptr(times), ptr(d_ncp), ptr(d_trbf), ptr(scales), ptr(opac), ptr(c[0]), ptr(c[1]),
+            bwd = lib.mobgs_prep_bwd_many_f16 if g_half else lib.mobgs_prep_bwd_many
+            check(bwd(times.shape[0] if times.dim() == 2 else 1, Ns, Nd, ptr(times), ptr(d_ncp), ptr(d_trbf), ptr(scales), ptr(opac), ptr(c[0]), ptr(c[1]),
                       ptr(c[2]), ptr(c[3]), ptr(c[4]), ptr(g["s_xyz"]), ptr(g["s_scaling"]), ptr(g["s_rotation"]),
                       ptr(g["s_opacity"]), ptr(g["s_fdc"]), ptr(g["s_ft"]), ptr(g["d_control"]), ptr(g["d_scaling"]),
                       ptr(g["d_rotation"]), ptr(g["d_omega"]), ptr(g["d_opacity"]), ptr(g["d_fdc"]), ptr(g["d_ft"]),

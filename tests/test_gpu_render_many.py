@@ -46,3 +46,48 @@ def test_render_many_equals_separate_renders(hip_device, size, ns, nd):
         sc = float(gr.abs().max())
         assert torch.allclose(p.grad, gr, rtol=1e-4, atol=2e-5 * sc + 1e-12), \
             f"leaf {i}: max err {float((p.grad - gr).abs().max()):.3e} of {sc:.3e}"
+
+
+def test_prep_of_k_instants_in_one_launch_equals_k_launches(hip_device):
+    """ops.PrepSplats with times [K,2] (mobgs_prep_{fwd,bwd}_many): row block k of means / quats / colours is the
+    single-instant result bit for bit, and the leaf gradients are those of K single-instant backward passes accumulated
+    in instant order -- bit for bit as well (LeafGradSink buffers: instant 0 writes, the others add)."""
+    import bench as B
+    from mobgs_amd.gaussian_renderer import _prep
+    dev = hip_device
+    _, _, stat, dyn, _ = B.build_scene(dev, 700, 400, 64, 48, seed=7)
+    K = 4
+    g = torch.Generator().manual_seed(5)
+    times = torch.tensor([[0.21, 0.21], [0.3, 0.3], [1.07, 1.0], [-0.04, 0.0]], device=dev)
+    N = 1100
+    cot = [torch.randn(K, N, 3, generator=g).to(dev), torch.randn(K, N, 4, generator=g).to(dev),
+           torch.randn(N, 3, generator=g).to(dev), torch.randn(N, generator=g).to(dev),
+           torch.randn(K, N, 9, generator=g).to(dev)]
+    params = B.leaves(stat, dyn)
+
+    def run(batched):
+        for p in params:
+            p.grad = None
+        if batched:
+            out = _prep(stat, dyn, times)
+            torch.autograd.backward(list(out), cot)
+        else:
+            outs = [_prep(stat, dyn, times[k]) for k in range(K)]
+            heads, grads = [], []
+            for k, o in enumerate(outs):   # scales / opacities: the cotangent exists once -> on instant 0
+                heads += [o[0], o[1], o[4]] + ([o[2], o[3]] if k == 0 else [])
+                grads += [cot[0][k], cot[1][k], cot[4][k]] + ([cot[2], cot[3]] if k == 0 else [])
+            torch.autograd.backward(heads, grads)
+            out = (torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]), outs[0][2], outs[0][3],
+                   torch.stack([o[4] for o in outs]))
+        return [t.detach().clone() for t in out], [p.grad.clone() for p in params if p.grad is not None]
+
+    a, ga = run(True)
+    b, gb = run(False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert len(ga) == len(gb) and len(ga) >= 13
+    for i, (x, y) in enumerate(zip(ga, gb)):
+        # autograd sums the K single-instant gradients pairwise in its own order; the batched kernel adds them in
+        # instant order: equal to rounding of K - 1 additions
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-6 * float(y.abs().max()) + 1e-12), (i, float((x - y).abs().max()))
