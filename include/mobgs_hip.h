@@ -471,6 +471,22 @@ int mobgs_decoder_bwd(int P, int CF, int has_depth, int width, const float* feat
                       float* v_rays, float* w_partial, float* g_w1, float* g_w2, float* g_c2w, int g_c2w_floats,
                       int accumulate_wgrad, void* stream);
 
+/* The decoder for a BATCH of C images in one launch (the K sub-frames of a blurry view): feat_hw [C,P,CF], alphas [C,P],
+ * rgb [C,3,P], depth [C,P] (and the cotangents alike); *_stride = floats between consecutive images' ray maps /
+ * intrinsics / poses, 0 = shared by all images.  The weight gradients are sums over all images (one fixed-order
+ * reduction); g_c2w [C, g_c2w_floats], w_partial [C * mobgs_decoder_bwd_blocks(P), 102].  A shared ray map / pose
+ * cannot receive a gradient when C > 1.  C = 1 is the single-image call. */
+int mobgs_decoder_fwd_many(int C, int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
+                           const float* rays, int64_t rays_stride, const float* ray_intr, int intr_stride,
+                           const float* ray_c2w, int c2w_stride, const float* w1, const float* w2, float* rgb,
+                           float* depth, void* stream);
+int mobgs_decoder_bwd_many(int C, int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
+                           const float* rays, int64_t rays_stride, const float* ray_intr, int intr_stride,
+                           const float* ray_c2w, int c2w_stride, const float* w1, const float* w2, const float* v_rgb,
+                           const float* v_depth, float* v_feat_hw, float* v_alphas, float* v_rays, float* w_partial,
+                           float* g_w1, float* g_w2, float* g_c2w, int g_c2w_floats, int accumulate_wgrad,
+                           void* stream);
+
 /* ---- K10: deformation network (the API the reference exposes as scene.deformation.deform_network) -----
  * /root/reference/scene/hexplane.py:75-108,165-187 (HexPlane multi-resolution bilinear planes, product over the
  * 6 planes of a level, concat over 3 levels -> 96 features); /root/reference/scene/deformation.py:158-199

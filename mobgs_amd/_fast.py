@@ -15,7 +15,7 @@ from .build import FAST_PATH, build_fastpath, fastpath_is_stale
 
 _SYMBOLS = ("mobgs_last_error", "mobgs_record_stride", "mobgs_prep_fwd_many", "mobgs_prep_fwd_many_f16",
             "mobgs_prep_bwd_many", "mobgs_prep_bwd_many_f16", "mobgs_raster_fwd", "mobgs_raster_bwd", "mobgs_raster_bwd_reduce",
-            "mobgs_decoder_fwd", "mobgs_decoder_bwd", "mobgs_decoder_bwd_blocks", "mobgs_project_bwd",
+            "mobgs_decoder_fwd_many", "mobgs_decoder_bwd_many", "mobgs_decoder_bwd_blocks", "mobgs_project_bwd",
             "mobgs_project_bwd_ex",
             "mobgs_project_bwd_scratch_floats", "mobgs_project_and_bin_speculative", "mobgs_tile_order_len",
             "mobgs_keep_scan_len", "mobgs_isect_scratch_bytes", "mobgs_raster_channels_supported")

@@ -82,15 +82,30 @@ __device__ inline void pixel_ray(const RayCam& c, int p, int W, float r[6], floa
     }
 }
 
+// per-image strides of a batched launch (grid.y = images; all 0 for one image): floats between consecutive images' ray
+// maps / intrinsics / poses (0 = shared by all images)
+struct DecBatch {
+    size_t rays_stride;
+    int intr_stride, c2w_stride;
+};
+
 // feat_hw: [P, CF] channels-last with CF >= 9 (+1 accumulated depth when has_depth)
 __global__ void __launch_bounds__(DEC_THREADS)
 decoder_fwd_kernel(int P, int CF, int has_depth, int width, const float* __restrict__ feat_hw,
                    const float* __restrict__ alphas, const float* __restrict__ rays,
                    const float* __restrict__ ray_intr, const float* __restrict__ ray_c2w,
                    const float* __restrict__ w1, const float* __restrict__ w2,
-                   float* __restrict__ rgb, float* __restrict__ depth) {
+                   float* __restrict__ rgb, float* __restrict__ depth, DecBatch bt) {
+    {   // image blockIdx.y of a batch (one launch decodes the K sub-frames of a blurry view)
+        const size_t cb = blockIdx.y;
+        feat_hw += cb * P * CF;
+        if (alphas) alphas += cb * P;
+        if (rays) rays += cb * bt.rays_stride;
+        rgb += cb * 3 * P;
+        if (depth) depth += cb * P;
+    }
     RayCam cam;
-    if (!rays) cam = load_raycam(ray_intr, ray_c2w);
+    if (!rays) cam = load_raycam(ray_intr + blockIdx.y * bt.intr_stride, ray_c2w + blockIdx.y * bt.c2w_stride);
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         const float* f = feat_hw + (size_t)p * CF;
         float x[12];
@@ -166,11 +181,23 @@ decoder_bwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
                    const float* __restrict__ w1,
                    const float* __restrict__ w2, const float* __restrict__ v_rgb, const float* __restrict__ v_depth,
                    float* __restrict__ v_feat_hw, float* __restrict__ v_alphas, float* __restrict__ v_rays,
-                   float* __restrict__ w_partial) {
+                   float* __restrict__ w_partial, DecBatch bt) {
     __shared__ __attribute__((aligned(16))) float s_a[DEC_THREADS / 64][64][8];    // vh[6] (+2 zeros) per pixel
     __shared__ __attribute__((aligned(16))) float s_b[DEC_THREADS / 64][64][12];   // x[12] per pixel
+    {   // image blockIdx.y of a batch; its partial rows follow those of the images before it
+        const size_t cb = blockIdx.y;
+        feat_hw += cb * P * CF;
+        if (alphas) alphas += cb * P;
+        if (RAY_MAP) rays += cb * bt.rays_stride;
+        v_rgb += cb * 3 * P;
+        if (v_depth) v_depth += cb * P;
+        v_feat_hw += cb * P * CF;
+        if (v_alphas) v_alphas += cb * P;
+        if (v_rays) v_rays += cb * 6 * P;
+        w_partial += cb * gridDim.x * NRED;
+    }
     RayCam cam;
-    if (!RAY_MAP) cam = load_raycam(ray_intr, ray_c2w);
+    if (!RAY_MAP) cam = load_raycam(ray_intr + blockIdx.y * bt.intr_stride, ray_c2w + blockIdx.y * bt.c2w_stride);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;  // MFMA operand coordinates of this lane
     float gw[NACC];
@@ -338,17 +365,30 @@ decoder_bwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
 // one workgroup per weight component: 102 workgroups x 256 threads sum the per-workgroup partial rows in a fixed
 // order.  `accumulate`: the weight gradients are ADDED to g_w1 / g_w2 (several renders of one backward pass writing
 // into the same .grad).  Workgroups past the 102nd clear the fourth row of a 4 x 4 pose gradient.
+// A batch of C images (grid.y): the weight gradients are sums over the rows of ALL images (workgroups with
+// blockIdx.y = 0), the pose gradient of image c over that image's rows only (g_c2w + c * c2w_floats).
 __global__ void __launch_bounds__(256) decoder_wgrad_reduce_kernel(int nblocks, const float* __restrict__ w_partial,
                                                                      float* __restrict__ g_w1,
                                                                      float* __restrict__ g_w2,
-                                                                     float* __restrict__ g_c2w, int accumulate) {
+                                                                     float* __restrict__ g_c2w, int accumulate,
+                                                                     int c2w_floats) {
     const int k = blockIdx.x;
+    const int img = blockIdx.y;
+    if (g_c2w) g_c2w += (size_t)img * c2w_floats;
     if (k >= NRED) {
         if (threadIdx.x == 0) g_c2w[k - 90] = 0.f;
         return;
     }
+    int first = 0, count = nblocks * (int)gridDim.y;     // weights: every row
+    if (k >= 90) {                                        // pose: the rows of this image
+        first = img * nblocks;
+        count = nblocks;
+    } else if (img != 0) {
+        return;
+    }
+    w_partial += (size_t)first * NRED;
     float s = 0.f;
-    for (int b = threadIdx.x; b < nblocks; b += 256) s += w_partial[(size_t)b * NRED + k];
+    for (int b = threadIdx.x; b < count; b += 256) s += w_partial[(size_t)b * NRED + k];
     s = wave_sum_f(s);
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -379,19 +419,61 @@ static int decoder_grid(int P) {
 
 int mobgs_decoder_bwd_blocks(int P) { return decoder_grid(P); }
 
-int mobgs_decoder_fwd(int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
-                      const float* rays, const float* ray_intr, const float* ray_c2w, const float* w1,
-                      const float* w2, float* rgb, float* depth, void* stream) {
-    if (P < 0 || CF < 9 + (has_depth ? 1 : 0) || (!rays && (!ray_intr || !ray_c2w || width <= 0))) {
-        set_error("mobgs_decoder_fwd: bad arguments P=%d CF=%d (rays or ray_intr+ray_c2w+width required)", P, CF);
-        return MOBGS_E_INVALID;
+static int decoder_args_ok(const char* who, int C, int P, int CF, int has_depth, int width, const float* rays,
+                           const float* ray_intr, const float* ray_c2w) {
+    if (C < 1 || C > 65535 || P < 0 || CF < 9 + (has_depth ? 1 : 0) || (!rays && (!ray_intr || !ray_c2w || width <= 0))) {
+        set_error("%s: bad arguments C=%d P=%d CF=%d (rays or ray_intr+ray_c2w+width required)", who, C, P, CF);
+        return 0;
     }
+    return 1;
+}
+
+int mobgs_decoder_fwd_many(int C, int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
+                           const float* rays, int64_t rays_stride, const float* ray_intr, int intr_stride,
+                           const float* ray_c2w, int c2w_stride, const float* w1, const float* w2, float* rgb,
+                           float* depth, void* stream) {
+    if (!decoder_args_ok("mobgs_decoder_fwd", C, P, CF, has_depth, width, rays, ray_intr, ray_c2w)) return MOBGS_E_INVALID;
     if (P == 0) return MOBGS_OK;
     int g = (P + DEC_THREADS - 1) / DEC_THREADS;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(decoder_fwd_kernel, dim3(g), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth, width,
-                       feat_hw, alphas, rays, ray_intr, ray_c2w, w1, w2, rgb, depth);
+    hipLaunchKernelGGL(decoder_fwd_kernel, dim3(g, C), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth, width,
+                       feat_hw, alphas, rays, ray_intr, ray_c2w, w1, w2, rgb, depth,
+                       DecBatch{(size_t)rays_stride, intr_stride, c2w_stride});
     return check_launch("decoder_fwd_kernel");
+}
+
+int mobgs_decoder_fwd(int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
+                      const float* rays, const float* ray_intr, const float* ray_c2w, const float* w1,
+                      const float* w2, float* rgb, float* depth, void* stream) {
+    return mobgs_decoder_fwd_many(1, P, CF, has_depth, width, feat_hw, alphas, rays, 0, ray_intr, 0, ray_c2w, 0, w1, w2,
+                                  rgb, depth, stream);
+}
+
+int mobgs_decoder_bwd_many(int C, int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
+                           const float* rays, int64_t rays_stride, const float* ray_intr, int intr_stride,
+                           const float* ray_c2w, int c2w_stride, const float* w1, const float* w2, const float* v_rgb,
+                           const float* v_depth, float* v_feat_hw, float* v_alphas, float* v_rays, float* w_partial,
+                           float* g_w1, float* g_w2, float* g_c2w, int g_c2w_floats, int accumulate_wgrad,
+                           void* stream) {
+    if (!decoder_args_ok("mobgs_decoder_bwd", C, P, CF, has_depth, width, rays, ray_intr, ray_c2w) || P == 0 ||
+        (g_c2w && g_c2w_floats != 12 && g_c2w_floats != 16)) {
+        if (P == 0) set_error("mobgs_decoder_bwd: P = 0");
+        return MOBGS_E_INVALID;
+    }
+    if (C > 1 && ((v_rays && rays_stride == 0) || (g_c2w && c2w_stride == 0))) {
+        set_error("mobgs_decoder_bwd_many: a ray map / pose shared by the images of a batch cannot receive a gradient "
+                  "(one gradient per image is written)");
+        return MOBGS_E_INVALID;
+    }
+    const int g = decoder_grid(P);
+    hipLaunchKernelGGL(rays ? decoder_bwd_kernel<true> : decoder_bwd_kernel<false>, dim3(g, C), dim3(DEC_THREADS), 0,
+                       (hipStream_t)stream, P, CF, has_depth, width,
+                       feat_hw, alphas, rays, ray_intr, ray_c2w, g_c2w ? 1 : 0, w1, w2, v_rgb, v_depth, v_feat_hw,
+                       v_alphas, v_rays, w_partial, DecBatch{(size_t)rays_stride, intr_stride, c2w_stride});
+    const int nred = NRED + ((g_c2w && g_c2w_floats == 16) ? 4 : 0);
+    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3(nred, C), dim3(256), 0, (hipStream_t)stream, g, w_partial, g_w1,
+                       g_w2, g_c2w, accumulate_wgrad, g_c2w_floats);
+    return check_launch("decoder_bwd_kernel");
 }
 
 int mobgs_decoder_bwd(int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
@@ -399,20 +481,9 @@ int mobgs_decoder_bwd(int P, int CF, int has_depth, int width, const float* feat
                       const float* w2, const float* v_rgb, const float* v_depth, float* v_feat_hw, float* v_alphas,
                       float* v_rays, float* w_partial, float* g_w1, float* g_w2, float* g_c2w, int g_c2w_floats,
                       int accumulate_wgrad, void* stream) {
-    if (P <= 0 || CF < 9 + (has_depth ? 1 : 0) || (!rays && (!ray_intr || !ray_c2w || width <= 0)) ||
-        (g_c2w && g_c2w_floats != 12 && g_c2w_floats != 16)) {
-        set_error("mobgs_decoder_bwd: bad arguments P=%d CF=%d", P, CF);
-        return MOBGS_E_INVALID;
-    }
-    const int g = decoder_grid(P);
-    hipLaunchKernelGGL(rays ? decoder_bwd_kernel<true> : decoder_bwd_kernel<false>, dim3(g), dim3(DEC_THREADS), 0,
-                       (hipStream_t)stream, P, CF, has_depth, width,
-                       feat_hw, alphas, rays, ray_intr, ray_c2w, g_c2w ? 1 : 0, w1, w2, v_rgb, v_depth, v_feat_hw,
-                       v_alphas, v_rays, w_partial);
-    const int nred = NRED + ((g_c2w && g_c2w_floats == 16) ? 4 : 0);
-    hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3(nred), dim3(256), 0, (hipStream_t)stream, g, w_partial, g_w1,
-                       g_w2, g_c2w, accumulate_wgrad);
-    return check_launch("decoder_bwd_kernel");
+    return mobgs_decoder_bwd_many(1, P, CF, has_depth, width, feat_hw, alphas, rays, 0, ray_intr, 0, ray_c2w, 0, w1, w2,
+                                  v_rgb, v_depth, v_feat_hw, v_alphas, v_rays, w_partial, g_w1, g_w2, g_c2w,
+                                  g_c2w_floats, accumulate_wgrad, stream);
 }
 
 }  // extern "C"

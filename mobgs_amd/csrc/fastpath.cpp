@@ -35,8 +35,8 @@ struct Api {
     decltype(&mobgs_raster_fwd) raster_fwd = nullptr;
     decltype(&mobgs_raster_bwd) raster_bwd = nullptr;
     decltype(&mobgs_raster_bwd_reduce) raster_bwd_reduce = nullptr;
-    decltype(&mobgs_decoder_fwd) decoder_fwd = nullptr;
-    decltype(&mobgs_decoder_bwd) decoder_bwd = nullptr;
+    decltype(&mobgs_decoder_fwd_many) decoder_fwd = nullptr;
+    decltype(&mobgs_decoder_bwd_many) decoder_bwd = nullptr;
     decltype(&mobgs_decoder_bwd_blocks) decoder_bwd_blocks = nullptr;
     decltype(&mobgs_project_bwd) project_bwd = nullptr;
     decltype(&mobgs_project_bwd_ex) project_bwd_ex = nullptr;
@@ -66,8 +66,8 @@ void bind(const std::unordered_map<std::string, uint64_t>& m) {
     take(m, "mobgs_raster_fwd", api.raster_fwd);
     take(m, "mobgs_raster_bwd", api.raster_bwd);
     take(m, "mobgs_raster_bwd_reduce", api.raster_bwd_reduce);
-    take(m, "mobgs_decoder_fwd", api.decoder_fwd);
-    take(m, "mobgs_decoder_bwd", api.decoder_bwd);
+    take(m, "mobgs_decoder_fwd_many", api.decoder_fwd);
+    take(m, "mobgs_decoder_bwd_many", api.decoder_bwd);
     take(m, "mobgs_decoder_bwd_blocks", api.decoder_bwd_blocks);
     take(m, "mobgs_project_bwd", api.project_bwd);
     take(m, "mobgs_project_bwd_ex", api.project_bwd_ex);
@@ -261,15 +261,33 @@ raster_bwd_reduce(int64_t C, int64_t N, int64_t channels, int64_t has_extra, con
 }
 
 // ---- ops.Decode ----------------------------------------------------------------------------------------------------
-// -> (rgb [3,H,W], depth [H,W] | None)
+// feat_hw [H,W,CF] -> (rgb [3,H,W], depth [H,W] | None); a batch feat_hw [C,H,W,CF] -> ([C,3,H,W], [C,H,W] | None) in one
+// launch: ray map [6,H,W] shared or [C,6,H,W]; intrinsics [4] or [C,4]; pose [3|4,4] shared or [C,3|4,4]
+struct DecStrides {
+    int64_t C, rays, intr, c2w;
+};
+static DecStrides decoder_strides(int64_t H, int64_t W, int64_t CF, const Tensor& feat_hw, const OptT& rays,
+                                  const OptT& intr, const OptT& c2w) {
+    DecStrides d{feat_hw.numel() / (H * W * CF), 0, 0, 0};
+    if (d.C > 1) {
+        if (rays.has_value() && rays->defined() && rays->numel() == d.C * 6 * H * W) d.rays = 6 * H * W;
+        if (intr.has_value() && intr->defined() && intr->numel() == d.C * 4) d.intr = 4;
+        if (c2w.has_value() && c2w->defined() && c2w->dim() == 3 && c2w->size(0) == d.C) d.c2w = c2w->numel() / d.C;
+    }
+    return d;
+}
+
 std::tuple<Tensor, OptT> decoder_fwd(int64_t H, int64_t W, int64_t CF, bool has_depth, const Tensor& feat_hw,
                                      const OptT& alphas, const OptT& rays, const OptT& intr, const OptT& c2w,
                                      const Tensor& w1, const Tensor& w2, int64_t stream) {
     const auto f = feat_hw.options();
-    Tensor rgb = at::empty({3, H, W}, f);
-    OptT depth = has_depth ? OptT(at::empty({H, W}, f)) : OptT();
-    check(api.decoder_fwd((int)(H * W), (int)CF, has_depth ? 1 : 0, (int)W, fp(feat_hw), fp(alphas), fp(rays),
-                          fp(intr), fp(c2w), fp(w1), fp(w2), fpw(rgb), fpw(depth), sp(stream)),
+    const DecStrides d = decoder_strides(H, W, CF, feat_hw, rays, intr, c2w);
+    const bool batch = feat_hw.dim() == 4;
+    Tensor rgb = batch ? at::empty({d.C, 3, H, W}, f) : at::empty({3, H, W}, f);
+    OptT depth = has_depth ? OptT(batch ? at::empty({d.C, H, W}, f) : at::empty({H, W}, f)) : OptT();
+    check(api.decoder_fwd((int)d.C, (int)(H * W), (int)CF, has_depth ? 1 : 0, (int)W, fp(feat_hw), fp(alphas), fp(rays),
+                          d.rays, fp(intr), (int)d.intr, fp(c2w), (int)d.c2w, fp(w1), fp(w2), fpw(rgb), fpw(depth),
+                          sp(stream)),
           "mobgs_decoder_fwd");
     return {rgb, depth};
 }
@@ -283,19 +301,21 @@ decoder_bwd(int64_t H, int64_t W, int64_t CF, bool has_depth, const Tensor& feat
             bool c2w_needs_grad, const OptT& g_w1_in, const OptT& g_w2_in, int64_t accumulate, int64_t stream) {
     const auto f = feat_hw.options();
     const int64_t P = H * W;
-    Tensor v_rgb = (v_rgb_in.has_value() && v_rgb_in->defined()) ? f32c(*v_rgb_in) : at::zeros({3, H, W}, f);
+    const DecStrides d = decoder_strides(H, W, CF, feat_hw, rays, intr, c2w);
+    Tensor v_rgb = (v_rgb_in.has_value() && v_rgb_in->defined()) ? f32c(*v_rgb_in) : at::zeros({d.C, 3, H, W}, f);
     OptT v_depth = has_depth ? f32c(v_depth_in) : OptT();
     Tensor v_feat = at::empty(feat_shape, f);
     OptT v_alphas = has_depth ? OptT(at::empty(alphas->sizes(), f)) : OptT();
     OptT v_rays = rays_need_grad ? OptT(at::empty_like(*rays)) : OptT();
     OptT g_c2w = c2w_needs_grad ? OptT(at::empty_like(*c2w)) : OptT();
-    Tensor partial = at::empty({(int64_t)api.decoder_bwd_blocks((int)P), 102}, f);
+    Tensor partial = at::empty({d.C * (int64_t)api.decoder_bwd_blocks((int)P), 102}, f);
     const bool sunk = g_w1_in.has_value() && g_w1_in->defined();
     Tensor g_w1 = sunk ? *g_w1_in : at::empty_like(w1);
     Tensor g_w2 = sunk ? *g_w2_in : at::empty_like(w2);
-    check(api.decoder_bwd((int)P, (int)CF, has_depth ? 1 : 0, (int)W, fp(feat_hw), fp(alphas), fp(rays), fp(intr),
-                          fp(c2w), fp(w1), fp(w2), fp(v_rgb), fp(v_depth), fpw(v_feat), fpw(v_alphas), fpw(v_rays),
-                          fpw(partial), fpw(g_w1), fpw(g_w2), fpw(g_c2w), g_c2w.has_value() ? (int)g_c2w->numel() : 0,
+    check(api.decoder_bwd((int)d.C, (int)P, (int)CF, has_depth ? 1 : 0, (int)W, fp(feat_hw), fp(alphas), fp(rays), d.rays,
+                          fp(intr), (int)d.intr, fp(c2w), (int)d.c2w, fp(w1), fp(w2), fp(v_rgb), fp(v_depth),
+                          fpw(v_feat), fpw(v_alphas), fpw(v_rays), fpw(partial), fpw(g_w1), fpw(g_w2), fpw(g_c2w),
+                          g_c2w.has_value() ? (int)(g_c2w->numel() / (d.c2w ? d.C : 1)) : 0,
                           sunk ? (int)accumulate : 0, sp(stream)),
           "mobgs_decoder_bwd");
     return {v_feat, v_alphas, v_rays, g_c2w, g_w1, g_w2};

@@ -177,6 +177,17 @@ def _rays_of(cam):
     return cam.cam_ray
 
 
+def _rays_of_many(cams):
+    """(intr [K,4], c2w [K,3|4,4]) for a batched decode of K cameras that all expose their pinhole parameters with
+    poses of one shape; else None (the caller decodes image by image)."""
+    if not (INKERNEL_RAYS and all(hasattr(c, "ray_c2w") and hasattr(c, "ray_intrinsics") for c in cams)):
+        return None
+    poses = [c.ray_c2w for c in cams]
+    if len({tuple(p.shape) for p in poses}) != 1:
+        return None
+    return torch.stack([c.ray_intrinsics for c in cams]), torch.stack(poses)
+
+
 _bg9_cache = DerivedCache()
 
 
@@ -391,6 +402,10 @@ def render_many(viewpoint_cameras, stat_pc, dyn_pc, pipe, bg_color, delta_exposu
 
     def composite_and_decode():
         img, alphas = sp.composite(cols, bgK)                  # [K,H,W,10], [K,H,W,1]
+        rays = _rays_of_many(cams)
+        if rays is not None:   # ONE decoder launch for the K images (forward and backward), per-image camera poses
+            rgb, depth = decode(img, alphas, rays, w1, w2, True)           # [K,3,H,W], [K,H,W]
+            return list(zip(rgb.unbind(0), depth.unbind(0)))
         # unbind: ONE autograd node whose backward stacks the K cotangents (a select per k would zero-fill and copy
         # the whole batch K times)
         return [decode(i, a, _rays_of(c), w1, w2, True) for i, a, c in zip(img.unbind(0), alphas.unbind(0), cams)]
@@ -556,14 +571,13 @@ def _get_flow_exposures(cam, stat_pc, dyn_pc, bg_color, deltas, mid):
     img12, alphas = sp.composite(torch.cat([cols, e2m], dim=-1), bg11)   # [G,H,W,12]
     rays = _rays_of(cam)
     outs = []
-    pix = None
-    # (unbind, not e2m[g]: one autograd node whose backward stacks the G cotangents; a select per g zero-fills and copies
-    # the whole [G,N,2] array G times)
-    for i12, a, la, e2m_g in zip(img12.unbind(0), alphas.unbind(0), latent_alpha.unbind(0), e2m.unbind(0)):
-        latent_img, e2m_img = decode_with_channels(i12, a, rays, w1, w2, 9, 2)
-        if pix is None:
-            pix = _pixel_grid(cam, W, H, e2m_img)
-        outs.append([pix + e2m_img[None], (pix, e2m_g), latent_img, la[None]])
+    # ONE decoder launch for the G images (same camera: shared rays); unbind, not [g]: one autograd node whose backward
+    # stacks the G cotangents (a select per g zero-fills and copies the whole array G times)
+    latent_imgs, e2m_imgs = decode_with_channels(img12, alphas, rays, w1, w2, 9, 2)    # [G,3,H,W], [G,H,W,2]
+    pix = _pixel_grid(cam, W, H, e2m_imgs)
+    exp2mid = pix + e2m_imgs                                                             # one add for the G maps
+    for x2m, li, la, e2m_g in zip(exp2mid.unbind(0), latent_imgs.unbind(0), latent_alpha.unbind(0), e2m.unbind(0)):
+        outs.append([x2m[None], (pix, e2m_g), li, la[None]])
     return outs
 
 

@@ -232,6 +232,16 @@ class PrepSplats(torch.autograd.Function):
                 g["d_ft"], None)
 
 
+def _decoder_strides(C, P, rays, intr, c2w):
+    """Floats between consecutive images' ray maps / intrinsics / poses of a batch of C images (0 = shared)."""
+    if C <= 1:
+        return 0, 0, 0
+    rs = 6 * P if (rays is not None and rays.numel() == C * 6 * P) else 0
+    is_ = 4 if (intr is not None and intr.numel() == 4 * C) else 0
+    cs = c2w.numel() // C if (c2w is not None and c2w.dim() == 3 and c2w.shape[0] == C) else 0
+    return rs, is_, cs
+
+
 class Decode(torch.autograd.Function):
     """Channels-last compositor image (+alpha) -> planar rgb [3,H,W] (+ expected depth [H,W]).
     Rays: either the reference's map `rays` [6,H,W], or (rays=None) the pinhole parameters `intr` = [fx,fy,cx,cy]
@@ -249,20 +259,27 @@ class Decode(torch.autograd.Function):
         alphas_c = f32c(alphas) if alphas is not None else None
         rays_c = f32c(rays) if rays is not None else None
         intr_c = c2w_c = None
+        C = feat_hw.numel() // (P * CF)   # > 1: a batch [C,H,W,CF] decoded in one launch -> rgb [C,3,H,W]
         if rays_c is None:  # pinhole parameters: the kernel reads the 4 intrinsics and the first 12 pose entries
             intr_c, c2w_c = f32c(intr.detach()), f32c(c2w.detach())
-            if intr_c.numel() != 4 or c2w_c.numel() not in (12, 16):
-                raise ValueError("decode: intr must be [fx, fy, cx, cy] and c2w a [3,4] or [4,4] camera-to-world matrix")
+            shared = intr_c.numel() == 4 and c2w_c.numel() in (12, 16) and c2w_c.dim() == 2
+            per_img = C > 1 and intr_c.numel() in (4, 4 * C) and c2w_c.dim() == 3 and c2w_c.shape[0] == C and \
+                c2w_c.numel() in (12 * C, 16 * C)
+            if not (shared or per_img):
+                raise ValueError("decode: intr must be [fx, fy, cx, cy] and c2w a [3,4] or [4,4] camera-to-world matrix "
+                                 "(a batch of C images: [C,4] / [C,3|4,4], or shared ones)")
         F = _fast.get()
         if F is not None:
             rgb, depth = F.decoder_fwd(H, W, CF, bool(has_depth), feat_hw, alphas_c, rays_c, intr_c, c2w_c, w1, w2,
                                        stream_int())
         else:
-            rgb = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-            depth = torch.empty(H, W, dtype=torch.float32, device=dev) if has_depth else None
-            check(lib.mobgs_decoder_fwd(P, CF, int(has_depth), W, ptr(feat_hw), ptr(alphas_c), ptr(rays_c),
-                                        ptr(intr_c), ptr(c2w_c), ptr(w1), ptr(w2), ptr(rgb), ptr(depth), stream()),
-                  "mobgs_decoder_fwd")
+            lead = (C,) if feat_hw.dim() == 4 else ()
+            rgb = torch.empty(*lead, 3, H, W, dtype=torch.float32, device=dev)
+            depth = torch.empty(*lead, H, W, dtype=torch.float32, device=dev) if has_depth else None
+            rs, is_, cs = _decoder_strides(C, P, rays_c, intr_c, c2w_c)
+            check(lib.mobgs_decoder_fwd_many(C, P, CF, int(has_depth), W, ptr(feat_hw), ptr(alphas_c), ptr(rays_c), rs,
+                                             ptr(intr_c), is_, ptr(c2w_c), cs, ptr(w1), ptr(w2), ptr(rgb), ptr(depth),
+                                             stream()), "mobgs_decoder_fwd")
         ctx.save_for_backward(feat_hw, alphas_c, rays_c, intr_c, c2w_c, w1, w2)
         ctx.has_depth = has_depth
         ctx.rays_need_grad = rays is not None and ctx.needs_input_grad[2]
@@ -293,22 +310,25 @@ class Decode(torch.autograd.Function):
             if sunk is not None:
                 return v_feat, v_alphas, v_rays, None, g_c2w, None, None, None
             return v_feat, v_alphas, v_rays, None, g_c2w, g_w1, g_w2, None
-        v_rgb = f32c(v_rgb) if v_rgb is not None else torch.zeros(3, H, W, dtype=torch.float32, device=dev)
+        C = feat_hw.numel() // (P * CF)
+        v_rgb = f32c(v_rgb) if v_rgb is not None else torch.zeros(C, 3, H, W, dtype=torch.float32, device=dev)
         v_depth = f32c(v_depth) if (has_depth and v_depth is not None) else None
         v_feat = torch.empty(ctx.feat_shape, dtype=torch.float32, device=dev)
         v_alphas = torch.empty(alphas.shape, dtype=torch.float32, device=dev) if has_depth else None
         v_rays = torch.empty_like(rays) if ctx.rays_need_grad else None
-        g_c2w = torch.empty_like(c2w) if ctx.c2w_needs_grad else None  # [3,4] or [4,4] like the input
+        g_c2w = torch.empty_like(c2w) if ctx.c2w_needs_grad else None  # [3,4] or [4,4] (per image) like the input
         nb = lib.mobgs_decoder_bwd_blocks(P)
-        partial = torch.empty(nb, 102, dtype=torch.float32, device=dev)
+        partial = torch.empty(C * nb, 102, dtype=torch.float32, device=dev)
         if sunk is not None:
             g_w1, g_w2, accumulate = sunk
         else:
             g_w1, g_w2, accumulate = torch.empty_like(w1), torch.empty_like(w2), 0
-        check(lib.mobgs_decoder_bwd(P, CF, int(has_depth), W, ptr(feat_hw), ptr(alphas), ptr(rays), ptr(intr),
-                                    ptr(c2w), ptr(w1), ptr(w2), ptr(v_rgb), ptr(v_depth), ptr(v_feat), ptr(v_alphas),
-                                    ptr(v_rays), ptr(partial), ptr(g_w1), ptr(g_w2), ptr(g_c2w),
-                                    g_c2w.numel() if g_c2w is not None else 0, accumulate, stream()),
+        rs, is_, cs = _decoder_strides(C, P, rays, intr, c2w)
+        check(lib.mobgs_decoder_bwd_many(C, P, CF, int(has_depth), W, ptr(feat_hw), ptr(alphas), ptr(rays), rs,
+                                         ptr(intr), is_, ptr(c2w), cs, ptr(w1), ptr(w2), ptr(v_rgb), ptr(v_depth),
+                                         ptr(v_feat), ptr(v_alphas), ptr(v_rays), ptr(partial), ptr(g_w1), ptr(g_w2),
+                                         ptr(g_c2w), (g_c2w.numel() // (C if cs else 1)) if g_c2w is not None else 0,
+                                         accumulate, stream()),
               "mobgs_decoder_bwd")
         if sunk is not None:
             return v_feat, v_alphas, v_rays, None, g_c2w, None, None, None
@@ -342,34 +362,39 @@ class DecodeWithChannels(torch.autograd.Function):
         return tuple(g[:7]) + (None, None)
 
 
+def _decode_args(feat_hw: Tensor, alphas: Optional[Tensor], rays):
+    """Shapes for Decode: one image [H,W,CF] (any number of leading 1-dimensions, as the reference's [1,H,W,CF]), or a
+    batch [C,H,W,CF] with C > 1 decoded in ONE launch.  -> (feat, alphas, ray map | None, intr | None, c2w | None)."""
+    H, W, CF = feat_hw.shape[-3:]
+    C = feat_hw.numel() // (H * W * CF)
+    lead = (C,) if C > 1 else ()
+    feat = feat_hw.reshape(*lead, H, W, CF)
+    if alphas is not None:
+        alphas = alphas.reshape(*lead, H, W)
+    if isinstance(rays, (tuple, list)):
+        intr, c2w = rays
+        if C > 1 and c2w.dim() == 2 and c2w.requires_grad:
+            c2w = c2w.expand(C, *c2w.shape).contiguous()   # one gradient per image, summed by autograd
+        return feat, alphas, None, intr, c2w
+    if C > 1 and rays.numel() == 6 * H * W and rays.requires_grad:
+        raise NotImplementedError("decode: a ray map shared by a batch of images cannot receive a gradient")
+    return feat, alphas, rays.reshape(*((C,) if rays.numel() == C * 6 * H * W and C > 1 else ()), 6, H, W), None, None
+
+
 def decode_with_channels(feat_hw: Tensor, alphas: Optional[Tensor], rays, w1: Tensor, w2: Tensor, c0: int, n: int):
     """decode(..., has_depth=False) + feat_hw[..., c0:c0+n] as a tensor of its own (see DecodeWithChannels):
-    -> (rgb [3,H,W], channels [H,W,n])."""
-    H, W = feat_hw.shape[-3], feat_hw.shape[-2]
-    if feat_hw.numel() != H * W * feat_hw.shape[-1]:
-        raise NotImplementedError("decoder batch size must be 1 (as in every reference call)")
-    if alphas is not None:
-        alphas = alphas.reshape(H, W)
-    feat = feat_hw.reshape(H, W, feat_hw.shape[-1])
-    if isinstance(rays, (tuple, list)):
-        return DecodeWithChannels.apply(feat, alphas, None, rays[0], rays[1], w1, w2, c0, n)
-    return DecodeWithChannels.apply(feat, alphas, rays.reshape(6, H, W), None, None, w1, w2, c0, n)
+    -> (rgb [3,H,W], channels [H,W,n]); a batch [C,H,W,CF]: ([C,3,H,W], [C,H,W,n])."""
+    feat, alphas, ray_map, intr, c2w = _decode_args(feat_hw, alphas, rays)
+    return DecodeWithChannels.apply(feat, alphas, ray_map, intr, c2w, w1, w2, c0, n)
 
 
 def decode(feat_hw: Tensor, alphas: Optional[Tensor], rays, w1: Tensor, w2: Tensor, has_depth: bool):
-    """feat_hw [..,H,W,CF>=9(+1)], alphas [..,H,W] or [..,H,W,1] -> rgb [3,H,W], depth [H,W]|None.
-    `rays`: the reference's cam_ray map [1,6,H,W], or a pair (intr [4] = fx,fy,cx,cy, c2w [3,4] or [4,4]) to have
-    the kernel generate the pinhole rays itself."""
-    H, W = feat_hw.shape[-3], feat_hw.shape[-2]
-    if feat_hw.numel() != H * W * feat_hw.shape[-1]:
-        raise NotImplementedError("decoder batch size must be 1 (as in every reference call)")
-    if alphas is not None:
-        alphas = alphas.reshape(H, W)
-    feat = feat_hw.reshape(H, W, feat_hw.shape[-1])
-    if isinstance(rays, (tuple, list)):
-        rgb, depth = Decode.apply(feat, alphas, None, rays[0], rays[1], w1, w2, bool(has_depth))
-    else:
-        rgb, depth = Decode.apply(feat, alphas, rays.reshape(6, H, W), None, None, w1, w2, bool(has_depth))
+    """feat_hw [..,H,W,CF>=9(+1)], alphas [..,H,W] or [..,H,W,1] -> rgb [3,H,W], depth [H,W]|None; a batch of C > 1 images
+    [C,H,W,CF] is decoded in one launch -> rgb [C,3,H,W], depth [C,H,W]|None.
+    `rays`: the reference's cam_ray map [1,6,H,W] (batch: shared, or [C,6,H,W]), or a pair (intr [4] = fx,fy,cx,cy,
+    c2w [3,4] or [4,4]) to have the kernel generate the pinhole rays itself (batch: shared, or [C,4] / [C,3|4,4])."""
+    feat, alphas, ray_map, intr, c2w = _decode_args(feat_hw, alphas, rays)
+    rgb, depth = Decode.apply(feat, alphas, ray_map, intr, c2w, w1, w2, bool(has_depth))
     return rgb, (depth if has_depth else None)
 
 

@@ -91,3 +91,62 @@ def test_prep_of_k_instants_in_one_launch_equals_k_launches(hip_device):
         # autograd sums the K single-instant gradients pairwise in its own order; the batched kernel adds them in
         # instant order: equal to rounding of K - 1 additions
         assert torch.allclose(x, y, rtol=1e-5, atol=1e-6 * float(y.abs().max()) + 1e-12), (i, float((x - y).abs().max()))
+
+
+def test_batched_decode_equals_image_by_image(hip_device):
+    """ops.decode / decode_with_channels on a batch [C,H,W,CF] (mobgs_decoder_{fwd,bwd}_many): images bit-identical to C
+    single-image calls; per-image pose gradients equal; weight gradients equal to the order of the sum over images; a
+    shared pose that needs a gradient is expanded per image."""
+    from mobgs_amd.ops import decode, decode_with_channels
+    dev = hip_device
+    g = torch.Generator().manual_seed(11)
+    C, H, W = 3, 37, 53
+    feat = torch.randn(C, H, W, 12, generator=g).to(dev).requires_grad_(True)
+    alphas = (0.2 + 0.8 * torch.rand(C, H, W, 1, generator=g)).to(dev).requires_grad_(True)
+    w1 = (0.3 * torch.randn(6, 12, generator=g)).to(dev).requires_grad_(True)
+    w2 = (0.3 * torch.randn(3, 6, generator=g)).to(dev).requires_grad_(True)
+    intr = torch.tensor([60.0, 55.0, 26.0, 18.0], device=dev)
+    poses = []
+    for c in range(C):
+        m = torch.eye(4)
+        m[:3, :3] = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+        m[:3, 3] = torch.randn(3, generator=g)
+        poses.append(m.to(dev).requires_grad_(True))
+    v_rgb = torch.randn(C, 3, H, W, generator=g).to(dev)
+    v_dep = torch.randn(C, H, W, generator=g).to(dev)
+    leaves = [feat, alphas, w1, w2] + poses
+
+    def grads():
+        out = [t.grad.clone() for t in leaves]
+        for t in leaves:
+            t.grad = None
+        return out
+
+    single = [decode(feat[c], alphas[c], (intr, poses[c]), w1, w2, True) for c in range(C)]
+    torch.autograd.backward([s[0] for s in single] + [s[1] for s in single], list(v_rgb) + list(v_dep))
+    g_single = grads()
+    rgb, dep = decode(feat, alphas, (intr.expand(C, 4).contiguous(), torch.stack(poses)), w1, w2, True)
+    assert rgb.shape == (C, 3, H, W) and dep.shape == (C, H, W)
+    for c in range(C):
+        assert torch.equal(rgb[c], single[c][0]) and torch.equal(dep[c], single[c][1])
+    torch.autograd.backward([rgb, dep], [v_rgb, v_dep])
+    g_batch = grads()
+    for i, (a, b) in enumerate(zip(g_batch, g_single)):
+        if i in (2, 3):   # weights: one reduction over all images instead of C accumulated ones
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max())), i
+        else:
+            assert torch.equal(a, b), i
+    # shared pose with a gradient + the channel hand-out of get_flow
+    shared = poses[0]
+    r1, ch1 = decode_with_channels(feat, None, (intr, shared), w1, w2, 9, 2)
+    assert r1.shape == (C, 3, H, W) and ch1.shape == (C, H, W, 2)
+    torch.autograd.backward([r1, ch1], [v_rgb, torch.ones_like(ch1)])
+    g_sh = shared.grad.clone()
+    feat_grad = feat.grad.clone()
+    grads()
+    outs = [decode_with_channels(feat[c], None, (intr, shared), w1, w2, 9, 2) for c in range(C)]
+    torch.autograd.backward([o[0] for o in outs] + [o[1] for o in outs], list(v_rgb) + [torch.ones(H, W, 2, device=dev)] * C)
+    assert torch.allclose(g_sh, shared.grad, rtol=1e-5, atol=1e-6 * float(shared.grad.abs().max()))
+    assert torch.equal(feat_grad, feat.grad)
+    for c in range(C):
+        assert torch.equal(r1[c], outs[c][0])
