@@ -117,7 +117,7 @@ def test_batched_decode_equals_image_by_image(hip_device):
     leaves = [feat, alphas, w1, w2] + poses
 
     def grads():
-        out = [t.grad.clone() for t in leaves]
+        out = [t.grad.clone() if t.grad is not None else None for t in leaves]
         for t in leaves:
             t.grad = None
         return out
