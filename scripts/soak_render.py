@@ -2,7 +2,8 @@
 (oracle/render_torch.py + oracle/gsplat_torch.py): random scene sizes, image sizes, camera times at and between the
 spline's knots (0, 1, k / (N-1)), exposure offsets that push the time below 0 and above 1, max_time, 4..12 control
 points per splat, rotated cameras, lean and train mode, random backgrounds.  radii must be bit-equal; images, depth
-and leaf gradients within the flip-aware tolerances.  GPU box only:   python scripts/soak_render.py [--cases 40]"""
+and leaf gradients within the flip-aware tolerances.  GPU box only:   python scripts/soak_render.py [--cases 40]
+[--flow: get_flow / get_flow_many with 1..9 calls of a view] [--many: render_many with 2..8 sub-frames]"""
 import argparse
 import math
 import os
@@ -116,7 +117,11 @@ def run_flow_case(rng, i, dev):
     dyn_x = dynamic_extras(dyn_p["xyz"], seed)
     max_time = int(rng.choice([7, 23]))
     t = float(rng.choice([0.0, 1.0, rng.random()]))
-    deltas = [float(rng.uniform(-1.0, 1.0)), 0.0][: int(rng.integers(1, 3))]
+    # 1..9 calls of one view; 0.0 (the mid exposure) among them half of the time, as in train.py's K = 9 loop
+    n_calls = int(rng.choice([1, 2, 3, 5, 9]))
+    deltas = [float(rng.uniform(-1.0, 1.0)) for _ in range(n_calls)]
+    if rng.random() < 0.5:
+        deltas[int(rng.integers(n_calls))] = 0.0
     many = bool(rng.random() < 0.5)
     g = torch.Generator().manual_seed(seed + 5)
     bg0 = torch.rand(9, generator=g) if rng.random() < 0.5 else torch.zeros(9)
@@ -172,12 +177,91 @@ def run_flow_case(rng, i, dev):
     return desc, problems
 
 
-def soak(cases, seed, dev, verbose=True, flow=False):
+def run_many_case(rng, i, dev):
+    """render_many() (K sub-frames as one batch: one prep / projection / binning / compositing pass / decode) against K
+    oracle renders: images, depths, radii and the leaf gradients of the sum."""
+    from mobgs_amd.gaussian_renderer import render_many
+    W = int(rng.choice([40, 97, 160, 232]))
+    H = int(rng.choice([24, 64, 88, 120]))
+    ns, nd = int(rng.choice([1, 30, 800, 2500])), int(rng.choice([1, 40, 600, 1500]))
+    K = int(rng.choice([2, 3, 5, 8]))
+    seed = int(rng.integers(1 << 30))
+    scam = SynthCamera().scaled(W, H)
+    stat_p, dyn_p = gaussian_cloud(ns, scam, seed), gaussian_cloud(nd, scam, seed + 1)
+    dyn_x = dynamic_extras(dyn_p["xyz"], seed)
+    max_time = int(rng.choice([1, 7, 23, 100]))
+    t = float(rng.choice([0.0, 1.0, rng.random()]))
+    deltas = [None if rng.random() < 0.2 else float(rng.uniform(-1.5, 1.5)) for _ in range(K)]
+    vms = []
+    for _ in range(K):
+        vm = torch.eye(4)
+        ang = float(rng.uniform(-0.1, 0.1))
+        vm[:3, :3] = torch.tensor([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
+        vm[:3, 3] = torch.tensor([float(rng.uniform(-0.1, 0.1)), float(rng.uniform(-0.1, 0.1)), float(rng.uniform(-0.1, 0.2))])
+        vms.append(vm)
+    g = torch.Generator().manual_seed(seed + 5)
+    bg0 = torch.rand(9, generator=g) if rng.random() < 0.5 else torch.zeros(9)
+    v3 = [torch.randn(3, H, W, generator=g) for _ in range(K)]
+    v1 = [torch.randn(1, H, W, generator=g) for _ in range(K)]
+    torch.manual_seed(seed)
+    dec = Sandwich(9, 3)
+    res = {}
+    for name, device in (("hip", dev), ("oracle", torch.device("cpu"))):
+        d = Sandwich(9, 3)
+        d.load_state_dict(dec.state_dict())
+        d = d.to(device)
+        stat = GaussianParams(stat_p, None, d, device, requires_grad=True)
+        dyn = GaussianParams(dyn_p, dyn_x, d, device, requires_grad=True)
+        cams = [PinholeCamera(W, H, scam.K, vm, t, max_time, device=device) for vm in vms]
+        bg = bg0.to(device)
+        des = [None if dl is None else torch.tensor(dl, device=device) for dl in deltas]
+        if name == "hip":
+            outs = render_many(cams, stat, dyn, None, bg, des)
+        else:
+            outs = [R.render(c, stat, dyn, bg, delta_exposure=de) for c, de in zip(cams, des)]
+        torch.autograd.backward([o["render"] for o in outs] + [o["depth"] for o in outs],
+                                [v.to(device) for v in v3] + [v.to(device) for v in v1])
+        grads = {}
+        for pc, tag in ((stat, "s"), (dyn, "d")):
+            for a in LEAVES:
+                p = getattr(pc, a, None)
+                if p is not None and getattr(p, "grad", None) is not None:
+                    grads[tag + a] = p.grad.detach().cpu()
+        res[name] = ([o["render"].detach().cpu() for o in outs], [o["depth"].detach().cpu() for o in outs],
+                     [o["radii"].cpu() for o in outs], grads)
+    desc = f"many case {i}: ns={ns} nd={nd} {W}x{H} K={K} t={t:.3f} deltas={deltas} max_time={max_time}"
+    problems = []
+    for k in range(K):
+        dr = (res["hip"][2][k].long() - res["oracle"][2][k].long()).abs()
+        if int((dr > 0).sum()) > max(1, dr.numel() // 10000) or int(dr.max()) > 1:
+            problems.append(f"sub-frame {k}: radii differ ({int((dr > 0).sum())} splats, max {int(dr.max())})")
+        for j, nm in ((0, "render"), (1, "depth")):
+            a, b = res["hip"][j][k].double(), res["oracle"][j][k].double()
+            err = (a - b).abs()
+            sc = max(1.0, float(b.abs().max()))
+            frac = float((err > 3e-5 * sc).double().mean())
+            if frac > 5e-3 or not torch.isfinite(a).all():
+                problems.append(f"sub-frame {k} {nm}: {frac:.2e} of the pixels off, max {float(err.max()):.2e}")
+    for k, ref in res["oracle"][3].items():
+        got = res["hip"][3].get(k)
+        if got is None:
+            problems.append(f"grad {k} missing")
+            continue
+        sc = float(ref.abs().max())
+        err = (got.double() - ref.double()).abs()
+        frac = float((err > 2e-3 * ref.abs().double() + 3e-4 * sc + 1e-7).double().mean())
+        few = ref.numel() <= 400
+        if (frac > 1e-2 and not (few and float(err.max()) <= 5e-2 * sc)) or not torch.isfinite(got).all():
+            problems.append(f"grad {k}: {frac:.2e} off, max {float(err.max()):.2e} (scale {sc:.2e})")
+    return desc, problems
+
+
+def soak(cases, seed, dev, verbose=True, flow=False, many=False):
     rng = np.random.default_rng(seed)
     failed, msgs = 0, []
     for i in range(cases):
         try:
-            desc, problems = (run_flow_case if flow else run_case)(rng, i, dev)
+            desc, problems = (run_many_case if many else run_flow_case if flow else run_case)(rng, i, dev)
         except Exception as exc:  # noqa: BLE001
             desc, problems = f"case {i}", [f"exception {type(exc).__name__}: {exc}"]
         if problems:
@@ -195,6 +279,7 @@ if __name__ == "__main__":
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--flow", action="store_true", help="get_flow() / get_flow_many() instead of render()")
+    ap.add_argument("--many", action="store_true", help="render_many() (K sub-frames as one batch) instead of render()")
     a = ap.parse_args()
-    failed, _ = soak(a.cases, a.seed, torch.device("cuda:0"), flow=a.flow)
+    failed, _ = soak(a.cases, a.seed, torch.device("cuda:0"), flow=a.flow, many=a.many)
     sys.exit(1 if failed else 0)
