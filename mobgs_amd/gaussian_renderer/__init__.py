@@ -402,7 +402,7 @@ def render_many(viewpoint_cameras, stat_pc, dyn_pc, pipe, bg_color, delta_exposu
 
     def composite_and_decode():
         img, alphas = sp.composite(cols, bgK)                  # [K,H,W,10], [K,H,W,1]
-        rays = _rays_of_many(cams)
+        rays = _rays_of_many(cams) if K > 1 else None   # (one image: the single-image call, [3,H,W] out)
         if rays is not None:   # ONE decoder launch for the K images (forward and backward), per-image camera poses
             rgb, depth = decode(img, alphas, rays, w1, w2, True)           # [K,3,H,W], [K,H,W]
             return list(zip(rgb.unbind(0), depth.unbind(0)))

@@ -373,6 +373,9 @@ def _decode_args(feat_hw: Tensor, alphas: Optional[Tensor], rays):
         alphas = alphas.reshape(*lead, H, W)
     if isinstance(rays, (tuple, list)):
         intr, c2w = rays
+        if C == 1:   # a stacked "batch" of one camera is that camera
+            intr = intr.reshape(4)
+            c2w = c2w.reshape(c2w.shape[-2:]) if c2w.dim() == 3 else c2w
         if C > 1 and c2w.dim() == 2 and c2w.requires_grad:
             c2w = c2w.expand(C, *c2w.shape).contiguous()   # one gradient per image, summed by autograd
         return feat, alphas, None, intr, c2w

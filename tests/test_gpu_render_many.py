@@ -150,3 +150,30 @@ def test_batched_decode_equals_image_by_image(hip_device):
     assert torch.equal(feat_grad, feat.grad)
     for c in range(C):
         assert torch.equal(r1[c], outs[c][0])
+
+
+def test_render_many_of_one_camera_is_render(hip_device):
+    """K = 1 (a rank that owns a single latent sub-frame of a view in a sharded run): the batch of one goes through the
+    single-image calls and equals render()."""
+    import bench as B
+    from mobgs_amd.camera import PinholeCamera
+    from mobgs_amd.gaussian_renderer import render, render_many
+    from mobgs_amd.ops import decode
+    dev = hip_device
+    W, H = 96, 64
+    scam, _, stat, dyn, _ = B.build_scene(dev, 500, 300, W, H, seed=9)
+    cam = PinholeCamera(W, H, scam.K, B.view_pose(1), time=scam.time, max_time=scam.max_time, device=dev)
+    bg = torch.zeros(9, device=dev)
+    d = torch.tensor(0.2, device=dev)
+    ref = render(cam, stat, dyn, None, bg, delta_exposure=d)
+    out, = render_many([cam], stat, dyn, None, bg, [d])
+    assert out["render"].shape == (3, H, W) and torch.equal(out["render"], ref["render"])
+    assert torch.equal(out["depth"], ref["depth"])
+    (out["render"].sum() + out["depth"].sum()).backward()
+    # stacked parameters of one camera are accepted by the decoder wrapper as that camera's
+    feat = torch.randn(1, H, W, 10, device=dev)
+    a = torch.rand(1, H, W, 1, device=dev) + 0.1
+    w1, w2 = torch.randn(6, 12, device=dev), torch.randn(3, 6, device=dev)
+    r1, d1 = decode(feat, a, (cam.ray_intrinsics[None], cam.ray_c2w[None]), w1, w2, True)
+    r0, d0 = decode(feat, a, (cam.ray_intrinsics, cam.ray_c2w), w1, w2, True)
+    assert r1.shape == (3, H, W) and torch.equal(r1, r0) and torch.equal(d1, d0)
