@@ -1,0 +1,30 @@
+"""The N > 1 code path of bench.py -- the driver's scaling run: `python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...` -- exercised on ONE GPU: all ranks share the device and exchange through gloo
+(MOBGS_BENCH_SHARE_GPU=1 MOBGS_BENCH_BACKEND=gloo; the line labels itself a functional check).  3 and 8 ranks: with 18
+(view, sub-frame) units some ranks own a single latent sub-frame of a view (a batch of one), some none of a view."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_bench_sharded_path_runs_and_reports(hip_device, world):
+    env = dict(os.environ, MOBGS_BENCH_SHARE_GPU="1", MOBGS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    port = 29650 + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--prewarm", "2",
+           "--ns", "6000", "--nd", "3000", "--width", "320", "--height", "240"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == world and line["steps"] == 2 and line["scaling"] == "strong"
+    assert line["value"] > 0 and line["config"]["renders_per_step"] == 18
+    assert "FUNCTIONAL CHECK" in line["data"]
