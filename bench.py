@@ -307,7 +307,7 @@ class DeblurWorkload:
         self.bucket.zero()
         # N > 1: units dealt by cost (the two train-mode mid frames weigh 2.3 latent renders), one asynchronous image
         # all-reduce per view behind the next view's renders
-        multi = self.shard.world > 1
+        multi = self.shard.collective
         pred, mids = render_blurry_batch(self.cams, self.stat, self.dyn, self.bg, self.shard, blce=self.blce,
                                          n_sub=self.K, weighted=multi, overlap=multi, batched_latent=self.batched)
         outs, cots = [pred], [self.v_pred]

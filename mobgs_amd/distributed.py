@@ -177,6 +177,12 @@ class SubframeShard:
         if rank is None:
             rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
         self.world, self.rank, self.group = int(world_size), int(rank), group
+        # the exchanges run when there is more than one rank -- or when asked to anyway (MOBGS_FORCE_COLLECTIVES=1 with an
+        # initialised process group: a ONE-rank RCCL group on a one-GPU box runs every collective of the N > 1 path on
+        # the real backend, identity sums; scripts/rccl_world1_check.py)
+        import os
+        self.collective = self.world > 1 or (os.environ.get("MOBGS_FORCE_COLLECTIVES") == "1"
+                                              and dist.is_available() and dist.is_initialized())
 
     # ---- partition ----------------------------------------------------------------------------------
     def units(self, n_units: int, offset: int = 0) -> List[int]:
@@ -250,7 +256,7 @@ class SubframeShard:
         sub-frames (+1e-10, as train.py:541), identical on every rank.  With one process and one unit it is the
         render itself.  reduce_backward: see _SumAcrossRanks -- needed as soon as some loss term on the prediction
         exists on ONE rank only (then every term all ranks form identically on it goes through replicated_term())."""
-        if self.world == 1:
+        if not self.collective:
             return local_sum if n_units == 1 else local_sum / n_units + 1e-10
         if reduce_backward and not local_sum.requires_grad:
             # a rank without a render unit (more ranks than units) still forms loss terms on the prediction and must
@@ -286,7 +292,7 @@ class SubframeShard:
         item 6b); the results are awaited together before the predictions are used."""
         mine = list(units) if units is not None else self.view_units(n_views, n_sub)
         sums: List[Optional[torch.Tensor]] = [None] * n_views
-        if not (overlap and self.world > 1):
+        if not (overlap and self.collective):
             for v, k in mine:
                 img = render_unit(v, k)
                 sums[v] = img if sums[v] is None else sums[v] + img
@@ -323,7 +329,7 @@ class SubframeShard:
         missing grads count as zero)."""
         if isinstance(params, FlatGradients):
             params.gather_stray()
-            if self.world == 1:
+            if not self.collective:
                 return None
             works = []
             for b in params.buffers():
@@ -339,7 +345,7 @@ class SubframeShard:
                 else:
                     works.append(_all_reduce_sum(b, self.group, async_op))
             return works if async_op else None
-        if self.world == 1:
+        if not self.collective:
             return None
         params = [p for p in params if p.requires_grad]
         if not params:
