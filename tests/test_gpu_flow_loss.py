@@ -88,3 +88,18 @@ def test_needs_input_grad_subsets_and_shapes(hip_device):
     assert torch.allclose(t["e2m"].grad.cpu(), gfull["e2m"], rtol=1e-5, atol=1e-9)
     with pytest.raises(ValueError):
         flow_warp_loss(case["ori"], case["latent"], case["e2m"][..., :1], case["m2e"], case["la"], case["da"])
+
+
+def test_flow_warp_loss_at_benchmark_size(hip_device):
+    """One view x K = 3 exposures at 1352x1014 (the 8-row strips of the backward pass, many workgroups) against the
+    reference block on the CPU."""
+    from mobgs_amd.loss_utils import flow_warp_loss
+    case = _case(1, 3, 1014, 1352, 9, flow=3.0)
+    ref, gref = _run(RT.flow_warp_loss, case, "cpu")
+    got, ggot = _run(flow_warp_loss, case, hip_device)
+    assert abs(got - ref) <= 3e-6 * abs(ref), (got, ref)
+    for k in NAMES:
+        a, b = ggot[k], gref[k]
+        tol = 2e-5 * float(b.abs().max()) + 1e-14
+        bad = (a - b).abs() > tol + 1e-4 * b.abs()
+        assert int(bad.sum()) <= 1e-5 * bad.numel(), (k, int(bad.sum()), float((a - b).abs().max()), tol)

@@ -6,18 +6,19 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("size,ns,nd", [((232, 120), 900, 500), ((512, 288), 20_000, 10_000)])
+@pytest.mark.parametrize("size,ns,nd", [((232, 120), 900, 500), ((512, 288), 20_000, 10_000),
+                                        ((1352, 1014), 200_000, 100_000)])   # ... and BASELINE config #2's size
 def test_render_many_equals_separate_renders(hip_device, size, ns, nd):
     import bench as B
     from mobgs_amd.camera import PinholeCamera
     from mobgs_amd.gaussian_renderer import render, render_many
     dev = hip_device
     W, H = size
-    K = 5
+    K = 5 if W < 1000 else 3
     scam, cam0, stat, dyn, _ = B.build_scene(dev, ns, nd, W, H, seed=4)
     cams = [PinholeCamera(W, H, scam.K, B.view_pose(k), time=scam.time, max_time=scam.max_time, device=dev)
             for k in range(K)]
-    deltas = [torch.tensor(0.3 * (k - 2), device=dev) for k in range(K)]
+    deltas = [torch.tensor(0.3 * (k - K // 2), device=dev) for k in range(K)]
     bg = torch.zeros(9, device=dev)
     g = torch.Generator().manual_seed(1)
     v3 = [torch.randn(3, H, W, generator=g).to(dev) for _ in range(K)]
