@@ -32,6 +32,7 @@ Inputs are resident in HBM before the timed region.  Prints ONE JSON line on ran
 from __future__ import annotations
 
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -396,6 +397,13 @@ def timed(step, steps, warmup, world, dist):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    # Host setting a training script on this stack would use (like the autograd threading switch in main()): a
+    # generation-2 pass of Python's cyclic collector over the ~270 k objects a torch process holds takes ~66 ms on this
+    # host (scripts/find_hiccup.py) -- during which nothing is enqueued and the device runs dry; it fires every few
+    # dozen iterations, in the middle of one.  Everything alive after set-up moves to the permanent generation: later
+    # collections only look at what the iterations themselves allocate.
+    gc.collect()
+    gc.freeze()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

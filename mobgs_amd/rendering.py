@@ -258,9 +258,11 @@ class _PendingCounts:
         _cap_listed[key] = max(_cap_listed.get(key, 0), int(fresh._n_isects * 1.25) + 1024)
         _len_hint[key] = fresh._max_tile_len
         tl.rebuilds += 1
+        list_rebuilds[0] += 1
         return True
 
 
+list_rebuilds = [0]  # speculative binning calls whose arena was too small (lists rebuilt synchronously) -- diagnostics
 _tile_culling = True
 # Caller-side policy handed to the library with every call (include/mobgs_hip.h MobgsTuning; the library itself keeps
 # no state).  tuning.heavy_tile_len / tuning.quadrant_culling / tuning.block_walk may be changed by tests and

@@ -3,6 +3,7 @@ read by the kernels as halves (fp32 masters for the optimiser: DESIGN 7a), 1352x
 K = 9 deblur iteration of two views (BLCE cameras), forward + backward.  GPU box only:
     python scripts/bench_config5.py [--steps 10] [--fp32]"""
 import argparse
+import gc
 import os
 import sys
 import time
@@ -24,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--fp32", action="store_true", help="fp32 attribute storage (the twin scene) for comparison")
+    ap.add_argument("--separate", action="store_true", help="one render() per latent sub-frame instead of render_many")
     a = ap.parse_args()
     torch.autograd.set_multithreading_enabled(False)
     dev = torch.device("cuda:0")
@@ -55,6 +57,8 @@ def main():
     def timed(fn, steps, warm):
         for _ in range(warm):
             fn()
+        gc.collect()
+        gc.freeze()   # (a generation-2 collection costs ~66 ms on this host: see bench.py timed())
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -66,8 +70,24 @@ def main():
     ms = timed(lean, 10 * a.steps, 20)
     print(f"config #5 ({ns + nd} Gaussians, {W}x{H}, {tag}): lean render fwd+bwd {ms:.3f} ms = {1e3 / ms:.1f} renders/s",
           flush=True)
-    wl = B.DeblurWorkload(dev, stat, dyn, scam, W, H, SubframeShard(world_size=1, rank=0))
-    ms = timed(wl.step, a.steps, 6)
+    wl = B.DeblurWorkload(dev, stat, dyn, scam, W, H, SubframeShard(world_size=1, rank=0), batched=not a.separate)
+    for _ in range(6):
+        wl.step()
+    st0 = torch.cuda.memory_stats()
+    ms = timed(wl.step, a.steps, 0)
+    st1 = torch.cuda.memory_stats()
+    from mobgs_amd import profiler
+    profiler.enable(True)
+    for _ in range(3):
+        wl.step()
+    summ = profiler.summary()
+    profiler.enable(False)
+    print("HIP-event regions over 3 iterations:", {k: (v["calls"], round(v["total_ms"], 2)) for k, v in summ.items()},
+          flush=True)
+    print("allocator during the timed iterations: device mallocs", st1["num_device_alloc"] - st0["num_device_alloc"],
+          "device frees", st1["num_device_free"] - st0["num_device_free"], "retries",
+          st1["num_alloc_retries"] - st0["num_alloc_retries"], "reserved GiB", st1["reserved_bytes.all.current"] / 2**30,
+          flush=True)
     print(f"config #5: K = 9 deblur iteration of two views {ms:.2f} ms = {18e3 / ms:.0f} renders/s, "
           f"{2e3 / ms:.1f} blurry views/s; memory in use {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB", flush=True)
 

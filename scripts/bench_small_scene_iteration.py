@@ -1,6 +1,6 @@
 """The K = 9 deblur iteration of two views (train.py:430-541) at the reference's own operating point (512x288, 20 k + 10 k
 splats) and at the headline size: one render() per sub-frame against one render_many() batch per view."""
-import os, sys, time, torch
+import gc, os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench as B
@@ -14,6 +14,7 @@ for (W, H, ns, nd, steps) in ((512, 288, 20_000, 10_000, 40), (1352, 1014, 200_0
         wl = B.DeblurWorkload(dev, stat, dyn, scam, W, H, SubframeShard(1, 0), 2, batched=batched)
         for _ in range(5):
             wl.step()
+        gc.collect(); gc.freeze()   # (a generation-2 collection costs ~66 ms on this host: see bench.py timed())
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(steps):
             wl.step()
@@ -28,6 +29,7 @@ import train_deblur_synth as TD
 tr = TD.DeblurTrainer("cuda:0", 20_000, 10_000, 512, 288, 2, iters=10000)
 for _ in range(5):
     tr.iteration()
+gc.collect(); gc.freeze()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(30):
     tr.iteration()
