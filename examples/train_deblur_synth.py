@@ -164,6 +164,10 @@ def train(dev="cuda:0", iters=40, ns=4000, nd=2000, width=256, height=192, n_vie
     history = []
     for it in range(1, iters + 1):
         history.append(float(t.iteration()))
+        if it == 2:   # everything long-lived exists now: keep Python's cyclic collector off it (66 ms per generation-2
+            import gc  # pass over a torch process's objects on this host, in the middle of an iteration: DESIGN section 5)
+            gc.collect()
+            gc.freeze()
         if log and (it % log == 0 or it == 1) and t.shard.rank == 0:
             print(f"it {it:4d}  photometric {history[-1]:.5f}")
     return history, t.stat, t.dyn, t.blce, t.bucket
