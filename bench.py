@@ -391,19 +391,32 @@ class DynamicWorkload:
         torch.autograd.backward([img], [self.v])
 
 
-def timed(step, steps, warmup, world, dist):
+def freeze_python_heap():
+    gc.collect()
+    gc.freeze()
+
+
+def timed(step, steps, warmup, world, dist, freeze=True):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize; per-step HIP events on the current
     stream give the median next to the wall-clock mean."""
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
     # Host setting a training script on this stack would use (like the autograd threading switch in main()): a
     # generation-2 pass of Python's cyclic collector over the ~270 k objects a torch process holds takes ~66 ms on this
     # host (scripts/find_hiccup.py) -- during which nothing is enqueued and the device runs dry; it fires every few
     # dozen iterations, in the middle of one.  Everything alive after set-up moves to the permanent generation: later
-    # collections only look at what the iterations themselves allocate.
-    gc.collect()
-    gc.freeze()
+    # collections only look at what the iterations themselves allocate.  (BEFORE the warm-up steps, not between them
+    # and the timed ones: the collection itself idles the device for ~0.1 s and the clocks drop.)
+    # freeze=False: the caller has done it during its own (longer) set-up steps.
+    if freeze:
+        if warmup > 0:   # the first of the W warm-up steps, then the collection, then the other W - 1
+            step()
+            torch.cuda.synchronize()
+        freeze_python_heap()
+        for _ in range(max(warmup - 1, 0)):
+            step()
+    else:
+        for _ in range(warmup):
+            step()
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -509,14 +522,17 @@ def main():
         # set-up, not measurement: the first frames of a workload size the speculative arenas (one synchronous rebuild)
         # and bring the clocks up; with a small --warmup (the driver's invocation) the K timed steps would otherwise
         # include that transient (20 steps after 5 warm-ups: 922 renders/s against 952 in steady state)
+        lean_step()
+        torch.cuda.synchronize()
+        freeze_python_heap()            # (see timed(): here, so that the set-up steps below re-heat the device after it)
         for _ in range(args.prewarm):
             lean_step()
         profiler.enable(True)
-        dt, med_ms = timed(lean_step, args.steps, args.warmup, world, dist)
+        dt, med_ms = timed(lean_step, args.steps, args.warmup, world, dist, freeze=False)
         prof = profiler.summary()
         profiler.enable(False)
         if args.repeat_steps > 0:  # the driver's K may be small: a longer run next to it (not `value`)
-            rdt, rmed = timed(lean_step, args.repeat_steps, 0, world, dist)
+            rdt, rmed = timed(lean_step, args.repeat_steps, 0, world, dist, freeze=False)
             repeat = {"steps": args.repeat_steps, "ms_per_step": round(rdt / args.repeat_steps * 1e3, 4),
                       "event_median_ms_per_step": round(rmed, 4),
                       "renders_per_s": round(args.repeat_steps / rdt, 2)}
@@ -582,10 +598,13 @@ def main():
             del tr
     else:
         wl = DeblurWorkload(dev, stat, dyn, scam, args.width, args.height, shard, args.views)
+        wl.step()
+        torch.cuda.synchronize()
+        freeze_python_heap()
         for _ in range(min(args.prewarm, 8)):   # set-up: arena sizing of this rank's batches (see the N = 1 branch)
             wl.step()
         profiler.enable(True)
-        dt, med_ms = timed(wl.step, args.steps, args.warmup, world, dist)
+        dt, med_ms = timed(wl.step, args.steps, args.warmup, world, dist, freeze=False)
         prof = profiler.summary()
         profiler.enable(False)
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

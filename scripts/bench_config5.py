@@ -55,10 +55,11 @@ def main():
             torch.autograd.backward([out["render"], out["depth"]], [v3, v1])
 
     def timed(fn, steps, warm):
-        for _ in range(warm):
-            fn()
+        fn()
         gc.collect()
         gc.freeze()   # (a generation-2 collection costs ~66 ms on this host: see bench.py timed())
+        for _ in range(warm):
+            fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):

@@ -12,9 +12,10 @@ for (W, H, ns, nd, steps) in ((512, 288, 20_000, 10_000, 40), (1352, 1014, 200_0
     res = {}
     for batched in (False, True):
         wl = B.DeblurWorkload(dev, stat, dyn, scam, W, H, SubframeShard(1, 0), 2, batched=batched)
+        wl.step()
+        gc.collect(); gc.freeze()   # (a generation-2 collection costs ~66 ms on this host: see bench.py timed())
         for _ in range(5):
             wl.step()
-        gc.collect(); gc.freeze()   # (a generation-2 collection costs ~66 ms on this host: see bench.py timed())
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(steps):
             wl.step()
@@ -27,9 +28,10 @@ for (W, H, ns, nd, steps) in ((512, 288, 20_000, 10_000, 40), (1352, 1014, 200_0
 sys.path.insert(0, os.path.join(ROOT, "examples"))
 import train_deblur_synth as TD
 tr = TD.DeblurTrainer("cuda:0", 20_000, 10_000, 512, 288, 2, iters=10000)
+tr.iteration()
+gc.collect(); gc.freeze()
 for _ in range(5):
     tr.iteration()
-gc.collect(); gc.freeze()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(30):
     tr.iteration()
