@@ -586,7 +586,10 @@ def main():
             tr = TD.DeblurTrainer(str(dev), args.ns, args.nd, args.width, args.height, args.views, shard=shard,
                                   iters=10000)
             tdt, tmed = timed(tr.iteration, args.train_steps, 2, world, dist)
+            tr.lambda_flow = 0.0   # the shipped configs (arguments/stereo/seesaw.py): calls made, no flow term in the graph
+            zdt, _ = timed(tr.iteration, args.train_steps, 2, world, dist)
             train_it = {"ms_per_iteration": round(tdt / args.train_steps * 1e3, 2),
+                        "ms_per_iteration_lambda_flow_loss_0": round(zdt / args.train_steps * 1e3, 2),
                         "event_median_ms_per_iteration": round(tmed, 2), "iterations_per_s": round(args.train_steps / tdt, 3),
                         "steps": args.train_steps, "views_per_iteration": args.views,
                         "what": "ONE whole training iteration (train.py:430-807) at the headline size: per view K = 9 "

@@ -134,7 +134,8 @@ class DeblurTrainer:
                                          cat(0), cat(1), cat(3).unsqueeze(2),
                                          torch.stack([mids[v]["d_alpha"].reshape(1, *pred.shape[-2:]) for v in views]),
                                          self.lambda_flow)
-        else:
+        elif self.lambda_flow != 0:   # (weight 0, the shipped seesaw / children configs: the calls above are made, as
+            # train.py makes them, and their results stay out of the loss graph -- flow_warp_loss returns a constant)
             # flow units sharded over ranks: each owner forms a rank-local stand-in (the reference's term normalises
             # over all (view, exposure) pairs and samples the view's mid render, which lives on one rank)
             for (v, k), (e2m, m2e, limg, lalpha) in flows.items():
