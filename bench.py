@@ -313,6 +313,8 @@ class DeblurWorkload:
                                          n_sub=self.K, weighted=multi, overlap=multi, batched_latent=self.batched)
         outs, cots = [pred], [self.v_pred]
         for v, pkg in mids.items():  # depth / mask terms live on the rank that rendered the mid frame
+            for key in ("s_render", "s_depth", "d_alpha", "d_depth", "s_alpha"):
+                pkg[key]             # train.py:445-464 reads these five auxiliary images of the mid render every iteration
             outs += [pkg["depth"], pkg["d_alpha"]]
             cots += [self.v_depth, self.v_alpha]
         if any(o.requires_grad for o in outs):

@@ -121,6 +121,8 @@ class DeblurTrainer:
         photo = photometric_loss(pred, self.gt, self.opt.lambda_dssim)
         loss = shard.replicated_term(photo)                      # every rank forms it on the replicated prediction
         for v, pkg in mids.items():                              # the rank that rendered the mid frame
+            for key in ("s_render", "s_depth", "d_alpha", "d_depth", "s_alpha"):
+                pkg[key]   # train.py:445-464 reads these five auxiliary images of the mid render every iteration
             normal = self.get_normals(pkg["depth"] + 1e-6, self.meta)   # train.py:590
             loss = loss + 0.05 * l1_loss(pkg["depth"], self.depths[v]) + 0.01 * pkg["d_alpha"].mean() \
                 + 0.01 * l1_loss(normal, self.normals[v])
