@@ -538,6 +538,15 @@ def main():
             repeat = {"steps": args.repeat_steps, "ms_per_step": round(rdt / args.repeat_steps * 1e3, 4),
                       "event_median_ms_per_step": round(rmed, 4),
                       "renders_per_s": round(args.repeat_steps / rdt, 2)}
+
+            def forward_only():  # eval.py / render.py: render() under no_grad (same scene, same camera)
+                with torch.no_grad():
+                    last["eval"] = render(cam, stat, dyn, None, bg)["render"]
+            fdt, fmed = timed(forward_only, args.repeat_steps, 10, world, dist, freeze=False)
+            repeat["forward_only_no_grad"] = {"ms_per_render": round(fdt / args.repeat_steps * 1e3, 4),
+                                              "event_median_ms": round(fmed, 4),
+                                              "renders_per_s": round(args.repeat_steps / fdt, 1),
+                                              "what": "render() under torch.no_grad() (the eval.py / render.py use)"}
         from mobgs_amd import rendering
         I = rendering.last_stats.get("n_isects", 0)  # of the PRIMARY workload (the secondary legs render too)
         I_box = rendering.last_stats.get("n_box", 0) or I
