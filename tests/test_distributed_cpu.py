@@ -446,3 +446,27 @@ def test_planned_units_with_overlapped_exchange_match_single_process(world):
         assert torch.allclose(gb, ref_b, atol=1e-6), f"rank {rank}"
         for v in range(V):
             assert torch.allclose(m2d[v], ref_m2d[v], atol=1e-7), f"rank {rank} view {v}"
+
+
+def _forced_worker(rank, world, port, q):
+    os.environ["MOBGS_FORCE_COLLECTIVES"] = "1"
+    _planned_worker(rank, world, port, q)
+
+
+def test_forced_collectives_on_a_one_rank_group_are_identities():
+    """MOBGS_FORCE_COLLECTIVES=1 with an initialised ONE-rank group: SubframeShard issues every exchange of the N > 1
+    path (what scripts/rccl_world1_check.py does with RCCL on the GPU box) and the sums over one rank reproduce the
+    single-process iteration; without the variable, or without a process group, a one-rank shard exchanges nothing."""
+    assert not SubframeShard(world_size=1, rank=0).collective
+    ref_pred, ref_w, ref_b, ref_m2d = _single_iteration()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    rank, pred, gw, gb, m2d, n_mine = _tensors(q.get(timeout=120))
+    p.join(timeout=60)
+    assert p.exitcode == 0 and n_mine == V * K
+    assert torch.allclose(pred, ref_pred, atol=1e-6) and torch.allclose(gw, ref_w, atol=1e-6)
+    assert torch.allclose(gb, ref_b, atol=1e-6)
+    for v in range(V):
+        assert torch.allclose(m2d[v], ref_m2d[v], atol=1e-7)
