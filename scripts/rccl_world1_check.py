@@ -31,7 +31,11 @@ def main():
     torch.cuda.set_device(dev)
     os.environ.pop("MOBGS_FORCE_COLLECTIVES", None)
     ref_pred, ref_grads = step_result(dev, SubframeShard(world_size=1, rank=0))
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29713", rank=0, world_size=1)
+    import socket
+    with socket.socket() as sk:   # a free port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
     os.environ["MOBGS_FORCE_COLLECTIVES"] = "1"
     shard = SubframeShard()
     assert shard.collective and shard.world == 1 and dist.get_backend() == "nccl"

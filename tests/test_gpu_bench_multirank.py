@@ -17,7 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("world", [3, 8])
 def test_bench_sharded_path_runs_and_reports(hip_device, world):
     env = dict(os.environ, MOBGS_BENCH_SHARE_GPU="1", MOBGS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    port = 29650 + world
+    import socket
+    with socket.socket() as sk:   # a free port (a fixed one may sit in TIME_WAIT after an earlier run)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world), "--steps", "2", "--warmup", "1", "--prewarm", "2",
