@@ -50,15 +50,17 @@ def test_flow_warp_loss_matches_reference_block(hip_device, B, K, H, W, seed):
     ref, gref = _run(RT.flow_warp_loss, case, "cpu")
     for combine in (True, False):
         got, ggot = _run(flow_warp_loss, case, hip_device, combine_taps=combine)
-        assert abs(got - ref) <= 2e-6 * abs(ref), (combine, got, ref)
+        # observed (scripts/observed_flow_loss_errors.py): loss 1e-7 relative; gradients <= 5e-7 of the tensor's maximum,
+        # no element beyond -- allowed: 3x that
+        assert abs(got - ref) <= 3e-7 * abs(ref), (combine, got, ref)
         for k in NAMES:
             a, b = ggot[k], gref[k]
             assert a.shape == b.shape
-            # fp32 sums in a different order (scatter: atomics); the sign of a difference that is exactly zero in one
-            # evaluation and 1e-8 in the other may flip one term
-            tol = 2e-5 * float(b.abs().max()) + 1e-12
-            bad = (a - b).abs() > tol + 1e-4 * b.abs()
-            assert int(bad.sum()) <= 1e-5 * bad.numel(), (combine, k, int(bad.sum()), float((a - b).abs().max()), tol)
+            # fp32 sums in a different order; the two scattered image gradients are sums of atomics whose order changes
+            # from run to run: twice the margin there
+            tol = (3e-6 if k in ("ori", "latent") else 1.5e-6) * float(b.abs().max()) + 1e-12
+            bad = (a - b).abs() > tol + 1e-5 * b.abs()
+            assert int(bad.sum()) == 0, (combine, k, int(bad.sum()), float((a - b).abs().max()), tol)
 
 
 def test_zero_weight_is_a_constant_and_inputs_are_untouched(hip_device):
@@ -97,9 +99,10 @@ def test_flow_warp_loss_at_benchmark_size(hip_device):
     case = _case(1, 3, 1014, 1352, 9, flow=3.0)
     ref, gref = _run(RT.flow_warp_loss, case, "cpu")
     got, ggot = _run(flow_warp_loss, case, hip_device)
-    assert abs(got - ref) <= 3e-6 * abs(ref), (got, ref)
+    assert abs(got - ref) <= 3e-7 * abs(ref), (got, ref)
     for k in NAMES:
         a, b = ggot[k], gref[k]
-        tol = 2e-5 * float(b.abs().max()) + 1e-14
-        bad = (a - b).abs() > tol + 1e-4 * b.abs()
-        assert int(bad.sum()) <= 1e-5 * bad.numel(), (k, int(bad.sum()), float((a - b).abs().max()), tol)
+        # observed: 2.3e-6 of the maximum on the scattered image gradients (sums of up to ~30 atomics), 2e-7 elsewhere
+        tol = (1.4e-5 if k in ("ori", "latent") else 1.5e-6) * float(b.abs().max()) + 1e-14   # (atomics: twice 3x)
+        bad = (a - b).abs() > tol + 1e-5 * b.abs()
+        assert int(bad.sum()) == 0, (k, int(bad.sum()), float((a - b).abs().max()), tol)
