@@ -75,6 +75,13 @@ extern "C" {
  *                      [C,N,3] and `quats` [C,N,4] -- every camera sees its OWN positions / rotations of the N splats
  *                      (the K sub-frames of one blurry view: same Gaussians at K exposure times through K cameras,
  *                      projected, binned, sorted and composited as ONE C = K batch); scales / opacities stay [N,..].
+ *   bwd_mfma           backward compositor of the passes with <= 10 total channels (round 4): the per-splat gradient
+ *                      sums on the matrix pipe (raster_bwd_mfma.hip: the pair weights alpha*T and v_sigma are transposed
+ *                      through LDS and summed over the pixels by v_mfma_f32_16x16x4_f32 against [colour cotangents |
+ *                      pixel moments]; no per-entry wave reduction).  0 = the quadrant kernel with per-lane accumulators;
+ *                      1 = one wave per tile, the four-wave team (one 8x8 quadrant per wave) for the schedule's heavy
+ *                      tiles; 2 = the team for every tile.  Gradients agree to summation order (observed <= 2e-5 of
+ *                      each tensor's maximum).  Default (-1): 1 on grids of <= 1024 tiles, else 0 (measured).
  *   reserved           must be 0 (or the struct zero-/minus-one-initialised). */
 typedef struct MobgsTuning {
     int32_t heavy_tile_len;
@@ -83,7 +90,8 @@ typedef struct MobgsTuning {
     int32_t block_walk;
     int32_t bwd_block_walk;
     int32_t geometry_per_camera;
-    int32_t reserved[2];
+    int32_t bwd_mfma;
+    int32_t reserved[1];
 } MobgsTuning;
 
 const char* mobgs_version(void);

@@ -13,7 +13,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 # MOBGS_LIB: load another build of the same library instead (A/B timing of kernel variants on one GPU box)
 LIB_PATH = Path(os.environ["MOBGS_LIB"]).resolve() if os.environ.get("MOBGS_LIB") else CSRC / "libmobgs_hip.so"
-SOURCES = ["project.hip", "isect.hip", "raster.hip", "raster_layers.hip", "pipeline.hip", "prep.hip", "decoder.hip", "deform.hip", "deform_bwd.hip", "hexplane_bwd.hip", "blce.hip", "loss.hip", "flowloss.hip", "densify.hip", "normals.hip"]
+SOURCES = ["project.hip", "isect.hip", "raster.hip", "raster_bwd_mfma.hip", "raster_layers.hip", "pipeline.hip", "prep.hip", "decoder.hip", "deform.hip", "deform_bwd.hip", "hexplane_bwd.hip", "blce.hip", "loss.hip", "flowloss.hip", "densify.hip", "normals.hip"]
 ARCH = "gfx950"
 # host fast path (csrc/fastpath.cpp): a plain C++ torch extension, no device code, no link against libmobgs_hip.so
 FAST_SRC = CSRC / "fastpath.cpp"
@@ -21,7 +21,7 @@ FAST_PATH = CSRC.parent / "_mobgs_fast.so"
 # Per-file extra flags.  -fno-slp-vectorize: the SLP vectoriser pairs independent fp32 FMAs into v_pk_fma_f32,
 # which on gfx950 issues at half rate (no gain) and needs v_mov shuffles to build the 64-bit operand pairs:
 # +6% renders/s on the compositing kernels without it (measured).
-NOSLP_FILES = os.environ.get("MOBGS_NOSLP_FILES", "raster.hip,raster_layers.hip").split(",")
+NOSLP_FILES = os.environ.get("MOBGS_NOSLP_FILES", "raster.hip,raster_bwd_mfma.hip,raster_layers.hip").split(",")
 EXTRA_FLAGS = {f: ["-fno-slp-vectorize"] for f in NOSLP_FILES if f}
 # project.hip: no implicit FMA contraction.  radii (= ceil(3 sqrt(lambda_max))), tile rectangles and the cull tests
 # are integer / boolean functions of float expressions; with the compiler free to fuse a * b + c differently from the
@@ -30,7 +30,7 @@ EXTRA_FLAGS = {f: ["-fno-slp-vectorize"] for f in NOSLP_FILES if f}
 # HBM-bound: no measurable cost.
 EXTRA_FLAGS.setdefault("project.hip", [])
 EXTRA_FLAGS["project.hip"] = EXTRA_FLAGS["project.hip"] + ["-ffp-contract=off"]
-for _f in ("raster.hip", "raster_layers.hip"):  # experiment hook: extra flags for the compositing kernels
+for _f in ("raster.hip", "raster_bwd_mfma.hip", "raster_layers.hip"):  # experiment hook: extra flags for the compositing kernels
     EXTRA_FLAGS.setdefault(_f, [])
     EXTRA_FLAGS[_f] = EXTRA_FLAGS[_f] + os.environ.get("MOBGS_RASTER_EXTRA_FLAGS", "").split()
 
@@ -74,7 +74,7 @@ def is_stale() -> bool:
     if not LIB_PATH.exists():
         return True
     t = LIB_PATH.stat().st_mtime
-    deps = sources() + [CSRC / "common.h", CSRC / "hexplane.h", CSRC.parent.parent / "include" / "mobgs_hip.h"]
+    deps = sources() + [CSRC / "common.h", CSRC / "raster_shared.h", CSRC / "hexplane.h", CSRC.parent.parent / "include" / "mobgs_hip.h"]
     return any(d.exists() and d.stat().st_mtime > t for d in deps)
 
 
@@ -97,6 +97,7 @@ def _build_extension_locked(force: bool, verbose: bool) -> Path:
         objs.append(obj)
         if not force and obj.exists() and obj.stat().st_mtime > max(
                 src.stat().st_mtime, (CSRC / "common.h").stat().st_mtime, (CSRC / "hexplane.h").stat().st_mtime,
+                (CSRC / "raster_shared.h").stat().st_mtime,
                 (CSRC.parent.parent / "include" / "mobgs_hip.h").stat().st_mtime):
             continue
         cmd = [hipcc, *flags, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]

@@ -66,7 +66,10 @@ __host__ __device__ inline TileRect tile_rect(float mx, float my, int radius, in
 // 66 us, raster_bwd 215 -> 113 us on a 30 k-splat scene; a 920-tile grid still gains 1.34x per step, a 1400-tile
 // grid already loses 2 %: four waves per tile pay the per-entry overhead four times).
 constexpr int SCHED_HEAVY = 1 << 30;
-constexpr size_t SCHED_SMALL_GRID = 1024;
+#ifndef MOBGS_SCHED_SMALL_GRID
+#define MOBGS_SCHED_SMALL_GRID 1024  // (experiments: a huge value makes every grid "small" = every tile may be heavy)
+#endif
+constexpr size_t SCHED_SMALL_GRID = MOBGS_SCHED_SMALL_GRID;
 __host__ __device__ inline size_t sched_max_heavy(size_t n_tiles) {
     return n_tiles <= SCHED_SMALL_GRID ? n_tiles : n_tiles / 8;
 }
@@ -194,6 +197,19 @@ inline int tuning_list_hint(const MobgsTuning* t) { return (t && t->longest_list
 inline int tuning_all_reach(const MobgsTuning* t) { return (t && t->quadrant_culling == 0) ? 1 : 0; }
 inline int tuning_block_walk(const MobgsTuning* t) { return (t && t->block_walk == 0) ? 0 : 1; }
 inline int tuning_bwd_block_walk(const MobgsTuning* t) { return (t && t->bwd_block_walk == 1) ? 1 : 0; }
+// backward compositor with the gradient sums on the matrix pipe (raster_bwd_mfma.hip; MobgsTuning.bwd_mfma): 0 = off,
+// 1 = one wave per tile + the four-wave team for the schedule's heavy tiles, 2 = the team for every tile.  Library
+// default (field < 0): 1 on grids of <= SCHED_SMALL_GRID tiles -- every tile is heavy there and the team kernel measures
+// 92 us against 120 us (512x288, 30 k splats) -- and 0 on larger grids, where the quadrant kernel is faster (517 us
+// against 614 / 722 us at 1352x1014, 300 k splats: DESIGN.md section 4d).
+#ifndef MOBGS_BWD_MFMA_DEFAULT
+#define MOBGS_BWD_MFMA_DEFAULT (-1)
+#endif
+inline int tuning_bwd_mfma(const MobgsTuning* t, int n_tiles) {
+    int v = (t && t->bwd_mfma >= 0) ? t->bwd_mfma : MOBGS_BWD_MFMA_DEFAULT;
+    if (v < 0) v = (size_t)n_tiles <= SCHED_SMALL_GRID ? 1 : 0;
+    return v > 2 ? 2 : v;
+}
 inline int tuning_geometry_per_camera(const MobgsTuning* t) { return (t && t->geometry_per_camera == 1) ? 1 : 0; }
 void isect_zeroed_region(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity, int32_t** ptr, size_t* count);
 

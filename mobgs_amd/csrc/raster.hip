@@ -23,62 +23,17 @@
 #include <type_traits>
 
 #include "common.h"
+#include "raster_shared.h"
 
 namespace mobgs {
 
-constexpr float ALPHA_MIN = 1.f / 255.f;
-constexpr float ALPHA_MAX = 0.999f;
-constexpr float T_STOP = 1e-4f;
-constexpr int PPL = 4;            // pixels per lane
-constexpr int TILES_PER_WG = 4;   // waves per workgroup, each on its own tile
-
-// Which tile this wave works on: with a schedule, workgroups take tiles in the given order (heaviest first);
-// without, tiles are taken in XCD-chunked raster order.  -1: nothing to do.  With a schedule the value may carry
-// SCHED_HEAVY: the 4 waves of the workgroup then share that ONE tile, wave w taking its 8x8 quadrant w.
-__device__ inline int scheduled_tile(const int32_t* tile_order, int n_groups, int n_tiles_total, int wv) {
-    if (tile_order) {
-        const int slot = blockIdx.x * TILES_PER_WG + wv;
-        return slot < (int)sched_slots((size_t)n_tiles_total) ? tile_order[slot] : -1;
-    }
-    const int group = xcd_chunked(blockIdx.x, n_groups);
-    if (group >= n_groups) return -1;
-    const int tile = group * TILES_PER_WG + wv;
-    return tile < n_tiles_total ? tile : -1;
-}
-
-__device__ inline void wave_lds_fence() {
-    // LDS operations of one wave execute in issue order; only the compiler has to be told
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Optional restriction of a compositing pass to one class of splats: sel = 1 keeps flat ids with (id % N) < Ns
-// ("static"), sel = 2 the others ("dynamic"), 0 = no restriction.  The pass walks the SAME per-tile lists and list
-// indices as the unrestricted one; entries of the other class are dropped when a batch is staged, so they cost a
-// class test per batch, not a trip through the blend loop.
-struct ClassSel {
-    int sel, N, Ns;
-    int all_reach;  // testing aid (MobgsTuning.quadrant_culling = 0): treat every quadrant as reachable
-    __device__ __forceinline__ bool keeps(int flat_id) const { return sel == 0 || (((flat_id % N) < Ns) == (sel == 1)); }
-};
-
-// sigma / visibility / alpha of one splat at one pixel; the same instruction sequence in fwd and bwd
-struct Eval {
-    float dx, dy, vis, alpha;
-    bool pass;
-};
-__device__ __forceinline__ Eval eval_splat(float gx, float gy, float ca, float cb, float cc, float op, float px,
-                                           float py) {
-    Eval e;
-    e.dx = gx - px;
-    e.dy = gy - py;
-    const float sigma = __fmaf_rn(0.5f, __fmaf_rn(ca * e.dx, e.dx, cc * e.dy * e.dy), cb * e.dx * e.dy);
-    e.vis = __expf(-sigma);
-    e.alpha = fminf(ALPHA_MAX, op * e.vis);
-    e.pass = !(sigma < 0.f || e.alpha < ALPHA_MIN);
-    return e;
-}
+// raster_bwd_mfma.hip: the backward compositor with the gradient sums on the matrix pipe (<= 10 total channels)
+bool raster_bwd_mfma_launch(int mode, int D, bool filter, int grid, hipStream_t st, int nt, int n_groups, int tile_w, int tile_h,
+                            int width, int height, const float* records, const float* backgrounds,
+                            const int32_t* radii, const int32_t* cum_tiles, const int32_t* keep_scan,
+                            const int32_t* tile_offsets, const int32_t* flatten_ids, const float* render_alphas,
+                            const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
+                            const int32_t* tile_order, ClassSel cls, const uint8_t* isect_reach, int32_t* any_record);
 
 // ---------------------------------------------------------------------------------------------------
 // pack: gather the per-splat inputs of the compositor into one aligned record
@@ -1555,6 +1510,11 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
     const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
     const int bwd_blocks = tuning_bwd_block_walk(tuning);
+    if (tuning_bwd_mfma(tuning, nt) && !bwd_blocks &&
+        raster_bwd_mfma_launch(tuning_bwd_mfma(tuning, nt), D, false, grid, st, nt, n_groups, tile_w, tile_h, width, height, records, backgrounds,
+                               radii, cum_tiles, keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids, v_render,
+                               v_alphas, grad_slots, tile_order, ClassSel{0, 1, 0, g_all_reach}, isect_reach, any_record))
+        return check_launch("raster_bwd_mfma_kernel");
     const int rc = dispatch_channels(D, [&](auto cd) {
         constexpr int CD = decltype(cd)::value;
         if constexpr (CD >= 7 && CD <= 10) {
@@ -1629,6 +1589,12 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
     const int nt = C * tile_w * tile_h;
     const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
+    if (tuning_bwd_mfma(tuning, nt) &&
+        raster_bwd_mfma_launch(tuning_bwd_mfma(tuning, nt), channels_total, true, grid, (hipStream_t)stream, nt, n_groups, tile_w, tile_h, width,
+                               height, records, backgrounds, radii, cum_tiles, keep_scan, tile_offsets, flatten_ids,
+                               render_alphas, last_ids, v_render, v_alphas, grad_slots, tile_order,
+                               ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach, any_record))
+        return check_launch("raster_bwd_mfma_kernel(class)");
     if (channels_total == 10)
         hipLaunchKernelGGL((raster_bwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream,
                            nt, n_groups, tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles,

@@ -268,12 +268,14 @@ _tile_culling = True
 # no state).  tuning.heavy_tile_len / tuning.quadrant_culling / tuning.block_walk may be changed by tests and
 # experiments.
 tuning = _lib.MobgsTuning()
+if os.environ.get("MOBGS_BWD_MFMA") is not None:  # A/B arm of the round-4 backward compositor (1 / 0; unset = library default)
+    tuning.bwd_mfma = int(os.environ["MOBGS_BWD_MFMA"])
 
 
 def _tuning_with_hint(key):
     """`tuning` plus the longest list the previous frame on this device had (selects the dense binning variant)."""
     t = _lib.MobgsTuning(tuning.heavy_tile_len, _len_hint.get(key, 0), tuning.quadrant_culling, tuning.block_walk,
-                          tuning.bwd_block_walk)
+                          tuning.bwd_block_walk, 0, tuning.bwd_mfma)
     _tuning_keepalive.append(t)
     del _tuning_keepalive[:-8]
     return t.ref()
@@ -873,7 +875,7 @@ class _ProjectAndBin(torch.autograd.Function):
             if not (quats.dim() == 3 and means.shape[0] == C and quats.shape[0] == C and SPECULATIVE_BINNING):
                 raise ValueError("per-camera geometry: means [C,N,3] and quats [C,N,4] with C = number of cameras")
             call_tuning = _lib.MobgsTuning(tuning.heavy_tile_len, tuning.longest_list_hint, tuning.quadrant_culling,
-                                           tuning.block_walk, tuning.bwd_block_walk, 1)
+                                           tuning.block_walk, tuning.bwd_block_walk, 1, tuning.bwd_mfma)
             _tuning_keepalive.append(call_tuning)
             del _tuning_keepalive[:-8]
         else:

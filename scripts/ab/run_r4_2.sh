@@ -1,0 +1,6 @@
+cd scripts/ubench && ./mfma_coissue > $GRAFT_REPO_ROOT/gpurun_out/mfma_coissue.txt 2>&1; cd $GRAFT_REPO_ROOT
+cat gpurun_out/mfma_coissue.txt
+for v in "$@"; do
+  echo "=== $v full"; MOBGS_LIB=$GRAFT_REPO_ROOT/scripts/ab/lib$v.so timeout 300 scripts/prof.sh chk_$v python $GRAFT_REPO_ROOT/scripts/check_bwd_mfma.py 300000 2>&1 | grep "raster_bwd\|raster_fwd" | cut -c1-200
+  grep "WORST\|bwd_mfma=" gpurun_out/chk_$v/stdout.log
+done

@@ -1,0 +1,7 @@
+export MOBGS_ARMS=0,1,2
+for v in "$@"; do
+  echo "=== $v full"; MOBGS_LIB=$GRAFT_REPO_ROOT/scripts/ab/lib$v.so timeout 300 scripts/prof.sh chk_$v python $GRAFT_REPO_ROOT/scripts/check_bwd_mfma.py 300000 2>&1 | grep "raster_bwd" | cut -c1-200
+  grep "WORST\|bwd_mfma=\|timing\|rror" gpurun_out/chk_$v/stdout.log
+done
+echo "=== small M3"; MOBGS_LIB=$GRAFT_REPO_ROOT/scripts/ab/libM3.so timeout 300 scripts/prof.sh chk_small python $GRAFT_REPO_ROOT/scripts/check_bwd_mfma.py 30000 512 288 2>&1 | grep "raster_bwd" | cut -c1-200
+grep "WORST\|bwd_mfma=\|timing\|rror" gpurun_out/chk_small/stdout.log

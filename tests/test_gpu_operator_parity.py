@@ -605,7 +605,9 @@ def test_zero_cotangent_pixels_are_skipped_exactly(hip_device):
     ref = grads(v_img * mask + 1e-30 * (1 - mask), v_a * mask)   # nowhere exactly zero: nothing is skipped
     got = grads(v_img * mask, v_a * mask)
     for k in names:
-        _close(got[k], ref[k], 1e-6, 1e-7 * float(ref[k].abs().max()) + 1e-12, f"grad[{k}] with masked cotangents")
+        # (the skipped pixels shorten the walk, which moves the batch boundaries: the matrix-pipe backward then groups the
+        # same terms differently -- observed 2e-6 of the maximum; the quadrant kernel adds them in the same order)
+        _close(got[k], ref[k], 1e-5, 1e-5 * float(ref[k].abs().max()) + 1e-12, f"grad[{k}] with masked cotangents")
     zero = grads(torch.zeros_like(v_img), torch.zeros_like(v_a))
     for k in names:
         assert float(zero[k].abs().max()) == 0.0, k
