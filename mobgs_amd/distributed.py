@@ -54,6 +54,25 @@ class _DoneWork:
         return True
 
 
+class _CopyBackWork:
+    """Handle of an asynchronous all-reduce that ran on an fp32 COPY of a half-precision buffer: wait() awaits the
+    exchange and rounds the sum back into the buffer (once)."""
+
+    def __init__(self, work, dst: torch.Tensor, src: torch.Tensor):
+        self.work, self.dst, self.src, self.done = work, dst, src, False
+
+    def wait(self, timeout=None):
+        if not self.done:
+            if self.work is not None:
+                self.work.wait()
+            self.dst.copy_(self.src)
+            self.done = True
+        return True
+
+    def is_completed(self):
+        return self.done or self.work is None or self.work.is_completed()
+
+
 class _SumAcrossRanks(torch.autograd.Function):
     """y = sum_r x_r (all-reduce).  reduce_backward=False: the caller's loss is a function of y that is IDENTICAL on
     every rank, so the gradient of that single loss w.r.t. this rank's x_r is dL/dy itself -- backward is the identity.
@@ -299,10 +318,16 @@ class SubframeShard:
             local = torch.stack([s if s is not None else torch.zeros_like(like) for s in sums])
             return self.mean_of_subframes(local, n_sub, donate=True, reduce_backward=reduce_backward)
         totals: List[Optional[torch.Tensor]] = [None] * n_views
+        counts = [0] * n_views
         works = []
 
         def exchange(v):
             part = sums[v] if sums[v] is not None else torch.zeros_like(like)
+            if counts[v] == 1:
+                # the partial "sum" of a rank with ONE unit of the view IS that unit's render -- a tensor the caller
+                # keeps reading (the mid frame's outputs feed the depth / flow terms): never reduce it in place
+                # (8 MB per view at 1352x1014).  Two or more units: the sum is a fresh temporary.
+                part = part.clone()
             if reduce_backward and not part.requires_grad:
                 part = part.detach().requires_grad_(True).clone()
             tot, work = _SumAcrossRanksAsync.apply_async(part, self.group, reduce_backward)
@@ -316,6 +341,7 @@ class SubframeShard:
                 if vv == v:
                     img = render_unit(v, k)
                     sums[v] = img if sums[v] is None else sums[v] + img
+                    counts[v] += 1
             exchange(v)
         for w in works:
             if w is not None:
@@ -338,10 +364,11 @@ class SubframeShard:
                     # fp32 and round once.  (The trainable fp16-storage mode keeps no half
                     # gradients at all: GaussianParams(attr_dtype=float16, master=True) accumulates them in fp32.)
                     w32 = b.float()
-                    _all_reduce_sum(w32, self.group)
-                    b.copy_(w32)
-                    if async_op:
-                        works.append(_DoneWork())
+                    if async_op:  # the fp32 copy is reduced asynchronously; wait() rounds it back once
+                        works.append(_CopyBackWork(_all_reduce_sum(w32, self.group, True), b, w32))
+                    else:
+                        _all_reduce_sum(w32, self.group)
+                        b.copy_(w32)
                 else:
                     works.append(_all_reduce_sum(b, self.group, async_op))
             return works if async_op else None

@@ -25,8 +25,8 @@ from .._lib import DerivedCache
 from ..ops import PrepSplats, decode, decode_with_channels
 from . import network_gui  # noqa: F401  (train.py imports it from here)
 
-__all__ = ["render", "render_many", "get_flow", "get_flow_many", "get_flow_static", "interpolate_cubic_hermite",
-           "network_gui"]
+__all__ = ["render", "render_many", "viewspace_grad", "get_flow", "get_flow_many", "get_flow_static",
+           "interpolate_cubic_hermite", "network_gui"]
 
 # True: the static-only / dynamic-only images of a train-mode render() come from one layered compositing pass over
 # the lists of the combined render (csrc/raster_layers.hip); False: one rasterization per set, call for call like
@@ -383,7 +383,11 @@ def render_many(viewpoint_cameras, stat_pc, dyn_pc, pipe, bg_color, delta_exposu
     single render already fills the chip and nothing is gained; at the reference's own operating point (512x288, ~30 k
     splats: 576 tiles, every kernel at its launch floor) the sub-frames' renders stop being latency-bound.
     Images are bit-identical to separate render() calls; gradients agree to summation order.
-    -> list of K dicts {"render" [3,H,W], "depth" [1,H,W], "radii" [N], "viewspace_points" [1,N,2], "visibility_filter"}."""
+    -> list of K dicts {"render" [3,H,W], "depth" [1,H,W], "radii" [N], "viewspace_points", "viewspace_index",
+    "visibility_filter"}.  NOTE "viewspace_points" is the ONE [K,N,2] tensor of the batch, shared by the K dicts (its
+    gradient arrives in one piece), NOT render()'s [1,N,2]: row "viewspace_index" belongs to the dict's camera.  Code
+    written for render() -- `viewspace_point_tensor.grad.squeeze(0)[:Ns]`, train.py:637-646 -- must go through
+    viewspace_grad(out), which returns that camera's [N,2] gradient."""
     cams = list(viewpoint_cameras)
     K = len(cams)
     deltas = list(delta_exposures) if delta_exposures is not None else [None] * K
@@ -427,6 +431,16 @@ def render_many(viewpoint_cameras, stat_pc, dyn_pc, pipe, bg_color, delta_exposu
         outs.append({"render": rendered, "depth": depth.unsqueeze(0), "radii": radii,
                      "viewspace_points": info["means2d"], "viewspace_index": k, "visibility_filter": radii > 0})
     return outs
+
+
+def viewspace_grad(out):
+    """[N,2] gradient of the 2-D means of ONE output dict -- of render() ("viewspace_points" [1,N,2]) or of render_many()
+    (the batch's shared [K,N,2] tensor, row out["viewspace_index"]): what train.py:637-646 reads as
+    `viewspace_point_tensor.grad.squeeze(0)`.  None before backward."""
+    g = out["viewspace_points"].grad
+    if g is None:
+        return None
+    return g[out["viewspace_index"]] if "viewspace_index" in out else g.squeeze(0)
 
 
 def _raster_acc(raster, sl, colors, bgs):

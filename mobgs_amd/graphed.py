@@ -14,7 +14,9 @@ count-sized buffers take their capacity, fixed from a warm-up frame times a marg
 device memory as they always did.  Arena overflow cannot be repaired inside a graph: the kernels then see empty lists,
 `check()` reports it from the pinned count rows and `recapture()` re-records with the larger sizes it has learnt.
 Outputs and gradients are bit-identical to the eager step (tests/test_gpu_graphed.py).
-Each replay OVERWRITES the leaves' .grad (static tensors owned by the graph) with the step's gradients.
+Each replay OVERWRITES the leaves' .grad (static tensors owned by the graph) with the step's gradients: gradients
+accumulated before capture() are discarded, and the step is NOT compatible with gradient storage that lives elsewhere --
+distributed.FlatGradients (views of a flat buffer), LeafGradSink / fp32 masters -- capture() raises when it sees them.
 """
 from __future__ import annotations
 
@@ -28,13 +30,14 @@ from .gaussian_renderer import render
 
 
 class _StaticCamera(PinholeCamera):
-    """A PinholeCamera whose pose and time live in ONE device buffer that is rewritten in place between replays
-    (one 184-byte host-to-device copy from a pinned staging row per call)."""
+    """A PinholeCamera whose pose and time live in ONE device buffer that is rewritten in place between replays (one
+    184-byte device copy of a cached state per call).  Only what the in-kernel ray path of render() reads is kept
+    current -- w2c, world_view_transform, ray_c2w, the times; camera_center / full_proj_transform / cam_ray keep the
+    identity pose of construction, which is why GraphedRenderStep refuses to capture with INKERNEL_RAYS off."""
 
     def __init__(self, width, height, K, device):
         super().__init__(width, height, K, torch.eye(4), time=0.0, max_time=1, device=device)
         self.buf = torch.zeros(46, dtype=torch.float32, device=device)
-        self.stage = torch.zeros(46, dtype=torch.float32, pin_memory=True)
         self._w2c = self.buf[0:16].view(4, 4)
         self.world_view_transform = self.buf[16:32].view(4, 4)   # the reference stores the transpose
         self.ray_c2w = self.buf[32:44].view(3, 4)
@@ -92,6 +95,19 @@ class GraphedRenderStep:
 
     def capture(self, w2c: torch.Tensor, time: float):
         """Warm up eagerly at this camera (sizes the arenas), then record forward + backward into one graph."""
+        from . import gaussian_renderer as _G
+        if not getattr(_G, "INKERNEL_RAYS", True):
+            raise RuntimeError("GraphedRenderStep needs the in-kernel rays (gaussian_renderer.INKERNEL_RAYS = True): the "
+                               "static camera does not refresh cam_ray / camera_center")
+        for p in self.params:
+            # the recorded backward ASSIGNS graph-owned .grad tensors: gradients that live as views of a flat buffer
+            # (distributed.FlatGradients) or are sunk into fp32 masters (LeafGradSink) would silently be detached
+            if p.grad is not None and p.grad._base is not None:
+                raise RuntimeError("GraphedRenderStep: a leaf's .grad is a view of a flat gradient buffer; the captured "
+                                   "backward would replace it -- copy step.params' .grad into the buffer after replay "
+                                   "instead, or capture before FlatGradients is built")
+            if getattr(p, "master", None) is not None:
+                raise RuntimeError("GraphedRenderStep does not support half-precision attributes with fp32 masters")
         self.cam.set(w2c, time)
         prev_mt = torch.autograd.is_multithreading_enabled()
         torch.autograd.set_multithreading_enabled(False)  # backward on the capturing thread / stream

@@ -935,6 +935,13 @@ class _ProjectAndBin(torch.autograd.Function):
         tile_offsets = torch.empty(nt + 1, dtype=torch.int32, device=dev)
         tile_order = (torch.empty(lib.mobgs_tile_order_len(nt), dtype=torch.int32, device=dev)
                       if TILE_SCHEDULE else None)
+        if _static is not None:
+            # this branch reads the frame's counts back on the host (an event wait or a poll of the pinned sequence
+            # word) -- inside a StaticCapacity context (HIP-graph capture: no kernel runs) that would raise a capture
+            # error or spin forever.  Say what is missing instead.
+            raise RuntimeError("StaticCapacity needs the C++ host fast path and speculative binning: "
+                               f"fast path {'loaded' if _fast.get() is not None else 'NOT loaded (MOBGS_FASTPATH=0 or the build failed)'}, "
+                               f"SPECULATIVE_BINNING = {SPECULATIVE_BINNING}")
         stats_dev = torch.empty(3, dtype=torch.int64, device=dev)
         stats_host = (ctypes.c_int64 * 3)()
         # optional: the projection kernel also writes the compositor's packed records (colours + depth channel)

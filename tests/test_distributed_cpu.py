@@ -405,15 +405,22 @@ def _planned_worker(rank, world, port, q):
         bucket = FlatGradients([w, b], extra={f"view{v}": 3 * NSPLAT for v in range(V)})
         bucket.zero()
         mids = {}
+        rendered = {}
 
         def unit(v, k):
             if k == K // 2:
                 mids[v] = _toy_mid_outputs((w, b), v)
                 mids[v][1].retain_grad()
-            return _toy_unit((w, b), v, k)
+            img = _toy_unit((w, b), v, k)
+            rendered[(v, k)] = (img, img.detach().clone())
+            return img
 
         mine = shard.planned_units(shard.iteration_plan(V, K, with_flows=False)["render"], K)
         pred = shard.render_blurry_views(unit, V, K, like=torch.zeros(3, 6, 8), units=mine, overlap=True)
+        # a unit's render stays what the rank rendered -- also on a rank that owns only ONE unit of a view, whose
+        # partial "sum" is that very tensor (the in-place exchange used to overwrite it with the cross-rank sum)
+        for key, (img, before) in rendered.items():
+            assert torch.equal(img.detach(), before), f"rank {rank}: render of unit {key} was overwritten by the exchange"
         loss = _iteration_loss(pred, mids, (w, b), shard)
         loss.backward()
         for v, (_, m2d) in mids.items():

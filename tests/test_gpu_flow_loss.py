@@ -36,31 +36,44 @@ def _case(B, K, H, W, seed, flow=2.5, zero_frac=0.3, far=0.02):
 NAMES = ("ori", "latent", "e2m", "m2e", "la", "da")
 
 
-def _run(fn, case, dev, **kw):
-    t = {k: v.clone().to(dev).requires_grad_(True) for k, v in case.items()}
+def _run(fn, case, dev, dtype=torch.float32, **kw):
+    t = {k: v.clone().to(dev, dtype).requires_grad_(True) for k, v in case.items()}
     loss = fn(*(t[k] for k in NAMES), **kw)
     loss.backward()
     return float(loss), {k: t[k].grad.detach().cpu() for k in NAMES}
+
+
+def _check(got, ggot, ref, gref, what):
+    """The reference is evaluated in float64 on the CPU, so the comparison does not depend on the order in which some
+    torch version / thread count happens to add fp32 terms.  Bounds: the loss is a mean over n = B K 3 H W
+    terms, each rounded once and summed in fp32 by a tree: error <= ~log2(n) eps relative, 1e-5 allowed.  A gradient
+    element is a sum of <= ~30 bilinear-tap terms of similar size: 1e-5 of the tensor's maximum + 1e-5 of the element.
+    The L1 terms have sgn() in their derivative: where |difference * mask| is within rounding of zero the fp32 and the
+    fp64 evaluation may pick different signs -- up to 1e-4 of the elements may be off by up to two terms of one pixel
+    (2 / n of the loss scale, i.e. far below 1e-3 of the tensor's maximum)."""
+    assert abs(got - ref) <= 1e-5 * abs(ref), (what, got, ref)
+    for k in NAMES:
+        a, b = ggot[k].double(), gref[k].double()
+        assert a.shape == b.shape
+        m = float(b.abs().max())
+        err = (a - b).abs()
+        bad = err > 1e-5 * m + 1e-5 * b.abs() + 1e-14
+        nbad = int(bad.sum())
+        assert nbad <= 1e-4 * bad.numel(), (what, k, nbad, float(err.max()), m)
+        if nbad:
+            assert float(err[bad].max()) <= 1e-3 * m, (what, k, nbad, float(err[bad].max()), m)
 
 
 @pytest.mark.parametrize("B,K,H,W,seed", [(1, 1, 5, 7, 0), (2, 3, 37, 70, 1), (1, 9, 67, 129, 2), (2, 2, 130, 64, 3)])
 def test_flow_warp_loss_matches_reference_block(hip_device, B, K, H, W, seed):
     from mobgs_amd.loss_utils import flow_warp_loss
     case = _case(B, K, H, W, seed)
-    ref, gref = _run(RT.flow_warp_loss, case, "cpu")
+    ref, gref = _run(RT.flow_warp_loss, case, "cpu", torch.float64)
     for combine in (True, False):
         got, ggot = _run(flow_warp_loss, case, hip_device, combine_taps=combine)
-        # observed (scripts/observed_flow_loss_errors.py): loss 1e-7 relative; gradients <= 5e-7 of the tensor's maximum,
-        # no element beyond -- allowed: 3x that
-        assert abs(got - ref) <= 3e-7 * abs(ref), (combine, got, ref)
-        for k in NAMES:
-            a, b = ggot[k], gref[k]
-            assert a.shape == b.shape
-            # fp32 sums in a different order; the two scattered image gradients are sums of atomics whose order changes
-            # from run to run: twice the margin there
-            tol = (3e-6 if k in ("ori", "latent") else 1.5e-6) * float(b.abs().max()) + 1e-12
-            bad = (a - b).abs() > tol + 1e-5 * b.abs()
-            assert int(bad.sum()) == 0, (combine, k, int(bad.sum()), float((a - b).abs().max()), tol)
+        # observed (scripts/observed_flow_loss_errors.py, against the fp32 CPU evaluation): loss 1e-7 relative; gradients
+        # <= 5e-7 of the tensor's maximum (2.3e-6 on the atomically summed image gradients at the benchmark size)
+        _check(got, ggot, ref, gref, f"combine_taps={combine}")
 
 
 def test_zero_weight_is_a_constant_and_inputs_are_untouched(hip_device):
@@ -97,12 +110,6 @@ def test_flow_warp_loss_at_benchmark_size(hip_device):
     reference block on the CPU."""
     from mobgs_amd.loss_utils import flow_warp_loss
     case = _case(1, 3, 1014, 1352, 9, flow=3.0)
-    ref, gref = _run(RT.flow_warp_loss, case, "cpu")
+    ref, gref = _run(RT.flow_warp_loss, case, "cpu", torch.float64)
     got, ggot = _run(flow_warp_loss, case, hip_device)
-    assert abs(got - ref) <= 3e-7 * abs(ref), (got, ref)
-    for k in NAMES:
-        a, b = ggot[k], gref[k]
-        # observed: 2.3e-6 of the maximum on the scattered image gradients (sums of up to ~30 atomics), 2e-7 elsewhere
-        tol = (1.4e-5 if k in ("ori", "latent") else 1.5e-6) * float(b.abs().max()) + 1e-14   # (atomics: twice 3x)
-        bad = (a - b).abs() > tol + 1e-5 * b.abs()
-        assert int(bad.sum()) == 0, (k, int(bad.sum()), float((a - b).abs().max()), tol)
+    _check(got, ggot, ref, gref, "benchmark size")

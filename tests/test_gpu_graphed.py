@@ -86,3 +86,33 @@ def test_graphed_step_reports_arena_overflow(hip_device):
         assert step.check() and float(out["render"].abs().max()) > 0
     finally:
         torch.autograd.set_multithreading_enabled(prev)
+
+
+def test_static_capacity_without_the_fast_path_raises_instead_of_hanging(hip_device, monkeypatch):
+    """rendering.StaticCapacity is honoured by the C++ host fast path only: the Python branch of the binning call reads
+    the frame's counts back on the host, which inside a graph capture is a capture error or an endless poll.
+    It must say so; GraphedRenderStep likewise refuses gradient storage it would silently detach."""
+    from mobgs_amd import rendering
+    from mobgs_amd.graphed import GraphedRenderStep
+    from mobgs_amd.rendering import rasterization
+    from mobgs_amd.synth import SynthCamera, splat_inputs
+    dev = hip_device
+    cam = SynthCamera().scaled(96, 64)
+    s = {k: v.to(dev) for k, v in splat_inputs(800, cam, 0, 3).items()}
+    args = (s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], s["viewmats"], s["Ks"], 96, 64)
+    rasterization(*args, packed=False)  # a first frame: capacities known
+    monkeypatch.setattr(rendering._fast, "get", lambda: None)
+    with rendering.StaticCapacity():
+        with pytest.raises(RuntimeError, match="StaticCapacity needs"):
+            rasterization(*args, packed=False)
+    monkeypatch.undo()
+    # a leaf whose .grad is a view of a flat buffer (distributed.FlatGradients)
+    from mobgs_amd.distributed import FlatGradients
+    scam, _, stat, dyn, _ = _scene(dev, 128, 96)
+    step = GraphedRenderStep(stat, dyn, 128, 96, scam.K, torch.zeros(9, device=dev))
+    flat = FlatGradients(step.params)
+    flat.zero()
+    with pytest.raises(RuntimeError, match="flat gradient buffer"):
+        step.capture(torch.eye(4), 0.3)
+    del flat, step
+    gc.collect()

@@ -34,6 +34,8 @@ def test_render_many_equals_separate_renders(hip_device, size, ns, nd):
     torch.autograd.backward([o["render"] for o in ref] + [o["depth"] for o in ref], v3 + v1)
     ref_out = [(o["render"].detach().clone(), o["depth"].detach().clone(), o["radii"].clone()) for o in ref]
     ref_g = grads()
+    from mobgs_amd.gaussian_renderer import viewspace_grad
+    ref_vs = [viewspace_grad(o).clone() for o in ref]   # what train.py:637-646 reads per render
     del ref
     for p in params:
         p.grad = None
@@ -47,6 +49,13 @@ def test_render_many_equals_separate_renders(hip_device, size, ns, nd):
         sc = float(gr.abs().max())
         assert torch.allclose(p.grad, gr, rtol=1e-4, atol=2e-5 * sc + 1e-12), \
             f"leaf {i}: max err {float((p.grad - gr).abs().max()):.3e} of {sc:.3e}"
+    # the densification input of every sub-frame: the batch shares ONE [K,N,2] tensor, viewspace_grad() picks the row
+    for k, (o, gr) in enumerate(zip(outs, ref_vs)):
+        assert o["viewspace_points"].shape[0] == K and o["viewspace_index"] == k
+        got = viewspace_grad(o)
+        assert got.shape == gr.shape
+        sc = float(gr.abs().max())
+        assert torch.allclose(got, gr, rtol=1e-4, atol=2e-5 * sc + 1e-12), f"viewspace gradient of sub-frame {k}"
 
 
 def test_prep_of_k_instants_in_one_launch_equals_k_launches(hip_device):

@@ -25,6 +25,38 @@ def test_render_matches_reference_fixture(hip_device, name):
     ref_keys = {k[4:] for k in fx if k.startswith("out_")}
     assert {k for k, v in out.items() if isinstance(v, torch.Tensor)} == ref_keys
     assert len(out) == 22
+    # What ONE flipped blend decision can do (two fp32 evaluations of alpha = o exp(-sigma) disagree in the last bit at the
+    # 1/255 threshold): the splat's weight is w = alpha T <= 1/255, so a composited feature / alpha moves by at most
+    # 2 w (|c| + |pixel|) (x 2: the flip also changes the next weights), an expected depth D / alpha by 2 w spread / alpha,
+    # and a decoded colour by the decoder's Lipschitz factor times the feature move: rgb = sigmoid(albedo + W2 relu(W1 .))
+    # -> 1/4 (1 + |W2|_inf |W1|_inf).  Derived, not a flat fraction of the range.
+    w = 1.001 / 255.0
+    cmax = float(np.abs(fx["out_colors_precomp_final"]).max())
+    w1, w2 = dyn.rgbdecoder.mlp1.weight.detach().reshape(6, 12).cpu(), dyn.rgbdecoder.mlp2.weight.detach().reshape(3, 6).cpu()
+    lip = 0.25 * (1.0 + float(w2.abs().sum(1).max()) * float(w1.abs().sum(1).max()))
+    feature_step = 2.0 * w * 2.0 * cmax
+    alpha_keys = {"d_depth": ("d_alpha",), "s_depth": ("s_alpha",), "depth": ("d_alpha", "s_alpha")}
+
+    def coverage_floor(k, ref):
+        """Lower bound of the coverage behind an expected-depth key (the combined pass covers at least what either
+        class covers); 1/255 where the fixture holds no matching map (s_depth's [3,H] quirk)."""
+        a = None
+        for name in alpha_keys[k]:
+            c = fx.get("out_" + name)
+            if c is not None and c.size == ref.size:
+                c = c.reshape(ref.shape)
+                a = c if a is None else np.maximum(a, c)
+        return np.maximum(a, 1.0 / 255.0) if a is not None else np.full(ref.shape, 1.0 / 255.0)
+
+    def flip_bound(k, ref):
+        if k in ("render", "s_render", "d_render"):
+            return lip * feature_step
+        if k in ("d_alpha", "s_alpha"):
+            return 2.0 * w
+        if k in alpha_keys:
+            return float((2.0 * w * float(ref.max() - ref.min()) / coverage_floor(k, ref)).max())
+        return 2.0 * w * 2.0 * max(1.0, float(np.abs(ref).max()))  # splatted flow / coordinate maps: w (|f| + |pixel f|)
+
     for k in sorted(ref_keys):
         ref = fx["out_" + k]
         got = out[k].detach().cpu()
@@ -33,10 +65,9 @@ def test_render_matches_reference_fixture(hip_device, name):
             assert np.array_equal(got.numpy(), ref), k
         elif k in IMG_KEYS:
             scale = max(1.0, float(np.abs(ref).max()))
-            # a flipped blend decision moves a feature / alpha / depth pixel by <= 2 w (|c| + |pixel|), w <= 1/255:
-            # ~ scale / 64 before the decoder (whose two layers are contractions here); observed: no flip at all in
-            # the three fixtures, allowed for 2e-4 of the elements (<= 6 of them)
-            close(got, ref, 0, 3e-5 * scale, f"out[{k}]", flip_frac=2e-4, flip_atol=scale / 100)
+            # observed: no flip at all in the three fixtures; allowed for 2e-4 of the elements (<= 6 of them), each
+            # within the derived one-blend-step bound of its key
+            close(got, ref, 0, 3e-5 * scale, f"out[{k}]", flip_frac=2e-4, flip_atol=flip_bound(k, ref))
         else:
             close(got, ref, 2e-5, 1e-5 * max(1.0, float(np.abs(ref).max())), f"out[{k}]")
     # north-star criterion: PSNR of the decoded image against a common target within 1e-4 dB
@@ -50,12 +81,15 @@ def test_render_matches_reference_fixture(hip_device, name):
             continue
         ref = fx["grad_" + k]
         scale = float(np.abs(ref).max())
-        close(leaf.grad, ref, 1e-3, 5e-4 * scale + 1e-7, f"grad[{k}]")
+        # the full-size comparison's form (tests/test_gpu_fullsize.py): rtol 1e-3 + 1e-4 of the tensor's maximum, a 1e-5
+        # tail for entries next to a flipped blend decision (was a flat 5e-4 of the maximum: VERDICT r3 item 8)
+        close(leaf.grad, ref, 1e-3, 1e-4 * scale + 1e-7, f"grad[{k}]", flip_frac=1e-5, flip_atol=5e-3 * scale)
     if use_w2c:
         ref = fx["grad_w2c"]
-        close(w2c_leaf.grad, ref, 1e-3, 5e-4 * float(np.abs(ref).max()), "grad[w2c]")
+        close(w2c_leaf.grad, ref, 1e-3, 1e-4 * float(np.abs(ref).max()), "grad[w2c]")
     ref = fx["grad_viewspace_points"]
-    close(out["viewspace_points"].grad, ref, 1e-3, 5e-4 * float(np.abs(ref).max()), "viewspace_points.grad")
+    sc = float(np.abs(ref).max())
+    close(out["viewspace_points"].grad, ref, 1e-3, 1e-4 * sc, "viewspace_points.grad", flip_frac=1e-5, flip_atol=5e-3 * sc)
 
 
 def test_get_flow_matches_reference_fixture(hip_device):
