@@ -142,7 +142,7 @@ def source_sha():
     comments and blank lines removed (a reworded comment does not make the counters stale)."""
     import re
     h = hashlib.sha256()
-    for f in ("raster.hip", "isect.hip", "common.h"):
+    for f in ("raster.hip", "raster_shared.h", "isect.hip", "common.h"):
         with open(os.path.join(ROOT, "mobgs_amd", "csrc", f), "r", encoding="utf-8") as fh:
             text = fh.read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -152,7 +152,7 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_raster_bwd_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r04_raster_bwd_pmc.json")
 
 
 def _rocprof_child(extra, tag, child_args):
@@ -242,7 +242,7 @@ def collect_pmc(args, I, P):
     """bench.py --pmc: re-collect the counters behind roofline.traffic / roofline.valu for raster_bwd -- three separate
     rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU: MI355X_MICROARCH.md, "rocprofv3 PMC slots"; no
     tracing flags) over a short child run -- and store them with the hash of the kernel sources in
-    profiles/r03_raster_bwd_pmc.json.  Correction rule (measured, DESIGN section 5: scripts/ubench/fetch_calib.hip):
+    profiles/r04_raster_bwd_pmc.json.  Correction rule (measured, DESIGN section 5: scripts/ubench/fetch_calib.hip):
     FETCH_SIZE counts a 16-byte-per-lane coalesced stream at 0.5x and 64-byte record gathers / stores at 1.0x."""
     import csv
     vals = {}
@@ -326,6 +326,34 @@ class DeblurWorkload:
         self.shard.all_reduce_gradients(self.bucket)
         self.mids = mids
         return pred
+
+
+    def step_unchanged(self):
+        """The same blurry views the way train.py:441-541 asks for them after nothing but the import swap: one render()
+        per latent sub-frame, every one with get_static = get_dynamic = True (train.py:441, :512), torch.mean of the stack,
+        a plain backward into ordinary .grad tensors -- no render_many, no LeafGradSink, no flat gradient buffer."""
+        for p in self.params:
+            p.grad = None
+        preds, outs, cots = [], [], []
+        for cam in self.cams:
+            pkg = render_fn(cam, self.stat, self.dyn, None, self.bg, get_static=True, get_dynamic=True)
+            for key in ("s_render", "s_depth", "d_alpha", "d_depth", "s_alpha"):
+                pkg[key]
+            warped_cams, exposure_time = self.blce.get_warped_cams(cam, None, None)
+            half = len(warped_cams) // 2
+            rendered = [pkg["render"] if k == half else
+                        render_fn(wc, self.stat, self.dyn, None, self.bg, get_static=True, get_dynamic=True,
+                                  delta_exposure=exposure_time[k])["render"] for k, wc in enumerate(warped_cams)]
+            preds.append(torch.mean(torch.stack(rendered, dim=0), dim=0) + 1e-10)
+            outs += [pkg["depth"], pkg["d_alpha"]]
+            cots += [self.v_depth, self.v_alpha]
+        torch.autograd.backward([torch.stack(preds)] + outs, [self.v_pred] + cots)
+        return preds
+
+
+def render_fn(*a, **kw):
+    from mobgs_amd.gaussian_renderer import render
+    return render(*a, **kw)
 
 
 class FlowWorkload:
@@ -565,6 +593,15 @@ def main():
                       "subframes_per_view": 9, "steps": args.deblur_steps,
                       "what": "train.py:430-541 per iteration: per view 1 train-mode mid render + 8 latent renders "
                               "(BLCE cameras + exposure offsets from the fused BLCE kernels), mean, backward, flat gradient buffer"}
+            # ... and what the UNCHANGED caller gets (north_star: train.py drops in unchanged): the same views through one
+            # render() call per sub-frame, all in train mode, plain autograd -- no opt-in entry point
+            udt, umed = timed(wl.step_unchanged, args.deblur_steps, 3, world, dist)
+            deblur["unchanged_caller"] = {
+                "ms_per_iteration": round(udt / args.deblur_steps * 1e3, 3), "event_median_ms_per_iteration": round(umed, 3),
+                "renders_per_s": round(n_units * args.deblur_steps / udt, 2),
+                "what": "the same two blurry views as train.py:441-541 issues them after the import swap of INTEGRATION.md "
+                        "section 1 alone: 9 render(get_static=True, get_dynamic=True) calls per view, torch.mean, backward "
+                        "into ordinary .grad tensors (no render_many / LeafGradSink / FlatGradients)"}
         if args.dynamic_steps > 0:
             dw = DynamicWorkload(dev, raw, scam, args.width, args.height)
             xdt, xmed = timed(dw.step, args.dynamic_steps, 3, world, dist)
@@ -609,6 +646,18 @@ def main():
                                 "the mid render, the flow-consistency term of train.py:651-671 (two grid_sample warps + masked L1, fused), backward into the flat gradient buffer, "
                                 "densification statistics, Adam on both Gaussian sets + decoder + BLCE "
                                 "(examples/train_deblur_synth.py DeblurTrainer.iteration)"}
+            tr.lambda_flow = 1e-2
+            udt, umed = timed(tr.iteration_unchanged, args.train_steps, 1, world, dist)
+            tr.lambda_flow = 0.0
+            uzdt, _ = timed(tr.iteration_unchanged, args.train_steps, 1, world, dist)
+            train_it["unchanged_caller"] = {
+                "ms_per_iteration": round(udt / args.train_steps * 1e3, 2),
+                "ms_per_iteration_lambda_flow_loss_0": round(uzdt / args.train_steps * 1e3, 2),
+                "event_median_ms_per_iteration": round(umed, 2),
+                "what": "the same iteration as train.py:430-807 writes it, after the import swap alone: per view 9 render() "
+                        "(train mode) + 9 get_flow() calls, l1_loss + ssim, the flow-consistency term as two F.grid_sample + "
+                        "two masked l1_loss (torch), loss.backward() into ordinary .grad tensors, three torch.optim.Adam steps "
+                        "(DeblurTrainer.iteration_unchanged)"}
             del tr
     else:
         wl = DeblurWorkload(dev, stat, dyn, scam, args.width, args.height, shard, args.views)
@@ -625,6 +674,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         renders = n_units * args.steps
+        # the anchor of the scaling curve, measured in THIS run: the same 18-unit iteration with all units on one GPU (no
+        # collective), every rank on its own device, outside the timed region; efficiency(N) = value / (N x scale_anchor)
+        awl = DeblurWorkload(dev, stat, dyn, scam, args.width, args.height, SubframeShard(1, 0), args.views)
+        adt, _ = timed(awl.step, max(args.steps // 2, 3), 3, world, dist, freeze=False)
+        t = torch.tensor([adt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        anchor = n_units * max(args.steps // 2, 3) / float(t.item())
+        del awl
         last["out"] = next(iter(wl.mids.values())) if wl.mids else render(cam, stat, dyn, None, bg)
         from mobgs_amd import rendering
         I = rendering.last_stats.get("n_isects", 0)
@@ -660,6 +717,17 @@ def main():
                    "renders_per_step": 1 if world == 1 else n_units,
                    "parallelism": f"subframe-shard x{world}" if world > 1 else "single"},
     }
+    # What the driver's 1 -> N curve must be anchored on: `value` at N = 1 is ONE lean render() per step (BASELINE's
+    # metric), `value` at N > 1 counts the 18 renders of a sharded deblur iteration -- unlike quantities.  scale_anchor is
+    # the N > 1 workload run on ONE GPU (renders/s): efficiency(N) = value(N) / (N x scale_anchor).
+    if world == 1:
+        result["scale_anchor"] = deblur["renders_per_s"] if deblur is not None else None
+        result["scale_anchor_field"] = "deblur.renders_per_s (this line); compare value of the N > 1 lines with it, not with `value`"
+    else:
+        result["scale_anchor"] = round(anchor, 2)
+        result["scale_anchor_field"] = ("the same 18-unit iteration with every unit on one GPU, timed in this run on every "
+                                        "rank (slowest rank): efficiency = value / (n_gpus x scale_anchor)")
+        result["scaling_efficiency_vs_anchor"] = round(value / (world * anchor), 4)
     if deblur is not None:
         result["deblur"] = deblur
     if dynamic is not None:
@@ -691,6 +759,10 @@ def main():
                     counters = json.load(open(pmc))
                     if counters.get("source_sha") == source_sha():
                         roof["traffic"] = counters.get("hbm_bytes_per_launch")
+                        roof["traffic_provenance"] = (
+                            "collected in this run (--pmc)" if roof.get("pmc_collected") else
+                            f"committed {os.path.relpath(pmc, ROOT)} (kernel sources sha {str(counters.get('source_sha'))[:12]} = "
+                            "this build's; collected by an earlier `bench.py --pmc` run, not by this invocation)")
                         pairs = counters.get("pixel_splat_pairs_per_launch")
                         vi = counters.get("valu_wave_insts_per_launch")
                         if pairs:
@@ -703,7 +775,7 @@ def main():
                                             "frac_of_fp32_vector_issue_peak": round(lane_ops / (F32_VECTOR_PEAK_TF
                                                                                                  * 1e12 / 2), 4)}
                     else:
-                        roof["traffic_note"] = ("profiles/r03_raster_bwd_pmc.json is from other kernel sources: ignored "
+                        roof["traffic_note"] = ("profiles/r04_raster_bwd_pmc.json is from other kernel sources: ignored "
                                                 "(python bench.py --pmc re-collects it)")
                 except Exception:  # noqa: BLE001
                     pass

@@ -161,6 +161,91 @@ class DeblurTrainer:
         return photo.detach()
 
 
+    def iteration_unchanged(self) -> torch.Tensor:
+        """The SAME iteration written the way /root/reference/train.py:430-807 writes it -- what runs after nothing but
+        the import swap of INTEGRATION.md section 1: one render() per latent sub-frame, every one of them with
+        get_static = get_dynamic = True (train.py:441 and :512), one get_flow() per exposure (:570-579), l1_loss + ssim
+        as two calls (:621-628), the flow-consistency term as torch statements (two F.grid_sample + two masked l1_loss,
+        :651-671), loss.backward() into ordinary .grad tensors, viewspace_points.grad for the densification statistics
+        (:634-648) and the three torch.optim.Adam steps (:790-807).  None of the opt-in entry points (render_many,
+        get_flow_many, flow_warp_loss, fused_adam_step, LeafGradSink, FlatGradients).  Single process."""
+        import torch.nn.functional as F
+        from mobgs_amd.gaussian_renderer import get_flow
+        from mobgs_amd.loss_utils import ssim
+        stat, dyn, blce, ns, bg = self.stat, self.dyn, self.blce, self.ns, self.bg
+        opts = [stat.optimizer, dyn.optimizer, blce.optimizer]
+        for o in opts:
+            o.zero_grad(set_to_none=True)
+        images, ori, d_alphas, depths, normals, vsp, radii = [], [], [], [], [], [], []
+        lat_img, lat_alpha, e2m_all, m2e_all = [], [], [], []
+        for cam in self.cams:
+            pkg = render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True)                      # train.py:441
+            for key in ("s_render", "s_depth", "d_alpha", "d_depth", "s_alpha"):
+                pkg[key]                                                                                    # :445-464
+            image_ori = pkg["render"]
+            warped_cams, exposure_time = blce.get_warped_cams(cam, None, None)                             # :472
+            half = len(warped_cams) // 2
+            rendered = []
+            for k, wc in enumerate(warped_cams):                                                           # :502-518
+                if k == half:
+                    rendered.append(image_ori)
+                else:
+                    rendered.append(render(wc, stat, dyn, None, bg, get_static=True, get_dynamic=True,
+                                           delta_exposure=exposure_time[k])["render"])
+            images.append(torch.mean(torch.stack(rendered, dim=0), dim=0) + 1e-10)                         # :540-541
+            cur = [[], [], [], []]
+            for k in range(len(warped_cams)):                                                              # :570-579
+                outs = get_flow(cam, stat, dyn, None, bg, delta_exposure=1.0 * (k - half) / half)
+                for lst, o in zip(cur, outs):
+                    lst.append(o)
+            e2m_all.append(torch.cat(cur[0], 0).unsqueeze(0))
+            m2e_all.append(torch.cat(cur[1], 0).unsqueeze(0))
+            lat_img.append(torch.cat([t.unsqueeze(0) for t in cur[2]], 0).unsqueeze(0))
+            lat_alpha.append(torch.cat([t.unsqueeze(0) for t in cur[3]], 0).unsqueeze(0))
+            ori.append(image_ori.unsqueeze(0))
+            d_alphas.append(pkg["d_alpha"].unsqueeze(0))
+            depths.append(pkg["depth"])
+            normals.append(self.get_normals(pkg["depth"] + 1e-6, self.meta))                               # :590
+            vsp.append(pkg["viewspace_points"])
+            radii.append(pkg["radii"])
+        pred = torch.stack(images)
+        Ll1 = l1_loss(pred, self.gt)                                                                       # :621-628
+        photo = (1.0 - self.opt.lambda_dssim) * Ll1 + self.opt.lambda_dssim * (1.0 - ssim(pred, self.gt))
+        loss = photo
+        for v in range(self.n_views):
+            loss = loss + 0.05 * l1_loss(depths[v], self.depths[v]) + 0.01 * d_alphas[v].mean() \
+                + 0.01 * l1_loss(normals[v], self.normals[v])
+        if self.lambda_flow != 0:                                                                          # :651-671
+            H, W = pred.shape[-2:]
+            E = K
+            ori_t, lat_t = torch.cat(ori, 0), torch.cat(lat_img, 0)
+            la_t, da_t = torch.cat(lat_alpha, 0), torch.cat(d_alphas, 0).reshape(self.n_views, 1, H, W)
+
+            def norm(c):
+                c = torch.stack([c[..., 0] / (W - 1), c[..., 1] / (H - 1)], -1)
+                return (2.0 * c - 1.0).flatten(0, 1)
+            ori_e = ori_t.unsqueeze(1).expand(-1, E, -1, -1, -1).flatten(0, 1)
+            w_e2m = F.grid_sample(ori_e, norm(torch.cat(e2m_all, 0)), mode="bilinear", padding_mode="border",
+                                  align_corners=False).reshape(-1, E, 3, H, W)
+            w_m2e = F.grid_sample(lat_t.flatten(0, 1), norm(torch.cat(m2e_all, 0)), mode="bilinear", padding_mode="border",
+                                  align_corners=False).reshape(-1, E, 3, H, W)
+            loss = loss + self.lambda_flow * (
+                l1_loss(w_e2m.flatten(0, 1), lat_t.flatten(0, 1), mask=la_t.flatten(0, 1))
+                + l1_loss(w_m2e.flatten(0, 1), ori_e,
+                          mask=da_t.unsqueeze(1).expand(-1, E, -1, -1, -1).flatten(0, 1)))
+        loss = loss + 1e-4 * ((stat._scaling ** 2).mean() + (dyn._scaling ** 2).mean())
+        loss.backward()
+        with torch.no_grad():                                                                              # :634-648
+            for v in range(self.n_views):
+                grad2d = vsp[v].grad.squeeze(0)
+                vis = radii[v] > 0
+                stat.add_densification_stats(grad2d[:ns], vis[:ns], radii=radii[v][:ns])
+                dyn.add_densification_stats(grad2d[ns:], vis[ns:], radii=radii[v][ns:])
+        for o in opts:                                                                                     # :790-807
+            o.step()
+        return photo.detach()
+
+
 def train(dev="cuda:0", iters=40, ns=4000, nd=2000, width=256, height=192, n_views=2, seed=0, lambda_flow=1e-2,
           shard=None, log=None):
     t = DeblurTrainer(dev, ns, nd, width, height, n_views, seed, lambda_flow, shard, iters)

@@ -374,6 +374,10 @@ def get_tile_culling() -> bool:
 @torch.no_grad()
 def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor,
                      tiles_per_gauss: Tensor, width: int, height: int, want_isect_ids: bool = True) -> TileLists:
+    if _static is not None:
+        raise RuntimeError("StaticCapacity: build_tile_lists (the separate projection + binning of rasterization()) reads "
+                           "the intersection counts back on the host -- use SharedProjection / render(), whose binning "
+                           "call honours the context")
     lib = _lib_()
     C, N = radii.shape
     dev = radii.device

@@ -99,12 +99,17 @@ def test_static_capacity_without_the_fast_path_raises_instead_of_hanging(hip_dev
     dev = hip_device
     cam = SynthCamera().scaled(96, 64)
     s = {k: v.to(dev) for k, v in splat_inputs(800, cam, 0, 3).items()}
-    args = (s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], s["viewmats"], s["Ks"], 96, 64)
-    rasterization(*args, packed=False)  # a first frame: capacities known
+    args = (s["means"], s["quats"], s["scales"], s["opacities"], s["viewmats"], s["Ks"], 96, 64)
+    rendering.SharedProjection(*args)  # a first frame: capacities known
+    with rendering.StaticCapacity():
+        rendering.SharedProjection(*args)   # the fast path honours the context
+        with pytest.raises(RuntimeError, match="StaticCapacity: build_tile_lists"):
+            rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], s["viewmats"], s["Ks"], 96, 64,
+                          packed=False)   # separate projection + binning: a host read-back
     monkeypatch.setattr(rendering._fast, "get", lambda: None)
     with rendering.StaticCapacity():
         with pytest.raises(RuntimeError, match="StaticCapacity needs"):
-            rasterization(*args, packed=False)
+            rendering.SharedProjection(*args)
     monkeypatch.undo()
     # a leaf whose .grad is a view of a flat buffer (distributed.FlatGradients)
     from mobgs_amd.distributed import FlatGradients
