@@ -300,6 +300,10 @@ class DeblurWorkload:
         self.params = leaves(stat, dyn) + list(self.blce.model.get_params())
         n = stat.get_xyz.shape[0] + dyn.get_xyz.shape[0]
         self.bucket = FlatGradients(self.params, extra={f"view{v}": 3 * n for v in range(n_views)})
+        # N > 1: one gradient message PER VIEW (its densification statistics ride in it), all-reduced on the communication
+        # stream while the next view back-propagates (SubframeShard.backward_by_view)
+        self.view_buckets = ([FlatGradients(self.params, extra={f"view{v}": 3 * n}) for v in range(n_views)]
+                             if shard.collective else None)
         self.mids = {}
 
     def step(self):
@@ -310,7 +314,28 @@ class DeblurWorkload:
         # all-reduce per view behind the next view's renders
         multi = self.shard.collective
         pred, mids = render_blurry_batch(self.cams, self.stat, self.dyn, self.bg, self.shard, blce=self.blce,
-                                         n_sub=self.K, weighted=multi, overlap=multi, batched_latent=self.batched)
+                                         n_sub=self.K, weighted=multi, overlap=multi, batched_latent=self.batched,
+                                         as_list=multi)
+        if multi:
+            def view_backward(v):
+                outs, cots = [pred[v]], [self.v_pred[v]]
+                if v in mids:
+                    for key in ("s_render", "s_depth", "d_alpha", "d_depth", "s_alpha"):
+                        mids[v][key]
+                    outs += [mids[v]["depth"], mids[v]["d_alpha"]]
+                    cots += [self.v_depth, self.v_alpha]
+                live = [(o, c) for o, c in zip(outs, cots) if o.requires_grad]
+                if live:
+                    with LeafGradSink(self.stat, self.dyn, extra=self.blce.model.get_params()):
+                        torch.autograd.backward([o for o, _ in live], [c for _, c in live])
+
+            def after_view(v):
+                if v in mids:
+                    self.shard.put_densification_stats(self.view_buckets[v], f"view{v}", mids[v]["viewspace_points"].grad,
+                                                       mids[v]["radii"])
+            self.shard.backward_by_view(self.view_buckets, view_backward, after_view)
+            self.mids = mids
+            return pred
         outs, cots = [pred], [self.v_pred]
         for v, pkg in mids.items():  # depth / mask terms live on the rank that rendered the mid frame
             for key in ("s_render", "s_depth", "d_alpha", "d_depth", "s_alpha"):

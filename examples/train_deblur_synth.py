@@ -110,8 +110,58 @@ class DeblurTrainer:
         params = [p for gr in stat.optimizer.param_groups + dyn.optimizer.param_groups for p in gr["params"]] \
             + list(self.blce.model.get_params())
         self.bucket = FlatGradients(params, extra={f"view{v}": 3 * (ns + nd) for v in range(n_views)})
+        # N > 1: one gradient message per view, exchanged while the next view back-propagates (backward_by_view)
+        self.view_buckets = ([FlatGradients(params, extra={f"view{v}": 3 * (ns + nd)}) for v in range(n_views)]
+                             if shard.collective else None)
+
+    def _iteration_sharded(self) -> torch.Tensor:
+        """N > 1: the same iteration with its loss kept apart per view, so that the backward pass runs view by view and
+        each view's gradient message (with its densification statistics) is all-reduced on the communication stream while
+        the next view back-propagates (SubframeShard.backward_by_view)."""
+        shard, stat, dyn, blce, ns, V = self.shard, self.stat, self.dyn, self.blce, self.ns, self.n_views
+        preds, mids = render_blurry_batch(self.cams, stat, dyn, self.bg, shard, blce=blce, n_sub=K, rank_local_terms=True,
+                                          weighted=True, with_flows=True, overlap=True, as_list=True)
+        flows = get_flow_batch(self.cams, stat, dyn, self.bg, shard, n_sub=K, weighted=True)
+        photos = [photometric_loss(preds[v][None], self.gt[v][None], self.opt.lambda_dssim) for v in range(V)]
+
+        def view_backward(v):
+            loss = shard.replicated_term(photos[v]) / V          # the mean over V equal-sized images, view by view
+            if v in mids:
+                pkg = mids[v]
+                for key in ("s_render", "s_depth", "d_alpha", "d_depth", "s_alpha"):
+                    pkg[key]
+                normal = self.get_normals(pkg["depth"] + 1e-6, self.meta)
+                loss = loss + 0.05 * l1_loss(pkg["depth"], self.depths[v]) + 0.01 * pkg["d_alpha"].mean() \
+                    + 0.01 * l1_loss(normal, self.normals[v])
+            if self.lambda_flow != 0:
+                for (vv, k), (e2m, m2e, limg, lalpha) in flows.items():
+                    if vv == v:
+                        loss = loss + self.lambda_flow / K * (l1_loss(limg, preds[v]) + 1e-3 * (e2m - m2e).abs().mean()
+                                                              + 0.1 * lalpha.mean())
+            if v == 0:
+                loss = loss + shard.replicated_term(1e-4 * ((stat._scaling ** 2).mean() + (dyn._scaling ** 2).mean()))
+            if loss.requires_grad:
+                with LeafGradSink(stat, dyn, extra=blce.model.get_params()):
+                    loss.backward()
+
+        def after_view(v):
+            if v in mids:
+                shard.put_densification_stats(self.view_buckets[v], f"view{v}", mids[v]["viewspace_points"].grad,
+                                              mids[v]["radii"])
+
+        shard.backward_by_view(self.view_buckets, view_backward, after_view)
+        with torch.no_grad():
+            for v in range(V):
+                grad2d, radii = shard.get_densification_stats(self.view_buckets[v], f"view{v}")
+                vis = radii > 0
+                stat.add_densification_stats(grad2d[:ns], vis[:ns], radii=radii[:ns])
+                dyn.add_densification_stats(grad2d[ns:], vis[ns:], radii=radii[ns:])
+        fused_adam_step([stat.optimizer, dyn.optimizer, blce.optimizer])
+        return torch.stack([p.detach() for p in photos]).mean()
 
     def iteration(self) -> torch.Tensor:
+        if self.shard.collective:   # N > 1 (or a forced one-rank group: the same code path on one GPU)
+            return self._iteration_sharded()
         shard, stat, dyn, blce, bucket, ns = self.shard, self.stat, self.dyn, self.blce, self.bucket, self.ns
         bucket.zero()
         multi = shard.world > 1  # units of both families dealt by cost, per-view asynchronous image exchange

@@ -47,12 +47,13 @@ def render_blurry_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor,
                         blce=None, n_sub: int = 9, exposures: Optional[Sequence[Sequence]] = None,
                         train_mode_mid: bool = True, pipe=None, rank_local_terms: bool = False,
                         weighted: bool = False, with_flows: bool = False, overlap: bool = False,
-                        batched_latent: bool = True) -> Tuple[torch.Tensor, Dict[int, dict]]:
+                        batched_latent: bool = True, as_list: bool = False) -> Tuple[torch.Tensor, Dict[int, dict]]:
     """cams: the batch's view cameras.  blce: a mobgs_amd.blce.blceKernel (None: every sub-frame uses the view's own
     camera and `exposures[v][k]` / 0 as exposure offset -- the reference before `start_warp`).
     -> (pred [V,3,H,W] on every rank, {view index: result dict of its mid (train-mode) render} for the mid frames this
     rank rendered).  rank_local_terms: some loss term on `pred` is formed by one rank only (get_flow_batch): the
-    exchange then all-reduces its backward too."""
+    exchange then all-reduces its backward too.  as_list: pred as a list of V [3,H,W] tensors that share no autograd node
+    (SubframeShard.backward_by_view back-propagates one view at a time)."""
     V = len(cams)
     half = n_sub // 2
     # weighted: units dealt by cost (SubframeShard.iteration_plan: the train-mode mid frames weigh 2.3 latent renders;
@@ -114,7 +115,7 @@ def render_blurry_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor,
         c = cams[0]
         like = torch.zeros(3, int(c.image_height), int(c.image_width), device=bg_color.device)
         return shard.render_blurry_views(unit, V, n_sub, like=like, reduce_backward=rank_local_terms, units=mine,
-                                         overlap=overlap), mids
+                                         overlap=overlap, as_list=as_list), mids
     # the image shape is known after the first unit; render_blurry_views only needs `like` for views this rank has no
     # unit of, so hand it a lazily-filled zero image
     first_v, first_k = mine[0]
@@ -125,4 +126,4 @@ def render_blurry_batch(cams: Sequence, stat_pc, dyn_pc, bg_color: torch.Tensor,
         return cache.pop((v, k)) if (v, k) in cache else unit(v, k)
 
     return shard.render_blurry_views(unit_cached, V, n_sub, like=torch.zeros_like(img0),
-                                     reduce_backward=rank_local_terms, units=mine, overlap=overlap), mids
+                                     reduce_backward=rank_local_terms, units=mine, overlap=overlap, as_list=as_list), mids

@@ -33,14 +33,64 @@ import torch
 import torch.distributed as dist
 
 
-def _all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
+_comm_streams: Dict[int, "torch.cuda.Stream"] = {}
+# (tag, start event, done event) of every asynchronous device all-reduce when MOBGS_COMM_LOG=1 -- how the overlap tests
+# and scripts/rccl_world1_check.py see WHERE an exchange ran relative to the compute stream's own events
+comm_log: List[Tuple[str, "torch.cuda.Event", "torch.cuda.Event"]] = []
+
+
+def comm_stream(device) -> "torch.cuda.Stream":
+    """The one side stream per device on which asynchronous exchanges are ENQUEUED (HIP streams: collectives beside
+    compute).  RCCL runs a collective on its own internal stream, ordered behind the stream that is current when the
+    call is made; issuing it from this side stream -- after the side stream has waited for the producer -- keeps it
+    independent of whatever the compute stream enqueues next."""
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = _comm_streams.get(idx)
+    if st is None:
+        st = _comm_streams[idx] = torch.cuda.Stream(device=idx)
+    return st
+
+
+class _StreamWork:
+    """Handle of an exchange enqueued on the communication stream: wait() makes the CURRENT stream wait for its
+    completion event (no host block)."""
+
+    def __init__(self, done: "torch.cuda.Event", keep=()):
+        self.done, self.keep = done, keep
+
+    def wait(self, timeout=None):
+        torch.cuda.current_stream().wait_event(self.done)
+        return True
+
+    def is_completed(self):
+        return self.done.query()
+
+
+def _all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False, tag: str = ""):
     """In-place SUM.  A gloo group gets device tensors staged through the host (functional tests of the N > 1 path on
-    a one-GPU box; the RCCL path reduces in place on the device)."""
+    a one-GPU box; the RCCL path reduces in place on the device).  async_op on a device tensor with the nccl (= RCCL)
+    backend: enqueued from the communication stream (see comm_stream) -> _StreamWork."""
     if t.is_cuda and dist.get_backend(group) == "gloo":
         h = t.detach().cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
         t.copy_(h)
         return _DoneWork() if async_op else None  # synchronous here; callers of async_op get a handle all the same
+    if async_op and t.is_cuda:
+        import os
+        side, main = comm_stream(t.device), torch.cuda.current_stream(t.device)
+        log = os.environ.get("MOBGS_COMM_LOG") == "1"
+        side.wait_stream(main)                      # the producer of `t` has finished before the exchange starts
+        with torch.cuda.stream(side):
+            start = torch.cuda.Event(enable_timing=log)
+            start.record(side)
+            work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            work.wait()                             # the SIDE stream waits for RCCL's stream (no host block)
+            done = torch.cuda.Event(enable_timing=log)
+            done.record(side)
+        t.record_stream(side)
+        if log:
+            comm_log.append((tag, start, done))
+        return _StreamWork(done, (t, work))
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
@@ -113,9 +163,9 @@ class _SumAcrossRanksAsync(torch.autograd.Function):
         y = x.detach()
         if not y.is_contiguous():
             y = y.clone(memory_format=torch.contiguous_format)
-            box.append(_all_reduce_sum(y, group, async_op=True))
+            box.append(_all_reduce_sum(y, group, async_op=True, tag="image"))
             return y
-        box.append(_all_reduce_sum(y, group, async_op=True))
+        box.append(_all_reduce_sum(y, group, async_op=True, tag="image"))
         ctx.mark_dirty(x)
         return x
 
@@ -150,6 +200,7 @@ class FlatGradients:
         for p in self.params:
             sizes[p.dtype] += p.numel()
         off = sizes[torch.float32]
+        self.param_floats = off   # fp32 words holding parameter gradients (the statistics slots follow)
         for name, k in (extra or {}).items():
             self.extra_slices[name] = slice(off, off + int(k))
             off += int(k)
@@ -302,7 +353,8 @@ class SubframeShard:
 
     def render_blurry_views(self, render_unit: Callable[[int, int], torch.Tensor], n_views: int, n_sub: int,
                             like: torch.Tensor, reduce_backward: bool = False,
-                            units: Optional[Sequence[Tuple[int, int]]] = None, overlap: bool = False) -> torch.Tensor:
+                            units: Optional[Sequence[Tuple[int, int]]] = None, overlap: bool = False,
+                            as_list: bool = False):
         """Batch form (train.py:430-541 loops over the views of the batch): render_unit(view, k) -> [3,H,W].
         Returns the blurry predictions [n_views,3,H,W] on every rank.  `units`: this rank's (view, sub-frame) pairs
         (default: the round-robin view_units).  overlap=False: ONE all-reduce for the whole batch.  overlap=True: one
@@ -315,6 +367,9 @@ class SubframeShard:
             for v, k in mine:
                 img = render_unit(v, k)
                 sums[v] = img if sums[v] is None else sums[v] + img
+            if as_list:
+                return [self.mean_of_subframes(s if s is not None else torch.zeros_like(like), n_sub,
+                                               reduce_backward=reduce_backward) for s in sums]
             local = torch.stack([s if s is not None else torch.zeros_like(like) for s in sums])
             return self.mean_of_subframes(local, n_sub, donate=True, reduce_backward=reduce_backward)
         totals: List[Optional[torch.Tensor]] = [None] * n_views
@@ -346,6 +401,8 @@ class SubframeShard:
         for w in works:
             if w is not None:
                 w.wait()
+        if as_list:   # per-view tensors without a common stack node: backward_by_view walks each view's graph on its own
+            return [t / n_sub + 1e-10 for t in totals]
         return torch.stack(totals) / n_sub + 1e-10
 
     # ---- backward exchange --------------------------------------------------------------------------
@@ -365,12 +422,12 @@ class SubframeShard:
                     # gradients at all: GaussianParams(attr_dtype=float16, master=True) accumulates them in fp32.)
                     w32 = b.float()
                     if async_op:  # the fp32 copy is reduced asynchronously; wait() rounds it back once
-                        works.append(_CopyBackWork(_all_reduce_sum(w32, self.group, True), b, w32))
+                        works.append(_CopyBackWork(_all_reduce_sum(w32, self.group, True, tag="grad16"), b, w32))
                     else:
                         _all_reduce_sum(w32, self.group)
                         b.copy_(w32)
                 else:
-                    works.append(_all_reduce_sum(b, self.group, async_op))
+                    works.append(_all_reduce_sum(b, self.group, async_op, tag="grad"))
             return works if async_op else None
         if not self.collective:
             return None
@@ -387,6 +444,41 @@ class SubframeShard:
             p.grad = g if p.dtype == torch.float32 else g.to(p.dtype)
             off += n
         return None
+
+    def backward_by_view(self, buckets: Sequence[FlatGradients], view_backward: Callable[[int], None],
+                         after_view: Optional[Callable[[int], None]] = None) -> FlatGradients:
+        """The backward pass of an iteration, one VIEW at a time, with one gradient message per view:
+
+            for v: buckets[v] becomes the .grad storage; view_backward(v) back-propagates the loss terms of view v (and
+                   only them: the caller keeps per-view loss terms apart -- the photometric mean over V equal-sized
+                   images is the mean of the per-view terms); after_view(v) may deposit that view's densification
+                   statistics in buckets[v]; its all-reduce STARTS asynchronously on the communication stream
+            then:  await them in order, buckets[0] += buckets[1:] (one multi-tensor add), re-attach buckets[0].
+
+        The exchange of view v's 68-MB message thus runs while view v + 1 back-propagates; only the last view's is
+        exposed.  Gradients afterwards live in buckets[0] (returned); every view's statistics
+        slots stay in its own bucket.  Without a process group: the same loop without exchanges."""
+        works = []
+        for v, b in enumerate(buckets):
+            b.zero()
+            view_backward(v)
+            if after_view is not None:
+                after_view(v)
+            works.append(self.all_reduce_gradients(b, async_op=True))
+        for ws in works:
+            for w in (ws or []):
+                w.wait()
+        first = buckets[0]
+        for name in ("flat", "flat_half"):
+            rest = [getattr(b, name) for b in buckets[1:] if getattr(b, name).numel()]
+            if rest:
+                n_par = getattr(first, name).numel() if name == "flat_half" else first.param_floats
+                dst = getattr(first, name)[:n_par]
+                for r in rest:   # (parameter part only: every bucket's statistics slots are its own)
+                    dst.add_(r[:n_par])
+        for p, view in zip(first.params, first.views):
+            p.grad = view
+        return first
 
     def put_densification_stats(self, bucket: FlatGradients, name: str, viewspace_grad: Optional[torch.Tensor],
                                 radii: Optional[torch.Tensor]) -> None:

@@ -22,8 +22,51 @@ def step_result(dev, shard, seed=3):
     for _ in range(3):
         pred = wl.step()
     torch.cuda.synchronize()
-    grads = [b.clone() for b in wl.bucket.buffers()]
+    if isinstance(pred, (list, tuple)):   # the collective path: per-view predictions, one gradient message per view
+        pred = torch.stack(list(pred))
+        first = wl.view_buckets[0]        # backward_by_view leaves the sum over views (and ranks) in the first bucket
+        grads = [first.flat[:first.param_floats].clone()] + ([first.flat_half.clone()] if first.flat_half.numel() else [])
+    else:
+        b = wl.bucket
+        grads = [b.flat[:b.param_floats].clone()] + ([b.flat_half.clone()] if b.flat_half.numel() else [])
     return pred.detach().clone(), grads
+
+
+def overlap_check(dev, shard):
+    """The per-view image exchange is enqueued from the communication stream, not from the compute stream, and the
+    exchange of view 0 completes WHILE view 1 is still being produced: device timestamps of the
+    exchange's start / done events (MOBGS_COMM_LOG=1) against two events around the units of view 1."""
+    from mobgs_amd import distributed as D
+    os.environ["MOBGS_COMM_LOG"] = "1"
+    D.comm_log.clear()
+    a = torch.randn(2048, 2048, device=dev)
+    marks = {}
+
+    def unit(v, k):
+        if v == 1 and "begin" not in marks:
+            marks["begin"] = torch.cuda.Event(enable_timing=True)
+            marks["begin"].record()
+        x = a
+        for _ in range(6):          # a few hundred microseconds of compute per unit on the current stream
+            x = (x @ a) * 1e-3
+        img = x.reshape(-1)[:3 * 240 * 320].reshape(3, 240, 320).clone().requires_grad_(True) * 1.0
+        if v == 1:
+            marks["end"] = torch.cuda.Event(enable_timing=True)
+            marks["end"].record()
+        return img
+
+    shard.render_blurry_views(unit, 2, 9, like=torch.zeros(3, 240, 320, device=dev), overlap=True)
+    torch.cuda.synchronize()
+    os.environ.pop("MOBGS_COMM_LOG", None)
+    images = [(s, d) for tag, s, d in D.comm_log if tag == "image"]
+    side, main = D.comm_stream(dev), torch.cuda.current_stream(dev)
+    view1_ms = marks["begin"].elapsed_time(marks["end"])
+    done0_ms = marks["begin"].elapsed_time(images[0][1])     # exchange of view 0 done, relative to the start of view 1
+    ok = len(images) == 2 and side != main and side.cuda_stream != main.cuda_stream and done0_ms < view1_ms
+    print(f"overlap: {len(images)} image exchanges on stream {side.cuda_stream:#x} (compute stream {main.cuda_stream:#x}); "
+          f"view 1 took {view1_ms:.3f} ms on the compute stream, the exchange of view 0 was complete {done0_ms:.3f} ms after "
+          f"view 1 began -> {'inside' if done0_ms < view1_ms else 'AFTER'} it")
+    return ok
 
 
 def main():
@@ -67,6 +110,7 @@ def main():
     q.grad = torch.ones_like(q)
     shard.all_reduce_gradients([q])
     ok = ok and torch.equal(q.grad, torch.ones_like(q))
+    ok = overlap_check(dev, shard) and ok
     print("RCCL world-1 check:", "OK" if ok else "MISMATCH")
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)

@@ -477,3 +477,74 @@ def test_forced_collectives_on_a_one_rank_group_are_identities():
     assert torch.allclose(gb, ref_b, atol=1e-6)
     for v in range(V):
         assert torch.allclose(m2d[v], ref_m2d[v], atol=1e-7)
+
+
+def _by_view_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        w = torch.randn(2, requires_grad=True)
+        b = torch.randn(1, requires_grad=True)
+        shard = SubframeShard()
+        buckets = [FlatGradients([w, b], extra={f"view{v}": 3 * NSPLAT}) for v in range(V)]
+        mids = {}
+
+        def unit(v, k):
+            if k == K // 2:
+                mids[v] = _toy_mid_outputs((w, b), v)
+                mids[v][1].retain_grad()
+            return _toy_unit((w, b), v, k)
+
+        mine = shard.planned_units(shard.iteration_plan(V, K, with_flows=False)["render"], K)
+        preds = shard.render_blurry_views(unit, V, K, like=torch.zeros(3, 6, 8), units=mine, overlap=True, as_list=True)
+        assert isinstance(preds, list) and len(preds) == V
+
+        def view_backward(v):
+            # the terms of _iteration_loss that belong to view v: the photometric mean over V equal-sized images is the
+            # mean of the per-view means; the regulariser (replicated data) goes with view 0
+            loss = (preds[v] - 0.3).abs().mean() / V
+            if v in mids:
+                depth, m2d = mids[v]
+                loss = loss + 0.2 * (depth - 0.1).abs().mean() + 1e-2 * (m2d ** 2).sum()
+            if v == 0:
+                loss = loss + shard.replicated_term(1e-3 * (w ** 2).sum() + 1e-3 * b.abs().sum())
+            if loss.requires_grad:
+                loss.backward()
+
+        def after_view(v):
+            if v in mids:
+                shard.put_densification_stats(buckets[v], f"view{v}", mids[v][1].grad,
+                                              torch.full((NSPLAT,), 3 + v, dtype=torch.int32))
+
+        total = shard.backward_by_view(buckets, view_backward, after_view)
+        assert total is buckets[0] and total.attached()
+        stats = [shard.get_densification_stats(buckets[v], f"view{v}") for v in range(V)]
+        q.put(_plain((rank, torch.stack(preds).detach(), w.grad.clone(), b.grad.clone(), [s[0].clone() for s in stats],
+                      [s[1].clone() for s in stats])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_backward_by_view_with_one_gradient_message_per_view(world):
+    """the backward pass one view at a time, each view's gradients (and densification statistics) in
+    its own flat buffer whose all-reduce starts while the next view back-propagates; afterwards buckets[0] holds the
+    single-process gradient and every view's statistics are in its own message."""
+    ref_pred, ref_w, ref_b, ref_m2d = _single_iteration()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_by_view_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    outs = [_tensors(q.get(timeout=300)) for _ in ps]
+    for p in ps:
+        p.join(timeout=120)
+    for rank, pred, gw, gb, m2d, radii in outs:
+        assert torch.allclose(pred, ref_pred, atol=1e-6), f"rank {rank}"
+        assert torch.allclose(gw, ref_w, atol=1e-6), f"rank {rank}: {gw} vs {ref_w}"
+        assert torch.allclose(gb, ref_b, atol=1e-6), f"rank {rank}"
+        for v in range(V):
+            assert torch.allclose(m2d[v], ref_m2d[v], atol=1e-7), f"rank {rank} view {v}"
+            assert torch.equal(radii[v], torch.full((NSPLAT,), 3 + v, dtype=torch.int32)), f"rank {rank} view {v}"

@@ -49,3 +49,36 @@ def test_miniature_deblur_training_loop(hip_device):
     assert float(stat.xyz_gradient_accum.abs().max()) > 0 and float(dyn.denom.max()) > 0
     moved = [float((p.grad.abs().max() if p.grad is not None else torch.zeros(()))) for p in blce.model.get_params()]
     assert sum(m > 0 for m in moved) >= 20, "BLCE parameters must receive gradients through the warped cameras"
+
+
+def test_sharded_iteration_with_per_view_gradient_messages_tracks_the_single_process_loop(hip_device):
+    """DeblurTrainer._iteration_sharded (per-view loss terms, SubframeShard.backward_by_view: one gradient message per
+    view on the communication stream) on a ONE-rank gloo group with MOBGS_FORCE_COLLECTIVES=1 -- every exchange an
+    identity -- must follow the ordinary single-process loop: same photometric loss curve to summation order."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, socket, torch
+import torch.distributed as dist
+sys.path.insert(0, os.path.join(%r, "examples")); sys.path.insert(0, %r)
+import train_deblur_synth as T
+kw = dict(dev="cuda:0", iters=8, ns=2500, nd=1200, width=160, height=112, seed=4)
+plain, *_ = T.train(**kw)
+with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+os.environ["MOBGS_FORCE_COLLECTIVES"] = "1"
+from mobgs_amd.distributed import SubframeShard
+shard = SubframeShard()
+assert shard.collective
+sharded, *_ = T.train(shard=shard, **kw)
+dist.destroy_process_group()
+print("PLAIN", plain); print("SHARDED", sharded)
+worst = max(abs(a - b) / abs(a) for a, b in zip(plain, sharded))
+print("WORST", worst)
+sys.exit(0 if worst < 2e-2 else 1)
+""" % (root, root)
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
