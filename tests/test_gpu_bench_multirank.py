@@ -31,3 +31,5 @@ def test_bench_sharded_path_runs_and_reports(hip_device, world):
     assert line["n_gpus"] == world and line["steps"] == 2 and line["scaling"] == "strong"
     assert line["value"] > 0 and line["config"]["renders_per_step"] == 18
     assert "FUNCTIONAL CHECK" in line["data"]
+    # the anchor of the scaling curve is measured in the same run: the N > 1 workload with every unit on one GPU
+    assert line["scale_anchor"] > 0 and "scaling_efficiency_vs_anchor" in line and "scale_anchor_field" in line
