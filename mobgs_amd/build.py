@@ -30,6 +30,12 @@ EXTRA_FLAGS = {f: ["-fno-slp-vectorize"] for f in NOSLP_FILES if f}
 # HBM-bound: no measurable cost.
 EXTRA_FLAGS.setdefault("project.hip", [])
 EXTRA_FLAGS["project.hip"] = EXTRA_FLAGS["project.hip"] + ["-ffp-contract=off"]
+# raster.hip: top-down pre-RA machine scheduling.  The compositing loops are long straight-line blocks bound by VALU
+# issue; of ten scheduler settings swept in round 4 (scripts/ab/build_variant_raster.sh + kernel_ab2.sh, three A/B
+# repetitions on one box) this is the only one outside the noise: raster_bwd<10> 512 -> 506 us, raster_fwd_blocks<10>
+# 219 -> 213.5 us, <12> forward -2 %, <16> backward -1 % (raster_fwd<16> +4 %).  Same instructions in another order:
+# results are bit-identical.
+EXTRA_FLAGS["raster.hip"] = EXTRA_FLAGS.get("raster.hip", []) + ["-mllvm", "-misched-prera-direction=topdown"]
 for _f in ("raster.hip", "raster_bwd_mfma.hip", "raster_layers.hip"):  # experiment hook: extra flags for the compositing kernels
     EXTRA_FLAGS.setdefault(_f, [])
     EXTRA_FLAGS[_f] = EXTRA_FLAGS[_f] + os.environ.get("MOBGS_RASTER_EXTRA_FLAGS", "").split()

@@ -126,7 +126,7 @@ struct MfmaWave {
         wave_lds_fence();
         mf4 A[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) A[t] = *(const __attribute__((address_space(3))) mf4*)(a_load ^ (unsigned)(t << 4));
+        for (int t = 0; t < 4; ++t) A[t] = *(const __attribute__((address_space(3))) mf4*)(unsigned long long)(a_load ^ (unsigned)(t << 4));
         const int4 pos = *reinterpret_cast<const int4*>(rowpos + 4 * d_half);
         float* a0 = acc + pos.x * STRIDE + d_col;
         float* a1 = acc + pos.y * STRIDE + d_col;
@@ -223,8 +223,8 @@ __device__ __forceinline__ void walk_quadrant(const MfmaWave<CD, STRIDE>& mw, co
         // rows nrow (fac) and 8 + nrow (v_sigma) of the weight tile, column = this lane's pixel
         const unsigned sw = (unsigned)((nrow << 8) | (((nrow + 4) & 15) << 4));
         const unsigned a_fac = mw.w_store ^ sw;
-        *(__attribute__((address_space(3))) float*)(a_fac) = fac;
-        *(__attribute__((address_space(3))) float*)(a_fac ^ 0x880u) = v_sigma;
+        *(__attribute__((address_space(3))) float*)(unsigned long long)(a_fac) = fac;
+        *(__attribute__((address_space(3))) float*)(unsigned long long)(a_fac ^ 0x880u) = v_sigma;
         if (mw.lane == 0) mw.rowpos[nrow] = jc;
         if (++nrow == GROUP) {
             MFMA_T(t_r0);

@@ -9,7 +9,7 @@ cd "$root/mobgs_amd/csrc"
 objs=()
 for f in *.hip; do
   extra=""
-  case $f in raster.hip|raster_bwd_mfma.hip|raster_layers.hip) extra="-fno-slp-vectorize $flags";; project.hip) extra="-ffp-contract=off $flags";; *) extra="$flags";; esac
+  case $f in raster.hip) extra="-fno-slp-vectorize -mllvm -misched-prera-direction=topdown $flags";; raster_bwd_mfma.hip|raster_layers.hip) extra="-fno-slp-vectorize $flags";; project.hip) extra="-ffp-contract=off $flags";; *) extra="$flags";; esac
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $extra -c $f -o $tmp/${f%.hip}.o &
   objs+=($tmp/${f%.hip}.o)
 done
