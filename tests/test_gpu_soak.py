@@ -20,6 +20,24 @@ def test_random_regimes_against_the_c_oracle(hip_device, seed):
     assert failed == 0, "\n".join(msgs)
 
 
+@pytest.mark.parametrize("arm,heavy", [(1, 0), (2, None)])
+def test_random_regimes_with_the_matrix_pipe_backward(hip_device, arm, heavy):
+    """The same soak with MobgsTuning.bwd_mfma forced (round 4): arm 1 without heavy tiles = the wave-per-tile kernel on
+    every grid, arm 2 = the four-wave team on every tile (the default policy -- team on grids of <= 1024 tiles -- is what
+    the unparametrised soak above runs, since most of its images are that small)."""
+    import soak_parity
+    from mobgs_amd import rendering
+    old = (rendering.tuning.bwd_mfma, rendering.tuning.heavy_tile_len)
+    rendering.tuning.bwd_mfma = arm
+    if heavy is not None:
+        rendering.tuning.heavy_tile_len = heavy
+    try:
+        failed, msgs = soak_parity.soak(40, 11 + arm, hip_device, verbose=False)
+    finally:
+        rendering.tuning.bwd_mfma, rendering.tuning.heavy_tile_len = old
+    assert failed == 0, "\n".join(msgs)
+
+
 def test_random_render_calls_against_the_torch_restatement(hip_device):
     """render() (boundary B1) in random regimes (scripts/soak_render.py): camera times on and between the spline's
     knots, exposure offsets pushing the time outside [0, 1], 4..12 control points, lean and train mode, random
