@@ -246,15 +246,15 @@ Tensor raster_bwd(int64_t C, int64_t N, int64_t channels, int64_t has_extra, int
 
 // -> (v_means2d [C,N,2], v_conics [C,N,3], v_opac [C,N], v_colors [C,N,channels], v_extra [C,N] | None)
 std::tuple<Tensor, Tensor, Tensor, Tensor, OptT>
-raster_bwd_reduce(int64_t C, int64_t N, int64_t channels, int64_t has_extra, const Tensor& cum_tiles,
-                  const Tensor& keep_scan, const Tensor& slots, int64_t stream) {
+raster_bwd_reduce(int64_t C, int64_t N, int64_t channels, int64_t has_extra, const Tensor& records,
+                  const Tensor& cum_tiles, const Tensor& keep_scan, const Tensor& slots, int64_t stream) {
     const auto f = slots.options();
     Tensor v_means2d = at::empty({C, N, 2}, f), v_conics = at::empty({C, N, 3}, f), v_opac = at::empty({C, N}, f),
            v_colors = at::empty({C, N, channels}, f);
     OptT v_extra = has_extra ? OptT(at::empty({C, N}, f)) : OptT();
     const int32_t* flag = reinterpret_cast<const int32_t*>(fp(slots) + (slots.size(0) - 1) * slots.size(1));
-    check(api.raster_bwd_reduce((int)C, (int)N, (int)channels, (int)has_extra, ip(cum_tiles), ip(keep_scan), fp(slots),
-                                flag, fpw(v_means2d), fpw(v_conics), fpw(v_opac), fpw(v_colors), fpw(v_extra),
+    check(api.raster_bwd_reduce((int)C, (int)N, (int)channels, (int)has_extra, fp(records), ip(cum_tiles), ip(keep_scan),
+                                fp(slots), flag, fpw(v_means2d), fpw(v_conics), fpw(v_opac), fpw(v_colors), fpw(v_extra),
                                 sp(stream)),
           "mobgs_raster_bwd_reduce");
     return {v_means2d, v_conics, v_opac, v_colors, v_extra};

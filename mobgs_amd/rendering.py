@@ -517,7 +517,7 @@ class _Rasterize(torch.autograd.Function):
                                      means2d, tl.cum_tiles, tl.keep_scan, tl.tile_offsets, tl.tile_order,
                                      tl.flatten_ids, alphas, last_ids, v_render, v_alphas, reach, tuning.address(), st)
             v_means2d, v_conics, v_opac, v_colors, v_extra = F.raster_bwd_reduce(
-                C, N, channels, int(has_extra), tl.cum_tiles, tl.keep_scan, slots, st)
+                C, N, channels, int(has_extra), records, tl.cum_tiles, tl.keep_scan, slots, st)
         else:
             v_render = f32c(v_render)
             v_alphas = f32c(v_alphas) if v_alphas is not None else None
@@ -536,8 +536,8 @@ class _Rasterize(torch.autograd.Function):
                                            ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas),
                                            ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(slots), ptr(reach),
                                            flag, tuning.ref(), stream()), "mobgs_raster_bwd")
-            check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(tl.cum_tiles), ptr(tl.keep_scan),
-                                              ptr(slots), flag, ptr(v_means2d), ptr(v_conics), ptr(v_opac),
+            check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(records), ptr(tl.cum_tiles),
+                                              ptr(tl.keep_scan), ptr(slots), flag, ptr(v_means2d), ptr(v_conics), ptr(v_opac),
                                               ptr(v_colors), ptr(v_extra), stream()), "mobgs_raster_bwd_reduce")
         if not colors_per_camera:
             v_colors = v_colors.sum(0) if C > 1 else v_colors[0]
@@ -617,7 +617,7 @@ class _RasterizeClassAlpha(torch.autograd.Function):
         v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
         v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
         v_colors = torch.empty(C, N, 1, dtype=torch.float32, device=dev)
-        check(lib.mobgs_raster_bwd_reduce(C, N, 1, 0, ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(slots), flag,
+        check(lib.mobgs_raster_bwd_reduce(C, N, 1, 0, ptr(records), ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(slots), flag,
                                           ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), None, stream()),
               "mobgs_raster_bwd_reduce")
         if not opac_per_camera:
@@ -845,7 +845,7 @@ class _RasterizeClasses(torch.autograd.Function):
         v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
         v_colors = torch.empty(C, N, channels, dtype=torch.float32, device=dev)
         v_extra = torch.empty(C, N, dtype=torch.float32, device=dev)
-        check(lib.mobgs_raster_bwd_reduce(C, N, channels, 1, ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(slots), None,
+        check(lib.mobgs_raster_bwd_reduce(C, N, channels, 1, ptr(records), ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(slots), None,
                                           ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra),
                                           stream()), "mobgs_raster_bwd_reduce")
         if not colors_per_camera:
