@@ -43,6 +43,20 @@ def test_size_queries_need_no_gpu():
     assert h.mobgs_decoder_bwd_blocks(1352 * 1014) >= 256
 
 
+def test_bad_arguments_are_refused_before_any_launch():
+    """Error behaviour of the C ABI: a bad argument returns MOBGS_E_INVALID with a message, without touching a device
+    (so this runs here).  mobgs_raster_bwd_reduce needs the packed records since the gradient slots carry raw sums."""
+    from mobgs_amd import _lib
+    h = _lib.load()
+    none = ctypes.c_void_p(None)
+    rc = h.mobgs_raster_bwd_reduce(1, 5, 3, 0, none, none, none, none, none, none, none, none, none, none, none)
+    assert rc == -1 and b"mobgs_raster_bwd_reduce" in h.mobgs_last_error()
+    rc = h.mobgs_raster_bwd_reduce(0, 5, 3, 0, none, none, none, none, none, none, none, none, none, none, none)
+    assert rc == -1
+    with pytest.raises(RuntimeError, match="mobgs_raster_bwd_reduce"):
+        _lib.check(rc, "mobgs_raster_bwd_reduce")
+
+
 def test_no_cpu_fallback():
     from mobgs_amd.rendering import fully_fused_projection, rasterization
     n = 8
