@@ -514,16 +514,9 @@ __device__ __forceinline__ void wave_reduce_components(float (&v)[NVP]) {
 // partner) in 6 instructions, and the last two quad_perm steps run on ONE register: 8 instead of 16 VALU.
 // Afterwards every lane holds the wave total of component lane >> 2.
 // (v_add_f32_dpp with a partial bank_mask keeps the destination in the masked-off lanes; the builtins cannot
-// express that, hence the inline assembly.  s_nop 1 on both sides: a DPP source written by the previous VALU needs
-// 2 wait states, and the compiler's hazard recogniser does not look inside the asm.)
-__device__ __forceinline__ float dpp_add_ror8_hi(float keep, float v) {  // lanes 8-15 of each row: v + v[lane ^ 8]
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\ts_nop 1" : "+v"(keep) : "v"(v));
-    return keep;
-}
-__device__ __forceinline__ float dpp_add_mirror_odd(float keep, float v) {  // banks 1, 3: v + v[half-row mirror]
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\ts_nop 1" : "+v"(keep) : "v"(v));
-    return keep;
-}
+// express that, hence the inline assembly; a DPP source written by the previous VALU needs 2 wait states and the
+// compiler's hazard recogniser does not look inside the asm: the nops are placed by hand.)
+//
 // the two swap stages alone: afterwards lane l holds, in v[0..3], components 4 (l >> 4) + {0..3} summed over the four
 // lanes {l & 15, (l & 15) + 16, + 32, + 48} -- the lanes of one block-walk worker
 template <int N>
@@ -585,15 +578,28 @@ __device__ __forceinline__ float wave_reduce16_scatter(float (&v)[N]) {
         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += v[i + 4];
-    // row r now holds components 4 r + {0, 1, 2, 3} in v[0..3]
-    float u0 = dpp_add<0x128>(v[0]);      // lanes 0-7: component 0 summed over {l, l ^ 8}
-    u0 = dpp_add_ror8_hi(u0, v[2]);       // lanes 8-15: component 2
-    float u1 = dpp_add<0x128>(v[1]);      // lanes 0-7: component 1
-    u1 = dpp_add_ror8_hi(u1, v[3]);       // lanes 8-15: component 3
-    float w = dpp_add<0x141>(u0);         // banks 0, 2: components 0, 2 over 8 lanes ...
-    w = dpp_add_mirror_odd(w, u1);        // banks 1, 3: components 1, 3
-    w = dpp_add<0xB1>(w);
-    w = dpp_add<0x4E>(w);
+    // row r now holds components 4 r + {0, 1, 2, 3} in v[0..3].  The halving steps inside the row as ONE block: the two
+    // independent chains (u0, u1) interleaved, a nop only where a DPP read follows the write of its source by fewer
+    // than two instructions (scripts/ubench/swap_cost.hip: 195 -> 183 cycles per reduction at four waves per SIMD, 416
+    // -> 340 for a lone wave, against one asm statement with its own nops per step)
+    float u0, u1, w;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  // lanes 0-7: component 0 over {l, l ^ 8}
+        "v_add_f32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  // lanes 0-7: component 1
+        "v_add_f32_dpp %0, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"               // lanes 8-15: component 2
+        "v_add_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"               // lanes 8-15: component 3
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  // banks 0, 2: components 0, 2
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"               // banks 1, 3: components 1, 3
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1"
+        : "=&v"(u0), "=&v"(u1), "=&v"(w)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
     return w;
 }
 
@@ -857,6 +863,10 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                 rec[4 * q + 2] = v.z;
                 rec[4 * q + 3] = v.w;
             }
+            // the entry's gradient slot, wave-uniform: fetched with the record and kept in an SGPR, so that the store
+            // behind the reduction needs no LDS round trip and no 64-bit vector address arithmetic
+            int slot_u = 0;
+            if constexpr (!HEAVY) slot_u = __builtin_amdgcn_readfirstlane(slot_of[wv][j]);
             float g[NVP];
             if constexpr (LDS_CLEAR) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3));
@@ -893,11 +903,11 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                 // every lane ends up with the total of component lane >> 2: one 64-byte store from 16 lanes
                 const float w = wave_reduce16_scatter(g);
                 if ((lane & 3) == 0 && (lane >> 2) < RS) {
-                    float* dst = HEAVY ? &sh.part[wv][j][0] : grad_slots + (size_t)slot_of[wv][j] * RS;
+                    float* dst = HEAVY ? &sh.part[wv][j][0] : grad_slots + (size_t)slot_u * RS;
                     dst[lane >> 2] = w;
                 }
             } else if constexpr (NVX > 0) {
-                float* dst = HEAVY ? &sh.part[wv][j][0] : grad_slots + (size_t)slot_of[wv][j] * RS;
+                float* dst = HEAVY ? &sh.part[wv][j][0] : grad_slots + (size_t)slot_u * RS;
                 if constexpr (NVX <= 2) {
                     const float x = wave_reduce_pair(g[16], g[17]);
                     if ((lane & 31) == 0 && (lane >> 5) < NVX) dst[16 + (lane >> 5)] = x;
@@ -917,7 +927,7 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                 constexpr int Q = NVP / 4;
                 const int base = (lane >> 5) * (NVP / 2) + ((lane >> 4) & 1) * Q;
                 if ((lane & 15) == 0 && base < RS) {
-                    float* dst = HEAVY ? &sh.part[wv][j][base] : grad_slots + (size_t)slot_of[wv][j] * RS + base;
+                    float* dst = HEAVY ? &sh.part[wv][j][base] : grad_slots + (size_t)slot_u * RS + base;
                     if constexpr (Q == 2) {
                         *reinterpret_cast<float2*>(dst) = make_float2(g[0], g[1]);
                     } else {

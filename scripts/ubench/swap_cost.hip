@@ -85,6 +85,40 @@ __device__ __forceinline__ float reduce16(float (&v)[NV]) {
     asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1" : "+v"(w));
     return w;
 }
+// the same sums with the DPP tail as ONE block: the two independent chains interleaved, a nop only where a DPP read
+// follows the write of its source by fewer than two instructions
+__device__ __forceinline__ float reduce16_v2(float (&v)[NV]) {
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\tv_permlane32_swap_b32 %2, %10\n\t"
+                 "v_permlane32_swap_b32 %3, %11\n\tv_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\t"
+                 "v_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15\n\ts_nop 1" : ALL16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += v[i + 8];
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\t"
+                 "v_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += v[i + 4];
+    float u0, u1, w;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_add_f32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_add_f32_dpp %0, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "s_nop 1"
+                 : "=&v"(u0), "=&v"(u1), "=&v"(w) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    return w;
+}
+KERNEL(reduce16_v2, 1, { const float w = reduce16_v2(v); _Pragma("unroll") for (int i = 0; i < NV; ++i) v[i] = w + (float)i; })
 KERNEL(reduce16, 1, { const float w = reduce16(v); _Pragma("unroll") for (int i = 0; i < NV; ++i) v[i] = w + (float)i; })
 // the loop shape alone (16 adds that re-seed the registers)
 KERNEL(reseed, 1, { const float w = v[0] + v[5]; _Pragma("unroll") for (int i = 0; i < NV; ++i) v[i] = w + (float)i; })
@@ -126,6 +160,7 @@ int main() {
         RUN(swizzle16, w);
         RUN(reseed, w);
         RUN(reduce16, w);
+        RUN(reduce16_v2, w);
     }
     return 0;
 }
