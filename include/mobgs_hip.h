@@ -260,14 +260,16 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
 /* ---- K7: rasterise backward (replaces gsplat rasterize_to_pixels bwd) ----------------------------------
  * Deterministic two-stage gradient reduction, no floating-point atomics:
  *   stage 1 (mobgs_raster_bwd) walks every tile back to front and writes ONE gradient record
- *     {A, B, Sxx, Sxy, Syy, v_opacity, v_colour[..]} per (tile, splat) intersection -- the geometry terms as raw sums
- *     over the tile's pixels, with d = mean2d - pixel centre and v_sigma the cotangent of the exponent:
- *     A = sum v_sigma dx, B = sum v_sigma dy, Sxx = sum v_sigma dx^2, Sxy = sum v_sigma dx dy, Syy = sum v_sigma dy^2 -- into
+ *     {A, B, Sxx, Sxy, Syy, S, v_colour[..]} per (tile, splat) intersection -- the geometry and opacity terms as raw
+ *     sums over the tile's pixels, with d = mean2d - pixel centre and v_sigma the cotangent of the exponent:
+ *     A = sum v_sigma dx, B = sum v_sigma dy, Sxx = sum v_sigma dx^2, Sxy = sum v_sigma dx dy, Syy = sum v_sigma dy^2,
+ *     S = sum v_sigma -- into
  *     grad_slots [I_listed, stride]; slot = compact index (see keep_scan) of cum_tiles[flat id] + position of the tile inside the
  *     splat's tile rectangle].  grad_slots must be zero-filled by the caller (intersections that no pixel blended stay 0).
  *   stage 2 (mobgs_raster_bwd_reduce) sums each splat's contiguous slots and applies the splat's conic (a, b, c) of
  *     `records` (the packed records stage 1 read) once: v_means2d = (a A + b B, b A + c B), v_conics = (Sxx / 2, Sxy,
- *     Syy / 2) -- the conic is constant per splat, so this equals summing gsplat's per-pixel terms -- into the dense
+ *     Syy / 2), v_opacity = -S / opacity (a pair's v_sigma is -opacity vis v_alpha) -- conic and opacity are constant
+ *     per splat, so this equals summing gsplat's per-pixel terms -- into the dense
  *     gradients v_means2d [C,N,2], v_conics [C,N,3], v_opacities [C,N], v_colors [C,N,channels], v_extra [C,N] (NULL
  *     when there was no extra channel); all fully written.
  *   any_record (optional, both stages the same zero-initialised int32; NULL = off): stage 1 sets it when it writes

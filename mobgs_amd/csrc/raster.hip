@@ -551,55 +551,58 @@ __device__ __forceinline__ void wave_reduce16_columns(float (&v)[N]) {
 template <int N>
 __device__ __forceinline__ float wave_reduce16_scatter(float (&v)[N]) {
     static_assert(N >= 16, "reduces v[0..15]");
-    // the swaps exchange register halves IN PLACE; through the builtin the compiler copies one operand of every
-    // swap first (7 v_mov + a 2-cycle bubble each), in assembly the sixteen sums are simply consumed where they lie
+    // The swaps exchange register halves IN PLACE; through the builtin the compiler copies one operand of every swap
+    // first (7 v_mov + a 2-cycle bubble each), in assembly the sixteen sums are simply consumed where they lie.
+    // The whole reduction is ONE block -- 8 + 4 swaps with their adds, then the halving steps inside the row with the
+    // two independent chains (u0, u1) interleaved: a VALU result needs 2 wait states before a swap or a DPP source
+    // reads it and the compiler's hazard recogniser does not look inside the asm, so the order keeps every consumer
+    // at least three instructions behind its producer and nops stand only in front (the sums were written by the FMAs
+    // just before) and inside the final dependent chain.  Against one statement with its own nops per step:
+    // raster_bwd<10> 492 -> 484 us (scripts/ubench/swap_cost.hip: 195 -> 183 cycles per reduction for the tail alone).
+    float u0, u1, w;
     asm volatile(
         "s_nop 1\n\t"
-        "v_permlane32_swap_b32 %0, %8\n\t"
-        "v_permlane32_swap_b32 %1, %9\n\t"
-        "v_permlane32_swap_b32 %2, %10\n\t"
         "v_permlane32_swap_b32 %3, %11\n\t"
         "v_permlane32_swap_b32 %4, %12\n\t"
         "v_permlane32_swap_b32 %5, %13\n\t"
         "v_permlane32_swap_b32 %6, %14\n\t"
         "v_permlane32_swap_b32 %7, %15\n\t"
-        "s_nop 1"
-        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-          "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] += v[i + 8];
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_permlane16_swap_b32 %0, %4\n\t"
-        "v_permlane16_swap_b32 %1, %5\n\t"
-        "v_permlane16_swap_b32 %2, %6\n\t"
+        "v_permlane32_swap_b32 %8, %16\n\t"
+        "v_permlane32_swap_b32 %9, %17\n\t"
+        "v_permlane32_swap_b32 %10, %18\n\t"
+        "v_add_f32 %3, %3, %11\n\t"
+        "v_add_f32 %7, %7, %15\n\t"
+        "v_add_f32 %4, %4, %12\n\t"
+        "v_add_f32 %8, %8, %16\n\t"
+        "v_add_f32 %5, %5, %13\n\t"
+        "v_add_f32 %9, %9, %17\n\t"
+        "v_add_f32 %6, %6, %14\n\t"
+        "v_add_f32 %10, %10, %18\n\t"
+        "s_nop 0\n\t"
         "v_permlane16_swap_b32 %3, %7\n\t"
-        "s_nop 1"
-        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] += v[i + 4];
-    // row r now holds components 4 r + {0, 1, 2, 3} in v[0..3].  The halving steps inside the row as ONE block: the two
-    // independent chains (u0, u1) interleaved, a nop only where a DPP read follows the write of its source by fewer
-    // than two instructions (scripts/ubench/swap_cost.hip: 195 -> 183 cycles per reduction at four waves per SIMD, 416
-    // -> 340 for a lone wave, against one asm statement with its own nops per step)
-    float u0, u1, w;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  // lanes 0-7: component 0 over {l, l ^ 8}
-        "v_add_f32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  // lanes 0-7: component 1
-        "v_add_f32_dpp %0, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"               // lanes 8-15: component 2
-        "v_add_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"               // lanes 8-15: component 3
+        "v_permlane16_swap_b32 %4, %8\n\t"
+        "v_permlane16_swap_b32 %5, %9\n\t"
+        "v_permlane16_swap_b32 %6, %10\n\t"
+        "v_add_f32 %3, %3, %7\n\t"
+        "v_add_f32 %4, %4, %8\n\t"
+        "v_add_f32 %5, %5, %9\n\t"
+        "v_add_f32 %6, %6, %10\n\t"
         "s_nop 0\n\t"
-        "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  // banks 0, 2: components 0, 2
+        "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
         "s_nop 0\n\t"
-        "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"               // banks 1, 3: components 1, 3
+        "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
         "s_nop 1\n\t"
         "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "s_nop 1\n\t"
         "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "s_nop 1"
-        : "=&v"(u0), "=&v"(u1), "=&v"(w)
-        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+        : "=&v"(u0), "=&v"(u1), "=&v"(w), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]),
+          "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
     return w;
 }
 
@@ -641,7 +644,6 @@ __device__ __forceinline__ void blend_bwd(const float (&rec)[RS], const Eval& ev
     const float ov = rec[5] * ev.vis;
     const bool live = pass && ov <= ALPHA_MAX;  // the clamp at 0.999 has zero slope
     const float v_sigma = live ? -ov * v_alpha : 0.f;
-    const float v_op = live ? v_alpha : 0.f;
     // Geometry terms as RAW sums: sum v_sigma dx, sum v_sigma dy, sum v_sigma dx^2, sum v_sigma dx dy, sum v_sigma dy^2.
     // The conic is a constant of the SPLAT, so v_xy = (ca A + cb B, cb A + cc B) and the factor 1/2 of the conic's
     // diagonal commute with the sums over pixels AND over tiles: stage 2 applies them once per splat
@@ -653,7 +655,7 @@ __device__ __forceinline__ void blend_bwd(const float (&rec)[RS], const Eval& ev
     acc(g[2], t, dx);
     acc(g[3], t, dy);
     acc(g[4], u, dy);
-    acc(g[5], ev.vis, v_op);
+    g[5] = FIRST ? v_sigma : g[5] + v_sigma;   // vis * v_alpha (where live) = -v_sigma / opacity: stage 2 divides once
     if (FIRST) {
 #pragma unroll
         for (int i = 6 + CD; i < NVP; ++i) g[i] = 0.f;
@@ -1256,7 +1258,9 @@ raster_bwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
 // ---------------------------------------------------------------------------------------------------
 // Components 0..4 of a slot are raw sums (blend_bwd): A = sum v_sigma dx, B = sum v_sigma dy, Sxx = sum v_sigma dx^2,
 // Sxy = sum v_sigma dx dy, Syy = sum v_sigma dy^2.  With the splat's conic (a, b, c) from its packed record:
-//     v_mean2d = (a A + b B, b A + c B),   v_conic = (Sxx / 2, Sxy, Syy / 2).
+//     v_mean2d = (a A + b B, b A + c B),   v_conic = (Sxx / 2, Sxy, Syy / 2);
+// component 5 is S = sum v_sigma and v_opacity = -S / opacity (0 for a splat without slots or with S = 0: a pair only
+// contributes when opacity * vis >= 1/255, so opacity > 0 wherever S != 0).
 // c0, c1, c2 = the summed components 0, 1, 2 in one lane -> v_x, v_y, v_conic_a (component 4 is halved by its lane).
 __device__ __forceinline__ void finish_geometry(const float* __restrict__ rec, bool any, float& c0, float& c1, float& c2) {
     if (any) {  // (a splat without slots may have no record at all: culled splats are never packed)
@@ -1308,6 +1312,7 @@ slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, const i
         } else if (comp == 2 || comp == 4) {
             acc *= 0.5f;
         }
+        else if (comp == 5) acc = (b > a && acc != 0.f) ? -acc / records[g * stride + 5] : 0.f;
     }
     if (comp < 2)
         v_means2d[2 * g + comp] = acc;
@@ -1358,8 +1363,10 @@ slot_reduce_wide_kernel(int n_gauss, int channels, int has_extra, int rq, const 
     const size_t g = (size_t)gid;
     if (q == 0)       // components 0..3 live in quarter 0
         finish_geometry(records + g * 4 * rq, b > a, acc[0], acc[1], acc[2]);
-    else if (q == 1)  // component 4: the conic's c
+    else if (q == 1) {  // component 4: the conic's c
         acc[0] *= 0.5f;
+        acc[1] = (b > a && acc[1] != 0.f) ? -acc[1] / records[g * 4 * rq + 5] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int comp = 4 * q + i;
@@ -1429,8 +1436,10 @@ slot_reduce16_kernel(int n_gauss, int channels, int has_extra, const int32_t* __
     const size_t g = (size_t)gid;
     if (q == 0)
         finish_geometry(records + g * 16, b > a, acc[0], acc[1], acc[2]);
-    else if (q == 1)
+    else if (q == 1) {
         acc[0] *= 0.5f;
+        acc[1] = (b > a && acc[1] != 0.f) ? -acc[1] / records[g * 16 + 5] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int comp = 4 * q + i;

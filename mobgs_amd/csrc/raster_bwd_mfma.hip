@@ -173,8 +173,8 @@ __device__ __forceinline__ void build_b_operands(float (&Bk)[16], int qd, int la
 }
 
 // moments -> slot record of one (tile, entry) pair in the format of blend_bwd (raster.hip): the RAW geometric sums
-// {sum v_sigma dx, sum v_sigma dy, sum v_sigma dx^2, sum v_sigma dx dy, sum v_sigma dy^2}, v_opacity, v_colour[..] --
-// the conic enters once per splat in stage 2 (finish_geometry)
+// {sum v_sigma dx, sum v_sigma dy, sum v_sigma dx^2, sum v_sigma dx dy, sum v_sigma dy^2, sum v_sigma}, v_colour[..] --
+// conic and opacity enter once per splat in stage 2 (finish_geometry)
 __device__ __forceinline__ void convert_moments(const float (&a)[16], float gx, float gy, float /*ca*/, float /*cb*/,
                                                 float /*cc*/, float op, float mcx, float mcy, float (&out)[16]) {
     const float S0 = a[0], Sx = a[1], Sy = a[2], Sxx = a[3], Sxy = a[4], Syy = a[5];
@@ -185,7 +185,7 @@ __device__ __forceinline__ void convert_moments(const float (&a)[16], float gx, 
     out[2] = __fmaf_rn(mx, Dx - Sx, Sxx);
     out[3] = __fmaf_rn(mx, Dy, __fmaf_rn(-my, Sx, Sxy));
     out[4] = __fmaf_rn(my, Dy - Sy, Syy);
-    out[5] = -S0 / op;
+    out[5] = S0;
 #pragma unroll
     for (int c = 6; c < 16; ++c) out[c] = a[c];
 }
