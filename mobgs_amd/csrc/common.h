@@ -142,14 +142,39 @@ __device__ inline int band_mask(float mx, float my, float ca, float cb, float cc
     return m;
 }
 
-// The compositor's packed splat record {x, y, conic a b | c, opacity, colour[0..1] | colour ... (extra) 0...}:
-// `stride` floats (a multiple of 4), 16-byte aligned.
+// The compositor's packed splat record {x, y, A, B | C, L, colour[0..1] | colour ... (extra) 0...}: `stride` floats (a
+// multiple of 4), 16-byte aligned.  Conic and opacity are stored in EXPONENT FORM: with the conic (a, b, c) and
+// d = mean2d - pixel,
+//     opacity * exp(-sigma) = exp2(A dx^2 + C dy^2 + B dx dy + L),
+//     A = -log2(e) a / 2,  B = -log2(e) b,  C = -log2(e) c / 2,  L = log2(opacity)
+// -- the per-(pixel, splat) evaluation (eval_splat, raster_shared.h) is then three multiplies, three FMAs and the
+// hardware exp2, without the scaling of sigma and the multiplication by the opacity (3 VALU fewer per pair in every
+// compositing kernel).  sigma < 0 (upstream's skip test) reads "exponent > L".  The few consumers that need conic and
+// opacity themselves (reach masks per staged entry, the per-splat finish of the gradient reduction) convert back.
+constexpr float MOBGS_LOG2E = 1.4426950408889634f;
+constexpr float MOBGS_LN2 = 0.6931471805599453f;
+__device__ inline void record_exponent_form(float ca, float cb, float cc, float op, float& A, float& B, float& C,
+                                            float& L) {
+    A = (-0.5f * MOBGS_LOG2E) * ca;
+    B = -MOBGS_LOG2E * cb;
+    C = (-0.5f * MOBGS_LOG2E) * cc;
+    L = op > 0.f ? __log2f(op) : -__builtin_inff();  // (opacity <= 0 or NaN: the splat never reaches 1/255)
+}
+__device__ inline void record_conic_form(float A, float B, float C, float L, float& ca, float& cb, float& cc,
+                                         float& op) {
+    ca = (-2.f * MOBGS_LN2) * A;
+    cb = -MOBGS_LN2 * B;
+    cc = (-2.f * MOBGS_LN2) * C;
+    op = __builtin_amdgcn_exp2f(L);
+}
 __device__ inline void write_splat_record(float* __restrict__ r, float x, float y, float ca, float cb, float cc,
                                           float op, const float* __restrict__ col, int channels, bool has_extra,
                                           float extra) {
-    reinterpret_cast<float4*>(r)[0] = make_float4(x, y, ca, cb);
+    float A, B, C, L;
+    record_exponent_form(ca, cb, cc, op, A, B, C, L);
+    reinterpret_cast<float4*>(r)[0] = make_float4(x, y, A, B);
     const int D = channels + (has_extra ? 1 : 0);
-    float buf[4] = {cc, op, 0.f, 0.f};
+    float buf[4] = {C, L, 0.f, 0.f};
     int fill = 2;
     int q = 1;
     for (int k = 0; k < D; ++k) {

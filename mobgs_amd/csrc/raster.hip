@@ -135,8 +135,7 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
             // which 8x8 quadrants of the tile the splat can reach at all (lane = splat: one test per entry, not per
             // pixel): ~40 % of the (entry, quadrant) pairs of a typical list are out of reach and are never evaluated
             unsigned reach = cls.all_reach ? 0xFu
-                                           : quadrant_reach_mask(pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x,
-                                                                 pre[1].y, tx, ty);
+                                           : quadrant_reach_mask_rec(pre[0], pre[1], tx, ty);
             // kept for the backward pass (it walks the same lists): one byte per list entry.  (Heavy tiles: all four
             // quadrant waves store the same byte -- any of them may leave the walk first.)
             if (isect_reach && b + lane < e && (!FILTER || pre_keep)) isect_reach[b + lane] = (uint8_t)reach;
@@ -290,6 +289,11 @@ __device__ inline unsigned block_reach_mask16(float mx, float my, float ca, floa
     return m & (((q & 1u) ? 0x0033u : 0u) | ((q & 2u) ? 0x00CCu : 0u) | ((q & 4u) ? 0x3300u : 0u) |
                 ((q & 8u) ? 0xCC00u : 0u));
 }
+// ... from a staged record head (exponent form: common.h, write_splat_record)
+__device__ inline unsigned block_reach_mask16_rec(const float4& r0, const float4& r1, int tx, int ty) {
+    const ConicOp c = head_conic(r0, r1);
+    return block_reach_mask16(r0.x, r0.y, c.ca, c.cb, c.cc, c.op, tx, ty);
+}
 
 #ifndef F2_WAVES
 #define F2_WAVES 4
@@ -373,7 +377,7 @@ raster_fwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
             }
             if (pre_g >= 0) {
                 m16 = all_reach ? 0xFFFFu
-                                : block_reach_mask16(pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, tx, ty);
+                                : block_reach_mask16_rec(pre[0], pre[1], tx, ty);
                 const bool kept = !FILTER || cls.keeps(pre_g);
                 if (!kept) m16 = 0u;
                 // the backward pass walks quadrants: a quadrant is reachable iff one of its blocks is.  Class-restricted
@@ -443,7 +447,9 @@ raster_fwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
                     T[k] = blend ? nT : (stop ? -fabsf(T[k]) : T[k]);
                     last[k] = blend ? list_idx : last[k];
                 }
-                if (!(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) > 0.f)) {  // all four pixels finished
+                // all four pixels finished = all four sign bits set (T is never +0: it starts at +-1 and a live pixel
+                // keeps T > 1e-4).  Three full-rate ANDs and one compare instead of the canonicalising v_max chain.
+                if ((__float_as_int(T[0]) & __float_as_int(T[1]) & __float_as_int(T[2]) & __float_as_int(T[3])) < 0) {
                     done = true;
                     mlo = mhi = 0u;
                 }
@@ -641,7 +647,7 @@ __device__ __forceinline__ void blend_bwd(const float (&rec)[RS], const Eval& ev
         dot = __fmaf_rn(rec[6 + c], vo[c], dot);
     }
     const float v_alpha = __fmaf_rn(T, dot, ra * (tvab - behind));
-    const float ov = rec[5] * ev.vis;
+    const float ov = ev.raw;   // opacity * visibility, before the clamp
     const bool live = pass && ov <= ALPHA_MAX;  // the clamp at 0.999 has zero slope
     const float v_sigma = live ? -ov * v_alpha : 0.f;
     // Geometry terms as RAW sums: sum v_sigma dx, sum v_sigma dy, sum v_sigma dx^2, sum v_sigma dx dy, sum v_sigma dy^2.
@@ -813,7 +819,7 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                 sh.reach_of[wv][pos] = isect_reach ? (unsigned)isect_reach[hi - lane]
                                        : cls.all_reach
                                            ? 0xFu
-                                           : quadrant_reach_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty);
+                                           : quadrant_reach_mask_rec(r0, r1, tx, ty);
                 const TileRect tr = tile_rect(r0.x, r0.y, radii[g], tile_w, tile_h);
                 slot_of[wv][pos] = keep_index(keep_scan, cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0));
                 if (FILTER) sh.idx_of[wv][pos] = hi - lane;
@@ -1114,7 +1120,7 @@ __device__ __forceinline__ void composite_bwd_blocks(int tile, int wv, int lane,
             sh.slab[wv][lane][1] = r1;
 #pragma unroll
             for (int q = 2; q < RQ; ++q) sh.slab[wv][lane][q] = rp[q];
-            m16 = all_reach ? 0xFFFFu : block_reach_mask16(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty);
+            m16 = all_reach ? 0xFFFFu : block_reach_mask16_rec(r0, r1, tx, ty);
             const TileRect tr = tile_rect(r0.x, r0.y, radii[g], tile_w, tile_h);
             sh.slot_of[wv][lane] = keep_index(keep_scan, cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0));
         }
@@ -1259,12 +1265,14 @@ raster_bwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
 // Components 0..4 of a slot are raw sums (blend_bwd): A = sum v_sigma dx, B = sum v_sigma dy, Sxx = sum v_sigma dx^2,
 // Sxy = sum v_sigma dx dy, Syy = sum v_sigma dy^2.  With the splat's conic (a, b, c) from its packed record:
 //     v_mean2d = (a A + b B, b A + c B),   v_conic = (Sxx / 2, Sxy, Syy / 2);
-// component 5 is S = sum v_sigma and v_opacity = -S / opacity (0 for a splat without slots or with S = 0: a pair only
-// contributes when opacity * vis >= 1/255, so opacity > 0 wherever S != 0).
+// component 5 is S = sum v_sigma and v_opacity = -S / opacity = -S exp2(-L) (0 for a splat without slots or with S = 0:
+// a pair only contributes when opacity * vis >= 1/255, so opacity > 0 wherever S != 0).  The record holds conic and
+// opacity in exponent form (common.h, write_splat_record): record_conic_form() converts back.
 // c0, c1, c2 = the summed components 0, 1, 2 in one lane -> v_x, v_y, v_conic_a (component 4 is halved by its lane).
 __device__ __forceinline__ void finish_geometry(const float* __restrict__ rec, bool any, float& c0, float& c1, float& c2) {
     if (any) {  // (a splat without slots may have no record at all: culled splats are never packed)
-        const float ca = rec[2], cb = rec[3], cc = rec[4];
+        float ca, cb, cc, op;
+        record_conic_form(rec[2], rec[3], rec[4], rec[5], ca, cb, cc, op);  // the record holds the exponent form
         const float A = c0, B = c1;
         c0 = ca * A + cb * B;
         c1 = cb * A + cc * B;
@@ -1307,12 +1315,14 @@ slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, const i
         if (comp < 2) {
             if (b > a) {  // (no slots: the record may never have been packed)
                 const float* rec = records + g * stride;
-                acc = comp == 0 ? rec[2] * acc + rec[3] * other : rec[3] * other + rec[4] * acc;
+                float ca, cb, cc, op;
+                record_conic_form(rec[2], rec[3], rec[4], rec[5], ca, cb, cc, op);
+                acc = comp == 0 ? ca * acc + cb * other : cb * other + cc * acc;
             }
         } else if (comp == 2 || comp == 4) {
             acc *= 0.5f;
         }
-        else if (comp == 5) acc = (b > a && acc != 0.f) ? -acc / records[g * stride + 5] : 0.f;
+        else if (comp == 5) acc = (b > a && acc != 0.f) ? -acc * __builtin_amdgcn_exp2f(-records[g * stride + 5]) : 0.f;
     }
     if (comp < 2)
         v_means2d[2 * g + comp] = acc;
@@ -1365,7 +1375,7 @@ slot_reduce_wide_kernel(int n_gauss, int channels, int has_extra, int rq, const 
         finish_geometry(records + g * 4 * rq, b > a, acc[0], acc[1], acc[2]);
     else if (q == 1) {  // component 4: the conic's c
         acc[0] *= 0.5f;
-        acc[1] = (b > a && acc[1] != 0.f) ? -acc[1] / records[g * 4 * rq + 5] : 0.f;
+        acc[1] = (b > a && acc[1] != 0.f) ? -acc[1] * __builtin_amdgcn_exp2f(-records[g * 4 * rq + 5]) : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1438,7 +1448,7 @@ slot_reduce16_kernel(int n_gauss, int channels, int has_extra, const int32_t* __
         finish_geometry(records + g * 16, b > a, acc[0], acc[1], acc[2]);
     else if (q == 1) {
         acc[0] *= 0.5f;
-        acc[1] = (b > a && acc[1] != 0.f) ? -acc[1] / records[g * 16 + 5] : 0.f;
+        acc[1] = (b > a && acc[1] != 0.f) ? -acc[1] * __builtin_amdgcn_exp2f(-records[g * 16 + 5]) : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -218,7 +218,7 @@ __device__ __forceinline__ void walk_quadrant(const MfmaWave<CD, STRIDE>& mw, co
 #pragma unroll
         for (int c = 0; c < CD; ++c) dot = __fmaf_rn(rec[6 + c], vo[c], dot);
         const float v_alpha = __fmaf_rn(T, dot, ra * (tvab - behind));
-        const float ov = rec[5] * ev.vis;
+        const float ov = ev.raw;
         const bool live = pass && ov <= ALPHA_MAX;
         const float v_sigma = live ? -ov * v_alpha : 0.f;
         behind = __fmaf_rn(fac, dot, behind);
@@ -405,7 +405,7 @@ __device__ __forceinline__ void composite_bwd_mfma(
             r1 = r[1];
             rm = isect_reach ? (unsigned)isect_reach[idx]
                  : cls.all_reach ? 0xFu
-                                 : quadrant_reach_mask(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty);
+                                 : quadrant_reach_mask_rec(r0, r1, tx, ty);
             const TileRect tr = tile_rect(r0.x, r0.y, radii[g], tile_w, tile_h);
             slot = keep_index(keep_scan, cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0));
         }
@@ -542,7 +542,7 @@ __device__ __forceinline__ void composite_bwd_team(
             h.r1 = *reinterpret_cast<const float2*>(r + 1);
             h.rm = isect_reach ? (unsigned)isect_reach[hi_x - sp]
                    : cls.all_reach ? 0xFu
-                                   : quadrant_reach_mask(h.r0.x, h.r0.y, h.r0.z, h.r0.w, h.r1.x, h.r1.y, tx, ty);
+                                   : quadrant_reach_mask_rec(h.r0, make_float4(h.r1.x, h.r1.y, 0.f, 0.f), tx, ty);
             const TileRect tr = tile_rect(h.r0.x, h.r0.y, radii[g], tile_w, tile_h);
             h.box = cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0);
         }

@@ -34,18 +34,21 @@ __device__ inline void l_fence() {
 }
 
 struct LEval {
-    float dx, dy, vis, alpha;
+    float dx, dy, raw, alpha;   // raw = opacity * exp(-sigma), before the clamp
     bool pass;
 };
-// identical instruction sequence to raster.hip's eval_splat (bit-identical alphas)
-__device__ __forceinline__ LEval l_eval(float gx, float gy, float ca, float cb, float cc, float op, float px, float py) {
+// identical instruction sequence to raster_shared.h's eval_splat (bit-identical alphas); A, B, C, L: the record's
+// exponent form (common.h, write_splat_record)
+__device__ __forceinline__ LEval l_eval(float gx, float gy, float A, float B, float C, float L, float px, float py) {
     LEval e;
     e.dx = gx - px;
     e.dy = gy - py;
-    const float sigma = __fmaf_rn(0.5f, __fmaf_rn(ca * e.dx, e.dx, cc * e.dy * e.dy), cb * e.dx * e.dy);
-    e.vis = __expf(-sigma);
-    e.alpha = fminf(L_ALPHA_MAX, op * e.vis);
-    e.pass = !(sigma < 0.f || e.alpha < L_ALPHA_MIN);
+    float s = __fmaf_rn(A * e.dx, e.dx, L);
+    s = __fmaf_rn(C * e.dy, e.dy, s);
+    s = __fmaf_rn(B * e.dx, e.dy, s);
+    e.raw = __builtin_amdgcn_exp2f(s);
+    e.alpha = fminf(L_ALPHA_MAX, e.raw);
+    e.pass = !(s > L || e.alpha < L_ALPHA_MIN);
     return e;
 }
 
@@ -264,6 +267,11 @@ struct LayerBwd {
 template <int CD, int NVP, bool XY0>
 __device__ __forceinline__ bool layer_grad(LayerBwd<CD>& B, const LEval (&ev)[LPPL], const float* rec, int idx,
                                            bool has_bg, float (&g)[NVP], float& e0, float& e1) {
+    // this kernel still accumulates the conic-weighted terms per pair: conic and 1 / opacity back from the record's
+    // exponent form (uniform per entry)
+    struct { float ca, cb, cc, op; } co;
+    record_conic_form(rec[2], rec[3], rec[4], rec[5], co.ca, co.cb, co.cc, co.op);
+    const float inv_op = __builtin_amdgcn_exp2f(-rec[5]);
     bool any = false;
 #pragma unroll
     for (int k = 0; k < LPPL; ++k) {
@@ -285,11 +293,11 @@ __device__ __forceinline__ bool layer_grad(LayerBwd<CD>& B, const LEval (&ev)[LP
         float v_alpha = __fmaf_rn(B.T[k], dot, -ra * B.behind[k]);
         v_alpha += B.Tf[k] * ra * B.va[k];
         if (has_bg) v_alpha -= B.Tf[k] * ra * B.bgdot[k];
-        const float ov = rec[5] * ev[k].vis;
+        const float ov = ev[k].raw;
         if (ov <= L_ALPHA_MAX) {
             const float v_sigma = -ov * v_alpha;
             const float dx = ev[k].dx, dy = ev[k].dy;
-            const float gx = v_sigma * (rec[2] * dx + rec[3] * dy), gy = v_sigma * (rec[3] * dx + rec[4] * dy);
+            const float gx = v_sigma * (co.ca * dx + co.cb * dy), gy = v_sigma * (co.cb * dx + co.cc * dy);
             g[0] += gx;
             g[1] += gy;
             if (XY0) {
@@ -299,7 +307,7 @@ __device__ __forceinline__ bool layer_grad(LayerBwd<CD>& B, const LEval (&ev)[LP
             g[2] = __fmaf_rn(0.5f * v_sigma * dx, dx, g[2]);
             g[3] = __fmaf_rn(v_sigma * dx, dy, g[3]);
             g[4] = __fmaf_rn(0.5f * v_sigma * dy, dy, g[4]);
-            g[5] = __fmaf_rn(ev[k].vis, v_alpha, g[5]);
+            g[5] = __fmaf_rn(ov * inv_op, v_alpha, g[5]);   // visibility = raw / opacity
         }
         B.behind[k] = __fmaf_rn(fac, dot, B.behind[k]);
     }

@@ -43,21 +43,38 @@ struct ClassSel {
     __device__ __forceinline__ bool keeps(int flat_id) const { return sel == 0 || (((flat_id % N) < Ns) == (sel == 1)); }
 };
 
-// sigma / visibility / alpha of one splat at one pixel; the same instruction sequence in fwd and bwd
+// offsets / unclamped alpha / alpha of one splat at one pixel from the record's exponent form (common.h,
+// write_splat_record): raw = opacity * exp(-sigma) = exp2(A dx^2 + C dy^2 + B dx dy + L); the same instruction
+// sequence in every forward and backward kernel, so all of them see bit-identical alphas.
+// pass = !(sigma < 0 || alpha < 1/255): sigma < 0 <=> the exponent exceeds L.
 struct Eval {
-    float dx, dy, vis, alpha;
+    float dx, dy, raw, alpha;
     bool pass;
 };
-__device__ __forceinline__ Eval eval_splat(float gx, float gy, float ca, float cb, float cc, float op, float px,
-                                           float py) {
+__device__ __forceinline__ Eval eval_splat(float gx, float gy, float A, float B, float C, float L, float px, float py) {
     Eval e;
     e.dx = gx - px;
     e.dy = gy - py;
-    const float sigma = __fmaf_rn(0.5f, __fmaf_rn(ca * e.dx, e.dx, cc * e.dy * e.dy), cb * e.dx * e.dy);
-    e.vis = __expf(-sigma);
-    e.alpha = fminf(ALPHA_MAX, op * e.vis);
-    e.pass = !(sigma < 0.f || e.alpha < ALPHA_MIN);
+    float s = __fmaf_rn(A * e.dx, e.dx, L);
+    s = __fmaf_rn(C * e.dy, e.dy, s);
+    s = __fmaf_rn(B * e.dx, e.dy, s);
+    e.raw = __builtin_amdgcn_exp2f(s);
+    e.alpha = fminf(ALPHA_MAX, e.raw);
+    e.pass = !(s > L || e.alpha < ALPHA_MIN);
     return e;
+}
+// conic and opacity of a staged record head {x, y, A, B | C, L, ..} for the reach tests
+struct ConicOp {
+    float ca, cb, cc, op;
+};
+__device__ __forceinline__ ConicOp head_conic(const float4& r0, const float4& r1) {
+    ConicOp c;
+    record_conic_form(r0.z, r0.w, r1.x, r1.y, c.ca, c.cb, c.cc, c.op);
+    return c;
+}
+__device__ __forceinline__ unsigned quadrant_reach_mask_rec(const float4& r0, const float4& r1, int tx, int ty) {
+    const ConicOp c = head_conic(r0, r1);
+    return quadrant_reach_mask(r0.x, r0.y, c.ca, c.cb, c.cc, c.op, tx, ty);
 }
 
 }  // namespace mobgs

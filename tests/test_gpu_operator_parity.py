@@ -135,8 +135,12 @@ def test_rasterization_backward(hip_device, mode, channels, use_bg):
     for k in ref:
         scale = float(ref[k].abs().max())
         _close(out[k], ref[k], 1e-3, 5e-4 * scale + 1e-6, f"grad[{k}] vs torch oracle")
-    # (2) against the C restatement of upstream's backward kernels (same recurrences): only summation order
-    #     and the last bit of exp() differ
+    # (2) against the C restatement of upstream's backward kernels (same recurrences): summation order and the fp32
+    #     rounding of alpha differ (the kernels evaluate opacity * exp(-sigma) as exp2 of ONE polynomial, common.h
+    #     write_splat_record).  The camera gradient is a sum over every splat with heavy cancellation:
+    #     scripts/exp_form_accuracy.py (profiles/r04/exp_form_accuracy.txt) measures this very scene against the exact
+    #     float64 gradients -- HIP 1.2e-4 of the maximum, the C restatement 1.9e-4, their mutual distance 6.8e-5 -- so
+    #     the allowance between the two fp32 evaluations is 1e-4 of the maximum there, 2e-5 elsewhere
     from oracle import gsplat_cpu as Cc
     g = torch.Generator().manual_seed(7)
     C = s["viewmats"].shape[0]
@@ -151,8 +155,8 @@ def test_rasterization_backward(hip_device, mode, channels, use_bg):
                   ("colors", "v_colors"), ("viewmats", "v_viewmats"), ("means2d", "v_means2d")]:
         refc = torch.from_numpy(r[ck])
         scale = float(refc.abs().max())
-        _close(out[k], refc, 2e-4, 2e-5 * scale + 1e-7, f"grad[{k}] vs C oracle", flip_frac=2e-3,
-               flip_atol=5e-4 * scale)
+        _close(out[k], refc, 2e-4, (1e-4 if k == "viewmats" else 2e-5) * scale + 1e-7, f"grad[{k}] vs C oracle",
+               flip_frac=2e-3, flip_atol=5e-4 * scale)
 
 
 @pytest.mark.parametrize("mode,channels", [("RGB+ED", 9), ("RGB", 2)])
