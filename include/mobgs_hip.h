@@ -244,7 +244,9 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
  * opacities: [C,N] (opac_per_camera=1) or [N] (0)
  * extra    : optional [C,N] channel appended after `channels` (gsplat's "+D"/"+ED" depth channel), or NULL
  * backgrounds: [C, channels(+1 if extra)] or NULL
- * records  : scratch/out [C*N, mobgs_record_stride(D)] packed splat records (kept for backward), D = total
+ * records  : scratch/out [C*N, mobgs_record_stride(D)] packed splat records (kept for backward; an OPAQUE format of
+ *            the kernels: {x, y, A, B, C, L, colours..} with conic and opacity in exponent form,
+ *            opacity exp(-sigma) = exp2(A dx^2 + C dy^2 + B dx dy + L) -- csrc/common.h write_splat_record), D = total
  * out: render [C,H,W,D], alphas [C,H,W], last_ids [C,H,W] (index into flatten_ids of the last blended splat)
  * isect_reach (optional out, else NULL): [I_listed] bytes -- per list entry, the 8x8 quadrants of its tile the splat
  *   can reach (what the kernel computes anyway to skip the others); hand it to mobgs_raster_bwd for the same lists and
