@@ -137,12 +137,29 @@ def run_case(c, dev):
     # a blend decision at the 1/255 threshold that falls the other way moves a pixel by alpha * T * |colour| <= |colour| / 255
     # -- of the SPLAT's colour, which may exceed the image's range (seed 4242 case 28: colour 3.2, pixel off by 1.26e-2)
     flip = max(scale, float(s["colors"].abs().max())) / 255
-    if f > 5e-3 or e > (flip if mode not in ("ED", "RGB+ED") else 1e9) * 1.5:
-        problems.append(f"image: {f:.2e} of the pixels off, max {e:.3e} (scale {scale:.2e})")
-    f, e = frac_off(a.detach().cpu().numpy()[..., 0], ref["alphas"], 0, 2e-5)
+    f_img = f
+    image_problem = f > 5e-3 or e > (flip if mode not in ("ED", "RGB+ED") else 1e9) * 1.5
+    image_msg = f"image: {f:.2e} of the pixels off, max {e:.3e} (scale {scale:.2e})"
+    a_out = a.detach().cpu().numpy()[..., 0].astype(np.float64)
+    f, e = frac_off(a_out, ref["alphas"], 0, 2e-5)
     stats["alpha"] = (f, e)
-    if f > 5e-3 or e > 1.5 / 255:
-        problems.append(f"alpha: {f:.2e} off, max {e:.3e}")
+    # two kinds of flipped blend decisions move a pixel's coverage: the 1/255 skip test (by alpha T <= 1/255) and the
+    # transmittance stop -- T (1 - alpha) <= 1e-4 ends the walk WITHOUT blending the splat, so the two outcomes are
+    # "T stays" and "T drops to ~1e-4": with an opaque splat (alpha up to the 0.999 clamp) that is a step of up to
+    # T <= 0.1 (seed 4203 case 48: a pixel at T = 8.9e-3 in front of an alpha 0.99 splat).  Such a pixel is recognised
+    # by one of the two results sitting at the stop threshold; its step is bounded by the other one's transmittance.
+    T_out, T_ref = 1.0 - a_out, 1.0 - np.asarray(ref["alphas"], np.float64)
+    d = np.abs(a_out - ref["alphas"])
+    stop_flip = (np.minimum(T_out, T_ref) <= 1.2e-4) & (d <= 1.001 * np.maximum(T_out, T_ref))
+    e_other = float(d[~stop_flip].max()) if (~stop_flip).any() else 0.0
+    if image_problem:  # ... unless every pixel beyond the 1/255 step is a transmittance-stop flip (bounded by T |colour|)
+        de = np.abs(img.detach().cpu().numpy().astype(np.float64) - ref["render"]).max(-1)
+        cmax = max(scale, float(s["colors"].abs().max()))
+        beyond = de > 1.5 * flip
+        if f_img > 5e-3 or (beyond & ~(stop_flip & (de <= 1.001 * np.maximum(T_out, T_ref) * cmax))).any():
+            problems.append(image_msg)
+    if f > 5e-3 or e_other > 1.5 / 255:
+        problems.append(f"alpha: {f:.2e} off, max {e:.3e} ({e_other:.3e} outside transmittance-stop flips)")
     for k, ck in [("means", "v_means"), ("quats", "v_quats"), ("scales", "v_scales"), ("opacities", "v_opacities"),
                   ("colors", "v_colors"), ("viewmats", "v_viewmats")]:
         if ref.get(ck) is None or t[k].grad is None:
