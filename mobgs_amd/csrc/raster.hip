@@ -634,10 +634,11 @@ __device__ __forceinline__ void blend_bwd(const float (&rec)[RS], const Eval& ev
                                           float tvab, const float (&vo)[CD], float (&g)[NVP]) {
     auto acc = [](float& dst, float a, float b) { dst = FIRST ? a * b : __fmaf_rn(a, b, dst); };
     const float alpha = pass ? ev.alpha : 0.f;
-    // 1 / (1 - alpha): hardware reciprocal + one Newton step (<= 1 ulp; 1 - alpha >= 1e-3)
+    // 1 / (1 - alpha): the hardware reciprocal (1 ulp; 1 - alpha >= 1e-3).  A Newton step behind it (0.5 ulp) changes
+    // no gradient at the third digit of its distance to the exact float64 value (scripts/exp_form_accuracy.py) -- the
+    // product T * ra rounds once per step anyway -- and costs 9 us of the 460 (docs/COMPOSITOR_NOTES.md)
     const float om = 1.f - alpha;
-    float ra = __builtin_amdgcn_rcpf(om);
-    ra = __fmaf_rn(__fmaf_rn(-om, ra, 1.f), ra, ra);
+    const float ra = __builtin_amdgcn_rcpf(om);
     T *= ra;
     const float fac = alpha * T;
     float dot = 0.f;

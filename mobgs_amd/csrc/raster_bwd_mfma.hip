@@ -6,7 +6,7 @@
 // raster_bwd_kernel (raster.hip) keeps 6 + CD gradient sums per lane and per list entry, adds 16 + 14 FMAs per
 // (pixel, splat) pair into them and pays a 64-lane reduction (12 permlane swaps + 8 DPP adds + the clears) per entry:
 // 176 issued lane-operations per live pair, of which the arithmetic of the pair is ~50.  Here the per-pixel arithmetic
-// is unchanged (eval_splat, the Newton reciprocal, T, `behind`, v_alpha, v_sigma: bit-identical per pixel) but a pair
+// is unchanged (eval_splat, the reciprocal, T, `behind`, v_alpha, v_sigma: bit-identical per pixel) but a pair
 // only PRODUCES its two weights
 //       fac = alpha * T                (weight of the colour cotangent:  v_colour[e] += fac * v_out[p])
 //       vs  = v_sigma                  (weight of the geometry terms:    v_xy, v_conic, v_opacity)
@@ -210,8 +210,7 @@ __device__ __forceinline__ void walk_quadrant(const MfmaWave<CD, STRIDE>& mw, co
         // the pair arithmetic of blend_bwd (raster.hip), minus the sums
         const float alpha = pass ? ev.alpha : 0.f;
         const float om = 1.f - alpha;
-        float ra = __builtin_amdgcn_rcpf(om);
-        ra = __fmaf_rn(__fmaf_rn(-om, ra, 1.f), ra, ra);
+        const float ra = __builtin_amdgcn_rcpf(om);   // (no Newton step: raster.hip, blend_bwd)
         T *= ra;
         const float fac = alpha * T;
         float dot = 0.f;

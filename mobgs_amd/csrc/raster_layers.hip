@@ -280,8 +280,7 @@ __device__ __forceinline__ bool layer_grad(LayerBwd<CD>& B, const LEval (&ev)[LP
         if (!pass) continue;
         const float alpha = ev[k].alpha;
         const float om = 1.f - alpha;
-        float ra = __builtin_amdgcn_rcpf(om);
-        ra = __fmaf_rn(__fmaf_rn(-om, ra, 1.f), ra, ra);
+        const float ra = __builtin_amdgcn_rcpf(om);   // (no Newton step: raster.hip, blend_bwd)
         B.T[k] *= ra;
         const float fac = alpha * B.T[k];
         float dot = 0.f;
