@@ -133,13 +133,18 @@ def check_deform_fixture_grads(fx, get_plane_grad, what=""):
 
 
 def close_image_with_blend_flips(img, ref, alphas_ref, colors_absmax, depth_spread, tight_atol, what, flip_frac=2e-3,
-                                 n_colour_channels=None):
+                                 n_colour_channels=None, alphas_img=None):
     """Image comparison whose discrete-decision allowance is DERIVED, not guessed.  Two fp32 implementations of
     alpha = o exp(-sigma) disagree in the last bit, so a splat sitting on the 1/255 skip threshold is blended by one
-    and skipped by the other (the 1e-4 transmittance stop moves a pixel by <= 1e-4 of the colour range).  The pixel
-    then moves by at most w (|c| + |pixel|) with w = alpha T <= 1/255 in a colour channel, and an expected-depth
-    channel (accumulated depth / alpha) by at most w spread / alpha_pixel.  `flip_frac` of the elements may use that
-    bound (x 2: the flip can also cascade into the next splat's weight), everything else must meet `tight_atol`.
+    and skipped by the other.  The pixel then moves by at most w (|c| + |pixel|) with w = alpha T <= 1/255 in a colour
+    channel, and an expected-depth channel (accumulated depth / alpha) by at most w spread / alpha_pixel.  `flip_frac`
+    of the elements may use that bound (x 2: the flip can also cascade into the next splat's weight), everything else
+    must meet `tight_atol`.
+    The OTHER discrete decision is the transmittance stop: T (1 - alpha) <= 1e-4 ends a pixel's walk WITHOUT blending
+    the splat, so its two outcomes are "T stays" and "T drops to ~1e-4" -- in front of an opaque splat (alpha up to the
+    0.999 clamp) a step of alpha T with T up to 0.1, not 1e-4 (found by scripts/soak_parity.py, seed 4203 case 48).
+    With `alphas_img` (the coverage of `img`) such pixels are recognised -- one of the two results sits at the stop
+    threshold -- and bounded by the other one's transmittance: max(T_ref, T_img) (|c| + |pixel|).
     -> (number of flipped elements, their largest error): logged by the callers."""
     img = torch.as_tensor(img).detach().cpu().double()
     ref = torch.as_tensor(ref).detach().cpu().double()
@@ -152,6 +157,16 @@ def close_image_with_blend_flips(img, ref, alphas_ref, colors_absmax, depth_spre
     bound[..., :nc] = 2.0 * w * (colors_absmax + ref[..., :nc].abs())
     if nc < C:
         bound[..., nc:] = 2.0 * w * depth_spread / a.clamp_min(1.0 / 255.0)
+    if alphas_img is not None:
+        ai = torch.as_tensor(alphas_img).detach().cpu().double().reshape(ref.shape[:-1] + (1,))
+        t_ref, t_img = 1.0 - a, 1.0 - ai
+        at_stop = torch.minimum(t_ref, t_img) <= 1.2e-4
+        step = 1.001 * torch.maximum(t_ref, t_img)
+        stop_bound = torch.empty_like(ref)
+        stop_bound[..., :nc] = step * (colors_absmax + ref[..., :nc].abs())
+        if nc < C:
+            stop_bound[..., nc:] = step * depth_spread / torch.minimum(a, ai).clamp_min(1.0 / 255.0)
+        bound = torch.where(at_stop.expand_as(ref), torch.maximum(bound, stop_bound), bound)
     err = (img - ref).abs()
     bad = err > tight_atol
     nbad = int(bad.sum())

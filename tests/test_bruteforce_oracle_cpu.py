@@ -60,7 +60,8 @@ def check_against_bruteforce(img, alpha, radii, means2d, conics, grads, scene, r
     spread = float((depth.max() - depth.min()).detach())
     scale = max(1.0, float(rimg[..., :9].abs().max()))
     close_image_with_blend_flips(img[0], rimg[0], ra[0], float(s["colors"].abs().max()), spread, 3e-5 * max(scale, spread),
-                                 f"{what}: image", flip_frac=2e-3, n_colour_channels=9)
+                                 f"{what}: image", flip_frac=2e-3, n_colour_channels=9,
+                                 alphas_img=torch.as_tensor(alpha).reshape(ra.shape)[0])
     close(torch.as_tensor(alpha).reshape(ra.shape), ra, 0, 3e-5, f"{what}: alpha", flip_frac=2e-3, flip_atol=2.0 * 1.001 / 255.0)
     for k in NAMES:
         sc = float(rg[k].abs().max())

@@ -61,7 +61,7 @@ def test_fullsize_forward_backward_against_c_oracle(hip_device, scene300k):
     vis_depth = meta["depths"][meta["radii"] > 0]
     nflip, worst = close_image_with_blend_flips(img, ref, r["alphas"], float(s["colors"].abs().max()),
                                                 float(vis_depth.max() - vis_depth.min()), 3e-5 * scale, "image",
-                                                flip_frac=2e-4, n_colour_channels=9)  # observed 2e-6 .. 6e-5
+                                                flip_frac=2e-4, n_colour_channels=9, alphas_img=a)  # observed 2e-6 .. 6e-5
     print(f"\n[fullsize] image: {nflip} of {ref.numel()} elements beyond 3e-5 x range (largest {worst:.2e}); all "
           "within the one-blend-step bound")
     target = (ref[..., :9] / scale + 0.05 * torch.randn(ref[..., :9].shape, generator=g))
@@ -162,7 +162,7 @@ def test_800k_fp32_twin_of_config5_against_c_oracle(hip_device, capsys):
     vis_depth = meta["depths"][meta["radii"] > 0]
     nflip, worst = close_image_with_blend_flips(img, ref, r["alphas"], float(s["colors"].abs().max()),
                                                 float(vis_depth.max() - vis_depth.min()), 3e-5 * scale,
-                                                "image (800k)", flip_frac=2e-4, n_colour_channels=9)
+                                                "image (800k)", flip_frac=2e-4, n_colour_channels=9, alphas_img=a)
     with capsys.disabled():
         print(f"\n[800k fp32] radii differing: {int(differ.sum())} of {rad.size}; image: {nflip} of {ref.numel()} "
               f"elements beyond 3e-5 x range (largest {worst:.2e}); visible {int((rad > 0).sum())}")
