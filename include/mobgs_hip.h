@@ -50,7 +50,7 @@ extern "C" {
 #define MOBGS_TILE 16
 #define MOBGS_MAX_CHANNELS 32
 
-/* Library identification.  Returns e.g. "mobgs_hip 0.1 gfx950". */
+/* Library identification.  Returns e.g. "mobgs_hip 0.2 gfx950". */
 /* Per-call policy of the binning / compositing entry points.  The library keeps NO mutable state: what used to be
  * process-wide setters travels with each call (host pointer, may be NULL = all defaults; a negative field = default).
  *   heavy_tile_len     scheduling: a tile whose list has at least this many entries is composited by a whole
@@ -78,7 +78,8 @@ extern "C" {
  *   bwd_mfma           backward compositor of the passes with <= 10 total channels (round 4): the per-splat gradient
  *                      sums on the matrix pipe (raster_bwd_mfma.hip: the pair weights alpha*T and v_sigma are transposed
  *                      through LDS and summed over the pixels by v_mfma_f32_16x16x4_f32 against [colour cotangents |
- *                      pixel moments]; no per-entry wave reduction).  0 = the quadrant kernel with per-lane accumulators;
+ *                      pixel moments]; no per-entry wave reduction).  0 = OFF (the quadrant kernel with per-lane accumulators) -- NOT "default": a
+ *                      zero-initialised struct selects the quadrant kernel on every grid, only a negative value defers to the library;
  *                      1 = one wave per tile, the four-wave team (one 8x8 quadrant per wave) for the schedule's heavy
  *                      tiles; 2 = the team for every tile.  Gradients agree to summation order (observed <= 2e-5 of
  *                      each tensor's maximum).  Default (-1): 1 on grids of <= 1024 tiles, else 0 (measured).
@@ -95,6 +96,12 @@ typedef struct MobgsTuning {
 } MobgsTuning;
 
 const char* mobgs_version(void);
+/* Integer that changes whenever a signature, a struct layout or the format of a scratch buffer handed between entry
+ * points changes (round 4 inserted `records` into mobgs_raster_bwd_reduce and changed the gradient-slot format without
+ * one: a stale host extension would have passed shifted pointers).  Bindings compare it with the MOBGS_ABI_VERSION
+ * they were built against and refuse to run on a mismatch (mobgs_amd/_lib.py, csrc/fastpath.cpp). */
+#define MOBGS_ABI_VERSION 5
+int mobgs_abi_version(void);
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* mobgs_last_error(void);
 
@@ -237,6 +244,34 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
                                       int64_t max_tile_len_hint, int64_t* stats_host_pinned, int64_t stats_seq,
                                       const float* pack_colors, int colors_per_camera, int pack_channels,
                                       float* pack_records, const MobgsTuning* tuning, void* stream);
+
+/* mobgs_project_and_bin_speculative with SINGLE-PASS lists (round 5).  The two-pass form ranks every kept intersection,
+ * scans the per-tile counts, and only then scatters the sort keys (scan -> bin -> tile_scan -> emit -> sort, with a
+ * second pass over the kept intersections in between).  Here the projection kernel also leaves one 48-byte "bin
+ * record" per visible splat inside `scratch`, the binning kernel reads that one row per intersection and writes each
+ * kept intersection's 64-bit key STRAIGHT into its tile's segment of a strided arena,
+ *     seg_keys [C * n_tiles][8][seg_stride] u64   (mobgs_fused_seg_keys_len(C * n_tiles, seg_stride) entries; the 8
+ *                                                  counter copies of the binning kernel each own a sub-segment),
+ * and the per-tile sort reads the segments and writes flatten_ids / isect_ids PACKED at tile_offsets -- every output
+ * is identical to the two-pass path's (same lists, same order, same keep_scan / cum_tiles / tile_order semantics).
+ * seg_stride: capacity of a tile's list, 1 .. mobgs_fused_max_seg_stride(); the caller sizes it from the longest list
+ * it expects (the previous frame's stats[2] plus slack).  A tile whose list is longer makes the call behave like an
+ * arena overflow: every list is written EMPTY, stats still hold the true counts (stats[2] > seg_stride tells), and
+ * the caller redoes the binning with the two-pass entry points.  Requires N > 0, capacity_box >= 4 C N + 2 and a
+ * 128-byte aligned scratch (each XCD ranks through its own copy of the per-tile counters, in its own cache lines).  Everything else as mobgs_project_and_bin_speculative (including the return value). */
+size_t mobgs_fused_seg_keys_len(int n_tiles, int seg_stride);
+int mobgs_fused_max_seg_stride(void);
+int mobgs_project_and_bin_fused(int C, int N, const float* means, const float* quats, const float* scales,
+                                const float* viewmats, const float* Ks, const float* opacities, int opac_per_camera,
+                                int width, int height, float eps2d, float near_plane, float far_plane,
+                                float radius_clip, int cull, int32_t* radii, float* means2d, float* depths,
+                                float* conics, int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* tile_offsets,
+                                int32_t* tile_order, int64_t* stats_dev, int capacity_box, int32_t* keep_scan,
+                                void* scratch, int64_t capacity_listed, int32_t* flatten_ids, uint64_t* seg_keys,
+                                int seg_stride, uint64_t* isect_ids, int64_t max_tile_len_hint,
+                                int64_t* stats_host_pinned, int64_t stats_seq, const float* pack_colors,
+                                int colors_per_camera, int pack_channels, float* pack_records,
+                                const MobgsTuning* tuning, void* stream);
 
 /* ---- K6: rasterise forward (replaces gsplat rasterize_to_pixels fwd) -----------------------------------
  * colors   : [C,N,channels] (colors_per_camera=1) or [N,channels] (0); NULL: `records` are already packed (by

@@ -36,8 +36,10 @@ class MobgsTuning(ctypes.Structure):
         return ctypes.addressof(self)
 
 P = c_void_p
+ABI_VERSION = 5  # include/mobgs_hip.h MOBGS_ABI_VERSION
 _SIGS = {
     "mobgs_version": (c_char_p, []),
+    "mobgs_abi_version": (c_int, []),
     "mobgs_last_error": (c_char_p, []),
     "mobgs_record_stride": (c_int, [c_int]),
     "mobgs_raster_channels_supported": (c_int, [c_int]),
@@ -65,6 +67,11 @@ _SIGS = {
                                                   c_float, c_float, c_float, c_int, P, P, P, P, P, P, P, P, P, c_int,
                                                   P, P, c_int64, P, P, P, c_int64, P, c_int64, P, c_int, c_int, P, P,
                                                   P]),
+    "mobgs_fused_seg_keys_len": (c_size_t, [c_int, c_int]),
+    "mobgs_fused_max_seg_stride": (c_int, []),
+    "mobgs_project_and_bin_fused": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
+                                            c_float, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, c_int,
+                                            P, c_int64, P, c_int64, P, c_int, c_int, P, P, P]),
     "mobgs_densify_stats": (c_int, [c_int, P, c_int, P, P, P, P, P, P]),
     "mobgs_densify_select": (c_int, [c_int, c_int, P, P, P, c_float, c_float, P, P, P]),
     "mobgs_mask_indices": (c_int, [c_int, P, c_int, P, P, P]),
@@ -143,6 +150,12 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     if not LIB_PATH.exists():
         raise RuntimeError(f"{LIB_PATH} not found; run `python -m mobgs_amd.build`")
     lib = ctypes.CDLL(str(LIB_PATH))
+    # include/mobgs_hip.h MOBGS_ABI_VERSION these bindings were written against: a stale or foreign build of the
+    # library (MOBGS_LIB) with other signatures / scratch formats must not be driven with shifted arguments
+    got = lib.mobgs_abi_version() if hasattr(lib, "mobgs_abi_version") else 0
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH}: mobgs_abi_version() = {got}, these bindings need {ABI_VERSION} "
+                           "(rebuild with `python -m mobgs_amd.build`)")
     for name, (restype, argtypes) in {**_SIGS, **_OPTIONAL_SIGS}.items():
         if name in _SIGS or hasattr(lib, name):
             _bind(lib, name, restype, argtypes)

@@ -92,28 +92,39 @@ __device__ inline int keep_index(const int32_t* __restrict__ keep_scan, int j) {
 // ---- reach tests (bit-exact culling of work the compositor would skip anyway) --------------------------------
 // Smallest sigma = 0.5 (a dx^2 + c dy^2) + b dx dy a splat can take over a pixel-centre rectangle
 // (convex quadratic: 0 if the centre is inside, else attained on one of the four edges).
-__device__ inline float min_sigma_over_tile(float mx, float my, float ca, float cb, float cc, float x0, float x1,
-                                            float y0, float y1) {
-    if (mx >= x0 && mx <= x1 && my >= y0 && my <= y1) return 0.f;
-    float best = 3.0e38f;
-    const float ex[2] = {x0, x1}, ey[2] = {y0, y1};
-    const float sx = cb / cc, sy = cb / ca;  // two divisions for the four edges (as quadrant_reach_mask below)
+// sx = cb / cc and sy = cb / ca are constants of the splat: the fused binning path (isect.hip, bin_kernel<.., true>)
+// reads them (and the halved conic diagonal) from the per-splat bin record the projection kernel wrote, the classic path
+// computes them per intersection -- the same arithmetic either way, so both paths take the same decisions.
+// ha = a / 2, hc = c / 2.  Every operation is written out (v_med3 clamps, explicit FMAs): this runs once per bounding-box
+// intersection, 3.3 M times per frame on the benchmark, and bin_kernel is bound by its instruction count.
+__device__ __forceinline__ float half_sigma_at(float ha, float cb, float hc, float dx, float dy) {
+    // a dx^2 / 2 + b dx dy + c dy^2 / 2 = dx (ha dx + b dy) + (hc dy) dy
+    return __fmaf_rn(hc * dy, dy, dx * __fmaf_rn(cb, dy, ha * dx));
+}
+__device__ inline float min_sigma_over_tile_pre(float mx, float my, float ha, float cb, float hc, float sx, float sy,
+                                                float x0, float x1, float y0, float y1) {
+    const bool inside = mx >= x0 && mx <= x1 && my >= y0 && my <= y1;
+    float s[4];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        {  // vertical edge px = ex[k]: optimum dy = -cb dx / cc
-            const float dx = mx - ex[k];
-            const float py = fminf(fmaxf(my + sx * dx, y0), y1);
-            const float dy = my - py;
-            best = fminf(best, 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy);
+        {  // vertical edge px = x0 / x1: optimum dy = -cb dx / cc, clamped to the edge
+            const float dx = mx - (k ? x1 : x0);
+            const float dy = my - __builtin_amdgcn_fmed3f(__fmaf_rn(sx, dx, my), y0, y1);
+            s[2 * k] = half_sigma_at(ha, cb, hc, dx, dy);
         }
-        {  // horizontal edge py = ey[k]
-            const float dy = my - ey[k];
-            const float px = fminf(fmaxf(mx + sy * dy, x0), x1);
-            const float dx = mx - px;
-            best = fminf(best, 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy);
+        {  // horizontal edge py = y0 / y1
+            const float dy = my - (k ? y1 : y0);
+            const float dx = mx - __builtin_amdgcn_fmed3f(__fmaf_rn(sy, dy, mx), x0, x1);
+            s[2 * k + 1] = half_sigma_at(ha, cb, hc, dx, dy);
         }
     }
-    return best;
+    const float best = fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
+    return inside ? 0.f : best;
+}
+__device__ inline float min_sigma_over_tile(float mx, float my, float ca, float cb, float cc, float x0, float x1,
+                                            float y0, float y1) {
+    // two divisions for the four edges (as quadrant_reach_mask below)
+    return min_sigma_over_tile_pre(mx, my, 0.5f * ca, cb, 0.5f * cc, cb / cc, cb / ca, x0, x1, y0, y1);
 }
 // alpha = min(0.999, op * exp(-sigma)) >= 1/255  <=>  sigma <= ln(255 op).  The returned threshold carries a
 // conservative margin (the compositor evaluates sigma at pixel centres in a different fp32 operation order);
@@ -121,7 +132,35 @@ __device__ inline float min_sigma_over_tile(float mx, float my, float ca, float 
 __device__ inline float reach_threshold(float op) {
     if (!(op * 255.f >= 1.f)) return -1.f;
     const float tau = __logf(255.f * op);
-    return tau + 0.05f + 0.02f * tau;
+    // (operation order pinned: the projection kernel -- built without FMA contraction -- evaluates this for the bin
+    // records of the fused path and must agree bit for bit with the binning / compositing translation units)
+    return __fmaf_rn(0.02f, tau, __fadd_rn(tau, 0.05f));
+}
+
+// ---- per-splat bin record (fused binning path) -----------------------------------------------------------------
+// Everything bin_kernel needs to know about a visible splat, in ONE 48-byte row written by the projection kernel while
+// the values are in registers (instead of five gathers from means2d / radii / conics / opacities / depths and two
+// divisions + a logarithm per bounding-box intersection):
+//   q0 = {mean2d.x, mean2d.y, reach threshold, depth bits}    threshold: -1 = the splat never reaches alpha >= 1/255,
+//                                                             3e38 = list it in every tile of its box (culling off,
+//                                                             or a degenerate conic)
+//   q1 = {conic a / 2, b, c / 2, first tile of the box: x0 | y0 << 16}
+//   q2 = {b / c, b / a, box width in tiles | camera << 16, unused}
+constexpr int BIN_RECORD_FLOATS = 12;
+constexpr float REACH_ALWAYS = 3.0e38f;
+__device__ inline void write_bin_record(float* __restrict__ r, float mx, float my, float ca, float cb, float cc,
+                                        float depth, float op, int cull, const TileRect& tr, int cam) {
+    float thr = REACH_ALWAYS;
+    if (cull) {
+        if (!(op * 255.f >= 1.f))
+            thr = -1.f;
+        else if (ca > 0.f && cc > 0.f)
+            thr = reach_threshold(op);
+    }
+    float4* o = reinterpret_cast<float4*>(r);
+    o[0] = make_float4(mx, my, thr, depth);
+    o[1] = make_float4(0.5f * ca, cb, 0.5f * cc, __uint_as_float((unsigned)tr.x0 | ((unsigned)tr.y0 << 16)));
+    o[2] = make_float4(cb / cc, cb / ca, __uint_as_float((unsigned)(tr.x1 - tr.x0) | ((unsigned)cam << 16)), 0.f);
 }
 // bit k set <=> the splat can reach alpha >= 1/255 somewhere in rows [4k, 4k+3] of the 16x16 tile (tx, ty)
 __device__ inline int band_mask(float mx, float my, float ca, float cb, float cc, float op, int tx, int ty, int width,
@@ -195,6 +234,13 @@ struct PackArgs {
     int opac_per_camera, colors_per_camera, channels, stride;
 };
 
+// optional side job of project_fwd: the per-splat bin records of the fused binning path (records == NULL: off)
+struct BinArgs {
+    float* records;           // [C*N, BIN_RECORD_FLOATS]
+    const float* opacities;   // [N] or [C,N]
+    int opac_per_camera, cull;
+};
+
 // ---- launchers shared between translation units (the orchestrator in pipeline.hip fuses small steps) ---------
 // project_fwd with the option to clear `zero_n` ints at `zero_ptr` on the way (the binning scratch counters) and to
 // pack the compositor's records
@@ -202,7 +248,7 @@ int project_fwd_launch(int C, int N, const float* means, const float* quats, con
                        const float* Ks, int width, int height, float eps2d, float near_plane, float far_plane,
                        float radius_clip, int32_t* radii, float* means2d, float* depths, float* conics,
                        int32_t* tiles_per_gauss, int32_t* zero_ptr, size_t zero_n, PackArgs pack, void* stream,
-                       int geometry_per_camera = 0);
+                       int geometry_per_camera = 0, BinArgs bin = BinArgs{nullptr, nullptr, 0, 0});
 // mobgs_isect_offsets; scratch_zeroed: the counters were cleared by the caller; stats_mirror: device-visible host
 // address that receives a copy of stats[0..2] (or NULL) and then, in word 3, stats_seq (when non-zero)
 int isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
@@ -237,6 +283,14 @@ inline int tuning_bwd_mfma(const MobgsTuning* t, int n_tiles) {
 }
 inline int tuning_geometry_per_camera(const MobgsTuning* t) { return (t && t->geometry_per_camera == 1) ? 1 : 0; }
 void isect_zeroed_region(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity, int32_t** ptr, size_t* count);
+// fused single-pass lists (isect.hip): where the projection kernel leaves the bin records inside the binning scratch,
+// and the launcher of scan -> bin (keys into strided segments) -> offsets / schedule -> per-tile sort
+float* isect_bin_records(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity);
+int isect_fused_launch(int C, int N, int tile_w, int tile_h, int width, int height, int capacity,
+                       const int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* keep_scan, int32_t* tile_offsets,
+                       int32_t* tile_order, int64_t capacity_listed, int64_t* stats, void* scratch, int64_t* stats_mirror,
+                       int64_t stats_seq, uint64_t* seg_keys, int seg_stride, int32_t* flatten_ids, uint64_t* isect_ids,
+                       int64_t max_tile_len_hint, const MobgsTuning* tuning, void* stream);
 
 // bit q = 2 * qy + qx set <=> the splat may reach alpha >= 1/255 at a pixel centre of the 8x8 quadrant (qx, qy) of
 // the 16x16 tile (tx, ty).  Same conservative test as min_sigma_over_tile / reach_threshold, on the four quadrant

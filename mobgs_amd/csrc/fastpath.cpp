@@ -42,6 +42,8 @@ struct Api {
     decltype(&mobgs_project_bwd_ex) project_bwd_ex = nullptr;
     decltype(&mobgs_project_bwd_scratch_floats) project_bwd_scratch_floats = nullptr;
     decltype(&mobgs_project_and_bin_speculative) project_and_bin_speculative = nullptr;
+    decltype(&mobgs_project_and_bin_fused) project_and_bin_fused = nullptr;
+    decltype(&mobgs_fused_seg_keys_len) fused_seg_keys_len = nullptr;
     decltype(&mobgs_tile_order_len) tile_order_len = nullptr;
     decltype(&mobgs_keep_scan_len) keep_scan_len = nullptr;
     decltype(&mobgs_isect_scratch_bytes) isect_scratch_bytes = nullptr;
@@ -57,6 +59,12 @@ void take(const std::unordered_map<std::string, uint64_t>& m, const char* name, 
 }
 
 void bind(const std::unordered_map<std::string, uint64_t>& m) {
+    // the header this file was compiled against must be the library's (a stale extension passed shifted pointers)
+    decltype(&mobgs_abi_version) abi = nullptr;
+    take(m, "mobgs_abi_version", abi);
+    if (abi() != MOBGS_ABI_VERSION)
+        throw std::runtime_error("mobgs fastpath: built against ABI " + std::to_string(MOBGS_ABI_VERSION) +
+                                 ", the library reports " + std::to_string(abi()) + " -- rebuild _mobgs_fast.so");
     take(m, "mobgs_last_error", api.last_error);
     take(m, "mobgs_record_stride", api.record_stride);
     take(m, "mobgs_prep_fwd_many", api.prep_fwd);
@@ -73,6 +81,8 @@ void bind(const std::unordered_map<std::string, uint64_t>& m) {
     take(m, "mobgs_project_bwd_ex", api.project_bwd_ex);
     take(m, "mobgs_project_bwd_scratch_floats", api.project_bwd_scratch_floats);
     take(m, "mobgs_project_and_bin_speculative", api.project_and_bin_speculative);
+    take(m, "mobgs_project_and_bin_fused", api.project_and_bin_fused);
+    take(m, "mobgs_fused_seg_keys_len", api.fused_seg_keys_len);
     take(m, "mobgs_tile_order_len", api.tile_order_len);
     take(m, "mobgs_keep_scan_len", api.keep_scan_len);
     take(m, "mobgs_isect_scratch_bytes", api.isect_scratch_bytes);
@@ -350,7 +360,7 @@ project_and_bin_speculative(const Tensor& means, const Tensor& quats, const Tens
                             double near_plane, double far_plane, double radius_clip, int64_t cull,
                             bool want_isect_ids, bool tile_schedule, const OptT& pack_colors, int64_t cap_box,
                             int64_t cap_listed, int64_t len_hint, int64_t stats_row, int64_t seq, int64_t tuning,
-                            int64_t stream) {
+                            int64_t stream, int64_t seg_stride) {
     const int64_t C = viewmats.size(0), N = means.size(-2);  // means [N,3] or, with geometry_per_camera, [C,N,3]
     const int64_t tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, nt = C * tile_w * tile_h;
     const auto f = means.options().dtype(at::kFloat);
@@ -371,20 +381,36 @@ project_and_bin_speculative(const Tensor& means, const Tensor& quats, const Tens
     Tensor keep_scan = at::empty({(int64_t)api.keep_scan_len((int)cap_box)}, i32);
     Tensor scratch = at::empty({(int64_t)api.isect_scratch_bytes((int)(C * N), (int)nt, (int)cap_box)},
                                f.dtype(at::kByte));
-    Tensor flatten_ids = at::empty({cap_listed}, i32), sort_keys = at::empty({cap_listed}, i64);
+    // seg_stride > 0: single-pass lists (mobgs_project_and_bin_fused) -- the key arena is [tile][8][seg_stride]
+    Tensor flatten_ids = at::empty({cap_listed}, i32),
+           sort_keys = at::empty({seg_stride > 0 ? (int64_t)api.fused_seg_keys_len((int)nt, (int)seg_stride) : cap_listed}, i64);
     OptT isect_ids = want_isect_ids ? OptT(at::empty({cap_listed}, i64)) : OptT();
     const bool pack = records.has_value();
-    const int rc = api.project_and_bin_speculative(
-        (int)C, (int)N, fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), fp(opac), opac.dim() == 2 ? 1 : 0,
-        (int)width, (int)height, (float)eps2d, (float)near_plane, (float)far_plane, (float)radius_clip, (int)cull,
-        static_cast<int32_t*>(dp(radii)), fpw(means2d), fpw(depths), fpw(conics),
-        static_cast<int32_t*>(dp(tiles_per_gauss)), static_cast<int32_t*>(dp(cum_tiles)),
-        static_cast<int32_t*>(dp(tile_offsets)), static_cast<int32_t*>(dp(tile_order)),
-        static_cast<int64_t*>(dp(stats_dev)), (int)cap_box, static_cast<int32_t*>(dp(keep_scan)), dp(scratch),
-        cap_listed, static_cast<int32_t*>(dp(flatten_ids)), static_cast<uint64_t*>(dp(sort_keys)),
-        static_cast<uint64_t*>(dp(isect_ids)), len_hint,
-        reinterpret_cast<int64_t*>(static_cast<uintptr_t>(stats_row)), seq, pack ? fp(*pack_colors) : nullptr,
-        (pack && pack_colors->dim() == 3) ? 1 : 0, pack ? (int)pack_ch : 0, fpw(records), tp(tuning), sp(stream));
+    int rc;
+    if (seg_stride > 0)
+        rc = api.project_and_bin_fused(
+            (int)C, (int)N, fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), fp(opac), opac.dim() == 2 ? 1 : 0,
+            (int)width, (int)height, (float)eps2d, (float)near_plane, (float)far_plane, (float)radius_clip, (int)cull,
+            static_cast<int32_t*>(dp(radii)), fpw(means2d), fpw(depths), fpw(conics),
+            static_cast<int32_t*>(dp(tiles_per_gauss)), static_cast<int32_t*>(dp(cum_tiles)),
+            static_cast<int32_t*>(dp(tile_offsets)), static_cast<int32_t*>(dp(tile_order)),
+            static_cast<int64_t*>(dp(stats_dev)), (int)cap_box, static_cast<int32_t*>(dp(keep_scan)), dp(scratch),
+            cap_listed, static_cast<int32_t*>(dp(flatten_ids)), static_cast<uint64_t*>(dp(sort_keys)), (int)seg_stride,
+            static_cast<uint64_t*>(dp(isect_ids)), len_hint,
+            reinterpret_cast<int64_t*>(static_cast<uintptr_t>(stats_row)), seq, pack ? fp(*pack_colors) : nullptr,
+            (pack && pack_colors->dim() == 3) ? 1 : 0, pack ? (int)pack_ch : 0, fpw(records), tp(tuning), sp(stream));
+    else
+        rc = api.project_and_bin_speculative(
+            (int)C, (int)N, fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), fp(opac), opac.dim() == 2 ? 1 : 0,
+            (int)width, (int)height, (float)eps2d, (float)near_plane, (float)far_plane, (float)radius_clip, (int)cull,
+            static_cast<int32_t*>(dp(radii)), fpw(means2d), fpw(depths), fpw(conics),
+            static_cast<int32_t*>(dp(tiles_per_gauss)), static_cast<int32_t*>(dp(cum_tiles)),
+            static_cast<int32_t*>(dp(tile_offsets)), static_cast<int32_t*>(dp(tile_order)),
+            static_cast<int64_t*>(dp(stats_dev)), (int)cap_box, static_cast<int32_t*>(dp(keep_scan)), dp(scratch),
+            cap_listed, static_cast<int32_t*>(dp(flatten_ids)), static_cast<uint64_t*>(dp(sort_keys)),
+            static_cast<uint64_t*>(dp(isect_ids)), len_hint,
+            reinterpret_cast<int64_t*>(static_cast<uintptr_t>(stats_row)), seq, pack ? fp(*pack_colors) : nullptr,
+            (pack && pack_colors->dim() == 3) ? 1 : 0, pack ? (int)pack_ch : 0, fpw(records), tp(tuning), sp(stream));
     if (rc != 0 && rc != 1) check(rc, "mobgs_project_and_bin_speculative");
     return {rc, {radii, means2d, depths, conics, tiles_per_gauss, cum_tiles, tile_offsets, keep_scan, flatten_ids},
             tile_order, isect_ids, records};

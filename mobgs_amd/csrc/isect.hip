@@ -201,6 +201,13 @@ constexpr int TC_STRIDE = 1;
 // shorter; tile_scan_kernel sums the copies into the list lengths and leaves every (copy, tile) pair's first
 // position in tile_base, which is what emit_kernel adds the rank to.  Ranks only have to be distinct inside a list.
 constexpr int TC_COPIES = 8;
+// s_getreg_b32 operand of HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this wave runs on, 0..7 (MI355X_MICROARCH.md)
+constexpr int GETREG_XCC_ID = 20 | (0 << 6) | ((4 - 1) << 11);
+// rank atomics of the fused path: relaxed, WORKGROUP scope = no sc1 bit = performed in the XCD's own L2 (see bin_kernel)
+__device__ __forceinline__ int rank_add(int32_t* p, int v, bool xcd_local) {
+    return xcd_local ? __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                     : __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 constexpr int OWNER_LDS = 4096;  // cum_tiles entries of the chunk's owner range cached in LDS
 static_assert(SCAN_BLOCK == KEEP_CHUNK, "one workgroup per keep_scan chunk");
 
@@ -217,25 +224,54 @@ static_assert(SCAN_BLOCK == KEEP_CHUNK, "one workgroup per keep_scan chunk");
 // its kept intersections per tile in LDS (one int per tile, dynamic shared memory), then ONE thread per touched tile
 // reserves the workgroup's range with a single global atomic: up to 20x fewer same-address atomics there, and still
 // ahead on uniform scenes (fewer returning global atomics per chunk).
-template <bool DENSE>
+//
+// FUSED variant (round 5; single-pass lists): the splat's position, conic, reach threshold, box origin / width and
+// depth bits come from ONE 48-byte bin record the projection kernel left behind (common.h, write_bin_record) instead
+// of five gathers, two divisions and a logarithm per intersection, and the kept intersection's 64-bit sort key goes
+// STRAIGHT into the tile's segment of a strided key arena -- [tile][counter copy][seg_stride] keys -- at the rank the
+// atomic returned: no (owner, tile, rank) triples, no per-(copy, tile) base table, no emit pass.  A rank beyond
+// seg_stride is dropped; tile_finish_kernel sees the counter and hands every consumer empty lists (the caller then
+// falls back to the two-pass path with the true counts).
+template <bool DENSE, bool FUSED>
 __global__ void __launch_bounds__(SCAN_THREADS)
 bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,
            const int32_t* __restrict__ cum, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
            const float* __restrict__ conics, const float* __restrict__ opacities, int opac_per_camera,
            int32_t* __restrict__ chunk_cnt, int32_t* __restrict__ owner, int32_t* __restrict__ tile_of_j,
            int32_t* __restrict__ rank_of_j, int32_t* __restrict__ tile_count, int32_t* __restrict__ keep_scan,
-           int n_tiles_total, const int32_t* __restrict__ chunk_owner) {
+           int n_tiles_total, const int32_t* __restrict__ chunk_owner, const float* __restrict__ binrec,
+           uint64_t* __restrict__ seg_keys, int seg_stride, int count_stride) {
     __shared__ int s_cum[OWNER_LDS + 1];
     extern __shared__ int s_tile[];  // DENSE: per-tile count of this workgroup, then the base of its range
     const int chunk = blockIdx.x;
+#ifdef ABL_TIMING
+    // debug build: phase time stamps (100 MHz counter) of every workgroup, parked in the unused tail of keep_scan
+    int64_t* tdbg = reinterpret_cast<int64_t*>(keep_scan + (size_t)(1800 + chunk / 100) * (KEEP_CHUNK + 1) + 8) + (chunk % 100) * 8;
+#define TSTAMP(i) do { if (threadIdx.x == 0) tdbg[i] = (int64_t)wall_clock64(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+    TSTAMP(0);
     int32_t* kchunk = keep_scan + (size_t)chunk * (KEEP_CHUNK + 1);
-    tile_count += (size_t)(chunk & (TC_COPIES - 1)) * n_tiles_total;  // this workgroup's copy of the counters
+    // This workgroup's copy of the counters.  Two-pass path: chunk mod 8, device-scope atomics (emit_kernel recomputes
+    // the copy from the chunk).  Fused path: the copy of the XCD the workgroup RUNS on (HW_REG_XCC_ID, whatever the
+    // dispatcher's placement), each copy in its own 128-byte lines -- a counter is then only ever touched through ONE
+    // XCD's L2, so the atomics need no device scope: they are performed in that L2 instead of at the memory side of the
+    // chip (sc1 atomics bypass the non-coherent L2s: ~120 ns each, one after the other per address, and a round trip
+    // several times longer).  The kernel boundary writes the L2 back before tile_finish_kernel reads the counts.
+    int copy = chunk & (TC_COPIES - 1);
+    if (FUSED) {
+        copy = (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & (TC_COPIES - 1));
+        tile_count += (size_t)copy * count_stride;
+    } else {
+        tile_count += (size_t)copy * n_tiles_total;
+    }
     const int I = min(cum[n_gauss], capacity);
     const int start = chunk * SCAN_BLOCK;
     if (start >= I) {
         if (threadIdx.x == 0) {
             kchunk[0] = 0;                   // empty chunk
-            chunk_cnt[chunk] = 0;
+            if (!FUSED) chunk_cnt[chunk] = 0;
             if (start == I) kchunk[1] = 0;  // local of position I (one past the last intersection)
         }
         return;
@@ -252,17 +288,44 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
         for (int t = threadIdx.x; t <= span; t += SCAN_THREADS) s_cum[t] = cum[g_lo + t];
         __syncthreads();
     }
+    TSTAMP(1);
     const int tiles_per_cam = tile_w * tile_h;
     // item k of thread t is intersection start + k * SCAN_THREADS + t: neighbouring lanes work on neighbouring
     // intersections (coalesced stores, shared owner data)
     __shared__ int s_cnt[SCAN_ITEMS][SCAN_THREADS / 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int keep[SCAN_ITEMS], own[SCAN_ITEMS], til[SCAN_ITEMS], before[SCAN_ITEMS];
+    uint32_t dbits[SCAN_ITEMS];  // FUSED: depth bits of the item's splat (high half of its sort key)
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const int j = start + k * SCAN_THREADS + threadIdx.x;
         int kp = 0, g = 0, t = 0;
-        if (j < end) {
+        dbits[k] = 0u;
+        if (FUSED && j < end) {
+            g = cached ? g_lo + owner_in(s_cum, 0, span, j) : owner_in(cum, g_lo, g_hi + 1, j);
+            const float4* rec = reinterpret_cast<const float4*>(binrec + (size_t)g * BIN_RECORD_FLOATS);
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            const int q = j - (cached ? s_cum[g - g_lo] : cum[g]);
+            const unsigned wc = __float_as_uint(r2.z);
+            const int w = (int)(wc & 0xFFFFu);
+            const unsigned xy0 = __float_as_uint(r1.w);
+            // q / w as below (exact for q < 2^21)
+            const int row = (int)(((float)q + 0.5f) * __builtin_amdgcn_rcpf((float)w));
+            const int ty = (int)(xy0 >> 16) + row, tx = (int)(xy0 & 0xFFFFu) + (q - row * w);
+            t = (int)(wc >> 16) * tile_w * tile_h + ty * tile_w + tx;
+            const float x0 = (float)(tx * MOBGS_TILE) + 0.5f, y0 = (float)(ty * MOBGS_TILE) + 0.5f;
+            const float x1 = fminf((float)(tx * MOBGS_TILE) + 15.5f, (float)width - 0.5f);
+            const float y1 = fminf((float)(ty * MOBGS_TILE) + 15.5f, (float)height - 0.5f);
+#ifdef ABL_NOTEST
+            kp = (r0.z >= 0.f && ((q ^ g) & 1)) ? 1 : 0;
+#else
+            // threshold -1: never listed (min sigma >= 0); REACH_ALWAYS: listed whatever the arithmetic below yields
+            kp = (r0.z >= REACH_ALWAYS ||
+                  min_sigma_over_tile_pre(r0.x, r0.y, r1.x, r1.y, r1.z, r2.x, r2.y, x0, x1, y0, y1) <= r0.z) ? 1 : 0;
+#endif
+            dbits[k] = __float_as_uint(r0.w);
+        }
+        if (!FUSED && j < end) {
             g = cached ? g_lo + owner_in(s_cum, 0, span, j) : owner_in(cum, g_lo, g_hi + 1, j);
             const float2 m = reinterpret_cast<const float2*>(means2d)[g];
             const TileRect tr = tile_rect(m.x, m.y, radii[g], tile_w, tile_h);
@@ -296,8 +359,20 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
         if (lane == 0) s_cnt[k][wv] = __builtin_popcountll(ballot);
     }
     // ranks inside the tiles' lists: all returning atomics in flight before the first result is consumed
+#ifdef ABL_TIMING
+    __syncthreads();
+#endif
+    TSTAMP(2);
     int rank[SCAN_ITEMS];
+#ifdef ABL_NOATOMIC
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = (threadIdx.x + k) & 31;
+    if (false) {
+#elif defined(ABL_NODENSE)
+    if (false) {
+#else
     if (DENSE) {
+#endif
         for (int t = threadIdx.x; t < n_tiles_total; t += SCAN_THREADS) s_tile[t] = 0;
         __syncthreads();
 #pragma unroll
@@ -306,7 +381,7 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
         int base_of[SCAN_ITEMS];
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; ++k)  // the intersection that got local rank 0 speaks for its tile
-            base_of[k] = (keep[k] && rank[k] == 0) ? atomicAdd(&tile_count[til[k] * TC_STRIDE], s_tile[til[k]]) : 0;
+            base_of[k] = (keep[k] && rank[k] == 0) ? rank_add(&tile_count[til[k] * TC_STRIDE], s_tile[til[k]], FUSED) : 0;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; ++k)
@@ -316,10 +391,21 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
         for (int k = 0; k < SCAN_ITEMS; ++k)
             if (keep[k]) rank[k] += s_tile[til[k]];
     } else {
+#ifndef ABL_NOATOMIC
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = keep[k] ? atomicAdd(&tile_count[til[k] * TC_STRIDE], 1) : 0;
+        for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = keep[k] ? rank_add(&tile_count[til[k] * TC_STRIDE], 1, FUSED) : 0;
+#endif
     }
+#ifdef ABL_TIMING
+    {
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) acc += rank[k];
+        asm volatile("" ::"v"(acc));  // the ranks have arrived
+    }
+#endif
     __syncthreads();
+    TSTAMP(3);
     // exclusive prefix of every (item row, wave) segment in intersection order, and the chunk total
     int seg[SCAN_ITEMS];
     int total = 0;
@@ -337,15 +423,29 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
         if (start + i < end) {
             const int local = seg[k] + before[k];
             kchunk[1 + i] = local;
-            if (keep[k]) {  // compacted: the chunk's kept intersections in order, at the start of its own range
+            if (FUSED) {
+#ifdef ABL_NOSTORE
+                if (keep[k] && rank[k] < -seg_stride)
+#else
+                if (keep[k] && rank[k] < seg_stride)
+#endif
+                    seg_keys[((size_t)til[k] * TC_COPIES + copy) * (size_t)seg_stride + rank[k]] =
+                        ((uint64_t)dbits[k] << 32) | (uint32_t)own[k];
+            } else if (keep[k]) {  // compacted: the chunk's kept intersections in order, at the start of its own range
                 owner[start + local] = own[k];
                 tile_of_j[start + local] = til[k];
                 rank_of_j[start + local] = rank[k];
             }
         }
     }
+#ifdef ABL_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    TSTAMP(4);
+    if (threadIdx.x == 0) tdbg[5] = (int64_t)__builtin_amdgcn_s_getreg(GETREG_XCC_ID);
+#endif
     if (threadIdx.x == 0) {
-        chunk_cnt[chunk] = total;
+        if (!FUSED) chunk_cnt[chunk] = total;
         kchunk[0] = total;
         if (end == I && end - start < SCAN_BLOCK) kchunk[1 + (end - start)] = total;  // local of position I
     }
@@ -780,6 +880,32 @@ __device__ inline int radix_sort_long(const uint64_t* __restrict__ seg, int n, R
 // through the cross-lane network.  No LDS, no barriers, and four tiles per 256-thread workgroup instead of four waves
 // that mostly wait at the barriers of one tile -- 53 -> ~25 us for the 5440 lists (~311 entries) of the benchmark.
 // ---------------------------------------------------------------------------------------------------
+// v of lane ^ d for d = 1 .. 32 WITHOUT the LDS crossbar (round 5): the network is a chain of ~21 dependent cross-lane
+// steps per list and ds_bpermute answers after ~100+ cycles; DPP moves (d <= 8, inside a 16-lane row) and the gfx950
+// permlane swaps (d = 16, 32) are VALU instructions with a few cycles of latency.
+//   d = 1, 2: quad_perm;  d = 4: row_half_mirror (l -> 7 - l) then the quad reversed;  d = 8: row_ror:8;
+//   d = 16 / 32: v_permlane16_swap / v_permlane32_swap of the register with itself leave the partner row / half in one of
+//   the two results, picked by the lane's own bit.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t v, int d, int lane) {
+    if (d == 1) return dpp_mov<0xB1>(v);
+    if (d == 2) return dpp_mov<0x4E>(v);
+    if (d == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));
+    if (d == 8) return dpp_mov<0x128>(v);
+    if (d == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (lane & 32) ? r[0] : r[1];
+}
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v, int d, int lane) {
+    return ((uint64_t)lane_xor32((uint32_t)(v >> 32), d, lane) << 32) | lane_xor32((uint32_t)v, d, lane);
+}
+
 template <int EPL>
 __device__ __forceinline__ void wave_bitonic_sort(uint64_t (&key)[EPL], int lane) {
     constexpr int N2 = 64 * EPL;
@@ -794,7 +920,11 @@ __device__ __forceinline__ void wave_bitonic_sort(uint64_t (&key)[EPL], int lane
                 const bool want_min = lower == asc;
 #pragma unroll
                 for (int r = 0; r < EPL; ++r) {
+#ifdef ABL_SORT_BPERMUTE
                     const uint64_t other = __shfl_xor(key[r], d, 64);
+#else
+                    const uint64_t other = lane_xor64(key[r], d, lane);
+#endif
                     const bool other_less = other < key[r];
                     key[r] = (other_less == want_min) ? other : key[r];
                 }
@@ -1151,6 +1281,296 @@ __global__ void __launch_bounds__(256) huge_finish_kernel(int tile_bits, int til
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fused single-pass lists (round 5): offsets / schedule / counts behind bin_kernel<.., true>, and the sort that reads
+// the strided key segments
+// ---------------------------------------------------------------------------------------------------
+// Where the i-th key of a tile lives in its strided segment [copy][seg_stride]: the copies' fill counts are
+// wave-uniform, entry i of the concatenation sits (i - prefix_c) into copy c.
+// ---- offsets / schedule / counts of the fused path -----------------------------------------------------------------------
+// tile_scan_kernel without the per-(copy, tile) base table, and with every global load of a phase in flight before the
+// first barrier (tile_scan_kernel loops "8 loads -> block scan" six times for 5440 tiles: six dependent trips to
+// counters the atomics left at the memory side, 12.9 us; here the lengths go to LDS in one sweep: 9.7 us).
+//   workgroup 0: list lengths (sum of the counter copies) -> tile_offsets, longest list, the counts for the host;
+//                EMPTY lists when an arena or a key segment was too small (seg_stride)
+//   workgroup 1: chunk totals of keep_scan -> chunk bases; stats[1]
+//   workgroup 2: the tile schedule (as tile_scan_kernel)
+// (Tried and dropped, round 5: folding this launch into the sort launch.  (a) A decoupled look-back among the 1360 sort
+// workgroups: they all start at once, so prefixes propagate one 64-group window per round trip -- 37 us against 25 + 9.7;
+// (b) an auxiliary workgroup of the sort launch scanning the lengths while the others sort, positions handed over through
+// {valid, value} words: correct, but a 256-thread workgroup needs 32 dependent rounds of loads for 5440 x 8 counters and
+// the sort waves wait for it -- 40 - 55 us.)
+constexpr int FIN_LDS_TILES = 8192;  // lengths kept in LDS per sweep (32 KiB)
+__global__ void __launch_bounds__(TSCAN_THREADS) tile_finish_kernel(int nt, const int32_t* __restrict__ tile_count,
+                                                                      int cstride, int32_t* __restrict__ tile_offsets,
+                                                                      int64_t* __restrict__ stats,
+                                                                      int32_t* __restrict__ tile_order,
+                                                                      int64_t capacity_box, int64_t capacity_listed,
+                                                                      int seg_stride, int32_t* __restrict__ keep_scan,
+                                                                      int n_chunks, int heavy_len,
+                                                                      int64_t* stats_mirror, int64_t stats_seq) {
+    __shared__ int s_len[FIN_LDS_TILES];
+    __shared__ int smax[TSCAN_THREADS / 64];
+    __shared__ int hist[ORDER_BUCKETS];
+    if (blockIdx.x == 1) {
+        // chunk totals -> bases: all of a thread's words requested before the first scan
+        constexpr int PER = 4;
+        int base = 0;
+        for (int c0 = 0; c0 < n_chunks; c0 += TSCAN_THREADS * PER) {
+            int v[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int c = c0 + threadIdx.x * PER + k;
+                v[k] = (c < n_chunks) ? keep_scan[(size_t)c * (KEEP_CHUNK + 1)] : 0;
+            }
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) sum += v[k];
+            int total;
+            const int inc = block_incl_scan_w<TSCAN_THREADS / 64>(sum, &total);
+            int run = base + inc - sum;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int c = c0 + threadIdx.x * PER + k;
+                if (c < n_chunks) keep_scan[(size_t)c * (KEEP_CHUNK + 1)] = run;
+                run += v[k];
+            }
+            base += total;
+        }
+        if (threadIdx.x == 0) stats[1] = (int64_t)base;
+        return;
+    }
+    const bool order_wg = blockIdx.x == 2;
+    auto length_of = [&](int i) { return i < FIN_LDS_TILES ? s_len[i] : tile_total(tile_count, cstride, i); };
+    int carry = 0, mx = 0;
+    constexpr int TPT = FIN_LDS_TILES / TSCAN_THREADS;  // consecutive tiles per thread in the scan phase
+    for (int sweep = 0; sweep < nt; sweep += FIN_LDS_TILES) {
+        // phase 1: coalesced loads of the counter copies, every one of them independent
+        int v[TPT];
+#pragma unroll
+        for (int m = 0; m < TPT; ++m) {
+            const int i = sweep + m * TSCAN_THREADS + threadIdx.x;
+            int sum = 0;
+            if (i < nt) {
+#pragma unroll
+                for (int c = 0; c < TC_COPIES; ++c) sum += tile_count[(size_t)c * cstride + i];
+            }
+            v[m] = sum;
+        }
+        if (sweep > 0) __syncthreads();  // the previous sweep's readers are done with s_len
+#pragma unroll
+        for (int m = 0; m < TPT; ++m) {
+            s_len[m * TSCAN_THREADS + threadIdx.x] = v[m];
+            mx = max(mx, v[m]);
+        }
+        __syncthreads();
+        if (order_wg) {
+            if (nt > FIN_LDS_TILES) continue;  // (only the maximum is needed from the later sweeps; lengths re-read)
+            break;
+        }
+        // phase 2: thread t scans tiles [TPT t, TPT t + TPT) of the sweep
+        int mine[TPT], sum = 0;
+#pragma unroll
+        for (int m = 0; m < TPT; ++m) {
+            mine[m] = s_len[threadIdx.x * TPT + m];
+            sum += mine[m];
+        }
+        int total;
+        const int inc = block_incl_scan_w<TSCAN_THREADS / 64>(sum, &total);
+        int run = carry + inc - sum;
+#pragma unroll
+        for (int m = 0; m < TPT; ++m) {
+            const int i = sweep + threadIdx.x * TPT + m;
+            if (i < nt) tile_offsets[i] = run;
+            run += mine[m];
+        }
+        carry += total;
+    }
+    if (order_wg && nt > FIN_LDS_TILES) {  // s_len must hold the FIRST sweep again for length_of()
+        __syncthreads();
+        for (int i = threadIdx.x; i < FIN_LDS_TILES; i += TSCAN_THREADS) s_len[i] = tile_total(tile_count, cstride, i);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    int longest = 0;
+#pragma unroll
+    for (int k = 0; k < TSCAN_THREADS / 64; ++k) longest = max(longest, smax[k]);
+    if (!order_wg) {
+        if (threadIdx.x == 0) {
+            tile_offsets[nt] = carry;
+            stats[2] = (int64_t)longest;
+            // the host's copy of {I_box, I_listed, longest list}: written straight into its pinned, device-mapped slot, the
+            // sequence number last (the host polls that word: no event, no marker packet in the queue)
+            if (stats_mirror) {
+                stats_mirror[0] = stats[0];
+                stats_mirror[1] = (int64_t)carry;
+                stats_mirror[2] = (int64_t)longest;
+                __threadfence_system();
+                if (stats_seq)
+                    __hip_atomic_store(&stats_mirror[3], stats_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        // an arena or a key segment too small: EMPTY lists for every consumer already enqueued; the counts stay true
+        if (stats[0] > capacity_box || (int64_t)carry > capacity_listed || longest > seg_stride) {
+            __syncthreads();
+            for (int i = threadIdx.x; i <= nt; i += TSCAN_THREADS) tile_offsets[i] = 0;
+        }
+        return;
+    }
+    if (!tile_order) return;
+    auto bucket = [&](int len) {
+        const int q = longest > 0 ? (int)(((int64_t)len * (ORDER_BUCKETS - 1)) / longest) : 0;
+        return ORDER_BUCKETS - 1 - q;  // bucket 0 = the longest lists
+    };
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt; i += TSCAN_THREADS) atomicAdd(&hist[bucket(length_of(i))], 1);
+    __syncthreads();
+    {
+        const int mine = hist[threadIdx.x];
+        int total;
+        const int inc = block_incl_scan_w<TSCAN_THREADS / 64>(mine, &total);
+        hist[threadIdx.x] = inc - mine;
+    }
+    __syncthreads();
+    // heavy set: as tile_scan_kernel (a function of the tiles' length classes only -> deterministic)
+    __shared__ int s_heavy, s_cut;
+    if (threadIdx.x == 0) s_cut = 0;
+    __syncthreads();
+    if (heavy_len > 0 && longest >= heavy_len) {
+        const int b_thr = bucket(heavy_len);
+        if ((int)threadIdx.x <= b_thr && hist[threadIdx.x] <= (int)sched_max_heavy((size_t)nt))
+            atomicMax(&s_cut, (int)threadIdx.x);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_heavy = hist[s_cut];
+    const int n_slots = (int)sched_slots((size_t)nt);
+    for (int i = threadIdx.x; i < n_slots; i += TSCAN_THREADS) tile_order[i] = -1;
+    __syncthreads();
+    const int n_heavy = s_heavy;
+    for (int i = threadIdx.x; i < nt; i += TSCAN_THREADS) {
+        const int pos = atomicAdd(&hist[bucket(length_of(i))], 1);
+        if (pos < n_heavy) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tile_order[4 * pos + q] = i | SCHED_HEAVY;
+        } else {
+            tile_order[3 * n_heavy + pos] = i;
+        }
+    }
+}
+
+// Where the i-th key of a tile lives in its strided segment [copy][seg_stride]: the copies' fill counts are
+// wave-uniform, entry i of the concatenation sits (i - prefix_c) into copy c.
+struct SegMap {
+    int gap[TC_COPIES];   // seg_stride - count of copy c: what an index gains when it steps over the end of copy c
+    int pre[TC_COPIES];   // entries in copies 0 .. c (inclusive prefix)
+    int n;
+    __device__ __forceinline__ void load(const int32_t* __restrict__ tile_count, int cstride, int t, int seg_stride) {
+        int run = 0;
+#pragma unroll
+        for (int c = 0; c < TC_COPIES; ++c) {
+            const int cnt = __builtin_amdgcn_readfirstlane(tile_count[(size_t)c * cstride + t]);
+            run += cnt;
+            pre[c] = run;
+            gap[c] = seg_stride - cnt;
+        }
+        n = run;
+    }
+    __device__ __forceinline__ int offset_of(int i) const {
+        int o = i;
+#pragma unroll
+        for (int c = 0; c + 1 < TC_COPIES; ++c) o += (i >= pre[c]) ? gap[c] : 0;
+        return o;
+    }
+};
+
+template <int EPL>
+__device__ __forceinline__ void sort_seg_in_wave(const uint64_t* __restrict__ seg, const SegMap& sm, int s,
+                                                 uint64_t hi_bits, int32_t* __restrict__ flatten_ids,
+                                                 uint64_t* __restrict__ isect_ids, int lane) {
+    uint64_t key[EPL];
+    const int n = sm.n;
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+        const int i = r * 64 + lane;
+        key[r] = i < n ? seg[sm.offset_of(i)] : ~0ull;
+    }
+    wave_bitonic_sort<EPL>(key, lane);
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+        const int i = lane * EPL + r;
+        if (i < n) {
+            flatten_ids[s + i] = (int32_t)(uint32_t)key[r];
+            if (isect_ids) isect_ids[s + i] = hi_bits | (key[r] >> 32);
+        }
+    }
+}
+
+// tile_sort_short_kernel over the strided segments: ONE launch sorts every list (the fused path is only taken while
+// the longest list expected fits SHORT_SORT_LDS_KEYS); output is PACKED at tile_offsets, exactly what the two-pass
+// path writes, so no consumer can tell the difference.
+template <int MAXEPL>
+__global__ void __launch_bounds__(256) tile_sort_seg_kernel(int n_tiles_total, int tile_bits,
+                                                              const int32_t* __restrict__ tile_offsets,
+                                                              const int32_t* __restrict__ tile_count, int cstride,
+                                                              const uint64_t* __restrict__ seg_keys, int seg_stride,
+                                                              int32_t* __restrict__ flatten_ids,
+                                                              uint64_t* __restrict__ isect_ids, int tiles_per_cam) {
+    __shared__ __attribute__((aligned(16))) uint64_t lds_keys[SHORT_SORT_LDS_KEYS];
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int s = 0, n = 0;
+    SegMap sm;
+    sm.n = 0;
+    if (t < n_tiles_total) {
+        sm.load(tile_count, cstride, t, seg_stride);
+        s = __builtin_amdgcn_readfirstlane(tile_offsets[t]);
+        // overflow (tile_finish_kernel emptied the lists): the packed range disagrees with the counters -> nothing to do
+        n = (__builtin_amdgcn_readfirstlane(tile_offsets[t + 1]) - s == sm.n) ? sm.n : 0;
+    }
+    constexpr int WAVE_MAX = 64 * MAXEPL;
+    if (n > 0 && n <= WAVE_MAX) {
+        const uint64_t* seg = seg_keys + (size_t)t * TC_COPIES * (size_t)seg_stride;
+        const int cam = t / tiles_per_cam, tl = t - cam * tiles_per_cam;
+        const uint64_t hi_bits = (((uint64_t)cam << tile_bits) | (uint64_t)tl) << 32;
+        if (n <= 128)
+            sort_seg_in_wave<2>(seg, sm, s, hi_bits, flatten_ids, isect_ids, lane);
+        else if (n <= 256)
+            sort_seg_in_wave<4>(seg, sm, s, hi_bits, flatten_ids, isect_ids, lane);
+        else if (MAXEPL == 8 || n <= 512)
+            sort_seg_in_wave<8>(seg, sm, s, hi_bits, flatten_ids, isect_ids, lane);
+        else if (MAXEPL == 16 || n <= 1024)
+            sort_seg_in_wave<16>(seg, sm, s, hi_bits, flatten_ids, isect_ids, lane);
+        else
+            sort_seg_in_wave<32>(seg, sm, s, hi_bits, flatten_ids, isect_ids, lane);
+    }
+    if (!__syncthreads_or(n > WAVE_MAX)) return;
+    for (int w = 0; w < 4; ++w) {  // the few lists beyond the register network: the workgroup's LDS network, one by one
+        const int t2 = blockIdx.x * 4 + w;
+        if (t2 >= n_tiles_total) break;
+        SegMap m2;
+        m2.load(tile_count, cstride, t2, seg_stride);
+        const int s2 = tile_offsets[t2];
+        const int n2 = (tile_offsets[t2 + 1] - s2 == m2.n) ? m2.n : 0;
+        if (n2 <= WAVE_MAX || n2 > SHORT_SORT_LDS_KEYS) continue;  // (n2 <= seg_stride <= SHORT_SORT_LDS_KEYS by construction)
+        const uint64_t* seg = seg_keys + (size_t)t2 * TC_COPIES * (size_t)seg_stride;
+        const int cam = t2 / tiles_per_cam, tl = t2 - cam * tiles_per_cam;
+        const uint64_t hi_bits = (((uint64_t)cam << tile_bits) | (uint64_t)tl) << 32;
+        for (int i = threadIdx.x; i < n2; i += 256) lds_keys[i] = seg[m2.offset_of(i)];
+        __syncthreads();
+        bitonic_sort_lds<256>(lds_keys, n2);
+        for (int i = threadIdx.x; i < n2; i += 256) {
+            const uint64_t k = lds_keys[i];
+            flatten_ids[s2 + i] = (int32_t)(uint32_t)k;
+            if (isect_ids) isect_ids[s2 + i] = hi_bits | (k >> 32);
+        }
+        __syncthreads();  // lds_keys is reused
+    }
+}
+
 }  // namespace mobgs
 
 using namespace mobgs;
@@ -1165,6 +1585,7 @@ extern "C" {
 // Layout of the scratch buffer shared by mobgs_isect_offsets and mobgs_isect_emit_sort (int32 units):
 //   [tile_count TC_COPIES * nt | ticket (+3 pad) | status 2*(nb1+1)]  <- zeroed by one memset
 //   [owner cap | tile cap | rank cap | chunk_cnt (cap >> 11) + 1]
+static inline size_t count_stride(size_t n_tiles) { return (n_tiles * TC_STRIDE + 31) & ~(size_t)31; }
 struct IsectScratch {
     int32_t *tile_count, *tickets, *chunk_cnt, *owner, *tile_of_j, *rank_of_j, *chunk_owner, *tile_base;
     int owner_slots;
@@ -1173,7 +1594,9 @@ struct IsectScratch {
     int nb1;
     IsectScratch(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity) {
         nb1 = (int)((n_gauss + SCAN_BLOCK - 1) / SCAN_BLOCK);
-        const size_t nt_pad = (n_tiles * TC_STRIDE * TC_COPIES + 1) & ~(size_t)1;  // (64-bit status words stay 8-byte aligned)
+        // every counter copy starts on its own 128-byte line (the fused path gives each XCD its own copy and lets the
+        // XCD's L2 perform the atomics: two XCDs must never share a line); the two-pass path packs its copies at the start
+        const size_t nt_pad = count_stride(n_tiles) * TC_COPIES;  // (even: the 64-bit status words stay 8-byte aligned)
         int32_t* p = (int32_t*)scratch;
         tile_count = p;
         tickets = p + nt_pad;
@@ -1263,15 +1686,15 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
     // 65.3), several times faster on dense image regions (long lists); larger grids keep the direct atomics
     (void)dense_hint;
     if (nt <= DENSE_MAX_TILES)
-        hipLaunchKernelGGL(bin_kernel<true>, dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n, N,
+        hipLaunchKernelGGL((bin_kernel<true, false>), dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n, N,
                            tile_w, tile_h, width, height, cull, capacity, cum_tiles, means2d, radii, conics, opacities,
                            opac_per_camera, L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan,
-                           (int)nt, L.chunk_owner);
+                           (int)nt, L.chunk_owner, (const float*)nullptr, (uint64_t*)nullptr, 0, 0);
     else
-        hipLaunchKernelGGL(bin_kernel<false>, dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h, width,
+        hipLaunchKernelGGL((bin_kernel<false, false>), dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h, width,
                            height, cull, capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera,
                            L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt,
-                           L.chunk_owner);
+                           L.chunk_owner, (const float*)nullptr, (uint64_t*)nullptr, 0, 0);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, L.tile_base, tile_offsets,
                        stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, heavy_len,
                        stats_mirror, stats_seq);
@@ -1369,3 +1792,78 @@ int mobgs_isect_emit_sort_speculative(int C, int N, int tile_w, int tile_h, int 
 }
 
 }  // extern "C"
+
+// ---- fused single-pass lists (round 5) --------------------------------------------------------------------------------
+extern "C" {
+
+size_t mobgs_fused_seg_keys_len(int n_tiles, int seg_stride) {
+    return (size_t)(n_tiles > 0 ? n_tiles : 0) * TC_COPIES * (size_t)(seg_stride > 0 ? seg_stride : 0);
+}
+int mobgs_fused_max_seg_stride(void) { return SHORT_SORT_LDS_KEYS; }
+
+}  // extern "C"
+
+float* mobgs::isect_bin_records(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity) {
+    // the (owner, tile, rank) triples of the two-pass path are not written by the fused one: 3 * capacity ints, and
+    // capacity >= 4 * n_gauss + 2 is checked by the launcher (12 floats per splat + the alignment slack)
+    const IsectScratch L(scratch, n_gauss, n_tiles, capacity);
+    return reinterpret_cast<float*>(((uintptr_t)L.owner + 15) & ~(uintptr_t)15);  // rows are read as float4
+}
+
+// scan -> bin (keys straight into the strided segments) -> offsets / schedule / counts -> per-tile sort: four launches
+// (the two-pass path: five, with a second pass over the kept intersections and six dependent counter sweeps)
+int mobgs::isect_fused_launch(int C, int N, int tile_w, int tile_h, int width, int height, int capacity,
+                              const int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* keep_scan,
+                              int32_t* tile_offsets, int32_t* tile_order, int64_t capacity_listed, int64_t* stats,
+                              void* scratch, int64_t* stats_mirror, int64_t stats_seq, uint64_t* seg_keys,
+                              int seg_stride, int32_t* flatten_ids, uint64_t* isect_ids, int64_t max_tile_len_hint,
+                              const MobgsTuning* tuning, void* stream) {
+    const long long ng = (long long)C * N;
+    const long long nt = (long long)C * tile_w * tile_h;
+    if (C <= 0 || N <= 0 || capacity < 1 || ng >= (1ll << 31) - 1 || nt >= (1ll << 31) - 1 || !seg_keys ||
+        seg_stride < 1 || seg_stride > SHORT_SORT_LDS_KEYS || (long long)capacity < 4 * ng + 2 || capacity_listed < 1 ||
+        tile_w > 0xFFFF || tile_h > 0xFFFF || C > 0xFFFF || ((uintptr_t)scratch & 127) != 0) {
+        set_error("mobgs_project_and_bin_fused: bad sizes C=%d N=%d tiles=%dx%d capacity=%d seg_stride=%d", C, N, tile_w,
+                  tile_h, capacity, seg_stride);
+        return MOBGS_E_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int n = (int)ng;
+    const int heavy_len = tuning_heavy_len(tuning, (int)(nt < (1ll << 30) ? nt : (1ll << 30)));
+    const IsectScratch L(scratch, (size_t)n, (size_t)nt, (size_t)capacity);
+    const float* binrec = isect_bin_records(scratch, (size_t)n, (size_t)nt, (size_t)capacity);
+    const int cstride = (int)count_stride((size_t)nt);
+    hipLaunchKernelGGL(scan_lookback_kernel, dim3(L.nb1), dim3(SCAN_THREADS), 0, st, n, tiles_per_gauss, cum_tiles,
+                       L.tickets, L.status1, stats, L.chunk_owner, L.owner_slots);
+    const int n_chunks = (capacity >> KEEP_CHUNK_LOG2) + 1;
+    // LDS-ranked variant: small grids (every workgroup touches most tiles several times) and scenes with long lists
+    // (dense image regions: thousands of atomics on a few counters); on a large grid with short lists the plain
+    // returning atomics are ahead (47.4 against 50.2 us at 5440 tiles / 300 k splats)
+#ifdef ABL_FORCE_DENSE
+    if (nt <= DENSE_MAX_TILES)
+#else
+    if (nt <= DENSE_MAX_TILES && (nt <= 2048 || max_tile_len_hint >= 1024))
+#endif
+        hipLaunchKernelGGL((bin_kernel<true, true>), dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n,
+                           N, tile_w, tile_h, width, height, 1, capacity, cum_tiles, (const float*)nullptr,
+                           (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, L.chunk_cnt, L.owner,
+                           L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt, L.chunk_owner, binrec, seg_keys,
+                           seg_stride, cstride);
+    else
+        hipLaunchKernelGGL((bin_kernel<false, true>), dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h,
+                           width, height, 1, capacity, cum_tiles, (const float*)nullptr, (const int32_t*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, 0, L.chunk_cnt, L.owner, L.tile_of_j,
+                           L.rank_of_j, L.tile_count, keep_scan, (int)nt, L.chunk_owner, binrec, seg_keys, seg_stride,
+                           cstride);
+    hipLaunchKernelGGL(tile_finish_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count,
+                       cstride, tile_offsets, stats, tile_order, (int64_t)capacity, capacity_listed, seg_stride, keep_scan,
+                       n_chunks, heavy_len, stats_mirror, stats_seq);
+    const int tiles_per_cam = tile_w * tile_h;
+    int tile_bits = 0;
+    while ((1ll << tile_bits) <= (long long)tiles_per_cam) ++tile_bits;
+    const int64_t longest = max_tile_len_hint > seg_stride ? seg_stride : max_tile_len_hint;
+    auto sort_seg = longest > 1024 ? tile_sort_seg_kernel<32> : longest > 512 ? tile_sort_seg_kernel<16> : tile_sort_seg_kernel<8>;
+    hipLaunchKernelGGL(sort_seg, dim3(((int)nt + 3) / 4), dim3(256), 0, st, (int)nt, tile_bits, tile_offsets, L.tile_count,
+                       cstride, seg_keys, seg_stride, flatten_ids, isect_ids, tiles_per_cam);
+    return check_launch("isect_fused");
+}

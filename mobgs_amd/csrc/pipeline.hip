@@ -54,17 +54,19 @@ int mobgs_project_and_bin(int C, int N, const float* means, const float* quats, 
                                  tile_offsets, scratch, sort_keys, flatten_ids, isect_ids, stream);
 }
 
-int mobgs_project_and_bin_speculative(int C, int N, const float* means, const float* quats, const float* scales,
-                                      const float* viewmats, const float* Ks, const float* opacities,
-                                      int opac_per_camera, int width, int height, float eps2d, float near_plane,
-                                      float far_plane, float radius_clip, int cull, int32_t* radii, float* means2d,
-                                      float* depths, float* conics, int32_t* tiles_per_gauss, int32_t* cum_tiles,
-                                      int32_t* tile_offsets, int32_t* tile_order, int64_t* stats_dev,
-                                      int capacity_box, int32_t* keep_scan, void* scratch, int64_t capacity_listed,
-                                      int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
-                                      int64_t max_tile_len_hint, int64_t* stats_host_pinned, int64_t stats_seq,
-                                      const float* pack_colors, int colors_per_camera, int pack_channels,
-                                      float* pack_records, const MobgsTuning* tuning, void* stream) {
+// seg_stride > 0: the fused single-pass lists (isect.hip, isect_fused_launch) -- sort_keys is then the strided key
+// arena [C * n_tiles][8][seg_stride]; 0: the two-pass path
+static int project_and_bin_enqueue(int C, int N, const float* means, const float* quats, const float* scales,
+                                   const float* viewmats, const float* Ks, const float* opacities,
+                                   int opac_per_camera, int width, int height, float eps2d, float near_plane,
+                                   float far_plane, float radius_clip, int cull, int32_t* radii, float* means2d,
+                                   float* depths, float* conics, int32_t* tiles_per_gauss, int32_t* cum_tiles,
+                                   int32_t* tile_offsets, int32_t* tile_order, int64_t* stats_dev,
+                                   int capacity_box, int32_t* keep_scan, void* scratch, int64_t capacity_listed,
+                                   int32_t* flatten_ids, uint64_t* sort_keys, int seg_stride, uint64_t* isect_ids,
+                                   int64_t max_tile_len_hint, int64_t* stats_host_pinned, int64_t stats_seq,
+                                   const float* pack_colors, int colors_per_camera, int pack_channels,
+                                   float* pack_records, const MobgsTuning* tuning, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
     if (!stats_host_pinned || capacity_listed < 1) {
@@ -88,9 +90,18 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
         pack = PackArgs{opacities, pack_colors, pack_records, opac_per_camera, colors_per_camera, pack_channels,
                         mobgs_record_stride(pack_channels + 1)};
     }
+    BinArgs bin{nullptr, nullptr, 0, 0};
+    if (seg_stride > 0) {
+        if (!fuse_zero || !opacities || (long long)capacity_box < 4 * n_all + 2 || ((uintptr_t)scratch & 127) != 0) {
+            set_error("mobgs_project_and_bin_fused: needs N > 0, opacities, a 128-byte aligned scratch and capacity_box >= 4 C N + 2");
+            return MOBGS_E_INVALID;
+        }
+        bin = BinArgs{mobgs::isect_bin_records(scratch, (size_t)n_all, (size_t)nt_all, (size_t)capacity_box), opacities,
+                      opac_per_camera, cull};
+    }
     int rc = mobgs::project_fwd_launch(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
                                        radius_clip, radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, zero_n, pack,
-                                       stream, tuning_geometry_per_camera(tuning));
+                                       stream, tuning_geometry_per_camera(tuning), bin);
     if (rc != MOBGS_OK) return rc;
     // the binning variant follows the caller's expectation of the longest list (max_tile_len_hint)
     MobgsTuning tn = tuning ? *tuning : MobgsTuning{-1, -1, -1, -1, -1, 0, -1, {0}};
@@ -100,10 +111,16 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
         (void)hipGetLastError();
         mirror = nullptr;
     }
-    rc = mobgs::isect_offsets_launch(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d, radii,
-                                     conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets, tile_order,
-                                     capacity_listed, stats_dev, scratch, fuse_zero, (int64_t*)mirror,
-                                     mirror ? stats_seq : 0, &tn, stream);
+    if (seg_stride > 0)
+        rc = mobgs::isect_fused_launch(C, N, tile_w, tile_h, width, height, capacity_box, tiles_per_gauss, cum_tiles,
+                                       keep_scan, tile_offsets, tile_order, capacity_listed, stats_dev, scratch,
+                                       (int64_t*)mirror, mirror ? stats_seq : 0, sort_keys, seg_stride, flatten_ids,
+                                       isect_ids, max_tile_len_hint, &tn, stream);
+    else
+        rc = mobgs::isect_offsets_launch(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d,
+                                         radii, conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets,
+                                         tile_order, capacity_listed, stats_dev, scratch, fuse_zero, (int64_t*)mirror,
+                                         mirror ? stats_seq : 0, &tn, stream);
     if (rc != MOBGS_OK) return rc;
     if (!mirror) {
         hipError_t e = hipMemcpyAsync(stats_host_pinned, stats_dev, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st);
@@ -112,13 +129,57 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
             return MOBGS_E_LAUNCH;
         }
     }
-    rc = mobgs_isect_emit_sort_speculative(C, N, tile_w, tile_h, capacity_box, capacity_listed, max_tile_len_hint,
-                                           depths, cum_tiles, tile_offsets, stats_dev, scratch, sort_keys, flatten_ids,
-                                           isect_ids, stream);
-    if (rc != MOBGS_OK) return rc;
+    if (seg_stride == 0) {
+        rc = mobgs_isect_emit_sort_speculative(C, N, tile_w, tile_h, capacity_box, capacity_listed, max_tile_len_hint,
+                                               depths, cum_tiles, tile_offsets, stats_dev, scratch, sort_keys,
+                                               flatten_ids, isect_ids, stream);
+        if (rc != MOBGS_OK) return rc;
+    }
     // 1: the counts travel by an ordinary asynchronous copy (or no sequence number was asked for) -- the caller
     // records an event behind this call and waits on it; 0: poll stats_host_pinned[3] for stats_seq instead
     return (mirror && stats_seq) ? MOBGS_OK : 1;
+}
+
+int mobgs_project_and_bin_speculative(int C, int N, const float* means, const float* quats, const float* scales,
+                                      const float* viewmats, const float* Ks, const float* opacities,
+                                      int opac_per_camera, int width, int height, float eps2d, float near_plane,
+                                      float far_plane, float radius_clip, int cull, int32_t* radii, float* means2d,
+                                      float* depths, float* conics, int32_t* tiles_per_gauss, int32_t* cum_tiles,
+                                      int32_t* tile_offsets, int32_t* tile_order, int64_t* stats_dev,
+                                      int capacity_box, int32_t* keep_scan, void* scratch, int64_t capacity_listed,
+                                      int32_t* flatten_ids, uint64_t* sort_keys, uint64_t* isect_ids,
+                                      int64_t max_tile_len_hint, int64_t* stats_host_pinned, int64_t stats_seq,
+                                      const float* pack_colors, int colors_per_camera, int pack_channels,
+                                      float* pack_records, const MobgsTuning* tuning, void* stream) {
+    return project_and_bin_enqueue(C, N, means, quats, scales, viewmats, Ks, opacities, opac_per_camera, width, height,
+                                   eps2d, near_plane, far_plane, radius_clip, cull, radii, means2d, depths, conics,
+                                   tiles_per_gauss, cum_tiles, tile_offsets, tile_order, stats_dev, capacity_box,
+                                   keep_scan, scratch, capacity_listed, flatten_ids, sort_keys, 0, isect_ids,
+                                   max_tile_len_hint, stats_host_pinned, stats_seq, pack_colors, colors_per_camera,
+                                   pack_channels, pack_records, tuning, stream);
+}
+
+int mobgs_project_and_bin_fused(int C, int N, const float* means, const float* quats, const float* scales,
+                                const float* viewmats, const float* Ks, const float* opacities, int opac_per_camera,
+                                int width, int height, float eps2d, float near_plane, float far_plane,
+                                float radius_clip, int cull, int32_t* radii, float* means2d, float* depths,
+                                float* conics, int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* tile_offsets,
+                                int32_t* tile_order, int64_t* stats_dev, int capacity_box, int32_t* keep_scan,
+                                void* scratch, int64_t capacity_listed, int32_t* flatten_ids, uint64_t* seg_keys,
+                                int seg_stride, uint64_t* isect_ids, int64_t max_tile_len_hint,
+                                int64_t* stats_host_pinned, int64_t stats_seq, const float* pack_colors,
+                                int colors_per_camera, int pack_channels, float* pack_records,
+                                const MobgsTuning* tuning, void* stream) {
+    if (seg_stride < 1 || !seg_keys) {
+        set_error("mobgs_project_and_bin_fused: seg_stride >= 1 and seg_keys are required");
+        return MOBGS_E_INVALID;
+    }
+    return project_and_bin_enqueue(C, N, means, quats, scales, viewmats, Ks, opacities, opac_per_camera, width, height,
+                                   eps2d, near_plane, far_plane, radius_clip, cull, radii, means2d, depths, conics,
+                                   tiles_per_gauss, cum_tiles, tile_offsets, tile_order, stats_dev, capacity_box,
+                                   keep_scan, scratch, capacity_listed, flatten_ids, seg_keys, seg_stride, isect_ids,
+                                   max_tile_len_hint, stats_host_pinned, stats_seq, pack_colors, colors_per_camera,
+                                   pack_channels, pack_records, tuning, stream);
 }
 
 }  // extern "C"

@@ -123,7 +123,7 @@ project_fwd_kernel(int N, const float* __restrict__ means, const float* __restri
                    float far_plane, float radius_clip, int tile_w, int tile_h,
                    int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
                    float* __restrict__ conics, int32_t* __restrict__ tiles_per_gauss, int32_t* __restrict__ zero_ptr,
-                   unsigned zero_n, PackArgs pack, int geom_stride) {
+                   unsigned zero_n, PackArgs pack, int geom_stride, BinArgs bin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     // geometry_per_camera: camera c reads rows [c N, c N + N) of means / quats (geom_stride = N), else the shared rows
@@ -145,6 +145,7 @@ project_fwd_kernel(int N, const float* __restrict__ means, const float* __restri
     int rad = 0;
     float m2x = 0.f, m2y = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, depth = 0.f;
     int ntiles = 0;
+    TileRect tr{0, 0, 0, 0};
     if (p[2] >= near_plane && p[2] <= far_plane) {
         const float4 qv = reinterpret_cast<const float4*>(quats)[i];
         const float q[4] = {qv.x, qv.y, qv.z, qv.w};
@@ -189,7 +190,7 @@ project_fwd_kernel(int N, const float* __restrict__ means, const float* __restri
                 cb = -b * inv_det;
                 cc = a * inv_det;
                 depth = p[2];
-                const TileRect tr = tile_rect(m2x, m2y, rad, tile_w, tile_h);
+                tr = tile_rect(m2x, m2y, rad, tile_w, tile_h);
                 ntiles = (tr.x1 - tr.x0) * (tr.y1 - tr.y0);
             }
         }
@@ -203,6 +204,10 @@ project_fwd_kernel(int N, const float* __restrict__ means, const float* __restri
     tiles_per_gauss[o] = ntiles;
     // side job for the orchestrator: the compositor's record of this splat (depth as the extra channel) while
     // everything it needs is in registers -- saves the pack launch and re-reading means2d / conics / depths
+    // ... and its bin record (fused binning path, common.h): only splats with tiles are ever looked up
+    if (bin.records && ntiles > 0)
+        write_bin_record(bin.records + o * BIN_RECORD_FLOATS, m2x, m2y, ca, cb, cc, depth,
+                         bin.opacities[bin.opac_per_camera ? o : (size_t)i], bin.cull, tr, c);
     if (pack.records && rad > 0)
         write_splat_record(pack.records + o * pack.stride, m2x, m2y, ca, cb, cc,
                            pack.opacities[pack.opac_per_camera ? o : (size_t)i],
@@ -471,7 +476,8 @@ using namespace mobgs;
 
 extern "C" {
 
-const char* mobgs_version(void) { return "mobgs_hip 0.1 gfx950"; }
+const char* mobgs_version(void) { return "mobgs_hip 0.2 gfx950"; }
+int mobgs_abi_version(void) { return MOBGS_ABI_VERSION; }
 const char* mobgs_last_error(void) { return g_err; }
 int mobgs_record_stride(int channels) { return record_stride(channels); }
 
@@ -490,7 +496,7 @@ int mobgs::project_fwd_launch(int C, int N, const float* means, const float* qua
                               const float* viewmats, const float* Ks, int width, int height, float eps2d,
                               float near_plane, float far_plane, float radius_clip, int32_t* radii, float* means2d,
                               float* depths, float* conics, int32_t* tiles_per_gauss, int32_t* zero_ptr, size_t zero_n,
-                              PackArgs pack, void* stream, int geometry_per_camera) {
+                              PackArgs pack, void* stream, int geometry_per_camera, BinArgs bin) {
     if (C <= 0 || N < 0 || width <= 0 || height <= 0) {
         set_error("mobgs_project_fwd: bad sizes C=%d N=%d W=%d H=%d", C, N, width, height);
         return MOBGS_E_INVALID;
@@ -504,7 +510,7 @@ int mobgs::project_fwd_launch(int C, int N, const float* means, const float* qua
     hipLaunchKernelGGL(project_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, means, quats, scales,
                        viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip, tile_w, tile_h,
                        radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, (unsigned)zero_n, pack,
-                       geometry_per_camera ? N : 0);
+                       geometry_per_camera ? N : 0, bin);
     return check_launch("project_fwd_kernel");
 }
 

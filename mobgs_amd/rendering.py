@@ -240,29 +240,58 @@ class _PendingCounts:
         n_box, n_isects, max_len = (int(v) for v in self.row[:3])
         _stats_slots.give(self.slot)
         self.slot = None
-        key, cap_box, cap_listed = self.caps
-        if n_box <= cap_box and n_isects <= cap_listed:
+        key, cap_box, cap_listed, seg_stride = self.caps
+        if n_box <= cap_box and n_isects <= cap_listed and (seg_stride == 0 or max_len <= seg_stride):
             tl._set_counts(n_box, n_isects, max_len, *self.arenas)
-            _len_hint[key] = max_len
+            _note_longest(key, max_len)
             _last_counts[key] = (n_box, n_isects)
             last_stats.update(n_isects=n_isects, n_box=n_box, max_tile_len=max_len,
                               n_tiles=tl.C * tl.tile_w * tl.tile_h)
             return False
-        # arena too small (first frame of a scene, or the scene grew): every kernel enqueued so far saw empty
-        # lists; rebuild synchronously -- the projection outputs do not depend on the arena
+        # arena too small (first frame of a scene, or the scene grew) or, with single-pass lists, a tile's list longer
+        # than its key segment: every kernel enqueued so far saw empty lists; rebuild synchronously with the two-pass
+        # entry points -- the projection outputs do not depend on the arena
+        if seg_stride and max_len > seg_stride:
+            seg_overflows[0] += 1
         _capacity[key] = max(_capacity.get(key, 0), int(n_box * 1.25) + 1024)
         fresh = build_tile_lists(*self.rebuild_args)
         for name in ("cum_tiles", "keep_scan", "tile_offsets", "tile_order"):
             setattr(tl, name, getattr(fresh, name))
         tl._set_counts(fresh._n_box, fresh._n_isects, fresh._max_tile_len, fresh.flatten_arena, fresh._isect_ids)
         _cap_listed[key] = max(_cap_listed.get(key, 0), int(fresh._n_isects * 1.25) + 1024)
-        _len_hint[key] = fresh._max_tile_len
+        _note_longest(key, fresh._max_tile_len)
         tl.rebuilds += 1
         list_rebuilds[0] += 1
         return True
 
 
 list_rebuilds = [0]  # speculative binning calls whose arena was too small (lists rebuilt synchronously) -- diagnostics
+seg_overflows = [0]  # ... of them, single-pass calls in which a tile's list outgrew its key segment
+fused_calls = [0]    # binning calls that took the single-pass path (diagnostics / tests)
+# Single-pass tile lists (round 5; include/mobgs_hip.h mobgs_project_and_bin_fused): the binning kernel writes every sort
+# key straight into its tile's segment of a strided arena sized from the previous frame's longest list x SEG_SLACK; the
+# first frame of a workload (no hint yet), lists beyond the one-launch sort (2048 entries) and arenas beyond
+# FUSED_ARENA_BYTES take the two-pass path, as does the synchronous rebuild after an overflow.  Outputs are identical.
+FUSED_LISTS = os.environ.get("MOBGS_FUSED_LISTS", "1") != "0"
+SEG_SLACK = 1.3
+FUSED_ARENA_BYTES = 2 << 30
+_FUSED_COPIES = 8  # counter copies of the binning kernel (csrc/isect.hip TC_COPIES)
+
+
+def _note_longest(key, max_len):
+    """The longest list of the frame just resolved becomes the next frame's hint; it decays slowly (5 % per frame), so
+    that a camera path whose longest list fluctuates does not overflow its segments every other frame."""
+    _len_hint[key] = max(int(max_len), int(_len_hint.get(key, 0) * 0.95))
+
+
+def _fused_seg_stride(len_hint, C, N, nt, cap_box) -> int:
+    """Key-segment capacity per tile for the single-pass path, or 0 = use the two-pass path."""
+    if not FUSED_LISTS or N <= 0 or len_hint <= 0 or cap_box < 4 * C * N + 2:
+        return 0
+    stride = max(64, (int(len_hint * SEG_SLACK) + 15) // 16 * 16)
+    if stride > _lib_().mobgs_fused_max_seg_stride() or nt * _FUSED_COPIES * stride * 8 > FUSED_ARENA_BYTES:
+        return 0
+    return stride
 _tile_culling = True
 # Caller-side policy handed to the library with every call (include/mobgs_hip.h MobgsTuning; the library itself keeps
 # no state).  tuning.heavy_tile_len / tuning.quadrant_culling / tuning.block_walk may be changed by tests and
@@ -297,7 +326,7 @@ class StaticCapacity:
 
     def __init__(self, margin: float = 1.5, max_calls: int = 64):
         self.margin = float(margin)
-        self.rows = []   # (pinned row, owner tensor, cap_box, cap_listed, key)
+        self.rows = []   # (pinned row, owner tensor, cap_box, cap_listed, key, seg_stride)
         self._prev = None
         # landing rows of the calls issued inside the context, page-locked BEFORE anything is captured (a pinned
         # allocation is not a legal call while a stream is capturing)
@@ -333,11 +362,11 @@ class StaticCapacity:
     def check(self) -> bool:
         """True when every binning call issued under this context fitted its arenas (call after a synchronisation)."""
         ok = True
-        for row, _, cap_box, cap_listed, key in self.rows:
+        for row, _, cap_box, cap_listed, key, seg_stride in self.rows:
             n_box, n_isects, max_len = (int(v) for v in row[:3])
             _last_counts[key] = (max(n_box, _last_counts.get(key, (0, 0))[0]), max(n_isects, _last_counts.get(key, (0, 0))[1]))
             _len_hint[key] = max(max_len, _len_hint.get(key, 0))
-            ok = ok and n_box <= cap_box and n_isects <= cap_listed
+            ok = ok and n_box <= cap_box and n_isects <= cap_listed and (seg_stride == 0 or max_len <= seg_stride)
         return ok
 
 
@@ -903,10 +932,12 @@ class _ProjectAndBin(torch.autograd.Function):
                 row, slot, row_addr, owner = _stats_slots.take()
             seq = _stats_slots.next_seq()
             row[3] = 0
+            seg_stride = _fused_seg_stride(len_hint, C, N, nt, cap_box)
+            fused_calls[0] += 1 if seg_stride else 0
             rc, outs, tile_order, isect_ids, records = F.project_and_bin_speculative(
                 means, quats, scales, viewmats, Ks, opac, width, height, eps2d, near_plane, far_plane, radius_clip,
                 int(_tile_culling), bool(want_isect_ids), bool(TILE_SCHEDULE), pack, cap_box, cap_listed,
-                len_hint, row_addr, seq, call_tuning.address(), stream_int())
+                len_hint, row_addr, seq, call_tuning.address(), stream_int(), seg_stride)
             radii, means2d, depths, conics, tiles_per_gauss, cum_tiles, tile_offsets, keep_scan, flatten_ids = outs
             tl.records = records
             event = None
@@ -917,11 +948,11 @@ class _ProjectAndBin(torch.autograd.Function):
             tl.cum_tiles, tl.keep_scan, tl.tile_offsets, tl.tile_order = cum_tiles, keep_scan, tile_offsets, tile_order
             tl.flatten_arena = flatten_ids
             if _static is not None:
-                _static.rows.append((row, owner, cap_box, cap_listed, key))
+                _static.rows.append((row, owner, cap_box, cap_listed, key, seg_stride))
                 tl._pending = None
                 tl._set_counts(cap_box, cap_listed, len_hint, flatten_ids, isect_ids)
             else:
-                tl._pending = _PendingCounts(row, slot, event, (key, cap_box, cap_listed), (flatten_ids, isect_ids),
+                tl._pending = _PendingCounts(row, slot, event, (key, cap_box, cap_listed, seg_stride), (flatten_ids, isect_ids),
                                              (means2d, radii, depths, conics, opac, tiles_per_gauss, width, height,
                                               want_isect_ids), seq, owner)
                 _capacity[key], _cap_listed[key] = cap_box, cap_listed
@@ -963,7 +994,9 @@ class _ProjectAndBin(torch.autograd.Function):
             keep_scan = torch.empty(lib.mobgs_keep_scan_len(cap_box), dtype=torch.int32, device=dev)
             scratch = torch.empty(lib.mobgs_isect_scratch_bytes(C * N, nt, cap_box), dtype=torch.uint8, device=dev)
             flatten_ids = torch.empty(cap_listed, dtype=torch.int32, device=dev)
-            sort_keys = torch.empty(cap_listed, dtype=torch.int64, device=dev)
+            seg_stride = _fused_seg_stride(_len_hint.get(key, 0), C, N, nt, cap_box) if SPECULATIVE_BINNING else 0
+            sort_keys = torch.empty(lib.mobgs_fused_seg_keys_len(nt, seg_stride) if seg_stride else cap_listed,
+                                    dtype=torch.int64, device=dev)
             isect_ids = torch.empty(cap_listed, dtype=torch.int64, device=dev) if want_isect_ids else None
             if SPECULATIVE_BINNING:
                 if _stats_slots is None:
@@ -971,16 +1004,20 @@ class _ProjectAndBin(torch.autograd.Function):
                 row, slot, row_addr, owner = _stats_slots.take()
                 seq = _stats_slots.next_seq()
                 row[3] = 0
-                rc = lib.mobgs_project_and_bin_speculative(
-                    C, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), ptr(opac),
-                    1 if opac.dim() == 2 else 0, width, height, eps2d, near_plane, far_plane, radius_clip,
-                    int(_tile_culling), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(tiles_per_gauss),
-                    ptr(cum_tiles), ptr(tile_offsets), ptr(tile_order), ptr(stats_dev), cap_box, ptr(keep_scan),
-                    ptr(scratch), cap_listed, ptr(flatten_ids), ptr(sort_keys), ptr(isect_ids),
-                    _len_hint.get(key, 0), ctypes.c_void_p(row_addr), seq,
-                    ptr(pack_colors) if records is not None else None,
-                    1 if (records is not None and pack_colors.dim() == 3) else 0,
-                    pack_colors.shape[-1] if records is not None else 0, ptr(records), call_tuning.ref(), stream())
+                head = (C, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), ptr(opac),
+                        1 if opac.dim() == 2 else 0, width, height, eps2d, near_plane, far_plane, radius_clip,
+                        int(_tile_culling), ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(tiles_per_gauss),
+                        ptr(cum_tiles), ptr(tile_offsets), ptr(tile_order), ptr(stats_dev), cap_box, ptr(keep_scan),
+                        ptr(scratch), cap_listed, ptr(flatten_ids), ptr(sort_keys))
+                tail = (ptr(isect_ids), _len_hint.get(key, 0), ctypes.c_void_p(row_addr), seq,
+                        ptr(pack_colors) if records is not None else None,
+                        1 if (records is not None and pack_colors.dim() == 3) else 0,
+                        pack_colors.shape[-1] if records is not None else 0, ptr(records), call_tuning.ref(), stream())
+                if seg_stride:  # single-pass lists (see FUSED_LISTS)
+                    fused_calls[0] += 1
+                    rc = lib.mobgs_project_and_bin_fused(*head, seg_stride, *tail)
+                else:
+                    rc = lib.mobgs_project_and_bin_speculative(*head, *tail)
                 if rc not in (0, 1):
                     check(rc, "mobgs_project_and_bin_speculative")
                 tl.records = records
@@ -991,7 +1028,8 @@ class _ProjectAndBin(torch.autograd.Function):
                 tl.C, tl.N, tl.tile_w, tl.tile_h = C, N, tile_w, tile_h
                 tl.cum_tiles, tl.keep_scan, tl.tile_offsets, tl.tile_order = cum_tiles, keep_scan, tile_offsets, tile_order
                 tl.flatten_arena = flatten_ids
-                tl._pending = _PendingCounts(row, slot, event, (key, cap_box, cap_listed), (flatten_ids, isect_ids),
+                tl._pending = _PendingCounts(row, slot, event, (key, cap_box, cap_listed, seg_stride),
+                                             (flatten_ids, isect_ids),
                                              (means2d, radii, depths, conics, opac, tiles_per_gauss, width, height,
                                               want_isect_ids), seq, owner)
                 break

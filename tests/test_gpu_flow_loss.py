@@ -43,27 +43,52 @@ def _run(fn, case, dev, dtype=torch.float32, **kw):
     return float(loss), {k: t[k].grad.detach().cpu() for k in NAMES}
 
 
-def _check(got, ggot, ref, gref, what):
+def _check(got, ggot, ref, gref, what, ref32=None, gref32=None, tight32=True):
     """The reference is evaluated in float64 on the CPU, so the comparison does not depend on the order in which some
-    torch version / thread count happens to add fp32 terms.  The bounds are those of the fp32 FORMULATION
-    (which the kernel shares with the reference's torch calls), measured as fp32-CPU against fp64-CPU at 1352x1014: the
-    loss (a mean over 12 M terms) 3e-8 relative -> 1e-5 allowed; gradient elements up to 1.3e-4 of the tensor's maximum
+    torch version / thread count happens to add fp32 terms.  Against float64 the bounds are those of the fp32
+    FORMULATION (which the kernel shares with the reference's torch calls), measured as fp32-CPU against fp64-CPU at
+    1352x1014: the loss (a mean over 12 M terms) 3e-8 relative; gradient elements up to 1.3e-4 of the tensor's maximum
     (coordinate gradients are differences of neighbouring image values, the mask gradients carry the fp32 sum of 4 M mask
-    values in their denominator) -> 3e-4 of the maximum + 1e-5 of the element.  The L1 terms have sgn() in their
-    derivative: where |difference * mask| is within rounding of zero fp32 and fp64 may pick different signs -- up to
-    1e-4 of the elements may be off by twice one of their terms (each at most the tensor's maximum; observed: 1 element of
-    a coordinate map at 3 % of it, 303 of 12 M image-gradient elements at 1.1e-3 of it)."""
-    assert abs(got - ref) <= 1e-5 * abs(ref), (what, got, ref)
+    values in their denominator).  Both grow with the number of summed terms, so the allowance does too (a flat
+    3e-4 let a regression 100x the observed error pass on the small cases): 3e-6 of the maximum at <= 64 k pixels, rising
+    linearly to 3e-4 at the benchmark size = ~2.3x what is observed there.
+    The L1 terms have sgn() in their derivative: where |difference * mask| is within rounding of zero fp32 and fp64 may pick
+    different signs.  Such an element is accepted only if (a) at most 1e-4 of the tensor's elements are concerned, and (b)
+    the element looks like a flipped term: the fp32 evaluation of the reference's own torch statements on the CPU misses
+    float64 there as well (same formulation, same near-zero difference), or the value is the reference mirrored
+    (|err| <= 2 |ref| + bound: what flipping the one term of an image-gradient element does).
+    ref32 / gref32 (small cases): a second, TIGHT comparison against that fp32 CPU evaluation -- observed <= 5e-7 of the
+    maximum (scripts/observed_flow_loss_errors.py), allowed 5e-6 and 3e-6 relative on the loss."""
+    n_terms = max(int(gref["latent"].numel()), 1)
+    rel = min(3e-4, max(3e-6, 3e-4 * n_terms / 12.3e6))
+    assert abs(got - ref) <= max(1e-6, 1e-5 * n_terms / 12.3e6) * abs(ref), (what, got, ref)
     for k in NAMES:
         a, b = ggot[k].double(), gref[k].double()
         assert a.shape == b.shape
         m = float(b.abs().max())
+        bound = rel * m + 1e-5 * b.abs() + 1e-14
         err = (a - b).abs()
-        bad = err > 3e-4 * m + 1e-5 * b.abs() + 1e-14
+        bad = err > bound
         nbad = int(bad.sum())
         assert nbad <= 1e-4 * bad.numel(), (what, k, nbad, float(err.max()), m)
-        if nbad:   # a flipped sgn() changes ONE term of the element by twice its size, and no term exceeds the maximum
+        if nbad:
+            mirrored = err <= 2.0 * b.abs() + bound
+            cpu_too = torch.zeros_like(bad)
+            if gref32 is not None:
+                cpu_too = (gref32[k].double() - b).abs() > bound
+            unexplained = bad & ~mirrored & ~cpu_too
+            assert int(unexplained.sum()) == 0, (what, k, nbad, int(unexplained.sum()), float(err[bad].max()), m)
             assert float(err[bad].max()) <= 2.0 * m, (what, k, nbad, float(err[bad].max()), m)
+    if gref32 is not None and tight32:
+        assert abs(got - ref32) <= 3e-6 * abs(ref32), (what, got, ref32)
+        for k in NAMES:
+            a, b = ggot[k].double(), gref32[k].double()
+            m = float(b.abs().max())
+            err = (a - b).abs()
+            bad = err > 5e-6 * m + 1e-14
+            # (fp32 against fp32: a sign may still flip where the difference is within rounding of zero)
+            assert int((bad & ~(err <= 2.0 * b.abs() + 5e-6 * m)).sum()) == 0 and int(bad.sum()) <= 1e-4 * bad.numel() + 1, \
+                (what, k, "fp32 reference", int(bad.sum()), float(err.max()), m)
 
 
 @pytest.mark.parametrize("B,K,H,W,seed", [(1, 1, 5, 7, 0), (2, 3, 37, 70, 1), (1, 9, 67, 129, 2), (2, 2, 130, 64, 3)])
@@ -71,11 +96,12 @@ def test_flow_warp_loss_matches_reference_block(hip_device, B, K, H, W, seed):
     from mobgs_amd.loss_utils import flow_warp_loss
     case = _case(B, K, H, W, seed)
     ref, gref = _run(RT.flow_warp_loss, case, "cpu", torch.float64)
+    ref32, gref32 = _run(RT.flow_warp_loss, case, "cpu", torch.float32)
     for combine in (True, False):
         got, ggot = _run(flow_warp_loss, case, hip_device, combine_taps=combine)
         # observed (scripts/observed_flow_loss_errors.py, against the fp32 CPU evaluation): loss 1e-7 relative; gradients
         # <= 5e-7 of the tensor's maximum (2.3e-6 on the atomically summed image gradients at the benchmark size)
-        _check(got, ggot, ref, gref, f"combine_taps={combine}")
+        _check(got, ggot, ref, gref, f"combine_taps={combine}", ref32, gref32)
 
 
 def test_zero_weight_is_a_constant_and_inputs_are_untouched(hip_device):
@@ -113,5 +139,6 @@ def test_flow_warp_loss_at_benchmark_size(hip_device):
     from mobgs_amd.loss_utils import flow_warp_loss
     case = _case(1, 3, 1014, 1352, 9, flow=3.0)
     ref, gref = _run(RT.flow_warp_loss, case, "cpu", torch.float64)
+    _, gref32 = _run(RT.flow_warp_loss, case, "cpu", torch.float32)  # only to tell flipped sgn() terms (see _check)
     got, ggot = _run(flow_warp_loss, case, hip_device)
-    _check(got, ggot, ref, gref, "benchmark size")
+    _check(got, ggot, ref, gref, "benchmark size", None, gref32, tight32=False)

@@ -1,0 +1,160 @@
+"""Single-pass tile lists (mobgs_project_and_bin_fused, round 5) against the two-pass path they replace.
+
+The fused path must be indistinguishable to every consumer: the same packed per-tile lists in the same order
+(flatten_ids, isect_ids, tile_offsets), the same box-intersection scan (cum_tiles), the same gradient-slot numbering
+(keep_scan) and a valid schedule -- with reach culling on AND off (off = gsplat's own lists, which other tests pin to the
+C oracle), through the C++ host path and the Python one, with ragged image sizes, several cameras, and when a tile's
+list outgrows its key segment (the call must then hand out EMPTY lists and the host must fall back to the two-pass
+rebuild and still return the right answer).
+"""
+import numpy as np
+import pytest
+import torch
+
+from mobgs_amd.synth import SynthCamera, splat_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _project(s, dev, W, H, fused, hint=None, C=1):
+    import mobgs_amd.rendering as R
+    old = R.FUSED_LISTS
+    R.FUSED_LISTS = fused
+    try:
+        t = {k: v.to(dev) for k, v in s.items()}
+        vm = t["viewmats"].expand(C, 4, 4).contiguous()
+        if C > 1:  # different cameras: shift each one a little
+            vm = vm.clone()
+            vm[:, 0, 3] += torch.linspace(-0.2, 0.2, C, device=dev)
+        Ks = t["Ks"].expand(C, 3, 3).contiguous()
+        if hint is not None:
+            key = R._workload_key(dev, C, t["means"].shape[0], W, H)
+            R._len_hint[key] = hint
+        before = R.fused_calls[0]
+        sp = R.SharedProjection(t["means"], t["quats"], t["scales"], t["opacities"], vm, Ks, W, H, want_isect_ids=True)
+        took_fused = R.fused_calls[0] > before
+        tl = sp.tl
+        n_box, n_isects = tl.n_box, tl.n_isects  # resolves (and rebuilds on overflow)
+        return sp, tl, took_fused, n_box, n_isects
+    finally:
+        R.FUSED_LISTS = old
+
+
+def _slots(tl, n_box):
+    """compact index of every box intersection j <= n_box (the gradient-slot numbering)"""
+    ks = tl.keep_scan.cpu().numpy().astype(np.int64).reshape(-1, 2049)
+    j = np.arange(n_box + 1)
+    return ks[j >> 11, 0] + ks[j >> 11, 1 + (j & 2047)]
+
+
+def _check_order(tl, nt):
+    order = tl.tile_order.cpu().numpy()
+    ids = order[order >= 0]
+    heavy = ids[(ids & (1 << 30)) != 0] & ~(1 << 30)
+    light = ids[(ids & (1 << 30)) == 0]
+    assert len(np.unique(heavy)) * 4 == len(heavy)
+    assert len(np.unique(light)) == len(light)
+    assert sorted(np.unique(heavy).tolist() + light.tolist()) == list(range(nt))
+
+
+def _compare(a, b, n_box, n_isects, nt):
+    assert torch.equal(a.cum_tiles, b.cum_tiles)
+    assert torch.equal(a.tile_offsets, b.tile_offsets)
+    assert torch.equal(a.flatten_ids[:n_isects], b.flatten_ids[:n_isects])
+    assert torch.equal(a.isect_ids[:n_isects], b.isect_ids[:n_isects])
+    assert np.array_equal(_slots(a, n_box), _slots(b, n_box))
+    _check_order(a, nt)
+    _check_order(b, nt)
+
+
+@pytest.mark.parametrize("culling", [True, False])
+@pytest.mark.parametrize("n,W,H,C", [(20_000, 512, 288, 1), (7_000, 333, 201, 3), (300_000, 1352, 1014, 1)])
+def test_fused_lists_equal_two_pass_lists(hip_device, culling, n, W, H, C):
+    import mobgs_amd.rendering as R
+    cam = SynthCamera().scaled(W, H)
+    s = splat_inputs(n, cam, 3, 9)
+    R.set_tile_culling(culling)
+    try:
+        _, ref, took, n_box, n_isects = _project(s, hip_device, W, H, fused=False, C=C)
+        assert not took
+        hint = ref.max_tile_len
+        _, got, took, n_box2, n_isects2 = _project(s, hip_device, W, H, fused=True, hint=hint, C=C)
+        assert took, "the single-pass path was not taken"
+        assert got.rebuilds == 0
+        assert (n_box2, n_isects2, got.max_tile_len) == (n_box, n_isects, ref.max_tile_len)
+        nt = C * ((W + 15) // 16) * ((H + 15) // 16)
+        _compare(got, ref, n_box, n_isects, nt)
+    finally:
+        R.set_tile_culling(True)
+
+
+def test_python_host_path_takes_the_fused_entry_point_too(hip_device):
+    import mobgs_amd.rendering as R
+    from mobgs_amd import _fast
+    W, H = 400, 240
+    cam = SynthCamera().scaled(W, H)
+    s = splat_inputs(15_000, cam, 5, 9)
+    _, ref, _, n_box, n_isects = _project(s, hip_device, W, H, fused=False)
+    _fast.reset(False)
+    try:
+        _, got, took, _, _ = _project(s, hip_device, W, H, fused=True, hint=ref.max_tile_len)
+    finally:
+        _fast.reset(None)
+    assert took and got.rebuilds == 0
+    _compare(got, ref, n_box, n_isects, ((W + 15) // 16) * ((H + 15) // 16))
+
+
+def test_segment_overflow_falls_back_to_the_two_pass_rebuild(hip_device):
+    """A hint far below the true longest list: the device hands out empty lists, the host sees longest > seg_stride,
+    rebuilds with the two-pass entry points and the NEXT frame's segments are large enough."""
+    import mobgs_amd.rendering as R
+    W, H = 512, 288
+    cam = SynthCamera().scaled(W, H)
+    s = splat_inputs(40_000, cam, 7, 9)
+    _, ref, _, n_box, n_isects = _project(s, hip_device, W, H, fused=False)
+    assert ref.max_tile_len > 100
+    over = R.seg_overflows[0]
+    _, got, took, _, _ = _project(s, hip_device, W, H, fused=True, hint=20)  # segments of 64 keys
+    assert took and got.rebuilds == 1 and R.seg_overflows[0] == over + 1
+    nt = ((W + 15) // 16) * ((H + 15) // 16)
+    _compare(got, ref, n_box, n_isects, nt)
+    _, again, took, _, _ = _project(s, hip_device, W, H, fused=True)  # the hint the rebuild left behind
+    assert took and again.rebuilds == 0
+    _compare(again, ref, n_box, n_isects, nt)
+
+
+def test_render_is_bit_identical_with_fused_lists(hip_device):
+    """End to end: the lean render() forward + backward through single-pass lists equals the two-pass run bit for bit
+    (same lists, same slots -> same kernels on the same data)."""
+    import mobgs_amd.rendering as R
+    from mobgs_amd.camera import PinholeCamera
+    from mobgs_amd.gaussian_model import GaussianParams
+    from mobgs_amd.gaussian_renderer import render
+    from mobgs_amd.helper_model import Sandwich
+    from mobgs_amd.synth import dynamic_extras, gaussian_cloud
+    dev = hip_device
+    W, H = 640, 360
+    scam = SynthCamera().scaled(W, H)
+    stat_p, dyn_p = gaussian_cloud(30_000, scam, 0), gaussian_cloud(15_000, scam, 1)
+    dyn_x = dynamic_extras(dyn_p["xyz"], 0)
+    torch.manual_seed(0)
+    dec = Sandwich(9, 3).to(dev)
+    v = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    res = {}
+    for fused in (False, True, True):
+        R.FUSED_LISTS = fused
+        try:
+            stat = GaussianParams(stat_p, None, dec, dev, requires_grad=True)
+            dyn = GaussianParams(dyn_p, dyn_x, dec, dev, requires_grad=True)
+            cam = PinholeCamera(W, H, scam.K, torch.eye(4), scam.time, scam.max_time, device=dev)
+            before = R.fused_calls[0]
+            out = render(cam, stat, dyn, None, torch.zeros(9, device=dev))
+            ((out["render"] * v).sum() + out["depth"].sum()).backward()
+            res[(fused, R.fused_calls[0] > before)] = (out["render"].detach().clone(), out["depth"].detach().clone(),
+                                                      stat._xyz.grad.clone(), dyn.control_xyz.grad.clone(),
+                                                      stat._opacity.grad.clone())
+        finally:
+            R.FUSED_LISTS = True
+    assert (True, True) in res, "the single-pass path never ran"
+    for a, b in zip(res[(False, False)], res[(True, True)]):
+        assert torch.equal(a, b)

@@ -210,7 +210,11 @@ def test_auxiliary_outputs_are_lazy(hip_device):
         assert profiler.summary()["raster_class_fwd"]["calls"] == 1
         assert torch.is_tensor(out["d_alpha"]) and torch.is_tensor(out["d_render"]) and torch.is_tensor(out["s_alpha"])
         assert profiler.summary()["raster_class_fwd"]["calls"] == 1
-        close(s_render, fx["out_s_render"], 0, 3e-5, "s_render", flip_frac=2e-3, flip_atol=0.01)
+        # one blend step through the decoder, derived (helpers.decoded_flip_bound), for <= 2e-4 of the elements -- the
+        # allowance of test_render_matches_reference_fixture (was a flat 0.01 for 2e-3 of them)
+        from helpers import decoded_flip_bound
+        fb = decoded_flip_bound(dyn.rgbdecoder, float(np.abs(fx["out_colors_precomp_final"]).max()))
+        close(s_render, fx["out_s_render"], 0, 3e-5, "s_render", flip_frac=2e-4, flip_atol=fb)
     finally:
         profiler.enable(False)
 
