@@ -142,7 +142,7 @@ def source_sha():
     comments and blank lines removed (a reworded comment does not make the counters stale)."""
     import re
     h = hashlib.sha256()
-    for f in ("raster.hip", "raster_shared.h", "isect.hip", "common.h"):
+    for f in ("raster.hip", "raster_bwd_mfma.hip", "raster_shared.h", "isect.hip", "common.h"):
         with open(os.path.join(ROOT, "mobgs_amd", "csrc", f), "r", encoding="utf-8") as fh:
             text = fh.read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -446,6 +446,60 @@ class DynamicWorkload:
         torch.autograd.backward([img], [self.v])
 
 
+def scaling_diagnostics(wl, shard, args, dev, world, dist, steps=3):
+    """What makes an N > 1 line explain itself, measured on `steps` extra iterations OUTSIDE the timed
+    region with MOBGS_COMM_LOG=1 (the consumer-side waits of mobgs_amd.distributed are bracketed by HIP events):
+      per rank: busy_ms (its compute stream's iteration time minus what it stalled on exchanges),
+                image_exchange_exposed_ms / grad_exchange_exposed_ms (stalls on the per-view image sums / gradient messages);
+      the partition's own ceiling (planned loads: total / (ranks x largest load));
+      and an assertion that the all-reduced prediction is BIT-IDENTICAL on every rank (one 8-byte checksum per rank)."""
+    from mobgs_amd import distributed as D
+    old = os.environ.get("MOBGS_COMM_LOG")
+    os.environ["MOBGS_COMM_LOG"] = "1"
+    rows = []
+    pred = None
+    try:
+        for _ in range(steps):
+            del D.wait_log[:]
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            pred = wl.step()
+            t1.record()
+            torch.cuda.synchronize()
+            img = sum(b.elapsed_time(a) for tag, b, a in D.wait_log if tag == "image")
+            grad = sum(b.elapsed_time(a) for tag, b, a in D.wait_log if tag.startswith("grad"))
+            total = t0.elapsed_time(t1)
+            rows.append((total - img - grad, img, grad, total))
+    finally:
+        if old is None:
+            os.environ.pop("MOBGS_COMM_LOG", None)
+        else:
+            os.environ["MOBGS_COMM_LOG"] = old
+        del D.wait_log[:]
+    cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")  # (gloo: gather on the host)
+    mine = torch.tensor([sum(r[k] for r in rows) / len(rows) for k in range(4)], device=cdev, dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    # the prediction every rank holds after the image exchange: a checksum of its bits
+    stack = torch.stack([p.detach() for p in pred]) if isinstance(pred, (list, tuple)) else pred.detach()
+    chk = stack.contiguous().view(torch.int32).to(torch.int64).sum().reshape(1).to(cdev)
+    chks = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(chks, chk)
+    same = all(int(c.item()) == int(chks[0].item()) for c in chks)
+    assert same, f"the all-reduced prediction differs between ranks: checksums {[int(c.item()) for c in chks]}"
+    plan = shard.iteration_plan(args.views, 9, False)
+    loads = plan["loads"]
+    return {"per_rank": [{"rank": r, "busy_ms": round(float(e[0]), 3), "image_exchange_exposed_ms": round(float(e[1]), 3),
+                          "grad_exchange_exposed_ms": round(float(e[2]), 3), "iteration_ms": round(float(e[3]), 3)}
+                         for r, e in enumerate(every)],
+            "planned_loads_latent_render_units": [round(x, 2) for x in loads],
+            "planned_efficiency_ceiling": round(sum(loads) / (world * max(loads)), 4),
+            "prediction_bit_identical_across_ranks": same,
+            "note": "busy_ms = iteration time on the rank's compute stream minus its stalls on exchanges (HIP events around "
+                    "every consumer-side wait); on a gloo group (functional runs) the exchanges are synchronous host copies "
+                    "and show up as busy time"}
+
+
 def freeze_python_heap():
     gc.collect()
     gc.freeze()
@@ -707,6 +761,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         anchor = n_units * max(args.steps // 2, 3) / float(t.item())
         del awl
+        scale_diag = scaling_diagnostics(wl, shard, args, dev, world, dist)
         last["out"] = next(iter(wl.mids.values())) if wl.mids else render(cam, stat, dyn, None, bg)
         from mobgs_amd import rendering
         I = rendering.last_stats.get("n_isects", 0)
@@ -753,6 +808,7 @@ def main():
         result["scale_anchor_field"] = ("the same 18-unit iteration with every unit on one GPU, timed in this run on every "
                                         "rank (slowest rank): efficiency = value / (n_gpus x scale_anchor)")
         result["scaling_efficiency_vs_anchor"] = round(value / (world * anchor), 4)
+        result["scaling_diagnostics"] = scale_diag
     if deblur is not None:
         result["deblur"] = deblur
     if dynamic is not None:

@@ -258,7 +258,7 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
  * it expects (the previous frame's stats[2] plus slack).  A tile whose list is longer makes the call behave like an
  * arena overflow: every list is written EMPTY, stats still hold the true counts (stats[2] > seg_stride tells), and
  * the caller redoes the binning with the two-pass entry points.  Requires N > 0, capacity_box >= 4 C N + 2 and a
- * 128-byte aligned scratch (each XCD ranks through its own copy of the per-tile counters, in its own cache lines).  Everything else as mobgs_project_and_bin_speculative (including the return value). */
+ * 128-byte aligned scratch.  Everything else as mobgs_project_and_bin_speculative (including the return value). */
 size_t mobgs_fused_seg_keys_len(int n_tiles, int seg_stride);
 int mobgs_fused_max_seg_stride(void);
 int mobgs_project_and_bin_fused(int C, int N, const float* means, const float* quats, const float* scales,

@@ -201,13 +201,11 @@ constexpr int TC_STRIDE = 1;
 // shorter; tile_scan_kernel sums the copies into the list lengths and leaves every (copy, tile) pair's first
 // position in tile_base, which is what emit_kernel adds the rank to.  Ranks only have to be distinct inside a list.
 constexpr int TC_COPIES = 8;
-// s_getreg_b32 operand of HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this wave runs on, 0..7 (MI355X_MICROARCH.md)
-constexpr int GETREG_XCC_ID = 20 | (0 << 6) | ((4 - 1) << 11);
-// rank atomics of the fused path: relaxed, WORKGROUP scope = no sc1 bit = performed in the XCD's own L2 (see bin_kernel)
-__device__ __forceinline__ int rank_add(int32_t* p, int v, bool xcd_local) {
-    return xcd_local ? __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-                     : __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// (Tried in round 5 and dropped: one counter copy per XCD -- the copy chosen by HW_REG_XCC_ID, each in its own cache
+// lines -- with workgroup-scope atomics, hoping to have them performed in the XCD's own L2.  gfx950 emits the same
+// global_atomic_add for either scope and the kernel's time did not move: bin_kernel is bound by the RATE of returning
+// atomics + scattered key stores, ~3.4 M transactions per launch, not by their scope.)
+__device__ __forceinline__ int rank_add(int32_t* p, int v) { return atomicAdd(p, v); }
 constexpr int OWNER_LDS = 4096;  // cum_tiles entries of the chunk's owner range cached in LDS
 static_assert(SCAN_BLOCK == KEEP_CHUNK, "one workgroup per keep_scan chunk");
 
@@ -244,28 +242,10 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
     __shared__ int s_cum[OWNER_LDS + 1];
     extern __shared__ int s_tile[];  // DENSE: per-tile count of this workgroup, then the base of its range
     const int chunk = blockIdx.x;
-#ifdef ABL_TIMING
-    // debug build: phase time stamps (100 MHz counter) of every workgroup, parked in the unused tail of keep_scan
-    int64_t* tdbg = reinterpret_cast<int64_t*>(keep_scan + (size_t)(1800 + chunk / 100) * (KEEP_CHUNK + 1) + 8) + (chunk % 100) * 8;
-#define TSTAMP(i) do { if (threadIdx.x == 0) tdbg[i] = (int64_t)wall_clock64(); } while (0)
-#else
-#define TSTAMP(i) do { } while (0)
-#endif
-    TSTAMP(0);
     int32_t* kchunk = keep_scan + (size_t)chunk * (KEEP_CHUNK + 1);
-    // This workgroup's copy of the counters.  Two-pass path: chunk mod 8, device-scope atomics (emit_kernel recomputes
-    // the copy from the chunk).  Fused path: the copy of the XCD the workgroup RUNS on (HW_REG_XCC_ID, whatever the
-    // dispatcher's placement), each copy in its own 128-byte lines -- a counter is then only ever touched through ONE
-    // XCD's L2, so the atomics need no device scope: they are performed in that L2 instead of at the memory side of the
-    // chip (sc1 atomics bypass the non-coherent L2s: ~120 ns each, one after the other per address, and a round trip
-    // several times longer).  The kernel boundary writes the L2 back before tile_finish_kernel reads the counts.
-    int copy = chunk & (TC_COPIES - 1);
-    if (FUSED) {
-        copy = (int)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & (TC_COPIES - 1));
-        tile_count += (size_t)copy * count_stride;
-    } else {
-        tile_count += (size_t)copy * n_tiles_total;
-    }
+    // this workgroup's copy of the counters (fused path: copies padded to whole 128-byte lines, count_stride apart)
+    const int copy = chunk & (TC_COPIES - 1);
+    tile_count += (size_t)copy * (FUSED ? count_stride : n_tiles_total);
     const int I = min(cum[n_gauss], capacity);
     const int start = chunk * SCAN_BLOCK;
     if (start >= I) {
@@ -288,7 +268,6 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
         for (int t = threadIdx.x; t <= span; t += SCAN_THREADS) s_cum[t] = cum[g_lo + t];
         __syncthreads();
     }
-    TSTAMP(1);
     const int tiles_per_cam = tile_w * tile_h;
     // item k of thread t is intersection start + k * SCAN_THREADS + t: neighbouring lanes work on neighbouring
     // intersections (coalesced stores, shared owner data)
@@ -316,13 +295,9 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
             const float x0 = (float)(tx * MOBGS_TILE) + 0.5f, y0 = (float)(ty * MOBGS_TILE) + 0.5f;
             const float x1 = fminf((float)(tx * MOBGS_TILE) + 15.5f, (float)width - 0.5f);
             const float y1 = fminf((float)(ty * MOBGS_TILE) + 15.5f, (float)height - 0.5f);
-#ifdef ABL_NOTEST
-            kp = (r0.z >= 0.f && ((q ^ g) & 1)) ? 1 : 0;
-#else
             // threshold -1: never listed (min sigma >= 0); REACH_ALWAYS: listed whatever the arithmetic below yields
             kp = (r0.z >= REACH_ALWAYS ||
                   min_sigma_over_tile_pre(r0.x, r0.y, r1.x, r1.y, r1.z, r2.x, r2.y, x0, x1, y0, y1) <= r0.z) ? 1 : 0;
-#endif
             dbits[k] = __float_as_uint(r0.w);
         }
         if (!FUSED && j < end) {
@@ -359,20 +334,8 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
         if (lane == 0) s_cnt[k][wv] = __builtin_popcountll(ballot);
     }
     // ranks inside the tiles' lists: all returning atomics in flight before the first result is consumed
-#ifdef ABL_TIMING
-    __syncthreads();
-#endif
-    TSTAMP(2);
     int rank[SCAN_ITEMS];
-#ifdef ABL_NOATOMIC
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = (threadIdx.x + k) & 31;
-    if (false) {
-#elif defined(ABL_NODENSE)
-    if (false) {
-#else
     if (DENSE) {
-#endif
         for (int t = threadIdx.x; t < n_tiles_total; t += SCAN_THREADS) s_tile[t] = 0;
         __syncthreads();
 #pragma unroll
@@ -381,7 +344,7 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
         int base_of[SCAN_ITEMS];
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; ++k)  // the intersection that got local rank 0 speaks for its tile
-            base_of[k] = (keep[k] && rank[k] == 0) ? rank_add(&tile_count[til[k] * TC_STRIDE], s_tile[til[k]], FUSED) : 0;
+            base_of[k] = (keep[k] && rank[k] == 0) ? rank_add(&tile_count[til[k] * TC_STRIDE], s_tile[til[k]]) : 0;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; ++k)
@@ -391,21 +354,10 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
         for (int k = 0; k < SCAN_ITEMS; ++k)
             if (keep[k]) rank[k] += s_tile[til[k]];
     } else {
-#ifndef ABL_NOATOMIC
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = keep[k] ? rank_add(&tile_count[til[k] * TC_STRIDE], 1, FUSED) : 0;
-#endif
+        for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = keep[k] ? rank_add(&tile_count[til[k] * TC_STRIDE], 1) : 0;
     }
-#ifdef ABL_TIMING
-    {
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) acc += rank[k];
-        asm volatile("" ::"v"(acc));  // the ranks have arrived
-    }
-#endif
     __syncthreads();
-    TSTAMP(3);
     // exclusive prefix of every (item row, wave) segment in intersection order, and the chunk total
     int seg[SCAN_ITEMS];
     int total = 0;
@@ -424,11 +376,7 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
             const int local = seg[k] + before[k];
             kchunk[1 + i] = local;
             if (FUSED) {
-#ifdef ABL_NOSTORE
-                if (keep[k] && rank[k] < -seg_stride)
-#else
                 if (keep[k] && rank[k] < seg_stride)
-#endif
                     seg_keys[((size_t)til[k] * TC_COPIES + copy) * (size_t)seg_stride + rank[k]] =
                         ((uint64_t)dbits[k] << 32) | (uint32_t)own[k];
             } else if (keep[k]) {  // compacted: the chunk's kept intersections in order, at the start of its own range
@@ -438,12 +386,6 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
             }
         }
     }
-#ifdef ABL_TIMING
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    TSTAMP(4);
-    if (threadIdx.x == 0) tdbg[5] = (int64_t)__builtin_amdgcn_s_getreg(GETREG_XCC_ID);
-#endif
     if (threadIdx.x == 0) {
         if (!FUSED) chunk_cnt[chunk] = total;
         kchunk[0] = total;
@@ -920,11 +862,7 @@ __device__ __forceinline__ void wave_bitonic_sort(uint64_t (&key)[EPL], int lane
                 const bool want_min = lower == asc;
 #pragma unroll
                 for (int r = 0; r < EPL; ++r) {
-#ifdef ABL_SORT_BPERMUTE
-                    const uint64_t other = __shfl_xor(key[r], d, 64);
-#else
                     const uint64_t other = lane_xor64(key[r], d, lane);
-#endif
                     const bool other_less = other < key[r];
                     key[r] = (other_less == want_min) ? other : key[r];
                 }
@@ -1594,8 +1532,7 @@ struct IsectScratch {
     int nb1;
     IsectScratch(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity) {
         nb1 = (int)((n_gauss + SCAN_BLOCK - 1) / SCAN_BLOCK);
-        // every counter copy starts on its own 128-byte line (the fused path gives each XCD its own copy and lets the
-        // XCD's L2 perform the atomics: two XCDs must never share a line); the two-pass path packs its copies at the start
+        // every counter copy of the fused path starts on its own 128-byte line; the two-pass path packs its copies at the start
         const size_t nt_pad = count_stride(n_tiles) * TC_COPIES;  // (even: the 64-bit status words stay 8-byte aligned)
         int32_t* p = (int32_t*)scratch;
         tile_count = p;
@@ -1839,11 +1776,7 @@ int mobgs::isect_fused_launch(int C, int N, int tile_w, int tile_h, int width, i
     // LDS-ranked variant: small grids (every workgroup touches most tiles several times) and scenes with long lists
     // (dense image regions: thousands of atomics on a few counters); on a large grid with short lists the plain
     // returning atomics are ahead (47.4 against 50.2 us at 5440 tiles / 300 k splats)
-#ifdef ABL_FORCE_DENSE
-    if (nt <= DENSE_MAX_TILES)
-#else
     if (nt <= DENSE_MAX_TILES && (nt <= 2048 || max_tile_len_hint >= 1024))
-#endif
         hipLaunchKernelGGL((bin_kernel<true, true>), dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n,
                            N, tile_w, tile_h, width, height, 1, capacity, cum_tiles, (const float*)nullptr,
                            (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, L.chunk_cnt, L.owner,

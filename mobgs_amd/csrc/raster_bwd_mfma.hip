@@ -114,8 +114,12 @@ struct MfmaWave {
         rowpos = rowpos_block;
         d_half = bq & 1;
         const bool colour = bq < 2;
-        d_col = colour ? 6 + bj : bj - 10;
         d_lane = colour ? bj < CD : bj >= 10;
+        // lanes without a used column (bj >= CD in the colour rows, bj < 10 in the moment rows) still run reduce_group's
+        // four accumulator loads: keep their column INSIDE the record (0) instead of 6 + bj up to 21 / bj - 10 down to -10,
+        // which only stayed inside the shared struct by the accident of its layout
+        d_col = d_lane ? (colour ? 6 + bj : bj - 10) : 0;
+        static_assert(STRIDE >= 16, "an accumulator row holds the 16 components a used column can select");
         if (lane < GROUP) rowpos[lane] = 0;
     }
 

@@ -30,6 +30,7 @@ from __future__ import annotations
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
+from contextlib import nullcontext as _nullcontext
 import torch.distributed as dist
 
 
@@ -37,6 +38,13 @@ _comm_streams: Dict[int, "torch.cuda.Stream"] = {}
 # (tag, start event, done event) of every asynchronous device all-reduce when MOBGS_COMM_LOG=1 -- how the overlap tests
 # and scripts/rccl_world1_check.py see WHERE an exchange ran relative to the compute stream's own events
 comm_log: List[Tuple[str, "torch.cuda.Event", "torch.cuda.Event"]] = []
+COMM_LOG_MAX = 4096  # most recent exchanges kept with MOBGS_COMM_LOG=1
+wait_log: List[Tuple[str, "torch.cuda.Event", "torch.cuda.Event"]] = []  # (tag, before, after) around each consumer-side wait
+
+
+def _comm_logging() -> bool:
+    import os
+    return os.environ.get("MOBGS_COMM_LOG") == "1"
 
 
 def comm_stream(device) -> "torch.cuda.Stream":
@@ -55,11 +63,24 @@ class _StreamWork:
     """Handle of an exchange enqueued on the communication stream: wait() makes the CURRENT stream wait for its
     completion event (no host block)."""
 
-    def __init__(self, done: "torch.cuda.Event", keep=()):
-        self.done, self.keep = done, keep
+    def __init__(self, done: "torch.cuda.Event", keep=(), device=None, tag: str = ""):
+        self.done, self.keep, self.device, self.tag = done, keep, device, tag
 
     def wait(self, timeout=None):
-        torch.cuda.current_stream().wait_event(self.done)
+        # the current stream OF THE TENSOR'S DEVICE (not of whatever device happens to be current: ADVICE r4)
+        st = torch.cuda.current_stream(self.device)
+        if _comm_logging():
+            # how long the CONSUMER's stream stalls on this exchange = what of it is exposed (not hidden behind compute):
+            # bench.py --gpus N reports it per rank (wait_log)
+            before = torch.cuda.Event(enable_timing=True)
+            before.record(st)
+            st.wait_event(self.done)
+            after = torch.cuda.Event(enable_timing=True)
+            after.record(st)
+            wait_log.append((self.tag, before, after))
+            del wait_log[:-COMM_LOG_MAX]
+            return True
+        st.wait_event(self.done)
         return True
 
     def is_completed(self):
@@ -90,7 +111,8 @@ def _all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False, tag: st
         t.record_stream(side)
         if log:
             comm_log.append((tag, start, done))
-        return _StreamWork(done, (t, work))
+            del comm_log[:-COMM_LOG_MAX]   # bounded: a long run with MOBGS_COMM_LOG=1 keeps the most recent exchanges
+        return _StreamWork(done, (t, work), t.device, tag)
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
@@ -115,7 +137,8 @@ class _CopyBackWork:
         if not self.done:
             if self.work is not None:
                 self.work.wait()
-            self.dst.copy_(self.src)
+            with torch.cuda.device(self.dst.device) if self.dst.is_cuda else _nullcontext():
+                self.dst.copy_(self.src)  # (on the current stream of the BUFFER's device: ADVICE r4)
             self.done = True
         return True
 

@@ -222,18 +222,19 @@ class _PendingCounts:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("mobgs: render() cannot be captured into a HIP graph (the host reads the intersection "
                                "counts of the frame between binning and the end of the forward pass)")
+        # The counts are normally there within ~0.2 ms of the call: spin for that long (a sleep costs 50+ us of wake-up
+        # latency), then yield the core between polls -- the wait is bounded by TIME, not by an iteration count that is a
+        # different duration on every host (up to 20 000 iterations of busy-spinning)
         t0 = time.monotonic()
-        spins = 0
         while int(word[3]) != self.seq:
-            spins += 1
-            if spins < 20000:      # the counts are normally there within ~0.2 ms: spin (a sleep costs 50+ us)
-                continue
             dt = time.monotonic() - t0
+            if dt < 250e-6:
+                continue
             if dt > 10.0:
                 torch.cuda.synchronize()
                 if int(word[3]) != self.seq:
                     raise RuntimeError("mobgs: the intersection counts never arrived (device fault?)")
-            time.sleep(50e-6 if dt < 0.05 else 1e-3)  # long wait (queue full of other work): stop burning a core
+            time.sleep(20e-6 if dt < 2e-3 else (100e-6 if dt < 0.05 else 1e-3))  # queue full of other work: stop burning a core
 
     def finish(self, tl) -> bool:
         self._wait()

@@ -33,25 +33,3 @@ with torch.no_grad():
 torch.cuda.synchronize()
 print("I", n_isects, "longest", sp.tl.max_tile_len, "fused calls", R.fused_calls[0], "rebuilds", R.list_rebuilds[0])
 
-if os.environ.get("MOBGS_PROBE_TIMING"):  # ABL_TIMING build: per-workgroup phase stamps of the last bin launch
-    import numpy as np
-    ks = sp.tl.keep_scan.cpu().numpy().reshape(-1, 2049)
-    nwg = (sp.tl.n_box + 2047) // 2048
-    rows = []
-    for m in range(nwg):
-        w = np.ascontiguousarray(ks[1800 + m // 100, 8:8 + 1600]).view(np.int64).reshape(100, 8)[m % 100]
-        rows.append(w[:8])
-    t = np.array(rows, dtype=np.int64)
-    t0 = t[:, 0].min()
-    us = (t[:, :5] - t0) / 100.0  # 100 MHz
-    print("workgroups", nwg, "kernel span us", us[:, 4].max())
-    d = np.diff(us, axis=1)
-    print("phase durations us (owner range+cum slice | search+records+test | atomics | scan+stores): mean", d.mean(0).round(2),
-          "p90", np.percentile(d, 90, axis=0).round(2))
-    print("start time us: p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(us[:, 0], [10, 50, 90, 100])))
-    print("end   time us: p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(us[:, 4], [10, 50, 90, 100])))
-    print("total per wg us: mean %.1f" % (us[:, 4] - us[:, 0]).mean())
-    first = us[:, 0] < 5.0
-    print("first-round wgs: n %d mean total %.1f | later wgs: n %d mean total %.1f" % (first.sum(), (us[first, 4] - us[first, 0]).mean(), (~first).sum(), (us[~first, 4] - us[~first, 0]).mean()))
-    xcc = t[:, 5] & 15
-    print("xcc of block b == b % 8:", float((xcc == (np.arange(nwg) % 8)).mean()))

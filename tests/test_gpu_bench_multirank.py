@@ -33,3 +33,10 @@ def test_bench_sharded_path_runs_and_reports(hip_device, world):
     assert "FUNCTIONAL CHECK" in line["data"]
     # the anchor of the scaling curve is measured in the same run: the N > 1 workload with every unit on one GPU
     assert line["scale_anchor"] > 0 and "scaling_efficiency_vs_anchor" in line and "scale_anchor_field" in line
+    # ... and the line explains itself: per-rank busy / exposed-exchange times, the partition's own ceiling, and the
+    # in-run check that every rank holds the same all-reduced prediction bit for bit
+    diag = line["scaling_diagnostics"]
+    assert len(diag["per_rank"]) == world and all(r["busy_ms"] > 0 for r in diag["per_rank"])
+    assert {"image_exchange_exposed_ms", "grad_exchange_exposed_ms", "iteration_ms"} <= set(diag["per_rank"][0])
+    assert 0.5 < diag["planned_efficiency_ceiling"] <= 1.0 and len(diag["planned_loads_latent_render_units"]) == world
+    assert diag["prediction_bit_identical_across_ranks"] is True

@@ -68,20 +68,30 @@ def test_blurry_view_k9_blce_matches_reference_fixture(hip_device, blce_mode):
         assert g is not None and g is not False, "BLCE must run as a captured HIP graph here (no eager fallback)"
     else:
         assert g is None, "the fused kernels must have been used (no torch module call)"
-    # an alpha within an ulp of 1/255 is kept by one exp() and dropped by the other: <= 0.1 % of the pixels may move
-    # by one such blend step
-    close(pred[0], fx["out_pred"], 2e-5, 2e-5, "blurry prediction", flip_frac=1e-3, flip_atol=5e-3)
-    close(mid["render"], fx["out_mid_render"], 2e-5, 2e-5, "mid render", flip_frac=1e-3, flip_atol=5e-3)
+    # an alpha within an ulp of 1/255 is kept by one exp() and dropped by the other: such a pixel moves by ONE blend step
+    # passed through the decoder -- derived from the decoder's weights and the splat colours' range
+    # (helpers.decoded_flip_bound), not a flat 5e-3.  Observed: no flipped element (largest error 2.5e-5); allowed for 2e-4
+    # of the mid render's elements and, the prediction being the mean of nine renders, nine times as many there
+    from helpers import decoded_flip_bound
+    from mobgs_amd.gaussian_renderer import _prep, _times
+    with torch.no_grad():
+        cmax = float(_prep(stat, dyn, _times(cam, None, dev))[4].abs().max())
+    fb = decoded_flip_bound(dyn.rgbdecoder, cmax)
+    close(pred[0], fx["out_pred"], 2e-5, 2e-5, "blurry prediction", flip_frac=9 * 2e-4, flip_atol=fb)
+    close(mid["render"], fx["out_mid_render"], 2e-5, 2e-5, "mid render", flip_frac=2e-4, flip_atol=fb)
     close(mid["depth"], fx["out_mid_depth"], 2e-5, 2e-5 * float(np.abs(fx["out_mid_depth"]).max()), "mid depth")
     close(mid["d_alpha"], fx["out_mid_d_alpha"], 2e-5, 2e-5, "mid d_alpha")
     assert torch.equal(mid["radii"].cpu(), torch.from_numpy(fx["out_radii"]))
     ref = fx["grad_viewspace_points"]
+    # gradients through nine renders with BLCE-warped cameras: observed at most ONE element per tensor beyond
+    # rtol 2e-3 + 1e-4 max, the largest error 2.3e-4 of the maximum -> 1e-3 of the elements up to 1e-3 max
+    # (was 5e-3 of them up to 5e-3 max)
     close(mid["viewspace_points"].grad, ref, 2e-3, 1e-4 * float(np.abs(ref).max()), "viewspace gradient",
-          flip_frac=5e-3, flip_atol=5e-3 * float(np.abs(ref).max()))
+          flip_frac=1e-3, flip_atol=1e-3 * float(np.abs(ref).max()))
     for k, leaf in leaf_map(stat, dyn).items():
         ref = fx["grad_" + k]
         sc = float(np.abs(ref).max())
-        close(leaf.grad, ref, 2e-3, 1e-4 * sc + 1e-8, f"grad {k}", flip_frac=5e-3, flip_atol=5e-3 * sc)
+        close(leaf.grad, ref, 2e-3, 1e-4 * sc + 1e-8, f"grad {k}", flip_frac=1e-3, flip_atol=1e-3 * sc)
     n = 0
     for k, p in kern.model.named_parameters():
         if "bgrad_" + k in fx:
@@ -179,9 +189,10 @@ def test_sharded_iteration_world2_on_one_gpu_equals_single_process(hip_device, w
     sc = float(ref_flat.abs().max())
     for rank, pred, flat, _ in results:
         close(pred, ref_pred, 1e-5, 1e-5, f"rank {rank}: predictions")
-        # summation order differs (per-rank partial sums, then the reduction): fp32 round-off only
-        close(flat, ref_flat, 1e-3, 2e-5 * sc, f"rank {rank}: flat gradient + statistics buffer", flip_frac=2e-4,
-              flip_atol=1e-2 * sc)
+        # summation order differs (per-rank partial sums, then the reduction): fp32 round-off only -- both runs are THIS
+        # build's kernels taking the same discrete decisions, so there is no flip allowance (was 2e-4 of the entries up to
+        # 1e-2 of the maximum)
+        close(flat, ref_flat, 1e-3, 2e-5 * sc, f"rank {rank}: flat gradient + statistics buffer")
 
 
 # ---------------------------------------------------------------------------------------------------------------------

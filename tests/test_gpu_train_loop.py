@@ -78,7 +78,16 @@ dist.destroy_process_group()
 print("PLAIN", plain); print("SHARDED", sharded)
 worst = max(abs(a - b) / abs(a) for a, b in zip(plain, sharded))
 print("WORST", worst)
-sys.exit(0 if worst < 2e-2 else 1)
+# a world-1 group: every exchange is an identity; what differs is the ORDER of fp32 additions (the sharded loop
+# back-propagates view by view into per-view flat buffers and adds them up at the end).  The first loss (same parameters,
+# same forward) must agree to rounding; from then on Adam divides every gradient element by its running RMS, so an element
+# whose gradient is within rounding of zero moves by ~lr in one loop and not in the other -- observed on the GPU: 8e-8
+# relative at iteration 0, growing to 2.0e-4 at iteration 7 (two runs of the SAME loop: 8e-7).  Allowed: 1e-6 on the first
+# loss, 6e-4 (3x observed) on the curve (was 2e-2: VERDICT r4 item 2)
+first = abs(plain[0] - sharded[0]) / abs(plain[0])
+print("FIRST", first)
+sys.exit(0 if (worst < 6e-4 and first < 1e-6) else 1)
 """ % (root, root)
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    tail = [ln for ln in out.stdout.splitlines() if ln.startswith(("PLAIN", "SHARDED", "WORST"))]
+    assert out.returncode == 0, (tail, out.stderr[-1500:])
