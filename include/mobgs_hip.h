@@ -294,6 +294,22 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
                      float* alphas, int32_t* last_ids, uint8_t* isect_reach, const MobgsTuning* tuning,
                      void* stream);
 
+/* mobgs_raster_fwd + the Sandwich decoder as the compositor's EPILOGUE (round 5): for the 9-feature + depth pass of
+ * render() (channels = 9, extra != NULL, MobgsTuning.block_walk on) the kernel also writes what mobgs_decoder_fwd_many
+ * would compute from `render` / `alphas` -- rgb [C,3,H,W] and the expected depth [C,H,W] -- while the pixel's features are
+ * still in registers: no decoder launch and no re-read of the feature image (which is written all the same: the backward
+ * passes read it).  Pinhole rays only: ray_intr [fx, fy, cx, cy] and ray_c2w (the first 12 entries of the row-major
+ * camera-to-world matrix) per camera, intr_stride / c2w_stride floats apart (0 = shared); w1 [6,12], w2 [3,6] as
+ * /root/reference/helper_model.py:19-28.  Bit-identical to the two separate calls.  Other channel counts / the quadrant
+ * kernel: MOBGS_E_UNSUPPORTED (call mobgs_raster_fwd and mobgs_decoder_fwd_many). */
+int mobgs_raster_fwd_decode(int C, int N, int channels, int width, int height, const float* means2d,
+                            const float* conics, const float* colors, int colors_per_camera, const float* opacities,
+                            int opac_per_camera, const float* extra, const float* backgrounds, const int32_t* radii,
+                            const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
+                            float* records, float* render, float* alphas, int32_t* last_ids, uint8_t* isect_reach,
+                            const float* ray_intr, int intr_stride, const float* ray_c2w, int c2w_stride, const float* w1,
+                            const float* w2, float* rgb, float* depth, const MobgsTuning* tuning, void* stream);
+
 /* ---- K7: rasterise backward (replaces gsplat rasterize_to_pixels bwd) ----------------------------------
  * Deterministic two-stage gradient reduction, no floating-point atomics:
  *   stage 1 (mobgs_raster_bwd) walks every tile back to front and writes ONE gradient record

@@ -17,6 +17,7 @@
 // channels-last image [H,W,10] (one 40-byte row per lane), the planar ray map [6,H,W] and writes planar rgb
 // [3,H,W] + depth [H,W]: every access is a unit-stride stream.  HBM-bound: 68 B read + 16 B written per pixel.
 #include "common.h"
+#include "decoder_shared.h"
 
 namespace mobgs {
 
@@ -39,47 +40,6 @@ __device__ inline Weights load_weights(const float* __restrict__ w1, const float
 #pragma unroll
     for (int k = 0; k < 18; ++k) W.w2[k] = w2[k];
     return W;
-}
-
-// The 90 weights + the camera + the kernel's pointers do not fit the SGPR file: kept live across the pixel loop, the
-// register allocator parks the excess in VGPR lanes and every iteration pays ~190 v_readlane_b32 (half-rate VALU) to get
-// them back -- as many issue slots as the arithmetic.  Instead each use re-reads its weights with scalar loads from a
-// pointer the optimiser cannot see through (so the loads stay inside the loop, next to their use): they hit the scalar
-// cache and issue on the scalar unit, off the VALU.
-typedef const float __attribute__((address_space(4))) * ConstWeights;  // constant address space: scalar loads
-__device__ __forceinline__ ConstWeights reload_here(const float* p) {
-    unsigned long long v = (unsigned long long)p;
-    asm volatile("" : "+s"(v));
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (ConstWeights)(((unsigned long long)hi << 32) | lo);
-}
-
-struct RayCam {
-    float fx, fy, cx, cy;
-    float c2w[12];  // row-major 3x4: [R | t], camera -> world
-};
-__device__ inline RayCam load_raycam(const float* __restrict__ intr, const float* __restrict__ c2w) {
-    RayCam c;
-    c.fx = intr[0]; c.fy = intr[1]; c.cx = intr[2]; c.cy = intr[3];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) c.c2w[k] = c2w[k];
-    return c;
-}
-// origin + normalised direction of pixel p (row-major, width W); also returns the local direction and 1/|d|
-__device__ inline void pixel_ray(const RayCam& c, int p, int W, float r[6], float loc[2], float& inv_n) {
-    const int py = p / W, px = p - py * W;
-    loc[0] = ((float)px + 0.5f - c.cx) / c.fx;
-    loc[1] = ((float)py + 0.5f - c.cy) / c.fy;
-    float d[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) d[i] = c.c2w[4 * i] * loc[0] + c.c2w[4 * i + 1] * loc[1] + c.c2w[4 * i + 2];
-    inv_n = 1.f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        r[i] = c.c2w[4 * i + 3];
-        r[3 + i] = d[i] * inv_n;
-    }
 }
 
 // per-image strides of a batched launch (grid.y = images; all 0 for one image): floats between consecutive images' ray
@@ -108,37 +68,20 @@ decoder_fwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
     if (!rays) cam = load_raycam(ray_intr + blockIdx.y * bt.intr_stride, ray_c2w + blockIdx.y * bt.c2w_stride);
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         const float* f = feat_hw + (size_t)p * CF;
-        float x[12];
+        float fr[10], r[6], out[3];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) x[k] = f[3 + k];
+        for (int k = 0; k < 9; ++k) fr[k] = f[k];
+        fr[9] = 0.f;
         if (rays) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) x[6 + k] = rays[(size_t)k * P + p];
+            for (int k = 0; k < 6; ++k) r[k] = rays[(size_t)k * P + p];
         } else {
             float loc[2], inv_n;
-            pixel_ray(cam, p, width, x + 6, loc, inv_n);
+            pixel_ray(cam, p, width, r, loc, inv_n);
         }
-        float h[6];
+        sandwich_forward(w1, w2, fr, r, out);
 #pragma unroll
-        for (int jg = 0; jg < 6 / W1_ROWS; ++jg) {  // W1_ROWS rows of W1 in SGPRs at a time
-            const ConstWeights w1a = reload_here(w1 + 12 * W1_ROWS * jg);
-#pragma unroll
-            for (int jj = 0; jj < W1_ROWS; ++jj) {
-                float s = 0.f;
-#pragma unroll
-                for (int c = 0; c < 12; ++c) s = __fmaf_rn(w1a[12 * jj + c], x[c], s);
-                h[W1_ROWS * jg + jj] = fmaxf(s, 0.f);
-            }
-        }
-        const ConstWeights w2a = reload_here(w2);
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            float y = 0.f;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) y = __fmaf_rn(w2a[6 * o + j], h[j], y);
-            const float z = f[o] + y;
-            rgb[(size_t)o * P + p] = 1.f / (1.f + __expf(-z));
-        }
+        for (int o = 0; o < 3; ++o) rgb[(size_t)o * P + p] = out[o];
         if (has_depth) depth[p] = f[9] / fmaxf(alphas[p], 1e-10f);
     }
 }

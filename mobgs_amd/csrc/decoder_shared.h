@@ -1,0 +1,129 @@
+// Pieces of the Sandwich decoder shared by decoder.hip (its own kernels) and raster.hip (the decoder as the epilogue of
+// the forward compositor): weight reloads through the scalar unit, the pinhole ray of a pixel, and ONE evaluation of
+//   rgb = sigmoid(albedo + W2 relu(W1 [spec | timefeat | rays])),  depth = accumulated depth / max(alpha, 1e-10)
+// (/root/reference/helper_model.py:19-28, gsplat's "ED" post-process) -- the same instruction sequence wherever it runs,
+// so a fused and a separate decode give bit-identical images.
+#pragma once
+#include "common.h"
+
+namespace mobgs {
+
+constexpr int W1_ROWS_SHARED = 2;  // rows of the first layer held in SGPRs at a time (see reload_here)
+
+// The 90 weights + the camera + the kernel's pointers do not fit the SGPR file: kept live across the pixel loop, the
+// register allocator parks the excess in VGPR lanes and every iteration pays ~190 v_readlane_b32 (half-rate VALU) to get
+// them back -- as many issue slots as the arithmetic.  Instead each use re-reads its weights with scalar loads from a
+// pointer the optimiser cannot see through (so the loads stay inside the loop, next to their use): they hit the scalar
+// cache and issue on the scalar unit, off the VALU.
+typedef const float __attribute__((address_space(4))) * ConstWeights;  // constant address space: scalar loads
+__device__ __forceinline__ ConstWeights reload_here(const float* p) {
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+s"(v));
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (ConstWeights)(((unsigned long long)hi << 32) | lo);
+}
+
+struct RayCam {
+    float fx, fy, cx, cy;
+    float c2w[12];  // row-major 3x4: [R | t], camera -> world
+};
+__device__ inline RayCam load_raycam(const float* __restrict__ intr, const float* __restrict__ c2w) {
+    RayCam c;
+    c.fx = intr[0]; c.fy = intr[1]; c.cx = intr[2]; c.cy = intr[3];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) c.c2w[k] = c2w[k];
+    return c;
+}
+// origin + normalised direction of pixel (px, py); also returns the local direction and 1/|d|.  Every product-sum is
+// an explicit FMA: this runs in decoder.hip AND as the compositor's epilogue in raster.hip, two translation units with
+// different vectoriser / contraction settings, and both must produce the same bits.
+__device__ inline void pixel_ray_xy(const RayCam& c, int px, int py, float r[6], float loc[2], float& inv_n) {
+    loc[0] = ((float)px + 0.5f - c.cx) / c.fx;
+    loc[1] = ((float)py + 0.5f - c.cy) / c.fy;
+    float d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = __fmaf_rn(c.c2w[4 * i], loc[0], __fmaf_rn(c.c2w[4 * i + 1], loc[1], c.c2w[4 * i + 2]));
+    inv_n = 1.f / sqrtf(__fmaf_rn(d[0], d[0], __fmaf_rn(d[1], d[1], d[2] * d[2])));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        r[i] = c.c2w[4 * i + 3];
+        r[3 + i] = d[i] * inv_n;
+    }
+}
+__device__ inline void pixel_ray(const RayCam& c, int p, int W, float r[6], float loc[2], float& inv_n) {
+    const int py = p / W, px = p - py * W;
+    pixel_ray_xy(c, px, py, r, loc, inv_n);
+}
+
+// One pixel: f[0..9] = the composited features (+ accumulated depth in f[9] when has_depth), rays r[6] -> rgb[3]
+__device__ __forceinline__ void sandwich_forward(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                 const float (&f)[10], const float (&r)[6], float (&rgb)[3]) {
+    float x[12];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        x[k] = f[3 + k];
+        x[6 + k] = r[k];
+    }
+    float h[6];
+#pragma unroll
+    for (int jg = 0; jg < 6 / W1_ROWS_SHARED; ++jg) {  // W1_ROWS_SHARED rows of W1 in SGPRs at a time
+        const ConstWeights w1a = reload_here(w1 + 12 * W1_ROWS_SHARED * jg);
+#pragma unroll
+        for (int jj = 0; jj < W1_ROWS_SHARED; ++jj) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) s = __fmaf_rn(w1a[12 * jj + c], x[c], s);
+            h[W1_ROWS_SHARED * jg + jj] = fmaxf(s, 0.f);
+        }
+    }
+    const ConstWeights w2a = reload_here(w2);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float y = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) y = __fmaf_rn(w2a[6 * o + j], h[j], y);
+        const float z = f[o] + y;
+        rgb[o] = 1.f / (1.f + __expf(-z));
+    }
+}
+
+// NPX pixels at once, WEIGHTS OUTER: each group of W1 rows (and W2) is fetched through the scalar unit once for all the
+// pixels of the lane instead of once per pixel -- in the compositor's epilogue the wave has nothing else to hide those
+// scalar-load round trips behind.  Per pixel the same FMA chains as sandwich_forward: bit-identical.
+template <int NPX>
+__device__ __forceinline__ void sandwich_forward_n(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                   const float (&f)[NPX][10], const float (&r)[NPX][6],
+                                                   float (&rgb)[NPX][3]) {
+    float h[NPX][6];
+#pragma unroll
+    for (int jg = 0; jg < 6 / W1_ROWS_SHARED; ++jg) {
+        const ConstWeights w1a = reload_here(w1 + 12 * W1_ROWS_SHARED * jg);
+#pragma unroll
+        for (int jj = 0; jj < W1_ROWS_SHARED; ++jj) {
+#pragma unroll
+            for (int k = 0; k < NPX; ++k) {
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) s = __fmaf_rn(w1a[12 * jj + c], f[k][3 + c], s);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) s = __fmaf_rn(w1a[12 * jj + 6 + c], r[k][c], s);
+                h[k][W1_ROWS_SHARED * jg + jj] = fmaxf(s, 0.f);
+            }
+        }
+    }
+    const ConstWeights w2a = reload_here(w2);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) {
+            float y = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) y = __fmaf_rn(w2a[6 * o + j], h[k][j], y);
+            const float z = f[k][o] + y;
+            rgb[k][o] = 1.f / (1.f + __expf(-z));
+        }
+    }
+}
+
+}  // namespace mobgs

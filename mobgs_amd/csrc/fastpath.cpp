@@ -33,6 +33,7 @@ struct Api {
     decltype(&mobgs_prep_bwd_many) prep_bwd = nullptr;
     decltype(&mobgs_prep_bwd_many_f16) prep_bwd_f16 = nullptr;
     decltype(&mobgs_raster_fwd) raster_fwd = nullptr;
+    decltype(&mobgs_raster_fwd_decode) raster_fwd_decode = nullptr;
     decltype(&mobgs_raster_bwd) raster_bwd = nullptr;
     decltype(&mobgs_raster_bwd_reduce) raster_bwd_reduce = nullptr;
     decltype(&mobgs_decoder_fwd_many) decoder_fwd = nullptr;
@@ -72,6 +73,7 @@ void bind(const std::unordered_map<std::string, uint64_t>& m) {
     take(m, "mobgs_prep_bwd_many", api.prep_bwd);
     take(m, "mobgs_prep_bwd_many_f16", api.prep_bwd_f16);
     take(m, "mobgs_raster_fwd", api.raster_fwd);
+    take(m, "mobgs_raster_fwd_decode", api.raster_fwd_decode);
     take(m, "mobgs_raster_bwd", api.raster_bwd);
     take(m, "mobgs_raster_bwd_reduce", api.raster_bwd_reduce);
     take(m, "mobgs_decoder_fwd_many", api.decoder_fwd);
@@ -208,13 +210,16 @@ std::vector<Tensor> prep_bwd(int64_t Ns, int64_t Nd, const Tensor& times, const 
 
 // ---- rendering._Rasterize ------------------------------------------------------------------------------------------
 // One compositing launch.  records / reach: pass the tensors to (re)use, or None to have them allocated.
-// -> (records, render [C,H,W,D], alphas [C,H,W], last_ids, reach)
-std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor>
+// dec_intr / dec_c2w / dec_w1 / dec_w2 (all or none): the Sandwich decoder runs as the kernel's epilogue
+// (mobgs_raster_fwd_decode) and rgb [C,3,H,W] / depth [C,H,W] come back too.
+// -> (records, render [C,H,W,D], alphas [C,H,W], last_ids, reach, rgb | None, depth | None)
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, OptT, OptT>
 raster_fwd(int64_t C, int64_t N, int64_t channels, int64_t width, int64_t height, const Tensor& means2d,
            const Tensor& conics, const OptT& colors, int64_t colors_per_camera, const Tensor& opacities,
            int64_t opac_per_camera, const OptT& extra, const OptT& bg, const Tensor& radii, const Tensor& tile_offsets,
            const OptT& tile_order, const Tensor& flatten_arena, const OptT& records_in, const OptT& reach_in,
-           int64_t tuning, int64_t stream) {
+           int64_t tuning, int64_t stream, const OptT& dec_intr, const OptT& dec_c2w, const OptT& dec_w1,
+           const OptT& dec_w2) {
     const bool has_extra = extra.has_value() && extra->defined();
     const int64_t D = channels + (has_extra ? 1 : 0);
     const auto f = means2d.options().dtype(at::kFloat);
@@ -225,13 +230,26 @@ raster_fwd(int64_t C, int64_t N, int64_t channels, int64_t width, int64_t height
                        ? *reach_in : at::empty({arena}, f.dtype(at::kByte));
     Tensor render = at::empty({C, height, width, D}, f), alphas = at::empty({C, height, width}, f),
            last_ids = at::empty({C, height, width}, f.dtype(at::kInt));
+    if (dec_intr.has_value() && dec_intr->defined()) {
+        Tensor rgb = at::empty({C, 3, height, width}, f), depth = at::empty({C, height, width}, f);
+        const int intr_stride = (C > 1 && dec_intr->numel() == 4 * C) ? 4 : 0;
+        const int c2w_stride = (C > 1 && dec_c2w->dim() == 3) ? (int)(dec_c2w->numel() / C) : 0;
+        check(api.raster_fwd_decode((int)C, (int)N, (int)channels, (int)width, (int)height, fp(means2d), fp(conics),
+                                    fp(colors), (int)colors_per_camera, fp(opacities), (int)opac_per_camera, fp(extra),
+                                    fp(bg), ip(radii), ip(tile_offsets), ip(tile_order), ip(flatten_arena), fpw(records),
+                                    fpw(render), fpw(alphas), static_cast<int32_t*>(dp(last_ids)),
+                                    static_cast<uint8_t*>(dp(reach)), fp(dec_intr), intr_stride, fp(dec_c2w), c2w_stride,
+                                    fp(dec_w1), fp(dec_w2), fpw(rgb), fpw(depth), tp(tuning), sp(stream)),
+              "mobgs_raster_fwd_decode");
+        return {records, render, alphas, last_ids, reach, OptT(rgb), OptT(depth)};
+    }
     check(api.raster_fwd((int)C, (int)N, (int)channels, (int)width, (int)height, fp(means2d), fp(conics), fp(colors),
                          (int)colors_per_camera, fp(opacities), (int)opac_per_camera, fp(extra), fp(bg), ip(radii),
                          ip(tile_offsets), ip(tile_order), ip(flatten_arena), fpw(records), fpw(render), fpw(alphas),
                          static_cast<int32_t*>(dp(last_ids)), static_cast<uint8_t*>(dp(reach)), tp(tuning),
                          sp(stream)),
           "mobgs_raster_fwd");
-    return {records, render, alphas, last_ids, reach};
+    return {records, render, alphas, last_ids, reach, OptT(), OptT()};
 }
 
 // -> zero-filled gradient slots [max(n_isects,1) + 1, stride] with the per-entry records written by the kernel; the

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "decoder_shared.h"
 #include "raster_shared.h"
 
 namespace mobgs {
@@ -57,10 +58,55 @@ pack_records_kernel(int N, int channels, int stride, const float* __restrict__ m
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
+// The Sandwich decoder as the EPILOGUE of the forward compositor (round 5; 10 total channels = 9 features + depth, pinhole
+// rays generated in registers): the pixel's composited features are in registers when its walk ends, so the decoded
+// colour and the expected depth leave the same kernel -- no decoder launch, no re-read of the 55-MB feature image
+// (decoder_fwd: 18 us; the image itself is still written: the backward pass reads it).  Same instruction sequence as
+// decoder_fwd_kernel (decoder_shared.h): bit-identical images.  rgb == NULL: off.
+struct DecodeEpi {
+    const float *intr, *c2w, *w1, *w2;   // [fx, fy, cx, cy] (+ intr_stride per camera), 3x4 pose (+ c2w_stride), weights
+    float *rgb, *depth;                  // [C,3,H,W], [C,H,W]
+    int intr_stride, c2w_stride;
+};
+// NPX pixels of one lane (pxi[k], pyi[k]; `inside` bit k = the pixel exists).  ROW4: the four pixels are consecutive in x
+// starting at a multiple of 4 (the block-walk lane layout): one 16-byte store per output plane when the image width allows.
+template <int NPX, bool ROW4>
+__device__ __forceinline__ void decode_epilogue(const DecodeEpi& d, const RayCam& rc, int cam, const int (&pxi)[NPX],
+                                                const int (&pyi)[NPX], unsigned inside, int width, int height,
+                                                const float (&f)[NPX][10], const float (&alpha)[NPX]) {
+    const int P = width * height;
+    float r[NPX][6], out[NPX][3];
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+        float loc[2], inv_n;
+        pixel_ray_xy(rc, pxi[k], pyi[k], r[k], loc, inv_n);
+    }
+    sandwich_forward_n<NPX>(d.w1, d.w2, f, r, out);
+    float* rgb = d.rgb + (size_t)cam * 3 * P;
+    float* dep = d.depth + (size_t)cam * P;
+    if (ROW4 && NPX == 4 && inside == 0xFu && (width & 3) == 0) {
+        const int p = pyi[0] * width + pxi[0];
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+            *reinterpret_cast<float4*>(rgb + (size_t)o * P + p) = make_float4(out[0][o], out[1][o], out[2][o], out[3][o]);
+        *reinterpret_cast<float4*>(dep + p) = make_float4(f[0][9] / fmaxf(alpha[0], 1e-10f), f[1][9] / fmaxf(alpha[1], 1e-10f),
+                                                          f[2][9] / fmaxf(alpha[2], 1e-10f), f[3][9] / fmaxf(alpha[3], 1e-10f));
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+        if (!((inside >> k) & 1u)) continue;
+        const int p = pyi[k] * width + pxi[k];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) rgb[(size_t)o * P + p] = out[k][o];
+        dep[p] = f[k][9] / fmaxf(alpha[k], 1e-10f);
+    }
+}
+
 // One wave composites NP pixels per lane of `tile` front to back: NP = 4 -> the whole 16x16 tile (pixel k of a lane
 // lies in quadrant k), NP = 1 -> only the 8x8 quadrant `quad` (heavy tiles: 4 waves share the list walk, which cuts
 // the critical path of a long list ~2.6x; every pixel sees exactly the same arithmetic either way).
-template <int CD, int NP, bool FILTER>
+template <int CD, int NP, bool FILTER, bool DECODE = false>
 __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int lane,
                                               float4 (*slab)[64][((6 + CD + 3) & ~3) / 4], int (*idx_of)[64],
                                               unsigned (*reach_of)[64], ClassSel cls, int tile_w, int tile_h,
@@ -69,7 +115,7 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
                                               const int32_t* __restrict__ tile_offsets,
                                               const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
                                               float* __restrict__ alphas, int32_t* __restrict__ last_ids,
-                                              uint8_t* __restrict__ isect_reach) {
+                                              uint8_t* __restrict__ isect_reach, const DecodeEpi* dec = nullptr) {
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
     constexpr int PPL = NP;
@@ -204,12 +250,17 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
             if (alive == 0u) break;
         }
     }
+    unsigned inside_mask = 0u;
+    float alpha_out[PPL];
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
+        alpha_out[k] = 0.f;
         if (!(pxi[k] < width && pyi[k] < height)) continue;
+        inside_mask |= 1u << k;
         const float Tk = fabsf(T[k]);
         const size_t pix = ((size_t)cam * height + pyi[k]) * width + pxi[k];
         alphas[pix] = 1.f - Tk;
+        alpha_out[k] = 1.f - Tk;
         last_ids[pix] = last[k];
         float* out = render + pix * CD;
 #pragma unroll
@@ -217,7 +268,12 @@ __device__ __forceinline__ void composite_fwd(int tile, int quad, int wv, int la
             float v = acc[k][c];
             if (backgrounds) v = __fmaf_rn(Tk, backgrounds[cam * CD + c], v);
             out[c] = v;
+            acc[k][c] = v;
         }
+    }
+    if constexpr (DECODE && CD == 10) {
+        const RayCam rc = load_raycam(dec->intr + cam * dec->intr_stride, dec->c2w + cam * dec->c2w_stride);
+        decode_epilogue<PPL, false>(*dec, rc, cam, pxi, pyi, inside_mask, width, height, acc, alpha_out);
     }
 }
 
@@ -300,13 +356,14 @@ __device__ inline unsigned block_reach_mask16_rec(const float4& r0, const float4
 #endif
 // FILTER: a class-restricted pass (ClassSel) -- entries of the other class simply get an empty block mask; list indices
 // stay those of the combined list.
-template <int CD, bool FILTER>
+template <int CD, bool FILTER, bool DECODE = false>
 __global__ void __launch_bounds__(64 * TILES_PER_WG) __attribute__((amdgpu_waves_per_eu(CD <= 10 ? F2_WAVES : (CD <= 12 ? 3 : 2))))
 raster_fwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
                          const float* __restrict__ records, const float* __restrict__ backgrounds,
                          const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
                          float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
-                         const int32_t* __restrict__ tile_order, ClassSel cls, uint8_t* __restrict__ isect_reach) {
+                         const int32_t* __restrict__ tile_order, ClassSel cls, uint8_t* __restrict__ isect_reach,
+                         DecodeEpi dec) {
     const int all_reach = cls.all_reach;
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
@@ -319,9 +376,9 @@ raster_fwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
     const int slot = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
     if (slot < 0) return;
     if (slot & SCHED_HEAVY) {
-        composite_fwd<CD, 1, FILTER>(slot & ~SCHED_HEAVY, wv, wv, lane, hslab, hidx, hreach, cls, tile_w, tile_h, width,
-                                     height, records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids,
-                                     isect_reach);
+        composite_fwd<CD, 1, FILTER, DECODE>(slot & ~SCHED_HEAVY, wv, wv, lane, hslab, hidx, hreach, cls, tile_w, tile_h,
+                                             width, height, records, backgrounds, tile_offsets, flatten_ids, render, alphas,
+                                             last_ids, isect_reach, &dec);
         return;
     }
     const int tile = slot;
@@ -456,12 +513,17 @@ raster_fwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
             }
         }
     }
+    unsigned inside_mask = 0u;
+    float alpha_out[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        alpha_out[k] = 0.f;
         if (!(pxi0 + k < width && pyi < height)) continue;
+        inside_mask |= 1u << k;
         const float Tk = fabsf(T[k]);
         const size_t pix = ((size_t)cam * height + pyi) * width + pxi0 + k;
         alphas[pix] = 1.f - Tk;
+        alpha_out[k] = 1.f - Tk;
         last_ids[pix] = last[k];
         float* out = render + pix * CD;
 #pragma unroll
@@ -469,7 +531,13 @@ raster_fwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
             float v = acc[k][c];
             if (backgrounds) v = __fmaf_rn(Tk, backgrounds[cam * CD + c], v);
             out[c] = v;
+            acc[k][c] = v;
         }
+    }
+    if constexpr (DECODE && CD == 10) {
+        const RayCam rc = load_raycam(dec.intr + cam * dec.intr_stride, dec.c2w + cam * dec.c2w_stride);
+        const int px4[4] = {pxi0, pxi0 + 1, pxi0 + 2, pxi0 + 3}, py4[4] = {pyi, pyi, pyi, pyi};
+        decode_epilogue<4, true>(dec, rc, cam, px4, py4, inside_mask, width, height, acc, alpha_out);
     }
 }
 
@@ -1513,12 +1581,12 @@ int mobgs_pack_records(int C, int N, int channels, const float* means2d, const f
     return check_launch("pack_records_kernel");
 }
 
-int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const float* means2d,
-                     const float* conics, const float* colors, int colors_per_camera, const float* opacities,
-                     int opac_per_camera, const float* extra, const float* backgrounds, const int32_t* radii,
-                     const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
-                     float* records, float* render, float* alphas, int32_t* last_ids, uint8_t* isect_reach,
-                     const MobgsTuning* tuning, void* stream) {
+static int raster_fwd_impl(int C, int N, int channels, int width, int height, const float* means2d,
+                           const float* conics, const float* colors, int colors_per_camera, const float* opacities,
+                           int opac_per_camera, const float* extra, const float* backgrounds, const int32_t* radii,
+                           const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
+                           float* records, float* render, float* alphas, int32_t* last_ids, uint8_t* isect_reach,
+                           const MobgsTuning* tuning, void* stream, const DecodeEpi* dec) {
     hipStream_t st = (hipStream_t)stream;
     const int g_all_reach = tuning_all_reach(tuning);
     const int D = channels + (extra ? 1 : 0);
@@ -1537,6 +1605,16 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
     const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
     const int block_walk = tuning_block_walk(tuning);
+    if (dec) {  // decoder epilogue: the block-walk kernel of the 9 + 1 channel pass
+        if (D != 10 || !extra || !block_walk) {
+            set_error("mobgs_raster_fwd_decode: needs 9 feature channels + the depth channel and the block-walk kernel");
+            return MOBGS_E_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL((raster_fwd_blocks_kernel<10, false, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt,
+                           n_groups, tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render,
+                           alphas, last_ids, tile_order, ClassSel{0, 1, 0, g_all_reach}, isect_reach, *dec);
+        return check_launch("raster_fwd_kernel(decode)");
+    }
     const int rc = dispatch_channels(D, [&](auto cd) {
         constexpr int CD = decltype(cd)::value;
         // measured (profiles/r03): the block walk wins where a pixel's blend is wide -- 10 channels 256 -> 218 us, 12
@@ -1545,7 +1623,7 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
         if (block_walk && CD >= 7 && CD <= 12)
             hipLaunchKernelGGL((raster_fwd_blocks_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt,
                                n_groups, tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids,
-                               render, alphas, last_ids, tile_order, ClassSel{0, 1, 0, g_all_reach}, isect_reach);
+                               render, alphas, last_ids, tile_order, ClassSel{0, 1, 0, g_all_reach}, isect_reach, DecodeEpi{});
         else
         hipLaunchKernelGGL((raster_fwd_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
                            tile_w, tile_h, width, height, records, backgrounds, tile_offsets, flatten_ids, render,
@@ -1556,6 +1634,34 @@ int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const fl
         return rc;
     }
     return check_launch("raster_fwd_kernel");
+}
+
+int mobgs_raster_fwd(int C, int N, int channels, int width, int height, const float* means2d,
+                     const float* conics, const float* colors, int colors_per_camera, const float* opacities,
+                     int opac_per_camera, const float* extra, const float* backgrounds, const int32_t* radii,
+                     const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
+                     float* records, float* render, float* alphas, int32_t* last_ids, uint8_t* isect_reach,
+                     const MobgsTuning* tuning, void* stream) {
+    return raster_fwd_impl(C, N, channels, width, height, means2d, conics, colors, colors_per_camera, opacities,
+                           opac_per_camera, extra, backgrounds, radii, tile_offsets, tile_order, flatten_ids, records, render,
+                           alphas, last_ids, isect_reach, tuning, stream, nullptr);
+}
+
+int mobgs_raster_fwd_decode(int C, int N, int channels, int width, int height, const float* means2d,
+                            const float* conics, const float* colors, int colors_per_camera, const float* opacities,
+                            int opac_per_camera, const float* extra, const float* backgrounds, const int32_t* radii,
+                            const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
+                            float* records, float* render, float* alphas, int32_t* last_ids, uint8_t* isect_reach,
+                            const float* ray_intr, int intr_stride, const float* ray_c2w, int c2w_stride, const float* w1,
+                            const float* w2, float* rgb, float* depth, const MobgsTuning* tuning, void* stream) {
+    if (!ray_intr || !ray_c2w || !w1 || !w2 || !rgb || !depth) {
+        set_error("mobgs_raster_fwd_decode: ray_intr, ray_c2w, w1, w2, rgb and depth are required");
+        return MOBGS_E_INVALID;
+    }
+    const DecodeEpi dec{ray_intr, ray_c2w, w1, w2, rgb, depth, intr_stride, c2w_stride};
+    return raster_fwd_impl(C, N, channels, width, height, means2d, conics, colors, colors_per_camera, opacities,
+                           opac_per_camera, extra, backgrounds, radii, tile_offsets, tile_order, flatten_ids, records, render,
+                           alphas, last_ids, isect_reach, tuning, stream, &dec);
 }
 
 int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int height, const float* records,
@@ -1629,7 +1735,7 @@ int mobgs_raster_class_fwd(int C, int N, int Ns, int class_sel, int channels_tot
     if (tuning_block_walk(tuning) && channels_total == 10)  // (the 1-channel coverage pass: 86 us vs 90 us, see above)
         hipLaunchKernelGGL((raster_fwd_blocks_kernel<10, true>), g3, b3, 0, st, nt, n_groups, tile_w, tile_h, width,
                            height, records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids,
-                           tile_order, cls, isect_reach);
+                           tile_order, cls, isect_reach, DecodeEpi{});
     else if (channels_total == 10)
         hipLaunchKernelGGL((raster_fwd_kernel<10, true>), g3, b3, 0, st, nt, n_groups, tile_w, tile_h, width, height,
                            records, backgrounds, tile_offsets, flatten_ids, render, alphas, last_ids, tile_order, cls,

@@ -301,14 +301,13 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     rebuilds = sp.tl.rebuilds
     sp.tl.defer = True
     try:
-        img, alphas = sp.composite(cols, bg1)
-        rendered, depth = decode_ed(img, alphas)
+        # (the decoder runs as the epilogue of the compositing kernel when the camera gives pinhole rays: one launch)
+        img, alphas, rendered, depth = sp.composite_decode(cols, bg1, rays, w1, w2)
     finally:
         sp.tl.defer = False
     sp.tl.resolve()
     if sp.tl.rebuilds != rebuilds:  # arena too small (first frame / scene grew): lists were rebuilt, do it again
-        img, alphas = sp.composite(cols, bg1)
-        rendered, depth = decode_ed(img, alphas)
+        img, alphas, rendered, depth = sp.composite_decode(cols, bg1, rays, w1, w2)
     info = sp.meta()
     radii = info["radii"].squeeze(0)
     _keep_grad(info["means2d"])
@@ -405,11 +404,11 @@ def render_many(viewpoint_cameras, stat_pc, dyn_pc, pipe, bg_color, delta_exposu
     sp = _R.SharedProjection(means, quats, scales, opac, viewmats, Ks, W, H, pack_colors=cols)
 
     def composite_and_decode():
-        img, alphas = sp.composite(cols, bgK)                  # [K,H,W,10], [K,H,W,1]
         rays = _rays_of_many(cams) if K > 1 else None   # (one image: the single-image call, [3,H,W] out)
-        if rays is not None:   # ONE decoder launch for the K images (forward and backward), per-image camera poses
-            rgb, depth = decode(img, alphas, rays, w1, w2, True)           # [K,3,H,W], [K,H,W]
+        if rays is not None:   # the K images decoded by the compositing launch itself (one decoder launch in backward)
+            _, _, rgb, depth = sp.composite_decode(cols, bgK, rays, w1, w2)  # [K,3,H,W], [K,H,W]
             return list(zip(rgb.unbind(0), depth.unbind(0)))
+        img, alphas = sp.composite(cols, bgK)                  # [K,H,W,10], [K,H,W,1]
         # unbind: ONE autograd node whose backward stacks the K cotangents (a select per k would zero-fill and copy
         # the whole batch K times)
         return [decode(i, a, _rays_of(c), w1, w2, True) for i, a, c in zip(img.unbind(0), alphas.unbind(0), cams)]

@@ -248,7 +248,9 @@ class Decode(torch.autograd.Function):
     and `c2w` [3,4] from which the kernel generates them (gradient flows into c2w)."""
 
     @staticmethod
-    def forward(ctx, feat_hw, alphas, rays, intr, c2w, w1, w2, has_depth: bool):
+    def forward(ctx, feat_hw, alphas, rays, intr, c2w, w1, w2, has_depth: bool, pre_rgb=None, pre_depth=None):
+        """pre_rgb / pre_depth: this node's outputs, already computed by the forward compositor's decoder epilogue
+        (rendering.SharedProjection.composite_decode) -- nothing is launched here, the backward pass is unchanged."""
         lib = _lib.load()
         ctx.set_materialize_grads(False)  # an unused depth output costs no zero image in backward
         ctx.w_inputs = (w1, w2)  # the caller's tensor objects (a LeafGradSink recognises its weights by identity)
@@ -269,7 +271,9 @@ class Decode(torch.autograd.Function):
                 raise ValueError("decode: intr must be [fx, fy, cx, cy] and c2w a [3,4] or [4,4] camera-to-world matrix "
                                  "(a batch of C images: [C,4] / [C,3|4,4], or shared ones)")
         F = _fast.get()
-        if F is not None:
+        if pre_rgb is not None:
+            rgb, depth = pre_rgb.view_as(pre_rgb), (pre_depth.view_as(pre_depth) if has_depth else None)
+        elif F is not None:
             rgb, depth = F.decoder_fwd(H, W, CF, bool(has_depth), feat_hw, alphas_c, rays_c, intr_c, c2w_c, w1, w2,
                                        stream_int())
         else:
@@ -294,7 +298,7 @@ class Decode(torch.autograd.Function):
         lib = _lib.load()
         feat_hw, alphas, rays, intr, c2w, w1, w2 = ctx.saved_tensors
         if v_rgb is None and v_depth is None:
-            return (None,) * 8
+            return (None,) * 10
         H, W, CF = feat_hw.shape[-3:]
         P = H * W
         dev = feat_hw.device
@@ -308,8 +312,8 @@ class Decode(torch.autograd.Function):
                 sunk[0] if sunk is not None else None, sunk[1] if sunk is not None else None,
                 sunk[2] if sunk is not None else 0, stream_int())
             if sunk is not None:
-                return v_feat, v_alphas, v_rays, None, g_c2w, None, None, None
-            return v_feat, v_alphas, v_rays, None, g_c2w, g_w1, g_w2, None
+                return v_feat, v_alphas, v_rays, None, g_c2w, None, None, None, None, None
+            return v_feat, v_alphas, v_rays, None, g_c2w, g_w1, g_w2, None, None, None
         C = feat_hw.numel() // (P * CF)
         v_rgb = f32c(v_rgb) if v_rgb is not None else torch.zeros(C, 3, H, W, dtype=torch.float32, device=dev)
         v_depth = f32c(v_depth) if (has_depth and v_depth is not None) else None
@@ -331,8 +335,8 @@ class Decode(torch.autograd.Function):
                                          accumulate, stream()),
               "mobgs_decoder_bwd")
         if sunk is not None:
-            return v_feat, v_alphas, v_rays, None, g_c2w, None, None, None
-        return v_feat, v_alphas, v_rays, None, g_c2w, g_w1, g_w2, None
+            return v_feat, v_alphas, v_rays, None, g_c2w, None, None, None, None, None
+        return v_feat, v_alphas, v_rays, None, g_c2w, g_w1, g_w2, None, None, None
 
 
 class DecodeWithChannels(torch.autograd.Function):

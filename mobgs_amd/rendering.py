@@ -468,7 +468,10 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, extra, backgrounds, radii, tl: TileLists, width, height,
-                packed=None):
+                packed=None, dec=None):
+        """dec = (intr, c2w, w1, w2) (detached, float32, contiguous): the Sandwich decoder runs as the kernel's epilogue
+        (mobgs_raster_fwd_decode) and the node returns (render, alphas, rgb, depth) -- rgb / depth non-differentiable here:
+        ops.Decode takes them as its precomputed outputs and owns their backward pass."""
         lib = _lib_()
         C, N = radii.shape
         dev = means2d.device
@@ -487,9 +490,15 @@ class _Rasterize(torch.autograd.Function):
         colors_arg = None if packed is not None else colors
         F = _fast.get()
         records, reach = packed, None
+        rgb = dec_depth = None
+        if dec is not None and not (D == 10 and extra is not None and tuning.block_walk != 0):
+            raise NotImplementedError("decoder epilogue: 9 feature channels + depth through the block-walk kernel only")
         if F is None:
             if records is None:
                 records = torch.empty(C * N, stride, dtype=torch.float32, device=dev)
+            if dec is not None:
+                rgb = torch.empty(C, 3, height, width, dtype=torch.float32, device=dev)
+                dec_depth = torch.empty(C, height, width, dtype=torch.float32, device=dev)
             render = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
             alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
             last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
@@ -499,19 +508,26 @@ class _Rasterize(torch.autograd.Function):
         with profiler.region("raster_fwd"):
             while True:
                 if F is not None:  # allocations + the launch in C++ (csrc/fastpath.cpp); buffers are reused on a redo
-                    records, render, alphas, last_ids, reach = F.raster_fwd(
+                    d4 = dec if dec is not None else (None, None, None, None)
+                    records, render, alphas, last_ids, reach, rgb, dec_depth = F.raster_fwd(
                         C, N, channels, width, height, means2d, conics, colors_arg, colors_per_camera, opacities,
                         opac_per_camera, extra, bg, radii, tl.tile_offsets, tl.tile_order, tl.flatten_arena, records,
-                        reach, tuning.address(), stream_int())
+                        reach, tuning.address(), stream_int(), *d4)
                 else:
                     if reach.numel() < tl.flatten_arena.numel():  # lists rebuilt into a larger arena
                         reach = torch.empty(tl.flatten_arena.numel(), dtype=torch.uint8, device=dev)
-                    check(lib.mobgs_raster_fwd(C, N, channels, width, height, ptr(means2d), ptr(conics),
-                                               ptr(colors_arg), colors_per_camera, ptr(opacities), opac_per_camera,
-                                               ptr(extra), ptr(bg), ptr(radii), ptr(tl.tile_offsets),
-                                               ptr(tl.tile_order), ptr(tl.flatten_arena), ptr(records), ptr(render),
-                                               ptr(alphas), ptr(last_ids), ptr(reach), tuning.ref(), stream()),
-                          "mobgs_raster_fwd")
+                    head = (C, N, channels, width, height, ptr(means2d), ptr(conics), ptr(colors_arg), colors_per_camera,
+                            ptr(opacities), opac_per_camera, ptr(extra), ptr(bg), ptr(radii), ptr(tl.tile_offsets),
+                            ptr(tl.tile_order), ptr(tl.flatten_arena), ptr(records), ptr(render), ptr(alphas),
+                            ptr(last_ids), ptr(reach))
+                    if dec is not None:
+                        intr, c2w, w1, w2 = dec
+                        check(lib.mobgs_raster_fwd_decode(*head, ptr(intr), 4 if (C > 1 and intr.numel() == 4 * C) else 0,
+                                                          ptr(c2w), (c2w.numel() // C) if (C > 1 and c2w.dim() == 3) else 0,
+                                                          ptr(w1), ptr(w2), ptr(rgb), ptr(dec_depth), tuning.ref(),
+                                                          stream()), "mobgs_raster_fwd_decode")
+                    else:
+                        check(lib.mobgs_raster_fwd(*head, tuning.ref(), stream()), "mobgs_raster_fwd")
                 # speculative lists whose arena was too small get rebuilt by resolve(): composite again.  A caller that
                 # wants to enqueue more work before waiting for the counts sets tl.defer and does this itself.
                 if tl.defer or not tl.resolve():
@@ -522,10 +538,13 @@ class _Rasterize(torch.autograd.Function):
         ctx.arena = tl.flatten_arena  # the lists `reach` belongs to (a rebuild replaces the arena)
         ctx.meta = (C, N, channels, extra is not None, width, height, colors_per_camera, opac_per_camera)
         ctx.bg_needs_grad = backgrounds is not None and backgrounds.requires_grad
+        if dec is not None:
+            ctx.mark_non_differentiable(rgb, dec_depth)
+            return render, alphas.unsqueeze(-1), rgb, dec_depth
         return render, alphas.unsqueeze(-1)
 
     @staticmethod
-    def backward(ctx, v_render, v_alphas):
+    def backward(ctx, v_render, v_alphas, *_unused):
         lib = _lib_()
         records, bg, radii, means2d, alphas, last_ids, reach = ctx.saved_tensors
         tl = ctx.tl
@@ -536,7 +555,7 @@ class _Rasterize(torch.autograd.Function):
         D = channels + (1 if has_extra else 0)
         stride = records.shape[1]
         if v_render is None and v_alphas is None:
-            return (None,) * 11
+            return (None,) * 12
         if v_render is None:  # only the alpha output was used
             v_render = torch.zeros(C, height, width, D, dtype=torch.float32, device=dev)
         F = _fast.get()
@@ -576,7 +595,7 @@ class _Rasterize(torch.autograd.Function):
         v_bg = None
         if ctx.bg_needs_grad:
             v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
-        return v_means2d, v_conics, v_colors, v_opac, v_extra, v_bg, None, None, None, None, None
+        return v_means2d, v_conics, v_colors, v_opac, v_extra, v_bg, None, None, None, None, None, None
 
 
 class _RasterizeClassAlpha(torch.autograd.Function):
@@ -774,6 +793,9 @@ class _RasterizeLayers(torch.autograd.Function):
                 None, None, None)
 
 
+# True: render() lets the forward compositor decode its own image (SharedProjection.composite_decode); False: a separate
+# decoder launch, as before round 5 (A/B; results are bit-identical)
+FUSE_DECODER = os.environ.get("MOBGS_FUSE_DECODER", "1") != "0"
 # True: static-only / dynamic-only images (without the combined one) come from two class-restricted passes of the
 # single-set compositor over the combined lists (every splat belongs to exactly one class, so together they do the
 # work of ONE pass and share one gradient-slot buffer); False: from the generic 3-layer kernel
@@ -1106,6 +1128,37 @@ class SharedProjection:
         return rasterize_to_pixels(self.means2d_main, self.conics, colors, self.opacities, self.radii, self.tl,
                                    self.width, self.height, backgrounds=self._bg(backgrounds), extra=self.depths,
                                    packed=self._packed_for(colors))
+
+    def composite_decode(self, colors, backgrounds, rays, w1, w2):
+        """composite() followed by ops.decode(img, alphas, rays, w1, w2, True) -- (img, alphas, rgb [3,H,W] | [C,3,H,W],
+        depth) -- with the decoder as the EPILOGUE of the compositing kernel when it can be (round 5: 9 features + depth,
+        block-walk kernel, pinhole rays given as (intr, c2w)): no decoder launch, no re-read of the feature image; the
+        results are bit-identical and the backward pass is ops.Decode's either way."""
+        from .ops import Decode, decode
+        fused = (FUSE_DECODER and isinstance(rays, (tuple, list)) and colors.shape[-1] == 9 and tuning.block_walk != 0)
+        if fused:
+            intr, c2w = rays
+            C = self.C
+            if C == 1:
+                intr, c2w = intr.reshape(4), (c2w.reshape(c2w.shape[-2:]) if c2w.dim() == 3 else c2w)
+            ok = intr.numel() in (4, 4 * C) and c2w.shape[-2] in (3, 4) and c2w.shape[-1] == 4 and \
+                (c2w.dim() == 2 or (c2w.dim() == 3 and c2w.shape[0] == C))
+            fused = ok and not (C > 1 and c2w.dim() == 2 and c2w.requires_grad)  # (decode expands that case itself)
+        if not fused:
+            img, alphas = self.composite(colors, backgrounds)
+            rgb, depth = decode(img, alphas, rays, w1, w2, True)
+            return img, alphas, rgb, depth
+        dec = (f32c(intr.detach()), f32c(c2w.detach()), f32c(w1.detach()), f32c(w2.detach()))
+        img, alphas, rgb0, depth0 = _Rasterize.apply(self.means2d_main, self.conics, colors, self.opacities, self.depths,
+                                                     self._bg(backgrounds), self.radii, self.tl, self.width, self.height,
+                                                     self._packed_for(colors), dec)
+        lead = (C,) if C > 1 else ()
+        feat = img.reshape(*lead, self.height, self.width, 10)
+        a2 = alphas.reshape(*lead, self.height, self.width)
+        if C == 1:
+            rgb0, depth0 = rgb0[0], depth0[0]
+        rgb, depth = Decode.apply(feat, a2, None, intr, c2w, w1, w2, True, rgb0, depth0)
+        return img, alphas, rgb, depth
 
     def composite_layers(self, colors, Ns, backgrounds=None, want_all=False, want_static=True, want_dynamic=True):
         """Layered "RGB+D" compositing over the SAME lists: lists (render, alphas) indexed by layer
