@@ -36,7 +36,7 @@ class MobgsTuning(ctypes.Structure):
         return ctypes.addressof(self)
 
 P = c_void_p
-ABI_VERSION = 5  # include/mobgs_hip.h MOBGS_ABI_VERSION
+ABI_VERSION = 6  # include/mobgs_hip.h MOBGS_ABI_VERSION
 _SIGS = {
     "mobgs_version": (c_char_p, []),
     "mobgs_abi_version": (c_int, []),
@@ -60,7 +60,7 @@ _SIGS = {
     "mobgs_raster_fwd_decode": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, P, P,
                                         P, P, P, P, P, c_int, P, c_int, P, P, P, P, P, P]),
     "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int] + [P] * 16 + [P, P]),
-    "mobgs_raster_bwd_reduce": (c_int, [c_int, c_int, c_int, c_int] + [P] * 10 + [P]),
+    "mobgs_raster_bwd_reduce": (c_int, [c_int, c_int, c_int, c_int] + [P] * 11 + [P]),
     "mobgs_project_and_bin": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
                                       c_float, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, P, P, P,
                                       P]),
@@ -73,7 +73,7 @@ _SIGS = {
     "mobgs_fused_max_seg_stride": (c_int, []),
     "mobgs_project_and_bin_fused": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
                                             c_float, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, c_int,
-                                            P, c_int64, P, c_int64, P, c_int, c_int, P, P, P]),
+                                            P, P, c_int64, P, c_int64, P, c_int, c_int, P, P, P]),
     "mobgs_densify_stats": (c_int, [c_int, P, c_int, P, P, P, P, P, P]),
     "mobgs_densify_select": (c_int, [c_int, c_int, P, P, P, c_float, c_float, P, P, P]),
     "mobgs_mask_indices": (c_int, [c_int, P, c_int, P, P, P]),
@@ -85,7 +85,7 @@ _SIGS = {
     "mobgs_raster_class_bwd": (c_int, [c_int] * 7 + [P] * 15 + [P, P]),
     "mobgs_pack_records": (c_int, [c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P]),
     "mobgs_raster_layers_fwd": (c_int, [c_int] * 7 + [P] * 8 + [P]),
-    "mobgs_raster_layers_bwd": (c_int, [c_int] * 8 + [P] * 20 + [P]),  # incl. 7 host pointer arrays of length 3
+    "mobgs_raster_layers_bwd": (c_int, [c_int] * 8 + [P] * 21 + [P]),  # incl. 7 host pointer arrays of length 3
     "mobgs_prep_fwd": (c_int, [c_int, c_int] + [P] * 21 + [P]),
     "mobgs_prep_bwd": (c_int, [c_int, c_int] + [P] * 23 + [c_int, P]),
     "mobgs_prep_fwd_f16": (c_int, [c_int, c_int] + [P] * 21 + [P]),

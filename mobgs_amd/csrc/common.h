@@ -290,7 +290,7 @@ int isect_fused_launch(int C, int N, int tile_w, int tile_h, int width, int heig
                        const int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* keep_scan, int32_t* tile_offsets,
                        int32_t* tile_order, int64_t capacity_listed, int64_t* stats, void* scratch, int64_t* stats_mirror,
                        int64_t stats_seq, uint64_t* seg_keys, int seg_stride, int32_t* flatten_ids, uint64_t* isect_ids,
-                       int64_t max_tile_len_hint, const MobgsTuning* tuning, void* stream);
+                       int64_t max_tile_len_hint, const int32_t* enum_order, const MobgsTuning* tuning, void* stream);
 
 // bit q = 2 * qy + qx set <=> the splat may reach alpha >= 1/255 at a pixel centre of the 8x8 quadrant (qx, qy) of
 // the 16x16 tile (tx, ty).  Same conservative test as min_sigma_over_tile / reach_threshold, on the four quadrant

@@ -275,7 +275,8 @@ Tensor raster_bwd(int64_t C, int64_t N, int64_t channels, int64_t has_extra, int
 // -> (v_means2d [C,N,2], v_conics [C,N,3], v_opac [C,N], v_colors [C,N,channels], v_extra [C,N] | None)
 std::tuple<Tensor, Tensor, Tensor, Tensor, OptT>
 raster_bwd_reduce(int64_t C, int64_t N, int64_t channels, int64_t has_extra, const Tensor& records,
-                  const Tensor& cum_tiles, const Tensor& keep_scan, const Tensor& slots, int64_t stream) {
+                  const Tensor& cum_tiles, const Tensor& keep_scan, const Tensor& slots, int64_t stream,
+                  const OptT& tiles_per_gauss) {
     const auto f = slots.options();
     Tensor v_means2d = at::empty({C, N, 2}, f), v_conics = at::empty({C, N, 3}, f), v_opac = at::empty({C, N}, f),
            v_colors = at::empty({C, N, channels}, f);
@@ -283,7 +284,7 @@ raster_bwd_reduce(int64_t C, int64_t N, int64_t channels, int64_t has_extra, con
     const int32_t* flag = reinterpret_cast<const int32_t*>(fp(slots) + (slots.size(0) - 1) * slots.size(1));
     check(api.raster_bwd_reduce((int)C, (int)N, (int)channels, (int)has_extra, fp(records), ip(cum_tiles), ip(keep_scan),
                                 fp(slots), flag, fpw(v_means2d), fpw(v_conics), fpw(v_opac), fpw(v_colors), fpw(v_extra),
-                                sp(stream)),
+                                ip(tiles_per_gauss), sp(stream)),
           "mobgs_raster_bwd_reduce");
     return {v_means2d, v_conics, v_opac, v_colors, v_extra};
 }
@@ -378,7 +379,7 @@ project_and_bin_speculative(const Tensor& means, const Tensor& quats, const Tens
                             double near_plane, double far_plane, double radius_clip, int64_t cull,
                             bool want_isect_ids, bool tile_schedule, const OptT& pack_colors, int64_t cap_box,
                             int64_t cap_listed, int64_t len_hint, int64_t stats_row, int64_t seq, int64_t tuning,
-                            int64_t stream, int64_t seg_stride) {
+                            int64_t stream, int64_t seg_stride, const OptT& enum_order) {
     const int64_t C = viewmats.size(0), N = means.size(-2);  // means [N,3] or, with geometry_per_camera, [C,N,3]
     const int64_t tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, nt = C * tile_w * tile_h;
     const auto f = means.options().dtype(at::kFloat);
@@ -414,7 +415,7 @@ project_and_bin_speculative(const Tensor& means, const Tensor& quats, const Tens
             static_cast<int32_t*>(dp(tile_offsets)), static_cast<int32_t*>(dp(tile_order)),
             static_cast<int64_t*>(dp(stats_dev)), (int)cap_box, static_cast<int32_t*>(dp(keep_scan)), dp(scratch),
             cap_listed, static_cast<int32_t*>(dp(flatten_ids)), static_cast<uint64_t*>(dp(sort_keys)), (int)seg_stride,
-            static_cast<uint64_t*>(dp(isect_ids)), len_hint,
+            ip(enum_order), static_cast<uint64_t*>(dp(isect_ids)), len_hint,
             reinterpret_cast<int64_t*>(static_cast<uintptr_t>(stats_row)), seq, pack ? fp(*pack_colors) : nullptr,
             (pack && pack_colors->dim() == 3) ? 1 : 0, pack ? (int)pack_ch : 0, fpw(records), tp(tuning), sp(stream));
     else

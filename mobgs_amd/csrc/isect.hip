@@ -126,14 +126,24 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_lookback_kernel(int n, cons
                                                                        uint64_t* __restrict__ status,
                                                                        int64_t* __restrict__ stats_slot,
                                                                        int32_t* __restrict__ chunk_owner,
-                                                                       int owner_slots) {
+                                                                       int owner_slots,
+                                                                       const int32_t* __restrict__ order,
+                                                                       int32_t* __restrict__ cum_enum) {
+    // order != NULL (round 5, fused path): the bounding-box intersections are ENUMERATED splat order[0], order[1], ...
+    // instead of 0, 1, ... -- a caller-chosen permutation of the splats (spatially coherent: neighbouring chunks of
+    // intersections then hit neighbouring tiles, and bin_kernel's LDS ranking turns ~1000 returning atomics per
+    // workgroup into ~100).  cum_enum[k] = first intersection of the k-th splat of that order (what bin_kernel searches);
+    // cum[g] = first intersection of splat g (what the backward pass and the slot reduction look up).  Every consumer
+    // only relies on "the intersections of a splat are consecutive": list contents, list order and the per-splat
+    // order of the gradient slots do not depend on the permutation.
     const int chunk = take_ticket(counter);
     const int base = chunk * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
-    int v[SCAN_ITEMS];
+    int v[SCAN_ITEMS], gid[SCAN_ITEMS];
     int s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        v[k] = (base + k < n) ? in[base + k] : 0;
+        gid[k] = (order && base + k < n) ? order[base + k] : base + k;
+        v[k] = (base + k < n) ? in[gid[k]] : 0;
         s += v[k];
     }
     int total;
@@ -141,7 +151,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_lookback_kernel(int n, cons
     int run = lookback_exclusive(status, chunk, total) + inc - s;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (base + k < n) cum[base + k] = run;
+        if (base + k < n) {
+            cum[gid[k]] = run;
+            if (order) cum_enum[base + k] = run;
+        }
         if (v[k] > 0) {  // chunk starts inside [run, run + v[k]): none or one, more only for splats over > 2048 tiles
             const unsigned m1 = ((unsigned)run + (unsigned)v[k] - 1u) >> KEEP_CHUNK_LOG2;
             for (unsigned m = ((unsigned)run + (unsigned)KEEP_CHUNK - 1u) >> KEEP_CHUNK_LOG2;
@@ -152,6 +165,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_lookback_kernel(int n, cons
     }
     if (base <= n - 1 && n - 1 < base + SCAN_ITEMS) {  // the thread that owns the last element
         cum[n] = run;
+        if (order) cum_enum[n] = run;
         if (stats_slot) *stats_slot = (int64_t)run;
     }
 }
@@ -238,7 +252,7 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
            int32_t* __restrict__ chunk_cnt, int32_t* __restrict__ owner, int32_t* __restrict__ tile_of_j,
            int32_t* __restrict__ rank_of_j, int32_t* __restrict__ tile_count, int32_t* __restrict__ keep_scan,
            int n_tiles_total, const int32_t* __restrict__ chunk_owner, const float* __restrict__ binrec,
-           uint64_t* __restrict__ seg_keys, int seg_stride, int count_stride) {
+           uint64_t* __restrict__ seg_keys, int seg_stride, int count_stride, const int32_t* __restrict__ order) {
     __shared__ int s_cum[OWNER_LDS + 1];
     extern __shared__ int s_tile[];  // DENSE: per-tile count of this workgroup, then the base of its range
     const int chunk = blockIdx.x;
@@ -281,10 +295,12 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
         int kp = 0, g = 0, t = 0;
         dbits[k] = 0u;
         if (FUSED && j < end) {
-            g = cached ? g_lo + owner_in(s_cum, 0, span, j) : owner_in(cum, g_lo, g_hi + 1, j);
+            // (`cum` is the scan in ENUMERATION order here: position ge of the caller's splat order, or the splat itself)
+            const int ge = cached ? g_lo + owner_in(s_cum, 0, span, j) : owner_in(cum, g_lo, g_hi + 1, j);
+            g = order ? order[ge] : ge;
             const float4* rec = reinterpret_cast<const float4*>(binrec + (size_t)g * BIN_RECORD_FLOATS);
             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-            const int q = j - (cached ? s_cum[g - g_lo] : cum[g]);
+            const int q = j - (cached ? s_cum[ge - g_lo] : cum[ge]);
             const unsigned wc = __float_as_uint(r2.z);
             const int w = (int)(wc & 0xFFFFu);
             const unsigned xy0 = __float_as_uint(r1.w);
@@ -1525,7 +1541,7 @@ extern "C" {
 //   [owner cap | tile cap | rank cap | chunk_cnt (cap >> 11) + 1]
 static inline size_t count_stride(size_t n_tiles) { return (n_tiles * TC_STRIDE + 31) & ~(size_t)31; }
 struct IsectScratch {
-    int32_t *tile_count, *tickets, *chunk_cnt, *owner, *tile_of_j, *rank_of_j, *chunk_owner, *tile_base;
+    int32_t *tile_count, *tickets, *chunk_cnt, *owner, *tile_of_j, *rank_of_j, *chunk_owner, *tile_base, *cum_enum;
     int owner_slots;
     uint64_t* status1;
     size_t zeroed_ints, total_ints;
@@ -1546,8 +1562,9 @@ struct IsectScratch {
         owner_slots = (int)(capacity >> KEEP_CHUNK_LOG2) + 2;
         chunk_owner = chunk_cnt + (capacity >> KEEP_CHUNK_LOG2) + 1;
         tile_base = chunk_owner + owner_slots;
+        cum_enum = tile_base + n_tiles * TC_COPIES;  // [n_gauss + 1]: the scan in the caller's enumeration order (fused path)
         total_ints = zeroed_ints + 3 * capacity + (capacity >> KEEP_CHUNK_LOG2) + 1 + (size_t)owner_slots +
-                     n_tiles * TC_COPIES;
+                     n_tiles * TC_COPIES + n_gauss + 1;
     }
 };
 
@@ -1614,7 +1631,7 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
     }
     // bounding-box counts -> cum_tiles; stats[0] = I_box
     hipLaunchKernelGGL(scan_lookback_kernel, dim3(L.nb1), dim3(SCAN_THREADS), 0, st, n, tiles_per_gauss, cum_tiles,
-                       L.tickets, L.status1, stats, L.chunk_owner, L.owner_slots);
+                       L.tickets, L.status1, stats, L.chunk_owner, L.owner_slots, (const int32_t*)nullptr, (int32_t*)nullptr);
     // keep flags, per-tile ranks and keep_scan over the first min(I_box, capacity) intersections (the caller
     // re-runs with a larger buffer when stats[0] > capacity); stats[1] = I_listed
     const int n_chunks = (capacity >> KEEP_CHUNK_LOG2) + 1;
@@ -1626,12 +1643,12 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
         hipLaunchKernelGGL((bin_kernel<true, false>), dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n, N,
                            tile_w, tile_h, width, height, cull, capacity, cum_tiles, means2d, radii, conics, opacities,
                            opac_per_camera, L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan,
-                           (int)nt, L.chunk_owner, (const float*)nullptr, (uint64_t*)nullptr, 0, 0);
+                           (int)nt, L.chunk_owner, (const float*)nullptr, (uint64_t*)nullptr, 0, 0, (const int32_t*)nullptr);
     else
         hipLaunchKernelGGL((bin_kernel<false, false>), dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h, width,
                            height, cull, capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera,
                            L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt,
-                           L.chunk_owner, (const float*)nullptr, (uint64_t*)nullptr, 0, 0);
+                           L.chunk_owner, (const float*)nullptr, (uint64_t*)nullptr, 0, 0, (const int32_t*)nullptr);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, L.tile_base, tile_offsets,
                        stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, heavy_len,
                        stats_mirror, stats_seq);
@@ -1754,7 +1771,7 @@ int mobgs::isect_fused_launch(int C, int N, int tile_w, int tile_h, int width, i
                               int32_t* tile_offsets, int32_t* tile_order, int64_t capacity_listed, int64_t* stats,
                               void* scratch, int64_t* stats_mirror, int64_t stats_seq, uint64_t* seg_keys,
                               int seg_stride, int32_t* flatten_ids, uint64_t* isect_ids, int64_t max_tile_len_hint,
-                              const MobgsTuning* tuning, void* stream) {
+                              const int32_t* enum_order, const MobgsTuning* tuning, void* stream) {
     const long long ng = (long long)C * N;
     const long long nt = (long long)C * tile_w * tile_h;
     if (C <= 0 || N <= 0 || capacity < 1 || ng >= (1ll << 31) - 1 || nt >= (1ll << 31) - 1 || !seg_keys ||
@@ -1770,24 +1787,28 @@ int mobgs::isect_fused_launch(int C, int N, int tile_w, int tile_h, int width, i
     const IsectScratch L(scratch, (size_t)n, (size_t)nt, (size_t)capacity);
     const float* binrec = isect_bin_records(scratch, (size_t)n, (size_t)nt, (size_t)capacity);
     const int cstride = (int)count_stride((size_t)nt);
+    // enum_order: the scan runs in the caller's splat order; its enumeration-order copy lives in the scratch buffer
+    const int32_t* cum_search = enum_order ? L.cum_enum : cum_tiles;
     hipLaunchKernelGGL(scan_lookback_kernel, dim3(L.nb1), dim3(SCAN_THREADS), 0, st, n, tiles_per_gauss, cum_tiles,
-                       L.tickets, L.status1, stats, L.chunk_owner, L.owner_slots);
+                       L.tickets, L.status1, stats, L.chunk_owner, L.owner_slots, enum_order, L.cum_enum);
     const int n_chunks = (capacity >> KEEP_CHUNK_LOG2) + 1;
     // LDS-ranked variant: small grids (every workgroup touches most tiles several times) and scenes with long lists
     // (dense image regions: thousands of atomics on a few counters); on a large grid with short lists the plain
     // returning atomics are ahead (47.4 against 50.2 us at 5440 tiles / 300 k splats)
-    if (nt <= DENSE_MAX_TILES && (nt <= 2048 || max_tile_len_hint >= 1024))
+    // ... and with a (spatially coherent) enumeration order, whose whole point is that a workgroup's intersections
+    // concentrate on few tiles
+    if (nt <= DENSE_MAX_TILES && (nt <= 2048 || max_tile_len_hint >= 1024 || enum_order))
         hipLaunchKernelGGL((bin_kernel<true, true>), dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n,
-                           N, tile_w, tile_h, width, height, 1, capacity, cum_tiles, (const float*)nullptr,
+                           N, tile_w, tile_h, width, height, 1, capacity, cum_search, (const float*)nullptr,
                            (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, L.chunk_cnt, L.owner,
                            L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt, L.chunk_owner, binrec, seg_keys,
-                           seg_stride, cstride);
+                           seg_stride, cstride, enum_order);
     else
         hipLaunchKernelGGL((bin_kernel<false, true>), dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h,
-                           width, height, 1, capacity, cum_tiles, (const float*)nullptr, (const int32_t*)nullptr,
+                           width, height, 1, capacity, cum_search, (const float*)nullptr, (const int32_t*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, 0, L.chunk_cnt, L.owner, L.tile_of_j,
                            L.rank_of_j, L.tile_count, keep_scan, (int)nt, L.chunk_owner, binrec, seg_keys, seg_stride,
-                           cstride);
+                           cstride, enum_order);
     hipLaunchKernelGGL(tile_finish_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count,
                        cstride, tile_offsets, stats, tile_order, (int64_t)capacity, capacity_listed, seg_stride, keep_scan,
                        n_chunks, heavy_len, stats_mirror, stats_seq);

@@ -63,7 +63,8 @@ static int project_and_bin_enqueue(int C, int N, const float* means, const float
                                    float* depths, float* conics, int32_t* tiles_per_gauss, int32_t* cum_tiles,
                                    int32_t* tile_offsets, int32_t* tile_order, int64_t* stats_dev,
                                    int capacity_box, int32_t* keep_scan, void* scratch, int64_t capacity_listed,
-                                   int32_t* flatten_ids, uint64_t* sort_keys, int seg_stride, uint64_t* isect_ids,
+                                   int32_t* flatten_ids, uint64_t* sort_keys, int seg_stride,
+                                   const int32_t* enum_order, uint64_t* isect_ids,
                                    int64_t max_tile_len_hint, int64_t* stats_host_pinned, int64_t stats_seq,
                                    const float* pack_colors, int colors_per_camera, int pack_channels,
                                    float* pack_records, const MobgsTuning* tuning, void* stream) {
@@ -115,7 +116,7 @@ static int project_and_bin_enqueue(int C, int N, const float* means, const float
         rc = mobgs::isect_fused_launch(C, N, tile_w, tile_h, width, height, capacity_box, tiles_per_gauss, cum_tiles,
                                        keep_scan, tile_offsets, tile_order, capacity_listed, stats_dev, scratch,
                                        (int64_t*)mirror, mirror ? stats_seq : 0, sort_keys, seg_stride, flatten_ids,
-                                       isect_ids, max_tile_len_hint, &tn, stream);
+                                       isect_ids, max_tile_len_hint, enum_order, &tn, stream);
     else
         rc = mobgs::isect_offsets_launch(C, N, tile_w, tile_h, width, height, cull, capacity_box, tiles_per_gauss, means2d,
                                          radii, conics, opacities, opac_per_camera, cum_tiles, keep_scan, tile_offsets,
@@ -154,7 +155,7 @@ int mobgs_project_and_bin_speculative(int C, int N, const float* means, const fl
     return project_and_bin_enqueue(C, N, means, quats, scales, viewmats, Ks, opacities, opac_per_camera, width, height,
                                    eps2d, near_plane, far_plane, radius_clip, cull, radii, means2d, depths, conics,
                                    tiles_per_gauss, cum_tiles, tile_offsets, tile_order, stats_dev, capacity_box,
-                                   keep_scan, scratch, capacity_listed, flatten_ids, sort_keys, 0, isect_ids,
+                                   keep_scan, scratch, capacity_listed, flatten_ids, sort_keys, 0, nullptr, isect_ids,
                                    max_tile_len_hint, stats_host_pinned, stats_seq, pack_colors, colors_per_camera,
                                    pack_channels, pack_records, tuning, stream);
 }
@@ -166,7 +167,7 @@ int mobgs_project_and_bin_fused(int C, int N, const float* means, const float* q
                                 float* conics, int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* tile_offsets,
                                 int32_t* tile_order, int64_t* stats_dev, int capacity_box, int32_t* keep_scan,
                                 void* scratch, int64_t capacity_listed, int32_t* flatten_ids, uint64_t* seg_keys,
-                                int seg_stride, uint64_t* isect_ids, int64_t max_tile_len_hint,
+                                int seg_stride, const int32_t* enum_order, uint64_t* isect_ids, int64_t max_tile_len_hint,
                                 int64_t* stats_host_pinned, int64_t stats_seq, const float* pack_colors,
                                 int colors_per_camera, int pack_channels, float* pack_records,
                                 const MobgsTuning* tuning, void* stream) {
@@ -177,8 +178,8 @@ int mobgs_project_and_bin_fused(int C, int N, const float* means, const float* q
     return project_and_bin_enqueue(C, N, means, quats, scales, viewmats, Ks, opacities, opac_per_camera, width, height,
                                    eps2d, near_plane, far_plane, radius_clip, cull, radii, means2d, depths, conics,
                                    tiles_per_gauss, cum_tiles, tile_offsets, tile_order, stats_dev, capacity_box,
-                                   keep_scan, scratch, capacity_listed, flatten_ids, seg_keys, seg_stride, isect_ids,
-                                   max_tile_len_hint, stats_host_pinned, stats_seq, pack_colors, colors_per_camera,
+                                   keep_scan, scratch, capacity_listed, flatten_ids, seg_keys, seg_stride, enum_order,
+                                   isect_ids, max_tile_len_hint, stats_host_pinned, stats_seq, pack_colors, colors_per_camera,
                                    pack_channels, pack_records, tuning, stream);
 }
 

@@ -1338,6 +1338,12 @@ raster_bwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
 // a pair only contributes when opacity * vis >= 1/255, so opacity > 0 wherever S != 0).  The record holds conic and
 // opacity in exponent form (common.h, write_splat_record): record_conic_form() converts back.
 // c0, c1, c2 = the summed components 0, 1, 2 in one lane -> v_x, v_y, v_conic_a (component 4 is halved by its lane).
+// one past the last bounding-box intersection of splat g: cum_tiles[g + 1] when the intersections are enumerated in splat
+// order; with a caller-chosen enumeration order (mobgs_project_and_bin_fused, enum_order) only "start + count" is right
+__device__ __forceinline__ int box_end(const int32_t* __restrict__ cum_tiles, const int32_t* __restrict__ tiles_per_gauss,
+                                       int g) {
+    return tiles_per_gauss ? cum_tiles[g] + tiles_per_gauss[g] : cum_tiles[g + 1];
+}
 __device__ __forceinline__ void finish_geometry(const float* __restrict__ rec, bool any, float& c0, float& c1, float& c2) {
     if (any) {  // (a splat without slots may have no record at all: culled splats are never packed)
         float ca, cb, cc, op;
@@ -1354,14 +1360,14 @@ slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, const i
                    const int32_t* __restrict__ keep_scan, const float* __restrict__ grad_slots, float* __restrict__ v_means2d,
                    float* __restrict__ v_conics, float* __restrict__ v_opacities, float* __restrict__ v_colors,
                    float* __restrict__ v_extra, const int32_t* __restrict__ any_record,
-                   const float* __restrict__ records) {
+                   const float* __restrict__ records, const int32_t* __restrict__ tiles_per_gauss) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPG;
     const int comp = threadIdx.x % LPG;
     if (gid >= n_gauss) return;
     // stage 1 wrote no record at all (every cotangent of the pass was zero): all sums are zero, read nothing
     const bool none = any_record && *any_record == 0;
     const int a = none ? 0 : keep_index(keep_scan, cum_tiles[gid]);
-    const int b = none ? 0 : keep_index(keep_scan, cum_tiles[gid + 1]);
+    const int b = none ? 0 : keep_index(keep_scan, box_end(cum_tiles, tiles_per_gauss, gid));
     float acc = 0.f;
     if (comp < stride) {
         // 4 independent partial sums keep 4 loads in flight per lane (the loop is latency-bound otherwise);
@@ -1415,13 +1421,14 @@ slot_reduce_wide_kernel(int n_gauss, int channels, int has_extra, int rq, const 
                         const int32_t* __restrict__ keep_scan, const float* __restrict__ grad_slots,
                         float* __restrict__ v_means2d, float* __restrict__ v_conics, float* __restrict__ v_opacities,
                         float* __restrict__ v_colors, float* __restrict__ v_extra,
-                        const int32_t* __restrict__ any_record, const float* __restrict__ records) {
+                        const int32_t* __restrict__ any_record, const float* __restrict__ records,
+                        const int32_t* __restrict__ tiles_per_gauss) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPS;
     const int q = threadIdx.x % LPS;
     if (gid >= n_gauss || q >= rq) return;
     const bool none = any_record && *any_record == 0;  // stage 1 wrote no record: all sums are zero
     const int a = none ? 0 : keep_index(keep_scan, cum_tiles[gid]);
-    const int b = none ? 0 : keep_index(keep_scan, cum_tiles[gid + 1]);
+    const int b = none ? 0 : keep_index(keep_scan, box_end(cum_tiles, tiles_per_gauss, gid));
     const float4* p = reinterpret_cast<const float4*>(grad_slots) + q;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
     int k = a;
@@ -1474,7 +1481,12 @@ slot_reduce16_kernel(int n_gauss, int channels, int has_extra, const int32_t* __
                      const int32_t* __restrict__ keep_scan, const float* __restrict__ grad_slots,
                      float* __restrict__ v_means2d, float* __restrict__ v_conics, float* __restrict__ v_opacities,
                      float* __restrict__ v_colors, float* __restrict__ v_extra,
-                     const int32_t* __restrict__ any_record, const float* __restrict__ records) {
+                     const int32_t* __restrict__ any_record, const float* __restrict__ records,
+                     const int32_t* __restrict__ tiles_per_gauss) {
+    // (With an enumeration order -- mobgs_hip.h, enum_order -- a splat's slots sit where the ORDER put them: this kernel
+    // then reads 360-byte runs at random places instead of one stream, 32 -> 39 us.  Walking the splats in enumeration
+    // order instead was measured: the slot buffer streams again, but cum_tiles / records are gathered and five small
+    // outputs per splat scattered -- 65 us.)
     constexpr int SUBS = LPS / 4;
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPS;
     const int l16 = threadIdx.x & (LPS - 1);
@@ -1483,7 +1495,7 @@ slot_reduce16_kernel(int n_gauss, int channels, int has_extra, const int32_t* __
     int a = 0, b = 0;
     if (live && !(any_record && *any_record == 0)) {  // (no record written by stage 1: every sum is zero)
         a = keep_index(keep_scan, cum_tiles[gid]);
-        b = keep_index(keep_scan, cum_tiles[gid + 1]);
+        b = keep_index(keep_scan, box_end(cum_tiles, tiles_per_gauss, gid));
     }
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     const float4* p = reinterpret_cast<const float4*>(grad_slots) + q;
@@ -1785,7 +1797,7 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
 int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const float* records,
                             const int32_t* cum_tiles, const int32_t* keep_scan, const float* grad_slots,
                             const int32_t* any_record, float* v_means2d, float* v_conics, float* v_opacities,
-                            float* v_colors, float* v_extra, void* stream) {
+                            float* v_colors, float* v_extra, const int32_t* tiles_per_gauss, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int D = channels + (has_extra ? 1 : 0);
     if (C <= 0 || N < 0 || D < 1 || ((long long)C * N > 0 && !records)) {
@@ -1798,31 +1810,31 @@ int mobgs_raster_bwd_reduce(int C, int N, int channels, int has_extra, const flo
         if (stride == 8) {
             hipLaunchKernelGGL(slot_reduce_wide_kernel<2>, dim3((int)(((size_t)n * 2 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, 2, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics,
-                               v_opacities, v_colors, v_extra, any_record, records);
+                               v_opacities, v_colors, v_extra, any_record, records, tiles_per_gauss);
         } else if (stride < 8) {
             hipLaunchKernelGGL(slot_reduce_kernel<8>, dim3((n * 8 + 255) / 256), dim3(256), 0, st, n, channels,
                                has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities, v_colors,
-                               v_extra, any_record, records);
+                               v_extra, any_record, records, tiles_per_gauss);
         } else if (stride == 12) {
             hipLaunchKernelGGL(slot_reduce_wide_kernel<4>, dim3((int)(((size_t)n * 4 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, 3, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics,
-                               v_opacities, v_colors, v_extra, any_record, records);
+                               v_opacities, v_colors, v_extra, any_record, records, tiles_per_gauss);
         } else if (stride == 16) {  // (slot_reduce_wide_kernel<4> measures the same here: 29.0 vs 28.7 us)
             hipLaunchKernelGGL(slot_reduce16_kernel<8>, dim3((int)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
-                               v_colors, v_extra, any_record, records);
+                               v_colors, v_extra, any_record, records, tiles_per_gauss);
         } else if (stride <= 16) {
             hipLaunchKernelGGL(slot_reduce_kernel<16>, dim3((int)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
-                               v_colors, v_extra, any_record, records);
+                               v_colors, v_extra, any_record, records, tiles_per_gauss);
         } else if (stride <= 32 && (stride & 3) == 0) {
             hipLaunchKernelGGL(slot_reduce_wide_kernel<8>, dim3((int)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, stride / 4, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics,
-                               v_opacities, v_colors, v_extra, any_record, records);
+                               v_opacities, v_colors, v_extra, any_record, records, tiles_per_gauss);
         } else {
             hipLaunchKernelGGL(slot_reduce_kernel<32>, dim3((int)(((size_t)n * 32 + 255) / 256)), dim3(256), 0, st, n,
                                channels, has_extra, stride, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
-                               v_colors, v_extra, any_record, records);
+                               v_colors, v_extra, any_record, records, tiles_per_gauss);
         }
     }
     return check_launch("slot_reduce_kernel");

@@ -465,11 +465,14 @@ layers_slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, 
                           const int32_t* __restrict__ keep_scan, const float* __restrict__ grad_slots,
                           const float* __restrict__ grad_xy0, float* __restrict__ v_means2d_l0,
                           float* __restrict__ v_means2d, float* __restrict__ v_conics,
-                          float* __restrict__ v_opacities, float* __restrict__ v_colors, float* __restrict__ v_extra) {
+                          float* __restrict__ v_opacities, float* __restrict__ v_colors, float* __restrict__ v_extra,
+                          const int32_t* __restrict__ tiles_per_gauss) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / 16;
     const int comp = threadIdx.x % 16;
     if (gid >= n_gauss) return;
-    const int a = 2 * keep_index(keep_scan, cum_tiles[gid]), b = 2 * keep_index(keep_scan, cum_tiles[gid + 1]);
+    // (with a caller-chosen enumeration order of the intersections only start + count is the end: mobgs_hip.h, enum_order)
+    const int end_box = tiles_per_gauss ? cum_tiles[gid] + tiles_per_gauss[gid] : cum_tiles[gid + 1];
+    const int a = 2 * keep_index(keep_scan, cum_tiles[gid]), b = 2 * keep_index(keep_scan, end_box);
     float acc = 0.f;
     if (comp < stride) {
         const float* p = grad_slots + (size_t)a * stride + comp;
@@ -535,7 +538,7 @@ int mobgs_raster_layers_bwd(int C, int N, int Ns, int layer_mask, int channels, 
                             const int32_t* const* last_ids3_host, const float* const* v_render3_host,
                             const float* const* v_alphas3_host, float* grad_slots, float* grad_xy0,
                             float* v_means2d_layer0, float* v_means2d, float* v_conics, float* v_opacities,
-                            float* v_colors, float* v_extra, void* stream) {
+                            float* v_colors, float* v_extra, const int32_t* tiles_per_gauss, void* stream) {
     const int D = channels + (has_extra ? 1 : 0);
     if (C <= 0 || N < 0 || D != 10 || !(layer_mask & 7)) {
         set_error("mobgs_raster_layers_bwd: unsupported arguments");
@@ -564,7 +567,7 @@ int mobgs_raster_layers_bwd(int C, int N, int Ns, int layer_mask, int channels, 
     if (n > 0)
         hipLaunchKernelGGL(layers_slot_reduce_kernel, dim3((int)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, n,
                            channels, has_extra, record_stride(D), cum_tiles, keep_scan, grad_slots, grad_xy0,
-                           v_means2d_layer0, v_means2d, v_conics, v_opacities, v_colors, v_extra);
+                           v_means2d_layer0, v_means2d, v_conics, v_opacities, v_colors, v_extra, tiles_per_gauss);
     return check_launch("raster_layers_bwd_kernel");
 }
 

@@ -158,6 +158,44 @@ def _times(cam, delta_exposure, dev):
     return const(float(t32))
 
 
+# Enumeration order of the binning (rendering.SharedProjection(order=), include/mobgs_hip.h enum_order): a Morton order of
+# the splats' 3-D positions, cached per (static set, dynamic set) and recomputed every ENUM_ORDER_REFRESH calls (the
+# Gaussians move slowly; densification changes N and forces a new one).  A performance structure only: lists, images and
+# gradients are bit-identical with any order or none (tests/test_gpu_fused_lists.py).
+ENUM_ORDER = __import__("os").environ.get("MOBGS_ENUM_ORDER", "1") != "0"
+ENUM_ORDER_REFRESH = 256
+_enum_cache = {}
+
+
+def _enum_order(stat_pc, dyn_pc, means, cameras=1):
+    if not (ENUM_ORDER and _R.FUSED_LISTS):
+        return None
+    key = (id(stat_pc), id(dyn_pc))
+    n = int(means.shape[-2])
+    e = _enum_cache.get(key)
+    fresh = e is None or e["stat"]() is not stat_pc or e["dyn"]() is not dyn_pc or e["n"] != n or \
+        e["dev"] != means.device
+    if not fresh:
+        e["calls"] += 1
+        fresh = e["calls"] >= ENUM_ORDER_REFRESH
+    if fresh:
+        if torch.cuda.is_current_stream_capturing():   # (a sort allocates: not inside a HIP-graph capture)
+            return None if e is None or e["n"] != n or e["dev"] != means.device else e["by_c"].get(cameras)
+        if len(_enum_cache) > 16:
+            _enum_cache.clear()
+        base = _R.spatial_order(means if means.dim() == 2 else means[0])
+        e = _enum_cache[key] = {"stat": weakref.ref(stat_pc), "dyn": weakref.ref(dyn_pc), "n": n, "dev": means.device,
+                                "calls": 0, "by_c": {1: base}}
+    order = e["by_c"].get(cameras)
+    if order is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        base = e["by_c"][1]
+        order = e["by_c"][cameras] = (base[None, :] + n * torch.arange(cameras, device=base.device,
+                                                                        dtype=torch.int32)[:, None]).reshape(-1).contiguous()
+    return order
+
+
 def _prep(stat_pc, dyn_pc, times):
     return PrepSplats.apply(times, stat_pc._xyz, stat_pc._scaling, stat_pc._rotation, stat_pc._opacity,
                             stat_pc._features_dc, stat_pc._features_t, dyn_pc.get_control_xyz,
@@ -294,7 +332,8 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     # ONE projection and ONE tile binning / sort per render() call; the whole-set image comes from the single-set
     # compositor, the static-only / dynamic-only images (when asked for) from ONE layered walk over the same lists
     # (the reference: 5 rasterizations, :143-176, :201-214, :236-268)
-    sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None], K[None], W, H, pack_colors=cols)
+    sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None], K[None], W, H, pack_colors=cols,
+                             order=_enum_order(stat_pc, dyn_pc, means))
     # The intersection counts are still on their way to the host (speculative binning).  Compositing AND decoding are
     # enqueued before waiting for them, so that the device has the rest of the forward pass queued while the host
     # waits -- on small scenes (tens of thousands of splats) the step is host-bound and this wait was a bubble.
@@ -401,7 +440,8 @@ def render_many(viewpoint_cameras, stat_pc, dyn_pc, pipe, bg_color, delta_exposu
     means, quats, scales, opac, cols = _prep(stat_pc, dyn_pc, torch.stack([_times(c, d, dev) for c, d in zip(cams, deltas)]))
     viewmats = torch.stack([c.world_view_transform.transpose(0, 1) for c in cams])
     Ks = torch.stack([c.K for c in cams])
-    sp = _R.SharedProjection(means, quats, scales, opac, viewmats, Ks, W, H, pack_colors=cols)
+    sp = _R.SharedProjection(means, quats, scales, opac, viewmats, Ks, W, H, pack_colors=cols,
+                             order=_enum_order(stat_pc, dyn_pc, means, K))
 
     def composite_and_decode():
         rays = _rays_of_many(cams) if K > 1 else None   # (one image: the single-image call, [3,H,W] out)
@@ -473,7 +513,8 @@ def _flow_mid_state(cam, stat_pc, dyn_pc, dev):
     W, H = int(cam.image_width), int(cam.image_height)
     viewmat = cam.world_view_transform.transpose(0, 1)
     mid_m, mid_q, scales, opac, cols = _prep(stat_pc, dyn_pc, _times(cam, None, dev))
-    sp = _R.SharedProjection(mid_m, mid_q, scales, opac, viewmat[None], cam.K[None], W, H)
+    sp = _R.SharedProjection(mid_m, mid_q, scales, opac, viewmat[None], cam.K[None], W, H,
+                             order=_enum_order(stat_pc, dyn_pc, mid_m))
     sp.flow_cols = cols  # the colour features at the mid time (get_flow_many: the call with exposure offset 0)
     return sp
 
@@ -493,7 +534,8 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     exp_m, exp_q, scales, opac, exp_c = _prep(stat_pc, dyn_pc, _times(cam, delta_exposure, dev))
 
     # two projections + two tile binnings of the whole set (the reference: 2 explicit projections + 4 rasterizations)
-    sp_exp = _R.SharedProjection(exp_m, exp_q, scales, opac, viewmat[None], K[None], W, H)
+    sp_exp = _R.SharedProjection(exp_m, exp_q, scales, opac, viewmat[None], K[None], W, H,
+                                 order=_enum_order(stat_pc, dyn_pc, exp_m))
     sp_mid = _mid if _mid is not None else _flow_mid_state(cam, stat_pc, dyn_pc, dev)
 
     def splat(sp, colors):
@@ -575,7 +617,8 @@ def _get_flow_exposures(cam, stat_pc, dyn_pc, bg_color, deltas, mid):
     w1, w2 = _decoder_weights(dyn_pc)
     Ns = stat_pc.get_xyz.shape[0]
     means, quats, scales, opac, cols = _prep(stat_pc, dyn_pc, torch.stack([_times(cam, d, dev) for d in deltas]))  # cols [G,N,9]
-    sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None].expand(G, 4, 4), cam.K[None].expand(G, 3, 3), W, H)
+    sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None].expand(G, 4, 4), cam.K[None].expand(G, 3, 3), W, H,
+                             order=_enum_order(stat_pc, dyn_pc, means, G))
     bgG = _bgK_cache.setdefault(G, DerivedCache()).get((bg1,), lambda: bg1.expand(G, 9).contiguous())
     bg11 = _bgK_cache.setdefault(("11", G), DerivedCache()).get(
         (bg1,), lambda: torch.cat([bg1, bg1.new_zeros(1, 2)], dim=-1).expand(G, 11).contiguous())

@@ -49,12 +49,21 @@ def test_bad_arguments_are_refused_before_any_launch():
     from mobgs_amd import _lib
     h = _lib.load()
     none = ctypes.c_void_p(None)
-    rc = h.mobgs_raster_bwd_reduce(1, 5, 3, 0, none, none, none, none, none, none, none, none, none, none, none)
+    rc = h.mobgs_raster_bwd_reduce(1, 5, 3, 0, none, none, none, none, none, none, none, none, none, none, none, none)
     assert rc == -1 and b"mobgs_raster_bwd_reduce" in h.mobgs_last_error()
-    rc = h.mobgs_raster_bwd_reduce(0, 5, 3, 0, none, none, none, none, none, none, none, none, none, none, none)
+    rc = h.mobgs_raster_bwd_reduce(0, 5, 3, 0, none, none, none, none, none, none, none, none, none, none, none, none)
     assert rc == -1
     with pytest.raises(RuntimeError, match="mobgs_raster_bwd_reduce"):
         _lib.check(rc, "mobgs_raster_bwd_reduce")
+
+
+def test_abi_version_is_checked():
+    """The bindings refuse a library whose mobgs_abi_version() differs from the header they were written against
+    (a signature changed mid-list without any version signal)."""
+    from mobgs_amd import _lib
+    h = _lib.load()
+    text = open(HEADER).read()
+    assert h.mobgs_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define MOBGS_ABI_VERSION (\d+)", text).group(1))
 
 
 def test_no_cpu_fallback():

@@ -16,7 +16,7 @@ from mobgs_amd.synth import SynthCamera, splat_inputs
 pytestmark = pytest.mark.gpu
 
 
-def _project(s, dev, W, H, fused, hint=None, C=1):
+def _project(s, dev, W, H, fused, hint=None, C=1, order=None):
     import mobgs_amd.rendering as R
     old = R.FUSED_LISTS
     R.FUSED_LISTS = fused
@@ -31,7 +31,8 @@ def _project(s, dev, W, H, fused, hint=None, C=1):
             key = R._workload_key(dev, C, t["means"].shape[0], W, H)
             R._len_hint[key] = hint
         before = R.fused_calls[0]
-        sp = R.SharedProjection(t["means"], t["quats"], t["scales"], t["opacities"], vm, Ks, W, H, want_isect_ids=True)
+        sp = R.SharedProjection(t["means"], t["quats"], t["scales"], t["opacities"], vm, Ks, W, H, want_isect_ids=True,
+                                order=order)
         took_fused = R.fused_calls[0] > before
         tl = sp.tl
         n_box, n_isects = tl.n_box, tl.n_isects  # resolves (and rebuilds on overflow)
@@ -157,4 +158,81 @@ def test_render_is_bit_identical_with_fused_lists(hip_device):
             R.FUSED_LISTS = True
     assert (True, True) in res, "the single-pass path never ran"
     for a, b in zip(res[(False, False)], res[(True, True)]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,W,H,C", [(20_000, 512, 288, 1), (7_000, 333, 201, 3), (300_000, 1352, 1014, 1)])
+def test_enumeration_order_changes_nothing_but_the_slot_numbering(hip_device, n, W, H, C):
+    """SharedProjection(order=): the bounding-box intersections enumerated along a Morton curve of the positions (and, as
+    a stress case, in a random order).  The lists -- contents, order, offsets -- must equal the unordered build's; the
+    gradient-slot numbering changes, but it must stay a bijection onto 0 .. I-1 in which every splat's slots are
+    consecutive and in its own tile order (cum_tiles[g] .. cum_tiles[g] + tiles_per_gauss[g])."""
+    import mobgs_amd.rendering as R
+    cam = SynthCamera().scaled(W, H)
+    s = splat_inputs(n, cam, 3, 9)
+    _, ref, _, n_box, n_isects = _project(s, hip_device, W, H, fused=False, C=C)
+    morton = R.spatial_order(s["means"].to(hip_device), C)
+    rnd = torch.randperm(C * n, generator=torch.Generator().manual_seed(5)).to(torch.int32).to(hip_device)
+    assert sorted(morton.cpu().tolist()) == list(range(C * n))
+    for name, order in (("morton", morton), ("random", rnd)):
+        _, got, took, n_box2, n_isects2 = _project(s, hip_device, W, H, fused=True, hint=ref.max_tile_len, C=C, order=order)
+        assert took and got.rebuilds == 0 and (n_box2, n_isects2) == (n_box, n_isects), name
+        assert torch.equal(got.tile_offsets, ref.tile_offsets), name
+        assert torch.equal(got.flatten_ids[:n_isects], ref.flatten_ids[:n_isects]), name
+        assert torch.equal(got.isect_ids[:n_isects], ref.isect_ids[:n_isects]), name
+        tpg = got.tiles_per_gauss.reshape(-1).cpu().numpy().astype(np.int64)
+        cum = got.cum_tiles.cpu().numpy().astype(np.int64)
+        assert cum[C * n] == n_box
+        # the splats' intervals [cum[g], cum[g] + tpg[g]) tile 0 .. n_box exactly, in the order given
+        o = order.cpu().numpy().astype(np.int64)
+        assert np.array_equal(cum[o], np.concatenate([[0], np.cumsum(tpg[o])[:-1]])), name
+        slots = _slots(got, n_box)
+        ref_slots, ref_cum = _slots(ref, n_box), ref.cum_tiles.cpu().numpy().astype(np.int64)
+        # per splat: the same number of kept intersections, at the same positions inside its box, as the unordered build
+        vis = np.nonzero(tpg)[0]
+        pick = vis[:: max(1, len(vis) // 4000)]
+        for g in pick:
+            a = slots[cum[g]: cum[g] + tpg[g] + 1] - slots[cum[g]]
+            b = ref_slots[ref_cum[g]: ref_cum[g] + tpg[g] + 1] - ref_slots[ref_cum[g]]
+            assert np.array_equal(a, b), (name, int(g))
+        assert slots[n_box] == n_isects, name
+
+
+def test_render_is_bit_identical_with_an_enumeration_order(hip_device):
+    """render() forward + backward with the cached Morton order (the default) against MOBGS_ENUM_ORDER off: every output
+    and gradient bit for bit -- the per-splat slot order, hence the summation order of the slot reduction, is unchanged."""
+    import mobgs_amd.gaussian_renderer as GR
+    import mobgs_amd.rendering as R
+    from mobgs_amd.camera import PinholeCamera
+    from mobgs_amd.gaussian_model import GaussianParams
+    from mobgs_amd.helper_model import Sandwich
+    from mobgs_amd.synth import dynamic_extras, gaussian_cloud
+    dev = hip_device
+    W, H = 640, 360
+    scam = SynthCamera().scaled(W, H)
+    stat_p, dyn_p = gaussian_cloud(30_000, scam, 0), gaussian_cloud(15_000, scam, 1)
+    dyn_x = dynamic_extras(dyn_p["xyz"], 0)
+    torch.manual_seed(0)
+    dec = Sandwich(9, 3).to(dev)
+    v = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    res = {}
+    for use_order in (False, True):
+        GR.ENUM_ORDER = use_order
+        try:
+            stat = GaussianParams(stat_p, None, dec, dev, requires_grad=True)
+            dyn = GaussianParams(dyn_p, dyn_x, dec, dev, requires_grad=True)
+            cam = PinholeCamera(W, H, scam.K, torch.eye(4), scam.time, scam.max_time, device=dev)
+            for rep in range(2):   # (the first call of a workload has no list-length hint yet: two-pass path, no order)
+                for p in (stat._xyz, dyn.control_xyz, stat._opacity, dyn._features_dc):
+                    p.grad = None
+                before = R.fused_calls[0]
+                out = GR.render(cam, stat, dyn, None, torch.zeros(9, device=dev), get_static=True, get_dynamic=True)
+                ((out["render"] * v).sum() + out["depth"].sum() + out["d_alpha"].sum() + out["s_render"].sum()).backward()
+            assert R.fused_calls[0] > before
+            res[use_order] = (out["render"].detach().clone(), out["depth"].detach().clone(), out["d_alpha"].detach().clone(),
+                              stat._xyz.grad.clone(), dyn.control_xyz.grad.clone(), stat._opacity.grad.clone(),
+                              dyn._features_dc.grad.clone(), out["viewspace_points"].grad.clone())
+        finally:
+            GR.ENUM_ORDER = True
+    for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
