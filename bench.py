@@ -199,14 +199,18 @@ def kernel_breakdown(args, N, Ns, Nd, I, I_box, P):
     algo = [  # (name as reported, substring of the kernel name, algorithmic bytes per launch)
         ("prep_fwd", "prep_fwd_kernel", 124.0 * Ns + 252.0 * Nd),
         ("prep_bwd", "prep_bwd_kernel", 124.0 * Ns + 252.0 * Nd + 80.0 * N),
-        ("project_fwd(+records)", "project_fwd_kernel", 140.0 * N),
+        ("project_fwd(+records, + bin records)", "project_fwd_kernel", 188.0 * N),
         ("project_bwd", "project_bwd_kernel", 140.0 * N),
         ("scan_lookback", "scan_lookback", 8.0 * N),
-        ("bin", "bin_kernel", 16.0 * I_box + 12.0 * I),
-        ("tile_scan", "tile_scan_kernel", None),
+        # single-pass lists (round 5): per box intersection 4 B of the scan + its share of the 48-byte bin record (read
+        # once per splat) + 4 B of keep_scan; per listed entry the 8-byte key written straight into its tile's segment
+        ("bin", "bin_kernel", 8.0 * I_box + 48.0 * N + 8.0 * I),
+        ("tile_finish", "tile_finish_kernel", None),
+        ("tile_scan", "tile_scan_kernel", None),       # (two-pass path: the first frame of a workload / after an overflow)
         ("emit", "emit_kernel", 20.0 * I),
-        ("tile_sort", "tile_sort", 16.0 * I),
-        ("raster_fwd", "raster_fwd", 68.0 * I + 48.0 * P),
+        ("tile_sort", "tile_sort", 12.0 * I),          # 8-byte key in, 4-byte id out
+        # (+ the decoder epilogue of the lean render: 16 B per pixel of rgb + depth on top of the 48)
+        ("raster_fwd(+decode)", "raster_fwd", 68.0 * I + 64.0 * P),
         ("raster_bwd", "raster_bwd", 132.0 * I + 52.0 * P),
         ("slot_reduce", "slot_reduce", 64.0 * I + 64.0 * N),
         ("slot_zero_fill", "FillFunctor", 64.0 * I),

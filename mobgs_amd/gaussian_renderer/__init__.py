@@ -159,11 +159,11 @@ def _times(cam, delta_exposure, dev):
 
 
 # Enumeration order of the binning (rendering.SharedProjection(order=), include/mobgs_hip.h enum_order): a Morton order of
-# the splats' 3-D positions, cached per (static set, dynamic set) and recomputed every ENUM_ORDER_REFRESH calls (the
+# the splats' 3-D positions, cached per (static set, dynamic set) and recomputed every ENUM_ORDER_REFRESH calls (~0.5 ms of small torch launches and a sort: amortised to a fraction of a microsecond per call; the
 # Gaussians move slowly; densification changes N and forces a new one).  A performance structure only: lists, images and
 # gradients are bit-identical with any order or none (tests/test_gpu_fused_lists.py).
 ENUM_ORDER = __import__("os").environ.get("MOBGS_ENUM_ORDER", "1") != "0"
-ENUM_ORDER_REFRESH = 256
+ENUM_ORDER_REFRESH = 2048
 _enum_cache = {}
 
 

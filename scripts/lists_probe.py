@@ -33,3 +33,4 @@ with torch.no_grad():
 torch.cuda.synchronize()
 print("I", n_isects, "longest", sp.tl.max_tile_len, "fused calls", R.fused_calls[0], "rebuilds", R.list_rebuilds[0])
 
+
