@@ -152,7 +152,7 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-PMC_JSON = os.path.join(ROOT, "profiles", "r04_raster_bwd_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r05_raster_bwd_pmc.json")
 
 
 def _rocprof_child(extra, tag, child_args):
@@ -246,7 +246,7 @@ def collect_pmc(args, I, P):
     """bench.py --pmc: re-collect the counters behind roofline.traffic / roofline.valu for raster_bwd -- three separate
     rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU: MI355X_MICROARCH.md, "rocprofv3 PMC slots"; no
     tracing flags) over a short child run -- and store them with the hash of the kernel sources in
-    profiles/r04_raster_bwd_pmc.json.  Correction rule (measured, DESIGN section 5: scripts/ubench/fetch_calib.hip):
+    profiles/r05_raster_bwd_pmc.json.  Correction rule (measured, DESIGN section 5: scripts/ubench/fetch_calib.hip):
     FETCH_SIZE counts a 16-byte-per-lane coalesced stream at 0.5x and 64-byte record gathers / stores at 1.0x."""
     import csv
     vals = {}
@@ -860,7 +860,7 @@ def main():
                                             "frac_of_fp32_vector_issue_peak": round(lane_ops / (F32_VECTOR_PEAK_TF
                                                                                                  * 1e12 / 2), 4)}
                     else:
-                        roof["traffic_note"] = ("profiles/r04_raster_bwd_pmc.json is from other kernel sources: ignored "
+                        roof["traffic_note"] = ("profiles/r05_raster_bwd_pmc.json is from other kernel sources: ignored "
                                                 "(python bench.py --pmc re-collects it)")
                 except Exception:  # noqa: BLE001
                     pass
