@@ -83,7 +83,17 @@ extern "C" {
  *                      1 = one wave per tile, the four-wave team (one 8x8 quadrant per wave) for the schedule's heavy
  *                      tiles; 2 = the team for every tile.  Gradients agree to summation order (observed <= 2e-5 of
  *                      each tensor's maximum).  Default (-1): 1 on grids of <= 1024 tiles, else 0 (measured).
- *   reserved           must be 0 (or the struct zero-/minus-one-initialised). */
+ *   gate_zero_cotangent  (round 5; was `reserved`) backward compositing passes, default 0 / -1 = off.  1: mobgs_raster_bwd
+ *                      and mobgs_raster_class_bwd first ask, on the device, whether ANY element of v_render / v_alphas
+ *                      is non-zero (one streaming kernel that stops at the first hit; NaN counts as non-zero).  If none
+ *                      is, the compositing kernel returns at once, no gradient record is written, any_record stays 0
+ *                      and mobgs_raster_bwd_reduce writes exact zeros without reading a slot: a loss term whose weight
+ *                      is 0 (/root/reference/train.py:675 with arguments/stereo/seesaw.py lambda_flow_loss = 0) then
+ *                      costs a probe instead of a backward pass.  No host synchronisation (HIP-graph safe).  Contract
+ *                      in this mode: `any_record` is the first word of the row right behind the slot rows
+ *                      (any_record == (int32_t*)grad_slots + rows * stride, at least 8 bytes), and the call itself
+ *                      clears the flag words and -- only when the pass runs -- the slot rows: hand over UNINITIALISED
+ *                      memory.  Ignored (treated as 0) with bwd_block_walk = 1. */
 typedef struct MobgsTuning {
     int32_t heavy_tile_len;
     int32_t longest_list_hint;
@@ -92,15 +102,21 @@ typedef struct MobgsTuning {
     int32_t bwd_block_walk;
     int32_t geometry_per_camera;
     int32_t bwd_mfma;
-    int32_t reserved[1];
+    int32_t gate_zero_cotangent;
 } MobgsTuning;
 
 const char* mobgs_version(void);
+/* Is any element of any of `n_arrays` float arrays (device pointers in the HOST array `arrays`, element counts in
+ * `counts`) non-zero?  -> *live (device int32) = 1 if so, else 0; NaN counts as non-zero, -0.0 as zero.  Streams every
+ * array once when all are zero, stops at the first hit otherwise.  The device-side form of "is this loss term's weight
+ * zero" (MobgsTuning.gate_zero_cotangent uses the same kernel for one pass; mobgs_amd.gaussian_renderer reads *live on
+ * the host to drop the whole backward graph of a view's get_flow() calls, /root/reference/train.py:570-579, :675). */
+int mobgs_cotangent_probe(int n_arrays, const float* const* arrays, const size_t* counts, int32_t* live, void* stream);
 /* Integer that changes whenever a signature, a struct layout or the format of a scratch buffer handed between entry
  * points changes (round 4 inserted `records` into mobgs_raster_bwd_reduce and changed the gradient-slot format without
  * one: a stale host extension would have passed shifted pointers).  Bindings compare it with the MOBGS_ABI_VERSION
  * they were built against and refuse to run on a mismatch (mobgs_amd/_lib.py, csrc/fastpath.cpp). */
-#define MOBGS_ABI_VERSION 6
+#define MOBGS_ABI_VERSION 7
 int mobgs_abi_version(void);
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* mobgs_last_error(void);

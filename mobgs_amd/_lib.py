@@ -22,12 +22,12 @@ class MobgsTuning(ctypes.Structure):
     _fields_ = [("heavy_tile_len", ctypes.c_int32), ("longest_list_hint", ctypes.c_int32),
                 ("quadrant_culling", ctypes.c_int32), ("block_walk", ctypes.c_int32),
                 ("bwd_block_walk", ctypes.c_int32), ("geometry_per_camera", ctypes.c_int32),
-                ("bwd_mfma", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
+                ("bwd_mfma", ctypes.c_int32), ("gate_zero_cotangent", ctypes.c_int32)]
 
     def __init__(self, heavy_tile_len=-1, longest_list_hint=-1, quadrant_culling=-1, block_walk=-1, bwd_block_walk=-1,
-                 geometry_per_camera=0, bwd_mfma=-1):
+                 geometry_per_camera=0, bwd_mfma=-1, gate_zero_cotangent=0):
         super().__init__(heavy_tile_len, longest_list_hint, quadrant_culling, block_walk, bwd_block_walk,
-                         geometry_per_camera, bwd_mfma)
+                         geometry_per_camera, bwd_mfma, gate_zero_cotangent)
 
     def ref(self):
         return ctypes.cast(ctypes.pointer(self), c_void_p)
@@ -36,7 +36,7 @@ class MobgsTuning(ctypes.Structure):
         return ctypes.addressof(self)
 
 P = c_void_p
-ABI_VERSION = 6  # include/mobgs_hip.h MOBGS_ABI_VERSION
+ABI_VERSION = 7  # include/mobgs_hip.h MOBGS_ABI_VERSION
 _SIGS = {
     "mobgs_version": (c_char_p, []),
     "mobgs_abi_version": (c_int, []),
@@ -60,6 +60,7 @@ _SIGS = {
     "mobgs_raster_fwd_decode": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, P, P,
                                         P, P, P, P, P, c_int, P, c_int, P, P, P, P, P, P]),
     "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int] + [P] * 16 + [P, P]),
+    "mobgs_cotangent_probe": (c_int, [c_int, P, P, P, P]),
     "mobgs_raster_bwd_reduce": (c_int, [c_int, c_int, c_int, c_int] + [P] * 11 + [P]),
     "mobgs_project_and_bin": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
                                       c_float, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, P, P, P,

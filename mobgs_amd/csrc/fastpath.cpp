@@ -262,7 +262,9 @@ Tensor raster_bwd(int64_t C, int64_t N, int64_t channels, int64_t has_extra, int
     const Tensor v_render = f32c(v_render_in);
     const OptT v_alphas = f32c(v_alphas_in);
     const int64_t rows = std::max<int64_t>(n_isects, 1), stride = records.size(1);
-    Tensor slots = at::zeros({rows + 1, stride}, records.options());
+    // (gate_zero_cotangent: the call clears the flag words itself and the slot rows only when the pass runs)
+    const bool gated = tp(tuning) && tp(tuning)->gate_zero_cotangent == 1 && tp(tuning)->bwd_block_walk != 1;
+    Tensor slots = gated ? at::empty({rows + 1, stride}, records.options()) : at::zeros({rows + 1, stride}, records.options());
     int32_t* flag = reinterpret_cast<int32_t*>(fpw(slots) + rows * stride);
     check(api.raster_bwd((int)C, (int)N, (int)channels, (int)has_extra, (int)width, (int)height, fp(records), fp(bg),
                          ip(radii), fp(means2d), ip(cum_tiles), ip(keep_scan), ip(tile_offsets), ip(tile_order),

@@ -1054,6 +1054,7 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
                   float* __restrict__ grad_slots, const int32_t* __restrict__ tile_order, ClassSel cls,
                   const uint8_t* __restrict__ isect_reach, int32_t* __restrict__ any_record) {
     __shared__ BwdShared<CD> sh;
+    if (cls.gated_off()) return;  // every cotangent of this pass is zero (uniform over the launch)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < 16) sh.zero16[threadIdx.x] = 0.f;
     __syncthreads();
@@ -1329,6 +1330,92 @@ raster_bwd_blocks_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h
 
 
 // ---------------------------------------------------------------------------------------------------
+// backward, stage 0 (MobgsTuning.gate_zero_cotangent): is any cotangent of this pass non-zero?
+// ---------------------------------------------------------------------------------------------------
+// live[0] was cleared by the launcher; any thread that meets a non-zero element (NaN included: x != 0 holds) stores 1.
+// The word is re-read once per grid-stride step, so with ordinary cotangents the kernel is over after the first wave
+// of workgroups; with all-zero ones it streams both arrays once (12 channels x 8 cameras at 1352x1014: 0.53 GB).
+__global__ void __launch_bounds__(256)
+cotangent_probe_kernel(const float* __restrict__ a, size_t na, const float* __restrict__ b, size_t nb,
+                       int32_t* __restrict__ live) {
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    bool nz = false;
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        const float* p = which ? b : a;
+        const size_t n = which ? nb : na;
+        if (!p || n == 0) continue;
+        const size_t head = min(n, (size_t)((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) / 4);
+        const float4* p4 = reinterpret_cast<const float4*>(p + head);
+        const size_t n4 = (n - head) / 4;
+#pragma unroll 1
+        for (size_t i = tid; i < n4; i += step) {
+            if (__builtin_nontemporal_load(live) != 0) return;
+            const float4 v = p4[i];
+            nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+            if (nz) break;
+        }
+        if (tid < head) nz |= p[tid] != 0.f;
+        const size_t tail = head + 4 * n4;
+        if (tail + tid < n) nz |= p[tail + tid] != 0.f;
+    }
+    if (nz) *live = 1;
+}
+// the same question for a LIST of arrays (the cotangents of all outputs of a group of get_flow() calls): the table rides in
+// the kernel arguments; blockIdx.y picks the array
+constexpr int PROBE_MAX = 40;
+struct ProbeTable {
+    const float* p[PROBE_MAX];
+    unsigned long long n[PROBE_MAX];
+};
+__global__ void __launch_bounds__(256) cotangent_probe_many_kernel(ProbeTable t, int32_t* __restrict__ live) {
+    const float* p = t.p[blockIdx.y];
+    const size_t n = t.n[blockIdx.y];
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    const size_t head = min(n, (size_t)((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) / 4);
+    const float4* p4 = reinterpret_cast<const float4*>(p + head);
+    const size_t n4 = (n - head) / 4;
+    bool nz = false;
+#pragma unroll 1
+    for (size_t i = tid; i < n4; i += step) {
+        if (__builtin_nontemporal_load(live) != 0) return;
+        const float4 v = p4[i];
+        nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+        if (nz) break;
+    }
+    if (tid < head) nz |= p[tid] != 0.f;
+    const size_t tail = head + 4 * n4;
+    if (tail + tid < n) nz |= p[tail + tid] != 0.f;
+    if (nz) *live = 1;
+}
+// the slot rows of a gated pass: cleared only when the pass is going to run
+__global__ void __launch_bounds__(256)
+gated_clear_kernel(float4* __restrict__ p, size_t n4, const int32_t* __restrict__ live) {
+    if (*live == 0) return;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = z;
+}
+// -> the gate word (any_record + 1), or nullptr when gating is off / the contract does not hold
+static const int32_t* arm_cotangent_gate(const MobgsTuning* tuning, const float* v_render, size_t n_render,
+                                         const float* v_alphas, size_t n_alphas, float* grad_slots,
+                                         int32_t* any_record, hipStream_t st) {
+    if (!tuning_gate_zero_cotangent(tuning) || !any_record || !grad_slots) return nullptr;
+    const ptrdiff_t words = reinterpret_cast<const float*>(any_record) - grad_slots;
+    if (words < 0 || (words & 3) || (reinterpret_cast<uintptr_t>(grad_slots) & 15)) return nullptr;
+    (void)hipMemsetAsync(any_record, 0, 2 * sizeof(int32_t), st);
+    int32_t* live = any_record + 1;
+    const size_t work = (n_render + n_alphas) / 4 + 1;
+    const int grid = (int)std::min<size_t>((work + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(cotangent_probe_kernel, dim3(grid), dim3(256), 0, st, v_render, n_render, v_alphas,
+                       v_alphas ? n_alphas : 0, live);
+    const size_t n4 = (size_t)words / 4;
+    if (n4)
+        hipLaunchKernelGGL(gated_clear_kernel, dim3((int)std::min<size_t>((n4 + 255) / 256, 256 * 16)), dim3(256), 0, st,
+                           reinterpret_cast<float4*>(grad_slots), n4, live);
+    return live;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // backward, stage 2: per-splat sum of its slots -> dense gradient tensors
 // ---------------------------------------------------------------------------------------------------
 // Components 0..4 of a slot are raw sums (blend_bwd): A = sum v_sigma dx, B = sum v_sigma dy, Sxx = sum v_sigma dx^2,
@@ -1574,6 +1661,31 @@ using namespace mobgs;
 
 extern "C" {
 
+int mobgs_cotangent_probe(int n_arrays, const float* const* arrays, const size_t* counts, int32_t* live, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n_arrays < 0 || !live || (n_arrays > 0 && (!arrays || !counts))) {
+        set_error("mobgs_cotangent_probe: bad arguments");
+        return MOBGS_E_INVALID;
+    }
+    (void)hipMemsetAsync(live, 0, sizeof(int32_t), st);
+    for (int a0 = 0; a0 < n_arrays; a0 += PROBE_MAX) {
+        ProbeTable t;
+        int m = 0;
+        size_t longest = 0;
+        for (int a = a0; a < n_arrays && a < a0 + PROBE_MAX; ++a) {
+            if (!arrays[a] || counts[a] == 0) continue;
+            t.p[m] = arrays[a];
+            t.n[m] = counts[a];
+            longest = std::max(longest, counts[a]);
+            ++m;
+        }
+        if (m == 0) continue;
+        const int gx = (int)std::min<size_t>((longest / 4 + 256) / 256, 256);
+        hipLaunchKernelGGL(cotangent_probe_many_kernel, dim3(gx, m), dim3(256), 0, st, t, live);
+    }
+    return check_launch("cotangent_probe_many_kernel");
+}
+
 int mobgs_raster_channels_supported(int D) {
     return D == 1 || D == 2 || D == 3 || D == 4 || D == 9 || D == 10 || D == 12 || D == 16 || D == 26;
 }
@@ -1696,10 +1808,14 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
     const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
     const int bwd_blocks = tuning_bwd_block_walk(tuning);
+    ClassSel cls{0, 1, 0, g_all_reach};
+    if (!bwd_blocks)
+        cls.gate = arm_cotangent_gate(tuning, v_render, (size_t)C * height * width * D, v_alphas,
+                                      (size_t)C * height * width, grad_slots, any_record, st);
     if (tuning_bwd_mfma(tuning, nt) && !bwd_blocks &&
         raster_bwd_mfma_launch(tuning_bwd_mfma(tuning, nt), D, false, grid, st, nt, n_groups, tile_w, tile_h, width, height, records, backgrounds,
                                radii, cum_tiles, keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids, v_render,
-                               v_alphas, grad_slots, tile_order, ClassSel{0, 1, 0, g_all_reach}, isect_reach, any_record))
+                               v_alphas, grad_slots, tile_order, cls, isect_reach, any_record))
         return check_launch("raster_bwd_mfma_kernel");
     const int rc = dispatch_channels(D, [&](auto cd) {
         constexpr int CD = decltype(cd)::value;
@@ -1715,7 +1831,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
         hipLaunchKernelGGL((raster_bwd_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
                            tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan,
                            tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots,
-                           tile_order, ClassSel{0, 1, 0, g_all_reach}, isect_reach, any_record);
+                           tile_order, cls, isect_reach, any_record);
     });
     if (rc != MOBGS_OK) {
         set_error("mobgs_raster_bwd: %d total channels not compiled in", D);
@@ -1775,22 +1891,25 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
     const int nt = C * tile_w * tile_h;
     const int n_groups = (nt + TILES_PER_WG - 1) / TILES_PER_WG;
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
+    ClassSel cls{class_sel, N, Ns, g_all_reach};
+    cls.gate = arm_cotangent_gate(tuning, v_render, (size_t)C * height * width * channels_total, v_alphas,
+                                  (size_t)C * height * width, grad_slots, any_record, (hipStream_t)stream);
     if (tuning_bwd_mfma(tuning, nt) &&
         raster_bwd_mfma_launch(tuning_bwd_mfma(tuning, nt), channels_total, true, grid, (hipStream_t)stream, nt, n_groups, tile_w, tile_h, width,
                                height, records, backgrounds, radii, cum_tiles, keep_scan, tile_offsets, flatten_ids,
                                render_alphas, last_ids, v_render, v_alphas, grad_slots, tile_order,
-                               ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach, any_record))
+                               cls, isect_reach, any_record))
         return check_launch("raster_bwd_mfma_kernel(class)");
     if (channels_total == 10)
         hipLaunchKernelGGL((raster_bwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream,
                            nt, n_groups, tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles,
                            keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas,
-                           grad_slots, tile_order, ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach, any_record);
+                           grad_slots, tile_order, cls, isect_reach, any_record);
     else
         hipLaunchKernelGGL((raster_bwd_kernel<1, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream,
                            nt, n_groups, tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles,
                            keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas,
-                           grad_slots, tile_order, ClassSel{class_sel, N, Ns, g_all_reach}, isect_reach, any_record);
+                           grad_slots, tile_order, cls, isect_reach, any_record);
     return check_launch("raster_bwd_kernel(class)");
 }
 

@@ -650,6 +650,7 @@ raster_bwd_mfma_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, 
                        const float* __restrict__ v_alphas, float* __restrict__ grad_slots,
                        const int32_t* __restrict__ tile_order, ClassSel cls, const uint8_t* __restrict__ isect_reach,
                        int32_t* __restrict__ any_record) {
+    if (cls.gated_off()) return;  // every cotangent of this pass is zero (uniform over the launch)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if constexpr (TEAM_ALL) {
         __shared__ TeamShared sh;

@@ -40,6 +40,11 @@ __device__ inline void wave_lds_fence() {
 struct ClassSel {
     int sel, N, Ns;
     int all_reach;  // testing aid (MobgsTuning.quadrant_culling = 0): treat every quadrant as reachable
+    // backward passes only (MobgsTuning.gate_zero_cotangent): a device word that is non-zero iff some cotangent of this
+    // pass is; when it reads 0 the kernel returns at once -- no record is written, any_record stays 0 and the slot
+    // reduction then writes exact zeros without reading a slot
+    const int32_t* gate = nullptr;
+    __device__ __forceinline__ bool gated_off() const { return gate && *gate == 0; }
     __device__ __forceinline__ bool keeps(int flat_id) const { return sel == 0 || (((flat_id % N) < Ns) == (sel == 1)); }
 };
 

@@ -507,6 +507,66 @@ def _pixel_grid(cam, W, H, like):
     return g
 
 
+# get_flow()'s images feed ONE loss term, the flow-consistency loss, whose weight is 0 in the shipped configurations
+# (/root/reference/train.py:675, arguments/stereo/seesaw.py:18 lambda_flow_loss = 0): the calls are made, their cotangents
+# arrive as exact zeros.  The compositing nodes recorded by the functions below therefore probe their cotangents on the
+# device in backward and skip the pass when all are zero (rendering.zero_cotangent_gate; bit-identical gradients
+# otherwise, exact zeros when skipped; no host synchronisation).  MOBGS_ZERO_GATE=0 switches it off (A/B).
+ZERO_GATE = __import__("os").environ.get("MOBGS_ZERO_GATE", "1") != "0"
+
+
+# ... and, outside HIP-graph captures, the callers' side of the same question is answered ONCE per call (group): the
+# outputs leave through _FlowHead, whose backward probes all their cotangents together and, when every one is zero,
+# hands autograd `None` for all of them -- nothing upstream runs at all (no compositing, decoder, projection, prep or
+# glue kernels; the leaves' .grad stay untouched, i.e. the term adds exactly nothing).  Costs one 4-byte read-back per
+# call group in backward; MOBGS_FLOW_HOST_GATE=0 leaves only the device-side gate.
+FLOW_HOST_GATE = __import__("os").environ.get("MOBGS_FLOW_HOST_GATE", "1") != "0"
+
+
+class _FlowHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *tensors):
+        ctx.set_materialize_grads(False)
+        return tuple(t.view_as(t) for t in tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if not FLOW_HOST_GATE or torch.cuda.is_current_stream_capturing():
+            return grads
+        live = [g for g in grads if g is not None]
+        if live and not all(g.is_cuda and g.dtype == torch.float32 for g in live):
+            return grads
+        if _R.cotangents_all_zero(live):
+            return (None,) * len(grads)
+        return grads
+
+
+def _flow_head(outs):
+    """outs: list of per-call output tuples -> the same structure behind one _FlowHead node."""
+    if not (ZERO_GATE and FLOW_HOST_GATE and torch.is_grad_enabled()):
+        return outs
+    flat = [t for o in outs for t in o]
+    if not any(t.requires_grad for t in flat):
+        return outs
+    flat = _FlowHead.apply(*flat)
+    res, i = [], 0
+    for o in outs:
+        res.append(tuple(flat[i:i + len(o)]))
+        i += len(o)
+    return res
+
+
+def _gated(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with _R.zero_cotangent_gate(ZERO_GATE):
+            return fn(*a, **k)
+    return wrapped
+
+
+@_gated
 def _flow_mid_state(cam, stat_pc, dyn_pc, dev):
     """Projection + tile lists of the scene at the camera's own (mid-exposure) time: the part of get_flow() that does
     not depend on delta_exposure."""
@@ -519,6 +579,58 @@ def _flow_mid_state(cam, stat_pc, dyn_pc, dev):
     return sp
 
 
+# Implicit sharing of the mid-exposure state between SEPARATE get_flow() calls: train.py:570-579
+# calls get_flow() nine times per view with nine exposure offsets; the prep / projection / tile lists at the camera's own
+# time do not depend on the offset.  get_flow_many() shares them explicitly; the unchanged caller gets the same through a
+# one-entry cache keyed on the camera, both Gaussian sets and the (storage, autograd version, length) of every tensor
+# that enters the state -- an optimiser step, densification or a new camera pose changes the key.  An entry whose graph
+# has been back-propagated through is dropped (its buffers are gone).  Not visible to the key: writes through `.data`
+# (they bypass the version counter) -- call invalidate_flow_cache() after such a write, or set MOBGS_FLOW_MID_CACHE=0.
+FLOW_MID_CACHE = __import__("os").environ.get("MOBGS_FLOW_MID_CACHE", "1") != "0"
+_mid_cache = {}
+mid_cache_stats = {"hits": 0, "misses": 0}
+
+
+def invalidate_flow_cache():
+    _mid_cache.clear()
+
+
+def _sig(t):
+    return (t.data_ptr(), t._version, tuple(t.shape), t.requires_grad) if torch.is_tensor(t) else t
+
+
+def _mid_signature(cam, stat_pc, dyn_pc):
+    ts = (stat_pc._xyz, stat_pc._scaling, stat_pc._rotation, stat_pc._opacity, stat_pc._features_dc, stat_pc._features_t,
+          dyn_pc.get_control_xyz, dyn_pc.current_control_num, dyn_pc._scaling, dyn_pc._rotation, dyn_pc._omega,
+          dyn_pc._opacity, dyn_pc._features_dc, dyn_pc._features_t, dyn_pc.get_trbfcenter, cam.world_view_transform,
+          cam.K, getattr(cam, "static_times", None))
+    return tuple(_sig(t) for t in ts) + (float(cam.time), float(cam.max_time), int(cam.image_width),
+                                         int(cam.image_height), torch.is_grad_enabled(), _R.stream_int())
+
+
+def _shared_mid_state(cam, stat_pc, dyn_pc, dev):
+    if not FLOW_MID_CACHE or torch.cuda.is_current_stream_capturing():
+        return _flow_mid_state(cam, stat_pc, dyn_pc, dev)
+    sig = _mid_signature(cam, stat_pc, dyn_pc)
+    e = _mid_cache.get("entry")
+    if e is not None and e["sig"] == sig and e["cam"]() is cam and e["stat"]() is stat_pc and e["dyn"]() is dyn_pc \
+            and not e["used"][0]:
+        mid_cache_stats["hits"] += 1
+        return e["sp"]
+    mid_cache_stats["misses"] += 1
+    sp = _flow_mid_state(cam, stat_pc, dyn_pc, dev)
+    used = [False]
+    if sp.means2d.requires_grad:
+        def _mark(g, used=used):
+            used[0] = True   # a backward pass reached the shared state: its saved buffers are being released
+            return g
+        sp.means2d.register_hook(_mark)
+    _mid_cache["entry"] = {"sig": sig, "cam": weakref.ref(cam), "stat": weakref.ref(stat_pc), "dyn": weakref.ref(dyn_pc),
+                           "sp": sp, "used": used}
+    return sp
+
+
+@_gated
 def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=None, _mid=None, _defer_mid=False):
     """/root/reference/gaussian_renderer/__init__.py:318-492 ->
     (exp2mid_coord_map [1,H,W,2], mid2exp_coord_map [1,H,W,2], latent_img [3,H,W], latent_alpha [1,H,W])."""
@@ -536,7 +648,7 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     # two projections + two tile binnings of the whole set (the reference: 2 explicit projections + 4 rasterizations)
     sp_exp = _R.SharedProjection(exp_m, exp_q, scales, opac, viewmat[None], K[None], W, H,
                                  order=_enum_order(stat_pc, dyn_pc, exp_m))
-    sp_mid = _mid if _mid is not None else _flow_mid_state(cam, stat_pc, dyn_pc, dev)
+    sp_mid = _mid if _mid is not None else _shared_mid_state(cam, stat_pc, dyn_pc, dev)
 
     def splat(sp, colors):
         return _R.rasterize_to_pixels(sp.means2d, sp.conics, colors, opac, sp.radii, sp.tl, W, H)[0]
@@ -554,10 +666,12 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     pix = _pixel_grid(cam, W, H, e2m_img)
     exp2mid = pix + e2m_img[None]
     # get_flow_many splats the mid-exposure flows of several calls in one walk over the shared lists
-    mid2exp = (pix, e2m) if _defer_mid else pix + splat(sp_mid, -e2m)
-    return exp2mid, mid2exp, latent_img, latent_alpha
+    if _defer_mid:
+        return exp2mid, (pix, e2m), latent_img, latent_alpha
+    return _flow_head([(exp2mid, pix + splat(sp_mid, -e2m), latent_img, latent_alpha)])[0]
 
 
+@_gated
 def get_flow_many(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposures):
     """[get_flow(..., delta_exposure=d) for d in delta_exposures] -- the 9 calls per view of train.py:570-579 -- with
     the mid-exposure prep / projection / tile lists (which do not depend on d) built once and shared by all of them,
@@ -600,7 +714,7 @@ def get_flow_many(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_expos
         tot = img.unflatten(-1, (len(grp), 2)) + grp[0][1][0][:, :, None, :]
         for o, part in zip(grp, tot.unbind(-2)):
             o[1] = part
-    return [tuple(o) for o in outs]
+    return _flow_head([tuple(o) for o in outs])
 
 
 BATCH_FLOW_EXPOSURES = True

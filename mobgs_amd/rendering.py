@@ -318,6 +318,59 @@ def _tuning_with_hint(key):
 
 _tuning_keepalive = []
 
+# Zero-cotangent gate (include/mobgs_hip.h MobgsTuning.gate_zero_cotangent): compositing nodes created while the gate is
+# on probe their cotangents on the device in backward and skip the pass when all of them are zero -- a loss term
+# multiplied by a zero weight (train.py:675 with lambda_flow_loss = 0) then costs a probe, not a backward pass.
+# get_flow() / get_flow_many() switch it on for their nodes; render() leaves it off (its images always carry a loss).
+_zero_gate = [0]
+
+
+class zero_cotangent_gate:
+    """with zero_cotangent_gate(): compositing nodes recorded inside skip their backward pass when every cotangent is
+    exactly zero (decided on the device: no synchronisation).  Gradients are bit-identical otherwise."""
+
+    def __init__(self, on=True):
+        self.on = 1 if on else 0
+
+    def __enter__(self):
+        self.prev = _zero_gate[0]
+        _zero_gate[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _zero_gate[0] = self.prev
+        return False
+
+
+_probe_flags = {}
+
+
+def cotangents_all_zero(tensors) -> bool:
+    """Are all elements of all given float32 HIP tensors exactly zero?  One streaming probe on the device
+    (mobgs_cotangent_probe) and ONE 4-byte read-back -- a host synchronisation: callers use it where dropping a whole
+    backward sub-graph is worth one (gaussian_renderer._FlowHead), never inside a HIP-graph capture."""
+    ts = [f32c(t) for t in tensors if t is not None and t.numel() > 0]
+    if not ts:
+        return True
+    dev = ts[0].device
+    flag = _probe_flags.get(dev)
+    if flag is None:
+        flag = _probe_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    n = len(ts)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    counts = (ctypes.c_size_t * n)(*[t.numel() for t in ts])
+    check(_lib_().mobgs_cotangent_probe(n, ptrs, counts, ptr(flag), stream()), "mobgs_cotangent_probe")
+    return int(flag.item()) == 0
+
+
+def _tuning_gated():
+    """`tuning` with the zero-cotangent gate on (a per-call copy: the gate is a property of the node, not of the module)."""
+    t = _lib.MobgsTuning(tuning.heavy_tile_len, tuning.longest_list_hint, tuning.quadrant_culling, tuning.block_walk,
+                         tuning.bwd_block_walk, 0, tuning.bwd_mfma, 1)
+    _tuning_keepalive.append(t)
+    del _tuning_keepalive[:-8]
+    return t
+
 
 class StaticCapacity:
     """Context: speculative binning WITHOUT the count read-back (round 3: HIP-graph capture of a whole render step).
@@ -544,6 +597,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.arena = tl.flatten_arena  # the lists `reach` belongs to (a rebuild replaces the arena)
         ctx.meta = (C, N, channels, extra is not None, width, height, colors_per_camera, opac_per_camera)
         ctx.bg_needs_grad = backgrounds is not None and backgrounds.requires_grad
+        ctx.gate = _zero_gate[0]
         if dec is not None:
             ctx.mark_non_differentiable(rgb, dec_depth)
             return render, alphas.unsqueeze(-1), rgb, dec_depth
@@ -565,12 +619,14 @@ class _Rasterize(torch.autograd.Function):
         if v_render is None:  # only the alpha output was used
             v_render = torch.zeros(C, height, width, D, dtype=torch.float32, device=dev)
         F = _fast.get()
+        gated = bool(ctx.gate) and tuning.bwd_block_walk != 1
+        tn = _tuning_gated() if gated else tuning
         if F is not None:  # the same body in C++ (csrc/fastpath.cpp)
             st = stream_int()
             with profiler.region("raster_bwd"):
                 slots = F.raster_bwd(C, N, channels, int(has_extra), width, height, tl.n_isects, records, bg, radii,
                                      means2d, tl.cum_tiles, tl.keep_scan, tl.tile_offsets, tl.tile_order,
-                                     tl.flatten_ids, alphas, last_ids, v_render, v_alphas, reach, tuning.address(), st)
+                                     tl.flatten_ids, alphas, last_ids, v_render, v_alphas, reach, tn.address(), st)
             v_means2d, v_conics, v_opac, v_colors, v_extra = F.raster_bwd_reduce(
                 C, N, channels, int(has_extra), records, tl.cum_tiles, tl.keep_scan, slots, st, tl.tiles_per_gauss)
         else:
@@ -578,7 +634,8 @@ class _Rasterize(torch.autograd.Function):
             v_alphas = f32c(v_alphas) if v_alphas is not None else None
             # one extra row: its first word is the any_record flag of include/mobgs_hip.h (zeroed by the same fill)
             rows = max(tl.n_isects, 1)
-            slots = torch.zeros(rows + 1, stride, dtype=torch.float32, device=dev)
+            # (gated: the call clears the flag words itself, and the slot rows only when the pass is going to run)
+            slots = (torch.empty if gated else torch.zeros)(rows + 1, stride, dtype=torch.float32, device=dev)
             flag = ctypes.c_void_p(slots.data_ptr() + 4 * rows * stride)
             v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
             v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
@@ -590,7 +647,7 @@ class _Rasterize(torch.autograd.Function):
                                            ptr(radii), ptr(means2d), ptr(tl.cum_tiles), ptr(tl.keep_scan),
                                            ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas),
                                            ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(slots), ptr(reach),
-                                           flag, tuning.ref(), stream()), "mobgs_raster_bwd")
+                                           flag, tn.ref(), stream()), "mobgs_raster_bwd")
             check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(records), ptr(tl.cum_tiles),
                                               ptr(tl.keep_scan), ptr(slots), flag, ptr(v_means2d), ptr(v_conics), ptr(v_opac),
                                               ptr(v_colors), ptr(v_extra), ptr(tl.tiles_per_gauss), stream()),
@@ -642,6 +699,7 @@ class _RasterizeClassAlpha(torch.autograd.Function):
                 break
         ctx.save_for_backward(records, radii, alphas, last, reach, bg)
         ctx.tl, ctx.arena = tl, tl.flatten_arena
+        ctx.gate = _zero_gate[0]
         ctx.meta = (C, N, width, height, opacities.dim() == 2, Ns, class_sel)
         return alphas if bg is None else render.squeeze(-1)
 
@@ -658,7 +716,10 @@ class _RasterizeClassAlpha(torch.autograd.Function):
             reach = None
         stride = records.shape[1]
         rows = max(tl.n_isects, 1)
-        slots = torch.zeros(rows + 1, stride, dtype=torch.float32, device=dev)  # last row: the any_record flag
+        gated = bool(ctx.gate)
+        tn = _tuning_gated() if gated else tuning
+        # last row: the any_record flag (gated: flag words and slot rows are cleared by the call, the rows only if it runs)
+        slots = (torch.empty if gated else torch.zeros)(rows + 1, stride, dtype=torch.float32, device=dev)
         flag = ctypes.c_void_p(slots.data_ptr() + 4 * rows * stride)
         if bg is None:   # the cotangent belongs to the alpha output
             v_render, v_a = _zero_image(C, height, width, dev), f32c(v_alphas)
@@ -668,7 +729,7 @@ class _RasterizeClassAlpha(torch.autograd.Function):
                                          ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(tl.tile_offsets),
                                          ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas), ptr(last),
                                          ptr(v_render), ptr(v_a), ptr(slots), ptr(reach), flag,
-                                         tuning.ref(), stream()), "mobgs_raster_class_bwd")
+                                         tn.ref(), stream()), "mobgs_raster_class_bwd")
         v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
         v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
         v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)

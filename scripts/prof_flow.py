@@ -44,6 +44,7 @@ def main():
     def step():
         for p in params:
             p.grad = None
+        GR.invalidate_flow_cache()   # (no optimiser step here: without this the implicit mid-state cache would hit across steps)
         if a.separate:
             outs = [GR.get_flow(cam, stat, dyn, None, bg, delta_exposure=d) for d in deltas]
         else:
