@@ -63,6 +63,12 @@ def build_scene(dev, ns, nd, width, height, seed=0):
     dec = Sandwich(9, 3).to(dev)
     stat = GaussianParams(stat_p, None, dec, dev, requires_grad=True)
     dyn = GaussianParams(dyn_p, dyn_x, dec, dev, requires_grad=True)
+    if os.environ.get("MOBGS_BENCH_UNSORTED") != "1":
+        # the model keeps its rows along a Morton curve (what a loader / densify.TrainableGaussians(keep_sorted) does after
+        # loading and after every densification): the same Gaussians, rows permuted.  MOBGS_BENCH_UNSORTED=1: rows as
+        # generated; the renderer then falls back to a cached enumeration order (+11 us of kernel time per step)
+        stat.spatial_sort_()
+        dyn.spatial_sort_()
     cam = PinholeCamera(width, height, scam.K, torch.eye(4), time=scam.time, max_time=scam.max_time, device=dev)
     return scam, cam, stat, dyn, (stat_p, dyn_p, dyn_x)
 

@@ -22,12 +22,20 @@ class MobgsTuning(ctypes.Structure):
     _fields_ = [("heavy_tile_len", ctypes.c_int32), ("longest_list_hint", ctypes.c_int32),
                 ("quadrant_culling", ctypes.c_int32), ("block_walk", ctypes.c_int32),
                 ("bwd_block_walk", ctypes.c_int32), ("geometry_per_camera", ctypes.c_int32),
-                ("bwd_mfma", ctypes.c_int32), ("gate_zero_cotangent", ctypes.c_int32)]
+                ("bwd_mfma", ctypes.c_int32), ("gate_zero_cotangent", ctypes.c_int32),
+                ("coherent_order", ctypes.c_int32)]
 
     def __init__(self, heavy_tile_len=-1, longest_list_hint=-1, quadrant_culling=-1, block_walk=-1, bwd_block_walk=-1,
-                 geometry_per_camera=0, bwd_mfma=-1, gate_zero_cotangent=0):
+                 geometry_per_camera=0, bwd_mfma=-1, gate_zero_cotangent=0, coherent_order=0):
         super().__init__(heavy_tile_len, longest_list_hint, quadrant_culling, block_walk, bwd_block_walk,
-                         geometry_per_camera, bwd_mfma, gate_zero_cotangent)
+                         geometry_per_camera, bwd_mfma, gate_zero_cotangent, coherent_order)
+
+    def copy(self, **overrides):
+        """A per-call copy with some fields replaced."""
+        t = MobgsTuning(*[getattr(self, n) for n, _ in self._fields_])
+        for k, v in overrides.items():
+            setattr(t, k, v)
+        return t
 
     def ref(self):
         return ctypes.cast(ctypes.pointer(self), c_void_p)

@@ -281,6 +281,7 @@ inline int tuning_bwd_mfma(const MobgsTuning* t, int n_tiles) {
     if (v < 0) v = (size_t)n_tiles <= SCHED_SMALL_GRID ? 1 : 0;
     return v > 2 ? 2 : v;
 }
+inline int tuning_coherent_order(const MobgsTuning* t) { return (t && t->coherent_order == 1) ? 1 : 0; }
 inline int tuning_gate_zero_cotangent(const MobgsTuning* t) { return (t && t->gate_zero_cotangent == 1) ? 1 : 0; }
 inline int tuning_geometry_per_camera(const MobgsTuning* t) { return (t && t->geometry_per_camera == 1) ? 1 : 0; }
 void isect_zeroed_region(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity, int32_t** ptr, size_t* count);

@@ -1797,7 +1797,8 @@ int mobgs::isect_fused_launch(int C, int N, int tile_w, int tile_h, int width, i
     // returning atomics are ahead (47.4 against 50.2 us at 5440 tiles / 300 k splats)
     // ... and with a (spatially coherent) enumeration order, whose whole point is that a workgroup's intersections
     // concentrate on few tiles
-    if (nt <= DENSE_MAX_TILES && (nt <= 2048 || max_tile_len_hint >= 1024 || enum_order))
+    // ... or with splats STORED in such an order (MobgsTuning.coherent_order: the caller's statement)
+    if (nt <= DENSE_MAX_TILES && (nt <= 2048 || max_tile_len_hint >= 1024 || enum_order || tuning_coherent_order(tuning)))
         hipLaunchKernelGGL((bin_kernel<true, true>), dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n,
                            N, tile_w, tile_h, width, height, 1, capacity, cum_search, (const float*)nullptr,
                            (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, L.chunk_cnt, L.owner,

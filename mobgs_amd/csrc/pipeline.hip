@@ -105,7 +105,7 @@ static int project_and_bin_enqueue(int C, int N, const float* means, const float
                                        stream, tuning_geometry_per_camera(tuning), bin);
     if (rc != MOBGS_OK) return rc;
     // the binning variant follows the caller's expectation of the longest list (max_tile_len_hint)
-    MobgsTuning tn = tuning ? *tuning : MobgsTuning{-1, -1, -1, -1, -1, 0, -1, 0};
+    MobgsTuning tn = tuning ? *tuning : MobgsTuning{-1, -1, -1, -1, -1, 0, -1, 0, 0};
     tn.longest_list_hint = (int32_t)(max_tile_len_hint > 0x7fffffff ? 0x7fffffff : max_tile_len_hint);
     void* mirror = nullptr;
     if (hipHostGetDevicePointer(&mirror, stats_host_pinned, 0) != hipSuccess) {

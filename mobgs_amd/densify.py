@@ -190,8 +190,21 @@ class TrainableGaussians(GaussianParams):
               "mobgs_mask_indices")
         return idx[:int(cnt.item())]
 
+    @torch.no_grad()
+    def spatial_sort_(self) -> torch.Tensor:
+        """GaussianParams.spatial_sort_ for the whole table: parameters, Adam moments and densification statistics move
+        together in ONE gather.  `keep_sorted = True` makes every densification end with it."""
+        from .rendering import spatial_order
+        order = spatial_order(self.sort_positions()).to(torch.int32)
+        self._rebuild(order, reset_stats=False)
+        self.rows_coherent = self._n
+        return order.long()
+
+    keep_sorted = False
+
     def _rebuild(self, index: torch.Tensor, reset_stats: bool):
         """Table := rows `index` (int32; negative = NEW copy of row -(i+1)) of the current table."""
+        self.rows_coherent = -1
         if self.optimizer is not None:
             self.adopt_optimizer_state()
         n_out = int(index.shape[0])
@@ -238,7 +251,10 @@ class TrainableGaussians(GaussianParams):
     @torch.no_grad()
     def prune_points(self, mask):
         keep = self._indices_of(mask.reshape(-1).to(torch.uint8), 0)
+        coherent = self.rows_coherent == self._n
         self._rebuild(keep, reset_stats=False)
+        if coherent:  # a subsequence of ordered rows is ordered
+            self.rows_coherent = self._n
 
     @torch.no_grad()
     def densify_and_clone(self, grads, grad_threshold, scene_extent, *_unused, **_unused_kw):
@@ -247,6 +263,8 @@ class TrainableGaussians(GaussianParams):
         sel = self._indices_of(clone, 1)
         every = torch.arange(self._n, dtype=torch.int32, device=sel.device)
         self._rebuild(torch.cat([every, -(sel + 1)]), reset_stats=True)
+        if self.keep_sorted:
+            self.spatial_sort_()
 
     @torch.no_grad()
     def densify_and_splitv2(self, grads, grad_threshold, scene_extent, N=2, samples=None):
@@ -272,6 +290,8 @@ class TrainableGaussians(GaussianParams):
                                                   ptr(self._fields["xyz"].view(self._n)),
                                                   ptr(self._fields["scaling"].view(self._n)), stream()),
                   "mobgs_split_children")
+        if self.keep_sorted:
+            self.spatial_sort_()
 
     @torch.no_grad()
     def densify_pruneclone(self, max_grad, min_opacity, extent, max_screen_size, splitN=2, samples=None):

@@ -30,6 +30,8 @@ class GaussianParams:
             return t
 
         self.attr_dtype = attr_dtype
+        self.is_dynamic = dynamic is not None
+        self.rows_coherent = -1   # the row count at which spatial_sort_() last ordered the rows (-1: never)
         self._xyz = P(params["xyz"])
         self._scaling = P(params["scaling"], attr=True)
         self._rotation = P(params["rotation"], attr=True)
@@ -47,6 +49,39 @@ class GaussianParams:
         self.scaling_activation = torch.exp
         self.opacity_activation = torch.sigmoid
         self.rotation_activation = F.normalize
+
+    # --- storage order ------------------------------------------------------------------------------
+    PER_SPLAT = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_t", "_omega", "_trbf_center",
+                 "control_xyz", "current_control_num")
+
+    def sort_positions(self) -> torch.Tensor:
+        """[n,3] representative positions of the rows: the static position, or the mean spline control point."""
+        return self.control_xyz.detach().float().mean(1) if self.is_dynamic else self._xyz.detach().float()
+
+    @torch.no_grad()
+    def spatial_sort_(self) -> torch.Tensor:
+        """Store the rows along a Morton curve of their positions (rendering.spatial_order) -> the permutation applied.
+        The renderer's binning kernel works on 2048 consecutive bounding-box intersections at a time; when consecutive
+        rows are neighbours in space those fall on a handful of tiles and are ranked in LDS with one global atomic per
+        (workgroup, tile) -- 1352x1014 / 300 k splats: bin 49.6 -> 29.9 us -- and every kernel that walks the rows
+        streams (gaussian_renderer passes rendering.COHERENT while `rows_coherent` equals the row count; otherwise it
+        falls back to a cached enumeration ORDER over unsorted rows, which costs an indirection in three kernels).
+        Rendering does not depend on the row order (ties in depth aside); optimiser state kept outside this object must
+        be permuted by the caller with the returned indices (densify.TrainableGaussians does it for its own).  Call it
+        after loading and after densification; positions drift slowly in between."""
+        from .rendering import spatial_order
+        order = spatial_order(self.sort_positions()).long()
+        for name in self.PER_SPLAT:
+            t = getattr(self, name, None)
+            if torch.is_tensor(t) and t.shape[:1] == order.shape:
+                t.data = t.data[order]
+                t.grad = None
+                m = getattr(t, "master", None)
+                if m is not None:
+                    m.data = m.data[order]
+                    m.grad = None
+        self.rows_coherent = int(order.numel())
+        return order
 
     # --- accessors with the reference's names -------------------------------------------------------
     @property

@@ -167,9 +167,15 @@ ENUM_ORDER_REFRESH = 2048
 _enum_cache = {}
 
 
+def _rows_coherent(pc):
+    return getattr(pc, "rows_coherent", -1) == pc.get_xyz.shape[0]
+
+
 def _enum_order(stat_pc, dyn_pc, means, cameras=1):
     if not (ENUM_ORDER and _R.FUSED_LISTS):
         return None
+    if _rows_coherent(stat_pc) and _rows_coherent(dyn_pc):
+        return _R.COHERENT   # both sets store their rows along a Morton curve (GaussianParams.spatial_sort_): no order needed
     key = (id(stat_pc), id(dyn_pc))
     n = int(means.shape[-2])
     e = _enum_cache.get(key)

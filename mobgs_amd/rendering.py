@@ -309,8 +309,7 @@ if os.environ.get("MOBGS_BWD_MFMA") is not None:  # A/B arm of the round-4 backw
 
 def _tuning_with_hint(key):
     """`tuning` plus the longest list the previous frame on this device had (selects the dense binning variant)."""
-    t = _lib.MobgsTuning(tuning.heavy_tile_len, _len_hint.get(key, 0), tuning.quadrant_culling, tuning.block_walk,
-                          tuning.bwd_block_walk, 0, tuning.bwd_mfma)
+    t = tuning.copy(longest_list_hint=_len_hint.get(key, 0), geometry_per_camera=0)
     _tuning_keepalive.append(t)
     del _tuning_keepalive[:-8]
     return t.ref()
@@ -365,8 +364,7 @@ def cotangents_all_zero(tensors) -> bool:
 
 def _tuning_gated():
     """`tuning` with the zero-cotangent gate on (a per-call copy: the gate is a property of the node, not of the module)."""
-    t = _lib.MobgsTuning(tuning.heavy_tile_len, tuning.longest_list_hint, tuning.quadrant_culling, tuning.block_walk,
-                         tuning.bwd_block_walk, 0, tuning.bwd_mfma, 1)
+    t = tuning.copy(geometry_per_camera=0, gate_zero_cotangent=1)
     _tuning_keepalive.append(t)
     del _tuning_keepalive[:-8]
     return t
@@ -1001,12 +999,17 @@ class _ProjectAndBin(torch.autograd.Function):
         if per_cam:
             if not (quats.dim() == 3 and means.shape[0] == C and quats.shape[0] == C and SPECULATIVE_BINNING):
                 raise ValueError("per-camera geometry: means [C,N,3] and quats [C,N,4] with C = number of cameras")
-            call_tuning = _lib.MobgsTuning(tuning.heavy_tile_len, tuning.longest_list_hint, tuning.quadrant_culling,
-                                           tuning.block_walk, tuning.bwd_block_walk, 1, tuning.bwd_mfma)
-            _tuning_keepalive.append(call_tuning)
-            del _tuning_keepalive[:-8]
+            call_tuning = tuning.copy(geometry_per_camera=1)
         else:
             call_tuning = tuning
+        if isinstance(order, str):  # COHERENT: the splats are STORED in a spatially coherent order (no indirection)
+            call_tuning = (call_tuning if call_tuning is not tuning else tuning.copy()) if order == COHERENT else call_tuning
+            if order == COHERENT:
+                call_tuning.coherent_order = 1
+            order = None
+        if call_tuning is not tuning:
+            _tuning_keepalive.append(call_tuning)
+            del _tuning_keepalive[:-8]
         F = _fast.get() if SPECULATIVE_BINNING else None
         if F is not None:  # allocations + the orchestrator call in C++ (csrc/fastpath.cpp)
             global _stats_slots
@@ -1169,6 +1172,11 @@ class _ProjectAndBin(torch.autograd.Function):
 _bg_ext_cache = DerivedCache()
 
 
+# SharedProjection(order=COHERENT): "the rows of this set are already stored along a space-filling curve" -- the binning
+# kernel then behaves as with an enumeration order, without one (MobgsTuning.coherent_order)
+COHERENT = "coherent"
+
+
 @torch.no_grad()
 def spatial_order(means: Tensor, cameras: int = 1) -> Tensor:
     """int32 [cameras * N]: the splats along a Morton (Z-order) curve of their 3-D positions `means` [N,3] (10 bits per
@@ -1203,7 +1211,8 @@ class SharedProjection:
         projection kernel then writes the compositor's packed records itself (one launch and one pass over the
         projection outputs fewer); passing other colours later simply packs again.
         order: int32 [C*N] permutation of the flat splat ids in which the binning enumerates the splats (see spatial_order():
-        a spatially coherent one makes the binning kernel ~2x faster; lists, images and gradients do not depend on it)."""
+        a spatially coherent one makes the binning kernel ~2x faster; lists, images and gradients do not depend on it),
+        or COHERENT: the rows themselves are stored in such an order (GaussianParams.spatial_sort_())."""
         self.width, self.height = int(width), int(height)
         self.C, self.N = viewmats.shape[0], means.shape[-2]
         self.opacities = opacities
