@@ -303,6 +303,33 @@ int mobgs_project_and_bin_fused(int C, int N, const float* means, const float* q
                                 int64_t* stats_host_pinned, int64_t stats_seq, const float* pack_colors,
                                 int colors_per_camera, int pack_channels, float* pack_records,
                                 const MobgsTuning* tuning, void* stream);
+/* The same call with the per-splat state built INSIDE the projection kernel (round 5): what
+ * mobgs_prep_fwd computes from the raw parameters of the two sets -- /root/reference/gaussian_renderer/__init__.py:93-125,
+ * :181-185 (spline position, rotation + t * omega, exp / sigmoid activations, colour features) -- is evaluated by the
+ * thread that projects the splat, bit for bit the arithmetic of mobgs_prep_fwd, so the activated state is not written
+ * by one launch and read back by the next.  One camera (C = 1), float attributes, N = prep->Ns + prep->Nd.
+ * `means` [N,3], `quats` [N,4], `scales` [N,3] and `opacities` [N] are OUTPUTS here (the backward pass and the caller's
+ * result dict need them); the 9 colour features only exist inside `pack_records` (stride mobgs_record_stride(10): the
+ * depth is the tenth channel), which is required.  All pointers in the struct are device pointers. */
+typedef struct MobgsPrepInputs {
+    int32_t Ns, Nd;
+    const float* times;      /* [2]: {t_feat, t_curve}, as mobgs_prep_fwd */
+    const float *s_xyz, *s_scaling, *s_rotation, *s_opacity, *s_fdc, *s_ft;
+    const float* d_control;
+    const int64_t* d_ncp;
+    const float *d_scaling, *d_rotation, *d_omega, *d_opacity, *d_fdc, *d_ft, *d_trbf;
+} MobgsPrepInputs;
+int mobgs_prep_project_and_bin_fused(const MobgsPrepInputs* prep, float* means, float* quats, float* scales,
+                                     const float* viewmats, const float* Ks, float* opacities, int width, int height,
+                                     float eps2d, float near_plane, float far_plane, float radius_clip, int cull,
+                                     int32_t* radii, float* means2d, float* depths, float* conics,
+                                     int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* tile_offsets,
+                                     int32_t* tile_order, int64_t* stats_dev, int capacity_box, int32_t* keep_scan,
+                                     void* scratch, int64_t capacity_listed, int32_t* flatten_ids, uint64_t* seg_keys,
+                                     int seg_stride, const int32_t* enum_order, uint64_t* isect_ids,
+                                     int64_t max_tile_len_hint, int64_t* stats_host_pinned, int64_t stats_seq,
+                                     float* pack_records, const MobgsTuning* tuning, void* stream);
+
 
 /* ---- K6: rasterise forward (replaces gsplat rasterize_to_pixels fwd) -----------------------------------
  * colors   : [C,N,channels] (colors_per_camera=1) or [N,channels] (0); NULL: `records` are already packed (by

@@ -43,6 +43,13 @@ class MobgsTuning(ctypes.Structure):
     def address(self) -> int:
         return ctypes.addressof(self)
 
+class MobgsPrepInputs(ctypes.Structure):
+    """include/mobgs_hip.h MobgsPrepInputs: the raw parameters of the two sets (device pointers)."""
+    _fields_ = [("Ns", ctypes.c_int32), ("Nd", ctypes.c_int32)] + [(n, c_void_p) for n in (
+        "times", "s_xyz", "s_scaling", "s_rotation", "s_opacity", "s_fdc", "s_ft", "d_control", "d_ncp", "d_scaling",
+        "d_rotation", "d_omega", "d_opacity", "d_fdc", "d_ft", "d_trbf")]
+
+
 P = c_void_p
 ABI_VERSION = 7  # include/mobgs_hip.h MOBGS_ABI_VERSION
 _SIGS = {
@@ -83,6 +90,9 @@ _SIGS = {
     "mobgs_project_and_bin_fused": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
                                             c_float, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, c_int,
                                             P, P, c_int64, P, c_int64, P, c_int, c_int, P, P, P]),
+    "mobgs_prep_project_and_bin_fused": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float,
+                                                 c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, c_int, P,
+                                                 P, c_int64, P, c_int64, P, P, P]),
     "mobgs_densify_stats": (c_int, [c_int, P, c_int, P, P, P, P, P, P]),
     "mobgs_densify_select": (c_int, [c_int, c_int, P, P, P, c_float, c_float, P, P, P]),
     "mobgs_mask_indices": (c_int, [c_int, P, c_int, P, P, P]),

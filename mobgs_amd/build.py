@@ -80,7 +80,7 @@ def is_stale() -> bool:
     if not LIB_PATH.exists():
         return True
     t = LIB_PATH.stat().st_mtime
-    deps = sources() + [CSRC / "common.h", CSRC / "raster_shared.h", CSRC / "decoder_shared.h", CSRC / "hexplane.h", CSRC.parent.parent / "include" / "mobgs_hip.h"]
+    deps = sources() + [CSRC / "common.h", CSRC / "raster_shared.h", CSRC / "decoder_shared.h", CSRC / "prep_shared.h", CSRC / "hexplane.h", CSRC.parent.parent / "include" / "mobgs_hip.h"]
     return any(d.exists() and d.stat().st_mtime > t for d in deps)
 
 
@@ -103,7 +103,7 @@ def _build_extension_locked(force: bool, verbose: bool) -> Path:
         objs.append(obj)
         if not force and obj.exists() and obj.stat().st_mtime > max(
                 src.stat().st_mtime, (CSRC / "common.h").stat().st_mtime, (CSRC / "hexplane.h").stat().st_mtime,
-                (CSRC / "raster_shared.h").stat().st_mtime, (CSRC / "decoder_shared.h").stat().st_mtime,
+                (CSRC / "raster_shared.h").stat().st_mtime, (CSRC / "decoder_shared.h").stat().st_mtime, (CSRC / "prep_shared.h").stat().st_mtime,
                 (CSRC.parent.parent / "include" / "mobgs_hip.h").stat().st_mtime):
             continue
         cmd = [hipcc, *flags, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]

@@ -248,7 +248,8 @@ int project_fwd_launch(int C, int N, const float* means, const float* quats, con
                        const float* Ks, int width, int height, float eps2d, float near_plane, float far_plane,
                        float radius_clip, int32_t* radii, float* means2d, float* depths, float* conics,
                        int32_t* tiles_per_gauss, int32_t* zero_ptr, size_t zero_n, PackArgs pack, void* stream,
-                       int geometry_per_camera = 0, BinArgs bin = BinArgs{nullptr, nullptr, 0, 0});
+                       int geometry_per_camera = 0, BinArgs bin = BinArgs{nullptr, nullptr, 0, 0},
+                       const MobgsPrepInputs* prep = nullptr);
 // mobgs_isect_offsets; scratch_zeroed: the counters were cleared by the caller; stats_mirror: device-visible host
 // address that receives a copy of stats[0..2] (or NULL) and then, in word 3, stats_seq (when non-zero)
 int isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width, int height, int cull, int capacity,

@@ -44,6 +44,7 @@ struct Api {
     decltype(&mobgs_project_bwd_scratch_floats) project_bwd_scratch_floats = nullptr;
     decltype(&mobgs_project_and_bin_speculative) project_and_bin_speculative = nullptr;
     decltype(&mobgs_project_and_bin_fused) project_and_bin_fused = nullptr;
+    decltype(&mobgs_prep_project_and_bin_fused) prep_project_and_bin_fused = nullptr;
     decltype(&mobgs_fused_seg_keys_len) fused_seg_keys_len = nullptr;
     decltype(&mobgs_tile_order_len) tile_order_len = nullptr;
     decltype(&mobgs_keep_scan_len) keep_scan_len = nullptr;
@@ -84,6 +85,7 @@ void bind(const std::unordered_map<std::string, uint64_t>& m) {
     take(m, "mobgs_project_bwd_scratch_floats", api.project_bwd_scratch_floats);
     take(m, "mobgs_project_and_bin_speculative", api.project_and_bin_speculative);
     take(m, "mobgs_project_and_bin_fused", api.project_and_bin_fused);
+    take(m, "mobgs_prep_project_and_bin_fused", api.prep_project_and_bin_fused);
     take(m, "mobgs_fused_seg_keys_len", api.fused_seg_keys_len);
     take(m, "mobgs_tile_order_len", api.tile_order_len);
     take(m, "mobgs_keep_scan_len", api.keep_scan_len);
@@ -381,7 +383,14 @@ project_and_bin_speculative(const Tensor& means, const Tensor& quats, const Tens
                             double near_plane, double far_plane, double radius_clip, int64_t cull,
                             bool want_isect_ids, bool tile_schedule, const OptT& pack_colors, int64_t cap_box,
                             int64_t cap_listed, int64_t len_hint, int64_t stats_row, int64_t seq, int64_t tuning,
-                            int64_t stream, int64_t seg_stride, const OptT& enum_order) {
+                            int64_t stream, int64_t seg_stride, const OptT& enum_order,
+                            const std::vector<Tensor>& prep) {
+    // prep (empty, or the 16 float32 / int64 contiguous inputs of ops.PrepSplats: times, s_xyz, s_scaling, s_rotation,
+    // s_opacity, s_fdc, s_ft, d_control, d_ncp, d_scaling, d_rotation, d_omega, d_opacity, d_fdc, d_ft, d_trbf): the
+    // projection kernel builds the per-splat state itself -- means / quats / scales / opac are then OUTPUT buffers and
+    // the packed records carry the colour features (mobgs_prep_project_and_bin_fused)
+    const bool fused_prep = !prep.empty();
+    if (fused_prep && prep.size() != 16) throw std::runtime_error("project_and_bin: 16 prep inputs expected");
     const int64_t C = viewmats.size(0), N = means.size(-2);  // means [N,3] or, with geometry_per_camera, [C,N,3]
     const int64_t tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, nt = C * tile_w * tile_h;
     const auto f = means.options().dtype(at::kFloat);
@@ -394,7 +403,9 @@ project_and_bin_speculative(const Tensor& means, const Tensor& quats, const Tens
     OptT tile_order = tile_schedule ? OptT(at::empty({(int64_t)api.tile_order_len((int)nt)}, i32)) : OptT();
     OptT records;
     int64_t pack_ch = 0;
-    if (pack_colors.has_value() && pack_colors->defined()) {
+    if (fused_prep) {
+        records = at::empty({C * N, (int64_t)api.record_stride(10)}, f);
+    } else if (pack_colors.has_value() && pack_colors->defined()) {
         pack_ch = pack_colors->size(-1);
         if (api.raster_channels_supported((int)pack_ch + 1))
             records = at::empty({C * N, (int64_t)api.record_stride((int)pack_ch + 1)}, f);
@@ -408,7 +419,29 @@ project_and_bin_speculative(const Tensor& means, const Tensor& quats, const Tens
     OptT isect_ids = want_isect_ids ? OptT(at::empty({cap_listed}, i64)) : OptT();
     const bool pack = records.has_value();
     int rc;
-    if (seg_stride > 0)
+    if (fused_prep) {
+        MobgsPrepInputs pi;
+        pi.Ns = (int32_t)prep[1].size(0);
+        pi.Nd = (int32_t)prep[7].size(0);
+        pi.times = fp(prep[0]);
+        pi.s_xyz = fp(prep[1]); pi.s_scaling = fp(prep[2]); pi.s_rotation = fp(prep[3]); pi.s_opacity = fp(prep[4]);
+        pi.s_fdc = fp(prep[5]); pi.s_ft = fp(prep[6]);
+        pi.d_control = fp(prep[7]);
+        pi.d_ncp = static_cast<const int64_t*>(dp(prep[8]));
+        pi.d_scaling = fp(prep[9]); pi.d_rotation = fp(prep[10]); pi.d_omega = fp(prep[11]); pi.d_opacity = fp(prep[12]);
+        pi.d_fdc = fp(prep[13]); pi.d_ft = fp(prep[14]); pi.d_trbf = fp(prep[15]);
+        if (C != 1 || pi.Ns + pi.Nd != N) throw std::runtime_error("project_and_bin: fused prep needs one camera and Ns + Nd = N");
+        rc = api.prep_project_and_bin_fused(
+            &pi, fpw(means), fpw(quats), fpw(scales), fp(viewmats), fp(Ks), fpw(opac), (int)width, (int)height,
+            (float)eps2d, (float)near_plane, (float)far_plane, (float)radius_clip, (int)cull,
+            static_cast<int32_t*>(dp(radii)), fpw(means2d), fpw(depths), fpw(conics),
+            static_cast<int32_t*>(dp(tiles_per_gauss)), static_cast<int32_t*>(dp(cum_tiles)),
+            static_cast<int32_t*>(dp(tile_offsets)), static_cast<int32_t*>(dp(tile_order)),
+            static_cast<int64_t*>(dp(stats_dev)), (int)cap_box, static_cast<int32_t*>(dp(keep_scan)), dp(scratch),
+            cap_listed, static_cast<int32_t*>(dp(flatten_ids)), static_cast<uint64_t*>(dp(sort_keys)), (int)seg_stride,
+            ip(enum_order), static_cast<uint64_t*>(dp(isect_ids)), len_hint,
+            reinterpret_cast<int64_t*>(static_cast<uintptr_t>(stats_row)), seq, fpw(records), tp(tuning), sp(stream));
+    } else if (seg_stride > 0)
         rc = api.project_and_bin_fused(
             (int)C, (int)N, fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), fp(opac), opac.dim() == 2 ? 1 : 0,
             (int)width, (int)height, (float)eps2d, (float)near_plane, (float)far_plane, (float)radius_clip, (int)cull,

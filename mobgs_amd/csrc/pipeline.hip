@@ -67,7 +67,8 @@ static int project_and_bin_enqueue(int C, int N, const float* means, const float
                                    const int32_t* enum_order, uint64_t* isect_ids,
                                    int64_t max_tile_len_hint, int64_t* stats_host_pinned, int64_t stats_seq,
                                    const float* pack_colors, int colors_per_camera, int pack_channels,
-                                   float* pack_records, const MobgsTuning* tuning, void* stream) {
+                                   float* pack_records, const MobgsTuning* tuning, void* stream,
+                                   const MobgsPrepInputs* prep = nullptr) {
     hipStream_t st = (hipStream_t)stream;
     const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
     if (!stats_host_pinned || capacity_listed < 1) {
@@ -84,7 +85,7 @@ static int project_and_bin_enqueue(int C, int N, const float* means, const float
     if (fuse_zero) mobgs::isect_zeroed_region(scratch, (size_t)n_all, (size_t)nt_all, (size_t)capacity_box, &zero_ptr, &zero_n);
     PackArgs pack{nullptr, nullptr, nullptr, 0, 0, 0, 0};
     if (pack_records) {
-        if (!pack_colors || !opacities || pack_channels < 0) {
+        if ((!pack_colors && !prep) || !opacities || pack_channels < 0) {
             set_error("mobgs_project_and_bin_speculative: pack_records needs pack_colors and opacities");
             return MOBGS_E_INVALID;
         }
@@ -102,7 +103,7 @@ static int project_and_bin_enqueue(int C, int N, const float* means, const float
     }
     int rc = mobgs::project_fwd_launch(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
                                        radius_clip, radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, zero_n, pack,
-                                       stream, tuning_geometry_per_camera(tuning), bin);
+                                       stream, tuning_geometry_per_camera(tuning), bin, prep);
     if (rc != MOBGS_OK) return rc;
     // the binning variant follows the caller's expectation of the longest list (max_tile_len_hint)
     MobgsTuning tn = tuning ? *tuning : MobgsTuning{-1, -1, -1, -1, -1, 0, -1, 0, 0};
@@ -181,6 +182,33 @@ int mobgs_project_and_bin_fused(int C, int N, const float* means, const float* q
                                    keep_scan, scratch, capacity_listed, flatten_ids, seg_keys, seg_stride, enum_order,
                                    isect_ids, max_tile_len_hint, stats_host_pinned, stats_seq, pack_colors, colors_per_camera,
                                    pack_channels, pack_records, tuning, stream);
+}
+
+int mobgs_prep_project_and_bin_fused(const MobgsPrepInputs* prep, float* means, float* quats, float* scales,
+                                     const float* viewmats, const float* Ks, float* opacities, int width, int height,
+                                     float eps2d, float near_plane, float far_plane, float radius_clip, int cull,
+                                     int32_t* radii, float* means2d, float* depths, float* conics,
+                                     int32_t* tiles_per_gauss, int32_t* cum_tiles, int32_t* tile_offsets,
+                                     int32_t* tile_order, int64_t* stats_dev, int capacity_box, int32_t* keep_scan,
+                                     void* scratch, int64_t capacity_listed, int32_t* flatten_ids, uint64_t* seg_keys,
+                                     int seg_stride, const int32_t* enum_order, uint64_t* isect_ids,
+                                     int64_t max_tile_len_hint, int64_t* stats_host_pinned, int64_t stats_seq,
+                                     float* pack_records, const MobgsTuning* tuning, void* stream) {
+    if (!prep || !means || !quats || !scales || !opacities || !pack_records) {
+        set_error("mobgs_prep_project_and_bin_fused: prep, the four state outputs and pack_records are required");
+        return MOBGS_E_INVALID;
+    }
+    if (prep->Ns < 0 || prep->Nd < 0 || prep->Ns + prep->Nd < 1) {
+        set_error("mobgs_prep_project_and_bin_fused: bad sizes Ns=%d Nd=%d", prep->Ns, prep->Nd);
+        return MOBGS_E_INVALID;
+    }
+    // seg_stride 0: the two-pass lists (first frame of a workload, or the caller's choice)
+    return project_and_bin_enqueue(1, prep->Ns + prep->Nd, means, quats, scales, viewmats, Ks, opacities, 0, width, height,
+                                   eps2d, near_plane, far_plane, radius_clip, cull, radii, means2d, depths, conics,
+                                   tiles_per_gauss, cum_tiles, tile_offsets, tile_order, stats_dev, capacity_box,
+                                   keep_scan, scratch, capacity_listed, flatten_ids, seg_keys, seg_stride, enum_order,
+                                   isect_ids, max_tile_len_hint, stats_host_pinned, stats_seq, nullptr, 0, 9, pack_records,
+                                   tuning, stream, prep);
 }
 
 }  // extern "C"

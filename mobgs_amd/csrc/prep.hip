@@ -22,120 +22,28 @@
 // 232 -> 188 per dynamic one).  Positions / spline control points / time centres stay fp32: a half cannot hold a
 // position in centimetres.  The backward kernel writes the attribute gradients in the type G the caller asks for
 // (half leaves need half .grad tensors; the multi-render accumulation buffers of LeafGradSink stay fp32).
-#include <hip/hip_fp16.h>
-
-#include "common.h"
+#include "prep_shared.h"
 
 namespace mobgs {
 
-__device__ inline float ldf(const float* p, size_t i) { return p[i]; }
-__device__ inline float ldf(const __half* p, size_t i) { return __half2float(p[i]); }
-__device__ inline float4 ld4(const float* p, size_t i) { return reinterpret_cast<const float4*>(p)[i]; }
-__device__ inline float4 ld4(const __half* p, size_t i) {
-    const uint2 u = reinterpret_cast<const uint2*>(p)[i];  // 4 halves = 8 bytes
-    const __half2 a = *reinterpret_cast<const __half2*>(&u.x), b = *reinterpret_cast<const __half2*>(&u.y);
-    const float2 fa = __half22float2(a), fb = __half22float2(b);
-    return make_float4(fa.x, fa.y, fb.x, fb.y);
-}
-__device__ inline void stf(float* p, size_t i, float v) { p[i] = v; }
-__device__ inline void stf(__half* p, size_t i, float v) { p[i] = __float2half(v); }
-__device__ inline void st4(float* p, size_t i, float4 v) { reinterpret_cast<float4*>(p)[i] = v; }
-__device__ inline void st4(__half* p, size_t i, float4 v) {
-    const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
-    uint2 u;
-    u.x = *reinterpret_cast<const unsigned*>(&a);
-    u.y = *reinterpret_cast<const unsigned*>(&b);
-    reinterpret_cast<uint2*>(p)[i] = u;
-}
-
-struct Hermite {
-    int i0, i1, i2, i3;  // left, index, right, right-right knots
-    float h00, h10, h01, h11;
-    bool left_edge, right_edge;
-};
-
-__device__ inline Hermite hermite_setup(float t, int n) {
-    Hermite H;
-    const float ts = t * (float)(n - 1);
-    int idx = (int)floorf(ts);
-    idx = min(max(idx, 0), n - 2);
-    H.i1 = idx;
-    H.i0 = min(max(idx - 1, 0), n - 1);
-    H.i2 = min(max(idx + 1, 0), n - 1);
-    H.i3 = min(max(idx + 2, 0), n - 1);
-    const float u = ts - (float)idx;
-    const float omu = 1.f - u;
-    H.h00 = (1.f + 2.f * u) * (omu * omu);
-    H.h10 = u * (omu * omu);
-    H.h01 = (u * u) * (3.f - 2.f * u);
-    H.h11 = (u * u) * (u - 1.f);
-    H.left_edge = (H.i0 == H.i1);
-    H.right_edge = (H.i3 == H.i2);
-    return H;
-}
-
 template <typename A>
 __global__ void __launch_bounds__(256)
-prep_fwd_kernel(int Ns, int Nd, const float* __restrict__ times,
-                // static
-                const float* __restrict__ s_xyz, const A* __restrict__ s_scaling,
-                const A* __restrict__ s_rotation, const A* __restrict__ s_opacity,
-                const A* __restrict__ s_fdc, const A* __restrict__ s_ft,
-                // dynamic
-                const float* __restrict__ d_control, const long long* __restrict__ d_ncp,
-                const A* __restrict__ d_scaling, const A* __restrict__ d_rotation,
-                const A* __restrict__ d_omega, const A* __restrict__ d_opacity,
-                const A* __restrict__ d_fdc, const A* __restrict__ d_ft, const float* __restrict__ d_trbf,
+prep_fwd_kernel(PrepIn<A> in,
                 // out
                 float* __restrict__ means, float* __restrict__ quats, float* __restrict__ scales,
                 float* __restrict__ opac, float* __restrict__ colors) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = Ns + Nd;
+    const int N = in.Ns + in.Nd;
     if (i >= N) return;
     // several time instants in one launch (grid.y; the K sub-frames of a blurry view): instant kk reads times[kk] and
     // writes row block kk of means / quats / colors; scales and opacities do not depend on time and are written once
     const int kk = blockIdx.y;
-    times += 2 * kk;
+    in.times += 2 * kk;
     means += (size_t)kk * N * 3;
     quats += (size_t)kk * N * 4;
     colors += (size_t)kk * N * 9;
     float m[3], q[4], s[3], o, col[9];
-    if (i < Ns) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            m[k] = s_xyz[3 * i + k];
-            s[k] = expf(ldf(s_scaling, 3 * (size_t)i + k));  // (accurate exp: the scale decides the integer radius)
-            col[6 + k] = 0.0f * ldf(s_ft, 3 * (size_t)i + k);
-        }
-        // the reference normalises static rotations (get_rotation_stat); emit them raw, see header
-        const float4 r = ld4(s_rotation, i);
-        q[0] = r.x; q[1] = r.y; q[2] = r.z; q[3] = r.w;
-        o = 1.f / (1.f + expf(-ldf(s_opacity, i)));
-#pragma unroll
-        for (int k = 0; k < 6; ++k) col[k] = ldf(s_fdc, 6 * (size_t)i + k);
-    } else {
-        const int j = i - Ns;
-        const float t_feat = times[0], t_curve = times[1];
-        const float tfp = t_feat - d_trbf[j];
-        const int n = (int)d_ncp[j];
-        const Hermite H = hermite_setup(t_curve, n);
-        const float* cp = d_control + (size_t)j * 36;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float p0 = cp[3 * H.i0 + k], p1 = cp[3 * H.i1 + k], p2 = cp[3 * H.i2 + k], p3 = cp[3 * H.i3 + k];
-            const float m0 = H.left_edge ? (p2 - p1) : (p2 - p0) * 0.5f;
-            const float m1 = H.right_edge ? (p2 - p1) : (p3 - p1) * 0.5f;
-            m[k] = (H.h00 * p1 + H.h10 * m0 + H.h01 * p2 + H.h11 * m1) * 1e-2f;
-            s[k] = expf(ldf(d_scaling, 3 * (size_t)j + k));
-            col[6 + k] = tfp * ldf(d_ft, 3 * (size_t)j + k);
-        }
-        const float4 r = ld4(d_rotation, j);
-        const float4 w = ld4(d_omega, j);
-        q[0] = r.x + tfp * w.x; q[1] = r.y + tfp * w.y; q[2] = r.z + tfp * w.z; q[3] = r.w + tfp * w.w;
-        o = 1.f / (1.f + expf(-ldf(d_opacity, j)));
-#pragma unroll
-        for (int k = 0; k < 6; ++k) col[k] = ldf(d_fdc, 6 * (size_t)j + k);
-    }
+    prep_splat(in, i, m, q, s, o, col);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         means[3 * i + k] = m[k];
@@ -320,10 +228,10 @@ static int prep_fwd_launch(int K, int Ns, int Nd, const float* times, const floa
     }
     const int N = Ns + Nd;
     if (N == 0) return MOBGS_OK;
-    hipLaunchKernelGGL(prep_fwd_kernel<A>, dim3((N + 255) / 256, K), dim3(256), 0, (hipStream_t)stream, Ns, Nd, times,
-                       s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_control, (const long long*)d_ncp,
-                       d_scaling, d_rotation, d_omega, d_opacity, d_fdc, d_ft, d_trbf, means, quats, scales, opacities,
-                       colors);
+    const PrepIn<A> in{Ns, Nd, times, s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_control,
+                       (const long long*)d_ncp, d_scaling, d_rotation, d_omega, d_opacity, d_fdc, d_ft, d_trbf};
+    hipLaunchKernelGGL(prep_fwd_kernel<A>, dim3((N + 255) / 256, K), dim3(256), 0, (hipStream_t)stream, in, means, quats,
+                       scales, opacities, colors);
     return check_launch("prep_fwd_kernel");
 }
 

@@ -9,6 +9,7 @@
 #include <stdarg.h>
 
 #include "common.h"
+#include "prep_shared.h"
 
 namespace mobgs {
 
@@ -116,6 +117,15 @@ __device__ inline Persp persp_setup(const Cam& cam, const float p[3], int width,
     return P;
 }
 
+// PREP (mobgs_prep_project_and_bin_fused, one camera): the thread BUILDS its splat's state from the raw parameters
+// (prep_shared.h: spline position, rotation, exp / sigmoid activations, colour features -- the arithmetic of
+// prep_fwd_kernel, bit for bit) instead of loading it, and writes position / rotation / scales / opacity out for the
+// backward pass and the caller's result dict; the colour features go straight into the compositor's record.
+struct PrepFused {
+    PrepIn<float> in;
+    float *means, *quats, *scales, *opac;
+};
+template <bool PREP>
 __global__ void __launch_bounds__(256)
 project_fwd_kernel(int N, const float* __restrict__ means, const float* __restrict__ quats,
                    const float* __restrict__ scales, const float* __restrict__ viewmats,
@@ -123,7 +133,7 @@ project_fwd_kernel(int N, const float* __restrict__ means, const float* __restri
                    float far_plane, float radius_clip, int tile_w, int tile_h,
                    int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
                    float* __restrict__ conics, int32_t* __restrict__ tiles_per_gauss, int32_t* __restrict__ zero_ptr,
-                   unsigned zero_n, PackArgs pack, int geom_stride, BinArgs bin) {
+                   unsigned zero_n, PackArgs pack, int geom_stride, BinArgs bin, PrepFused prep) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     // geometry_per_camera: camera c reads rows [c N, c N + N) of means / quats (geom_stride = N), else the shared rows
@@ -136,7 +146,21 @@ project_fwd_kernel(int N, const float* __restrict__ means, const float* __restri
     const Cam cam = load_cam(viewmats, Ks, c);
     const size_t o = (size_t)c * N + i;
 
-    const float m[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    float m[3], pq[4] = {0.f, 0.f, 0.f, 0.f}, ps[3] = {0.f, 0.f, 0.f}, pop = 0.f, pcol[9];
+    if constexpr (PREP) {
+        prep_splat(prep.in, i, m, pq, ps, pop, pcol);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            prep.means[3 * i + k] = m[k];
+            prep.scales[3 * i + k] = ps[k];
+        }
+        reinterpret_cast<float4*>(prep.quats)[i] = make_float4(pq[0], pq[1], pq[2], pq[3]);
+        prep.opac[i] = pop;
+    } else {
+        m[0] = means[3 * i];
+        m[1] = means[3 * i + 1];
+        m[2] = means[3 * i + 2];
+    }
     float p[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -147,9 +171,17 @@ project_fwd_kernel(int N, const float* __restrict__ means, const float* __restri
     int ntiles = 0;
     TileRect tr{0, 0, 0, 0};
     if (p[2] >= near_plane && p[2] <= far_plane) {
-        const float4 qv = reinterpret_cast<const float4*>(quats)[i];
-        const float q[4] = {qv.x, qv.y, qv.z, qv.w};
-        const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        float q[4], s[3];
+        if constexpr (PREP) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = pq[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s[k] = ps[k];
+        } else {
+            const float4 qv = reinterpret_cast<const float4*>(quats)[i];
+            q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+            s[0] = scales[3 * i]; s[1] = scales[3 * i + 1]; s[2] = scales[3 * i + 2];
+        }
         float Rq[9], M[9], S3[9], RS[9], Sc[9];
         quat_to_rotmat(q, Rq);
 #pragma unroll
@@ -205,14 +237,21 @@ project_fwd_kernel(int N, const float* __restrict__ means, const float* __restri
     // side job for the orchestrator: the compositor's record of this splat (depth as the extra channel) while
     // everything it needs is in registers -- saves the pack launch and re-reading means2d / conics / depths
     // ... and its bin record (fused binning path, common.h): only splats with tiles are ever looked up
-    if (bin.records && ntiles > 0)
-        write_bin_record(bin.records + o * BIN_RECORD_FLOATS, m2x, m2y, ca, cb, cc, depth,
-                         bin.opacities[bin.opac_per_camera ? o : (size_t)i], bin.cull, tr, c);
-    if (pack.records && rad > 0)
-        write_splat_record(pack.records + o * pack.stride, m2x, m2y, ca, cb, cc,
-                           pack.opacities[pack.opac_per_camera ? o : (size_t)i],
-                           pack.colors + (pack.colors_per_camera ? o : (size_t)i) * pack.channels, pack.channels, true,
-                           depth);
+    if constexpr (PREP) {
+        if (bin.records && ntiles > 0)
+            write_bin_record(bin.records + o * BIN_RECORD_FLOATS, m2x, m2y, ca, cb, cc, depth, pop, bin.cull, tr, c);
+        if (pack.records && rad > 0)
+            write_splat_record(pack.records + o * pack.stride, m2x, m2y, ca, cb, cc, pop, pcol, 9, true, depth);
+    } else {
+        if (bin.records && ntiles > 0)
+            write_bin_record(bin.records + o * BIN_RECORD_FLOATS, m2x, m2y, ca, cb, cc, depth,
+                             bin.opacities[bin.opac_per_camera ? o : (size_t)i], bin.cull, tr, c);
+        if (pack.records && rad > 0)
+            write_splat_record(pack.records + o * pack.stride, m2x, m2y, ca, cb, cc,
+                               pack.opacities[pack.opac_per_camera ? o : (size_t)i],
+                               pack.colors + (pack.colors_per_camera ? o : (size_t)i) * pack.channels, pack.channels, true,
+                               depth);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -496,7 +535,8 @@ int mobgs::project_fwd_launch(int C, int N, const float* means, const float* qua
                               const float* viewmats, const float* Ks, int width, int height, float eps2d,
                               float near_plane, float far_plane, float radius_clip, int32_t* radii, float* means2d,
                               float* depths, float* conics, int32_t* tiles_per_gauss, int32_t* zero_ptr, size_t zero_n,
-                              PackArgs pack, void* stream, int geometry_per_camera, BinArgs bin) {
+                              PackArgs pack, void* stream, int geometry_per_camera, BinArgs bin,
+                              const MobgsPrepInputs* prep) {
     if (C <= 0 || N < 0 || width <= 0 || height <= 0) {
         set_error("mobgs_project_fwd: bad sizes C=%d N=%d W=%d H=%d", C, N, width, height);
         return MOBGS_E_INVALID;
@@ -507,10 +547,31 @@ int mobgs::project_fwd_launch(int C, int N, const float* means, const float* qua
     }
     const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
     dim3 grid((N + 255) / 256, C);
-    hipLaunchKernelGGL(project_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, means, quats, scales,
+    if (prep) {
+        // the state is built in-kernel: means / quats / scales / pack.opacities are OUTPUT arrays here
+        if (C != 1 || geometry_per_camera || prep->Ns + prep->Nd != N || !pack.records || pack.channels != 9 ||
+            !pack.opacities) {
+            set_error("mobgs_prep_project_and_bin_fused: one camera, Ns + Nd = N and 9-channel packed records required");
+            return MOBGS_E_INVALID;
+        }
+        PrepFused pf;
+        pf.in = PrepIn<float>{prep->Ns, prep->Nd, prep->times, prep->s_xyz, prep->s_scaling, prep->s_rotation,
+                              prep->s_opacity, prep->s_fdc, prep->s_ft, prep->d_control,
+                              (const long long*)prep->d_ncp, prep->d_scaling, prep->d_rotation, prep->d_omega,
+                              prep->d_opacity, prep->d_fdc, prep->d_ft, prep->d_trbf};
+        pf.means = const_cast<float*>(means);
+        pf.quats = const_cast<float*>(quats);
+        pf.scales = const_cast<float*>(scales);
+        pf.opac = const_cast<float*>(pack.opacities);
+        hipLaunchKernelGGL(project_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, N, means, quats, scales,
+                           viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip, tile_w, tile_h,
+                           radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, (unsigned)zero_n, pack, 0, bin, pf);
+        return check_launch("project_fwd_kernel<prep>");
+    }
+    hipLaunchKernelGGL(project_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, N, means, quats, scales,
                        viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip, tile_w, tile_h,
                        radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, (unsigned)zero_n, pack,
-                       geometry_per_camera ? N : 0, bin);
+                       geometry_per_camera ? N : 0, bin, PrepFused{});
     return check_launch("project_fwd_kernel");
 }
 

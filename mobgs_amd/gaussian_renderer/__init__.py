@@ -177,6 +177,15 @@ def _enum_order(stat_pc, dyn_pc, means, cameras=1):
     if _rows_coherent(stat_pc) and _rows_coherent(dyn_pc):
         return _R.COHERENT   # both sets store their rows along a Morton curve (GaussianParams.spatial_sort_): no order needed
     key = (id(stat_pc), id(dyn_pc))
+    if means is None:   # (the fused-prep path has no activated positions yet: the raw ones order just as well)
+        class _Raw:
+            shape = (stat_pc._xyz.shape[0] + dyn_pc.get_control_xyz.shape[0], 3)
+            device = stat_pc._xyz.device
+
+            @staticmethod
+            def dim():
+                return 2
+        means = _Raw
     n = int(means.shape[-2])
     e = _enum_cache.get(key)
     fresh = e is None or e["stat"]() is not stat_pc or e["dyn"]() is not dyn_pc or e["n"] != n or \
@@ -189,6 +198,9 @@ def _enum_order(stat_pc, dyn_pc, means, cameras=1):
             return None if e is None or e["n"] != n or e["dev"] != means.device else e["by_c"].get(cameras)
         if len(_enum_cache) > 16:
             _enum_cache.clear()
+        if not torch.is_tensor(means):
+            means = torch.cat((stat_pc._xyz.detach().float(),
+                               dyn_pc.get_control_xyz.detach().float().mean(1) * 1e-2), 0)
         base = _R.spatial_order(means if means.dim() == 2 else means[0])
         e = _enum_cache[key] = {"stat": weakref.ref(stat_pc), "dyn": weakref.ref(dyn_pc), "n": n, "dev": means.device,
                                 "calls": 0, "by_c": {1: base}}
@@ -200,6 +212,27 @@ def _enum_order(stat_pc, dyn_pc, means, cameras=1):
         order = e["by_c"][cameras] = (base[None, :] + n * torch.arange(cameras, device=base.device,
                                                                         dtype=torch.int32)[:, None]).reshape(-1).contiguous()
     return order
+
+
+def _raw_inputs(stat_pc, dyn_pc):
+    """The 15 tensors ops.PrepSplats takes behind `times`."""
+    return (stat_pc._xyz, stat_pc._scaling, stat_pc._rotation, stat_pc._opacity, stat_pc._features_dc,
+            stat_pc._features_t, dyn_pc.get_control_xyz, dyn_pc.current_control_num, dyn_pc._scaling, dyn_pc._rotation,
+            dyn_pc._omega, dyn_pc._opacity, dyn_pc._features_dc, dyn_pc._features_t, dyn_pc.get_trbfcenter)
+
+
+# Lean render(): the per-splat state (spline position, activations, colour features) is built INSIDE the projection kernel
+# instead of by a launch of its own (rendering._PrepProjectAndBin; VERDICT r4 item 1d).  Same arithmetic, same outputs,
+# same gradients; MOBGS_FUSE_PREP=0 keeps the two launches (A/B).  Train-mode renders (static / dynamic layers read the
+# colour features as an array), the `coherent` offset, half-stored attributes and the python host path keep them too.
+FUSE_PREP = __import__("os").environ.get("MOBGS_FUSE_PREP", "1") != "0"
+
+
+def _can_fuse_prep(raw, times):
+    from .. import _fast
+    if not (FUSE_PREP and _R.SPECULATIVE_BINNING and _fast.get() is not None and times.dim() == 1):
+        return False
+    return all(t.dtype == torch.float32 for i, t in enumerate(raw) if i != 7) and raw[0].shape[0] + raw[6].shape[0] > 0
 
 
 def _prep(stat_pc, dyn_pc, times):
@@ -308,7 +341,17 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
 
     dyn_sl, stat_sl, all_sl = slice(Ns, None), slice(0, Ns), slice(None)
     times = _times(cam, delta_exposure, dev)
-    means, quats, scales, opac, cols = _prep(stat_pc, dyn_pc, times)
+    raw = _raw_inputs(stat_pc, dyn_pc)
+    fuse_prep = (coherent is None and not get_static and not get_dynamic and not (delta_exposure is not None and get_flow)
+                 and _can_fuse_prep(raw, times))
+    sp = None
+    if fuse_prep:
+        # (cols: the token the compositing node returns its colour gradient through -- never read as data)
+        sp, means, quats, scales, opac = _R.SharedProjection.from_raw(times, raw, viewmat[None], K[None], W, H,
+                                                                      order=_enum_order(stat_pc, dyn_pc, None))
+        cols = sp.state_colors
+    else:
+        means, quats, scales, opac, cols = _prep(stat_pc, dyn_pc, times)
     if coherent is not None:
         means = torch.cat((means[:Ns], means[Ns:] + coherent), 0)
 
@@ -338,8 +381,9 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     # ONE projection and ONE tile binning / sort per render() call; the whole-set image comes from the single-set
     # compositor, the static-only / dynamic-only images (when asked for) from ONE layered walk over the same lists
     # (the reference: 5 rasterizations, :143-176, :201-214, :236-268)
-    sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None], K[None], W, H, pack_colors=cols,
-                             order=_enum_order(stat_pc, dyn_pc, means))
+    if sp is None:
+        sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None], K[None], W, H, pack_colors=cols,
+                                 order=_enum_order(stat_pc, dyn_pc, means))
     # The intersection counts are still on their way to the host (speculative binning).  Compositing AND decoding are
     # enqueued before waiting for them, so that the device has the rest of the forward pass queued while the host
     # waits -- on small scenes (tens of thousands of splats) the step is host-bound and this wait was a bubble.
@@ -400,8 +444,11 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
         out["ori_flow"] = flow_img
         out["ori_coord_map"] = _pixel_grid(cam, W, H, flow_img) + flow_img
 
-    out.update({"viewspace_points": info["means2d"], "radii": radii, "colors_precomp_final": cols,
-                "means_3d": means[dyn_sl]})
+    out.update({"viewspace_points": info["means2d"], "radii": radii, "means_3d": means[dyn_sl]})
+    if fuse_prep:  # the colour features as an ARRAY only exist when somebody asks for them (train.py does not)
+        out.defer(["colors_precomp_final"], lambda: {"colors_precomp_final": _prep(stat_pc, dyn_pc, times)[4]})
+    else:
+        out["colors_precomp_final"] = cols
     if LAZY_AUX:  # train.py reads these two from the mid sub-frame only (:448-456), not from the 8 latent ones
         out.defer(["visibility_filter"], lambda: {"visibility_filter": radii > 0})
         out.defer(["means_3d_final"], lambda: {"means_3d_final": means * 1e2})

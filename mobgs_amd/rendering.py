@@ -983,12 +983,16 @@ class _ProjectAndBin(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, viewmats, Ks, opacities, tl, width, height, eps2d, near_plane, far_plane,
-                radius_clip, want_isect_ids, pack_colors=None, order=None):
+                radius_clip, want_isect_ids, pack_colors=None, order=None, prep=None):
         """order (optional): int32 [C*N], a permutation of the flat splat ids -- the enumeration order of the bounding-box
-        intersections (include/mobgs_hip.h, enum_order).  Only the single-pass path takes it; results do not depend on it."""
+        intersections (include/mobgs_hip.h, enum_order).  Only the single-pass path takes it; results do not depend on it.
+        prep (internal, _PrepProjectAndBin): the 16 raw inputs of ops.PrepSplats -- the projection kernel builds the
+        per-splat state itself; means / quats / scales / opacities are then uninitialised OUTPUT buffers."""
         import ctypes
         lib = _lib_()
         means, quats, scales, viewmats, Ks, opac = map(f32c, (means, quats, scales, viewmats, Ks, opacities))
+        if prep is not None and not (SPECULATIVE_BINNING and _fast.get() is not None):
+            raise RuntimeError("fused prep needs the C++ host fast path and speculative binning")
         C, N = viewmats.shape[0], means.shape[-2]
         dev = means.device
         tile_w, tile_h = math.ceil(width / TILE), math.ceil(height / TILE)
@@ -1036,7 +1040,8 @@ class _ProjectAndBin(torch.autograd.Function):
             rc, outs, tile_order, isect_ids, records = F.project_and_bin_speculative(
                 means, quats, scales, viewmats, Ks, opac, width, height, eps2d, near_plane, far_plane, radius_clip,
                 int(_tile_culling), bool(want_isect_ids), bool(TILE_SCHEDULE), pack, cap_box, cap_listed,
-                len_hint, row_addr, seq, call_tuning.address(), stream_int(), seg_stride, order)
+                len_hint, row_addr, seq, call_tuning.address(), stream_int(), seg_stride, order,
+                prep if prep is not None else [])
             radii, means2d, depths, conics, tiles_per_gauss, cum_tiles, tile_offsets, keep_scan, flatten_ids = outs
             tl.records = records
             event = None
@@ -1169,6 +1174,79 @@ class _ProjectAndBin(torch.autograd.Function):
                 None, None)
 
 
+class _CtxShim:
+    """What _ProjectAndBin.forward asks of its ctx, for callers that are not its autograd node."""
+
+    def save_for_backward(self, *ts):
+        self.saved_tensors = ts
+
+    def mark_non_differentiable(self, *ts):
+        pass
+
+    def set_materialize_grads(self, v):
+        pass
+
+
+class _PrepProjectAndBin(torch.autograd.Function):
+    """ops.PrepSplats + _ProjectAndBin as ONE node whose forward is one kernel fewer (round 5): the
+    projection kernel evaluates the spline / activations of its splat itself (mobgs_prep_project_and_bin_fused; the
+    arithmetic of prep_fwd_kernel, bit for bit), so the activated state is not written by one launch and read back by
+    the next, and the 9 colour features go straight into the compositor's records.
+    -> (means, quats, scales, opac, cols, radii, means2d, depths, conics, tiles_per_gauss).  `cols` [N,9] is a TOKEN: the
+    tensor through which the compositing node hands its colour gradient back; its storage is never written (the
+    features live in tl.records) -- SharedProjection.from_raw() does not expose it as data.
+    Backward: the projection backward followed by the prep backward, exactly the two separate nodes' kernels."""
+
+    @staticmethod
+    def forward(ctx, times, s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_control, d_ncp, d_scaling,
+                d_rotation, d_omega, d_opacity, d_fdc, d_ft, d_trbf, viewmats, Ks, tl, width, height, eps2d,
+                near_plane, far_plane, radius_clip, order):
+        leaf_inputs = (s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_control, d_scaling, d_rotation,
+                       d_omega, d_opacity, d_fdc, d_ft)
+        times_c, s_xyz_c, d_control_c, d_trbf_c = map(f32c, (times, s_xyz, d_control, d_trbf))
+        attrs = [f32c(a) for a in (s_scaling, s_rotation, s_opacity, s_fdc, s_ft)]
+        dattrs = [f32c(a) for a in (d_scaling, d_rotation, d_omega, d_opacity, d_fdc, d_ft)]
+        d_ncp_c = d_ncp.to(torch.int64).contiguous()
+        prep = [times_c, s_xyz_c, *attrs, d_control_c, d_ncp_c, *dattrs, d_trbf_c]
+        Ns, Nd = s_xyz.shape[0], d_control.shape[0]
+        N = Ns + Nd
+        dev = s_xyz.device
+        E = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        means, quats, scales, opac, cols = E(N, 3), E(N, 4), E(N, 3), E(N), E(N, 9)
+        shim = _CtxShim()
+        radii, means2d, depths, conics, tiles_per_gauss = _ProjectAndBin.forward(
+            shim, means, quats, scales, viewmats, Ks, opac, tl, width, height, eps2d, near_plane, far_plane, radius_clip,
+            False, None, order, prep)
+        ctx.save_for_backward(*shim.saved_tensors, times_c, d_ncp_c, d_trbf_c, opac)
+        ctx.dims = shim.dims
+        ctx.sizes = (Ns, Nd)
+        ctx.leaf_inputs = leaf_inputs
+        ctx.mark_non_differentiable(radii, tiles_per_gauss)
+        ctx.set_materialize_grads(False)
+        return means, quats, scales, opac, cols, radii, means2d, depths, conics, tiles_per_gauss
+
+    @staticmethod
+    def backward(ctx, v_means, v_quats, v_scales, v_opac, v_cols, _v_radii, v_means2d, v_depths, v_conics, _v_tpg):
+        from types import SimpleNamespace
+        from .ops import PrepSplats
+        saved = ctx.saved_tensors
+        means, quats, scales = saved[0], saved[1], saved[2]
+        times, d_ncp, d_trbf, opac = saved[7:11]
+        pm = pq = ps = v_viewmats = None
+        if v_means2d is not None or v_depths is not None or v_conics is not None:
+            pm, pq, ps, v_viewmats = _Project.backward(SimpleNamespace(saved_tensors=saved[:7], dims=ctx.dims), None,
+                                                       v_means2d, v_depths, v_conics, None)[:4]
+        # cotangents that reach the state directly (a loss on out["d_means3d"], a scale regulariser, ...)
+        pm = v_means if pm is None else (pm if v_means is None else pm + v_means)
+        pq = v_quats if pq is None else (pq if v_quats is None else pq + v_quats)
+        ps = v_scales if ps is None else (ps if v_scales is None else ps + v_scales)
+        f32 = torch.float32
+        g = PrepSplats.backward(SimpleNamespace(saved_tensors=(times, d_ncp, d_trbf, scales, opac), sizes=ctx.sizes,
+                                                leaf_inputs=ctx.leaf_inputs, half=False, attr_dtypes=(f32,) * 11),
+                                pm, pq, ps, v_opac, v_cols)
+        return (*g, v_viewmats, None, None, None, None, None, None, None, None, None)
+
+
 _bg_ext_cache = DerivedCache()
 
 
@@ -1226,6 +1304,29 @@ class SharedProjection:
         # position gradient of the whole-set render alone (the reference's static / dynamic passes have their own,
         # un-retained means2d tensors, gaussian_renderer/__init__.py:218-223)
         self.means2d_main = self.means2d.view_as(self.means2d)
+
+    @classmethod
+    def from_raw(cls, times, raw, viewmats, Ks, width, height, near_plane=0.01, far_plane=1e10, radius_clip=0.0,
+                 eps2d=0.3, order=None):
+        """The projection of ops.PrepSplats.apply(times, *raw)'s state without the prep launch: `raw` = the 15 tensors
+        ops.PrepSplats takes behind `times` (float32 attributes, one time instant, one camera).  -> (sp, means, quats,
+        scales, opac); sp.state_colors is the token composite() / composite_decode() must be called with (the colour
+        features exist only inside the packed records).  See _PrepProjectAndBin."""
+        self = cls.__new__(cls)
+        self.width, self.height = int(width), int(height)
+        self.tl = TileLists()
+        (means, quats, scales, opac, cols, self.radii, self.means2d, self.depths, self.conics,
+         self.tiles_per_gauss) = _PrepProjectAndBin.apply(times, *raw, viewmats, Ks, self.tl, self.width, self.height,
+                                                          float(eps2d), float(near_plane), float(far_plane),
+                                                          float(radius_clip), order)
+        self.C, self.N = 1, means.shape[0]
+        self.opacities = opac
+        self.state_colors = cols
+        self._packed_colors = cols if self.tl.records is not None else None
+        if self._packed_colors is None:
+            raise RuntimeError("fused prep: the projection kernel did not leave packed records")
+        self.means2d_main = self.means2d.view_as(self.means2d)
+        return self, means, quats, scales, opac
 
     def _bg(self, backgrounds):
         if backgrounds is None:

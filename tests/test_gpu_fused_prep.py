@@ -1,0 +1,111 @@
+"""The per-splat state built inside the projection kernel (mobgs_prep_project_and_bin_fused, rendering._PrepProjectAndBin;
+round 5) against the two launches it replaces (ops.PrepSplats + the projection): the lean render()
+must return bit-identical images, radii, positions and gradients either way -- sorted and unsorted rows, first frame
+(two-pass lists) and later frames (single-pass lists), with a camera-pose gradient, with a loss on the returned positions
+and inside an ops.LeafGradSink; the colour features, which the fused path never writes as an array, are produced on demand."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(dev, W, H, ns, nd, sort):
+    from mobgs_amd.camera import PinholeCamera
+    from mobgs_amd.gaussian_model import GaussianParams
+    from mobgs_amd.helper_model import Sandwich
+    from mobgs_amd.synth import SynthCamera, dynamic_extras, gaussian_cloud
+    scam = SynthCamera().scaled(W, H)
+    stat_p, dyn_p = gaussian_cloud(ns, scam, 0), gaussian_cloud(nd, scam, 1)
+    dyn_x = dynamic_extras(dyn_p["xyz"], 0)
+    torch.manual_seed(0)
+    dec = Sandwich(9, 3).to(dev)
+    stat = GaussianParams(stat_p, None, dec, dev, requires_grad=True)
+    dyn = GaussianParams(dyn_p, dyn_x, dec, dev, requires_grad=True)
+    if sort:
+        stat.spatial_sort_()
+        dyn.spatial_sort_()
+    pose = torch.eye(4)
+    pose[0, 3], pose[2, 3] = 0.05, 0.1
+    cam = PinholeCamera(W, H, scam.K, pose, 0.37, scam.max_time, device=dev)
+    cam.world_view_transform.requires_grad_(True)
+    return cam, stat, dyn
+
+
+def _leaves(stat, dyn):
+    return [stat._xyz, stat._scaling, stat._rotation, stat._opacity, stat._features_dc, stat._features_t, dyn.control_xyz,
+            dyn._scaling, dyn._rotation, dyn._omega, dyn._opacity, dyn._features_dc, dyn._features_t]
+
+
+@pytest.mark.parametrize("W,H,ns,nd,sort", [(650, 362, 30_000, 15_000, False), (650, 362, 30_000, 15_000, True),
+                                            (250, 170, 4_000, 2_000, False), (320, 200, 3_000, 0, True)])
+def test_lean_render_with_the_state_built_in_the_projection_kernel(hip_device, W, H, ns, nd, sort):
+    import mobgs_amd.gaussian_renderer as G
+    import mobgs_amd.rendering as R
+    dev = hip_device
+    gen = torch.Generator().manual_seed(1)
+    v = torch.randn(3, H, W, generator=gen).to(dev)
+    vd = torch.randn(1, H, W, generator=gen).to(dev)
+    res = {}
+    for fused in (False, True):
+        G.FUSE_PREP = fused
+        try:
+            cam, stat, dyn = _scene(dev, W, H, ns, max(nd, 1) if nd == 0 else nd, sort)
+            frames = []
+            for rep in range(3):   # frame 0: two-pass lists (no length hint yet); later frames: single-pass lists
+                for p in _leaves(stat, dyn) + [cam.world_view_transform] + list(dyn.rgbdecoder.parameters()):
+                    p.grad = None
+                out = G.render(cam, stat, dyn, None, torch.zeros(9, device=dev), delta_exposure=(None, 0.2, -0.3)[rep])
+                vm = torch.linspace(-1, 1, out["means_3d"].numel(), device=dev).reshape(out["means_3d"].shape)
+                ((out["render"] * v).sum() + (out["depth"] * vd).sum() + (out["means_3d"] * vm).sum()).backward()
+                frames.append([out["render"].detach().clone(), out["depth"].detach().clone(), out["radii"].clone(),
+                               out["means_3d"].detach().clone(), out["viewspace_points"].grad.clone(),
+                               cam.world_view_transform.grad.clone(), out["colors_precomp_final"].detach().clone(),
+                               out["means_3d_final"].detach().clone()]
+                              + [p.grad.clone() for p in _leaves(stat, dyn)]
+                              + [p.grad.clone() for p in dyn.rgbdecoder.parameters()])
+            res[fused] = frames
+        finally:
+            G.FUSE_PREP = True
+    assert R.fused_calls[0] > 0
+    for fa, fb in zip(res[False], res[True]):
+        for i, (a, b) in enumerate(zip(fa, fb)):
+            assert torch.equal(a, b), f"output {i}"
+
+
+def test_fused_prep_inside_a_leaf_gradient_sink_and_on_the_fallbacks(hip_device):
+    """ops.LeafGradSink recognises the fused node's leaves (gradients accumulate over two renders exactly as with the
+    separate prep node); train-mode renders, a `coherent` offset and half-stored attributes keep the two launches."""
+    import mobgs_amd.gaussian_renderer as G
+    from mobgs_amd.ops import LeafGradSink
+    dev = hip_device
+    W, H = 320, 200
+    gen = torch.Generator().manual_seed(2)
+    v = torch.randn(3, H, W, generator=gen).to(dev)
+    res = {}
+    for fused in (False, True):
+        G.FUSE_PREP = fused
+        try:
+            cam, stat, dyn = _scene(dev, W, H, 5_000, 2_500, False)
+            bg = torch.zeros(9, device=dev)
+            with LeafGradSink(stat, dyn):
+                outs = [G.render(cam, stat, dyn, None, bg, delta_exposure=d) for d in (None, 0.25)]
+                sum((o["render"] * v).sum() + o["depth"].sum() for o in outs).backward()
+            res[fused] = [p.grad.clone() for p in _leaves(stat, dyn)]
+        finally:
+            G.FUSE_PREP = True
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
+    # fallbacks: same results as ever, through the separate prep launch
+    cam, stat, dyn = _scene(dev, W, H, 5_000, 2_500, False)
+    seen = []
+    real = G._R.SharedProjection.from_raw
+    G._R.SharedProjection.from_raw = classmethod(lambda cls, *a, **k: seen.append(1) or real(*a, **k))
+    try:
+        bg = torch.zeros(9, device=dev)
+        G.render(cam, stat, dyn, None, bg)
+        assert len(seen) == 1
+        G.render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True)["d_render"]
+        G.render(cam, stat, dyn, None, bg, coherent=torch.zeros(2_500, 3, device=dev))
+        assert len(seen) == 1
+    finally:
+        G._R.SharedProjection.from_raw = real
