@@ -205,8 +205,12 @@ def kernel_breakdown(args, N, Ns, Nd, I, I_box, P):
     algo = [  # (name as reported, substring of the kernel name, algorithmic bytes per launch)
         ("prep_fwd", "prep_fwd_kernel", 124.0 * Ns + 252.0 * Nd),
         ("prep_bwd", "prep_bwd_kernel", 124.0 * Ns + 252.0 * Nd + 80.0 * N),
-        ("project_fwd(+records, + bin records)", "project_fwd_kernel", 188.0 * N),
-        ("project_bwd", "project_bwd_kernel", 140.0 * N),
+        # round 5, lean render: the projection kernel builds the per-splat state itself (raw parameters in: 80 B per static,
+        # 232 B per dynamic splat; state for the backward pass 44 B, projection outputs 32 B, compositor record 64 B and
+        # bin record 48 B out) and the projection backward ends in the leaf gradients (state + cotangents in: 124 B per
+        # splat; 80 B of gradients per static, 228 B per dynamic splat out) -- no prep_fwd / prep_bwd launch
+        ("project_fwd(+prep, records, bin records)", "project_fwd_kernel", 80.0 * Ns + 232.0 * Nd + 188.0 * N),
+        ("project_bwd(+prep_bwd)", "project_bwd_kernel", 124.0 * N + 80.0 * Ns + 228.0 * Nd),
         ("scan_lookback", "scan_lookback", 8.0 * N),
         # single-pass lists (round 5): per box intersection 4 B of the scan + its share of the 48-byte bin record (read
         # once per splat) + 4 B of keep_scan; per listed entry the 8-byte key written straight into its tile's segment

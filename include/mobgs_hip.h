@@ -159,6 +159,25 @@ int mobgs_project_bwd_ex(int C, int N, int geometry_per_camera, const float* mea
                          float eps2d, const int32_t* radii, const float* conics, const float* v_means2d,
                          const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
                          float* v_scales, float* v_viewmats, float* v_viewmats_partial, void* stream);
+/* Projection backward + prep backward of ONE camera in one launch (round 5; the backward half of
+ * mobgs_prep_project_and_bin_fused): what mobgs_project_bwd would store as v_means / v_quats / v_scales stays in the
+ * thread's registers and goes through the arithmetic of mobgs_prep_bwd (bit for bit) to the 13 leaf gradients.
+ * x_means / x_quats / x_scales (each may be NULL): cotangents that reach the activated state directly, added first.
+ * v_opacities / v_colors (may be NULL): as mobgs_prep_bwd.  accumulate: as mobgs_prep_bwd.  v_viewmats [4,4] is fully
+ * written; v_viewmats_partial: mobgs_project_bwd_scratch_floats(1, N) floats.  float32 leaves only. */
+typedef struct MobgsLeafGrads {
+    float *s_xyz, *s_scaling, *s_rotation, *s_opacity, *s_fdc, *s_ft, *d_control, *d_scaling, *d_rotation, *d_omega,
+        *d_opacity, *d_fdc, *d_ft;
+} MobgsLeafGrads;
+int mobgs_project_prep_bwd_fused(int N, const float* means, const float* quats, const float* scales,
+                                 const float* viewmats, const float* Ks, int width, int height, float eps2d,
+                                 const int32_t* radii, const float* conics, const float* v_means2d,
+                                 const float* v_depths, const float* v_conics, const float* x_means,
+                                 const float* x_quats, const float* x_scales, float* v_viewmats,
+                                 float* v_viewmats_partial, int Ns, int Nd, const float* times, const int64_t* d_ncp,
+                                 const float* d_trbf, const float* opacities, const float* v_opacities,
+                                 const float* v_colors, const MobgsLeafGrads* grads, int accumulate, void* stream);
+
 
 /* ---- K3a: intersection offsets (replaces isect_tiles pass 1 + cumsum + isect_offset_encode) ------------
  * in : tiles_per_gauss [C*N] (bounding-box tile counts from mobgs_project_fwd), means2d, radii, conics,

@@ -93,6 +93,8 @@ _SIGS = {
     "mobgs_prep_project_and_bin_fused": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float,
                                                  c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, c_int64, P, P, c_int, P,
                                                  P, c_int64, P, c_int64, P, P, P]),
+    "mobgs_project_prep_bwd_fused": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_float] + [P] * 10 + [c_int, c_int] +
+                                     [P] * 7 + [c_int, P]),
     "mobgs_densify_stats": (c_int, [c_int, P, c_int, P, P, P, P, P, P]),
     "mobgs_densify_select": (c_int, [c_int, c_int, P, P, P, c_float, c_float, P, P, P]),
     "mobgs_mask_indices": (c_int, [c_int, P, c_int, P, P, P]),

@@ -45,6 +45,7 @@ struct Api {
     decltype(&mobgs_project_and_bin_speculative) project_and_bin_speculative = nullptr;
     decltype(&mobgs_project_and_bin_fused) project_and_bin_fused = nullptr;
     decltype(&mobgs_prep_project_and_bin_fused) prep_project_and_bin_fused = nullptr;
+    decltype(&mobgs_project_prep_bwd_fused) project_prep_bwd_fused = nullptr;
     decltype(&mobgs_fused_seg_keys_len) fused_seg_keys_len = nullptr;
     decltype(&mobgs_tile_order_len) tile_order_len = nullptr;
     decltype(&mobgs_keep_scan_len) keep_scan_len = nullptr;
@@ -86,6 +87,7 @@ void bind(const std::unordered_map<std::string, uint64_t>& m) {
     take(m, "mobgs_project_and_bin_speculative", api.project_and_bin_speculative);
     take(m, "mobgs_project_and_bin_fused", api.project_and_bin_fused);
     take(m, "mobgs_prep_project_and_bin_fused", api.prep_project_and_bin_fused);
+    take(m, "mobgs_project_prep_bwd_fused", api.project_prep_bwd_fused);
     take(m, "mobgs_fused_seg_keys_len", api.fused_seg_keys_len);
     take(m, "mobgs_tile_order_len", api.tile_order_len);
     take(m, "mobgs_keep_scan_len", api.keep_scan_len);
@@ -373,6 +375,41 @@ project_bwd(int64_t width, int64_t height, double eps2d, const Tensor& means, co
     return {v_means, v_quats, v_scales, v_viewmats};
 }
 
+// ---- rendering._PrepProjectAndBin.backward: projection backward + prep backward in one launch -----------------------------
+// g: a sink's 13 float32 gradient buffers (accumulate = 1) or empty -> allocated here.  -> (the 13 buffers, v_viewmats)
+std::tuple<std::vector<Tensor>, Tensor>
+project_prep_bwd(int64_t width, int64_t height, double eps2d, const Tensor& means, const Tensor& quats,
+                 const Tensor& scales, const Tensor& viewmats, const Tensor& Ks, const Tensor& radii,
+                 const Tensor& conics, const OptT& v_means2d, const OptT& v_depths, const OptT& v_conics,
+                 const OptT& x_means, const OptT& x_quats, const OptT& x_scales, int64_t Ns, int64_t Nd,
+                 const Tensor& times, const Tensor& d_ncp, const Tensor& d_trbf, const Tensor& opac, const OptT& v_opac,
+                 const OptT& v_colors, std::vector<Tensor> g, int64_t accumulate, int64_t stream) {
+    const int64_t N = means.size(0);
+    const auto f = means.options().dtype(at::kFloat);
+    if (g.empty()) {
+        g = {at::empty({Ns, 3}, f), at::empty({Ns, 3}, f), at::empty({Ns, 4}, f), at::empty({Ns, 1}, f),
+             at::empty({Ns, 6}, f), at::empty({Ns, 3}, f), at::empty({Nd, 12, 3}, f), at::empty({Nd, 3}, f),
+             at::empty({Nd, 4}, f), at::empty({Nd, 4}, f), at::empty({Nd, 1}, f), at::empty({Nd, 6}, f),
+             at::empty({Nd, 3}, f)};
+        accumulate = 0;
+    } else if (g.size() != 13) {
+        throw std::runtime_error("project_prep_bwd: 13 gradient buffers expected");
+    }
+    Tensor v_viewmats = at::empty_like(viewmats);
+    Tensor partial = at::empty({(int64_t)api.project_bwd_scratch_floats(1, (int)N)}, f);
+    const OptT g2 = f32c(v_means2d), gd = f32c(v_depths), gc = f32c(v_conics), xm = f32c(x_means), xq = f32c(x_quats),
+               xs = f32c(x_scales), vo = f32c(v_opac), vc = f32c(v_colors);
+    MobgsLeafGrads lg{fpw(g[0]), fpw(g[1]), fpw(g[2]), fpw(g[3]), fpw(g[4]), fpw(g[5]), fpw(g[6]),
+                      fpw(g[7]), fpw(g[8]), fpw(g[9]), fpw(g[10]), fpw(g[11]), fpw(g[12])};
+    check(api.project_prep_bwd_fused((int)N, fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), (int)width,
+                                     (int)height, (float)eps2d, ip(radii), fp(conics), fp(g2), fp(gd), fp(gc), fp(xm),
+                                     fp(xq), fp(xs), fpw(v_viewmats), fpw(partial), (int)Ns, (int)Nd, fp(times),
+                                     static_cast<const int64_t*>(dp(d_ncp)), fp(d_trbf), fp(opac), fp(vo), fp(vc), &lg,
+                                     (int)accumulate, sp(stream)),
+          "mobgs_project_prep_bwd_fused");
+    return {g, v_viewmats};
+}
+
 // ---- rendering._ProjectAndBin.forward, speculative binning ---------------------------------------------------------
 // Allocates every output / arena and makes the ONE orchestrator call.  -> (rc, [radii, means2d, depths, conics,
 // tiles_per_gauss, cum_tiles, tile_offsets, keep_scan, flatten_ids], tile_order | None, isect_ids | None,
@@ -484,4 +521,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("decoder_bwd", &decoder_bwd);
     m.def("project_bwd", &project_bwd);
     m.def("project_and_bin_speculative", &project_and_bin_speculative);
+    m.def("project_prep_bwd", &project_prep_bwd);
 }

@@ -84,81 +84,8 @@ __device__ __forceinline__ void prep_bwd_instant(
         const float o = opac[i];
         vo = v_opac[i] * o * (1.f - o);
     }
-    if (i < Ns) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            g_s_xyz[3 * i + k] = (ACC ? g_s_xyz[3 * i + k] : 0.f) + vm[k];
-            stf(g_s_scaling, 3 * (size_t)i + k, (ACC ? ldf(g_s_scaling, 3 * (size_t)i + k) : 0.f) + vs[k]);
-            stf(g_s_ft, 3 * (size_t)i + k, (ACC ? ldf(g_s_ft, 3 * (size_t)i + k) : 0.f) + 0.0f * vc[6 + k]);
-        }
-        {
-            float4 q = make_float4(vq[0], vq[1], vq[2], vq[3]);
-            if (ACC) {
-                const float4 o = ld4(g_s_rotation, i);
-                q = make_float4(o.x + q.x, o.y + q.y, o.z + q.z, o.w + q.w);
-            }
-            st4(g_s_rotation, i, q);
-        }
-        stf(g_s_opacity, i, (ACC ? ldf(g_s_opacity, i) : 0.f) + vo);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) stf(g_s_fdc, 6 * (size_t)i + k, (ACC ? ldf(g_s_fdc, 6 * (size_t)i + k) : 0.f) + vc[k]);
-    } else {
-        const int j = i - Ns;
-        const float tfp = times[0] - d_trbf[j];
-        const int n = (int)d_ncp[j];
-        const Hermite H = hermite_setup(times[1], n);
-        float* gc = g_d_control + (size_t)j * 36;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float v = vm[k] * 1e-2f;
-            float a0 = 0.f, a1 = H.h00 * v, a2 = H.h01 * v, a3 = 0.f;
-            const float vm0 = H.h10 * v, vm1 = H.h11 * v;
-            if (H.left_edge) {
-                a2 += vm0;
-                a1 -= vm0;
-            } else {
-                a2 += 0.5f * vm0;
-                a0 -= 0.5f * vm0;
-            }
-            if (H.right_edge) {
-                a2 += vm1;
-                a1 -= vm1;
-            } else {
-                a3 += 0.5f * vm1;
-                a1 -= 0.5f * vm1;
-            }
-            // knots coincide only at the curve ends (i0 == i1: a0 is 0; i3 == i2: a3 is 0), where the dead term is
-            // simply not stored.  !ACC: the rows were zero-filled by the kernel, plain stores; ACC: read-modify-write
-            if (ACC) {
-                if (!H.left_edge) gc[3 * H.i0 + k] += a0;
-                gc[3 * H.i1 + k] += a1;
-                gc[3 * H.i2 + k] += a2;
-                if (!H.right_edge) gc[3 * H.i3 + k] += a3;
-            } else {
-                if (!H.left_edge) gc[3 * H.i0 + k] = a0;
-                gc[3 * H.i1 + k] = a1;
-                gc[3 * H.i2 + k] = a2;
-                if (!H.right_edge) gc[3 * H.i3 + k] = a3;
-            }
-            stf(g_d_scaling, 3 * (size_t)j + k, (ACC ? ldf(g_d_scaling, 3 * (size_t)j + k) : 0.f) + vs[k]);
-            stf(g_d_ft, 3 * (size_t)j + k, (ACC ? ldf(g_d_ft, 3 * (size_t)j + k) : 0.f) + tfp * vc[6 + k]);
-        }
-        {
-            float4 q = make_float4(vq[0], vq[1], vq[2], vq[3]);
-            float4 w = make_float4(tfp * vq[0], tfp * vq[1], tfp * vq[2], tfp * vq[3]);
-            if (ACC) {
-                const float4 o = ld4(g_d_rotation, j);
-                const float4 p = ld4(g_d_omega, j);
-                q = make_float4(o.x + q.x, o.y + q.y, o.z + q.z, o.w + q.w);
-                w = make_float4(p.x + w.x, p.y + w.y, p.z + w.z, p.w + w.w);
-            }
-            st4(g_d_rotation, j, q);
-            st4(g_d_omega, j, w);
-        }
-        stf(g_d_opacity, j, (ACC ? ldf(g_d_opacity, j) : 0.f) + vo);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) stf(g_d_fdc, 6 * (size_t)j + k, (ACC ? ldf(g_d_fdc, 6 * (size_t)j + k) : 0.f) + vc[k]);
-    }
+    prep_bwd_apply<ACC, G>(i, Ns, times, d_ncp, d_trbf, vm, vq, vs, vo, vc, g_s_xyz, g_s_scaling, g_s_rotation, g_s_opacity,
+                           g_s_fdc, g_s_ft, g_d_control, g_d_scaling, g_d_rotation, g_d_omega, g_d_opacity, g_d_fdc, g_d_ft);
 }
 
 // K time instants (times [K,2]; v_means [K,N,3], v_quats [K,N,4], v_colors [K,N,9]; v_scales [N,3] and v_opac [N] exist
@@ -183,21 +110,7 @@ prep_bwd_kernel(int Ns, int Nd, int K, const float* __restrict__ times, const lo
                 G* __restrict__ g_d_ft) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = Ns + Nd;
-    if (!ACC) {
-        // the 144-byte control-point gradient rows of this WAVE's dynamic splats are contiguous: clear them with
-        // coalesced 16-byte stores (a thread clearing its own row issues 36 stores that each touch 64 lines), then
-        // every thread drops its <= 12 non-zero entries into its row.  Same wave, program order: the fill's stores
-        // are complete (s_waitcnt vmcnt(0) of the wavefront-scope release) before the entries are written.
-        const int wave_first = (blockIdx.x * blockDim.x + (threadIdx.x & ~63)) - Ns;  // first dynamic index
-        const int j0 = max(wave_first, 0), j1 = min(wave_first + 64, Nd);
-        if (j1 > j0) {
-            float4* row = reinterpret_cast<float4*>(g_d_control + (size_t)j0 * 36);
-            const int n4 = (j1 - j0) * 9;
-            for (int t = threadIdx.x & 63; t < n4; t += 64) row[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_s_waitcnt(0);
-        }
-    }
+    if (!ACC) prep_bwd_clear_rows(Ns, Nd, g_d_control);  // (all threads of the wave, before any return)
     if (i >= N) return;
     prep_bwd_instant<ACC, G>(i, Ns, times, d_ncp, d_trbf, scales, opac, v_means, v_quats, v_scales, v_opac, v_colors,
                              g_s_xyz, g_s_scaling, g_s_rotation, g_s_opacity, g_s_fdc, g_s_ft, g_d_control, g_d_scaling,

@@ -263,6 +263,22 @@ __device__ inline float wave_sum(float v) {
     return v;
 }
 
+// PREPB (mobgs_project_prep_bwd_fused, one camera): the thread hands its splat's state cotangents -- in registers -- to
+// the prep backward (prep_shared.h prep_bwd_apply: the arithmetic of prep_bwd_kernel, bit for bit) instead of storing
+// v_means / v_quats / v_scales for a second launch to read back; the leaf gradients leave this kernel.
+struct LeafGrads {
+    float *s_xyz, *s_scaling, *s_rotation, *s_opacity, *s_fdc, *s_ft, *d_control, *d_scaling, *d_rotation, *d_omega,
+        *d_opacity, *d_fdc, *d_ft;
+};
+struct PrepBwdFused {
+    int Ns, Nd, accumulate;
+    const float* times;
+    const long long* d_ncp;
+    const float *d_trbf, *opac, *v_opac, *v_colors;
+    const float *x_means, *x_quats, *x_scales;  // cotangents that reach the state directly (optional)
+    LeafGrads g;
+};
+template <bool PREPB>
 __global__ void __launch_bounds__(256)
 project_bwd_kernel(int N, const float* __restrict__ means, const float* __restrict__ quats,
                    const float* __restrict__ scales, const float* __restrict__ viewmats,
@@ -272,9 +288,12 @@ project_bwd_kernel(int N, const float* __restrict__ means, const float* __restri
                    const float* __restrict__ v_conics, float* __restrict__ v_means,
                    float* __restrict__ v_quats, float* __restrict__ v_scales,
                    float* __restrict__ v_view_partial, int accumulate, int accumulate_scales, size_t geom_stride,
-                   size_t scales_stride) {
+                   size_t scales_stride, PrepBwdFused pb) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
+    if constexpr (PREPB) {
+        if (!pb.accumulate) prep_bwd_clear_rows(pb.Ns, pb.Nd, pb.g.d_control);
+    }
     // cameras in parallel (grid.y = C > 1, per-camera geometry): camera c reads / writes its own rows of means, quats
     // and their gradients, and its own copy of the shared scales' gradient (summed over the cameras afterwards)
     means += 3 * c * geom_stride;
@@ -432,7 +451,36 @@ project_bwd_kernel(int N, const float* __restrict__ means, const float* __restri
         vq[2] = (vn[2] - dotp * y) * inv;
         vq[3] = (vn[3] - dotp * z) * inv;
     }
-    if (i < N) {
+    if constexpr (PREPB) {
+        if (i < N) {
+            float vsx[3], vo = 0.f, vc[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) vc[k] = pb.v_colors ? pb.v_colors[9 * i + k] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (pb.x_means) vm[k] = vm[k] + pb.x_means[3 * i + k];
+                const float t = pb.x_scales ? vs[k] + pb.x_scales[3 * i + k] : vs[k];
+                vsx[k] = t * scales[3 * i + k];  // d exp = exp
+            }
+            if (pb.x_quats) {
+                const float4 r = reinterpret_cast<const float4*>(pb.x_quats)[i];
+                vq[0] = vq[0] + r.x; vq[1] = vq[1] + r.y; vq[2] = vq[2] + r.z; vq[3] = vq[3] + r.w;
+            }
+            if (pb.v_opac) {
+                const float op = pb.opac[i];
+                vo = pb.v_opac[i] * op * (1.f - op);
+            }
+            const LeafGrads& g = pb.g;
+            if (pb.accumulate)
+                prep_bwd_apply<true, float>(i, pb.Ns, pb.times, pb.d_ncp, pb.d_trbf, vm, vq, vsx, vo, vc, g.s_xyz,
+                                            g.s_scaling, g.s_rotation, g.s_opacity, g.s_fdc, g.s_ft, g.d_control,
+                                            g.d_scaling, g.d_rotation, g.d_omega, g.d_opacity, g.d_fdc, g.d_ft);
+            else
+                prep_bwd_apply<false, float>(i, pb.Ns, pb.times, pb.d_ncp, pb.d_trbf, vm, vq, vsx, vo, vc, g.s_xyz,
+                                             g.s_scaling, g.s_rotation, g.s_opacity, g.s_fdc, g.s_ft, g.d_control,
+                                             g.d_scaling, g.d_rotation, g.d_omega, g.d_opacity, g.d_fdc, g.d_ft);
+        }
+    } else if (i < N) {
         if (accumulate) {
             // cameras c>0 run as later launches on the same stream, so a plain read-modify-write is safe
             v_means[3 * i] += vm[0];
@@ -612,9 +660,9 @@ int mobgs_project_bwd_ex(int C, int N, int geometry_per_camera, const float* mea
         // only the scales' gradient is shared -- every camera writes its own copy, summed in camera order (the order of
         // the sequential accumulation below: same bits)
         float* scales_partial = v_viewmats_partial + (size_t)C * nblocks * 16;
-        hipLaunchKernelGGL(project_bwd_kernel, dim3(nblocks, C), dim3(256), 0, (hipStream_t)stream, N, means, quats, scales,
+        hipLaunchKernelGGL(project_bwd_kernel<false>, dim3(nblocks, C), dim3(256), 0, (hipStream_t)stream, N, means, quats, scales,
                            viewmats, Ks, width, height, eps2d, radii, conics, v_means2d, v_depths, v_conics, v_means,
-                           v_quats, scales_partial, v_viewmats_partial, 0, 0, (size_t)N, (size_t)N);
+                           v_quats, scales_partial, v_viewmats_partial, 0, 0, (size_t)N, (size_t)N, PrepBwdFused{});
         hipLaunchKernelGGL(camera_sum_kernel, dim3((3 * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, C,
                            (size_t)3 * N, scales_partial, v_scales);
         hipLaunchKernelGGL(viewmat_reduce_kernel, dim3(16 * C), dim3(256), 0, (hipStream_t)stream, nblocks,
@@ -623,18 +671,56 @@ int mobgs_project_bwd_ex(int C, int N, int geometry_per_camera, const float* mea
     }
     // one launch per camera so that the accumulation into v_means/v_quats/v_scales is race-free and ordered
     for (int c = 0; c < C; ++c) {
-        hipLaunchKernelGGL(project_bwd_kernel, dim3(nblocks, 1), dim3(256), 0, (hipStream_t)stream, N,
+        hipLaunchKernelGGL(project_bwd_kernel<false>, dim3(nblocks, 1), dim3(256), 0, (hipStream_t)stream, N,
                            means + 3 * c * gs, quats + 4 * c * gs, scales, viewmats + 16 * c, Ks + 9 * c, width, height,
                            eps2d, radii + (size_t)c * N, conics + (size_t)3 * c * N,
                            v_means2d ? v_means2d + (size_t)2 * c * N : nullptr,
                            v_depths ? v_depths + (size_t)c * N : nullptr,
                            v_conics ? v_conics + (size_t)3 * c * N : nullptr, v_means + 3 * c * gs, v_quats + 4 * c * gs,
                            v_scales, v_viewmats_partial + (size_t)c * nblocks * 16,
-                           (c > 0 && !geometry_per_camera) ? 1 : 0, c > 0 ? 1 : 0, (size_t)0, (size_t)0);
+                           (c > 0 && !geometry_per_camera) ? 1 : 0, c > 0 ? 1 : 0, (size_t)0, (size_t)0, PrepBwdFused{});
     }
     hipLaunchKernelGGL(viewmat_reduce_kernel, dim3(16 * C), dim3(256), 0, (hipStream_t)stream, nblocks,
                        v_viewmats_partial, v_viewmats);
     return check_launch("project_bwd_kernel");
+}
+
+int mobgs_project_prep_bwd_fused(int N, const float* means, const float* quats, const float* scales,
+                                 const float* viewmats, const float* Ks, int width, int height, float eps2d,
+                                 const int32_t* radii, const float* conics, const float* v_means2d,
+                                 const float* v_depths, const float* v_conics, const float* x_means,
+                                 const float* x_quats, const float* x_scales, float* v_viewmats,
+                                 float* v_viewmats_partial, int Ns, int Nd, const float* times, const int64_t* d_ncp,
+                                 const float* d_trbf, const float* opacities, const float* v_opacities,
+                                 const float* v_colors, const MobgsLeafGrads* grads, int accumulate, void* stream) {
+    if (N < 1 || Ns < 0 || Nd < 0 || Ns + Nd != N || !grads || !v_viewmats || !v_viewmats_partial) {
+        set_error("mobgs_project_prep_bwd_fused: bad arguments (N=%d Ns=%d Nd=%d)", N, Ns, Nd);
+        return MOBGS_E_INVALID;
+    }
+    PrepBwdFused pb;
+    pb.Ns = Ns;
+    pb.Nd = Nd;
+    pb.accumulate = accumulate ? 1 : 0;
+    pb.times = times;
+    pb.d_ncp = (const long long*)d_ncp;
+    pb.d_trbf = d_trbf;
+    pb.opac = opacities;
+    pb.v_opac = v_opacities;
+    pb.v_colors = v_colors;
+    pb.x_means = x_means;
+    pb.x_quats = x_quats;
+    pb.x_scales = x_scales;
+    pb.g = LeafGrads{grads->s_xyz, grads->s_scaling, grads->s_rotation, grads->s_opacity, grads->s_fdc, grads->s_ft,
+                     grads->d_control, grads->d_scaling, grads->d_rotation, grads->d_omega, grads->d_opacity,
+                     grads->d_fdc, grads->d_ft};
+    const int nblocks = (N + 255) / 256;
+    hipLaunchKernelGGL(project_bwd_kernel<true>, dim3(nblocks, 1), dim3(256), 0, (hipStream_t)stream, N, means, quats,
+                       scales, viewmats, Ks, width, height, eps2d, radii, conics, v_means2d, v_depths, v_conics,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, v_viewmats_partial, 0, 0, (size_t)0, (size_t)0,
+                       pb);
+    hipLaunchKernelGGL(viewmat_reduce_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, nblocks, v_viewmats_partial,
+                       v_viewmats);
+    return check_launch("project_bwd_kernel<prep>");
 }
 
 }  // extern "C"

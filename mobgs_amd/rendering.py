@@ -1187,6 +1187,11 @@ class _CtxShim:
         pass
 
 
+# _PrepProjectAndBin.backward as one launch (A/B: MOBGS_FUSE_PREP_BWD=0 runs the projection backward and the prep
+# backward one after the other, as the separate nodes do)
+FUSE_PREP_BWD = os.environ.get("MOBGS_FUSE_PREP_BWD", "1") != "0"
+
+
 class _PrepProjectAndBin(torch.autograd.Function):
     """ops.PrepSplats + _ProjectAndBin as ONE node whose forward is one kernel fewer (round 5): the
     projection kernel evaluates the spline / activations of its splat itself (mobgs_prep_project_and_bin_fused; the
@@ -1232,6 +1237,26 @@ class _PrepProjectAndBin(torch.autograd.Function):
         saved = ctx.saved_tensors
         means, quats, scales = saved[0], saved[1], saved[2]
         times, d_ncp, d_trbf, opac = saved[7:11]
+        F = _fast.get()
+        if FUSE_PREP_BWD and F is not None:
+            # ONE launch: the state cotangents never leave the registers (mobgs_project_prep_bwd_fused)
+            from . import ops as _ops
+            sink = _ops._active_sink
+            use_sink = sink is not None and sink.accepts(ctx.leaf_inputs)
+            have = use_sink and sink.buffers is not None
+            Ns, Nd = ctx.sizes
+            width, height, eps2d = ctx.dims
+            bufs, v_viewmats = F.project_prep_bwd(
+                width, height, eps2d, means, quats, scales, saved[3], saved[4], saved[5], saved[6], v_means2d, v_depths,
+                v_conics, v_means, v_quats, v_scales, Ns, Nd, times, d_ncp, d_trbf, opac, v_opac, v_cols,
+                [sink.buffers[n_] for n_ in _ops._LEAF_NAMES] if have else [], 1 if have else 0, stream_int())
+            g = sink.buffers if have else dict(zip(_ops._LEAF_NAMES, bufs))
+            if use_sink:
+                sink.buffers = g
+                return (None,) * 16 + (v_viewmats,) + (None,) * 9
+            return (None, g["s_xyz"], g["s_scaling"], g["s_rotation"], g["s_opacity"], g["s_fdc"], g["s_ft"],
+                    g["d_control"], None, g["d_scaling"], g["d_rotation"], g["d_omega"], g["d_opacity"], g["d_fdc"],
+                    g["d_ft"], None, v_viewmats) + (None,) * 9
         pm = pq = ps = v_viewmats = None
         if v_means2d is not None or v_depths is not None or v_conics is not None:
             pm, pq, ps, v_viewmats = _Project.backward(SimpleNamespace(saved_tensors=saved[:7], dims=ctx.dims), None,
