@@ -7,6 +7,8 @@ Bounds: projection outputs 1e-5 relative (fp32 vs fp64 arithmetic); radii equal 
 within fp32 rounding of an integer; images within 3e-5 of the channel range except the elements a flipped skip / stop
 decision touches (helpers.close_image_with_blend_flips: derived one-blend-step bound); gradients rtol 1e-3 + 1e-4 of the
 tensor's maximum with the 1e-5 flip tail of the full-size tests."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -35,11 +37,44 @@ def _run(fn, s, bg, v_img, v_a, w, h, dtype):
     return img.detach(), a.detach(), meta, {k: t[k].grad.detach() for k in NAMES}
 
 
+# The float64 evaluation of _scene() takes ~45 s of CPU time.  The CPU suite computes it (fixture below) and checks the
+# stored copy tests/golden/bruteforce_ref.npz against it; the GPU suite, which has 300 s for everything, loads the copy
+# (`python tests/test_bruteforce_oracle_cpu.py` rewrites it: the oracle's own output on _scene(), nothing else).
+REF_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bruteforce_ref.npz")
+_META = ("radii", "means2d", "conics", "depths")
+
+
+def save_reference(ref, path=REF_FILE):
+    img, a, meta, g = ref
+    np.savez_compressed(path, img=img.numpy(), alpha=a.numpy(), **{"meta_" + k: meta[k].detach().numpy() for k in _META},
+                        **{"grad_" + k: v.numpy() for k, v in g.items()})
+
+
+def load_reference(path=REF_FILE):
+    z = np.load(path)
+    meta = {k: torch.from_numpy(z["meta_" + k]) for k in _META}
+    return (torch.from_numpy(z["img"]), torch.from_numpy(z["alpha"]), meta,
+            {k: torch.from_numpy(z["grad_" + k]) for k in NAMES})
+
+
 @pytest.fixture(scope="module")
 def brute():
     from oracle import gsplat_bruteforce as BF
     s, bg, v_img, v_a, w, h = _scene()
     return (s, bg, v_img, v_a, w, h), _run(BF.rasterization, s, bg, v_img, v_a, w, h, torch.float64)
+
+
+def test_stored_reference_is_the_oracles_output(brute):
+    """tests/golden/bruteforce_ref.npz (what tests/test_gpu_bruteforce.py compares the HIP path with) IS what
+    oracle/gsplat_bruteforce.py computes on _scene() -- to float64 rounding of another host's summation order."""
+    _, ref = brute
+    img, a, meta, g = ref
+    simg, sa, smeta, sg = load_reference()
+    assert torch.equal(smeta["radii"], meta["radii"])
+    for name, x, y in [("img", simg, img), ("alpha", sa, a)] + [(k, smeta[k], meta[k].detach()) for k in _META[1:]] + \
+            [("grad " + k, sg[k], g[k]) for k in NAMES]:
+        assert x.dtype == torch.float64 and x.shape == y.shape, name
+        assert float((x - y).abs().max()) <= 1e-10 * max(1.0, float(y.abs().max())), name
 
 
 def check_against_bruteforce(img, alpha, radii, means2d, conics, grads, scene, ref, what):
@@ -104,3 +139,10 @@ def test_membership_rule_matters():
     assert float(outside.abs().max()) == 0.0, "the splat must not be evaluated outside its tile rectangle"
     _, a2, _ = BF.composite(m2d, conics, col, op, depth, torch.tensor([1000]), 48, 48)  # rectangle = whole image
     assert 0.0055 < float(a2[24, 15]) < 0.0065 and float(a2[24, 15]) > 1.0 / 255.0
+
+
+if __name__ == "__main__":
+    from oracle import gsplat_bruteforce as BF
+    sc = _scene()
+    save_reference(_run(BF.rasterization, *sc, torch.float64))
+    print("wrote", REF_FILE, os.path.getsize(REF_FILE), "bytes")
