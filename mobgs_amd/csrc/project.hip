@@ -125,8 +125,11 @@ struct PrepFused {
     PrepIn<float> in;
     float *means, *quats, *scales, *opac;
 };
+#ifndef MOBGS_PROJ_FWD_THREADS
+#define MOBGS_PROJ_FWD_THREADS 256
+#endif
 template <bool PREP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(MOBGS_PROJ_FWD_THREADS)
 project_fwd_kernel(int N, const float* __restrict__ means, const float* __restrict__ quats,
                    const float* __restrict__ scales, const float* __restrict__ viewmats,
                    const float* __restrict__ Ks, int width, int height, float eps2d, float near_plane,
@@ -594,7 +597,8 @@ int mobgs::project_fwd_launch(int C, int N, const float* means, const float* qua
         return MOBGS_OK;
     }
     const int tile_w = (width + MOBGS_TILE - 1) / MOBGS_TILE, tile_h = (height + MOBGS_TILE - 1) / MOBGS_TILE;
-    dim3 grid((N + 255) / 256, C);
+    constexpr int T = MOBGS_PROJ_FWD_THREADS;
+    dim3 grid((N + T - 1) / T, C);
     if (prep) {
         // the state is built in-kernel: means / quats / scales / pack.opacities are OUTPUT arrays here
         if (C != 1 || geometry_per_camera || prep->Ns + prep->Nd != N || !pack.records || pack.channels != 9 ||
@@ -611,12 +615,12 @@ int mobgs::project_fwd_launch(int C, int N, const float* means, const float* qua
         pf.quats = const_cast<float*>(quats);
         pf.scales = const_cast<float*>(scales);
         pf.opac = const_cast<float*>(pack.opacities);
-        hipLaunchKernelGGL(project_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, N, means, quats, scales,
+        hipLaunchKernelGGL(project_fwd_kernel<true>, grid, dim3(T), 0, (hipStream_t)stream, N, means, quats, scales,
                            viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip, tile_w, tile_h,
                            radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, (unsigned)zero_n, pack, 0, bin, pf);
         return check_launch("project_fwd_kernel<prep>");
     }
-    hipLaunchKernelGGL(project_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, N, means, quats, scales,
+    hipLaunchKernelGGL(project_fwd_kernel<false>, grid, dim3(T), 0, (hipStream_t)stream, N, means, quats, scales,
                        viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip, tile_w, tile_h,
                        radii, means2d, depths, conics, tiles_per_gauss, zero_ptr, (unsigned)zero_n, pack,
                        geometry_per_camera ? N : 0, bin, PrepFused{});
