@@ -90,10 +90,9 @@ extern "C" {
  *                      and mobgs_raster_bwd_reduce writes exact zeros without reading a slot: a loss term whose weight
  *                      is 0 (/root/reference/train.py:675 with arguments/stereo/seesaw.py lambda_flow_loss = 0) then
  *                      costs a probe instead of a backward pass.  No host synchronisation (HIP-graph safe).  Contract
- *                      in this mode: `any_record` is the first word of the row right behind the slot rows
- *                      (any_record == (int32_t*)grad_slots + rows * stride, at least 8 bytes), and the call itself
- *                      clears the flag words and -- only when the pass runs -- the slot rows: hand over UNINITIALISED
- *                      memory.  Ignored (treated as 0) with bwd_block_walk = 1.
+ *                      in this mode: `any_record` points at TWO zeroed int32 words (the second is the gate; the usual
+ *                      zero fill of grad_slots + the extra row behind them provides both).  One extra kernel launch per
+ *                      call.  Ignored (treated as 0) with bwd_block_walk = 1.
  *   coherent_order     (round 5) mobgs_project_and_bin_fused, default 0 / -1 = unknown.  1: the caller states that the
  *                      splats are STORED in a spatially coherent order (neighbouring rows are neighbours in space, e.g.
  *                      rows along a Morton curve: mobgs_amd GaussianParams.spatial_sort_(), kept by TrainableGaussians

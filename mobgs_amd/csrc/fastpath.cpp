@@ -266,9 +266,7 @@ Tensor raster_bwd(int64_t C, int64_t N, int64_t channels, int64_t has_extra, int
     const Tensor v_render = f32c(v_render_in);
     const OptT v_alphas = f32c(v_alphas_in);
     const int64_t rows = std::max<int64_t>(n_isects, 1), stride = records.size(1);
-    // (gate_zero_cotangent: the call clears the flag words itself and the slot rows only when the pass runs)
-    const bool gated = tp(tuning) && tp(tuning)->gate_zero_cotangent == 1 && tp(tuning)->bwd_block_walk != 1;
-    Tensor slots = gated ? at::empty({rows + 1, stride}, records.options()) : at::zeros({rows + 1, stride}, records.options());
+    Tensor slots = at::zeros({rows + 1, stride}, records.options());
     int32_t* flag = reinterpret_cast<int32_t*>(fpw(slots) + rows * stride);
     check(api.raster_bwd((int)C, (int)N, (int)channels, (int)has_extra, (int)width, (int)height, fp(records), fp(bg),
                          ip(radii), fp(means2d), ip(cum_tiles), ip(keep_scan), ip(tile_offsets), ip(tile_order),
@@ -373,6 +371,12 @@ project_bwd(int64_t width, int64_t height, double eps2d, const Tensor& means, co
                              fpw(v_quats), fpw(v_scales), fpw(v_viewmats), fpw(partial), sp(stream)),
           "mobgs_project_bwd");
     return {v_means, v_quats, v_scales, v_viewmats};
+}
+
+// the five state buffers of rendering._PrepProjectAndBin.forward in one call (means, quats, scales, opac, colour token)
+std::vector<Tensor> prep_state_buffers(int64_t N, const Tensor& like) {
+    const auto f = like.options().dtype(at::kFloat);
+    return {at::empty({N, 3}, f), at::empty({N, 4}, f), at::empty({N, 3}, f), at::empty({N}, f), at::empty({N, 9}, f)};
 }
 
 // ---- rendering._PrepProjectAndBin.backward: projection backward + prep backward in one launch -----------------------------
@@ -522,4 +526,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("project_bwd", &project_bwd);
     m.def("project_and_bin_speculative", &project_and_bin_speculative);
     m.def("project_prep_bwd", &project_prep_bwd);
+    m.def("prep_state_buffers", &prep_state_buffers);
 }

@@ -1388,30 +1388,19 @@ __global__ void __launch_bounds__(256) cotangent_probe_many_kernel(ProbeTable t,
     if (tail + tid < n) nz |= p[tail + tid] != 0.f;
     if (nz) *live = 1;
 }
-// the slot rows of a gated pass: cleared only when the pass is going to run
-__global__ void __launch_bounds__(256)
-gated_clear_kernel(float4* __restrict__ p, size_t n4, const int32_t* __restrict__ live) {
-    if (*live == 0) return;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = z;
-}
-// -> the gate word (any_record + 1), or nullptr when gating is off / the contract does not hold
+// -> the gate word (any_record + 1), or nullptr when gating is off.  ONE extra launch: the caller's zero fill of the slot
+// rows has cleared the two flag words behind them as well.  (A first version cleared the rows itself, and only when the
+// pass was going to run -- memset + probe + gated clear: three launches per node, measured at +0.7 ms of HOST time per
+// training iteration at 512x288, where the step is host-bound; the fill it saved matters only when the cotangents are
+// zero, and then the host-side head of gaussian_renderer has dropped the node altogether.)
 static const int32_t* arm_cotangent_gate(const MobgsTuning* tuning, const float* v_render, size_t n_render,
-                                         const float* v_alphas, size_t n_alphas, float* grad_slots,
-                                         int32_t* any_record, hipStream_t st) {
-    if (!tuning_gate_zero_cotangent(tuning) || !any_record || !grad_slots) return nullptr;
-    const ptrdiff_t words = reinterpret_cast<const float*>(any_record) - grad_slots;
-    if (words < 0 || (words & 3) || (reinterpret_cast<uintptr_t>(grad_slots) & 15)) return nullptr;
-    (void)hipMemsetAsync(any_record, 0, 2 * sizeof(int32_t), st);
+                                         const float* v_alphas, size_t n_alphas, int32_t* any_record, hipStream_t st) {
+    if (!tuning_gate_zero_cotangent(tuning) || !any_record) return nullptr;
     int32_t* live = any_record + 1;
     const size_t work = (n_render + n_alphas) / 4 + 1;
     const int grid = (int)std::min<size_t>((work + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(cotangent_probe_kernel, dim3(grid), dim3(256), 0, st, v_render, n_render, v_alphas,
                        v_alphas ? n_alphas : 0, live);
-    const size_t n4 = (size_t)words / 4;
-    if (n4)
-        hipLaunchKernelGGL(gated_clear_kernel, dim3((int)std::min<size_t>((n4 + 255) / 256, 256 * 16)), dim3(256), 0, st,
-                           reinterpret_cast<float4*>(grad_slots), n4, live);
     return live;
 }
 
@@ -1811,7 +1800,7 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
     ClassSel cls{0, 1, 0, g_all_reach};
     if (!bwd_blocks)
         cls.gate = arm_cotangent_gate(tuning, v_render, (size_t)C * height * width * D, v_alphas,
-                                      (size_t)C * height * width, grad_slots, any_record, st);
+                                      (size_t)C * height * width, any_record, st);
     if (tuning_bwd_mfma(tuning, nt) && !bwd_blocks &&
         raster_bwd_mfma_launch(tuning_bwd_mfma(tuning, nt), D, false, grid, st, nt, n_groups, tile_w, tile_h, width, height, records, backgrounds,
                                radii, cum_tiles, keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids, v_render,
@@ -1893,7 +1882,7 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
     const int grid = tile_order ? (int)((sched_slots((size_t)nt) + TILES_PER_WG - 1) / TILES_PER_WG) : ((n_groups + 7) / 8) * 8;
     ClassSel cls{class_sel, N, Ns, g_all_reach};
     cls.gate = arm_cotangent_gate(tuning, v_render, (size_t)C * height * width * channels_total, v_alphas,
-                                  (size_t)C * height * width, grad_slots, any_record, (hipStream_t)stream);
+                                  (size_t)C * height * width, any_record, (hipStream_t)stream);
     if (tuning_bwd_mfma(tuning, nt) &&
         raster_bwd_mfma_launch(tuning_bwd_mfma(tuning, nt), channels_total, true, grid, (hipStream_t)stream, nt, n_groups, tile_w, tile_h, width,
                                height, records, backgrounds, radii, cum_tiles, keep_scan, tile_offsets, flatten_ids,

@@ -362,12 +362,17 @@ def cotangents_all_zero(tensors) -> bool:
     return int(flag.item()) == 0
 
 
+_gated_copy = [None, None]
+
+
 def _tuning_gated():
-    """`tuning` with the zero-cotangent gate on (a per-call copy: the gate is a property of the node, not of the module)."""
-    t = tuning.copy(geometry_per_camera=0, gate_zero_cotangent=1)
-    _tuning_keepalive.append(t)
-    del _tuning_keepalive[:-8]
-    return t
+    """`tuning` with the zero-cotangent gate on (the gate is a property of the node, not of the module); the copy is
+    rebuilt only when a field of `tuning` has changed."""
+    key = (tuning.heavy_tile_len, tuning.longest_list_hint, tuning.quadrant_culling, tuning.block_walk,
+           tuning.bwd_block_walk, tuning.bwd_mfma)
+    if _gated_copy[0] != key:
+        _gated_copy[0], _gated_copy[1] = key, tuning.copy(geometry_per_camera=0, gate_zero_cotangent=1)
+    return _gated_copy[1]
 
 
 class StaticCapacity:
@@ -632,8 +637,7 @@ class _Rasterize(torch.autograd.Function):
             v_alphas = f32c(v_alphas) if v_alphas is not None else None
             # one extra row: its first word is the any_record flag of include/mobgs_hip.h (zeroed by the same fill)
             rows = max(tl.n_isects, 1)
-            # (gated: the call clears the flag words itself, and the slot rows only when the pass is going to run)
-            slots = (torch.empty if gated else torch.zeros)(rows + 1, stride, dtype=torch.float32, device=dev)
+            slots = torch.zeros(rows + 1, stride, dtype=torch.float32, device=dev)
             flag = ctypes.c_void_p(slots.data_ptr() + 4 * rows * stride)
             v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
             v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
@@ -716,8 +720,8 @@ class _RasterizeClassAlpha(torch.autograd.Function):
         rows = max(tl.n_isects, 1)
         gated = bool(ctx.gate)
         tn = _tuning_gated() if gated else tuning
-        # last row: the any_record flag (gated: flag words and slot rows are cleared by the call, the rows only if it runs)
-        slots = (torch.empty if gated else torch.zeros)(rows + 1, stride, dtype=torch.float32, device=dev)
+        # last row: the any_record flag (+ the gate word of a gated pass)
+        slots = torch.zeros(rows + 1, stride, dtype=torch.float32, device=dev)
         flag = ctypes.c_void_p(slots.data_ptr() + 4 * rows * stride)
         if bg is None:   # the cotangent belongs to the alpha output
             v_render, v_a = _zero_image(C, height, width, dev), f32c(v_alphas)
@@ -1208,16 +1212,13 @@ class _PrepProjectAndBin(torch.autograd.Function):
                 near_plane, far_plane, radius_clip, order):
         leaf_inputs = (s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_ft, d_control, d_scaling, d_rotation,
                        d_omega, d_opacity, d_fdc, d_ft)
-        times_c, s_xyz_c, d_control_c, d_trbf_c = map(f32c, (times, s_xyz, d_control, d_trbf))
-        attrs = [f32c(a) for a in (s_scaling, s_rotation, s_opacity, s_fdc, s_ft)]
-        dattrs = [f32c(a) for a in (d_scaling, d_rotation, d_omega, d_opacity, d_fdc, d_ft)]
-        d_ncp_c = d_ncp.to(torch.int64).contiguous()
-        prep = [times_c, s_xyz_c, *attrs, d_control_c, d_ncp_c, *dattrs, d_trbf_c]
+        d_ncp_c = d_ncp if (d_ncp.dtype == torch.int64 and d_ncp.is_contiguous()) else d_ncp.to(torch.int64).contiguous()
+        prep = [f32c(times), f32c(s_xyz), f32c(s_scaling), f32c(s_rotation), f32c(s_opacity), f32c(s_fdc), f32c(s_ft),
+                f32c(d_control), d_ncp_c, f32c(d_scaling), f32c(d_rotation), f32c(d_omega), f32c(d_opacity), f32c(d_fdc),
+                f32c(d_ft), f32c(d_trbf)]
+        times_c, d_trbf_c = prep[0], prep[15]
         Ns, Nd = s_xyz.shape[0], d_control.shape[0]
-        N = Ns + Nd
-        dev = s_xyz.device
-        E = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
-        means, quats, scales, opac, cols = E(N, 3), E(N, 4), E(N, 3), E(N), E(N, 9)
+        means, quats, scales, opac, cols = _fast.get().prep_state_buffers(Ns + Nd, s_xyz)
         shim = _CtxShim()
         radii, means2d, depths, conics, tiles_per_gauss = _ProjectAndBin.forward(
             shim, means, quats, scales, viewmats, Ks, opac, tl, width, height, eps2d, near_plane, far_plane, radius_clip,
