@@ -817,7 +817,11 @@ def main():
         "config": {"workload": workload, "gaussians": args.ns + args.nd, "visible": n_vis, "intersections": I,
                    "pixels": P, "subframes_per_step": 1 if world == 1 else n_units,
                    "renders_per_step": 1 if world == 1 else n_units,
-                   "parallelism": f"subframe-shard x{world}" if world > 1 else "single"},
+                   "parallelism": f"subframe-shard x{world}" if world > 1 else "single",
+                   "row_order": ("as generated (MOBGS_BENCH_UNSORTED=1): cached enumeration order in the binning kernel"
+                                 if os.environ.get("MOBGS_BENCH_UNSORTED") == "1" else
+                                 "rows of both sets stored along a Morton curve (GaussianParams.spatial_sort_(), what "
+                                 "densify.TrainableGaussians(keep_sorted) maintains): same Gaussians, permuted")},
     }
     # What the driver's 1 -> N curve must be anchored on: `value` at N = 1 is ONE lean render() per step (BASELINE's
     # metric), `value` at N > 1 counts the 18 renders of a sharded deblur iteration -- unlike quantities.  scale_anchor is
