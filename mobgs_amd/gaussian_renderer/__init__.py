@@ -658,13 +658,13 @@ def _mid_signature(cam, stat_pc, dyn_pc):
           dyn_pc._opacity, dyn_pc._features_dc, dyn_pc._features_t, dyn_pc.get_trbfcenter, cam.world_view_transform,
           cam.K, getattr(cam, "static_times", None))
     return tuple(_sig(t) for t in ts) + (float(cam.time), float(cam.max_time), int(cam.image_width),
-                                         int(cam.image_height), torch.is_grad_enabled(), _R.stream_int())
+                                         int(cam.image_height), torch.is_grad_enabled())
 
 
 def _shared_mid_state(cam, stat_pc, dyn_pc, dev):
     if not FLOW_MID_CACHE or torch.cuda.is_current_stream_capturing():
         return _flow_mid_state(cam, stat_pc, dyn_pc, dev)
-    sig = _mid_signature(cam, stat_pc, dyn_pc)
+    sig = _mid_signature(cam, stat_pc, dyn_pc) + (_R.stream_int(),)
     e = _mid_cache.get("entry")
     if e is not None and e["sig"] == sig and e["cam"]() is cam and e["stat"]() is stat_pc and e["dyn"]() is dyn_pc \
             and not e["used"][0]:

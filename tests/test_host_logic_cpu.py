@@ -139,3 +139,64 @@ def test_init_geometry_helpers_match_reference_live():
     out, grid = D.inverse_warp_rt1_rt2(img, depth, w1, w2, K, torch.inverse(K), ret_grid=True)
     assert torch.allclose(grid, ref_grid, atol=1e-5) and torch.allclose(out, ref_img, atol=1e-5)
     assert float((ref_grid == 2).float().mean()) > 0.0  # some pixels do leave the image
+
+
+def test_round5_host_switches_and_keys():
+    """Host logic added in round 5 that needs no GPU: the per-node zero-cotangent gate context, per-call tuning copies, the
+    signature that keys the implicit mid-exposure cache of get_flow(), row-order bookkeeping of the model classes."""
+    import mobgs_amd.gaussian_renderer as G
+    import mobgs_amd.rendering as R
+    from mobgs_amd import _lib
+    from mobgs_amd.camera import PinholeCamera
+    from mobgs_amd.gaussian_model import GaussianParams
+    from mobgs_amd.synth import SynthCamera, dynamic_extras, gaussian_cloud
+    # gate: nested contexts restore the previous state; nodes read the state at construction time
+    assert R._zero_gate[0] == 0
+    with R.zero_cotangent_gate():
+        assert R._zero_gate[0] == 1
+        with R.zero_cotangent_gate(False):
+            assert R._zero_gate[0] == 0
+        assert R._zero_gate[0] == 1
+    assert R._zero_gate[0] == 0
+    # tuning copies: every field carried over, overrides applied, the module's struct untouched
+    t = R.tuning.copy(gate_zero_cotangent=1, coherent_order=1)
+    for name, _ in _lib.MobgsTuning._fields_:
+        if name not in ("gate_zero_cotangent", "coherent_order"):
+            assert getattr(t, name) == getattr(R.tuning, name)
+    assert (t.gate_zero_cotangent, t.coherent_order) == (1, 1)
+    assert (R.tuning.gate_zero_cotangent, R.tuning.coherent_order) == (0, 0)
+    g1 = R._tuning_gated()
+    assert g1 is R._tuning_gated() and g1.gate_zero_cotangent == 1   # cached until a field of `tuning` changes
+    old = R.tuning.heavy_tile_len
+    try:
+        R.tuning.heavy_tile_len = 77
+        g2 = R._tuning_gated()
+        assert g2 is not g1 and g2.heavy_tile_len == 77
+    finally:
+        R.tuning.heavy_tile_len = old
+    # cache signature: an in-place update (what an optimiser step does) and a new tensor both change it; reading does not
+    scam = SynthCamera().scaled(64, 48)
+    sp, dp = gaussian_cloud(50, scam, 0), gaussian_cloud(20, scam, 1)
+    stat = GaussianParams(sp, None, None, "cpu", requires_grad=True)
+    dyn = GaussianParams(dp, dynamic_extras(dp["xyz"], 0), stat.rgbdecoder, "cpu", requires_grad=True)
+    cam = PinholeCamera(64, 48, scam.K, torch.eye(4), scam.time, scam.max_time, device="cpu")
+    sig = lambda: G._mid_signature(cam, stat, dyn)
+    s0 = sig()
+    assert sig() == s0
+    with torch.no_grad():
+        dyn.control_xyz.add_(0.5)
+    s1 = sig()
+    assert s1 != s0
+    stat._opacity = stat._opacity.detach().clone().requires_grad_(True)
+    assert sig() != s1
+    s2 = sig()
+    with torch.no_grad():
+        assert sig() != s2   # (grad mode is part of the key)
+    # row order: a fresh model is not "coherent"; spatial_sort_ needs the library only for nothing -- it is torch code
+    assert stat.rows_coherent == -1 and not G._rows_coherent(stat)
+    xyz = stat._xyz.detach().clone()
+    order = stat.spatial_sort_()
+    assert stat.rows_coherent == 50 and G._rows_coherent(stat) and torch.equal(stat._xyz.detach(), xyz[order])
+    assert sorted(order.tolist()) == list(range(50)) and stat._xyz.requires_grad
+    o2 = dyn.spatial_sort_()
+    assert dyn.rows_coherent == 20 and dyn.control_xyz.shape == (20, 12, 3) and sorted(o2.tolist()) == list(range(20))
