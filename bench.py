@@ -627,11 +627,18 @@ def main():
     params = leaves(stat, dyn)
     shard = SubframeShard(world, rank)
     last = {}
+    # the headline workload includes the camera-pose gradient (config.workload says so; eval.py's test-time pose
+    # optimisation needs it): its camera ASKS for it -- since round 5 the projection backward skips the pose gradient when
+    # nobody does (train.py never optimises the pose), and the headline must not get faster by doing less
+    cam_lean = PinholeCamera(args.width, args.height, scam.K, torch.eye(4), time=scam.time, max_time=scam.max_time,
+                             device=dev)
+    cam_lean.world_view_transform.requires_grad_(True)
 
     def lean_step():
         for p in params:
             p.grad = None
-        out = render(cam, stat, dyn, None, bg)
+        cam_lean.world_view_transform.grad = None
+        out = render(cam_lean, stat, dyn, None, bg)
         # back-propagate fixed random cotangents: d(loss)/d(pred) = v_render, d(loss)/d(depth) = v_depth
         torch.autograd.backward([out["render"], out["depth"]], [v_render, v_depth])
         last["out"] = out

@@ -163,7 +163,9 @@ int mobgs_project_bwd_ex(int C, int N, int geometry_per_camera, const float* mea
  * thread's registers and goes through the arithmetic of mobgs_prep_bwd (bit for bit) to the 13 leaf gradients.
  * x_means / x_quats / x_scales (each may be NULL): cotangents that reach the activated state directly, added first.
  * v_opacities / v_colors (may be NULL): as mobgs_prep_bwd.  accumulate: as mobgs_prep_bwd.  v_viewmats [4,4] is fully
- * written; v_viewmats_partial: mobgs_project_bwd_scratch_floats(1, N) floats.  float32 leaves only. */
+ * written (scratch v_viewmats_partial: mobgs_project_bwd_scratch_floats(1, N) floats); v_viewmats = NULL: the pose needs no
+ * gradient (the training loop never optimises it; eval.py's test-time pose optimisation does) -- the per-workgroup partial
+ * rows and the reduction launch are skipped.  float32 leaves only. */
 typedef struct MobgsLeafGrads {
     float *s_xyz, *s_scaling, *s_rotation, *s_opacity, *s_fdc, *s_ft, *d_control, *d_scaling, *d_rotation, *d_omega,
         *d_opacity, *d_fdc, *d_ft;

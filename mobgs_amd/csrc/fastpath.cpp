@@ -381,13 +381,13 @@ std::vector<Tensor> prep_state_buffers(int64_t N, const Tensor& like) {
 
 // ---- rendering._PrepProjectAndBin.backward: projection backward + prep backward in one launch -----------------------------
 // g: a sink's 13 float32 gradient buffers (accumulate = 1) or empty -> allocated here.  -> (the 13 buffers, v_viewmats)
-std::tuple<std::vector<Tensor>, Tensor>
+std::tuple<std::vector<Tensor>, OptT>
 project_prep_bwd(int64_t width, int64_t height, double eps2d, const Tensor& means, const Tensor& quats,
                  const Tensor& scales, const Tensor& viewmats, const Tensor& Ks, const Tensor& radii,
                  const Tensor& conics, const OptT& v_means2d, const OptT& v_depths, const OptT& v_conics,
                  const OptT& x_means, const OptT& x_quats, const OptT& x_scales, int64_t Ns, int64_t Nd,
                  const Tensor& times, const Tensor& d_ncp, const Tensor& d_trbf, const Tensor& opac, const OptT& v_opac,
-                 const OptT& v_colors, std::vector<Tensor> g, int64_t accumulate, int64_t stream) {
+                 const OptT& v_colors, std::vector<Tensor> g, int64_t accumulate, int64_t stream, bool want_viewmats) {
     const int64_t N = means.size(0);
     const auto f = means.options().dtype(at::kFloat);
     if (g.empty()) {
@@ -399,8 +399,11 @@ project_prep_bwd(int64_t width, int64_t height, double eps2d, const Tensor& mean
     } else if (g.size() != 13) {
         throw std::runtime_error("project_prep_bwd: 13 gradient buffers expected");
     }
-    Tensor v_viewmats = at::empty_like(viewmats);
-    Tensor partial = at::empty({(int64_t)api.project_bwd_scratch_floats(1, (int)N)}, f);
+    OptT v_viewmats, partial;
+    if (want_viewmats) {
+        v_viewmats = at::empty_like(viewmats);
+        partial = at::empty({(int64_t)api.project_bwd_scratch_floats(1, (int)N)}, f);
+    }
     const OptT g2 = f32c(v_means2d), gd = f32c(v_depths), gc = f32c(v_conics), xm = f32c(x_means), xq = f32c(x_quats),
                xs = f32c(x_scales), vo = f32c(v_opac), vc = f32c(v_colors);
     MobgsLeafGrads lg{fpw(g[0]), fpw(g[1]), fpw(g[2]), fpw(g[3]), fpw(g[4]), fpw(g[5]), fpw(g[6]),

@@ -512,6 +512,9 @@ project_bwd_kernel(int N, const float* __restrict__ means, const float* __restri
         }
     }
     // camera gradient: wave reduce -> LDS -> one 16-float partial row per workgroup (deterministic)
+    if constexpr (PREPB) {
+        if (!v_view_partial) return;  // (uniform over the launch: nobody asked for the pose gradient)
+    }
     __shared__ float red[4][12];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -697,7 +700,7 @@ int mobgs_project_prep_bwd_fused(int N, const float* means, const float* quats, 
                                  float* v_viewmats_partial, int Ns, int Nd, const float* times, const int64_t* d_ncp,
                                  const float* d_trbf, const float* opacities, const float* v_opacities,
                                  const float* v_colors, const MobgsLeafGrads* grads, int accumulate, void* stream) {
-    if (N < 1 || Ns < 0 || Nd < 0 || Ns + Nd != N || !grads || !v_viewmats || !v_viewmats_partial) {
+    if (N < 1 || Ns < 0 || Nd < 0 || Ns + Nd != N || !grads || (v_viewmats && !v_viewmats_partial)) {
         set_error("mobgs_project_prep_bwd_fused: bad arguments (N=%d Ns=%d Nd=%d)", N, Ns, Nd);
         return MOBGS_E_INVALID;
     }
@@ -720,10 +723,11 @@ int mobgs_project_prep_bwd_fused(int N, const float* means, const float* quats, 
     const int nblocks = (N + 255) / 256;
     hipLaunchKernelGGL(project_bwd_kernel<true>, dim3(nblocks, 1), dim3(256), 0, (hipStream_t)stream, N, means, quats,
                        scales, viewmats, Ks, width, height, eps2d, radii, conics, v_means2d, v_depths, v_conics,
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr, v_viewmats_partial, 0, 0, (size_t)0, (size_t)0,
-                       pb);
-    hipLaunchKernelGGL(viewmat_reduce_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, nblocks, v_viewmats_partial,
-                       v_viewmats);
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, v_viewmats ? v_viewmats_partial : nullptr, 0, 0,
+                       (size_t)0, (size_t)0, pb);
+    if (v_viewmats)  // (NULL: the caller's camera pose does not require a gradient -- train.py never optimises it)
+        hipLaunchKernelGGL(viewmat_reduce_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, nblocks,
+                           v_viewmats_partial, v_viewmats);
     return check_launch("project_bwd_kernel<prep>");
 }
 

@@ -1250,7 +1250,8 @@ class _PrepProjectAndBin(torch.autograd.Function):
             bufs, v_viewmats = F.project_prep_bwd(
                 width, height, eps2d, means, quats, scales, saved[3], saved[4], saved[5], saved[6], v_means2d, v_depths,
                 v_conics, v_means, v_quats, v_scales, Ns, Nd, times, d_ncp, d_trbf, opac, v_opac, v_cols,
-                [sink.buffers[n_] for n_ in _ops._LEAF_NAMES] if have else [], 1 if have else 0, stream_int())
+                [sink.buffers[n_] for n_ in _ops._LEAF_NAMES] if have else [], 1 if have else 0, stream_int(),
+                bool(ctx.needs_input_grad[16]))
             g = sink.buffers if have else dict(zip(_ops._LEAF_NAMES, bufs))
             if use_sink:
                 sink.buffers = g

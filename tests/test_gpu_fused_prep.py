@@ -109,3 +109,28 @@ def test_fused_prep_inside_a_leaf_gradient_sink_and_on_the_fallbacks(hip_device)
         assert len(seen) == 1
     finally:
         G._R.SharedProjection.from_raw = real
+
+
+def test_pose_gradient_is_skipped_only_when_nobody_asks_for_it(hip_device):
+    """mobgs_project_prep_bwd_fused with v_viewmats = NULL (the camera pose does not require a gradient: train.py never
+    optimises it): no partial rows, no reduction launch -- and exactly the same leaf gradients."""
+    import mobgs_amd.gaussian_renderer as G
+    dev = hip_device
+    W, H = 320, 200
+    v = torch.randn(3, H, W, generator=torch.Generator().manual_seed(4)).to(dev)
+    res = {}
+    for want in (True, False):
+        cam, stat, dyn = _scene(dev, W, H, 5_000, 2_500, False)
+        cam.world_view_transform.requires_grad_(want)
+        for rep in range(2):
+            for p in _leaves(stat, dyn):
+                p.grad = None
+            cam.world_view_transform.grad = None
+            out = G.render(cam, stat, dyn, None, torch.zeros(9, device=dev))
+            ((out["render"] * v).sum() + out["depth"].sum()).backward()
+        res[want] = [p.grad.clone() for p in _leaves(stat, dyn)]
+        assert (cam.world_view_transform.grad is not None) == want
+        if want:
+            assert float(cam.world_view_transform.grad.abs().max()) > 0
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
