@@ -635,6 +635,23 @@ int mobgs_decoder_bwd_many(int C, int P, int CF, int has_depth, int width, const
                            float* g_w1, float* g_w2, float* g_c2w, int g_c2w_floats, int accumulate_wgrad,
                            void* stream);
 
+/* The batched decoder with `n` further channels [c0, c0 + n) of the image -- behind the ones the decoder reads -- handed
+ * out as an array of their own, chan_out [C,P,n] (forward), and their cotangent v_chan [C,P,n] written into those
+ * channels of v_feat_hw (backward; the other unread channels get 0 as before).  get_flow()
+ * (/root/reference/gaussian_renderer/__init__.py:436-476) composites 9 features + 2 flow channels in one pass; taking the
+ * two channels off the 12-channel image with a PyTorch slice is a strided copy of the whole image each way.
+ * chan_out / v_chan = NULL: exactly mobgs_decoder_fwd_many / mobgs_decoder_bwd_many. */
+int mobgs_decoder_fwd_channels(int C, int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
+                               const float* rays, int64_t rays_stride, const float* ray_intr, int intr_stride,
+                               const float* ray_c2w, int c2w_stride, const float* w1, const float* w2, float* rgb,
+                               float* depth, float* chan_out, int c0, int n, void* stream);
+int mobgs_decoder_bwd_channels(int C, int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
+                               const float* rays, int64_t rays_stride, const float* ray_intr, int intr_stride,
+                               const float* ray_c2w, int c2w_stride, const float* w1, const float* w2, const float* v_rgb,
+                               const float* v_depth, float* v_feat_hw, float* v_alphas, float* v_rays, float* w_partial,
+                               float* g_w1, float* g_w2, float* g_c2w, int g_c2w_floats, int accumulate_wgrad,
+                               const float* v_chan, int c0, int n, void* stream);
+
 /* ---- K10: deformation network (the API the reference exposes as scene.deformation.deform_network) -----
  * /root/reference/scene/hexplane.py:75-108,165-187 (HexPlane multi-resolution bilinear planes, product over the
  * 6 planes of a level, concat over 3 levels -> 96 features); /root/reference/scene/deformation.py:158-199

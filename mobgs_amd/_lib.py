@@ -122,6 +122,10 @@ _SIGS = {
                                        P]),
     "mobgs_decoder_bwd_many": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, c_int, P, c_int] + [P] * 11
                                + [c_int, c_int, P]),
+    "mobgs_decoder_fwd_channels": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, c_int, P, c_int, P, P, P,
+                                           P, P, c_int, c_int, P]),
+    "mobgs_decoder_bwd_channels": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, c_int, P, c_int] +
+                                   [P] * 11 + [c_int, c_int, P, c_int, c_int, P]),
     "mobgs_ssim_l1_blocks": (c_int, [c_int, c_int, c_int]),
     "mobgs_ssim_l1_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P]),
     "mobgs_ssim_l1_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P]),

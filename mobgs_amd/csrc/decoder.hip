@@ -47,6 +47,12 @@ __device__ inline Weights load_weights(const float* __restrict__ w1, const float
 struct DecBatch {
     size_t rays_stride;
     int intr_stride, c2w_stride;
+    // channels [c0, c0 + cn) of the image that the decoder does not read, handed out as a tensor of their own [C,P,cn]
+    // (forward: chan_out) / their cotangent taken in (backward: v_chan) -- get_flow()'s two flow channels ride in the
+    // 12-channel exposure image; slicing them off in PyTorch is a strided copy of the whole image each way
+    float* chan_out = nullptr;
+    const float* v_chan = nullptr;
+    int c0 = 0, cn = 0;
 };
 
 // feat_hw: [P, CF] channels-last with CF >= 9 (+1 accumulated depth when has_depth)
@@ -83,6 +89,8 @@ decoder_fwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
 #pragma unroll
         for (int o = 0; o < 3; ++o) rgb[(size_t)o * P + p] = out[o];
         if (has_depth) depth[p] = f[9] / fmaxf(alphas[p], 1e-10f);
+        if (bt.chan_out)
+            for (int k = 0; k < bt.cn; ++k) bt.chan_out[((size_t)blockIdx.y * P + p) * bt.cn + k] = f[bt.c0 + k];
     }
 }
 
@@ -250,7 +258,9 @@ decoder_bwd_kernel(int P, int CF, int has_depth, int width, const float* __restr
                 vf[9] = g / ac;
                 v_alphas[p] = a > 1e-10f ? -g * f[9] / (ac * ac) : 0.f;
             }
-            for (int k = 9 + (has_depth ? 1 : 0); k < CF; ++k) vf[k] = 0.f;
+            for (int k = 9 + (has_depth ? 1 : 0); k < CF; ++k)
+                vf[k] = (bt.v_chan && k >= bt.c0 && k < bt.c0 + bt.cn)
+                            ? bt.v_chan[((size_t)blockIdx.y * P + p) * bt.cn + (k - bt.c0)] : 0.f;
             if (v_rays) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) v_rays[(size_t)k * P + p] = vx[6 + k];
@@ -371,18 +381,43 @@ static int decoder_args_ok(const char* who, int C, int P, int CF, int has_depth,
     return 1;
 }
 
+static bool channel_args_ok(const char* who, int CF, int has_depth, const void* chan, int c0, int n) {
+    if (!chan) return true;
+    if (n < 1 || c0 < 9 + (has_depth ? 1 : 0) || c0 + n > CF) {
+        set_error("%s: extra channels [%d, %d) must lie behind the channels the decoder reads and inside CF = %d", who, c0,
+                  c0 + n, CF);
+        return false;
+    }
+    return true;
+}
+
+int mobgs_decoder_fwd_channels(int C, int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
+                               const float* rays, int64_t rays_stride, const float* ray_intr, int intr_stride,
+                               const float* ray_c2w, int c2w_stride, const float* w1, const float* w2, float* rgb,
+                               float* depth, float* chan_out, int c0, int n, void* stream) {
+    if (!decoder_args_ok("mobgs_decoder_fwd", C, P, CF, has_depth, width, rays, ray_intr, ray_c2w) ||
+        !channel_args_ok("mobgs_decoder_fwd_channels", CF, has_depth, chan_out, c0, n))
+        return MOBGS_E_INVALID;
+    if (P == 0) return MOBGS_OK;
+    int g = (P + DEC_THREADS - 1) / DEC_THREADS;
+    if (g > 4096) g = 4096;
+    DecBatch bt{(size_t)rays_stride, intr_stride, c2w_stride};
+    if (chan_out) {
+        bt.chan_out = chan_out;
+        bt.c0 = c0;
+        bt.cn = n;
+    }
+    hipLaunchKernelGGL(decoder_fwd_kernel, dim3(g, C), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth, width,
+                       feat_hw, alphas, rays, ray_intr, ray_c2w, w1, w2, rgb, depth, bt);
+    return check_launch("decoder_fwd_kernel");
+}
+
 int mobgs_decoder_fwd_many(int C, int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
                            const float* rays, int64_t rays_stride, const float* ray_intr, int intr_stride,
                            const float* ray_c2w, int c2w_stride, const float* w1, const float* w2, float* rgb,
                            float* depth, void* stream) {
-    if (!decoder_args_ok("mobgs_decoder_fwd", C, P, CF, has_depth, width, rays, ray_intr, ray_c2w)) return MOBGS_E_INVALID;
-    if (P == 0) return MOBGS_OK;
-    int g = (P + DEC_THREADS - 1) / DEC_THREADS;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(decoder_fwd_kernel, dim3(g, C), dim3(DEC_THREADS), 0, (hipStream_t)stream, P, CF, has_depth, width,
-                       feat_hw, alphas, rays, ray_intr, ray_c2w, w1, w2, rgb, depth,
-                       DecBatch{(size_t)rays_stride, intr_stride, c2w_stride});
-    return check_launch("decoder_fwd_kernel");
+    return mobgs_decoder_fwd_channels(C, P, CF, has_depth, width, feat_hw, alphas, rays, rays_stride, ray_intr, intr_stride,
+                                      ray_c2w, c2w_stride, w1, w2, rgb, depth, nullptr, 0, 0, stream);
 }
 
 int mobgs_decoder_fwd(int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
@@ -398,6 +433,18 @@ int mobgs_decoder_bwd_many(int C, int P, int CF, int has_depth, int width, const
                            const float* v_depth, float* v_feat_hw, float* v_alphas, float* v_rays, float* w_partial,
                            float* g_w1, float* g_w2, float* g_c2w, int g_c2w_floats, int accumulate_wgrad,
                            void* stream) {
+    return mobgs_decoder_bwd_channels(C, P, CF, has_depth, width, feat_hw, alphas, rays, rays_stride, ray_intr, intr_stride,
+                                      ray_c2w, c2w_stride, w1, w2, v_rgb, v_depth, v_feat_hw, v_alphas, v_rays, w_partial,
+                                      g_w1, g_w2, g_c2w, g_c2w_floats, accumulate_wgrad, nullptr, 0, 0, stream);
+}
+
+int mobgs_decoder_bwd_channels(int C, int P, int CF, int has_depth, int width, const float* feat_hw, const float* alphas,
+                               const float* rays, int64_t rays_stride, const float* ray_intr, int intr_stride,
+                               const float* ray_c2w, int c2w_stride, const float* w1, const float* w2, const float* v_rgb,
+                               const float* v_depth, float* v_feat_hw, float* v_alphas, float* v_rays, float* w_partial,
+                               float* g_w1, float* g_w2, float* g_c2w, int g_c2w_floats, int accumulate_wgrad,
+                               const float* v_chan, int c0, int n, void* stream) {
+    if (!channel_args_ok("mobgs_decoder_bwd_channels", CF, has_depth, v_chan, c0, n)) return MOBGS_E_INVALID;
     if (!decoder_args_ok("mobgs_decoder_bwd", C, P, CF, has_depth, width, rays, ray_intr, ray_c2w) || P == 0 ||
         (g_c2w && g_c2w_floats != 12 && g_c2w_floats != 16)) {
         if (P == 0) set_error("mobgs_decoder_bwd: P = 0");
@@ -409,10 +456,16 @@ int mobgs_decoder_bwd_many(int C, int P, int CF, int has_depth, int width, const
         return MOBGS_E_INVALID;
     }
     const int g = decoder_grid(P);
+    DecBatch bt{(size_t)rays_stride, intr_stride, c2w_stride};
+    if (v_chan) {
+        bt.v_chan = v_chan;
+        bt.c0 = c0;
+        bt.cn = n;
+    }
     hipLaunchKernelGGL(rays ? decoder_bwd_kernel<true> : decoder_bwd_kernel<false>, dim3(g, C), dim3(DEC_THREADS), 0,
                        (hipStream_t)stream, P, CF, has_depth, width,
                        feat_hw, alphas, rays, ray_intr, ray_c2w, g_c2w ? 1 : 0, w1, w2, v_rgb, v_depth, v_feat_hw,
-                       v_alphas, v_rays, w_partial, DecBatch{(size_t)rays_stride, intr_stride, c2w_stride});
+                       v_alphas, v_rays, w_partial, bt);
     const int nred = NRED + ((g_c2w && g_c2w_floats == 16) ? 4 : 0);
     hipLaunchKernelGGL(decoder_wgrad_reduce_kernel, dim3(nred, C), dim3(256), 0, (hipStream_t)stream, g, w_partial, g_w1,
                        g_w2, g_c2w, accumulate_wgrad, g_c2w_floats);

@@ -36,8 +36,8 @@ struct Api {
     decltype(&mobgs_raster_fwd_decode) raster_fwd_decode = nullptr;
     decltype(&mobgs_raster_bwd) raster_bwd = nullptr;
     decltype(&mobgs_raster_bwd_reduce) raster_bwd_reduce = nullptr;
-    decltype(&mobgs_decoder_fwd_many) decoder_fwd = nullptr;
-    decltype(&mobgs_decoder_bwd_many) decoder_bwd = nullptr;
+    decltype(&mobgs_decoder_fwd_channels) decoder_fwd = nullptr;
+    decltype(&mobgs_decoder_bwd_channels) decoder_bwd = nullptr;
     decltype(&mobgs_decoder_bwd_blocks) decoder_bwd_blocks = nullptr;
     decltype(&mobgs_project_bwd) project_bwd = nullptr;
     decltype(&mobgs_project_bwd_ex) project_bwd_ex = nullptr;
@@ -78,8 +78,8 @@ void bind(const std::unordered_map<std::string, uint64_t>& m) {
     take(m, "mobgs_raster_fwd_decode", api.raster_fwd_decode);
     take(m, "mobgs_raster_bwd", api.raster_bwd);
     take(m, "mobgs_raster_bwd_reduce", api.raster_bwd_reduce);
-    take(m, "mobgs_decoder_fwd_many", api.decoder_fwd);
-    take(m, "mobgs_decoder_bwd_many", api.decoder_bwd);
+    take(m, "mobgs_decoder_fwd_channels", api.decoder_fwd);
+    take(m, "mobgs_decoder_bwd_channels", api.decoder_bwd);
     take(m, "mobgs_decoder_bwd_blocks", api.decoder_bwd_blocks);
     take(m, "mobgs_project_bwd", api.project_bwd);
     take(m, "mobgs_project_bwd_ex", api.project_bwd_ex);
@@ -310,19 +310,27 @@ static DecStrides decoder_strides(int64_t H, int64_t W, int64_t CF, const Tensor
     return d;
 }
 
-std::tuple<Tensor, OptT> decoder_fwd(int64_t H, int64_t W, int64_t CF, bool has_depth, const Tensor& feat_hw,
-                                     const OptT& alphas, const OptT& rays, const OptT& intr, const OptT& c2w,
-                                     const Tensor& w1, const Tensor& w2, int64_t stream) {
+// chan_n > 0: channels [chan_c0, chan_c0 + chan_n) of the image come back as a contiguous tensor [..., chan_n] of their own
+std::tuple<Tensor, OptT, OptT> decoder_fwd(int64_t H, int64_t W, int64_t CF, bool has_depth, const Tensor& feat_hw,
+                                           const OptT& alphas, const OptT& rays, const OptT& intr, const OptT& c2w,
+                                           const Tensor& w1, const Tensor& w2, int64_t stream, int64_t chan_c0,
+                                           int64_t chan_n) {
     const auto f = feat_hw.options();
     const DecStrides d = decoder_strides(H, W, CF, feat_hw, rays, intr, c2w);
     const bool batch = feat_hw.dim() == 4;
     Tensor rgb = batch ? at::empty({d.C, 3, H, W}, f) : at::empty({3, H, W}, f);
     OptT depth = has_depth ? OptT(batch ? at::empty({d.C, H, W}, f) : at::empty({H, W}, f)) : OptT();
+    OptT chan;
+    if (chan_n > 0) {
+        std::vector<int64_t> shape(feat_hw.sizes().begin(), feat_hw.sizes().end());
+        shape.back() = chan_n;
+        chan = at::empty(shape, f);
+    }
     check(api.decoder_fwd((int)d.C, (int)(H * W), (int)CF, has_depth ? 1 : 0, (int)W, fp(feat_hw), fp(alphas), fp(rays),
                           d.rays, fp(intr), (int)d.intr, fp(c2w), (int)d.c2w, fp(w1), fp(w2), fpw(rgb), fpw(depth),
-                          sp(stream)),
+                          fpw(chan), (int)chan_c0, (int)chan_n, sp(stream)),
           "mobgs_decoder_fwd");
-    return {rgb, depth};
+    return {rgb, depth, chan};
 }
 
 // g_w1 / g_w2: a sink's buffers (accumulate as given) or None -> allocated here and overwritten.
@@ -331,7 +339,11 @@ std::tuple<Tensor, OptT, OptT, OptT, Tensor, Tensor>
 decoder_bwd(int64_t H, int64_t W, int64_t CF, bool has_depth, const Tensor& feat_hw, const OptT& alphas,
             const OptT& rays, const OptT& intr, const OptT& c2w, const Tensor& w1, const Tensor& w2,
             const OptT& v_rgb_in, const OptT& v_depth_in, std::vector<int64_t> feat_shape, bool rays_need_grad,
-            bool c2w_needs_grad, const OptT& g_w1_in, const OptT& g_w2_in, int64_t accumulate, int64_t stream) {
+            bool c2w_needs_grad, const OptT& g_w1_in, const OptT& g_w2_in, int64_t accumulate, int64_t stream,
+            const OptT& v_chan_in, int64_t chan_c0) {
+    // v_chan (optional): the cotangent of the channels decoder_fwd handed out; written into v_feat by the kernel
+    const OptT v_chan = f32c(v_chan_in);
+    const int64_t chan_n = (v_chan.has_value() && v_chan->defined()) ? v_chan->size(-1) : 0;
     const auto f = feat_hw.options();
     const int64_t P = H * W;
     const DecStrides d = decoder_strides(H, W, CF, feat_hw, rays, intr, c2w);
@@ -349,7 +361,7 @@ decoder_bwd(int64_t H, int64_t W, int64_t CF, bool has_depth, const Tensor& feat
                           fp(intr), (int)d.intr, fp(c2w), (int)d.c2w, fp(w1), fp(w2), fp(v_rgb), fp(v_depth),
                           fpw(v_feat), fpw(v_alphas), fpw(v_rays), fpw(partial), fpw(g_w1), fpw(g_w2), fpw(g_c2w),
                           g_c2w.has_value() ? (int)(g_c2w->numel() / (d.c2w ? d.C : 1)) : 0,
-                          sunk ? (int)accumulate : 0, sp(stream)),
+                          sunk ? (int)accumulate : 0, fp(v_chan), (int)chan_c0, (int)chan_n, sp(stream)),
           "mobgs_decoder_bwd");
     return {v_feat, v_alphas, v_rays, g_c2w, g_w1, g_w2};
 }

@@ -248,9 +248,11 @@ class Decode(torch.autograd.Function):
     and `c2w` [3,4] from which the kernel generates them (gradient flows into c2w)."""
 
     @staticmethod
-    def forward(ctx, feat_hw, alphas, rays, intr, c2w, w1, w2, has_depth: bool, pre_rgb=None, pre_depth=None):
+    def forward(ctx, feat_hw, alphas, rays, intr, c2w, w1, w2, has_depth: bool, pre_rgb=None, pre_depth=None, _chan=None):
         """pre_rgb / pre_depth: this node's outputs, already computed by the forward compositor's decoder epilogue
-        (rendering.SharedProjection.composite_decode) -- nothing is launched here, the backward pass is unchanged."""
+        (rendering.SharedProjection.composite_decode) -- nothing is launched here, the backward pass is unchanged.
+        _chan = (c0, n) (DecodeWithChannels, host fast path): the kernel also hands out channels [c0, c0 + n) of the image
+        as a contiguous tensor, left in ctx.chan_out."""
         lib = _lib.load()
         ctx.set_materialize_grads(False)  # an unused depth output costs no zero image in backward
         ctx.w_inputs = (w1, w2)  # the caller's tensor objects (a LeafGradSink recognises its weights by identity)
@@ -274,8 +276,9 @@ class Decode(torch.autograd.Function):
         if pre_rgb is not None:
             rgb, depth = pre_rgb.view_as(pre_rgb), (pre_depth.view_as(pre_depth) if has_depth else None)
         elif F is not None:
-            rgb, depth = F.decoder_fwd(H, W, CF, bool(has_depth), feat_hw, alphas_c, rays_c, intr_c, c2w_c, w1, w2,
-                                       stream_int())
+            rgb, depth, ctx.chan_out = F.decoder_fwd(H, W, CF, bool(has_depth), feat_hw, alphas_c, rays_c, intr_c, c2w_c,
+                                                     w1, w2, stream_int(), _chan[0] if _chan else 0,
+                                                     _chan[1] if _chan else 0)
         else:
             lead = (C,) if feat_hw.dim() == 4 else ()
             rgb = torch.empty(*lead, 3, H, W, dtype=torch.float32, device=dev)
@@ -294,7 +297,9 @@ class Decode(torch.autograd.Function):
         return rgb, rgb.new_empty(0)
 
     @staticmethod
-    def backward(ctx, v_rgb, v_depth):
+    def backward(ctx, v_rgb, v_depth, _v_chan=None, _chan_c0=0):
+        """_v_chan / _chan_c0 (DecodeWithChannels, host fast path): the cotangent of the channels handed out by forward;
+        the kernel writes it into those channels of the image's gradient."""
         lib = _lib.load()
         feat_hw, alphas, rays, intr, c2w, w1, w2 = ctx.saved_tensors
         if v_rgb is None and v_depth is None:
@@ -310,7 +315,7 @@ class Decode(torch.autograd.Function):
                 H, W, CF, bool(has_depth), feat_hw, alphas, rays, intr, c2w, w1, w2, v_rgb, v_depth,
                 list(ctx.feat_shape), bool(ctx.rays_need_grad), bool(ctx.c2w_needs_grad),
                 sunk[0] if sunk is not None else None, sunk[1] if sunk is not None else None,
-                sunk[2] if sunk is not None else 0, stream_int())
+                sunk[2] if sunk is not None else 0, stream_int(), _v_chan, int(_chan_c0))
             if sunk is not None:
                 return v_feat, v_alphas, v_rays, None, g_c2w, None, None, None, None, None
             return v_feat, v_alphas, v_rays, None, g_c2w, g_w1, g_w2, None, None, None
@@ -347,9 +352,14 @@ class DecodeWithChannels(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feat_hw, alphas, rays, intr, c2w, w1, w2, c0: int, n: int):
-        rgb, _ = Decode.forward(ctx, feat_hw, alphas, rays, intr, c2w, w1, w2, False)
         ctx.chan = (int(c0), int(n))
-        return rgb, feat_hw[..., c0:c0 + n].contiguous()
+        ctx.chan_out = None
+        rgb, _ = Decode.forward(ctx, feat_hw, alphas, rays, intr, c2w, w1, w2, False, None, None,
+                                ctx.chan if _fast.get() is not None else None)
+        chan, ctx.chan_out = ctx.chan_out, None
+        if chan is None:   # (Python host path: the slice as a strided copy)
+            chan = feat_hw[..., c0:c0 + n].contiguous()
+        return rgb, chan
 
     @staticmethod
     def backward(ctx, v_rgb, v_chan):
@@ -360,6 +370,9 @@ class DecodeWithChannels(torch.autograd.Function):
             v_feat = torch.zeros(ctx.feat_shape, dtype=torch.float32, device=v_chan.device)
             v_feat[..., c0:c0 + n].copy_(v_chan)
             return (v_feat,) + (None,) * 8
+        if _fast.get() is not None and v_chan is not None:
+            g = Decode.backward(ctx, v_rgb, None, v_chan, c0)   # (the kernel drops the cotangent into its channels)
+            return tuple(g[:7]) + (None, None)
         g = Decode.backward(ctx, v_rgb, None)
         if v_chan is not None:
             g[0][..., c0:c0 + n].copy_(v_chan)
