@@ -223,8 +223,9 @@ def _raw_inputs(stat_pc, dyn_pc):
 
 # Lean render(): the per-splat state (spline position, activations, colour features) is built INSIDE the projection kernel
 # instead of by a launch of its own (rendering._PrepProjectAndBin).  Same arithmetic, same outputs,
-# same gradients; MOBGS_FUSE_PREP=0 keeps the two launches (A/B).  Train-mode renders (static / dynamic layers read the
-# colour features as an array), the `coherent` offset, half-stored attributes and the python host path keep them too.
+# same gradients; MOBGS_FUSE_PREP=0 keeps the two launches (A/B).  Train-mode renders take the same path (their static /
+# dynamic layers are class passes over the same packed records); the `coherent` offset, half-stored attributes and the
+# python host path keep the two launches.
 FUSE_PREP = __import__("os").environ.get("MOBGS_FUSE_PREP", "1") != "0"
 
 
@@ -342,8 +343,10 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     dyn_sl, stat_sl, all_sl = slice(Ns, None), slice(0, Ns), slice(None)
     times = _times(cam, delta_exposure, dev)
     raw = _raw_inputs(stat_pc, dyn_pc)
-    fuse_prep = (coherent is None and not get_static and not get_dynamic and not (delta_exposure is not None and get_flow)
-                 and _can_fuse_prep(raw, times))
+    # (train-mode renders too: their static / dynamic layers are class passes over the SAME packed records; the layered
+    # walk that reads the colour features as an array gets them from a prep launch of its own, see aux_images)
+    fuse_prep = (coherent is None and not (delta_exposure is not None and get_flow) and _can_fuse_prep(raw, times)
+                 and ((not get_static and not get_dynamic) or (FUSE_LAYERS and _R.CLASS_PASSES)))
     sp = None
     if fuse_prep:
         # (cols: the token the compositing node returns its colour gradient through -- never read as data)
@@ -411,8 +414,10 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
         """The reference's ones-colour pass (:163-177, :255-269): sum_i w_i + T_final * bg = (1 - T) + T * bg."""
         return a + (1.0 - a) * bg[0]
 
-    def aux_images():
+    def aux_images(cols=cols):
         res = {}
+        if fuse_prep and not (FUSE_LAYERS and _R.CLASS_PASSES):
+            cols = _prep(stat_pc, dyn_pc, times)[4]   # (switched off since the render: the features as an array after all)
         if FUSE_LAYERS:
             imgs, alps = sp.composite_layers(cols, Ns, bg1, want_static=get_static, want_dynamic=get_dynamic)
             if get_dynamic:

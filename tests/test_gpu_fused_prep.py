@@ -74,7 +74,8 @@ def test_lean_render_with_the_state_built_in_the_projection_kernel(hip_device, W
 
 def test_fused_prep_inside_a_leaf_gradient_sink_and_on_the_fallbacks(hip_device):
     """ops.LeafGradSink recognises the fused node's leaves (gradients accumulate over two renders exactly as with the
-    separate prep node); train-mode renders, a `coherent` offset and half-stored attributes keep the two launches."""
+    separate prep node); a `coherent` offset, half-stored attributes and the layered walk (class passes off) keep the two
+    launches; train-mode renders are fused like lean ones and stay bit-identical."""
     import mobgs_amd.gaussian_renderer as G
     from mobgs_amd.ops import LeafGradSink
     dev = hip_device
@@ -104,9 +105,15 @@ def test_fused_prep_inside_a_leaf_gradient_sink_and_on_the_fallbacks(hip_device)
         bg = torch.zeros(9, device=dev)
         G.render(cam, stat, dyn, None, bg)
         assert len(seen) == 1
-        G.render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True)["d_render"]
+        G.render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True)["d_render"]   # (class passes: fused too)
+        assert len(seen) == 2
         G.render(cam, stat, dyn, None, bg, coherent=torch.zeros(2_500, 3, device=dev))
-        assert len(seen) == 1
+        G._R.CLASS_PASSES = False
+        try:
+            G.render(cam, stat, dyn, None, bg, get_static=True, get_dynamic=True)["d_render"]
+        finally:
+            G._R.CLASS_PASSES = True
+        assert len(seen) == 2
     finally:
         G._R.SharedProjection.from_raw = real
 
@@ -134,3 +141,32 @@ def test_pose_gradient_is_skipped_only_when_nobody_asks_for_it(hip_device):
             assert float(cam.world_view_transform.grad.abs().max()) > 0
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+def test_train_mode_render_with_fused_prep_is_bit_identical(hip_device):
+    """render(get_static=True, get_dynamic=True): the three images, the auxiliary alphas / depths and every leaf gradient,
+    fused prep against the separate prep launch."""
+    import mobgs_amd.gaussian_renderer as G
+    dev = hip_device
+    W, H = 400, 240
+    gen = torch.Generator().manual_seed(7)
+    vs = [torch.randn(3, H, W, generator=gen).to(dev) for _ in range(3)]
+    res = {}
+    for fused in (False, True):
+        G.FUSE_PREP = fused
+        try:
+            cam, stat, dyn = _scene(dev, W, H, 8_000, 4_000, True)
+            for rep in range(2):
+                for p in _leaves(stat, dyn) + list(dyn.rgbdecoder.parameters()):
+                    p.grad = None
+                out = G.render(cam, stat, dyn, None, torch.zeros(9, device=dev), get_static=True, get_dynamic=True)
+                loss = (out["render"] * vs[0]).sum() + (out["s_render"] * vs[1]).sum() + (out["d_render"] * vs[2]).sum() + \
+                    out["d_alpha"].sum() + out["s_alpha"].sum() + out["d_depth"].sum() + out["depth"].sum()
+                loss.backward()
+            res[fused] = [out[k].detach().clone() for k in ("render", "s_render", "d_render", "d_alpha", "s_alpha",
+                                                            "d_depth", "depth", "s_depth")] + \
+                [p.grad.clone() for p in _leaves(stat, dyn)] + [p.grad.clone() for p in dyn.rgbdecoder.parameters()]
+        finally:
+            G.FUSE_PREP = True
+    for i, (a, b) in enumerate(zip(res[False], res[True])):
+        assert torch.equal(a, b), f"output {i}"
