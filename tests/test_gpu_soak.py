@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("seed", [0, 7])
 def test_random_regimes_against_the_c_oracle(hip_device, seed):
     import soak_parity
-    failed, msgs = soak_parity.soak(60, seed, hip_device, verbose=False)
+    failed, msgs = soak_parity.soak(40, seed, hip_device, verbose=False)
     assert failed == 0, "\n".join(msgs)
 
 
@@ -32,7 +32,7 @@ def test_random_regimes_with_the_matrix_pipe_backward(hip_device, arm, heavy):
     if heavy is not None:
         rendering.tuning.heavy_tile_len = heavy
     try:
-        failed, msgs = soak_parity.soak(40, 11 + arm, hip_device, verbose=False)
+        failed, msgs = soak_parity.soak(24, 11 + arm, hip_device, verbose=False)
     finally:
         rendering.tuning.bwd_mfma, rendering.tuning.heavy_tile_len = old
     assert failed == 0, "\n".join(msgs)
@@ -43,7 +43,7 @@ def test_random_render_calls_against_the_torch_restatement(hip_device):
     knots, exposure offsets pushing the time outside [0, 1], 4..12 control points, lean and train mode, random
     backgrounds and cameras -- against oracle/render_torch.py."""
     import soak_render
-    failed, msgs = soak_render.soak(6, 3, hip_device, verbose=False)
+    failed, msgs = soak_render.soak(4, 3, hip_device, verbose=False)
     assert failed == 0, "\n".join(msgs)
 
 
@@ -73,7 +73,7 @@ def test_random_full_size_scenes_with_long_lists(hip_device):
     per-tile lists reach thousands to tens of thousands of entries (every sort build, heavy tiles): lists bit-equal
     to the C oracle's, images and gradients within tolerance."""
     import soak_parity
-    failed, msgs = soak_parity.soak(6, 2, hip_device, verbose=False, large=True)
+    failed, msgs = soak_parity.soak(4, 2, hip_device, verbose=False, large=True)
     assert failed == 0, "\n".join(msgs)
 
 
