@@ -35,10 +35,10 @@ struct Hermite {
 };
 
 __device__ inline Hermite hermite_setup(float t, int n) {
-    // no implicit contraction here: this body is compiled into several kernels that must agree to the bit (plain
-    // operators, NOT the __fmul_rn / __fadd_rn spellings: those are inline functions of the toolchain's header with
-    // contraction allowed inside, which this pragma does not reach -- measured: u = fma(t, n - 1, -idx) in the ISA);
-    // fused multiply-adds below are the explicit __fmaf_rn ones
+    // no implicit contraction here: this body is compiled into several kernels that must agree to the bit, and the
+    // reference's torch expressions round every product and sum on their own (plain operators, NOT the __fmul_rn /
+    // __fadd_rn spellings: those are inline functions of the toolchain's header with contraction allowed inside, which
+    // this pragma does not reach -- measured: u = fma(t, n - 1, -idx) in the ISA)
 #pragma clang fp contract(off)
     Hermite H;
     const float ts = t * (float)(n - 1);
@@ -77,10 +77,10 @@ struct PrepIn {
 template <typename A>
 __device__ __forceinline__ void prep_splat(const PrepIn<A>& in, int i, float (&m)[3], float (&q)[4], float (&s)[3],
                                            float& o, float (&col)[9]) {
-    // no implicit contraction here: this body is compiled into several kernels that must agree to the bit (plain
-    // operators, NOT the __fmul_rn / __fadd_rn spellings: those are inline functions of the toolchain's header with
-    // contraction allowed inside, which this pragma does not reach -- measured: u = fma(t, n - 1, -idx) in the ISA);
-    // fused multiply-adds below are the explicit __fmaf_rn ones
+    // no implicit contraction here: this body is compiled into several kernels that must agree to the bit, and the
+    // reference's torch expressions round every product and sum on their own (plain operators, NOT the __fmul_rn /
+    // __fadd_rn spellings: those are inline functions of the toolchain's header with contraction allowed inside, which
+    // this pragma does not reach -- measured: u = fma(t, n - 1, -idx) in the ISA)
 #pragma clang fp contract(off)
     if (i < in.Ns) {
 #pragma unroll
@@ -107,15 +107,15 @@ __device__ __forceinline__ void prep_splat(const PrepIn<A>& in, int i, float (&m
             const float p0 = cp[3 * H.i0 + k], p1 = cp[3 * H.i1 + k], p2 = cp[3 * H.i2 + k], p3 = cp[3 * H.i3 + k];
             const float m0 = H.left_edge ? (p2 - p1) : (p2 - p0) * 0.5f;
             const float m1 = H.right_edge ? (p2 - p1) : (p3 - p1) * 0.5f;
-            m[k] = __fmaf_rn(H.h11, m1, __fmaf_rn(H.h01, p2, __fmaf_rn(H.h10, m0, H.h00 * p1))) * 1e-2f;
+            // (as the reference's torch expression evaluates it: every product rounded, the sums left to right)
+            m[k] = (H.h00 * p1 + H.h10 * m0 + H.h01 * p2 + H.h11 * m1) * 1e-2f;
             s[k] = expf(ldf(in.d_scaling, 3 * (size_t)j + k));
             col[6 + k] = tfp * ldf(in.d_ft, 3 * (size_t)j + k);
         }
         const float4 r = ld4(in.d_rotation, j);
         const float4 w = ld4(in.d_omega, j);
-        // (explicit FMAs: this function is compiled into two kernels, which must round alike)
-        q[0] = __fmaf_rn(tfp, w.x, r.x); q[1] = __fmaf_rn(tfp, w.y, r.y);
-        q[2] = __fmaf_rn(tfp, w.z, r.z); q[3] = __fmaf_rn(tfp, w.w, r.w);
+        // (rotation + t * omega as torch evaluates it: product rounded, then the sum -- no contraction in this body)
+        q[0] = r.x + tfp * w.x; q[1] = r.y + tfp * w.y; q[2] = r.z + tfp * w.z; q[3] = r.w + tfp * w.w;
         o = 1.f / (1.f + expf(-ldf(in.d_opacity, j)));
 #pragma unroll
         for (int k = 0; k < 6; ++k) col[k] = ldf(in.d_fdc, 6 * (size_t)j + k);
