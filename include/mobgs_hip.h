@@ -99,7 +99,18 @@ extern "C" {
  *                      after every densification) -- the binning kernel then ranks through LDS on grids of up to 8192
  *                      tiles, as it does with an enum_order, without the order's indirection (measured at 300 k splats,
  *                      1352x1014: bin 49.6 -> 29.9 us; against an enum_order: scan 12.5 -> 7.1 us, slot reduction
- *                      38.9 -> 35.4 us).  A performance hint only: a wrong statement costs time, never correctness. */
+ *                      38.9 -> 35.4 us).  A performance hint only: a wrong statement costs time, never correctness.
+ *   static_rows        (round 6) mobgs_raster_bwd / mobgs_raster_class_bwd with 10 or 12 total channels, default 0 / -1 =
+ *                      none.  S > 0: the caller states that the splats with (flat id % N) < S are MoBGS's STATIC set --
+ *                      colour features cat(f_dc, 0.0 * f_t) (/root/reference/scene/gaussian_model.py:244-246; in
+ *                      get_flow()'s 12-channel pass also a flow of exactly 0, gaussian_renderer/__init__.py:436-476) --
+ *                      i.e. channels 6..8 (10 channels) / 6..10 (12 channels) of those rows are zero AND their gradient
+ *                      is not wanted (the reference multiplies it by 0.0).  The backward compositor then runs a blend body
+ *                      without those channels for such entries (one wave-uniform branch per list entry; 6 / 10 of ~50 VALU
+ *                      per evaluated 8x8 quadrant) and v_colors[.., 6..] of those rows is written as 0.  Every other
+ *                      output is BIT-identical (fma(0, v, acc) = acc).  The zeros are verified per staged entry (an entry
+ *                      whose dead channels are not all +-0 takes the full body): a wrong statement about the DATA costs
+ *                      nothing; a caller that does want d/d(colour 6..8) of such rows must leave this at 0. */
 typedef struct MobgsTuning {
     int32_t heavy_tile_len;
     int32_t longest_list_hint;
@@ -110,6 +121,7 @@ typedef struct MobgsTuning {
     int32_t bwd_mfma;
     int32_t gate_zero_cotangent;
     int32_t coherent_order;
+    int32_t static_rows;
 } MobgsTuning;
 
 const char* mobgs_version(void);
@@ -123,7 +135,7 @@ int mobgs_cotangent_probe(int n_arrays, const float* const* arrays, const size_t
  * points changes (round 4 inserted `records` into mobgs_raster_bwd_reduce and changed the gradient-slot format without
  * one: a stale host extension would have passed shifted pointers).  Bindings compare it with the MOBGS_ABI_VERSION
  * they were built against and refuse to run on a mismatch (mobgs_amd/_lib.py, csrc/fastpath.cpp). */
-#define MOBGS_ABI_VERSION 7
+#define MOBGS_ABI_VERSION 8
 int mobgs_abi_version(void);
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* mobgs_last_error(void);
@@ -519,6 +531,20 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
 
 /* 1 if raster kernels are compiled for `total_channels` (colour channels + optional extra channel). */
 int mobgs_raster_channels_supported(int total_channels);
+
+/* Which compositing kernels a pass of `total_channels` over a grid of `n_tiles` tiles (all cameras) takes under
+ * `tuning` -- the decision functions the launchers themselves use, exported so that a test can ASSERT which kernels a
+ * comparison exercised (round-5 review: every reference-generated fixture ran the small-grid selection, the benchmark
+ * the other one).  class_filter: 1 for mobgs_raster_class_fwd/bwd.  Returns a bit field:
+ *   bits 0-1  backward kernel: 0 = quadrant kernel raster_bwd_kernel (per-lane accumulators + wave reduction),
+ *             1 = matrix-pipe backward, one wave per tile + four-wave team for heavy tiles, 2 = team for every tile,
+ *             3 = block-walk backward (MobgsTuning.bwd_block_walk)
+ *   bit 2     forward: 1 = block-walk kernel raster_fwd_blocks_kernel (the decoder epilogue exists only there)
+ *   bit 3     the tile schedule may mark tiles heavy (four waves per tile) -- whether any IS heavy depends on the list
+ *             lengths: count the entries of tile_order with bit 30 set
+ *   bits 8-.. the list length from which a tile is scheduled heavy (0 = never)
+ * Not a launch: no device work, no error state. */
+int mobgs_raster_path(int total_channels, int class_filter, int n_tiles, const MobgsTuning* tuning);
 
 /* ---- K8: per-splat state build (replaces the reference's per-Gaussian torch glue) -----------------------
  * /root/reference/gaussian_renderer/__init__.py:23-56 (interpolate_cubic_hermite), :93-125 (time offset,

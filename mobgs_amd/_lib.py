@@ -23,12 +23,12 @@ class MobgsTuning(ctypes.Structure):
                 ("quadrant_culling", ctypes.c_int32), ("block_walk", ctypes.c_int32),
                 ("bwd_block_walk", ctypes.c_int32), ("geometry_per_camera", ctypes.c_int32),
                 ("bwd_mfma", ctypes.c_int32), ("gate_zero_cotangent", ctypes.c_int32),
-                ("coherent_order", ctypes.c_int32)]
+                ("coherent_order", ctypes.c_int32), ("static_rows", ctypes.c_int32)]
 
     def __init__(self, heavy_tile_len=-1, longest_list_hint=-1, quadrant_culling=-1, block_walk=-1, bwd_block_walk=-1,
-                 geometry_per_camera=0, bwd_mfma=-1, gate_zero_cotangent=0, coherent_order=0):
+                 geometry_per_camera=0, bwd_mfma=-1, gate_zero_cotangent=0, coherent_order=0, static_rows=0):
         super().__init__(heavy_tile_len, longest_list_hint, quadrant_culling, block_walk, bwd_block_walk,
-                         geometry_per_camera, bwd_mfma, gate_zero_cotangent, coherent_order)
+                         geometry_per_camera, bwd_mfma, gate_zero_cotangent, coherent_order, static_rows)
 
     def copy(self, **overrides):
         """A per-call copy with some fields replaced."""
@@ -51,13 +51,14 @@ class MobgsPrepInputs(ctypes.Structure):
 
 
 P = c_void_p
-ABI_VERSION = 7  # include/mobgs_hip.h MOBGS_ABI_VERSION
+ABI_VERSION = 8  # include/mobgs_hip.h MOBGS_ABI_VERSION
 _SIGS = {
     "mobgs_version": (c_char_p, []),
     "mobgs_abi_version": (c_int, []),
     "mobgs_last_error": (c_char_p, []),
     "mobgs_record_stride": (c_int, [c_int]),
     "mobgs_raster_channels_supported": (c_int, [c_int]),
+    "mobgs_raster_path": (c_int, [c_int, c_int, c_int, P]),
     "mobgs_project_fwd": (c_int, [c_int, c_int, P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float,
                                   P, P, P, P, P, P]),
     "mobgs_project_bwd_scratch_floats": (c_size_t, [c_int, c_int]),

@@ -44,9 +44,36 @@ struct ClassSel {
     // pass is; when it reads 0 the kernel returns at once -- no record is written, any_record stays 0 and the slot
     // reduction then writes exact zeros without reading a slot
     const int32_t* gate = nullptr;
+    // backward passes only (MobgsTuning.static_rows, round 6): rows (flat id % set_n) < static_rows are MoBGS's STATIC
+    // splats -- colour features cat(f_dc, 0.0 * f_t) (/root/reference/scene/gaussian_model.py:244-246), flow channels
+    // identically zero -- whose dead channels the caller neither fills nor wants a gradient for (dead_channels<CD>)
+    int static_rows = 0, set_n = 1;
     __device__ __forceinline__ bool gated_off() const { return gate && *gate == 0; }
     __device__ __forceinline__ bool keeps(int flat_id) const { return sel == 0 || (((flat_id % N) < Ns) == (sel == 1)); }
+    __device__ __forceinline__ bool static_row(int flat_id) const {
+        return static_rows > 0 && (flat_id % set_n) < static_rows;
+    }
 };
+
+// Colour channels [DEAD_FIRST, DEAD_FIRST + dead_channels<CD>) of a STATIC splat's record are structurally zero in the
+// two passes that carry MoBGS's feature layout: CD = 10 = [f_dc(6) | t f_t(3) | depth] (render(),
+// /root/reference/gaussian_renderer/__init__.py:125,201-217: the static rows hold 0.0 * f_t) and CD = 12 = [f_dc(6) |
+// t f_t(3) | flow(2) | depth] (get_flow(), :436-476: a static splat projects to the same pixel at both exposures, its
+// flow is x - x = 0).  fma(0, w, acc) = acc: leaving those FMAs out changes no bit of any other sum; the gradient of the
+// dead channels themselves is multiplied by 0.0 downstream (prep_shared.h: g_s_ft = 0.0f * v_col) and is written as 0.
+constexpr int DEAD_FIRST = 6;
+template <int CD>
+constexpr int dead_channels() { return CD == 10 ? 3 : (CD == 12 ? 5 : 0); }
+// ... and that is CHECKED per staged entry (the record's quarters pass through registers then: 3 / 5 compares per 64
+// entries): an entry of a static row whose dead channels are not all +-0 simply takes the full blend body.
+// -> quarter q (floats 4 q .. 4 q + 3 of the record) holds no non-zero dead channel
+template <int CD>
+__device__ __forceinline__ bool quarter_dead_zero(int q, const float4& v) {
+    if constexpr (CD == 10) return q != 3 || (v.x == 0.f && v.y == 0.f && v.z == 0.f);                 // floats 12..14
+    if constexpr (CD == 12)
+        return q == 3 ? (v.x == 0.f && v.y == 0.f && v.z == 0.f && v.w == 0.f) : (q != 4 || v.x == 0.f);  // 12..16
+    return false;
+}
 
 // offsets / unclamped alpha / alpha of one splat at one pixel from the record's exponent form (common.h,
 // write_splat_record): raw = opacity * exp(-sigma) = exp2(A dx^2 + C dy^2 + B dx dy + L); the same instruction

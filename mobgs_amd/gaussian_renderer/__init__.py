@@ -348,6 +348,8 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     fuse_prep = (coherent is None and not (delta_exposure is not None and get_flow) and _can_fuse_prep(raw, times)
                  and ((not get_static and not get_dynamic) or (FUSE_LAYERS and _R.CLASS_PASSES)))
     sp = None
+    if _R.path_log is not None:   # (tests: which prep path this call takes)
+        _R.path_log.append({"dir": "prep", "D": 0, "fused": bool(fuse_prep)})
     if fuse_prep:
         # (cols: the token the compositing node returns its colour gradient through -- never read as data)
         sp, means, quats, scales, opac = _R.SharedProjection.from_raw(times, raw, viewmat[None], K[None], W, H,
@@ -390,6 +392,9 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
     # The intersection counts are still on their way to the host (speculative binning).  Compositing AND decoding are
     # enqueued before waiting for them, so that the device has the rest of the forward pass queued while the host
     # waits -- on small scenes (tens of thousands of splats) the step is host-bound and this wait was a bubble.
+    # rows [0, Ns) are the static set: colour features cat(f_dc, 0.0 * f_t) (scene/gaussian_model.py:244-246) -- the
+    # backward compositor leaves their three dead channels out (include/mobgs_hip.h MobgsTuning.static_rows)
+    sp.static_rows = Ns
     rebuilds = sp.tl.rebuilds
     sp.tl.defer = True
     try:
@@ -500,6 +505,7 @@ def render_many(viewpoint_cameras, stat_pc, dyn_pc, pipe, bg_color, delta_exposu
     Ks = torch.stack([c.K for c in cams])
     sp = _R.SharedProjection(means, quats, scales, opac, viewmats, Ks, W, H, pack_colors=cols,
                              order=_enum_order(stat_pc, dyn_pc, means, K))
+    sp.static_rows = stat_pc.get_xyz.shape[0]
 
     def composite_and_decode():
         rays = _rays_of_many(cams) if K > 1 else None   # (one image: the single-image call, [3,H,W] out)
@@ -634,6 +640,7 @@ def _flow_mid_state(cam, stat_pc, dyn_pc, dev):
     sp = _R.SharedProjection(mid_m, mid_q, scales, opac, viewmat[None], cam.K[None], W, H,
                              order=_enum_order(stat_pc, dyn_pc, mid_m))
     sp.flow_cols = cols  # the colour features at the mid time (get_flow_many: the call with exposure offset 0)
+    sp.static_rows = stat_pc.get_xyz.shape[0]
     return sp
 
 
@@ -706,6 +713,10 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     # two projections + two tile binnings of the whole set (the reference: 2 explicit projections + 4 rasterizations)
     sp_exp = _R.SharedProjection(exp_m, exp_q, scales, opac, viewmat[None], K[None], W, H,
                                  order=_enum_order(stat_pc, dyn_pc, exp_m))
+    # static rows in the 12-channel pass below: f_t channels 0.0 * f_t, flow channels x_mid - x_exp = 0 exactly (a static
+    # splat projects alike at both exposures; the +g / -g its flow gradient sends through the two identical projections
+    # cancel) -- five dead channels (MobgsTuning.static_rows; verified per entry by the kernel)
+    sp_exp.static_rows = Ns
     sp_mid = _mid if _mid is not None else _shared_mid_state(cam, stat_pc, dyn_pc, dev)
 
     def splat(sp, colors):
@@ -791,6 +802,7 @@ def _get_flow_exposures(cam, stat_pc, dyn_pc, bg_color, deltas, mid):
     means, quats, scales, opac, cols = _prep(stat_pc, dyn_pc, torch.stack([_times(cam, d, dev) for d in deltas]))  # cols [G,N,9]
     sp = _R.SharedProjection(means, quats, scales, opac, viewmat[None].expand(G, 4, 4), cam.K[None].expand(G, 3, 3), W, H,
                              order=_enum_order(stat_pc, dyn_pc, means, G))
+    sp.static_rows = Ns   # (see get_flow)
     bgG = _bgK_cache.setdefault(G, DerivedCache()).get((bg1,), lambda: bg1.expand(G, 9).contiguous())
     bg11 = _bgK_cache.setdefault(("11", G), DerivedCache()).get(
         (bg1,), lambda: torch.cat([bg1, bg1.new_zeros(1, 2)], dim=-1).expand(G, 11).contiguous())

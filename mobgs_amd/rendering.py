@@ -362,17 +362,32 @@ def cotangents_all_zero(tensors) -> bool:
     return int(flag.item()) == 0
 
 
-_gated_copy = [None, None]
+_variant_copies = {}
+# A/B switch of MobgsTuning.static_rows (round 6): 0 = render() / get_flow() never state which rows are static, every
+# entry takes the full blend body (gradients are bit-identical either way except for the sign of the zeros the static
+# rows' f_t receive)
+STATIC_ROWS = os.environ.get("MOBGS_STATIC_ROWS", "1") != "0"
+
+
+def _tuning_variant(gated: bool, static_rows: int = 0):
+    """`tuning` with the zero-cotangent gate on and / or the static row count of the node (both are properties of the
+    node, not of the module); copies are cached per (fields of `tuning`, gate, rows)."""
+    static_rows = int(static_rows) if STATIC_ROWS else 0
+    if not gated and static_rows <= 0:
+        return tuning
+    key = (tuning.heavy_tile_len, tuning.longest_list_hint, tuning.quadrant_culling, tuning.block_walk,
+           tuning.bwd_block_walk, tuning.bwd_mfma, bool(gated), static_rows)
+    t = _variant_copies.get(key)
+    if t is None:
+        if len(_variant_copies) > 64:
+            _variant_copies.clear()
+        t = _variant_copies[key] = tuning.copy(geometry_per_camera=0, gate_zero_cotangent=1 if gated else 0,
+                                               static_rows=max(static_rows, 0))
+    return t
 
 
 def _tuning_gated():
-    """`tuning` with the zero-cotangent gate on (the gate is a property of the node, not of the module); the copy is
-    rebuilt only when a field of `tuning` has changed."""
-    key = (tuning.heavy_tile_len, tuning.longest_list_hint, tuning.quadrant_culling, tuning.block_walk,
-           tuning.bwd_block_walk, tuning.bwd_mfma)
-    if _gated_copy[0] != key:
-        _gated_copy[0], _gated_copy[1] = key, tuning.copy(geometry_per_camera=0, gate_zero_cotangent=1)
-    return _gated_copy[1]
+    return _tuning_variant(True, 0)
 
 
 class StaticCapacity:
@@ -517,6 +532,29 @@ def build_tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Ten
 # --------------------------------------------------------------------------------------------------
 _SUPPORTED = (1, 2, 3, 4, 9, 10, 12, 16, 26)
 
+# Which compositing kernels the passes took (tests only; None = off, the default: nothing is computed).  A test sets
+# `rendering.path_log = []`, runs, and ASSERTS the selection from the entries -- dicts {"dir": "fwd" | "bwd", "D", "n_tiles",
+# "class_filter", "bwd_kernel": "quadrant" | "mfma" | "mfma_team" | "block_walk", "fwd_kernel": "blocks" | "quadrant",
+# "heavy_len", "heavy_tiles" (tiles the schedule composites with four waves: read back from tile_order -- a host sync),
+# "decode": the Sandwich epilogue ran inside the forward compositor, "static_rows"}.  The kernel names come from
+# mobgs_raster_path(), the decision functions the launchers themselves use (include/mobgs_hip.h).
+path_log = None
+_BWD_NAMES = ("quadrant", "mfma", "mfma_team", "block_walk")
+
+
+def _log_path(direction, D, tl, class_filter=False, tn=None, **extra):
+    if path_log is None:
+        return
+    nt = tl.C * tl.tile_w * tl.tile_h
+    bits = _lib_().mobgs_raster_path(int(D), 1 if class_filter else 0, nt, (tn if tn is not None else tuning).ref())
+    heavy = 0
+    if tl.tile_order is not None:
+        order = tl.tile_order
+        heavy = int(((order >= 0) & ((order & (1 << 30)) != 0)).sum().item()) // 4
+    path_log.append(dict(dir=direction, D=int(D), n_tiles=nt, class_filter=bool(class_filter),
+                         bwd_kernel=_BWD_NAMES[bits & 3], fwd_kernel="blocks" if bits & 4 else "quadrant",
+                         heavy_len=bits >> 8, heavy_tiles=heavy, **extra))
+
 
 def _pad_channels(D: int) -> int:
     for s in _SUPPORTED:
@@ -530,10 +568,13 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, extra, backgrounds, radii, tl: TileLists, width, height,
-                packed=None, dec=None):
+                packed=None, dec=None, static_rows=0):
         """dec = (intr, c2w, w1, w2) (detached, float32, contiguous): the Sandwich decoder runs as the kernel's epilogue
         (mobgs_raster_fwd_decode) and the node returns (render, alphas, rgb, depth) -- rgb / depth non-differentiable here:
-        ops.Decode takes them as its precomputed outputs and owns their backward pass."""
+        ops.Decode takes them as its precomputed outputs and owns their backward pass.
+        static_rows = S > 0: the first S splats are the reference's STATIC set (include/mobgs_hip.h
+        MobgsTuning.static_rows: colour channels 6.. structurally zero, their gradient multiplied by 0.0 downstream) --
+        the backward compositor takes the short blend body for their entries and returns zeros for those channels."""
         lib = _lib_()
         C, N = radii.shape
         dev = means2d.device
@@ -594,6 +635,7 @@ class _Rasterize(torch.autograd.Function):
                 # wants to enqueue more work before waiting for the counts sets tl.defer and does this itself.
                 if tl.defer or not tl.resolve():
                     break
+        _log_path("fwd", D, tl, decode=dec is not None)
         ctx.save_for_backward(records, bg, radii, means2d, alphas, last_ids, reach)
         ctx.set_materialize_grads(False)  # an output nothing back-propagates through costs no zero image
         ctx.tl = tl
@@ -601,6 +643,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.meta = (C, N, channels, extra is not None, width, height, colors_per_camera, opac_per_camera)
         ctx.bg_needs_grad = backgrounds is not None and backgrounds.requires_grad
         ctx.gate = _zero_gate[0]
+        ctx.static_rows = int(static_rows) if D in (10, 12) else 0
         if dec is not None:
             ctx.mark_non_differentiable(rgb, dec_depth)
             return render, alphas.unsqueeze(-1), rgb, dec_depth
@@ -618,12 +661,13 @@ class _Rasterize(torch.autograd.Function):
         D = channels + (1 if has_extra else 0)
         stride = records.shape[1]
         if v_render is None and v_alphas is None:
-            return (None,) * 12
+            return (None,) * 13
         if v_render is None:  # only the alpha output was used
             v_render = torch.zeros(C, height, width, D, dtype=torch.float32, device=dev)
         F = _fast.get()
         gated = bool(ctx.gate) and tuning.bwd_block_walk != 1
-        tn = _tuning_gated() if gated else tuning
+        tn = _tuning_variant(gated, ctx.static_rows)
+        _log_path("bwd", D, tl, tn=tn, static_rows=tn.static_rows)
         if F is not None:  # the same body in C++ (csrc/fastpath.cpp)
             st = stream_int()
             with profiler.region("raster_bwd"):
@@ -661,7 +705,7 @@ class _Rasterize(torch.autograd.Function):
         v_bg = None
         if ctx.bg_needs_grad:
             v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
-        return v_means2d, v_conics, v_colors, v_opac, v_extra, v_bg, None, None, None, None, None, None
+        return v_means2d, v_conics, v_colors, v_opac, v_extra, v_bg, None, None, None, None, None, None, None
 
 
 class _RasterizeClassAlpha(torch.autograd.Function):
@@ -880,8 +924,9 @@ class _RasterizeClasses(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, extra, backgrounds, radii, tl: TileLists, width, height, Ns,
-                mask, packed=None):
+                mask, packed=None, static_rows=0):
         lib = _lib_()
+        ctx.static_rows = int(static_rows)
         C, N = radii.shape
         dev = means2d.device
         means2d, conics, colors, opacities, extra = map(f32c, (means2d, conics, colors, opacities, extra))
@@ -920,6 +965,7 @@ class _RasterizeClasses(torch.autograd.Function):
                     if not tl.resolve():
                         break
                 outs[cls] = (render, alphas, last)
+                _log_path("fwd", D, tl, class_filter=True, decode=False)
         saved = [records, bg, radii]
         for cls in (1, 2):
             if cls in outs:
@@ -957,11 +1003,14 @@ class _RasterizeClasses(torch.autograd.Function):
                 v_render = f32c(v_render) if v_render is not None else torch.zeros(C, height, width, D, device=dev)
                 v_alpha = f32c(v_alpha) if v_alpha is not None else None
                 # the two classes own disjoint slots of the one buffer
+                # (the static class IS the reference's static set: its rows' dead channels take the short blend body)
+                tn = _tuning_variant(False, ctx.static_rows if cls == 1 else 0)
+                _log_path("bwd", D, tl, class_filter=True, tn=tn, static_rows=tn.static_rows)
                 check(lib.mobgs_raster_class_bwd(C, N, Ns, cls, D, width, height, ptr(records), ptr(bg), ptr(radii),
                                                  ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(tl.tile_offsets),
                                                  ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(alphas), ptr(last),
                                                  ptr(v_render), ptr(v_alpha), ptr(slots), ptr(reach), None,
-                                                 tuning.ref(), stream()),
+                                                 tn.ref(), stream()),
                       "mobgs_raster_class_bwd")
         v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
         v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
@@ -975,7 +1024,7 @@ class _RasterizeClasses(torch.autograd.Function):
             v_colors = v_colors.sum(0) if C > 1 else v_colors[0]
         if not opac_per_camera:
             v_opac = v_opac.sum(0) if C > 1 else v_opac[0]
-        return v_means2d, v_conics, v_colors, v_opac, v_extra, None, None, None, None, None, None, None, None
+        return v_means2d, v_conics, v_colors, v_opac, v_extra, None, None, None, None, None, None, None, None, None
 
 
 _cap_listed = {}  # workload key -> capacity of the listed-intersection buffers
@@ -1321,6 +1370,7 @@ class SharedProjection:
         self.width, self.height = int(width), int(height)
         self.C, self.N = viewmats.shape[0], means.shape[-2]
         self.opacities = opacities
+        self.static_rows = 0   # set by render() & co: the first rows are the reference's static set (_Rasterize.forward)
         self.tl = TileLists()
         (self.radii, self.means2d, self.depths, self.conics, self.tiles_per_gauss) = _ProjectAndBin.apply(
             means, quats, scales, viewmats, Ks, opacities.detach(), self.tl, self.width, self.height, float(eps2d),
@@ -1341,6 +1391,7 @@ class SharedProjection:
         features exist only inside the packed records).  See _PrepProjectAndBin."""
         self = cls.__new__(cls)
         self.width, self.height = int(width), int(height)
+        self.static_rows = 0
         self.tl = TileLists()
         (means, quats, scales, opac, cols, self.radii, self.means2d, self.depths, self.conics,
          self.tiles_per_gauss) = _PrepProjectAndBin.apply(times, *raw, viewmats, Ks, self.tl, self.width, self.height,
@@ -1368,7 +1419,7 @@ class SharedProjection:
         """"RGB+D" compositing of the whole set: (render [C,H,W,D+1], alphas [C,H,W,1])."""
         return rasterize_to_pixels(self.means2d_main, self.conics, colors, self.opacities, self.radii, self.tl,
                                    self.width, self.height, backgrounds=self._bg(backgrounds), extra=self.depths,
-                                   packed=self._packed_for(colors))
+                                   packed=self._packed_for(colors), static_rows=self.static_rows)
 
     def composite_decode(self, colors, backgrounds, rays, w1, w2):
         """composite() followed by ops.decode(img, alphas, rays, w1, w2, True) -- (img, alphas, rgb [3,H,W] | [C,3,H,W],
@@ -1392,7 +1443,7 @@ class SharedProjection:
         dec = (f32c(intr.detach()), f32c(c2w.detach()), f32c(w1.detach()), f32c(w2.detach()))
         img, alphas, rgb0, depth0 = _Rasterize.apply(self.means2d_main, self.conics, colors, self.opacities, self.depths,
                                                      self._bg(backgrounds), self.radii, self.tl, self.width, self.height,
-                                                     self._packed_for(colors), dec)
+                                                     self._packed_for(colors), dec, self.static_rows)
         lead = (C,) if C > 1 else ()
         feat = img.reshape(*lead, self.height, self.width, 10)
         a2 = alphas.reshape(*lead, self.height, self.width)
@@ -1410,7 +1461,8 @@ class SharedProjection:
         if CLASS_PASSES and not want_all and colors.shape[-1] == 9:
             rs, a_s, rd, a_d = _RasterizeClasses.apply(self.means2d, self.conics, colors, self.opacities, self.depths,
                                                        self._bg(backgrounds), self.radii, self.tl, self.width,
-                                                       self.height, int(Ns), mask, self._packed_for(colors))
+                                                       self.height, int(Ns), mask, self._packed_for(colors),
+                                                       min(int(Ns), self.static_rows))
             return ([None, rs if want_static else None, rd if want_dynamic else None],
                     [None, a_s if want_static else None, a_d if want_dynamic else None])
         m2d_view = self.means2d.view_as(self.means2d)
@@ -1458,16 +1510,17 @@ def rasterize_layers(means, quats, scales, opacities, colors, viewmats, Ks, widt
 
 
 def rasterize_to_pixels(means2d, conics, colors, opacities, radii, tl: TileLists, width, height, backgrounds=None,
-                        extra=None, packed=None):
+                        extra=None, packed=None, static_rows=0):
     """Composite; channel counts without a compiled variant are zero-padded up to the next one.
-    packed: records of exactly these inputs already written by the projection kernel (see SharedProjection)."""
+    packed: records of exactly these inputs already written by the projection kernel (see SharedProjection).
+    static_rows: see _Rasterize.forward (only passes of exactly 10 / 12 total channels honour it)."""
     C = radii.shape[0]
     channels = colors.shape[-1]
     D = channels + (1 if extra is not None else 0)
     Dp = _pad_channels(D)
     if Dp == D:
         return _Rasterize.apply(means2d, conics, colors, opacities, extra, backgrounds, radii, tl, width, height,
-                                packed if extra is not None else None)
+                                packed if extra is not None else None, None, static_rows)
     parts = [colors if colors.dim() == 3 else colors.unsqueeze(0).expand(C, *colors.shape)]
     if extra is not None:
         parts.append(extra.unsqueeze(-1))

@@ -186,3 +186,74 @@ def rasterization_fwd_bwd(means, quats, scales, opacities, colors, viewmats, Ks,
                 "v_colors": None if v_cols is None else (v_cols.sum(0) if colors.ndim == 2 else v_cols),
                 "v_means2d": v_means2d})
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same C routines behind torch.autograd on the CPU: a drop-in for the `rasterization=` argument of
+# oracle/render_torch.render() / get_flow(), so that a FULL-SIZE render() -- prep and Sandwich decoder in plain torch
+# (render_torch), projection / lists / compositing forward and backward in C -- finishes in seconds on the host
+# (tests/test_gpu_fullsize.py: the render()-level oracle of the benchmark's own kernel selection).
+# Test infrastructure like everything in this file.
+# ---------------------------------------------------------------------------------------------------------------------
+def torch_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height, packed=False,
+                        backgrounds=None, render_mode="RGB", **_unused):
+    """gsplat.rendering.rasterization's signature as the reference calls it -> (colors [C,H,W,X], alphas [C,H,W,1],
+    {"radii", "means2d" (autograd non-leaf)}); CPU tensors, differentiable w.r.t. means / quats / scales / opacities /
+    colors / viewmats."""
+    import torch
+
+    W, H = int(width), int(height)
+
+    class _Proj(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means, quats, scales, viewmats):
+            a = [t.detach().numpy() for t in (means, quats, scales, viewmats)]
+            radii, means2d, depths, conics = project_fwd(a[0], a[1], a[2], a[3], Ks.detach().numpy(), W, H)
+            ctx.np = (a, radii, conics)
+            ctx.mark_non_differentiable(*(r := [torch.from_numpy(radii)]))
+            return r[0], torch.from_numpy(means2d), torch.from_numpy(depths), torch.from_numpy(conics)
+
+        @staticmethod
+        def backward(ctx, _vr, v_m2d, v_dep, v_con):
+            a, radii, conics = ctx.np
+            C, N = radii.shape
+            z = lambda g, shape: np.zeros(shape, np.float32) if g is None else g.numpy()  # noqa: E731
+            vm, vq, vs, vv = project_bwd(a[0], a[1], a[2], a[3], Ks.detach().numpy(), W, H, radii, conics,
+                                         z(v_m2d, (C, N, 2)), z(v_dep, (C, N)), z(v_con, (C, N, 3)))
+            return tuple(torch.from_numpy(x) for x in (vm, vq, vs, vv))
+
+    class _Raster(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means2d, conics, cols, opac, radii, depths):
+            C, N = radii.shape
+            _, _, flat, offs = isect(means2d.detach().numpy(), radii.numpy(), depths.detach().numpy(), W, H)
+            bg = None if backgrounds is None else backgrounds.detach().numpy()
+            if bg is not None and bg.shape[-1] < cols.shape[-1]:
+                bg = np.concatenate([bg, np.zeros((C, cols.shape[-1] - bg.shape[-1]), np.float32)], -1)
+            a = [np.ascontiguousarray(t.detach().numpy(), np.float32) for t in (means2d, conics, cols, opac)]
+            render, alphas, last = raster_fwd(a[0], a[1], a[2], a[3], bg, offs, flat, W, H)
+            ctx.np = (a, bg, offs, flat, alphas, last)
+            return torch.from_numpy(render), torch.from_numpy(alphas)
+
+        @staticmethod
+        def backward(ctx, v_render, v_alphas):
+            a, bg, offs, flat, alphas, last = ctx.np
+            C, _, D = a[2].shape
+            vr = np.zeros((C, H, W, D), np.float32) if v_render is None else v_render.contiguous().numpy()
+            va = np.zeros((C, H, W), np.float32) if v_alphas is None else v_alphas.contiguous().numpy()
+            g = raster_bwd(a[0], a[1], a[2], a[3], bg, offs, flat, W, H, alphas, last, vr, va)
+            return tuple(torch.from_numpy(x) for x in g) + (None, None)
+
+    C, N = viewmats.shape[0], means.shape[0]
+    radii, means2d, depths, conics = _Proj.apply(means, quats, scales, viewmats)
+    cols = colors.expand(C, N, colors.shape[-1]) if colors.dim() == 2 else colors
+    with_depth = render_mode in ("RGB+D", "RGB+ED")
+    if with_depth:
+        cols = torch.cat([cols, depths[..., None]], -1)
+    elif render_mode in ("D", "ED"):
+        cols = depths[..., None]
+    opac = opacities.expand(C, N) if opacities.dim() == 1 else opacities
+    render, alphas = _Raster.apply(means2d, conics, cols.contiguous(), opac.contiguous(), radii, depths)
+    if render_mode in ("ED", "RGB+ED"):
+        render = torch.cat([render[..., :-1], render[..., -1:] / alphas[..., None].clamp(min=1e-10)], -1)
+    return render, alphas[..., None], {"radii": radii, "means2d": means2d, "depths": depths, "conics": conics}

@@ -40,7 +40,8 @@ def blce_mode(request):
 
 
 @pytest.mark.parametrize("blce_mode", ["fused", "graph"], indirect=True)
-def test_blurry_view_k9_blce_matches_reference_fixture(hip_device, blce_mode):
+def test_blurry_view_k9_blce_matches_reference_fixture(hip_device, blce_mode, kernel_selection):
+    """(also under the benchmark's kernel selection: conftest.kernel_selection)"""
     from mobgs_amd import blce as B
     from mobgs_amd.deblur import render_blurry_batch
     from mobgs_amd.distributed import SubframeShard
@@ -99,6 +100,7 @@ def test_blurry_view_k9_blce_matches_reference_fixture(hip_device, blce_mode):
             close(p.grad, ref, 5e-3, 5e-4 * float(np.abs(ref).max()), f"BLCE grad {k}")
             n += 1
     assert n >= 20
+    kernel_selection.check()
 
 
 # ---------------------------------------------------------------------------------------------------------------------

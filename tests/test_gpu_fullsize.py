@@ -184,3 +184,120 @@ def test_800k_gaussians_config5_scale(hip_device):
     (out["render"].sum() + out["depth"].sum()).backward()
     assert torch.isfinite(out["render"]).all() and torch.isfinite(stat._xyz.grad).all()
     assert int((out["radii"] > 0).sum()) > 700_000
+
+
+def test_fullsize_lean_render_against_the_oracle_chain(hip_device, capsys):
+    """the BENCHMARK's call -- lean render() forward + backward at 1352x1014, 200 k static + 100 k
+    dynamic splats, Morton-sorted rows, a non-trivial pose with its gradient, the library's DEFAULT kernel selection
+    for this grid (asserted: project_fwd<PREP> / project_bwd<PREPB>, one wave per tile raster_fwd_blocks<10, ., DECODE>,
+    quadrant raster_bwd_kernel<10> with the static-row blend body) -- against a render()-level oracle on the host:
+    oracle/render_torch.render (spline, activations, colour features and the Sandwich decoder in plain torch, restating
+    /root/reference/gaussian_renderer/__init__.py:59-316 and helper_model.py:19-28) over oracle/gsplat_cpu.c
+    (projection, lists, compositing both ways in C).  Decoded image, expected depth, radii, every leaf gradient, the
+    decoder-weight gradients, the pose gradient and viewspace_points.grad; blend-flip-aware criteria as everywhere."""
+    import bench as B
+    from helpers import decoded_flip_bound
+    from mobgs_amd import _fast, rendering
+    from mobgs_amd.camera import PinholeCamera
+    from mobgs_amd.gaussian_model import GaussianParams
+    from mobgs_amd.gaussian_renderer import render
+    from mobgs_amd.helper_model import Sandwich
+    from oracle import gsplat_cpu as Cc
+    from oracle import render_torch as R
+    dev = hip_device
+    ns, nd = 200_000, 100_000
+    scam, _, stat, dyn, _ = B.build_scene(dev, ns, nd, W, H, seed=0)
+    pose = B.view_pose(1)
+    g = torch.Generator().manual_seed(77)
+    v_img, v_dep = torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g)
+
+    def params_on(pc, device, dec, dynamic):
+        keys = ["xyz", "scaling", "rotation", "opacity", "features_dc", "features_t"]
+        base = {k: getattr(pc, "_" + k).detach().cpu() for k in keys if not (dynamic and k == "xyz")}
+        if dynamic:
+            base["xyz"] = pc.get_xyz.detach().cpu()
+            extra = {"omega": pc._omega.detach().cpu(), "trbf_center": pc.get_trbfcenter.detach().cpu(),
+                     "control_xyz": pc.get_control_xyz.detach().cpu(),
+                     "current_control_num": pc.current_control_num.detach().cpu()}
+            return GaussianParams(base, extra, dec, device, requires_grad=True)
+        return GaussianParams(base, None, dec, device, requires_grad=True)
+
+    res = {}
+    rendering.path_log = []
+    try:
+        for name, device in (("hip", dev), ("oracle", torch.device("cpu"))):
+            dec = Sandwich(9, 3)
+            dec.load_state_dict({k: v.detach().cpu() for k, v in dyn.rgbdecoder.state_dict().items()})
+            dec = dec.to(device)
+            st, dy = params_on(stat, device, dec, False), params_on(dyn, device, dec, True)
+            if name == "hip":
+                st.rows_coherent, dy.rows_coherent = stat.rows_coherent, dyn.rows_coherent   # (the bench scene's row order)
+            cam = PinholeCamera(W, H, scam.K, pose, scam.time, scam.max_time, device=device)
+            cam.world_view_transform.requires_grad_(True)
+            bg = torch.zeros(9, device=device)
+            if name == "hip":
+                out = render(cam, st, dy, None, bg)   # frame 0: two-pass lists
+                out = render(cam, st, dy, None, bg)   # the steady state the benchmark times: single-pass lists
+            else:
+                out = R.render(cam, st, dy, bg, rasterization=Cc.torch_rasterization)
+            ((out["render"] * v_img.to(device)).sum() + (out["depth"].reshape(1, H, W) * v_dep.to(device)).sum()).backward()
+            leaves = {"s_" + k: getattr(st, "_" + k).grad for k in ("xyz", "scaling", "rotation", "opacity", "features_dc",
+                                                                    "features_t")}
+            leaves.update({"d_" + k: getattr(dy, "_" + k).grad for k in ("scaling", "rotation", "opacity", "features_dc",
+                                                                         "features_t", "omega")})
+            leaves["d_control_xyz"] = dy.control_xyz.grad
+            leaves["w1"], leaves["w2"] = dec.mlp1.weight.grad, dec.mlp2.weight.grad
+            leaves["pose"] = cam.world_view_transform.grad
+            leaves["viewspace"] = out["viewspace_points"].grad
+            res[name] = (out["render"].detach().cpu(), out["depth"].detach().cpu().reshape(1, H, W), out["radii"].cpu(),
+                         {k: (None if v is None else v.detach().cpu()) for k, v in leaves.items()},
+                         float(R._dyn_state(dy, cam.time, cam.max_time, None)[3].detach().abs().max()) if name == "oracle"
+                         else 0.0, dec)
+        log = list(rendering.path_log)
+    finally:
+        rendering.path_log = None
+    # the kernels this ran on
+    e_f = [e for e in log if e["dir"] == "fwd" and e["D"] == 10][-1]
+    e_b = [e for e in log if e["dir"] == "bwd" and e["D"] == 10][-1]
+    assert e_f["n_tiles"] == 85 * 64 and e_f["fwd_kernel"] == "blocks" and e_b["bwd_kernel"] == "quadrant", (e_f, e_b)
+    assert e_f["heavy_tiles"] <= e_f["n_tiles"] // 8
+    if _fast.get() is not None:
+        assert e_f["decode"] and [e for e in log if e["dir"] == "prep"][-1]["fused"] and rendering.fused_calls[0] > 0
+    if rendering.STATIC_ROWS:
+        assert e_b["static_rows"] == ns
+    hip, ora = res["hip"], res["oracle"]
+    differ = int((hip[2] != ora[2]).sum())
+    assert differ == 0, f"radii differing from the oracle chain: {differ} of {ns + nd}"
+    cmax = max(ora[4], float(stat._features_dc.detach().abs().max()))
+    fb = decoded_flip_bound(ora[5], cmax)
+    nbad = int(((hip[0] - ora[0]).abs() > 3e-5).sum())
+    close(hip[0], ora[0], 0, 3e-5, "decoded image", flip_frac=2e-4, flip_atol=fb)
+    dref = ora[1]
+    vis = float(dref.max() - dref.min())
+    close(hip[1], dref, 0, 3e-5 * max(1.0, float(dref.abs().max())), "expected depth", flip_frac=2e-4,
+          flip_atol=2.0 * (1.001 / 255.0) * vis / (1.0 / 255.0))
+    target = (ora[0] + 0.05 * torch.randn(ora[0].shape, generator=g)).clamp(0, 1)
+    assert abs(psnr(hip[0], target) - psnr(ora[0], target)) <= 1e-4
+    worst = {}
+    for k, ref in ora[3].items():
+        got = hip[3][k]
+        if ref is None:
+            assert got is None or float(got.abs().max()) == 0.0, k
+            continue
+        if k == "s_features_t":   # 0.0 * f_t: the gradient is 0.0 * v (exact zeros either way)
+            assert float(ref.abs().max()) == 0.0 and float(got.abs().max()) == 0.0
+            continue
+        sc = float(ref.abs().max())
+        worst[k] = float((got - ref).abs().max()) / max(sc, 1e-30)
+        # the full-size operator test's criterion: rtol 1e-3 + 1e-4 of the maximum; a flipped blend decision moves the
+        # gradients of ONE pixel's splats: 1e-5 of the entries up to 5e-3 of the maximum.  Sums over all pixels (decoder
+        # weights, pose: 16 / 72 / 18 numbers each fed by 1.4 M pixels) get 2e-4 of the maximum
+        if k in ("w1", "w2", "pose"):
+            close(got, ref, 1e-3, 2e-4 * sc, f"grad[{k}]")
+        else:
+            close(got, ref, 1e-3, 1e-4 * sc, f"grad[{k}]", flip_frac=1e-5, flip_atol=5e-3 * sc)
+    with capsys.disabled():
+        print(f"\n[fullsize render()] kernels: {e_f['fwd_kernel']} fwd (decode={e_f['decode']}), {e_b['bwd_kernel']} bwd, "
+              f"static_rows={e_b.get('static_rows')}, heavy tiles {e_f['heavy_tiles']} of {e_f['n_tiles']}; image elements "
+              f"beyond 3e-5: {nbad} of {hip[0].numel()}; largest gradient error / max: "
+              + ", ".join(f"{k} {v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]))

@@ -13,7 +13,11 @@ IMG_KEYS = ("render", "s_render", "d_render", "d_alpha", "s_alpha", "depth", "d_
 
 
 @pytest.mark.parametrize("name", ["render_lean", "render_train", "render_train_delta_flow"])
-def test_render_matches_reference_fixture(hip_device, name):
+def test_render_matches_reference_fixture(hip_device, name, kernel_selection):
+    """Twice: under the library's default selection for the fixture's small grid (four waves per tile, matrix-pipe
+    backward) and under the BENCHMARK's selection (conftest.kernel_selection "headline": one wave per tile
+    raster_fwd_blocks<10, ., DECODE> with the decoder epilogue, quadrant raster_bwd_kernel<10> with the static-row blend
+    body, project_fwd<PREP> / project_bwd<PREPB>) -- asserted from rendering.path_log, not assumed."""
     from mobgs_amd.gaussian_renderer import render
     fx = load(name)
     cam, stat, dyn, bg, w2c = scene_from_fixture(fx, device=hip_device)
@@ -90,9 +94,18 @@ def test_render_matches_reference_fixture(hip_device, name):
     ref = fx["grad_viewspace_points"]
     sc = float(np.abs(ref).max())
     close(out["viewspace_points"].grad, ref, 1e-3, 1e-4 * sc, "viewspace_points.grad", flip_frac=1e-5, flip_atol=5e-3 * sc)
+    ps = kernel_selection.check()
+    from mobgs_amd import _fast, rendering
+    if _fast.get() is not None and not (has_delta and get_flow):
+        # the whole-set pass: prep inside the projection kernels, decoder inside the forward compositor
+        assert any(e.get("decode") for e in ps if e["dir"] == "fwd" and not e["class_filter"]), ps
+        assert [e for e in rendering.path_log if e["dir"] == "prep"][-1]["fused"], "fused prep -> project path not taken"
+    if rendering.STATIC_ROWS:
+        ns = stat.get_xyz.shape[0]
+        assert any(e["dir"] == "bwd" and e.get("static_rows") == ns for e in ps), ps
 
 
-def test_get_flow_matches_reference_fixture(hip_device):
+def test_get_flow_matches_reference_fixture(hip_device, kernel_selection):
     from mobgs_amd.camera import PinholeCamera
     from mobgs_amd.gaussian_renderer import get_flow, get_flow_static
     fx = load("get_flow")
@@ -116,16 +129,20 @@ def test_get_flow_matches_reference_fixture(hip_device):
     fmax = float(np.abs(fx["out_static_flow_2d"]).max())
     close(fimg, fx["out_static_flow_img"], 1e-5, 2e-4, "static flow image", flip_frac=2e-4,
           flip_atol=2.0 * (1.001 / 255.0) * 2.0 * fmax)  # one blend step of a splatted per-splat flow <= fmax
+    kernel_selection.check(need_bwd=False)
 
 
-def test_get_flow_gradients_match_reference_fixture(hip_device):
+def test_get_flow_gradients_match_reference_fixture(hip_device, kernel_selection):
     """get_flow() / get_flow_static() forward AND backward against the reference's own autograd result (the only
-    reference check the 12-channel compositor backward, raster_bwd<12>, gets)."""
+    reference check the 12-channel compositor backward, raster_bwd<12>, gets) -- under both kernel selections
+    (conftest.kernel_selection: "headline" = one wave per tile, quadrant backward with the static-row blend body)."""
     from test_oracle_cpu import _flow_grad_check
     from mobgs_amd.gaussian_renderer import get_flow, get_flow_static
     _flow_grad_check(load("get_flow_grad"), lambda cam, s, d, bg, dl: get_flow(cam, s, d, None, bg, delta_exposure=dl),
                      lambda a, b, c, s, d, bg: get_flow_static(a, b, c, s, d, None, bg), hip_device, 2e-3, 2e-4,
                      flip={"flip_frac": 2e-4, "flip_atol": "derived"})
+    ps = kernel_selection.check()
+    assert any(e["D"] == 12 and e["dir"] == "bwd" for e in ps), ps
 
 
 def test_hermite_wrapper_matches_reference_fixture(hip_device):
