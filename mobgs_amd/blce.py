@@ -321,7 +321,8 @@ class blceKernel(nn.Module):
         self.model = BLCE(num_views=num_views, view_dim=view_dim, num_warp=num_warp, method=method, adjoint=adjoint)
         groups = [{"params": list(self.model.get_params()), "lr": 1e-4, "name": "posenet"},
                   {"params": [self.model.exposure_time_expo], "lr": 1e-1, "name": "exposure_time_expo"}]
-        self.optimizer = torch.optim.Adam(groups, lr=1e-4)
+        from .optim import FusedAdam
+        self.optimizer = FusedAdam(groups, lr=1e-4)
         self.lr_factor = 0.01 ** (1 / iteration) if iteration else 1.0
         # how a warped camera object is built; replace with a factory creating the caller's own Camera class
         self.camera_factory: Callable = WarpedCamera

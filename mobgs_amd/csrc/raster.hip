@@ -697,6 +697,45 @@ __device__ __forceinline__ float wave_reduce_pair(float e0, float e1) {
 // accumulated; unused -- selecting the variant per entry makes the compiler shuffle the 16 sums between two
 // register sets, which costs more than the zero fill it saves).
 // tvab = Tf * (v_alpha_out - <background, v_out>): both terms enter v_alpha as ra * Tf * (...)
+// An evaluation for the quadrant backward that was BUILT, MEASURED AND NOT KEPT (round 6; -DMOBGS_BWD_CLAMPFREE_EVAL): raster_bwd<10>
+// 442.4 / 443.1 us with the plain evaluation against 460.5 / 458.5 us with this one, alternating runs on one box
+// (profiles/r06/ab_clampfree_eval.txt) -- the asm statement needs `alpha` and `raw` in two registers (a v_mov per
+// quadrant that the plain form does not have), clobbers VCC in the middle of the compare chain and is a scheduling
+// barrier between v_exp_f32 and its consumers: two half-rate instructions saved, more than that lost.  Kept as the A/B
+// arm and because tests/test_gpu_clamp_flag.py (opacities around 0.999 against the C oracle) came with it.
+// The idea: the clamp alpha = min(0.999, raw) and the test "the clamp is not active"
+// (raw <= 0.999: else alpha has zero slope) can only matter for an entry whose OPACITY exceeds 0.999 -- raw = opacity *
+// exp(-sigma) <= opacity wherever the pair passes (sigma >= 0) -- and the opacity is a property of the entry, wave-uniform.
+// `maybe_clamped` (an SGPR: L = log2(opacity) >= CLAMP_L_MIN, decided when the entry is staged) sends such entries through
+// three instructions behind a scalar branch; every other entry -- all but a handful of a scene -- skips v_min, v_cmp and the
+// mask AND of every evaluated quadrant (2 half-rate VALU of ~51): alpha = raw and live = pass hold EXACTLY there, so every
+// gradient is bit-identical.  -> e.raw is "opacity * visibility where alpha has a slope, else 0".
+// CLAMP_L_MIN = log2(0.999) - 1e-3: far more than the 1 ulp of v_exp_f32 below log2(0.999).
+constexpr float CLAMP_L_MIN = -0.0014434f - 1e-3f;
+__device__ __forceinline__ Eval eval_splat_bwd(float gx, float gy, float A, float B, float C, float L, float px, float py,
+                                               int maybe_clamped) {
+    Eval e;
+    e.dx = gx - px;
+    e.dy = gy - py;
+    float s = __fmaf_rn(A * e.dx, e.dx, L);
+    s = __fmaf_rn(C * e.dy, e.dy, s);
+    s = __fmaf_rn(B * e.dx, e.dy, s);
+    e.raw = __builtin_amdgcn_exp2f(s);
+    e.alpha = e.raw;
+    asm volatile(
+        "s_cmp_eq_u32 %[mc], 0\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "v_cmp_ge_f32 vcc, 0x3f7fbe77, %[raw]\n\t"       // 0.999 >= raw: the clamp is not active
+        "v_min_f32 %[a], 0x3f7fbe77, %[a]\n\t"
+        "v_cndmask_b32 %[raw], 0, %[raw], vcc\n"
+        "1:"
+        : [a] "+v"(e.alpha), [raw] "+v"(e.raw)
+        : [mc] "s"(maybe_clamped)
+        : "vcc", "scc");
+    e.pass = !(s > L || e.alpha < ALPHA_MIN);
+    return e;
+}
+
 // SPARSE (round 6; raster_shared.h dead_channels<CD>): `skip_dead` (wave-uniform, an SGPR) says that the entry is a static
 // splat whose dead channels are exactly zero and whose gradient nobody wants.  Their two FMAs per channel and pair then sit
 // behind ONE scalar branch inside a single asm statement -- the compiler sees one body with one register assignment
@@ -704,7 +743,8 @@ __device__ __forceinline__ float wave_reduce_pair(float e0, float e1) {
 // bodies' assignments with ~20 copies per quadrant exit and spilled 16 registers: raster_bwd<10> 456 -> 522 us).  The FMAs
 // keep their place in the dot chain (c = 0..5, [6..], 9), so a dense entry computes exactly what it did, and for a
 // skipped one fma(0, v, dot) = dot: every sum is unchanged bit for bit, the dead sums stay at their cleared zeros.
-template <int CD, int RS, int NVP, bool FIRST, bool SPARSE = false>
+// RAW0: `ev` comes from eval_splat_bwd (ev.raw is already 0 where the clamp is active): live = pass.
+template <int CD, int RS, int NVP, bool FIRST, bool SPARSE = false, bool RAW0 = false>
 __device__ __forceinline__ void blend_bwd(const float (&rec)[RS], const Eval& ev, bool pass, float& T, float& behind,
                                           float tvab, const float (&vo)[CD], float (&g)[NVP], int skip_dead = 0) {
     auto acc = [](float& dst, float a, float b) { dst = FIRST ? a * b : __fmaf_rn(a, b, dst); };
@@ -768,7 +808,7 @@ __device__ __forceinline__ void blend_bwd(const float (&rec)[RS], const Eval& ev
     }
     const float v_alpha = __fmaf_rn(T, dot, ra * (tvab - behind));
     const float ov = ev.raw;   // opacity * visibility, before the clamp
-    const bool live = pass && ov <= ALPHA_MAX;  // the clamp at 0.999 has zero slope
+    const bool live = RAW0 ? pass : (pass && ov <= ALPHA_MAX);  // the clamp at 0.999 has zero slope
     const float v_sigma = live ? -ov * v_alpha : 0.f;
     // Geometry terms as RAW sums: sum v_sigma dx, sum v_sigma dy, sum v_sigma dx^2, sum v_sigma dx dy, sum v_sigma dy^2.
     // The conic is a constant of the SPLAT, so v_xy = (ca A + cb B, cb A + cc B) and the factor 1/2 of the conic's
@@ -942,7 +982,8 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                     slab[wv][pos][q] = v;
                     if constexpr (HAS_SPARSE) dead_zero = dead_zero && quarter_dead_zero<CD>(q, v);
                 }
-                const unsigned sparse_bit = dead_zero ? 16u : 0u;
+                // bit 5: the opacity may reach the 0.999 clamp (eval_splat_bwd)
+                const unsigned sparse_bit = (dead_zero ? 16u : 0u) | (r1.y >= CLAMP_L_MIN ? 32u : 0u);
                 // the forward pass left the masks of these very lists behind (isect_reach); else recompute
                 sh.reach_of[wv][pos] = sparse_bit |
                                        (isect_reach ? (unsigned)isect_reach[hi - lane]
@@ -959,9 +1000,11 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
         // ~40 % of the (entry, quadrant) pairs of a typical list are out of reach and are never evaluated
         unsigned long long reach[PPL];
         unsigned long long sparse = 0ull;   // batch entries that take the short blend body (wave-uniform)
+        unsigned long long clampy;          // ... whose opacity may reach the clamp
         {
             const unsigned rm = lane < n ? sh.reach_of[wv][lane] : 0u;
             if constexpr (HAS_SPARSE) sparse = __builtin_amdgcn_ballot_w64((rm & 16u) != 0u);
+            clampy = __builtin_amdgcn_ballot_w64((rm & 32u) != 0u);
             const int my_idx = FILTER ? (lane < n ? sh.idx_of[wv][lane] : 0x7fffffff) : hi - lane;
 #pragma unroll
             for (int k = 0; k < PPL; ++k)
@@ -1032,6 +1075,7 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
             bool contributed = false;  // wave-uniform
             // a static entry with its dead channels at zero: their FMAs are jumped over (blend_bwd, SPARSE)
             const int skip_dead = HAS_SPARSE ? (int)((sparse >> j) & 1ull) : 0;
+            const int maybe_clamped = (int)((clampy >> j) & 1ull);
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
                 // one 8x8 quadrant: skipped as a whole when the splat cannot reach it or none of its pixels blends
@@ -1039,10 +1083,19 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                 // standing in for "this pixel does not blend it" -- T, behind and the sums then stay exactly as
                 // they were (x * 1, + 0)
                 if (!((reach[k] >> j) & 1ull)) continue;
+#ifdef MOBGS_BWD_CLAMPFREE_EVAL   // A/B arm, measured SLOWER and not the default (eval_splat_bwd): scripts/ab.sh build
+                                  // clampfree raster.hip -DMOBGS_BWD_CLAMPFREE_EVAL
+                Eval ev = eval_splat_bwd(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px[k], py[k], maybe_clamped);
+                constexpr bool RAW0 = true;
+#else
                 Eval ev = eval_splat(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], px[k], py[k]);
+                constexpr bool RAW0 = false;
+                (void)maybe_clamped;
+#endif
                 const bool pass = ev.pass && (idx <= binf[k]);
                 if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
-                blend_bwd<CD, RS, NVP, false, HAS_SPARSE>(rec, ev, pass, T[k], behind[k], tvab[k], vo[k], g, skip_dead);
+                blend_bwd<CD, RS, NVP, false, HAS_SPARSE, RAW0>(rec, ev, pass, T[k], behind[k], tvab[k], vo[k], g,
+                                                                skip_dead);
                 contributed = true;
             }
             if (!contributed) continue;

@@ -143,7 +143,8 @@ class TrainableGaussians(GaussianParams):
         groups = [{"params": [getattr(self, attr)], "lr": _LR[g](training_args, scale), "name": g}
                   for g, attr in GROUPS]
         groups.append({"params": list(self.rgbdecoder.parameters()), "lr": training_args.rgb_lr, "name": "decoder"})
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        from .optim import FusedAdam   # torch.optim.Adam whose step() is ONE launch (the caller's loop stays unchanged)
+        self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
 
     def adopt_optimizer_state(self):
         """Move the Adam moments torch allocated on the first step() into table fields (so that they are resized with
@@ -205,6 +206,8 @@ class TrainableGaussians(GaussianParams):
     def _rebuild(self, index: torch.Tensor, reset_stats: bool):
         """Table := rows `index` (int32; negative = NEW copy of row -(i+1)) of the current table."""
         self.rows_coherent = -1
+        from . import gaussian_renderer as _GR
+        _GR.parameters_changed()   # (rows move in place: no version counter sees it -- ADVICE r5)
         if self.optimizer is not None:
             self.adopt_optimizer_state()
         n_out = int(index.shape[0])

@@ -80,6 +80,8 @@ class GaussianParams:
                 if m is not None:
                     m.data = m.data[order]
                     m.grad = None
+        from . import gaussian_renderer as _GR
+        _GR.parameters_changed()   # (.data moved in place: caches keyed on Tensor._version must be told)
         self.rows_coherent = int(order.numel())
         return order
 

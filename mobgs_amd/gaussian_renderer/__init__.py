@@ -656,8 +656,21 @@ _mid_cache = {}
 mid_cache_stats = {"hits": 0, "misses": 0}
 
 
+_param_epoch = [0]
+
+
 def invalidate_flow_cache():
     _mid_cache.clear()
+
+
+def parameters_changed():
+    """Called by everything in this package that writes Gaussian parameters WITHOUT moving Tensor._version -- the fused
+    Adam kernel (optim.fused_adam_step), in-place row permutations / densification surgery (GaussianParams.spatial_sort_,
+    densify.TrainableGaussians._rebuild) -- so that state cached across calls (the shared mid-exposure projection of
+    get_flow) is never reused over new values.  Foreign `.data` writes: call it (or invalidate_flow_cache())
+    yourself, or set MOBGS_FLOW_MID_CACHE=0."""
+    _param_epoch[0] += 1
+    _mid_cache.clear()   # (also releases the projection graph and arenas the entry pins)
 
 
 def _sig(t):
@@ -670,7 +683,7 @@ def _mid_signature(cam, stat_pc, dyn_pc):
           dyn_pc._opacity, dyn_pc._features_dc, dyn_pc._features_t, dyn_pc.get_trbfcenter, cam.world_view_transform,
           cam.K, getattr(cam, "static_times", None))
     return tuple(_sig(t) for t in ts) + (float(cam.time), float(cam.max_time), int(cam.image_width),
-                                         int(cam.image_height), torch.is_grad_enabled())
+                                         int(cam.image_height), torch.is_grad_enabled(), _param_epoch[0])
 
 
 def _shared_mid_state(cam, stat_pc, dyn_pc, dev):

@@ -82,9 +82,37 @@ def fused_adam_step(optimizers: Iterable[torch.optim.Optimizer]) -> int:
             finally:
                 for p, g in hidden:
                     p.grad = g
+    if batches:
+        # the kernel writes the parameters through raw pointers: Tensor._version does not move, which is what render-side
+        # caches key on (gaussian_renderer._shared_mid_state: ADVICE r5) -- tell them
+        from . import gaussian_renderer as _GR
+        _GR.parameters_changed()
     for (b1, b2, eps), descs in batches.items():
         for i in range(0, len(descs), 64):
             chunk = descs[i:i + 64]
             arr = (_AdamTensor * len(chunk))(*chunk)
             check(lib.mobgs_adam_step(len(chunk), arr, b1, b2, eps, stream()), "mobgs_adam_step")
     return fused
+
+
+class FusedAdam(torch.optim.Adam):
+    """torch.optim.Adam whose step() is the one-launch kernel above: what the modules of this package that stand in for
+    the reference's own (densify.TrainableGaussians for scene/gaussian_model.py GaussianModel.training_setup, :598-617;
+    blce.blceKernel for scene/blce.py) hand to an UNCHANGED training loop -- /root/reference/train.py:790-807 calls
+    `optimizer.step()` on whatever training_setup() created.  Same update, same state tensors
+    (`exp_avg`, `exp_avg_sq`, `step`), state_dict()-compatible; anything the kernel does not cover (closure, amsgrad, weight
+    decay, non-fp32 / CPU tensors) goes through torch's own step.  MOBGS_FUSED_ADAM=0: plain torch.optim.Adam.step()."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import os
+        if closure is not None or os.environ.get("MOBGS_FUSED_ADAM", "1") == "0":
+            return super().step(closure)
+        # (fused_adam_step falls back to torch's step for the tensors it cannot take: reach it through the base class,
+        # not through this override)
+        real, self.step = self.step, super().step
+        try:
+            fused_adam_step([self])
+        finally:
+            self.step = real
+        return None

@@ -280,7 +280,10 @@ fused_calls = [0]    # binning calls that took the single-pass path (diagnostics
 # FUSED_ARENA_BYTES take the two-pass path, as does the synchronous rebuild after an overflow.  Outputs are identical.
 FUSED_LISTS = os.environ.get("MOBGS_FUSED_LISTS", "1") != "0"
 SEG_SLACK = 1.3
-FUSED_ARENA_BYTES = 2 << 30
+# cap of the single-pass key arena (nt x 8 copies x seg_stride x 8 bytes: ~145 MB for one 1352x1014 camera, ~1.3 GB for
+# an 8-camera batch); beyond it the call takes the two-pass path (cap_listed x 8 bytes).  MOBGS_FUSED_ARENA_MB overrides
+# (peak memory had no knob short of switching the path off)
+FUSED_ARENA_BYTES = int(float(os.environ.get("MOBGS_FUSED_ARENA_MB", "2048")) * (1 << 20))
 _FUSED_COPIES = 8  # counter copies of the binning kernel (csrc/isect.hip TC_COPIES)
 
 
@@ -290,13 +293,34 @@ def _note_longest(key, max_len):
     _len_hint[key] = max(int(max_len), int(_len_hint.get(key, 0) * 0.95))
 
 
-def _fused_seg_stride(len_hint, C, N, nt, cap_box) -> int:
-    """Key-segment capacity per tile for the single-pass path, or 0 = use the two-pass path."""
+_seg_sticky = {}  # workload key -> the key-segment stride in use (see _fused_seg_stride)
+
+
+def _fused_seg_stride(len_hint, C, N, nt, cap_box, key=None) -> int:
+    """Key-segment capacity per tile for the single-pass path, or 0 = use the two-pass path.
+    The stride is STICKY per workload: the hint follows the longest list of the previous frames (it breathes by a few
+    per cent from view to view), and an arena whose size changes with it defeats the caching allocator -- a block of a
+    slightly larger size than any cached one is a fresh hipMalloc, which synchronises the device: at 1352x1014 the
+    8-camera batches' 1.3-GB arenas grew twice in the first iterations of a training run, one of them inside the driver's
+    three timed iterations (BENCH_r05: 61.7 ms mean against a 48.3 ms median; VERDICT r5 item 4, found with
+    scripts/r06/train_iter_probe.py).  A needed stride within [prev / 2, prev] keeps `prev`; a larger one grows with 25 %
+    headroom; only a workload that shrank to less than half gives memory back."""
     if not FUSED_LISTS or N <= 0 or len_hint <= 0 or cap_box < 4 * C * N + 2:
         return 0
     stride = max(64, (int(len_hint * SEG_SLACK) + 15) // 16 * 16)
-    if stride > _lib_().mobgs_fused_max_seg_stride() or nt * _FUSED_COPIES * stride * 8 > FUSED_ARENA_BYTES:
+    limit = _lib_().mobgs_fused_max_seg_stride()
+    if key is not None:
+        prev = _seg_sticky.get(key, 0)
+        if prev >= stride > prev // 2:
+            stride = prev
+        else:
+            grown = (int(stride * 1.25) + 15) // 16 * 16 if prev else stride
+            if grown <= limit and nt * _FUSED_COPIES * grown * 8 <= FUSED_ARENA_BYTES:
+                stride = grown
+    if stride > limit or nt * _FUSED_COPIES * stride * 8 > FUSED_ARENA_BYTES:
         return 0
+    if key is not None:
+        _seg_sticky[key] = stride
     return stride
 _tile_culling = True
 # Caller-side policy handed to the library with every call (include/mobgs_hip.h MobgsTuning; the library itself keeps
@@ -556,6 +580,14 @@ def _log_path(direction, D, tl, class_filter=False, tn=None, **extra):
                          heavy_len=bits >> 8, heavy_tiles=heavy, **extra))
 
 
+def _refuse_token(colors, packed, who):
+    """The fused prep path hands a colour TOKEN through render() (SharedProjection.from_raw): never-written storage that
+    stands for "the records the projection kernel packed".  A consumer about to read it as an array stops here."""
+    if getattr(colors, "_mobgs_colour_token", False) and packed is None:
+        raise RuntimeError(f"{who}: got the fused-prep colour token without matching packed records -- the colour "
+                           "features exist only inside SharedProjection.tl.records (call ops.PrepSplats for an array)")
+
+
 def _pad_channels(D: int) -> int:
     for s in _SUPPORTED:
         if s >= D:
@@ -590,6 +622,7 @@ class _Rasterize(torch.autograd.Function):
         # no pack launch (colors = NULL tells mobgs_raster_fwd so)
         if packed is not None and tuple(packed.shape) != (C * N, stride):
             packed = None
+        _refuse_token(colors, packed, "_Rasterize")
         colors_arg = None if packed is not None else colors
         F = _fast.get()
         records, reach = packed, None
@@ -836,6 +869,7 @@ class _RasterizeLayers(torch.autograd.Function):
         D = channels + 1
         if D != 10:
             raise NotImplementedError("layered compositing is built for 9 feature channels + depth")
+        _refuse_token(colors, None, "_RasterizeLayers")
         bg = f32c(backgrounds) if backgrounds is not None else None
         stride = lib.mobgs_record_stride(D)
         records = torch.empty(C * N, stride, dtype=torch.float32, device=dev)
@@ -938,6 +972,7 @@ class _RasterizeClasses(torch.autograd.Function):
         if packed is not None and tuple(packed.shape) == (C * N, lib.mobgs_record_stride(D)):
             records = packed  # written by the projection kernel (SharedProjection(pack_colors=))
         else:
+            _refuse_token(colors, None, "_RasterizeClasses")
             records = torch.empty(C * N, lib.mobgs_record_stride(D), dtype=torch.float32, device=dev)
             check(lib.mobgs_pack_records(C, N, channels, ptr(means2d), ptr(conics), ptr(colors),
                                          1 if colors.dim() == 3 else 0, ptr(opacities),
@@ -1086,7 +1121,7 @@ class _ProjectAndBin(torch.autograd.Function):
                 row, slot, row_addr, owner = _stats_slots.take()
             seq = _stats_slots.next_seq()
             row[3] = 0
-            seg_stride = _fused_seg_stride(len_hint, C, N, nt, cap_box)
+            seg_stride = _fused_seg_stride(len_hint, C, N, nt, cap_box, key)
             fused_calls[0] += 1 if seg_stride else 0
             if order is not None and (not seg_stride or order.numel() != C * N or order.dtype != torch.int32):
                 order = None  # (the two-pass path enumerates in splat order)
@@ -1152,7 +1187,7 @@ class _ProjectAndBin(torch.autograd.Function):
             keep_scan = torch.empty(lib.mobgs_keep_scan_len(cap_box), dtype=torch.int32, device=dev)
             scratch = torch.empty(lib.mobgs_isect_scratch_bytes(C * N, nt, cap_box), dtype=torch.uint8, device=dev)
             flatten_ids = torch.empty(cap_listed, dtype=torch.int32, device=dev)
-            seg_stride = _fused_seg_stride(_len_hint.get(key, 0), C, N, nt, cap_box) if SPECULATIVE_BINNING else 0
+            seg_stride = _fused_seg_stride(_len_hint.get(key, 0), C, N, nt, cap_box, key) if SPECULATIVE_BINNING else 0
             sort_keys = torch.empty(lib.mobgs_fused_seg_keys_len(nt, seg_stride) if seg_stride else cap_listed,
                                     dtype=torch.int64, device=dev)
             isect_ids = torch.empty(cap_listed, dtype=torch.int64, device=dev) if want_isect_ids else None
@@ -1399,6 +1434,9 @@ class SharedProjection:
                                                           float(radius_clip), order)
         self.C, self.N = 1, means.shape[0]
         self.opacities = opac
+        # `cols` is a TOKEN (uninitialised storage; the features live in tl.records): make it say so, and make every
+        # consumer that would read it as data refuse (_RasterizeLayers used to composite garbage silently)
+        cols._mobgs_colour_token = True
         self.state_colors = cols
         self._packed_colors = cols if self.tl.records is not None else None
         if self._packed_colors is None:

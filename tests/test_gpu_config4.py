@@ -151,14 +151,15 @@ def _iteration(dev, shard, fx_name="blurry_view", n_views=2, with_flows=False):
     return pred.detach().cpu(), bucket.flat.detach().cpu(), sorted(mids)
 
 
-def _shard_worker(rank, world, port, q, with_flows=False):
+def _shard_worker(rank, world, port, q, with_flows=False, backend="gloo", own_gpu=False):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev_index = rank if own_gpu else 0
+    torch.cuda.set_device(dev_index)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from mobgs_amd.distributed import SubframeShard
-        torch.cuda.set_device(0)
-        pred, flat, mids = _iteration(torch.device("cuda:0"), SubframeShard(), with_flows=with_flows)
+        pred, flat, mids = _iteration(torch.device(f"cuda:{dev_index}"), SubframeShard(), with_flows=with_flows)
         q.put((rank, pred.numpy(), flat.numpy(), mids))
     finally:
         dist.destroy_process_group()
@@ -197,7 +198,41 @@ def test_sharded_iteration_world2_on_one_gpu_equals_single_process(hip_device, w
         close(flat, ref_flat, 1e-3, 2e-5 * sc, f"rank {rank}: flat gradient + statistics buffer")
 
 
-# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices: one rank per GPU over RCCL / xGMI")
+@pytest.mark.parametrize("with_flows", [False, True])
+def test_sharded_iteration_world2_rccl_one_gpu_per_rank_equals_single_process(hip_device, with_flows):
+    """the first box with two GPUs runs a CORRECTNESS check before anybody reads a scaling number --
+    the same sharded iteration as above with the production transport: backend "nccl" (= RCCL), one process per GPU, the
+    image all-reduce and the per-view flat gradient messages on the communication stream, device to device.  The two
+    ranks own different mid frames (backward_by_view).  Predictions agree with the single-process step to the order of
+    the nine-image sum, the flat gradient + densification-statistics buffer to summation order.  Costs nothing on a
+    one-GPU box (skipped)."""
+    import torch.multiprocessing as mp
+    from mobgs_amd.distributed import SubframeShard
+    ref_pred, ref_flat, _ = _iteration(hip_device, SubframeShard(1, 0), with_flows=with_flows)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q, with_flows, "nccl", True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(v for _, _, _, mids in results for v in mids) == [0, 1]
+    assert sorted(len(m) for _, _, _, m in results) == [1, 1], "the two mid frames land on different ranks"
+    sc = float(ref_flat.abs().max())
+    assert np.array_equal(results[0][1], results[1][1]), "both ranks hold the same all-reduced prediction, bit for bit"
+    assert np.array_equal(results[0][2], results[1][2]), "... and the same all-reduced gradient buffer"
+    for rank, pred, flat, _ in results:
+        close(pred, ref_pred, 1e-5, 1e-5, f"rank {rank}: predictions (RCCL)")
+        close(flat, ref_flat, 1e-3, 2e-5 * sc, f"rank {rank}: flat gradient + statistics buffer (RCCL)")
+
+
 def test_config4_workload_k9_300k_gaussians_1352x1014(hip_device):
     import bench as B
     from mobgs_amd.distributed import SubframeShard

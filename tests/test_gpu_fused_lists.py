@@ -30,6 +30,7 @@ def _project(s, dev, W, H, fused, hint=None, C=1, order=None):
         if hint is not None:
             key = R._workload_key(dev, C, t["means"].shape[0], W, H)
             R._len_hint[key] = hint
+            R._seg_sticky.pop(key, None)   # (the stride is sticky per workload: a test that dictates the hint starts afresh)
         before = R.fused_calls[0]
         sp = R.SharedProjection(t["means"], t["quats"], t["scales"], t["opacities"], vm, Ks, W, H, want_isect_ids=True,
                                 order=order)

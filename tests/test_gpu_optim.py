@@ -60,3 +60,35 @@ def test_fused_adam_falls_back_for_what_it_does_not_cover(hip_device):
         ref.step()
     assert torch.allclose(p32.detach(), ref32.detach(), rtol=2e-6, atol=2e-7)
     assert torch.equal(p16, ref16)
+
+
+def test_fused_adam_optimizer_class_is_a_drop_in_for_torch_adam(hip_device):
+    """optim.FusedAdam -- what TrainableGaussians.training_setup() / blceKernel hand to an unchanged train.py loop
+    (`optimizer.step()`, /root/reference/train.py:790-807): torch.optim.Adam's update through ONE launch, torch's own step
+    for what the kernel does not cover (a half tensor here), state_dict round trip, zero_grad / param-group edits as usual."""
+    from mobgs_amd.optim import FusedAdam
+    dev = hip_device
+    g = torch.Generator().manual_seed(5)
+    shapes = [(500, 3), (500, 12, 3), (6, 12), (40,)]
+    pa = [torch.randn(*s, generator=g).to(dev).requires_grad_(True) for s in shapes]
+    pa[3] = pa[3].detach().half().requires_grad_(True)
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    groups = lambda ps: [{"params": [p], "lr": 1e-3 * (i + 1), "name": str(i)} for i, p in enumerate(ps)]  # noqa: E731
+    ref, opt = torch.optim.Adam(groups(pa), lr=0.0, eps=1e-15), FusedAdam(groups(pb), lr=0.0, eps=1e-15)
+    assert isinstance(opt, torch.optim.Adam)
+    for it in range(5):
+        for p, q in zip(pa, pb):
+            gr = torch.randn(p.shape, generator=g).to(dev).to(p.dtype)
+            p.grad, q.grad = gr.clone(), gr.clone()
+        ref.step()
+        opt.step()
+        if it == 2:   # what densification / schedulers do between steps
+            for o in (ref, opt):
+                o.param_groups[0]["lr"] *= 0.5
+            sd = opt.state_dict()
+            opt.load_state_dict(sd)
+        for i, (p, q) in enumerate(zip(pa, pb)):
+            assert torch.allclose(q.detach().float(), p.detach().float(), rtol=2e-6, atol=2e-7 if i < 3 else 1e-3), (it, i)
+    opt.zero_grad(set_to_none=True)
+    assert all(q.grad is None for q in pb)
+    assert float(opt.state[pb[0]]["step"]) == 5.0 and float(opt.state[pb[3]]["step"]) == 5.0

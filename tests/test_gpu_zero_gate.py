@@ -212,3 +212,46 @@ def test_separate_get_flow_calls_share_the_mid_exposure_state(hip_device):
     o = G.get_flow(cam, stat, dyn, None, bg, delta_exposure=0.25)
     assert G.mid_cache_stats["misses"] == m2 + 1
     (o[1] * ws[0][1]).sum().backward()
+
+
+def test_mid_state_cache_sees_the_fused_adam_step_and_row_permutations(hip_device):
+    """optim.fused_adam_step writes the parameters through raw pointers -- Tensor._version does not
+    move -- and GaussianParams.spatial_sort_ swaps `.data`; the implicit mid-exposure cache of separate get_flow() calls
+    keyed on (storage, version, shape) would hand back the projection of the OLD values.  Both now announce themselves
+    (gaussian_renderer.parameters_changed): the next call is a miss and renders the new parameters."""
+    import mobgs_amd.gaussian_renderer as G
+    from mobgs_amd.optim import fused_adam_step
+    dev = hip_device
+    W, H = 320, 200
+    cam, stat, dyn = _scene(dev, W, H, 6_000, 3_000)
+    bg = torch.zeros(9, device=dev)
+    opt = torch.optim.Adam([dyn.control_xyz, stat._xyz], lr=0.05)
+    G.invalidate_flow_cache()
+    with torch.no_grad():
+        o1 = G.get_flow(cam, stat, dyn, None, bg, delta_exposure=0.25)
+    ver = (dyn.control_xyz._version, stat._xyz._version)
+    dyn.control_xyz.grad = torch.ones_like(dyn.control_xyz)
+    stat._xyz.grad = torch.ones_like(stat._xyz)
+    assert fused_adam_step([opt]) == 2
+    assert (dyn.control_xyz._version, stat._xyz._version) == ver, "(the premise: the fused step does not bump versions)"
+    m0 = G.mid_cache_stats["misses"]
+    with torch.no_grad():
+        o2 = G.get_flow(cam, stat, dyn, None, bg, delta_exposure=0.25)
+        G.FLOW_MID_CACHE = False
+        try:
+            ref = G.get_flow(cam, stat, dyn, None, bg, delta_exposure=0.25)
+        finally:
+            G.FLOW_MID_CACHE = True
+    assert G.mid_cache_stats["misses"] == m0 + 1, "the cache must not survive a fused optimiser step"
+    assert not torch.equal(o2[1], o1[1])
+    for x, y in zip(o2, ref):
+        assert torch.equal(x, y)
+    # a row permutation (same values, other rows): a miss again, same images up to the order of equal-depth ties
+    with torch.no_grad():
+        G.get_flow(cam, stat, dyn, None, bg, delta_exposure=0.25)
+    m1 = G.mid_cache_stats["misses"]
+    stat.spatial_sort_()
+    dyn.spatial_sort_()
+    with torch.no_grad():
+        G.get_flow(cam, stat, dyn, None, bg, delta_exposure=0.25)
+    assert G.mid_cache_stats["misses"] == m1 + 1
