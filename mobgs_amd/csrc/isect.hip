@@ -252,9 +252,15 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
            int32_t* __restrict__ chunk_cnt, int32_t* __restrict__ owner, int32_t* __restrict__ tile_of_j,
            int32_t* __restrict__ rank_of_j, int32_t* __restrict__ tile_count, int32_t* __restrict__ keep_scan,
            int n_tiles_total, const int32_t* __restrict__ chunk_owner, const float* __restrict__ binrec,
-           uint64_t* __restrict__ seg_keys, int seg_stride, int count_stride, const int32_t* __restrict__ order) {
+           uint64_t* __restrict__ seg_keys, int seg_stride, int count_stride, const int32_t* __restrict__ order,
+           int dense_window) {
     __shared__ int s_cum[OWNER_LDS + 1];
-    extern __shared__ int s_tile[];  // DENSE: per-tile count of this workgroup, then the base of its range
+    // DENSE: per-tile count of this workgroup, then the base of its range -- for the `dense_window` tiles of ONE camera
+    // (round 6: a batch of C cameras has C x the tiles, but the 2048 intersections of a chunk belong to one camera -- the
+    // enumeration is camera-major -- so the table covers the camera of the chunk's first intersection; the few
+    // intersections of a chunk that straddles two cameras take the direct atomic.  8 cameras at 1352x1014: 43 520 tiles
+    // did not fit the 8192-entry table, the batch fell back to direct atomics: 357 us against 8 x 30)
+    extern __shared__ int s_tile[];
     const int chunk = blockIdx.x;
     int32_t* kchunk = keep_scan + (size_t)chunk * (KEEP_CHUNK + 1);
     // this workgroup's copy of the counters (fused path: copies padded to whole 128-byte lines, count_stride apart)
@@ -352,23 +358,32 @@ bin_kernel(int n_gauss, int N, int tile_w, int tile_h, int width, int height, in
     // ranks inside the tiles' lists: all returning atomics in flight before the first result is consumed
     int rank[SCAN_ITEMS];
     if (DENSE) {
-        for (int t = threadIdx.x; t < n_tiles_total; t += SCAN_THREADS) s_tile[t] = 0;
+        __shared__ int s_wbase;
+        if (threadIdx.x == 0) s_wbase = (til[0] / dense_window) * dense_window;  // (item 0 of thread 0 = intersection `start`)
+        for (int t = threadIdx.x; t < dense_window; t += SCAN_THREADS) s_tile[t] = 0;
         __syncthreads();
+        const int wbase = s_wbase;
+        int loc[SCAN_ITEMS];   // index into the table, or -1: outside the window (direct atomic)
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = keep[k] ? atomicAdd(&s_tile[til[k]], 1) : 0;
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            const int l = til[k] - wbase;
+            loc[k] = (keep[k] && (unsigned)l < (unsigned)dense_window) ? l : -1;
+            rank[k] = loc[k] >= 0 ? atomicAdd(&s_tile[loc[k]], 1)
+                                  : (keep[k] ? rank_add(&tile_count[til[k] * TC_STRIDE], 1) : 0);
+        }
         __syncthreads();
         int base_of[SCAN_ITEMS];
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; ++k)  // the intersection that got local rank 0 speaks for its tile
-            base_of[k] = (keep[k] && rank[k] == 0) ? rank_add(&tile_count[til[k] * TC_STRIDE], s_tile[til[k]]) : 0;
+            base_of[k] = (loc[k] >= 0 && rank[k] == 0) ? rank_add(&tile_count[til[k] * TC_STRIDE], s_tile[loc[k]]) : 0;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; ++k)
-            if (keep[k] && rank[k] == 0) s_tile[til[k]] = base_of[k];
+            if (loc[k] >= 0 && rank[k] == 0) s_tile[loc[k]] = base_of[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; ++k)
-            if (keep[k]) rank[k] += s_tile[til[k]];
+            if (loc[k] >= 0) rank[k] += s_tile[loc[k]];
     } else {
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; ++k) rank[k] = keep[k] ? rank_add(&tile_count[til[k] * TC_STRIDE], 1) : 0;
@@ -1643,12 +1658,12 @@ int mobgs::isect_offsets_launch(int C, int N, int tile_w, int tile_h, int width,
         hipLaunchKernelGGL((bin_kernel<true, false>), dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n, N,
                            tile_w, tile_h, width, height, cull, capacity, cum_tiles, means2d, radii, conics, opacities,
                            opac_per_camera, L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan,
-                           (int)nt, L.chunk_owner, (const float*)nullptr, (uint64_t*)nullptr, 0, 0, (const int32_t*)nullptr);
+                           (int)nt, L.chunk_owner, (const float*)nullptr, (uint64_t*)nullptr, 0, 0, (const int32_t*)nullptr, (int)nt);
     else
         hipLaunchKernelGGL((bin_kernel<false, false>), dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h, width,
                            height, cull, capacity, cum_tiles, means2d, radii, conics, opacities, opac_per_camera,
                            L.chunk_cnt, L.owner, L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt,
-                           L.chunk_owner, (const float*)nullptr, (uint64_t*)nullptr, 0, 0, (const int32_t*)nullptr);
+                           L.chunk_owner, (const float*)nullptr, (uint64_t*)nullptr, 0, 0, (const int32_t*)nullptr, 0);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count, L.tile_base, tile_offsets,
                        stats, tile_order, (int64_t)capacity, capacity_listed, keep_scan, n_chunks, heavy_len,
                        stats_mirror, stats_seq);
@@ -1798,18 +1813,21 @@ int mobgs::isect_fused_launch(int C, int N, int tile_w, int tile_h, int width, i
     // ... and with a (spatially coherent) enumeration order, whose whole point is that a workgroup's intersections
     // concentrate on few tiles
     // ... or with splats STORED in such an order (MobgsTuning.coherent_order: the caller's statement)
-    if (nt <= DENSE_MAX_TILES && (nt <= 2048 || max_tile_len_hint >= 1024 || enum_order || tuning_coherent_order(tuning)))
-        hipLaunchKernelGGL((bin_kernel<true, true>), dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)nt, st, n,
+    // ... for a batch of cameras the table covers ONE camera's tiles (bin_kernel, dense_window)
+    const long long dense_window = nt < (long long)tile_w * tile_h ? nt : (long long)tile_w * tile_h;
+    if (dense_window <= DENSE_MAX_TILES &&
+        (nt <= 2048 || max_tile_len_hint >= 1024 || enum_order || tuning_coherent_order(tuning)))
+        hipLaunchKernelGGL((bin_kernel<true, true>), dim3(n_chunks), dim3(SCAN_THREADS), sizeof(int32_t) * (size_t)dense_window, st, n,
                            N, tile_w, tile_h, width, height, 1, capacity, cum_search, (const float*)nullptr,
                            (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, L.chunk_cnt, L.owner,
                            L.tile_of_j, L.rank_of_j, L.tile_count, keep_scan, (int)nt, L.chunk_owner, binrec, seg_keys,
-                           seg_stride, cstride, enum_order);
+                           seg_stride, cstride, enum_order, (int)dense_window);
     else
         hipLaunchKernelGGL((bin_kernel<false, true>), dim3(n_chunks), dim3(SCAN_THREADS), 0, st, n, N, tile_w, tile_h,
                            width, height, 1, capacity, cum_search, (const float*)nullptr, (const int32_t*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, 0, L.chunk_cnt, L.owner, L.tile_of_j,
                            L.rank_of_j, L.tile_count, keep_scan, (int)nt, L.chunk_owner, binrec, seg_keys, seg_stride,
-                           cstride, enum_order);
+                           cstride, enum_order, 0);
     hipLaunchKernelGGL(tile_finish_kernel, dim3(tile_order ? 3 : 2), dim3(TSCAN_THREADS), 0, st, (int)nt, L.tile_count,
                        cstride, tile_offsets, stats, tile_order, (int64_t)capacity, capacity_listed, seg_stride, keep_scan,
                        n_chunks, heavy_len, stats_mirror, stats_seq);
