@@ -110,7 +110,15 @@ extern "C" {
  *                      per evaluated 8x8 quadrant) and v_colors[.., 6..] of those rows is written as 0.  Every other
  *                      output is BIT-identical (fma(0, v, acc) = acc).  The zeros are verified per staged entry (an entry
  *                      whose dead channels are not all +-0 takes the full body): a wrong statement about the DATA costs
- *                      nothing; a caller that does want d/d(colour 6..8) of such rows must leave this at 0. */
+ *                      nothing; a caller that does want d/d(colour 6..8) of such rows must leave this at 0.
+ *   cover_slots        (round 6) mobgs_raster_bwd / mobgs_raster_bwd_decode, default 0 / -1 = off.  1: the caller did NOT
+ *                      zero-fill grad_slots (108 MB at 1352x1014 / 300 k splats: a 15-us fill per render, 9 of them per
+ *                      blurry view) -- the kernel writes the slot of EVERY entry of its lists, zeros where no pixel blended
+ *                      the splat (entries behind every pixel's last blended one included), so mobgs_raster_bwd_reduce
+ *                      sums exactly what it would have; pass any_record = NULL to both stages then (the flag would live in
+ *                      unwritten memory).  Honoured only where the quadrant kernel runs ((mobgs_raster_path(D, 0, n_tiles,
+ *                      tuning) & 3) == 0; other selections return MOBGS_E_UNSUPPORTED) and not together with
+ *                      gate_zero_cotangent (a gated-off pass writes nothing).  Gradients are bit-identical. */
 typedef struct MobgsTuning {
     int32_t heavy_tile_len;
     int32_t longest_list_hint;
@@ -122,6 +130,7 @@ typedef struct MobgsTuning {
     int32_t gate_zero_cotangent;
     int32_t coherent_order;
     int32_t static_rows;
+    int32_t cover_slots;
 } MobgsTuning;
 
 const char* mobgs_version(void);
@@ -135,7 +144,7 @@ int mobgs_cotangent_probe(int n_arrays, const float* const* arrays, const size_t
  * points changes (round 4 inserted `records` into mobgs_raster_bwd_reduce and changed the gradient-slot format without
  * one: a stale host extension would have passed shifted pointers).  Bindings compare it with the MOBGS_ABI_VERSION
  * they were built against and refuse to run on a mismatch (mobgs_amd/_lib.py, csrc/fastpath.cpp). */
-#define MOBGS_ABI_VERSION 8
+#define MOBGS_ABI_VERSION 9
 int mobgs_abi_version(void);
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* mobgs_last_error(void);
@@ -425,6 +434,29 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
                      const float* render_alphas, const int32_t* last_ids, const float* v_render,
                      const float* v_alphas, float* grad_slots, const uint8_t* isect_reach,
                      int32_t* any_record, const MobgsTuning* tuning, void* stream);
+/* Stage 1 with the Sandwich decoder's BACKWARD pass as its prologue (round 6; the counterpart of mobgs_raster_fwd_decode;
+ * replaces, for the lean render() of /root/reference/gaussian_renderer/__init__.py:201-227, the chain
+ * [helper_model.py:19-28 backward -> gsplat rasterize_to_pixels backward]): 9 feature channels + the depth channel,
+ * pinhole rays.  The kernel reads the decoder's inputs -- `render` [C,H,W,10] (the composited image mobgs_raster_fwd[_decode]
+ * wrote), `render_alphas`, the cotangents v_rgb [C,3,H,W] of the decoded colour and v_depth [C,H,W] (NULL = none) of the
+ * expected depth -- and forms the cotangent of the composited image in registers (bit for bit what mobgs_decoder_bwd
+ * would have written to v_feat_hw / v_alphas; v_alphas here = an ADDITIONAL cotangent of the alpha output, NULL = none).
+ * Weight gradients g_w1 [6,12], g_w2 [3,6] (accumulate_wgrad != 0: added to what is there) and the pose gradient
+ * g_c2w [C, g_c2w_floats = 12 | 16] (NULL = not wanted) are fully written from w_partial (scratch of
+ * mobgs_raster_bwd_decode_scratch_floats(C, width, height) floats, contents irrelevant on entry: one row of 102 sums per
+ * tile, then chunk sums and a ticket word; summed in a fixed order: deterministic).  Only where the quadrant kernel is the
+ * selection ((mobgs_raster_path(10, 0, n_tiles, tuning) & 3) == 0), else MOBGS_E_UNSUPPORTED: callers then run
+ * mobgs_decoder_bwd + mobgs_raster_bwd.  Everything else as mobgs_raster_bwd (channels = 9, has_extra = 1). */
+int mobgs_raster_bwd_decode(int C, int N, int width, int height, const float* records, const float* backgrounds,
+                            const int32_t* radii, const int32_t* cum_tiles, const int32_t* keep_scan,
+                            const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
+                            const float* render, const float* render_alphas, const int32_t* last_ids, const float* v_rgb,
+                            const float* v_depth, const float* v_alphas, const float* ray_intr, int intr_stride,
+                            const float* ray_c2w, int c2w_stride, const float* w1, const float* w2, float* grad_slots,
+                            const uint8_t* isect_reach, int32_t* any_record, float* w_partial, float* g_w1, float* g_w2,
+                            float* g_c2w, int g_c2w_floats, int accumulate_wgrad, const MobgsTuning* tuning,
+                            void* stream);
+size_t mobgs_raster_bwd_decode_scratch_floats(int C, int width, int height);
 /* tiles_per_gauss (optional, else NULL): [C*N] -- splat g's intersections are then [cum_tiles[g], cum_tiles[g] +
  *     tiles_per_gauss[g]) instead of [cum_tiles[g], cum_tiles[g + 1]): REQUIRED when the lists were built with an enum_order
  *     (mobgs_project_and_bin_fused), equivalent otherwise. */

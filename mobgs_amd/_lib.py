@@ -23,12 +23,13 @@ class MobgsTuning(ctypes.Structure):
                 ("quadrant_culling", ctypes.c_int32), ("block_walk", ctypes.c_int32),
                 ("bwd_block_walk", ctypes.c_int32), ("geometry_per_camera", ctypes.c_int32),
                 ("bwd_mfma", ctypes.c_int32), ("gate_zero_cotangent", ctypes.c_int32),
-                ("coherent_order", ctypes.c_int32), ("static_rows", ctypes.c_int32)]
+                ("coherent_order", ctypes.c_int32), ("static_rows", ctypes.c_int32), ("cover_slots", ctypes.c_int32)]
 
     def __init__(self, heavy_tile_len=-1, longest_list_hint=-1, quadrant_culling=-1, block_walk=-1, bwd_block_walk=-1,
-                 geometry_per_camera=0, bwd_mfma=-1, gate_zero_cotangent=0, coherent_order=0, static_rows=0):
+                 geometry_per_camera=0, bwd_mfma=-1, gate_zero_cotangent=0, coherent_order=0, static_rows=0,
+                 cover_slots=0):
         super().__init__(heavy_tile_len, longest_list_hint, quadrant_culling, block_walk, bwd_block_walk,
-                         geometry_per_camera, bwd_mfma, gate_zero_cotangent, coherent_order, static_rows)
+                         geometry_per_camera, bwd_mfma, gate_zero_cotangent, coherent_order, static_rows, cover_slots)
 
     def copy(self, **overrides):
         """A per-call copy with some fields replaced."""
@@ -51,7 +52,7 @@ class MobgsPrepInputs(ctypes.Structure):
 
 
 P = c_void_p
-ABI_VERSION = 8  # include/mobgs_hip.h MOBGS_ABI_VERSION
+ABI_VERSION = 9  # include/mobgs_hip.h MOBGS_ABI_VERSION
 _SIGS = {
     "mobgs_version": (c_char_p, []),
     "mobgs_abi_version": (c_int, []),
@@ -76,6 +77,9 @@ _SIGS = {
     "mobgs_raster_fwd_decode": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, P, P,
                                         P, P, P, P, P, c_int, P, c_int, P, P, P, P, P, P]),
     "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int] + [P] * 16 + [P, P]),
+    "mobgs_raster_bwd_decode": (c_int, [c_int, c_int, c_int, c_int] + [P] * 15 + [c_int, P, c_int] + [P] * 9 +
+                                [c_int, c_int, P, P]),
+    "mobgs_raster_bwd_decode_scratch_floats": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "mobgs_cotangent_probe": (c_int, [c_int, P, P, P, P]),
     "mobgs_raster_bwd_reduce": (c_int, [c_int, c_int, c_int, c_int] + [P] * 11 + [P]),
     "mobgs_project_and_bin": (c_int, [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float,

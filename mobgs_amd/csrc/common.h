@@ -285,6 +285,7 @@ inline int tuning_bwd_mfma(const MobgsTuning* t, int n_tiles) {
 inline int tuning_coherent_order(const MobgsTuning* t) { return (t && t->coherent_order == 1) ? 1 : 0; }
 inline int tuning_gate_zero_cotangent(const MobgsTuning* t) { return (t && t->gate_zero_cotangent == 1) ? 1 : 0; }
 inline int tuning_static_rows(const MobgsTuning* t) { return (t && t->static_rows > 0) ? t->static_rows : 0; }
+inline int tuning_cover_slots(const MobgsTuning* t) { return (t && t->cover_slots > 0) ? 1 : 0; }
 inline int tuning_geometry_per_camera(const MobgsTuning* t) { return (t && t->geometry_per_camera == 1) ? 1 : 0; }
 void isect_zeroed_region(void* scratch, size_t n_gauss, size_t n_tiles, size_t capacity, int32_t** ptr, size_t* count);
 // fused single-pass lists (isect.hip): where the projection kernel leaves the bin records inside the binning scratch,

@@ -357,6 +357,94 @@ __global__ void __launch_bounds__(256) decoder_wgrad_reduce_kernel(int nblocks, 
     }
 }
 
+// The same sums for the MANY rows of the backward compositor's decoder prologue (raster.hip DECB: one row per tile, 5440 per
+// image at 1352x1014; the kernel above walks one column per workgroup -- every workgroup touches every cache line of the
+// rows: 10 us there).  Here workgroup (b, img) streams a contiguous chunk of image img's rows (thread = column, two row
+// phases: coalesced 408-byte rows) into chunk_sums[img * G + b][102]; the last workgroup to finish (a ticket) adds the chunk
+// sums in a fixed order: deterministic, one launch.  The ticket word is zeroed by the compositing launch in front of it.
+constexpr int WRED_CHUNKS_MAX = 64;
+__host__ __device__ inline int wred_chunks(int rows_per_image) { return min(WRED_CHUNKS_MAX, (rows_per_image + 31) / 32); }
+
+constexpr int WRED_THREADS = 1024, WRED_PHASES = WRED_THREADS / 128;
+__global__ void __launch_bounds__(WRED_THREADS) decoder_wgrad_reduce_rows_kernel(int rows_per_image, const float* __restrict__ w_partial,
+                                                                          float* __restrict__ chunk_sums,
+                                                                          unsigned* __restrict__ ticket,
+                                                                          float* __restrict__ g_w1, float* __restrict__ g_w2,
+                                                                          float* __restrict__ g_c2w, int accumulate,
+                                                                          int c2w_floats) {
+    const int G = gridDim.x, C = gridDim.y;
+    const int b = blockIdx.x, img = blockIdx.y;
+    const int per = (rows_per_image + G - 1) / G;
+    const int r0 = img * rows_per_image + b * per;
+    const int r1 = min(r0 + per, (img + 1) * rows_per_image);
+    const int col = threadIdx.x & 127, ph = threadIdx.x >> 7;
+    float s = 0.f;
+    if (col < NRED) {
+#pragma unroll 4
+        for (int r = r0 + ph; r < r1; r += WRED_PHASES) s += w_partial[(size_t)r * NRED + col];
+    }
+    __shared__ float red[WRED_PHASES][128];
+    __shared__ int is_last;
+    red[ph][col] = s;
+    __syncthreads();
+    if (threadIdx.x < NRED) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < WRED_PHASES; ++q) t += red[q][threadIdx.x];
+        // relaxed agent-scope atomics for the words that cross workgroups (they go to the coherence point, past the XCD's own
+        // L2): a release / acquire fence pair instead writes back and invalidates that whole L2 per workgroup -- 25 us for
+        // the 64 workgroups of one image (isect.hip scan_lookback found the same)
+        __hip_atomic_store(&chunk_sums[(size_t)(img * G + b) * NRED + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // the stores have left before the workgroup takes its ticket (the barrier orders the waves)
+    __syncthreads();
+    if (threadIdx.x == 0)
+        is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(G * C - 1);
+    __syncthreads();
+    if (!is_last) return;
+    // image by image: the G chunk sums of an image staged in LDS by all threads at once (one dependent load each -- a thread
+    // summing its column straight from memory pays a memory round trip per chunk: 33 us), then added in chunk order
+    __shared__ float stage[WRED_CHUNKS_MAX * NRED];
+    const int k = threadIdx.x;
+    float wsum = 0.f;
+    for (int im = 0; im < C; ++im) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < G * NRED; i += WRED_THREADS)
+            stage[i] = __hip_atomic_load(&chunk_sums[(size_t)im * G * NRED + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (k < NRED) {
+            float t = 0.f;
+            for (int i = 0; i < G; ++i) t += stage[i * NRED + k];
+            if (k < 90)
+                wsum += t;
+            else if (g_c2w)
+                g_c2w[(size_t)im * c2w_floats + (k - 90)] = t;
+        } else if (g_c2w && c2w_floats == 16 && k < NRED + 4) {
+            g_c2w[(size_t)im * c2w_floats + (k - 90)] = 0.f;
+        }
+    }
+    if (k < 72)
+        g_w1[k] = accumulate ? g_w1[k] + wsum : wsum;
+    else if (k < 90)
+        g_w2[k - 72] = accumulate ? g_w2[k - 72] + wsum : wsum;
+    if (k == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// decoder_shared.h: the fixed-order sum of the prologue's partial rows; `scratch` = decoder_wgrad_scratch_floats(C, rows) floats
+size_t decoder_wgrad_scratch_floats(int C, int rows_per_image) {
+    return (size_t)C * rows_per_image * NRED + (size_t)C * wred_chunks(rows_per_image) * NRED + 4;
+}
+unsigned* decoder_wgrad_ticket(float* scratch, int C, int rows_per_image) {
+    return reinterpret_cast<unsigned*>(scratch + decoder_wgrad_scratch_floats(C, rows_per_image) - 4);
+}
+void launch_decoder_wgrad_reduce(int C, int rows_per_image, float* scratch, float* g_w1, float* g_w2, float* g_c2w,
+                                 int g_c2w_floats, int accumulate, hipStream_t st) {
+    float* chunk_sums = scratch + (size_t)C * rows_per_image * NRED;
+    hipLaunchKernelGGL(decoder_wgrad_reduce_rows_kernel, dim3(wred_chunks(rows_per_image), C), dim3(WRED_THREADS), 0, st,
+                       rows_per_image, scratch, chunk_sums, decoder_wgrad_ticket(scratch, C, rows_per_image), g_w1, g_w2,
+                       g_c2w, accumulate, g_c2w_floats);
+}
+
 }  // namespace mobgs
 
 using namespace mobgs;

@@ -126,4 +126,83 @@ __device__ __forceinline__ void sandwich_forward_n(const float* __restrict__ w1,
     }
 }
 
+// One pixel of the decoder's BACKWARD pass (decoder_bwd_kernel's arithmetic, instruction for instruction: explicit FMAs, the
+// same chains in the same order, so that the backward compositor's prologue -- raster.hip, DECB -- hands the compositing
+// loop bit for bit the cotangents a separate decoder_bwd launch would have written to memory):
+//   in : f[0..9] composited features (+ accumulated depth in f[9]), x6[0..5] = ray origin | normalised direction,
+//        v_rgb[3], alpha, g = cotangent of the expected depth (0 when unused)
+//   out: vf[10] = cotangent of the composited image, v_alpha (from the depth normalisation), h[6] hidden activations,
+//        vh[6] their cotangents, vy[3] pre-sigmoid cotangents, vdir[3] = cotangent of the normalised direction
+__device__ __forceinline__ void sandwich_backward(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                  const float (&f)[10], const float (&x6)[6], const float (&v_rgb)[3],
+                                                  float alpha, float g, float (&vf)[10], float& v_alpha, float (&h)[6],
+                                                  float (&vh)[6], float (&vy)[3], float (&vdir)[3], float (&vorg)[3]) {
+    float x[12];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        x[k] = f[3 + k];
+        x[6 + k] = x6[k];
+    }
+#pragma unroll
+    for (int jg = 0; jg < 6 / W1_ROWS_SHARED; ++jg) {
+        const ConstWeights w1a = reload_here(w1 + 12 * W1_ROWS_SHARED * jg);
+#pragma unroll
+        for (int jj = 0; jj < W1_ROWS_SHARED; ++jj) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) s = __fmaf_rn(w1a[12 * jj + c], x[c], s);
+            h[W1_ROWS_SHARED * jg + jj] = fmaxf(s, 0.f);
+        }
+    }
+    const ConstWeights w2a = reload_here(w2);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float y = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) y = __fmaf_rn(w2a[6 * o + j], h[j], y);
+        const float sg = 1.f / (1.f + __expf(-(f[o] + y)));
+        vy[o] = v_rgb[o] * sg * (1.f - sg);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) s = __fmaf_rn(w2a[6 * o + j], vy[o], s);
+        vh[j] = h[j] > 0.f ? s : 0.f;
+    }
+    float vx[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) vx[c] = 0.f;
+#pragma unroll
+    for (int jg = 0; jg < 6 / W1_ROWS_SHARED; ++jg) {  // (j ascending per component, as one chain of FMAs)
+        const ConstWeights w1b = reload_here(w1 + 12 * W1_ROWS_SHARED * jg);
+#pragma unroll
+        for (int jj = 0; jj < W1_ROWS_SHARED; ++jj)
+#pragma unroll
+            for (int c = 0; c < 12; ++c) vx[c] = __fmaf_rn(w1b[12 * jj + c], vh[W1_ROWS_SHARED * jg + jj], vx[c]);
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) vf[o] = vy[o];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vf[3 + k] = vx[k];
+    const float ac = fmaxf(alpha, 1e-10f);
+    vf[9] = g / ac;
+    v_alpha = alpha > 1e-10f ? -g * f[9] / (ac * ac) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        vorg[i] = vx[6 + i];
+        vdir[i] = vx[9 + i];
+    }
+}
+
+// decoder.hip: sums the partial rows the backward compositor's decoder prologue left at the start of `scratch`
+// ([C * rows_per_image, 102], decoder_bwd_kernel's row layout) in a fixed order into g_w1 [6,12], g_w2 [3,6] (over all
+// images; accumulate != 0: added to what is there) and g_c2w [C, g_c2w_floats] (per image; may be NULL).  `scratch` holds
+// decoder_wgrad_scratch_floats(C, rows_per_image) floats: the rows, the chunk sums, and a ticket word that must be ZERO
+// when the reduction starts (the compositing kernel clears it) and is zero again when it ends.
+size_t decoder_wgrad_scratch_floats(int C, int rows_per_image);
+unsigned* decoder_wgrad_ticket(float* scratch, int C, int rows_per_image);
+void launch_decoder_wgrad_reduce(int C, int rows_per_image, float* scratch, float* g_w1, float* g_w2, float* g_c2w,
+                                 int g_c2w_floats, int accumulate, hipStream_t st);
+
 }  // namespace mobgs

@@ -843,12 +843,37 @@ struct BwdShared {
     float zero16[16] __attribute__((aligned(16)));  // 64 bytes of zeros: the accumulators are cleared by reading them
 };
 
+// The BACKWARD half of the decoder fusion (round 6; DECB): the Sandwich decoder's backward pass as the PROLOGUE of the backward
+// compositor.  A lane needs the cotangent of the composited image at its four pixels before it can walk the list; instead of
+// reading what a decoder_bwd launch wrote (40 B per pixel, after that launch read 56 B and wrote 44 B per pixel: 47 us +
+// a 4.7-us reduction at 1352x1014), the lane reads the decoder's own inputs -- the composited features the forward pass kept,
+// the cotangents of the decoded colour and of the expected depth -- and evaluates decoder_shared.h sandwich_backward for each
+// pixel: the same instruction sequence as decoder_bwd_kernel, so the compositing loop sees the same bits.  The weight and
+// pose gradients are sums over pixels of outer products; ALL of them come out of one 16x16 accumulator block of
+// v_mfma_f32_16x16x4_f32 per wave (exact fp32):
+//     rows  (A) = [vh_0..5 | vd_0..2 | h_0..5 | 0]            vh: hidden cotangents, vd: cotangent of the un-normalised ray
+//     cols  (B) = [x_0..5 | dir_0..2 | loc_x, loc_y, 1 | vy_0..2 | 0]
+//   g_w1[j][c]   = C[j][c] (c < 6: features), C[j][c - 3] (c >= 9: direction), t_(c-6) * C[j][11] (c = 6..8: the ray origin is
+//                  the camera position t, one constant per image);  g_w2[o][j] = C[9 + j][12 + o];
+//   pose: d/dR[i][0..1], d/d(third column)[i] = C[6 + i][9..11];  d/dt[i] = sum_j w1[j][6 + i] C[j][11] (vx is linear in vh)
+// -- no per-lane accumulators, no wave reductions.  One partial row of 102 sums per TILE (w_partial[tile][102], the layout of
+// decoder_bwd_kernel's rows: decoder_wgrad_reduce_kernel sums them, image by image for the pose).  Tiles with empty lists
+// run the prologue too: their pixels still carry decoder gradients.
+struct DecodeBwd {
+    const float *feat, *v_rgb, *v_depth;   // [C,H,W,10] composited image, [C,3,H,W], [C,H,W] | NULL
+    const float *intr, *c2w, *w1, *w2;     // as DecodeEpi
+    float* w_partial;                      // [C * tiles, 102]
+    unsigned* ticket;                      // the reduction's ticket word (cleared here)
+    int intr_stride, c2w_stride;
+};
+constexpr int DECB_NRED = 102;
+
 // One wave walks `tile` back to front for NP pixels per lane.  NP = 4: the whole tile, one gradient record per
 // (tile, splat) straight to grad_slots.  NP = 1 (HEAVY): the 4 waves of the workgroup share the tile, wave `quad`
 // taking one 8x8 quadrant; they walk the same batches in step, leave their partial records in LDS and the
 // workgroup sums the (up to 4) partials of every entry into its ONE slot -- still no floating-point atomics, and a
 // fixed summation order (quadrant 0..3), so gradients stay bit-reproducible.
-template <int CD, int NP, bool FILTER>
+template <int CD, int NP, bool FILTER, bool DECB = false>
 __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int lane, BwdShared<CD>& sh, ClassSel cls,
                                               int tile_w,
                                               int tile_h, int width, int height, const float* __restrict__ records,
@@ -862,10 +887,11 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                                               const float* __restrict__ v_render, const float* __restrict__ v_alphas,
                                               float* __restrict__ grad_slots,
                                               const uint8_t* __restrict__ isect_reach,
-                                              int32_t* __restrict__ any_record) {
+                                              int32_t* __restrict__ any_record, const DecodeBwd& db = DecodeBwd{}) {
     constexpr int RS = (6 + CD + 3) & ~3;
     constexpr int RQ = RS / 4;
     constexpr int NV = 6 + CD;
+    static_assert(!DECB || (CD == 10 && !FILTER), "decoder prologue: the 9 + 1 channel pass");
     // per-lane gradient sums of one entry: 6 + CD components, padded to what the wave reduction handles -- a power of
     // two, or sixteen plus 2 / plus 8 (NVX extra components reduced on their own, see below)
     constexpr int NVX = (NV > 16 && NV <= 24) ? NV - 16 : 0;
@@ -882,7 +908,7 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
 
     const int s = __builtin_amdgcn_readfirstlane(tile_offsets[tile]);
     const int e = __builtin_amdgcn_readfirstlane(tile_offsets[tile + 1]);
-    if (e <= s) return;
+    if (!DECB && e <= s) return;
 
     // behind[k] = sum over the splats BEHIND the current one of fac * <colour, v_out>: upstream keeps the
     // per-channel sums buffer[c] and forms sum_c (colour_c T - buffer_c ra) v_out_c; distributing v_out gives
@@ -891,6 +917,10 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
     float vo[PPL][CD];
     int binf[PPL];
     int top = -1;
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    f32x4 wacc = {0.f, 0.f, 0.f, 0.f};   // DECB: C[4 (lane >> 4) + i][lane & 15] of the weight-gradient block
+    RayCam rc;
+    if constexpr (DECB) rc = load_raycam(db.intr + (size_t)cam * db.intr_stride, db.c2w + (size_t)cam * db.c2w_stride);
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
         const int qd = HEAVY ? quad : k;
@@ -906,7 +936,75 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
         behind[k] = 0.f;
 #pragma unroll
         for (int c = 0; c < CD; ++c) vo[k][c] = 0.f;
-        if (inside) {
+        if constexpr (DECB) {
+            // every load unconditional, from clamped addresses (pixels past the image edge are computed and then dropped):
+            // the weights arrive by scalar loads, which a divergent branch would not skip anyway
+            const int cxi = min(pxi, width - 1), cyi = min(pyi, height - 1);
+            const size_t P = (size_t)width * height;
+            const size_t p = (size_t)cyi * width + cxi;
+            const size_t pix = (size_t)cam * P + p;
+            float f[10], vr[3], x6[6], loc[2], inv_n;
+            const float* fp = db.feat + pix * 10;
+#pragma unroll
+            for (int c = 0; c < 10; ++c) f[c] = fp[c];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) vr[o] = db.v_rgb[((size_t)cam * 3 + o) * P + p];
+            const float gdep = db.v_depth ? db.v_depth[pix] : 0.f;
+            const float alpha_px = render_alphas[pix];
+            pixel_ray_xy(rc, cxi, cyi, x6, loc, inv_n);
+            float vf[10], v_a, hh[6], vh[6], vy[3], vdir[3], vorg[3];
+            sandwich_backward(db.w1, db.w2, f, x6, vr, alpha_px, gdep, vf, v_a, hh, vh, vy, vdir, vorg);
+            (void)vorg;
+            // dir = d / |d|: v_d = (v_dir - dir <dir, v_dir>) / |d|
+            const float dotp = __fmaf_rn(x6[3], vdir[0], __fmaf_rn(x6[4], vdir[1], x6[5] * vdir[2]));
+            float arow[16], brow[16];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                arow[j] = vh[j];
+                arow[9 + j] = hh[j];
+                brow[j] = f[3 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                arow[6 + i] = (vdir[i] - x6[3 + i] * dotp) * inv_n;
+                brow[6 + i] = x6[3 + i];
+                brow[12 + i] = vy[i];
+            }
+            arow[15] = 0.f;
+            brow[9] = loc[0];
+            brow[10] = loc[1];
+            brow[11] = 1.f;
+            brow[15] = 0.f;
+            if (inside) {
+                binf[k] = last_ids[pix];
+                Tf[k] = 1.f - alpha_px;
+                va[k] = (v_alphas ? v_alphas[pix] : 0.f) + v_a;
+#pragma unroll
+                for (int c = 0; c < CD; ++c) vo[k][c] = vf[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) arow[c] = 0.f;   // (a zero row: the pixel adds nothing to any sum)
+            }
+            // [16 x 64 px] x [64 px x 16] on the matrix pipe: lane (m, kq) supplies A[m][kq], B[kq][m] of pixels 4 s + kq
+            float4* sa = &sh.slab[wv][lane][0];
+            float4* sb = reinterpret_cast<float4*>(&sh.part[wv][lane][0]);
+            wave_lds_fence();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sa[q] = make_float4(arow[4 * q], arow[4 * q + 1], arow[4 * q + 2], arow[4 * q + 3]);
+                sb[q] = make_float4(brow[4 * q], brow[4 * q + 1], brow[4 * q + 2], brow[4 * q + 3]);
+            }
+            wave_lds_fence();
+            const float* sa_f = reinterpret_cast<const float*>(&sh.slab[wv][0][0]);
+            const float* sb_f = &sh.part[wv][0][0];
+#pragma unroll
+            for (int s4 = 0; s4 < 16; ++s4) {
+                const int pxl = 4 * s4 + (lane >> 4);
+                wacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sa_f[pxl * 16 + (lane & 15)], sb_f[pxl * 16 + (lane & 15)], wacc,
+                                                            0, 0, 0);
+            }
+        }
+        if (!DECB && inside) {
             const size_t pix = ((size_t)cam * height + pyi) * width + pxi;
             binf[k] = last_ids[pix];
             Tf[k] = 1.f - render_alphas[pix];
@@ -914,6 +1012,8 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
             const float* vr = v_render + pix * CD;
 #pragma unroll
             for (int c = 0; c < CD; ++c) vo[k][c] = vr[c];
+        }
+        if (inside) {
             if (backgrounds) {
 #pragma unroll
                 for (int c = 0; c < CD; ++c) bgdot[k] = __fmaf_rn(backgrounds[cam * CD + c], vo[k][c], bgdot[k]);
@@ -929,6 +1029,46 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
         }
         T[k] = Tf[k];
         tvab[k] = Tf[k] * (va[k] - bgdot[k]);
+    }
+    if constexpr (DECB) {
+        // the tile's partial row of weight / pose gradient sums, from the 16 x 16 block (layout: DecodeBwd)
+        float* cm = reinterpret_cast<float*>(&sh.slab[wv][0][0]);   // this wave's block, row-major
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cm[(4 * (lane >> 4) + i) * 16 + (lane & 15)] = wacc[i];
+        wave_lds_fence();
+        if (HEAVY) __syncthreads();   // the four quadrant waves of a heavy tile: wave 0 adds the four blocks
+        if (!HEAVY || wv == 0) {
+            auto C_ = [&](int r, int c) -> float {
+                if (!HEAVY) return cm[r * 16 + c];
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < TILES_PER_WG; ++w) t += reinterpret_cast<const float*>(&sh.slab[w][0][0])[r * 16 + c];
+                return t;
+            };
+            float* row = db.w_partial + (size_t)tile * DECB_NRED;
+            for (int en = lane; en < DECB_NRED; en += 64) {
+                float v;
+                if (en < 72) {
+                    const int j = en / 12, c = en - 12 * j;
+                    const float tc = c == 6 ? rc.c2w[3] : (c == 7 ? rc.c2w[7] : rc.c2w[11]);   // (no run-time index: registers)
+                    v = c < 6 ? C_(j, c) : (c < 9 ? tc * C_(j, 11) : C_(j, c - 3));
+                } else if (en < 90) {
+                    const int o = (en - 72) / 6, j = (en - 72) - 6 * o;
+                    v = C_(9 + j, 12 + o);
+                } else {
+                    const int i = (en - 90) >> 2, q = (en - 90) & 3;
+                    if (q < 3) {
+                        v = C_(6 + i, 9 + q);
+                    } else {
+                        v = 0.f;
+                        for (int j = 0; j < 6; ++j) v = __fmaf_rn(db.w1[12 * j + 6 + i], C_(j, 11), v);
+                    }
+                }
+                row[en] = v;
+            }
+        }
+        if (e <= s) return;
     }
     // highest list index any pixel of pixel slot k (= one 8x8 quadrant) blended: entries behind it cannot contribute
     // to that quadrant and are not even evaluated there (on the benchmark lists 21 % of the entries lie behind every
@@ -955,6 +1095,23 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
     // when every cotangent of the pass is zero no pixel is valid, top stays below s and nobody sets it.  (Setting it
     // at the first record instead cost 16 us of the 540: a branch per list entry.)
     if (any_record && top >= s && lane == 0) *any_record = 1;
+    // cover (MobgsTuning.cover_slots): nobody zero-filled the slots.  The entries behind every pixel's last blended one
+    // are never staged: their slots get their zeros here (lane = entry; the slot index by the same chain as below)
+    const bool cover = !FILTER && cls.cover != 0;
+    if (cover && (!HEAVY || quad == 0)) {
+        for (int base = e - 1; base > top; base -= 64) {
+            const int idx = base - lane;
+            if (idx > top && idx >= s) {
+                const int g = flatten_ids[idx];
+                const float2 m = *reinterpret_cast<const float2*>(records + (size_t)g * RS);
+                const TileRect tr = tile_rect(m.x, m.y, radii[g], tile_w, tile_h);
+                const int slot = keep_index(keep_scan, cum_tiles[g] + (ty - tr.y0) * (tr.x1 - tr.x0) + (tx - tr.x0));
+                float4* dst = reinterpret_cast<float4*>(grad_slots + (size_t)slot * RS);
+#pragma unroll
+                for (int q = 0; q < RQ; ++q) dst[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
 
     for (int hi = top; hi >= s; hi -= 64) {
         int n = min(64, hi - s + 1);
@@ -1099,7 +1256,7 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                 contributed = true;
             }
             if (!contributed) continue;
-            if (HEAVY) touched |= 1ull << j;
+            touched |= 1ull << j;
             if constexpr (NVP == 16) {
                 // every lane ends up with the total of component lane >> 2: one 64-byte store from 16 lanes
                 const float w = wave_reduce16_scatter(g);
@@ -1140,6 +1297,11 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                 }
             }
         }
+        if (!HEAVY && cover && lane < n && !((touched >> lane) & 1ull)) {   // staged, but no pixel blended it: zeros
+            float4* dst = reinterpret_cast<float4*>(grad_slots + (size_t)slot_of[wv][lane] * RS);
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) dst[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         if (HEAVY) {
             if (lane == 0) sh.touched[wv] = touched;
             __syncthreads();
@@ -1159,14 +1321,14 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
                         any = true;
                     }
                 }
-                if (any) reinterpret_cast<float4*>(grad_slots + (size_t)slot_of[0][r] * RS)[q] = acc4;
+                if (any || cover) reinterpret_cast<float4*>(grad_slots + (size_t)slot_of[0][r] * RS)[q] = acc4;
             }
             __syncthreads();  // the partial records and slot table are free for the next batch
         }
     }
 }
 
-template <int CD, bool FILTER>
+template <int CD, bool FILTER, bool DECB = false>
 __global__ void __launch_bounds__(64 * TILES_PER_WG) __attribute__((amdgpu_waves_per_eu(CD <= 10 ? 4 : (CD <= 16 ? 3 : 1))))
 raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int width, int height,
                   const float* __restrict__ records, const float* __restrict__ backgrounds,
@@ -1176,22 +1338,26 @@ raster_bwd_kernel(int n_tiles_total, int n_groups, int tile_w, int tile_h, int w
                   const int32_t* __restrict__ last_ids,
                   const float* __restrict__ v_render, const float* __restrict__ v_alphas,
                   float* __restrict__ grad_slots, const int32_t* __restrict__ tile_order, ClassSel cls,
-                  const uint8_t* __restrict__ isect_reach, int32_t* __restrict__ any_record) {
+                  const uint8_t* __restrict__ isect_reach, int32_t* __restrict__ any_record, DecodeBwd db) {
     __shared__ BwdShared<CD> sh;
     if (cls.gated_off()) return;  // every cotangent of this pass is zero (uniform over the launch)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < 16) sh.zero16[threadIdx.x] = 0.f;
+    if constexpr (DECB) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *db.ticket = 0u;
+    }
     __syncthreads();
     const int slot = scheduled_tile(tile_order, n_groups, n_tiles_total, wv);
     if (slot < 0) return;
     if (slot & SCHED_HEAVY)  // workgroup-uniform: all 4 slots of a heavy workgroup carry the flag
-        composite_bwd<CD, 1, FILTER>(slot & ~SCHED_HEAVY, wv, wv, lane, sh, cls, tile_w, tile_h, width, height, records,
-                                     backgrounds, radii, cum_tiles, keep_scan, tile_offsets, flatten_ids,
-                                     render_alphas, last_ids, v_render, v_alphas, grad_slots, isect_reach, any_record);
+        composite_bwd<CD, 1, FILTER, DECB>(slot & ~SCHED_HEAVY, wv, wv, lane, sh, cls, tile_w, tile_h, width, height, records,
+                                           backgrounds, radii, cum_tiles, keep_scan, tile_offsets, flatten_ids,
+                                           render_alphas, last_ids, v_render, v_alphas, grad_slots, isect_reach, any_record,
+                                           db);
     else
-        composite_bwd<CD, 4, FILTER>(slot, 0, wv, lane, sh, cls, tile_w, tile_h, width, height, records, backgrounds,
-                                     radii, cum_tiles, keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids,
-                                     v_render, v_alphas, grad_slots, isect_reach, any_record);
+        composite_bwd<CD, 4, FILTER, DECB>(slot, 0, wv, lane, sh, cls, tile_w, tile_h, width, height, records, backgrounds,
+                                           radii, cum_tiles, keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids,
+                                           v_render, v_alphas, grad_slots, isect_reach, any_record, db);
 }
 
 
@@ -1915,12 +2081,13 @@ int mobgs_raster_fwd_decode(int C, int N, int channels, int width, int height, c
                            alphas, last_ids, isect_reach, tuning, stream, &dec);
 }
 
-int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int height, const float* records,
+static int raster_bwd_impl(int C, int N, int channels, int has_extra, int width, int height, const float* records,
                      const float* backgrounds, const int32_t* radii, const float* means2d,
                      const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
                      const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
                      const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
-                     const uint8_t* isect_reach, int32_t* any_record, const MobgsTuning* tuning, void* stream) {
+                     const uint8_t* isect_reach, int32_t* any_record, const MobgsTuning* tuning, void* stream,
+                     const DecodeBwd* db) {
     hipStream_t st = (hipStream_t)stream;
     const int g_all_reach = tuning_all_reach(tuning);
     (void)means2d;
@@ -1938,6 +2105,24 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
     ClassSel cls{0, 1, 0, g_all_reach};
     cls.static_rows = tuning_static_rows(tuning);
     cls.set_n = N > 0 ? N : 1;
+    cls.cover = tuning_cover_slots(tuning);
+    const bool quadrant_selected = (mobgs_raster_path(D, 0, nt, tuning) & 3) == 0;   // (what the dispatch below arrives at)
+    if (cls.cover && (!quadrant_selected || tuning_gate_zero_cotangent(tuning))) {
+        set_error("mobgs_raster_bwd: cover_slots needs the quadrant kernel and no zero-cotangent gate");
+        return MOBGS_E_UNSUPPORTED;
+    }
+    if (db) {   // decoder prologue: the quadrant kernel of the 9 + 1 channel pass (mobgs_raster_path tells beforehand)
+        if (D != 10 || !has_extra || !quadrant_selected) {
+            set_error("mobgs_raster_bwd_decode: needs 9 feature channels + the depth channel and the quadrant kernel "
+                      "(mobgs_raster_path(10, 0, n_tiles, tuning) & 3 == 0)");
+            return MOBGS_E_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL((raster_bwd_kernel<10, false, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
+                           tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan,
+                           tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots,
+                           tile_order, cls, isect_reach, any_record, *db);
+        return check_launch("raster_bwd_kernel(decode)");
+    }
     if (!bwd_blocks)
         cls.gate = arm_cotangent_gate(tuning, v_render, (size_t)C * height * width * D, v_alphas,
                                       (size_t)C * height * width, any_record, st);
@@ -1960,13 +2145,59 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
         hipLaunchKernelGGL((raster_bwd_kernel<CD, false>), dim3(grid), dim3(64 * TILES_PER_WG), 0, st, nt, n_groups,
                            tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles, keep_scan,
                            tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas, grad_slots,
-                           tile_order, cls, isect_reach, any_record);
+                           tile_order, cls, isect_reach, any_record, DecodeBwd{});
     });
     if (rc != MOBGS_OK) {
         set_error("mobgs_raster_bwd: %d total channels not compiled in", D);
         return rc;
     }
     return check_launch("raster_bwd_kernel");
+}
+
+int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int height, const float* records,
+                     const float* backgrounds, const int32_t* radii, const float* means2d,
+                     const int32_t* cum_tiles, const int32_t* keep_scan, const int32_t* tile_offsets,
+                     const int32_t* tile_order, const int32_t* flatten_ids, const float* render_alphas,
+                     const int32_t* last_ids, const float* v_render, const float* v_alphas, float* grad_slots,
+                     const uint8_t* isect_reach, int32_t* any_record, const MobgsTuning* tuning, void* stream) {
+    return raster_bwd_impl(C, N, channels, has_extra, width, height, records, backgrounds, radii, means2d, cum_tiles,
+                           keep_scan, tile_offsets, tile_order, flatten_ids, render_alphas, last_ids, v_render, v_alphas,
+                           grad_slots, isect_reach, any_record, tuning, stream, nullptr);
+}
+
+int mobgs_raster_bwd_decode(int C, int N, int width, int height, const float* records, const float* backgrounds,
+                            const int32_t* radii, const int32_t* cum_tiles, const int32_t* keep_scan,
+                            const int32_t* tile_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
+                            const float* render, const float* render_alphas, const int32_t* last_ids, const float* v_rgb,
+                            const float* v_depth, const float* v_alphas, const float* ray_intr, int intr_stride,
+                            const float* ray_c2w, int c2w_stride, const float* w1, const float* w2, float* grad_slots,
+                            const uint8_t* isect_reach, int32_t* any_record, float* w_partial, float* g_w1, float* g_w2,
+                            float* g_c2w, int g_c2w_floats, int accumulate_wgrad, const MobgsTuning* tuning,
+                            void* stream) {
+    if (!render || !v_rgb || !ray_intr || !ray_c2w || !w1 || !w2 || !w_partial || !g_w1 || !g_w2 ||
+        (g_c2w && g_c2w_floats != 12 && g_c2w_floats != 16)) {
+        set_error("mobgs_raster_bwd_decode: render, v_rgb, ray_intr, ray_c2w, w1, w2, w_partial, g_w1 and g_w2 are required "
+                  "(g_c2w: 12 or 16 floats per image)");
+        return MOBGS_E_INVALID;
+    }
+    if (C > 1 && g_c2w && c2w_stride == 0) {
+        set_error("mobgs_raster_bwd_decode: a pose shared by the images of a batch cannot receive a gradient");
+        return MOBGS_E_INVALID;
+    }
+    const int tiles = ((width + MOBGS_TILE - 1) / MOBGS_TILE) * ((height + MOBGS_TILE - 1) / MOBGS_TILE);
+    const DecodeBwd db{render, v_rgb, v_depth, ray_intr, ray_c2w, w1, w2, w_partial, decoder_wgrad_ticket(w_partial, C, tiles),
+                       intr_stride, c2w_stride};
+    const int rc = raster_bwd_impl(C, N, 9, 1, width, height, records, backgrounds, radii, nullptr, cum_tiles, keep_scan,
+                                   tile_offsets, tile_order, flatten_ids, render_alphas, last_ids, nullptr, v_alphas,
+                                   grad_slots, isect_reach, any_record, tuning, stream, &db);
+    if (rc != MOBGS_OK) return rc;
+    launch_decoder_wgrad_reduce(C, tiles, w_partial, g_w1, g_w2, g_c2w, g_c2w_floats, accumulate_wgrad, (hipStream_t)stream);
+    return check_launch("decoder_wgrad_reduce_kernel");
+}
+
+size_t mobgs_raster_bwd_decode_scratch_floats(int C, int width, int height) {
+    if (C <= 0 || width <= 0 || height <= 0) return 0;
+    return decoder_wgrad_scratch_floats(C, ((width + MOBGS_TILE - 1) / MOBGS_TILE) * ((height + MOBGS_TILE - 1) / MOBGS_TILE));
 }
 
 // class-restricted passes over the lists of the whole set: 10 total channels (the render() configuration) or 1 (the
@@ -2035,12 +2266,12 @@ int mobgs_raster_class_bwd(int C, int N, int Ns, int class_sel, int channels_tot
         hipLaunchKernelGGL((raster_bwd_kernel<10, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream,
                            nt, n_groups, tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles,
                            keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas,
-                           grad_slots, tile_order, cls, isect_reach, any_record);
+                           grad_slots, tile_order, cls, isect_reach, any_record, DecodeBwd{});
     else
         hipLaunchKernelGGL((raster_bwd_kernel<1, true>), dim3(grid), dim3(64 * TILES_PER_WG), 0, (hipStream_t)stream,
                            nt, n_groups, tile_w, tile_h, width, height, records, backgrounds, radii, cum_tiles,
                            keep_scan, tile_offsets, flatten_ids, render_alphas, last_ids, v_render, v_alphas,
-                           grad_slots, tile_order, cls, isect_reach, any_record);
+                           grad_slots, tile_order, cls, isect_reach, any_record, DecodeBwd{});
     return check_launch("raster_bwd_kernel(class)");
 }
 

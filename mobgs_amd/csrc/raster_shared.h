@@ -48,6 +48,9 @@ struct ClassSel {
     // splats -- colour features cat(f_dc, 0.0 * f_t) (/root/reference/scene/gaussian_model.py:244-246), flow channels
     // identically zero -- whose dead channels the caller neither fills nor wants a gradient for (dead_channels<CD>)
     int static_rows = 0, set_n = 1;
+    // backward passes only (MobgsTuning.cover_slots, round 6): the caller did NOT zero-fill grad_slots -- the kernel writes
+    // the slot of EVERY entry of its lists (zeros where no pixel blended the splat)
+    int cover = 0;
     __device__ __forceinline__ bool gated_off() const { return gate && *gate == 0; }
     __device__ __forceinline__ bool keeps(int flat_id) const { return sel == 0 || (((flat_id % N) < Ns) == (sel == 1)); }
     __device__ __forceinline__ bool static_row(int flat_id) const {

@@ -393,20 +393,25 @@ _variant_copies = {}
 STATIC_ROWS = os.environ.get("MOBGS_STATIC_ROWS", "1") != "0"
 
 
-def _tuning_variant(gated: bool, static_rows: int = 0):
-    """`tuning` with the zero-cotangent gate on and / or the static row count of the node (both are properties of the
-    node, not of the module); copies are cached per (fields of `tuning`, gate, rows)."""
+# MobgsTuning.cover_slots (round 6): the plain backward pass on the quadrant kernel writes every gradient slot itself -- no
+# zero fill of the slot buffer (108 MB per 1352x1014 render).  0: the fill, as before (A/B; gradients are bit-identical)
+COVER_SLOTS = os.environ.get("MOBGS_COVER_SLOTS", "1") != "0"
+
+
+def _tuning_variant(gated: bool, static_rows: int = 0, cover: bool = False):
+    """`tuning` with the zero-cotangent gate on and / or the static row count of the node and / or cover_slots (all are
+    properties of the node, not of the module); copies are cached per (fields of `tuning`, gate, rows, cover)."""
     static_rows = int(static_rows) if STATIC_ROWS else 0
-    if not gated and static_rows <= 0:
+    if not gated and static_rows <= 0 and not cover:
         return tuning
     key = (tuning.heavy_tile_len, tuning.longest_list_hint, tuning.quadrant_culling, tuning.block_walk,
-           tuning.bwd_block_walk, tuning.bwd_mfma, bool(gated), static_rows)
+           tuning.bwd_block_walk, tuning.bwd_mfma, bool(gated), static_rows, bool(cover))
     t = _variant_copies.get(key)
     if t is None:
         if len(_variant_copies) > 64:
             _variant_copies.clear()
         t = _variant_copies[key] = tuning.copy(geometry_per_camera=0, gate_zero_cotangent=1 if gated else 0,
-                                               static_rows=max(static_rows, 0))
+                                               static_rows=max(static_rows, 0), cover_slots=1 if cover else 0)
     return t
 
 
@@ -600,10 +605,14 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, extra, backgrounds, radii, tl: TileLists, width, height,
-                packed=None, dec=None, static_rows=0):
+                packed=None, dec=None, static_rows=0, dec_c2w=None, dec_w1=None, dec_w2=None):
         """dec = (intr, c2w, w1, w2) (detached, float32, contiguous): the Sandwich decoder runs as the kernel's epilogue
         (mobgs_raster_fwd_decode) and the node returns (render, alphas, rgb, depth) -- rgb / depth non-differentiable here:
         ops.Decode takes them as its precomputed outputs and owns their backward pass.
+        dec_c2w / dec_w1 / dec_w2 (round 6, FUSE_DECODER_BWD): the caller's pose and weight TENSORS -- rgb / depth are then
+        differentiable outputs of THIS node and its backward pass runs the decoder's backward as the prologue of the backward
+        compositor (mobgs_raster_bwd_decode: no decoder launch, no cotangent image in memory) whenever only rgb / depth
+        carry cotangents and the quadrant kernel is the selection; else decoder_bwd runs as a launch of its own.
         static_rows = S > 0: the first S splats are the reference's STATIC set (include/mobgs_hip.h
         MobgsTuning.static_rows: colour channels 6.. structurally zero, their gradient multiplied by 0.0 downstream) --
         the backward compositor takes the short blend body for their entries and returns zeros for those channels."""
@@ -669,7 +678,11 @@ class _Rasterize(torch.autograd.Function):
                 if tl.defer or not tl.resolve():
                     break
         _log_path("fwd", D, tl, decode=dec is not None)
-        ctx.save_for_backward(records, bg, radii, means2d, alphas, last_ids, reach)
+        dec_fused = dec is not None and dec_w1 is not None
+        if dec_fused:   # (+ the decoder's inputs: the composited image -- an output, saved the way outputs are -- and weights)
+            ctx.save_for_backward(records, bg, radii, means2d, alphas, last_ids, reach, render, *dec)
+        else:
+            ctx.save_for_backward(records, bg, radii, means2d, alphas, last_ids, reach)
         ctx.set_materialize_grads(False)  # an output nothing back-propagates through costs no zero image
         ctx.tl = tl
         ctx.arena = tl.flatten_arena  # the lists `reach` belongs to (a rebuild replaces the arena)
@@ -677,15 +690,44 @@ class _Rasterize(torch.autograd.Function):
         ctx.bg_needs_grad = backgrounds is not None and backgrounds.requires_grad
         ctx.gate = _zero_gate[0]
         ctx.static_rows = int(static_rows) if D in (10, 12) else 0
+        ctx.dec_fused = dec_fused
+        if ctx.dec_fused:
+            ctx.dec_w_inputs = (dec_w1, dec_w2)          # the caller's tensor objects (a LeafGradSink knows them by identity)
+            ctx.dec_c2w_needs_grad = dec_c2w is not None and ctx.needs_input_grad[13]
+            ctx.dec_c2w_shape = tuple(dec_c2w.shape) if dec_c2w is not None else None
+            return render, alphas.unsqueeze(-1), rgb, dec_depth
         if dec is not None:
             ctx.mark_non_differentiable(rgb, dec_depth)
             return render, alphas.unsqueeze(-1), rgb, dec_depth
         return render, alphas.unsqueeze(-1)
 
     @staticmethod
-    def backward(ctx, v_render, v_alphas, *_unused):
+    def _decoder_bwd_separately(ctx, alphas, v_rgb, v_depth):
+        """decoder_bwd as a launch of its own (ops.Decode's backward on this node's saved state) -> (v_feat [C,H,W,10],
+        v_alphas [C,H,W], g_c2w | None, g_w1 | None, g_w2 | None)."""
+        from types import SimpleNamespace
+        from . import ops
+        render, intr, c2w, w1, w2 = ctx.saved_tensors[7:12]
+        C, H, W = alphas.shape
+        lead = (C,) if C > 1 else ()
+        feat = render.reshape(*lead, H, W, 10)
+        c2w_d = c2w if (C > 1 or c2w.dim() == 2) else c2w.reshape(c2w.shape[-2:])
+        fake = SimpleNamespace(saved_tensors=(feat, alphas.reshape(*lead, H, W), None, intr.reshape(-1) if C == 1 else intr,
+                                              c2w_d, w1, w2),
+                               has_depth=True, w_inputs=ctx.dec_w_inputs, feat_shape=feat.shape, rays_need_grad=False,
+                               c2w_needs_grad=ctx.dec_c2w_needs_grad)
+        if v_rgb is not None:
+            v_rgb = v_rgb.reshape(*lead, 3, H, W)
+        if v_depth is not None:
+            v_depth = v_depth.reshape(*lead, H, W)
+        g = ops.Decode.backward(fake, v_rgb, v_depth)
+        g_c2w = g[4].reshape(ctx.dec_c2w_shape) if g[4] is not None else None
+        return g[0].reshape(C, H, W, 10), g[1].reshape(C, H, W), g_c2w, g[5], g[6]
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas, v_rgb=None, v_depth=None):
         lib = _lib_()
-        records, bg, radii, means2d, alphas, last_ids, reach = ctx.saved_tensors
+        records, bg, radii, means2d, alphas, last_ids, reach = ctx.saved_tensors[:7]
         tl = ctx.tl
         if tl.flatten_arena is not ctx.arena:  # lists rebuilt after this forward ran (deferred resolve): recompute
             reach = None
@@ -693,29 +735,105 @@ class _Rasterize(torch.autograd.Function):
         dev = records.device
         D = channels + (1 if has_extra else 0)
         stride = records.shape[1]
-        if v_render is None and v_alphas is None:
-            return (None,) * 13
-        if v_render is None:  # only the alpha output was used
-            v_render = torch.zeros(C, height, width, D, dtype=torch.float32, device=dev)
+        if not ctx.dec_fused:
+            v_rgb = v_depth = None
+        if v_render is None and v_alphas is None and v_rgb is None and v_depth is None:
+            return (None,) * 16
         F = _fast.get()
         gated = bool(ctx.gate) and tuning.bwd_block_walk != 1
-        tn = _tuning_variant(gated, ctx.static_rows)
-        _log_path("bwd", D, tl, tn=tn, static_rows=tn.static_rows)
-        if F is not None:  # the same body in C++ (csrc/fastpath.cpp)
+        nt = tl.C * tl.tile_w * tl.tile_h
+        quadrant = tuning.bwd_block_walk != 1 and (lib.mobgs_raster_path(D, 0, nt, tuning.ref()) & 3) == 0
+        cover = COVER_SLOTS and quadrant and not gated   # the kernel writes every slot: no zero fill, no flag
+        tn = _tuning_variant(gated, ctx.static_rows, cover)
+        g_c2w = g_w1 = g_w2 = None
+        slots = None
+        if v_rgb is not None or v_depth is not None:
+            fuse = v_render is None and not ctx.bg_needs_grad and not gated and quadrant
+            if fuse:   # the decoder's backward pass inside the backward compositor
+                from . import ops
+                render, intr, c2w, w1, w2 = ctx.saved_tensors[7:12]
+                sunk = ops._active_sink.decoder_buffers(*ctx.dec_w_inputs) if ops._active_sink is not None else None
+                _log_path("bwd", D, tl, tn=tn, static_rows=tn.static_rows, decode_bwd=True)
+                va = v_alphas.reshape(C, height, width) if v_alphas is not None else None
+                with profiler.region("raster_bwd"):
+                    if F is not None:
+                        slots, g_c2w, g_w1, g_w2 = F.raster_bwd_decode(
+                            C, N, width, height, tl.n_isects, records, bg, radii, tl.cum_tiles, tl.keep_scan,
+                            tl.tile_offsets, tl.tile_order, tl.flatten_ids, render, alphas, last_ids, v_rgb, v_depth, va,
+                            intr, c2w, w1, w2, reach, bool(ctx.dec_c2w_needs_grad), sunk[0] if sunk is not None else None,
+                            sunk[1] if sunk is not None else None, sunk[2] if sunk is not None else 0, tn.address(),
+                            stream_int(), cover)
+                    else:
+                        v_rgb_c = f32c(v_rgb) if v_rgb is not None else torch.zeros(C, 3, height, width, dtype=torch.float32,
+                                                                                    device=dev)
+                        v_depth_c = f32c(v_depth) if v_depth is not None else None
+                        va = f32c(va) if va is not None else None
+                        rows = max(tl.n_isects, 1)
+                        slots = (torch.empty if cover else torch.zeros)(rows + 1, stride, dtype=torch.float32, device=dev)
+                        flag = None if cover else ctypes.c_void_p(slots.data_ptr() + 4 * rows * stride)
+                        partial = torch.empty(lib.mobgs_raster_bwd_decode_scratch_floats(C, width, height),
+                                              dtype=torch.float32, device=dev)
+                        if sunk is not None:
+                            g_w1, g_w2, accumulate = sunk
+                        else:
+                            g_w1, g_w2, accumulate = torch.empty_like(w1), torch.empty_like(w2), 0
+                        g_c2w = torch.empty_like(c2w) if ctx.dec_c2w_needs_grad else None
+                        istr = 4 if (C > 1 and intr.numel() == 4 * C) else 0
+                        cstr = (c2w.numel() // C) if (C > 1 and c2w.dim() == 3) else 0
+                        check(lib.mobgs_raster_bwd_decode(
+                            C, N, width, height, ptr(records), ptr(bg), ptr(radii), ptr(tl.cum_tiles), ptr(tl.keep_scan),
+                            ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(render), ptr(alphas),
+                            ptr(last_ids), ptr(v_rgb_c), ptr(v_depth_c), ptr(va), ptr(intr), istr, ptr(c2w), cstr, ptr(w1),
+                            ptr(w2), ptr(slots), ptr(reach), flag, ptr(partial), ptr(g_w1), ptr(g_w2), ptr(g_c2w),
+                            (g_c2w.numel() // (C if cstr else 1)) if g_c2w is not None else 0, accumulate, tn.ref(),
+                            stream()), "mobgs_raster_bwd_decode")
+                if g_c2w is not None:
+                    g_c2w = g_c2w.reshape(ctx.dec_c2w_shape)
+                if sunk is not None:
+                    g_w1 = g_w2 = None
+            else:      # some other output carries a cotangent too (or another kernel is selected): decoder_bwd by itself
+                v_feat, v_a_dec, g_c2w, g_w1, g_w2 = _Rasterize._decoder_bwd_separately(ctx, alphas, v_rgb, v_depth)
+                v_render = v_feat if v_render is None else v_render + v_feat
+                v_a_dec = v_a_dec.reshape(C, height, width, 1)
+                v_alphas = v_a_dec if v_alphas is None else v_alphas + v_a_dec
+        if slots is None and v_render is None:  # only the alpha output was used
+            v_render = torch.zeros(C, height, width, D, dtype=torch.float32, device=dev)
+        if slots is None:
+            _log_path("bwd", D, tl, tn=tn, static_rows=tn.static_rows)
+        if slots is not None:
+            st = stream_int()
+            if F is not None:
+                v_means2d, v_conics, v_opac, v_colors, v_extra = F.raster_bwd_reduce(
+                    C, N, channels, int(has_extra), records, tl.cum_tiles, tl.keep_scan, slots, st, tl.tiles_per_gauss,
+                    not cover)
+            else:
+                rows = max(tl.n_isects, 1)
+                flag = None if cover else ctypes.c_void_p(slots.data_ptr() + 4 * rows * stride)
+                v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+                v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+                v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
+                v_colors = torch.empty(C, N, channels, dtype=torch.float32, device=dev)
+                v_extra = torch.empty(C, N, dtype=torch.float32, device=dev) if has_extra else None
+                check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(records), ptr(tl.cum_tiles),
+                                                  ptr(tl.keep_scan), ptr(slots), flag, ptr(v_means2d), ptr(v_conics),
+                                                  ptr(v_opac), ptr(v_colors), ptr(v_extra), ptr(tl.tiles_per_gauss),
+                                                  stream()), "mobgs_raster_bwd_reduce")
+        elif F is not None:  # the same body in C++ (csrc/fastpath.cpp)
             st = stream_int()
             with profiler.region("raster_bwd"):
                 slots = F.raster_bwd(C, N, channels, int(has_extra), width, height, tl.n_isects, records, bg, radii,
                                      means2d, tl.cum_tiles, tl.keep_scan, tl.tile_offsets, tl.tile_order,
-                                     tl.flatten_ids, alphas, last_ids, v_render, v_alphas, reach, tn.address(), st)
+                                     tl.flatten_ids, alphas, last_ids, v_render, v_alphas, reach, tn.address(), st, cover)
             v_means2d, v_conics, v_opac, v_colors, v_extra = F.raster_bwd_reduce(
-                C, N, channels, int(has_extra), records, tl.cum_tiles, tl.keep_scan, slots, st, tl.tiles_per_gauss)
+                C, N, channels, int(has_extra), records, tl.cum_tiles, tl.keep_scan, slots, st, tl.tiles_per_gauss,
+                not cover)
         else:
             v_render = f32c(v_render)
             v_alphas = f32c(v_alphas) if v_alphas is not None else None
             # one extra row: its first word is the any_record flag of include/mobgs_hip.h (zeroed by the same fill)
             rows = max(tl.n_isects, 1)
-            slots = torch.zeros(rows + 1, stride, dtype=torch.float32, device=dev)
-            flag = ctypes.c_void_p(slots.data_ptr() + 4 * rows * stride)
+            slots = (torch.empty if cover else torch.zeros)(rows + 1, stride, dtype=torch.float32, device=dev)
+            flag = None if cover else ctypes.c_void_p(slots.data_ptr() + 4 * rows * stride)
             v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
             v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
             v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
@@ -738,7 +856,8 @@ class _Rasterize(torch.autograd.Function):
         v_bg = None
         if ctx.bg_needs_grad:
             v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
-        return v_means2d, v_conics, v_colors, v_opac, v_extra, v_bg, None, None, None, None, None, None, None
+        return (v_means2d, v_conics, v_colors, v_opac, v_extra, v_bg, None, None, None, None, None, None, None,
+                g_c2w, g_w1, g_w2)
 
 
 class _RasterizeClassAlpha(torch.autograd.Function):
@@ -945,6 +1064,10 @@ class _RasterizeLayers(torch.autograd.Function):
 # True: render() lets the forward compositor decode its own image (SharedProjection.composite_decode); False: a separate
 # decoder launch, as before round 5 (A/B; results are bit-identical)
 FUSE_DECODER = os.environ.get("MOBGS_FUSE_DECODER", "1") != "0"
+# True (round 6): the backward half too -- rgb / depth are outputs of the compositing node itself and the decoder's backward
+# pass is the prologue of the backward compositor (mobgs_raster_bwd_decode); False: ops.Decode owns it (a launch of its
+# own + a 55-MB cotangent image).  Splat gradients are bit-identical either way, weight / pose gradients to summation order.
+FUSE_DECODER_BWD = os.environ.get("MOBGS_FUSE_DECODER_BWD", "1") != "0"
 # True: static-only / dynamic-only images (without the combined one) come from two class-restricted passes of the
 # single-set compositor over the combined lists (every splat belongs to exactly one class, so together they do the
 # work of ONE pass and share one gradient-slot buffer); False: from the generic 3-layer kernel
@@ -1479,6 +1602,14 @@ class SharedProjection:
             rgb, depth = decode(img, alphas, rays, w1, w2, True)
             return img, alphas, rgb, depth
         dec = (f32c(intr.detach()), f32c(c2w.detach()), f32c(w1.detach()), f32c(w2.detach()))
+        if FUSE_DECODER_BWD:
+            img, alphas, rgb, depth = _Rasterize.apply(self.means2d_main, self.conics, colors, self.opacities, self.depths,
+                                                       self._bg(backgrounds), self.radii, self.tl, self.width,
+                                                       self.height, self._packed_for(colors), dec, self.static_rows,
+                                                       c2w, w1, w2)
+            if C == 1:   # (views, not [0]: a select's backward is a zero image + a copy)
+                rgb, depth = rgb.view(3, self.height, self.width), depth.view(self.height, self.width)
+            return img, alphas, rgb, depth
         img, alphas, rgb0, depth0 = _Rasterize.apply(self.means2d_main, self.conics, colors, self.opacities, self.depths,
                                                      self._bg(backgrounds), self.radii, self.tl, self.width, self.height,
                                                      self._packed_for(colors), dec, self.static_rows)

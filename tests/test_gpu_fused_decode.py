@@ -41,6 +41,7 @@ def test_render_with_the_decoder_epilogue_is_bit_identical(hip_device, W, H, ns,
     res = {}
     for fused in (False, True):
         R.FUSE_DECODER = fused
+        R.FUSE_DECODER_BWD = False   # (the backward half has its own file: weight gradients there agree to rounding)
         try:
             cam, stat, dyn, _ = _scene(dev, W, H, ns, nd)
             cam.world_view_transform.requires_grad_(True)
@@ -52,6 +53,7 @@ def test_render_with_the_decoder_epilogue_is_bit_identical(hip_device, W, H, ns,
                           out["viewspace_points"].grad.clone()]
         finally:
             R.FUSE_DECODER = True
+            R.FUSE_DECODER_BWD = True
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
     # ... on the kernels the grid size is meant to select (asserted, not assumed)
@@ -102,6 +104,7 @@ def test_render_many_with_the_decoder_epilogue_is_bit_identical(hip_device):
     res = {}
     for fused in (False, True):
         R.FUSE_DECODER = fused
+        R.FUSE_DECODER_BWD = False
         try:
             cam, stat, dyn, scam = _scene(dev, W, H, 8_000, 4_000)
             cams = []
@@ -121,5 +124,6 @@ def test_render_many_with_the_decoder_epilogue_is_bit_identical(hip_device):
                 [c.world_view_transform.grad.clone() for c in cams]
         finally:
             R.FUSE_DECODER = True
+            R.FUSE_DECODER_BWD = True
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
