@@ -158,7 +158,19 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-PMC_JSON = os.path.join(ROOT, "profiles", "r05_raster_bwd_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r06_raster_bwd_pmc.json")
+
+
+def raster_bwd_bytes(I, P):
+    """Algorithmic bytes of the lean step's backward compositor per launch -> (total, per-pixel
+    streaming part, what).  Per intersection 4 (id) + 64 (splat record) gathered + 64 (gradient record) written.  Per pixel,
+    with the decoder's backward pass as the kernel's prologue (round 6, rendering.FUSE_DECODER_BWD): 40 (composited
+    features) + 12 (cotangent of the decoded colour) + 4 (of the depth) + 4 (alpha) + 4 (last id) = 64 read; without it:
+    40 (cotangent image) + 4 (alpha cotangent) + 4 + 4 = 52."""
+    import mobgs_amd.rendering as _R
+    per_px = 64.0 if (_R.FUSE_DECODER_BWD and _R.FUSE_DECODER) else 52.0
+    return 132.0 * I + per_px * P, per_px * P, ("132 I + 64 P (decoder backward as the prologue)" if per_px == 64.0
+                                                 else "132 I + 52 P")
 
 
 def _rocprof_child(extra, tag, child_args):
@@ -221,11 +233,12 @@ def kernel_breakdown(args, N, Ns, Nd, I, I_box, P):
         ("tile_sort", "tile_sort", 12.0 * I),          # 8-byte key in, 4-byte id out
         # (+ the decoder epilogue of the lean render: 16 B per pixel of rgb + depth on top of the 48)
         ("raster_fwd(+decode)", "raster_fwd", 68.0 * I + 64.0 * P),
-        ("raster_bwd", "raster_bwd", 132.0 * I + 52.0 * P),
+        ("raster_bwd(+decoder_bwd prologue)", "raster_bwd", raster_bwd_bytes(I, P)[0]),
         ("slot_reduce", "slot_reduce", 64.0 * I + 64.0 * N),
         ("slot_zero_fill", "FillFunctor", 64.0 * I),
         ("decoder_fwd", "decoder_fwd_kernel", 84.0 * P),
         ("decoder_bwd", "decoder_bwd_kernel", 132.0 * P),
+        ("decoder_wgrad_reduce", "decoder_wgrad_reduce", None),
     ]
     rows = list(csv.DictReader(open(f)))
     total_ns = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -284,9 +297,8 @@ def collect_pmc(args, I, P):
         import shutil
         shutil.rmtree(out, ignore_errors=True)
     fetch, write = vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
-    stream = 52.0 * P
-    alg = 132.0 * I + 52.0 * P
-    d = {"source_sha": source_sha(), "kernel": "raster_bwd_kernel<10, false>",
+    alg, stream, what = raster_bwd_bytes(I, P)
+    d = {"source_sha": source_sha(), "kernel": "raster_bwd_kernel<10, false, DECB>", "algorithmic_bytes_formula": what,
          "source": "bench.py --pmc: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU (three separate passes over "
                    "bench.py --steps 10 --warmup 2 --breakdown-child)",
          "FETCH_SIZE_KiB_per_launch_raw": vals["FETCH_SIZE"], "WRITE_SIZE_KiB_per_launch_raw": vals["WRITE_SIZE"],
@@ -892,9 +904,10 @@ def main():
             # algorithmic bytes of raster_bwd per launch (DESIGN.md "Kernels"): per intersection 4 (id) + 64 (splat
             # record) gathered + 64 (gradient record) written; per pixel 40 (v_render) + 4 (v_alpha) + 4 (alpha)
             # + 4 (last_id) read
-            alg_bytes = 132.0 * I + 52.0 * P
+            alg_bytes, _, alg_what = raster_bwd_bytes(I, P)
             achieved = alg_bytes / (rb["avg_ms"] * 1e-3) / 1e9
-            roof = {"kernel": "raster_bwd_kernel<10>", "bound": "hbm", "achieved": round(achieved, 2),
+            roof = {"kernel": "raster_bwd_kernel<10>", "algorithmic_bytes_formula": alg_what, "bound": "hbm",
+                    "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "avg_kernel_ms": round(rb["avg_ms"], 4), "algorithmic_bytes": alg_bytes, "calls": rb["calls"]}
             # counter-derived figures are attached only when the committed PMC summary was collected with exactly
@@ -923,7 +936,7 @@ def main():
                                             "frac_of_fp32_vector_issue_peak": round(lane_ops / (F32_VECTOR_PEAK_TF
                                                                                                  * 1e12 / 2), 4)}
                     else:
-                        roof["traffic_note"] = ("profiles/r05_raster_bwd_pmc.json is from other kernel sources: ignored "
+                        roof["traffic_note"] = ("profiles/r06_raster_bwd_pmc.json is from other kernel sources: ignored "
                                                 "(python bench.py --pmc re-collects it)")
                 except Exception:  # noqa: BLE001
                     pass

@@ -441,10 +441,11 @@ int mobgs_raster_bwd(int C, int N, int channels, int has_extra, int width, int h
  * wrote), `render_alphas`, the cotangents v_rgb [C,3,H,W] of the decoded colour and v_depth [C,H,W] (NULL = none) of the
  * expected depth -- and forms the cotangent of the composited image in registers (bit for bit what mobgs_decoder_bwd
  * would have written to v_feat_hw / v_alphas; v_alphas here = an ADDITIONAL cotangent of the alpha output, NULL = none).
- * Weight gradients g_w1 [6,12], g_w2 [3,6] (accumulate_wgrad != 0: added to what is there) and the pose gradient
- * g_c2w [C, g_c2w_floats = 12 | 16] (NULL = not wanted) are fully written from w_partial (scratch of
- * mobgs_raster_bwd_decode_scratch_floats(C, width, height) floats, contents irrelevant on entry: one row of 102 sums per
- * tile, then chunk sums and a ticket word; summed in a fixed order: deterministic).  Only where the quadrant kernel is the
+ * The weight and pose gradients leave the kernel as ONE row of 102 sums per tile in w_partial (scratch of
+ * mobgs_raster_bwd_decode_scratch_floats(C, width, height) floats, contents irrelevant on entry: the rows, then chunk sums
+ * and a ticket word); mobgs_raster_bwd_decode_finish -- any time later on the same stream -- adds them in a fixed order
+ * (deterministic) into g_w1 [6,12], g_w2 [3,6] (accumulate_wgrad != 0: added to what is there; sums over all images) and
+ * g_c2w [C, g_c2w_floats = 12 | 16] (NULL = not wanted; per image, fully written).  Only where the quadrant kernel is the
  * selection ((mobgs_raster_path(10, 0, n_tiles, tuning) & 3) == 0), else MOBGS_E_UNSUPPORTED: callers then run
  * mobgs_decoder_bwd + mobgs_raster_bwd.  Everything else as mobgs_raster_bwd (channels = 9, has_extra = 1). */
 int mobgs_raster_bwd_decode(int C, int N, int width, int height, const float* records, const float* backgrounds,
@@ -453,9 +454,18 @@ int mobgs_raster_bwd_decode(int C, int N, int width, int height, const float* re
                             const float* render, const float* render_alphas, const int32_t* last_ids, const float* v_rgb,
                             const float* v_depth, const float* v_alphas, const float* ray_intr, int intr_stride,
                             const float* ray_c2w, int c2w_stride, const float* w1, const float* w2, float* grad_slots,
-                            const uint8_t* isect_reach, int32_t* any_record, float* w_partial, float* g_w1, float* g_w2,
-                            float* g_c2w, int g_c2w_floats, int accumulate_wgrad, const MobgsTuning* tuning,
+                            const uint8_t* isect_reach, int32_t* any_record, float* w_partial, const MobgsTuning* tuning,
                             void* stream);
+int mobgs_raster_bwd_decode_finish(int C, int width, int height, float* w_partial, int c2w_stride, float* g_w1,
+                                   float* g_w2, float* g_c2w, int g_c2w_floats, int accumulate_wgrad, void* stream);
+/* mobgs_raster_bwd_reduce (channels = 9, has_extra = 1) and mobgs_raster_bwd_decode_finish in ONE launch: the weight / pose
+ * sums run as extra leading workgroups of the slot reduction (no launch of their own).  Same results as the two calls
+ * (weight / pose gradients to summation order). */
+int mobgs_raster_bwd_reduce_decode(int C, int N, const float* records, const int32_t* cum_tiles, const int32_t* keep_scan,
+                                   const float* grad_slots, const int32_t* any_record, float* v_means2d, float* v_conics,
+                                   float* v_opacities, float* v_colors, float* v_extra, const int32_t* tiles_per_gauss,
+                                   int width, int height, const float* w_partial, int c2w_stride, float* g_w1, float* g_w2,
+                                   float* g_c2w, int g_c2w_floats, int accumulate_wgrad, void* stream);
 size_t mobgs_raster_bwd_decode_scratch_floats(int C, int width, int height);
 /* tiles_per_gauss (optional, else NULL): [C*N] -- splat g's intersections are then [cum_tiles[g], cum_tiles[g] +
  *     tiles_per_gauss[g]) instead of [cum_tiles[g], cum_tiles[g + 1]): REQUIRED when the lists were built with an enum_order

@@ -14,7 +14,7 @@ from . import _lib
 from .build import FAST_PATH, build_fastpath, fastpath_is_stale
 
 _SYMBOLS = ("mobgs_abi_version", "mobgs_project_and_bin_fused", "mobgs_prep_project_and_bin_fused", "mobgs_decoder_fwd_channels", "mobgs_decoder_bwd_channels", "mobgs_project_prep_bwd_fused", "mobgs_fused_seg_keys_len", "mobgs_last_error", "mobgs_record_stride", "mobgs_prep_fwd_many", "mobgs_prep_fwd_many_f16",
-            "mobgs_prep_bwd_many", "mobgs_prep_bwd_many_f16", "mobgs_raster_fwd", "mobgs_raster_fwd_decode", "mobgs_raster_bwd", "mobgs_raster_bwd_decode", "mobgs_raster_bwd_decode_scratch_floats", "mobgs_raster_bwd_reduce",
+            "mobgs_prep_bwd_many", "mobgs_prep_bwd_many_f16", "mobgs_raster_fwd", "mobgs_raster_fwd_decode", "mobgs_raster_bwd", "mobgs_raster_bwd_decode", "mobgs_raster_bwd_decode_scratch_floats", "mobgs_raster_bwd_decode_finish", "mobgs_raster_bwd_reduce_decode", "mobgs_raster_bwd_reduce",
             "mobgs_decoder_fwd_many", "mobgs_decoder_bwd_many", "mobgs_decoder_bwd_blocks", "mobgs_project_bwd",
             "mobgs_project_bwd_ex",
             "mobgs_project_bwd_scratch_floats", "mobgs_project_and_bin_speculative", "mobgs_tile_order_len",

@@ -77,8 +77,9 @@ _SIGS = {
     "mobgs_raster_fwd_decode": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, P, P,
                                         P, P, P, P, P, c_int, P, c_int, P, P, P, P, P, P]),
     "mobgs_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int] + [P] * 16 + [P, P]),
-    "mobgs_raster_bwd_decode": (c_int, [c_int, c_int, c_int, c_int] + [P] * 15 + [c_int, P, c_int] + [P] * 9 +
-                                [c_int, c_int, P, P]),
+    "mobgs_raster_bwd_decode": (c_int, [c_int, c_int, c_int, c_int] + [P] * 15 + [c_int, P, c_int] + [P] * 6 + [P, P]),
+    "mobgs_raster_bwd_decode_finish": (c_int, [c_int, c_int, c_int, P, c_int, P, P, P, c_int, c_int, P]),
+    "mobgs_raster_bwd_reduce_decode": (c_int, [c_int, c_int] + [P] * 11 + [c_int, c_int, P, c_int, P, P, P, c_int, c_int, P]),
     "mobgs_raster_bwd_decode_scratch_floats": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "mobgs_cotangent_probe": (c_int, [c_int, P, P, P, P]),
     "mobgs_raster_bwd_reduce": (c_int, [c_int, c_int, c_int, c_int] + [P] * 11 + [P]),

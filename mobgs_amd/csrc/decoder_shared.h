@@ -195,6 +195,52 @@ __device__ __forceinline__ void sandwich_backward(const float* __restrict__ w1, 
     }
 }
 
+// One output element of the weight / pose gradient, by ONE workgroup of 256 threads: the fixed-order sum of column k of the
+// partial rows [n_images * rows_per_image, 102] (rows of decoder_bwd_kernel or of the backward compositor's prologue) --
+// k < 72: g_w1, < 90: g_w2 (over the rows of ALL images, by the workgroups with img = 0), < 102: the pose of image img (its
+// own rows), 102..105: the fourth row of a 4 x 4 pose gradient (zeros).  Slow per workgroup (a strided column), which is why
+// it runs BESIDE something else: as extra leading workgroups of the gradient-slot reduction (raster.hip, slot_reduce16).
+struct WgradFinish {
+    const float* w_partial = nullptr;
+    float *g_w1 = nullptr, *g_w2 = nullptr, *g_c2w = nullptr;
+    int rows_per_image = 0, n_images = 0, accumulate = 0, c2w_floats = 0;
+};
+constexpr int WGRAD_NRED = 102;
+__host__ __device__ inline int wgrad_finish_outputs(const WgradFinish& f) {
+    return WGRAD_NRED + ((f.g_c2w && f.c2w_floats == 16) ? 4 : 0);
+}
+__device__ inline void wgrad_column_sum(const WgradFinish& f, int k, int img) {
+    float* g_c2w = f.g_c2w ? f.g_c2w + (size_t)img * f.c2w_floats : nullptr;
+    if (k >= WGRAD_NRED) {
+        if (threadIdx.x == 0) g_c2w[k - 90] = 0.f;
+        return;
+    }
+    int first = 0, count = f.rows_per_image * f.n_images;   // weights: every row
+    if (k >= 90) {                                            // pose: the rows of this image
+        first = img * f.rows_per_image;
+        count = f.rows_per_image;
+    } else if (img != 0) {
+        return;
+    }
+    const float* wp = f.w_partial + (size_t)first * WGRAD_NRED;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < count; b += 256) s += wp[(size_t)b * WGRAD_NRED + k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    __shared__ float wgrad_red[4];
+    if ((threadIdx.x & 63) == 0) wgrad_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = wgrad_red[0] + wgrad_red[1] + wgrad_red[2] + wgrad_red[3];
+        if (k < 72)
+            f.g_w1[k] = f.accumulate ? f.g_w1[k] + t : t;
+        else if (k < 90)
+            f.g_w2[k - 72] = f.accumulate ? f.g_w2[k - 72] + t : t;
+        else if (g_c2w)
+            g_c2w[k - 90] = t;
+    }
+}
+
 // decoder.hip: sums the partial rows the backward compositor's decoder prologue left at the start of `scratch`
 // ([C * rows_per_image, 102], decoder_bwd_kernel's row layout) in a fixed order into g_w1 [6,12], g_w2 [3,6] (over all
 // images; accumulate != 0: added to what is there) and g_c2w [C, g_c2w_floats] (per image; may be NULL).  `scratch` holds

@@ -37,6 +37,8 @@ struct Api {
     decltype(&mobgs_raster_bwd) raster_bwd = nullptr;
     decltype(&mobgs_raster_bwd_decode) raster_bwd_decode = nullptr;
     decltype(&mobgs_raster_bwd_decode_scratch_floats) raster_bwd_decode_scratch_floats = nullptr;
+    decltype(&mobgs_raster_bwd_decode_finish) raster_bwd_decode_finish = nullptr;
+    decltype(&mobgs_raster_bwd_reduce_decode) raster_bwd_reduce_decode = nullptr;
     decltype(&mobgs_raster_bwd_reduce) raster_bwd_reduce = nullptr;
     decltype(&mobgs_decoder_fwd_channels) decoder_fwd = nullptr;
     decltype(&mobgs_decoder_bwd_channels) decoder_bwd = nullptr;
@@ -81,6 +83,8 @@ void bind(const std::unordered_map<std::string, uint64_t>& m) {
     take(m, "mobgs_raster_bwd", api.raster_bwd);
     take(m, "mobgs_raster_bwd_decode", api.raster_bwd_decode);
     take(m, "mobgs_raster_bwd_decode_scratch_floats", api.raster_bwd_decode_scratch_floats);
+    take(m, "mobgs_raster_bwd_decode_finish", api.raster_bwd_decode_finish);
+    take(m, "mobgs_raster_bwd_reduce_decode", api.raster_bwd_reduce_decode);
     take(m, "mobgs_raster_bwd_reduce", api.raster_bwd_reduce);
     take(m, "mobgs_decoder_fwd_channels", api.decoder_fwd);
     take(m, "mobgs_decoder_bwd_channels", api.decoder_bwd);
@@ -281,16 +285,14 @@ Tensor raster_bwd(int64_t C, int64_t N, int64_t channels, int64_t has_extra, int
     return slots;
 }
 
-// The same with the decoder's backward pass as the kernel's prologue (mobgs_raster_bwd_decode): -> (slots, g_c2w | None,
-// g_w1, g_w2); g_w1 / g_w2: a sink's buffers (accumulate as given) or None -> allocated here and overwritten.
-std::tuple<Tensor, OptT, Tensor, Tensor>
+// The same with the decoder's backward pass as the kernel's prologue (mobgs_raster_bwd_decode): -> (slots, partial rows)
+std::tuple<Tensor, Tensor>
 raster_bwd_decode(int64_t C, int64_t N, int64_t width, int64_t height, int64_t n_isects, const Tensor& records,
                   const OptT& bg, const Tensor& radii, const Tensor& cum_tiles, const Tensor& keep_scan,
                   const Tensor& tile_offsets, const OptT& tile_order, const Tensor& flatten_ids, const Tensor& render,
                   const Tensor& alphas, const Tensor& last_ids, const OptT& v_rgb_in, const OptT& v_depth_in,
                   const OptT& v_alphas_in, const Tensor& intr, const Tensor& c2w, const Tensor& w1, const Tensor& w2,
-                  const OptT& reach, bool c2w_needs_grad, const OptT& g_w1_in, const OptT& g_w2_in, int64_t accumulate,
-                  int64_t tuning, int64_t stream, bool cover) {
+                  const OptT& reach, int64_t tuning, int64_t stream, bool cover) {
     const auto f = records.options();
     const Tensor v_rgb = (v_rgb_in.has_value() && v_rgb_in->defined()) ? f32c(*v_rgb_in) : at::zeros({C, 3, height, width}, f);
     const OptT v_depth = f32c(v_depth_in);
@@ -299,21 +301,60 @@ raster_bwd_decode(int64_t C, int64_t N, int64_t width, int64_t height, int64_t n
     Tensor slots = cover ? at::empty({rows + 1, stride}, f) : at::zeros({rows + 1, stride}, f);
     int32_t* flag = cover ? nullptr : reinterpret_cast<int32_t*>(fpw(slots) + rows * stride);
     Tensor partial = at::empty({(int64_t)api.raster_bwd_decode_scratch_floats((int)C, (int)width, (int)height)}, f);
-    const bool sunk = g_w1_in.has_value() && g_w1_in->defined();
-    Tensor g_w1 = sunk ? *g_w1_in : at::empty_like(w1);
-    Tensor g_w2 = sunk ? *g_w2_in : at::empty_like(w2);
-    OptT g_c2w = c2w_needs_grad ? OptT(at::empty_like(c2w)) : OptT();
     const int64_t intr_stride = (C > 1 && intr.numel() == 4 * C) ? 4 : 0;
     const int64_t c2w_stride = (C > 1 && c2w.dim() == 3) ? c2w.numel() / C : 0;
     check(api.raster_bwd_decode((int)C, (int)N, (int)width, (int)height, fp(records), fp(bg), ip(radii), ip(cum_tiles),
                                 ip(keep_scan), ip(tile_offsets), ip(tile_order), ip(flatten_ids), fp(render), fp(alphas),
                                 ip(last_ids), fp(v_rgb), fp(v_depth), fp(v_alphas), fp(intr), (int)intr_stride, fp(c2w),
                                 (int)c2w_stride, fp(w1), fp(w2), fpw(slots), static_cast<const uint8_t*>(dp(reach)), flag,
-                                fpw(partial), fpw(g_w1), fpw(g_w2), fpw(g_c2w),
-                                g_c2w.has_value() ? (int)(g_c2w->numel() / (c2w_stride ? C : 1)) : 0,
-                                sunk ? (int)accumulate : 0, tp(tuning), sp(stream)),
+                                fpw(partial), tp(tuning), sp(stream)),
           "mobgs_raster_bwd_decode");
-    return {slots, g_c2w, g_w1, g_w2};
+    return {slots, partial};
+}
+
+// ... and the fixed-order sum of its partial rows (mobgs_raster_bwd_decode_finish): -> (g_c2w | None, g_w1, g_w2);
+// g_w1 / g_w2: a sink's buffers (accumulate as given) or None -> allocated here and overwritten.
+std::tuple<OptT, Tensor, Tensor>
+raster_bwd_decode_finish(int64_t C, int64_t width, int64_t height, const Tensor& partial, const Tensor& c2w, const Tensor& w1,
+                         const Tensor& w2, bool c2w_needs_grad, const OptT& g_w1_in, const OptT& g_w2_in, int64_t accumulate,
+                         int64_t stream) {
+    const bool sunk = g_w1_in.has_value() && g_w1_in->defined();
+    Tensor g_w1 = sunk ? *g_w1_in : at::empty_like(w1);
+    Tensor g_w2 = sunk ? *g_w2_in : at::empty_like(w2);
+    OptT g_c2w = c2w_needs_grad ? OptT(at::empty_like(c2w)) : OptT();
+    const int64_t c2w_stride = (C > 1 && c2w.dim() == 3) ? c2w.numel() / C : 0;
+    check(api.raster_bwd_decode_finish((int)C, (int)width, (int)height, fpw(partial), (int)c2w_stride, fpw(g_w1), fpw(g_w2),
+                                       fpw(g_c2w), g_c2w.has_value() ? (int)(g_c2w->numel() / (c2w_stride ? C : 1)) : 0,
+                                       sunk ? (int)accumulate : 0, sp(stream)),
+          "mobgs_raster_bwd_decode_finish");
+    return {g_c2w, g_w1, g_w2};
+}
+
+// raster_bwd_reduce + raster_bwd_decode_finish in one launch (mobgs_raster_bwd_reduce_decode):
+// -> (v_means2d, v_conics, v_opac, v_colors, v_extra, g_c2w | None, g_w1, g_w2)
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, OptT, Tensor, Tensor>
+raster_bwd_reduce_decode(int64_t C, int64_t N, int64_t width, int64_t height, const Tensor& records, const Tensor& cum_tiles,
+                         const Tensor& keep_scan, const Tensor& slots, const OptT& tiles_per_gauss, bool use_flag,
+                         const Tensor& partial, const Tensor& c2w, const Tensor& w1, const Tensor& w2, bool c2w_needs_grad,
+                         const OptT& g_w1_in, const OptT& g_w2_in, int64_t accumulate, int64_t stream) {
+    const auto f = slots.options();
+    Tensor v_means2d = at::empty({C, N, 2}, f), v_conics = at::empty({C, N, 3}, f), v_opac = at::empty({C, N}, f),
+           v_colors = at::empty({C, N, 9}, f), v_extra = at::empty({C, N}, f);
+    const int32_t* flag =
+        use_flag ? reinterpret_cast<const int32_t*>(fp(slots) + (slots.size(0) - 1) * slots.size(1)) : nullptr;
+    const bool sunk = g_w1_in.has_value() && g_w1_in->defined();
+    Tensor g_w1 = sunk ? *g_w1_in : at::empty_like(w1);
+    Tensor g_w2 = sunk ? *g_w2_in : at::empty_like(w2);
+    OptT g_c2w = c2w_needs_grad ? OptT(at::empty_like(c2w)) : OptT();
+    const int64_t c2w_stride = (C > 1 && c2w.dim() == 3) ? c2w.numel() / C : 0;
+    check(api.raster_bwd_reduce_decode((int)C, (int)N, fp(records), ip(cum_tiles), ip(keep_scan), fp(slots), flag,
+                                       fpw(v_means2d), fpw(v_conics), fpw(v_opac), fpw(v_colors), fpw(v_extra),
+                                       ip(tiles_per_gauss), (int)width, (int)height, fp(partial), (int)c2w_stride, fpw(g_w1),
+                                       fpw(g_w2), fpw(g_c2w),
+                                       g_c2w.has_value() ? (int)(g_c2w->numel() / (c2w_stride ? C : 1)) : 0,
+                                       sunk ? (int)accumulate : 0, sp(stream)),
+          "mobgs_raster_bwd_reduce_decode");
+    return {v_means2d, v_conics, v_opac, v_colors, v_extra, g_c2w, g_w1, g_w2};
 }
 
 // -> (v_means2d [C,N,2], v_conics [C,N,3], v_opac [C,N], v_colors [C,N,channels], v_extra [C,N] | None)
@@ -577,6 +618,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("raster_fwd", &raster_fwd);
     m.def("raster_bwd", &raster_bwd);
     m.def("raster_bwd_decode", &raster_bwd_decode);
+    m.def("raster_bwd_decode_finish", &raster_bwd_decode_finish);
+    m.def("raster_bwd_reduce_decode", &raster_bwd_reduce_decode);
     m.def("raster_bwd_reduce", &raster_bwd_reduce);
     m.def("decoder_fwd", &decoder_fwd);
     m.def("decoder_bwd", &decoder_bwd);

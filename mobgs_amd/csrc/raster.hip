@@ -1841,20 +1841,32 @@ slot_reduce_wide_kernel(int n_gauss, int channels, int has_extra, int rq, const 
 // partial sums per component are combined with DPP adds.  Measured: 16 lanes 33 us, 8 lanes (twice the splats per
 // wave, half the waves to schedule) 30 us, 4 lanes 34 us.
 // Fixed association order -> deterministic.
-template <int LPS>  // lanes per splat: 16 (four slots per load instruction and splat) or 8 (two)
+// WRED (round 6): the launch carries wgrad_finish_outputs(wf) * n_images extra LEADING workgroups that sum the decoder's
+// weight / pose gradient rows the backward compositor's prologue left (decoder_shared.h wgrad_column_sum) -- a strided,
+// latency-bound column each, finished long before the slot streams are: the 8-us reduction launch behind raster_bwd is gone.
+template <int LPS, bool WRED = false>  // lanes per splat: 16 (four slots per load instruction and splat) or 8 (two)
 __global__ void __launch_bounds__(256)
 slot_reduce16_kernel(int n_gauss, int channels, int has_extra, const int32_t* __restrict__ cum_tiles,
                      const int32_t* __restrict__ keep_scan, const float* __restrict__ grad_slots,
                      float* __restrict__ v_means2d, float* __restrict__ v_conics, float* __restrict__ v_opacities,
                      float* __restrict__ v_colors, float* __restrict__ v_extra,
                      const int32_t* __restrict__ any_record, const float* __restrict__ records,
-                     const int32_t* __restrict__ tiles_per_gauss) {
+                     const int32_t* __restrict__ tiles_per_gauss, WgradFinish wf = WgradFinish{}) {
     // (With an enumeration order -- mobgs_hip.h, enum_order -- a splat's slots sit where the ORDER put them: this kernel
     // then reads 360-byte runs at random places instead of one stream, 32 -> 39 us.  Walking the splats in enumeration
     // order instead was measured: the slot buffer streams again, but cum_tiles / records are gathered and five small
     // outputs per splat scattered -- 65 us.)
     constexpr int SUBS = LPS / 4;
-    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPS;
+    int bid = blockIdx.x;
+    if constexpr (WRED) {
+        const int nout = wgrad_finish_outputs(wf), nw = nout * wf.n_images;
+        if (bid < nw) {   // (workgroup-uniform)
+            wgrad_column_sum(wf, bid % nout, bid / nout);
+            return;
+        }
+        bid -= nw;
+    }
+    const int gid = (bid * blockDim.x + threadIdx.x) / LPS;
     const int l16 = threadIdx.x & (LPS - 1);
     const int q = l16 & 3, sub = l16 >> 2;
     const bool live = gid < n_gauss;
@@ -2171,28 +2183,62 @@ int mobgs_raster_bwd_decode(int C, int N, int width, int height, const float* re
                             const float* render, const float* render_alphas, const int32_t* last_ids, const float* v_rgb,
                             const float* v_depth, const float* v_alphas, const float* ray_intr, int intr_stride,
                             const float* ray_c2w, int c2w_stride, const float* w1, const float* w2, float* grad_slots,
-                            const uint8_t* isect_reach, int32_t* any_record, float* w_partial, float* g_w1, float* g_w2,
-                            float* g_c2w, int g_c2w_floats, int accumulate_wgrad, const MobgsTuning* tuning,
+                            const uint8_t* isect_reach, int32_t* any_record, float* w_partial, const MobgsTuning* tuning,
                             void* stream) {
-    if (!render || !v_rgb || !ray_intr || !ray_c2w || !w1 || !w2 || !w_partial || !g_w1 || !g_w2 ||
-        (g_c2w && g_c2w_floats != 12 && g_c2w_floats != 16)) {
-        set_error("mobgs_raster_bwd_decode: render, v_rgb, ray_intr, ray_c2w, w1, w2, w_partial, g_w1 and g_w2 are required "
-                  "(g_c2w: 12 or 16 floats per image)");
-        return MOBGS_E_INVALID;
-    }
-    if (C > 1 && g_c2w && c2w_stride == 0) {
-        set_error("mobgs_raster_bwd_decode: a pose shared by the images of a batch cannot receive a gradient");
+    if (!render || !v_rgb || !ray_intr || !ray_c2w || !w1 || !w2 || !w_partial) {
+        set_error("mobgs_raster_bwd_decode: render, v_rgb, ray_intr, ray_c2w, w1, w2 and w_partial are required");
         return MOBGS_E_INVALID;
     }
     const int tiles = ((width + MOBGS_TILE - 1) / MOBGS_TILE) * ((height + MOBGS_TILE - 1) / MOBGS_TILE);
     const DecodeBwd db{render, v_rgb, v_depth, ray_intr, ray_c2w, w1, w2, w_partial, decoder_wgrad_ticket(w_partial, C, tiles),
                        intr_stride, c2w_stride};
-    const int rc = raster_bwd_impl(C, N, 9, 1, width, height, records, backgrounds, radii, nullptr, cum_tiles, keep_scan,
-                                   tile_offsets, tile_order, flatten_ids, render_alphas, last_ids, nullptr, v_alphas,
-                                   grad_slots, isect_reach, any_record, tuning, stream, &db);
-    if (rc != MOBGS_OK) return rc;
+    return raster_bwd_impl(C, N, 9, 1, width, height, records, backgrounds, radii, nullptr, cum_tiles, keep_scan,
+                           tile_offsets, tile_order, flatten_ids, render_alphas, last_ids, nullptr, v_alphas,
+                           grad_slots, isect_reach, any_record, tuning, stream, &db);
+}
+
+int mobgs_raster_bwd_decode_finish(int C, int width, int height, float* w_partial, int c2w_stride, float* g_w1,
+                                   float* g_w2, float* g_c2w, int g_c2w_floats, int accumulate_wgrad, void* stream) {
+    if (C <= 0 || width <= 0 || height <= 0 || !w_partial || !g_w1 || !g_w2 ||
+        (g_c2w && g_c2w_floats != 12 && g_c2w_floats != 16)) {
+        set_error("mobgs_raster_bwd_decode_finish: w_partial, g_w1 and g_w2 are required (g_c2w: 12 or 16 floats per image)");
+        return MOBGS_E_INVALID;
+    }
+    if (C > 1 && g_c2w && c2w_stride == 0) {
+        set_error("mobgs_raster_bwd_decode_finish: a pose shared by the images of a batch cannot receive a gradient");
+        return MOBGS_E_INVALID;
+    }
+    const int tiles = ((width + MOBGS_TILE - 1) / MOBGS_TILE) * ((height + MOBGS_TILE - 1) / MOBGS_TILE);
     launch_decoder_wgrad_reduce(C, tiles, w_partial, g_w1, g_w2, g_c2w, g_c2w_floats, accumulate_wgrad, (hipStream_t)stream);
-    return check_launch("decoder_wgrad_reduce_kernel");
+    return check_launch("decoder_wgrad_reduce_rows_kernel");
+}
+
+int mobgs_raster_bwd_reduce_decode(int C, int N, const float* records, const int32_t* cum_tiles, const int32_t* keep_scan,
+                                   const float* grad_slots, const int32_t* any_record, float* v_means2d, float* v_conics,
+                                   float* v_opacities, float* v_colors, float* v_extra, const int32_t* tiles_per_gauss,
+                                   int width, int height, const float* w_partial, int c2w_stride, float* g_w1, float* g_w2,
+                                   float* g_c2w, int g_c2w_floats, int accumulate_wgrad, void* stream) {
+    if (C <= 0 || N < 0 || width <= 0 || height <= 0 || ((long long)C * N > 0 && !records) || !w_partial || !g_w1 || !g_w2 ||
+        (g_c2w && g_c2w_floats != 12 && g_c2w_floats != 16) || (C > 1 && g_c2w && c2w_stride == 0)) {
+        set_error("mobgs_raster_bwd_reduce_decode: bad arguments (w_partial, g_w1, g_w2 required; g_c2w: 12 or 16 floats per "
+                  "image, one pose per image)");
+        return MOBGS_E_INVALID;
+    }
+    WgradFinish wf;
+    wf.w_partial = w_partial;
+    wf.g_w1 = g_w1;
+    wf.g_w2 = g_w2;
+    wf.g_c2w = g_c2w;
+    wf.rows_per_image = ((width + MOBGS_TILE - 1) / MOBGS_TILE) * ((height + MOBGS_TILE - 1) / MOBGS_TILE);
+    wf.n_images = C;
+    wf.accumulate = accumulate_wgrad;
+    wf.c2w_floats = g_c2w_floats;
+    const int n = C * N;
+    const int extra = wgrad_finish_outputs(wf) * C;
+    hipLaunchKernelGGL((slot_reduce16_kernel<8, true>), dim3(extra + (int)(((size_t)n * 8 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, n, 9, 1, cum_tiles, keep_scan, grad_slots, v_means2d, v_conics, v_opacities,
+                       v_colors, v_extra, any_record, records, tiles_per_gauss, wf);
+    return check_launch("slot_reduce16_kernel(+wgrad)");
 }
 
 size_t mobgs_raster_bwd_decode_scratch_floats(int C, int width, int height) {

@@ -746,7 +746,7 @@ class _Rasterize(torch.autograd.Function):
         cover = COVER_SLOTS and quadrant and not gated   # the kernel writes every slot: no zero fill, no flag
         tn = _tuning_variant(gated, ctx.static_rows, cover)
         g_c2w = g_w1 = g_w2 = None
-        slots = None
+        slots, reduced = None, False
         if v_rgb is not None or v_depth is not None:
             fuse = v_render is None and not ctx.bg_needs_grad and not gated and quadrant
             if fuse:   # the decoder's backward pass inside the backward compositor
@@ -755,14 +755,14 @@ class _Rasterize(torch.autograd.Function):
                 sunk = ops._active_sink.decoder_buffers(*ctx.dec_w_inputs) if ops._active_sink is not None else None
                 _log_path("bwd", D, tl, tn=tn, static_rows=tn.static_rows, decode_bwd=True)
                 va = v_alphas.reshape(C, height, width) if v_alphas is not None else None
+                istr = 4 if (C > 1 and intr.numel() == 4 * C) else 0
+                cstr = (c2w.numel() // C) if (C > 1 and c2w.dim() == 3) else 0
                 with profiler.region("raster_bwd"):
                     if F is not None:
-                        slots, g_c2w, g_w1, g_w2 = F.raster_bwd_decode(
+                        slots, partial = F.raster_bwd_decode(
                             C, N, width, height, tl.n_isects, records, bg, radii, tl.cum_tiles, tl.keep_scan,
                             tl.tile_offsets, tl.tile_order, tl.flatten_ids, render, alphas, last_ids, v_rgb, v_depth, va,
-                            intr, c2w, w1, w2, reach, bool(ctx.dec_c2w_needs_grad), sunk[0] if sunk is not None else None,
-                            sunk[1] if sunk is not None else None, sunk[2] if sunk is not None else 0, tn.address(),
-                            stream_int(), cover)
+                            intr, c2w, w1, w2, reach, tn.address(), stream_int(), cover)
                     else:
                         v_rgb_c = f32c(v_rgb) if v_rgb is not None else torch.zeros(C, 3, height, width, dtype=torch.float32,
                                                                                     device=dev)
@@ -773,20 +773,48 @@ class _Rasterize(torch.autograd.Function):
                         flag = None if cover else ctypes.c_void_p(slots.data_ptr() + 4 * rows * stride)
                         partial = torch.empty(lib.mobgs_raster_bwd_decode_scratch_floats(C, width, height),
                                               dtype=torch.float32, device=dev)
-                        if sunk is not None:
-                            g_w1, g_w2, accumulate = sunk
-                        else:
-                            g_w1, g_w2, accumulate = torch.empty_like(w1), torch.empty_like(w2), 0
-                        g_c2w = torch.empty_like(c2w) if ctx.dec_c2w_needs_grad else None
-                        istr = 4 if (C > 1 and intr.numel() == 4 * C) else 0
-                        cstr = (c2w.numel() // C) if (C > 1 and c2w.dim() == 3) else 0
                         check(lib.mobgs_raster_bwd_decode(
                             C, N, width, height, ptr(records), ptr(bg), ptr(radii), ptr(tl.cum_tiles), ptr(tl.keep_scan),
                             ptr(tl.tile_offsets), ptr(tl.tile_order), ptr(tl.flatten_ids), ptr(render), ptr(alphas),
                             ptr(last_ids), ptr(v_rgb_c), ptr(v_depth_c), ptr(va), ptr(intr), istr, ptr(c2w), cstr, ptr(w1),
-                            ptr(w2), ptr(slots), ptr(reach), flag, ptr(partial), ptr(g_w1), ptr(g_w2), ptr(g_c2w),
-                            (g_c2w.numel() // (C if cstr else 1)) if g_c2w is not None else 0, accumulate, tn.ref(),
-                            stream()), "mobgs_raster_bwd_decode")
+                            ptr(w2), ptr(slots), ptr(reach), flag, ptr(partial), tn.ref(), stream()),
+                            "mobgs_raster_bwd_decode")
+                # the weight / pose gradient sums ride in the slot reduction's launch (mobgs_raster_bwd_reduce_decode);
+                # WGRAD_IN_REDUCE = False: a launch of their own (mobgs_raster_bwd_decode_finish), then the usual reduction
+                if not WGRAD_IN_REDUCE:
+                    if sunk is not None:
+                        g_w1, g_w2, accumulate = sunk
+                    else:
+                        g_w1, g_w2, accumulate = torch.empty_like(w1), torch.empty_like(w2), 0
+                    g_c2w = torch.empty_like(c2w) if ctx.dec_c2w_needs_grad else None
+                    check(lib.mobgs_raster_bwd_decode_finish(
+                        C, width, height, ptr(partial), cstr, ptr(g_w1), ptr(g_w2), ptr(g_c2w),
+                        (g_c2w.numel() // (C if cstr else 1)) if g_c2w is not None else 0, accumulate, stream()),
+                        "mobgs_raster_bwd_decode_finish")
+                elif F is not None:
+                    v_means2d, v_conics, v_opac, v_colors, v_extra, g_c2w, g_w1, g_w2 = F.raster_bwd_reduce_decode(
+                        C, N, width, height, records, tl.cum_tiles, tl.keep_scan, slots, tl.tiles_per_gauss, not cover,
+                        partial, c2w, w1, w2, bool(ctx.dec_c2w_needs_grad), sunk[0] if sunk is not None else None,
+                        sunk[1] if sunk is not None else None, sunk[2] if sunk is not None else 0, stream_int())
+                else:
+                    if sunk is not None:
+                        g_w1, g_w2, accumulate = sunk
+                    else:
+                        g_w1, g_w2, accumulate = torch.empty_like(w1), torch.empty_like(w2), 0
+                    g_c2w = torch.empty_like(c2w) if ctx.dec_c2w_needs_grad else None
+                    v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+                    v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+                    v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
+                    v_colors = torch.empty(C, N, channels, dtype=torch.float32, device=dev)
+                    v_extra = torch.empty(C, N, dtype=torch.float32, device=dev)
+                    flag2 = None if cover else ctypes.c_void_p(slots.data_ptr() + 4 * max(tl.n_isects, 1) * stride)
+                    check(lib.mobgs_raster_bwd_reduce_decode(
+                        C, N, ptr(records), ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(slots), flag2, ptr(v_means2d),
+                        ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra), ptr(tl.tiles_per_gauss), width, height,
+                        ptr(partial), cstr, ptr(g_w1), ptr(g_w2), ptr(g_c2w),
+                        (g_c2w.numel() // (C if cstr else 1)) if g_c2w is not None else 0, accumulate, stream()),
+                        "mobgs_raster_bwd_reduce_decode")
+                reduced = WGRAD_IN_REDUCE
                 if g_c2w is not None:
                     g_c2w = g_c2w.reshape(ctx.dec_c2w_shape)
                 if sunk is not None:
@@ -800,7 +828,7 @@ class _Rasterize(torch.autograd.Function):
             v_render = torch.zeros(C, height, width, D, dtype=torch.float32, device=dev)
         if slots is None:
             _log_path("bwd", D, tl, tn=tn, static_rows=tn.static_rows)
-        if slots is not None:
+        if slots is not None and not reduced:
             st = stream_int()
             if F is not None:
                 v_means2d, v_conics, v_opac, v_colors, v_extra = F.raster_bwd_reduce(
@@ -818,6 +846,8 @@ class _Rasterize(torch.autograd.Function):
                                                   ptr(tl.keep_scan), ptr(slots), flag, ptr(v_means2d), ptr(v_conics),
                                                   ptr(v_opac), ptr(v_colors), ptr(v_extra), ptr(tl.tiles_per_gauss),
                                                   stream()), "mobgs_raster_bwd_reduce")
+        elif reduced:
+            pass
         elif F is not None:  # the same body in C++ (csrc/fastpath.cpp)
             st = stream_int()
             with profiler.region("raster_bwd"):
@@ -1068,6 +1098,9 @@ FUSE_DECODER = os.environ.get("MOBGS_FUSE_DECODER", "1") != "0"
 # pass is the prologue of the backward compositor (mobgs_raster_bwd_decode); False: ops.Decode owns it (a launch of its
 # own + a 55-MB cotangent image).  Splat gradients are bit-identical either way, weight / pose gradients to summation order.
 FUSE_DECODER_BWD = os.environ.get("MOBGS_FUSE_DECODER_BWD", "1") != "0"
+# True: the decoder's weight / pose gradient sums run as extra workgroups of the gradient-slot reduction (no launch of their
+# own); False: mobgs_raster_bwd_decode_finish (A/B; same sums to summation order)
+WGRAD_IN_REDUCE = os.environ.get("MOBGS_WGRAD_IN_REDUCE", "1") != "0"
 # True: static-only / dynamic-only images (without the combined one) come from two class-restricted passes of the
 # single-set compositor over the combined lists (every splat belongs to exactly one class, so together they do the
 # work of ONE pass and share one gradient-slot buffer); False: from the generic 3-layer kernel

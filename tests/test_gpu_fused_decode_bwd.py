@@ -152,3 +152,32 @@ def test_gradient_sink_receives_the_decoder_gradients(hip_device):
                           stat._xyz.grad.clone(), dyn.control_xyz.grad.clone()]
     assert _close(res[True][0], res[False][0]) and _close(res[True][1], res[False][1])
     assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
+
+
+def test_standalone_finish_equals_the_sums_inside_the_slot_reduction(hip_device):
+    """mobgs_raster_bwd_decode_finish (a launch of its own, chunked + ticketed) against the same sums taken by the extra
+    workgroups of the slot reduction (mobgs_raster_bwd_reduce_decode): equal to summation order; everything else bit for bit."""
+    import mobgs_amd.rendering as R
+    from mobgs_amd.gaussian_renderer import render
+    dev = hip_device
+    W, H = 704, 400
+    v = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    res = {}
+    saved = R.WGRAD_IN_REDUCE
+    try:
+        for inside in (True, False):
+            R.WGRAD_IN_REDUCE = inside
+            with _bwd_fusion(True):
+                cam, stat, dyn, _ = _scene(dev, W, H, 30_000, 15_000)
+                cam.world_view_transform.requires_grad_(True)
+                out = render(cam, stat, dyn, None, torch.zeros(9, device=dev))
+                ((out["render"] * v).sum() + out["depth"].sum()).backward()
+                res[inside] = ([stat._xyz.grad.clone(), dyn.control_xyz.grad.clone(), dyn._features_t.grad.clone()],
+                               [dyn.rgbdecoder.mlp1.weight.grad.clone(), dyn.rgbdecoder.mlp2.weight.grad.clone(),
+                                cam.world_view_transform.grad.clone()])
+    finally:
+        R.WGRAD_IN_REDUCE = saved
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.isfinite(b).all() and _close(b, a)
