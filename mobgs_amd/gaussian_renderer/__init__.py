@@ -595,10 +595,12 @@ class _FlowHead(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        if not FLOW_HOST_GATE or torch.cuda.is_current_stream_capturing():
+        if not FLOW_HOST_GATE:
             return grads
         live = [g for g in grads if g is not None]
-        if live and not all(g.is_cuda and g.dtype == torch.float32 for g in live):
+        if not live or not all(g.is_cuda and g.dtype == torch.float32 for g in live):
+            return grads
+        if torch.cuda.is_current_stream_capturing():
             return grads
         if _R.cotangents_all_zero(live):
             return (None,) * len(grads)
@@ -711,7 +713,12 @@ def _shared_mid_state(cam, stat_pc, dyn_pc, dev):
 @_gated
 def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=None, _mid=None, _defer_mid=False):
     """/root/reference/gaussian_renderer/__init__.py:318-492 ->
-    (exp2mid_coord_map [1,H,W,2], mid2exp_coord_map [1,H,W,2], latent_img [3,H,W], latent_alpha [1,H,W])."""
+    (exp2mid_coord_map [1,H,W,2], mid2exp_coord_map [1,H,W,2], latent_img [3,H,W], latent_alpha [1,H,W]).
+    While gradients are recorded (and the zero-cotangent host gate is on, the default) the four maps of a call are outputs of
+    ONE autograd node that returns views (_FlowHead): use them out of place.  /root/reference/train.py:570-579, :658-668
+    does -- it concatenates the nine calls' maps (torch.cat: a fresh tensor) before normalising `coord[..., 0] /= W - 1` in
+    place; an in-place edit of a RETURNED map itself raises PyTorch's "output of a function that returns multiple views"
+    error (tests/test_host_logic_cpu.py pins both).  MOBGS_FLOW_HOST_GATE=0 returns ordinary tensors."""
     cam = viewpoint_camera
     dev = _device_of(dyn_pc)
     W, H = int(cam.image_width), int(cam.image_height)

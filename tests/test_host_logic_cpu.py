@@ -200,3 +200,25 @@ def test_round5_host_switches_and_keys():
     assert sorted(order.tolist()) == list(range(50)) and stat._xyz.requires_grad
     o2 = dyn.spatial_sort_()
     assert dyn.rows_coherent == 20 and dyn.control_xyz.shape == (20, 12, 3) and sorted(o2.tolist()) == list(range(20))
+
+
+def test_flow_head_outputs_are_used_the_way_the_reference_uses_them():
+    """gaussian_renderer._FlowHead hands the maps of a get_flow() group out as views of one autograd node: the
+    reference's own use -- torch.cat of the calls' maps, THEN the in-place normalisation of /root/reference/train.py:658-660
+    -- works and back-propagates; an in-place edit of a returned map itself is PyTorch's multiple-views error (documented in
+    get_flow's docstring)."""
+    import pytest
+    import torch
+    from mobgs_amd.gaussian_renderer import _FlowHead
+    a = torch.rand(1, 4, 5, 2, requires_grad=True)
+    b = torch.rand(1, 4, 5, 2, requires_grad=True)
+    o = _FlowHead.apply(a * 1.0, b * 1.0)
+    cat = torch.cat([o[0], o[1]], 0).unsqueeze(0)           # train.py:583-586
+    cat[..., 0] = cat[..., 0] / 4                            # :659 (W - 1)
+    cat[..., 1] = cat[..., 1] / 3                            # :660 (H - 1)
+    (2.0 * cat - 1.0).sum().backward()
+    assert torch.allclose(a.grad[..., 0], torch.full_like(a.grad[..., 0], 0.5))
+    assert torch.allclose(b.grad[..., 1], torch.full_like(b.grad[..., 1], 2.0 / 3.0))
+    o2 = _FlowHead.apply(a * 1.0, b * 1.0)
+    with pytest.raises(RuntimeError, match="multiple views|view"):
+        o2[0][..., 0] = o2[0][..., 0] / 2
