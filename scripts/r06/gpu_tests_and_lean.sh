@@ -1,5 +1,5 @@
 #!/bin/bash
-# cover_slots: bit-identity tests (poisoned allocator), the operator / render suites around it, then the lean-step profile
+# the GPU tests around the backward compositor (cover_slots, decoder prologue, operator / render parity, graphs, soaks), then the lean-step kernel profile
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root; mkdir -p gpurun_out/r06i
 timeout 1500 python -X faulthandler -m pytest tests/test_gpu_cover_slots.py tests/test_gpu_fused_decode_bwd.py tests/test_gpu_operator_parity.py tests/test_gpu_render_parity.py tests/test_gpu_fullsize.py tests/test_gpu_graphed.py tests/test_gpu_static_rows.py tests/test_gpu_soak.py -x -q -m gpu > gpurun_out/r06i/pytest.log 2>&1
