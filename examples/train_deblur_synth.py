@@ -162,6 +162,19 @@ class DeblurTrainer:
     def iteration(self) -> torch.Tensor:
         if self.shard.collective:   # N > 1 (or a forced one-rank group: the same code path on one GPU)
             return self._iteration_sharded()
+        photo = self.forward_backward()
+        self.optimizer_step()
+        return photo
+
+    def optimizer_step(self):
+        # train.py:790-807 steps the three optimisers one after the other (~26 one-tensor groups x 8 launches); here
+        # ONE launch performs the same Adam update on all of them (mobgs_amd.optim)
+        fused_adam_step([self.stat.optimizer, self.dyn.optimizer, self.blce.optimizer])
+
+    def forward_backward(self) -> torch.Tensor:
+        """Everything of the single-process iteration but the optimiser step: renders, flows, loss, backward into the flat
+        gradient buffer, densification statistics -- device work over persistent tensors only, i.e. what
+        mobgs_amd.graphed.GraphedCallable can record once and replay (scripts/bench_small_scene_iteration.py --graph)."""
         shard, stat, dyn, blce, bucket, ns = self.shard, self.stat, self.dyn, self.blce, self.bucket, self.ns
         bucket.zero()
         multi = shard.world > 1  # units of both families dealt by cost, per-view asynchronous image exchange
@@ -205,9 +218,6 @@ class DeblurTrainer:
                 vis = radii > 0
                 stat.add_densification_stats(grad2d[:ns], vis[:ns], radii=radii[:ns])
                 dyn.add_densification_stats(grad2d[ns:], vis[ns:], radii=radii[ns:])
-        # train.py:790-807 steps the three optimisers one after the other (~26 one-tensor groups x 8 launches); here
-        # ONE launch performs the same Adam update on all of them (mobgs_amd.optim)
-        fused_adam_step([stat.optimizer, dyn.optimizer, blce.optimizer])
         return photo.detach()
 
 

@@ -305,6 +305,13 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--flow", action="store_true", help="get_flow() / get_flow_many() instead of render()")
     ap.add_argument("--many", action="store_true", help="render_many() (K sub-frames as one batch) instead of render()")
+    ap.add_argument("--headline", action="store_true",
+                    help="the benchmark's kernel selection on these small images: one wave per tile (heavy_tile_len = 0), the "
+                         "quadrant backward (bwd_mfma = 0) -- with it the decoder prologue and cover_slots of round 6")
     a = ap.parse_args()
+    if a.headline:
+        import mobgs_amd.rendering as _R
+        _R.tuning.heavy_tile_len = 0
+        _R.tuning.bwd_mfma = 0
     failed, _ = soak(a.cases, a.seed, torch.device("cuda:0"), flow=a.flow, many=a.many)
     sys.exit(1 if failed else 0)
