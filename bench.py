@@ -614,6 +614,8 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--prewarm", type=int, default=40, help="untimed set-up steps before the W warm-up steps (arena sizing)")
     ap.add_argument("--train-steps", type=int, default=10, help="N=1: whole training iterations timed (0: skip)")
+    ap.add_argument("--small-steps", type=int, default=20,
+                    help="N=1: whole iterations at the reference's own 512x288 / 30 k operating point, eager and graphed (0: skip)")
     ap.add_argument("--repeat-steps", type=int, default=100,
                     help="N=1: further lean steps after the K timed ones; their HIP-event median is reported as `repeat`")
     ap.add_argument("--no-kernel-breakdown", action="store_true",
@@ -681,7 +683,7 @@ def main():
 
     P = args.width * args.height
     n_units = args.views * 9
-    deblur = dynamic = flows = train_it = repeat = None
+    deblur = dynamic = flows = train_it = repeat = small_scene = None
     if args.breakdown_child:  # the profiled child of kernel_breakdown() / collect_pmc(): lean steps only, no output
         for _ in range(args.steps + args.warmup):
             lean_step()
@@ -812,7 +814,53 @@ def main():
                         "(train mode) + 9 get_flow() calls, l1_loss + ssim, the flow-consistency term as two F.grid_sample + "
                         "two masked l1_loss (torch), loss.backward() into ordinary .grad tensors, three torch.optim.Adam steps "
                         "(DeblurTrainer.iteration_unchanged)"}
+            # the same iteration with its forward + loss + backward recorded ONCE as a HIP graph (graphed.GraphedCallable;
+            # the one-launch Adam step outside): at this size the iteration is device-bound -- what a graph removes is gaps
+            try:
+                from mobgs_amd.graphed import GraphedCallable
+                tr.lambda_flow = 1e-2
+                fb = GraphedCallable(tr.forward_backward)
+                fb()
+
+                def graphed_iteration():
+                    fb()
+                    tr.optimizer_step()
+                gdt, gmed = timed(graphed_iteration, args.train_steps, 2, world, dist)
+                train_it["graphed"] = {"ms_per_iteration": round(gdt / args.train_steps * 1e3, 2),
+                                       "event_median_ms_per_iteration": round(gmed, 2), "arenas_fitted": bool(fb.check()),
+                                       "what": "DeblurTrainer.forward_backward as one HIP graph + fused_adam_step"}
+                del fb
+            except Exception as exc:  # noqa: BLE001
+                train_it["graphed"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             del tr
+        if args.small_steps > 0:
+            # The reference's OWN operating point (scene/dataset_readers.py:1448-1460, arguments/stereo/seesaw.py:13-14):
+            # 512x288 images, ~30 k Gaussians at the start of training.  An iteration is ~1400 launches of a few microseconds
+            # and bound by the host; recorded as a HIP graph it is bound by the device again.
+            sys.path.insert(0, os.path.join(ROOT, "examples"))
+            import train_deblur_synth as TD
+            from mobgs_amd.graphed import GraphedCallable
+            small = {"what": "ONE whole training iteration (as train_iteration) at 512x288 / 20 k + 10 k Gaussians, 2 views: "
+                             "eager, and with DeblurTrainer.forward_backward replayed as one HIP graph (Adam outside)",
+                     "steps": args.small_steps}
+            for lam, tag in ((1e-2, ""), (0.0, "_lambda_flow_loss_0")):
+                try:
+                    trs = TD.DeblurTrainer(str(dev), 20_000, 10_000, 512, 288, 2, iters=10000, lambda_flow=lam)
+                    edt, _ = timed(trs.iteration, args.small_steps, 4, world, dist)
+                    fbs = GraphedCallable(trs.forward_backward)
+                    fbs()
+
+                    def graphed_small():
+                        fbs()
+                        trs.optimizer_step()
+                    sdt, _ = timed(graphed_small, args.small_steps, 3, world, dist)
+                    small["eager_ms_per_iteration" + tag] = round(edt / args.small_steps * 1e3, 3)
+                    small["graphed_ms_per_iteration" + tag] = round(sdt / args.small_steps * 1e3, 3)
+                    small["arenas_fitted" + tag] = bool(fbs.check())
+                    del fbs, trs
+                except Exception as exc:  # noqa: BLE001
+                    small["error" + tag] = f"{type(exc).__name__}: {exc}"[:300]
+            small_scene = small
     else:
         wl = DeblurWorkload(dev, stat, dyn, scam, args.width, args.height, shard, args.views)
         wl.step()
@@ -898,6 +946,8 @@ def main():
         result["train_iteration"] = train_it
     if repeat is not None:
         result["repeat"] = repeat
+    if small_scene is not None:
+        result["reference_operating_point"] = small_scene
     if rank == 0:
         rb = prof.get("raster_bwd")
         if rb:

@@ -13,7 +13,7 @@ set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 cmd=$1; shift
 lib_of() { [ "$1" = main ] && echo "$root/mobgs_amd/csrc/libmobgs_hip.so" || echo "$root/scripts/ab/lib$1.so"; }
-BENCH_LEAN="--no-cpu-baseline --no-cpu-torch --deblur-steps 0 --dynamic-steps 0 --flow-steps 0 --train-steps 0 --repeat-steps 0 --no-kernel-breakdown"
+BENCH_LEAN="--no-cpu-baseline --no-cpu-torch --deblur-steps 0 --dynamic-steps 0 --flow-steps 0 --train-steps 0 --small-steps 0 --repeat-steps 0 --no-kernel-breakdown"
 case $cmd in
 build)
   name=$1; unit=${2:-all}; flags=${3:-}

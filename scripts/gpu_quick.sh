@@ -6,7 +6,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 if [ $# -gt 0 ]; then
   timeout 900 python -m pytest "$@" -x -q -m gpu 2>&1 | tail -15
 fi
-scripts/prof.sh $tag python $root/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-cpu-torch --deblur-steps 0 --dynamic-steps 0 --flow-steps 0 --train-steps 0 --repeat-steps 0 --no-kernel-breakdown | cut -c1-150 | head -24
+scripts/prof.sh $tag python $root/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-cpu-torch --deblur-steps 0 --dynamic-steps 0 --flow-steps 0 --train-steps 0 --small-steps 0 --repeat-steps 0 --no-kernel-breakdown | cut -c1-150 | head -24
 python - $root/gpurun_out/$tag/kernel_stats.csv <<'PY'
 import csv, sys
 tot = 0.0; comp = 0.0

@@ -5,7 +5,7 @@ tag=${1:-r06k}
 cd $root; mkdir -p gpurun_out/$tag
 for leg in deblur flow; do
   if [ $leg = deblur ]; then args="--deblur-steps 10 --flow-steps 0"; else args="--deblur-steps 0 --flow-steps 6"; fi
-  scripts/prof.sh ${tag}_$leg python $root/bench.py --steps 2 --warmup 1 --prewarm 1 --no-cpu-baseline --no-cpu-torch $args --dynamic-steps 0 --train-steps 0 --repeat-steps 0 --no-kernel-breakdown > gpurun_out/$tag/prof_$leg.txt 2>&1
+  scripts/prof.sh ${tag}_$leg python $root/bench.py --steps 2 --warmup 1 --prewarm 1 --no-cpu-baseline --no-cpu-torch $args --dynamic-steps 0 --train-steps 0 --small-steps 0 --repeat-steps 0 --no-kernel-breakdown > gpurun_out/$tag/prof_$leg.txt 2>&1
   echo "== $leg"
   python - gpurun_out/${tag}_$leg/kernel_stats.csv <<'PY'
 import csv,sys

@@ -29,10 +29,31 @@ for _ in range(5):
 eager_ms = timed(tr.iteration)
 eager_fb_ms = timed(tr.forward_backward)
 
-# bit-identity: one eager forward_backward and one graphed one on the SAME parameters
+# bit-identity: one eager forward_backward and one graphed one on the SAME parameters (and eager against eager: is the
+# iteration itself run-to-run deterministic?)
 tr.forward_backward()
 torch.cuda.synchronize()
-ref = tr.bucket.flat.clone() if hasattr(tr.bucket, "flat") else None
+ref = tr.bucket.flat.clone()
+tr.forward_backward()
+torch.cuda.synchronize()
+d = (ref - tr.bucket.flat).abs()
+print(f"eager vs eager: equal {bool(torch.equal(ref, tr.bucket.flat))}, max |diff| {float(d.max())}, differing words {int((d > 0).sum())} of {d.numel()}")
+
+
+def where(diff):
+    idx = torch.nonzero(diff > 0).flatten()
+    if idx.numel() == 0:
+        return "-"
+    off, names = 0, []
+    lo, hi = int(idx.min()), int(idx.max())
+    for p_ in tr.bucket.params:
+        n = p_.numel()
+        if off + n > lo and off <= hi and bool((diff[off:off + n] > 0).any()):
+            names.append(f"{tuple(p_.shape)}@{off}")
+        off += n
+    return f"words {lo}..{hi} (param floats {tr.bucket.param_floats}): " + ", ".join(names[:8])
+
+
 fb = GraphedCallable(tr.forward_backward)
 loss = fb()            # warm-up (eager) + capture
 fb()                   # a replay
@@ -40,7 +61,7 @@ torch.cuda.synchronize()
 ok = fb.check()
 same = bool(torch.equal(ref, tr.bucket.flat)) if ref is not None else None
 maxdiff = float((ref - tr.bucket.flat).abs().max()) if ref is not None else None
-print(f"capture ok, arenas fitted: {ok}; gradient buffer after a replay == eager: {same} (max |diff| {maxdiff})")
+print(f"capture ok, arenas fitted: {ok}; gradient buffer after a replay == eager: {same} (max |diff| {maxdiff}); where: {where((ref - tr.bucket.flat).abs())}")
 
 
 def graphed_iteration():

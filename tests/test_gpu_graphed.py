@@ -121,3 +121,50 @@ def test_static_capacity_without_the_fast_path_raises_instead_of_hanging(hip_dev
         step.capture(torch.eye(4), 0.3)
     del flat, step
     gc.collect()
+
+
+@pytest.mark.parametrize("lambda_flow", [0.0, 1e-2])
+def test_whole_training_iteration_as_one_graph(hip_device, lambda_flow):
+    """graphed.GraphedCallable (round 6): forward + losses + backward of a WHOLE training iteration (train.py:430-807:
+    render_many through BLCE cameras, get_flow_many, L1 + D-SSIM, depth / mask / normal terms, the flow-consistency term,
+    backward into the flat gradient buffer through LeafGradSink, densification statistics) recorded once and replayed, the
+    one-launch Adam step outside.  With the shipped lambda_flow_loss = 0 the iteration is run-to-run deterministic and the
+    replay must reproduce the eager gradient buffer BIT FOR BIT -- also after the parameters have moved through optimiser
+    steps; with the flow term live its backward scatters with float atomics (grid-sample backward): eager runs differ from each
+    other in the last bits, and so may the replay -- bounded by a few ulps of the largest gradient."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import train_deblur_synth as TD
+    from mobgs_amd.graphed import GraphedCallable
+    tr = TD.DeblurTrainer(str(hip_device), 4000, 2000, 256, 192, 2, iters=1000, lambda_flow=lambda_flow)
+    for _ in range(3):
+        tr.iteration()
+
+    def compare(a, b):
+        if lambda_flow == 0.0:
+            assert torch.equal(a, b)
+        else:
+            assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+
+    tr.forward_backward()
+    torch.cuda.synchronize()
+    ref = tr.bucket.flat.clone()
+    fb = GraphedCallable(tr.forward_backward)
+    loss0 = fb()                      # eager warm-up + capture
+    fb()                              # a replay
+    torch.cuda.synchronize()
+    assert fb.check()
+    compare(tr.bucket.flat, ref)
+    assert torch.isfinite(loss0).all()
+    for _ in range(5):                # training with the graph: parameters move in place, the graph follows them
+        fb()
+        tr.optimizer_step()
+    fb()
+    torch.cuda.synchronize()
+    assert fb.check()
+    g = tr.bucket.flat.clone()
+    tr.forward_backward()             # the eager iteration on the same (moved) parameters
+    torch.cuda.synchronize()
+    compare(g, tr.bucket.flat)
+    assert not torch.equal(g, ref)    # (the parameters did move)
