@@ -323,6 +323,21 @@ def _keep_grad(t: torch.Tensor) -> None:
     t.register_hook(hook)
 
 
+def _scoped(fn, stat_at=1):
+    """The entry point runs inside rendering.hint_scope(token of its (stat_pc, dyn_pc) pair): arena capacities, list-length
+    hints and key-segment strides are kept per scene (and per thread), not per (device, N, W, H) alone."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        stat_pc = a[stat_at] if len(a) > stat_at else k.get("stat_pc")
+        dyn_pc = a[stat_at + 1] if len(a) > stat_at + 1 else k.get("dyn_pc")
+        with _R.hint_scope(_R.scene_token(stat_pc, dyn_pc)):
+            return fn(*a, **k)
+    return wrapped
+
+
+@_scoped
 def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1.0, override_color=None,
            stage="fine", cam_type=None, is_static=False, over_t=None, over_vde=None, get_static=False,
            get_dynamic=False, stat_stat=True, ref_wc=None, iter_fact=1, flow=None, coherent=None, target_ts=None,
@@ -475,6 +490,7 @@ def render(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, scaling_modifier=1
 _bgK_cache = {}  # K -> DerivedCache of the [K,9] background rows
 
 
+@_scoped
 def render_many(viewpoint_cameras, stat_pc, dyn_pc, pipe, bg_color, delta_exposures=None):
     """[render(cam_k, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=d_k) for k] in lean mode -- the K latent sub-frames
     of one blurry view (train.py:502-518: same Gaussians at K exposure times through K warped cameras) -- as ONE batch of
@@ -632,6 +648,8 @@ def _gated(fn):
     return wrapped
 
 
+
+
 @_gated
 def _flow_mid_state(cam, stat_pc, dyn_pc, dev):
     """Projection + tile lists of the scene at the camera's own (mid-exposure) time: the part of get_flow() that does
@@ -710,6 +728,7 @@ def _shared_mid_state(cam, stat_pc, dyn_pc, dev):
     return sp
 
 
+@_scoped
 @_gated
 def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=None, _mid=None, _defer_mid=False):
     """/root/reference/gaussian_renderer/__init__.py:318-492 ->
@@ -760,6 +779,7 @@ def get_flow(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposure=N
     return _flow_head([(exp2mid, pix + splat(sp_mid, -e2m), latent_img, latent_alpha)])[0]
 
 
+@_scoped
 @_gated
 def get_flow_many(viewpoint_camera, stat_pc, dyn_pc, pipe, bg_color, delta_exposures):
     """[get_flow(..., delta_exposure=d) for d in delta_exposures] -- the 9 calls per view of train.py:570-579 -- with
@@ -887,3 +907,6 @@ def get_flow_static(source_camera, target_camera, splat_camera, stat_pc, dyn_pc,
                            Ks=K[None], width=int(splat_camera.image_width), height=int(splat_camera.image_height),
                            packed=False, render_mode="RGB")[0]
     return flow_2d, img
+
+get_flow_static = _scoped(get_flow_static, stat_at=3)
+

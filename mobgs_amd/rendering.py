@@ -486,12 +486,56 @@ TILE_SCHEDULE = os.environ.get("MOBGS_TILE_SCHEDULE", "1") != "0"
 _capacity = {}  # workload key -> current capacity of the keep-flag buffer (grows geometrically, never shrinks)
 
 
+# Whose hints: the renderer's entry points (gaussian_renderer.render & co) run inside hint_scope(scene token) -- a small
+# integer attached to the (static, dynamic) pair of Gaussian sets the first time they are rendered -- and the token is part
+# of every workload key: two scenes of equal size, or two threads rendering different scenes, no longer read and overwrite
+# each other's arena capacities / list-length hints / segment strides (the hints are performance-only,
+# sharing them costs rebuilds, never results).  Thread-local; token 0 = callers of the operator API without a scope.
+import threading as _threading
+
+_hint_tls = _threading.local()
+
+
+class hint_scope:
+    def __init__(self, token: int):
+        self.token = int(token)
+
+    def __enter__(self):
+        self.prev = getattr(_hint_tls, "token", 0)
+        _hint_tls.token = self.token
+        return self
+
+    def __exit__(self, *exc):
+        _hint_tls.token = self.prev
+        return False
+
+
+_scene_counter = [0]
+
+
+def scene_token(stat_pc, dyn_pc) -> int:
+    """The pair's token (kept on the dynamic set's object: it dies with it; ids of dead objects are never reused)."""
+    tok = getattr(dyn_pc, "_mobgs_scene_tokens", None)
+    if tok is None:
+        tok = {}
+        try:
+            dyn_pc._mobgs_scene_tokens = tok
+        except AttributeError:   # (an object that takes no attributes: one shared scope)
+            return 0
+    t = tok.get(id(stat_pc))
+    if t is None:
+        _scene_counter[0] += 1
+        t = tok[id(stat_pc)] = _scene_counter[0]
+    return t
+
+
 def _workload_key(dev, C, N, width, height):
-    """Arena sizes and list-length hints carry over from the previous frame OF THE SAME WORKLOAD: device, cameras,
-    splat count (in steps of 1/8 octave, so a scene that densifies keeps its arenas) and image size -- two scenes or
-    a full-set and a dynamic-only projection sharing a device do not fight over one entry."""
+    """Arena sizes and list-length hints carry over from the previous frame OF THE SAME WORKLOAD: scene (hint_scope),
+    device, cameras, splat count (in steps of 1/8 octave, so a scene that densifies keeps its arenas) and image size -- two
+    scenes or a full-set and a dynamic-only projection sharing a device do not fight over one entry."""
     n_bucket = 0 if N <= 0 else int(8 * math.log2(N))
-    return (dev.index if dev.index is not None else -1, int(C), n_bucket, int(width), int(height))
+    return (getattr(_hint_tls, "token", 0), dev.index if dev.index is not None else -1, int(C), n_bucket, int(width),
+            int(height))
 
 
 def set_tile_culling(flag: bool) -> None:

@@ -143,11 +143,15 @@ def test_render_is_bit_identical_with_fused_lists(hip_device):
     dec = Sandwich(9, 3).to(dev)
     v = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
     res = {}
+    # ONE scene object for the three renders: list-length hints are kept per scene (rendering.hint_scope, round 6), and the
+    # single-pass path needs the hint its own previous frame left
+    stat = GaussianParams(stat_p, None, dec, dev, requires_grad=True)
+    dyn = GaussianParams(dyn_p, dyn_x, dec, dev, requires_grad=True)
     for fused in (False, True, True):
         R.FUSED_LISTS = fused
         try:
-            stat = GaussianParams(stat_p, None, dec, dev, requires_grad=True)
-            dyn = GaussianParams(dyn_p, dyn_x, dec, dev, requires_grad=True)
+            for p_ in (stat._xyz, dyn.control_xyz, stat._opacity):
+                p_.grad = None
             cam = PinholeCamera(W, H, scam.K, torch.eye(4), scam.time, scam.max_time, device=dev)
             before = R.fused_calls[0]
             out = render(cam, stat, dyn, None, torch.zeros(9, device=dev))

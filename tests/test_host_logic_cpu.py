@@ -222,3 +222,33 @@ def test_flow_head_outputs_are_used_the_way_the_reference_uses_them():
     o2 = _FlowHead.apply(a * 1.0, b * 1.0)
     with pytest.raises(RuntimeError, match="multiple views|view"):
         o2[0][..., 0] = o2[0][..., 0] / 2
+
+
+def test_hints_are_kept_per_scene_and_per_thread():
+    """rendering.hint_scope / scene_token (round 6): the workload key of arena capacities, list-length
+    hints and key-segment strides carries a token of the (static, dynamic) pair being rendered -- two scenes of equal size do
+    not share an entry, the token of a pair is stable, and the scope is thread-local."""
+    import threading
+    import torch
+    import mobgs_amd.rendering as R
+
+    class PC:
+        pass
+    s1, d1, s2, d2 = PC(), PC(), PC(), PC()
+    t1, t2 = R.scene_token(s1, d1), R.scene_token(s2, d2)
+    assert t1 != t2 and t1 == R.scene_token(s1, d1) and R.scene_token(s2, d1) not in (t1, t2)
+    dev = torch.device("cpu")
+    with R.hint_scope(t1):
+        k1 = R._workload_key(dev, 1, 300000, 1352, 1014)
+        seen = {}
+
+        def other():
+            seen["outside"] = R._workload_key(dev, 1, 300000, 1352, 1014)
+            with R.hint_scope(t2):
+                seen["k2"] = R._workload_key(dev, 1, 300000, 1352, 1014)
+        th = threading.Thread(target=other)
+        th.start()
+        th.join()
+        assert R._workload_key(dev, 1, 300000, 1352, 1014) == k1    # the other thread's scope did not leak into this one
+    assert k1[0] == t1 and seen["k2"][0] == t2 and seen["outside"][0] == 0 and k1[1:] == seen["k2"][1:]
+    assert R._workload_key(dev, 1, 300000, 1352, 1014)[0] == 0      # outside any scope: the operator API's shared entry
