@@ -148,7 +148,7 @@ def source_sha():
     comments and blank lines removed (a reworded comment does not make the counters stale)."""
     import re
     h = hashlib.sha256()
-    for f in ("raster.hip", "raster_bwd_mfma.hip", "raster_shared.h", "isect.hip", "common.h"):
+    for f in ("raster.hip", "raster_bwd_mfma.hip", "raster_shared.h", "decoder_shared.h", "isect.hip", "common.h"):
         with open(os.path.join(ROOT, "mobgs_amd", "csrc", f), "r", encoding="utf-8") as fh:
             text = fh.read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
