@@ -819,7 +819,7 @@ def main():
             try:
                 from mobgs_amd.graphed import GraphedCallable
                 tr.lambda_flow = 1e-2
-                fb = GraphedCallable(tr.forward_backward)
+                fb = GraphedCallable(tr.forward_backward, warmup=0)
                 fb()
 
                 def graphed_iteration():
@@ -847,7 +847,7 @@ def main():
                 try:
                     trs = TD.DeblurTrainer(str(dev), 20_000, 10_000, 512, 288, 2, iters=10000, lambda_flow=lam)
                     edt, _ = timed(trs.iteration, args.small_steps, 4, world, dist)
-                    fbs = GraphedCallable(trs.forward_backward)
+                    fbs = GraphedCallable(trs.forward_backward, warmup=0)
                     fbs()
 
                     def graphed_small():

@@ -307,11 +307,25 @@ class DeblurTrainer:
 
 
 def train(dev="cuda:0", iters=40, ns=4000, nd=2000, width=256, height=192, n_views=2, seed=0, lambda_flow=1e-2,
-          shard=None, log=None):
+          shard=None, log=None, graph=False):
+    """graph=True (single process): forward + losses + backward of the iteration recorded ONCE as a HIP graph
+    (mobgs_amd.graphed.GraphedCallable) and replayed, the Adam step outside -- for small images / few Gaussians, where an
+    iteration is ~1400 launches and bound by the host (the reference's own 512x288 / 30 k operating point: 9.5 -> 7.5 ms)."""
     t = DeblurTrainer(dev, ns, nd, width, height, n_views, seed, lambda_flow, shard, iters)
     history = []
+    fb = None
     for it in range(1, iters + 1):
-        history.append(float(t.iteration()))
+        if graph and it == 2 and not t.shard.collective:   # (iteration 1 ran eagerly: arenas and hints exist)
+            from mobgs_amd.graphed import GraphedCallable
+            fb = GraphedCallable(t.forward_backward, warmup=0)
+        if fb is not None:
+            photo = fb()
+            t.optimizer_step()
+            if it % 50 == 0 and not fb.check():   # (a synchronisation; an arena outgrown by the moving scene: record again)
+                fb.recapture()
+            history.append(float(photo))
+        else:
+            history.append(float(t.iteration()))
         if it == 2:   # everything long-lived exists now: keep Python's cyclic collector off it (66 ms per generation-2
             import gc  # pass over a torch process's objects on this host, in the middle of an iteration: DESIGN section 5)
             gc.collect()
@@ -328,6 +342,7 @@ if __name__ == "__main__":
     ap.add_argument("--nd", type=int, default=10000)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--height", type=int, default=288)
+    ap.add_argument("--graph", action="store_true", help="replay forward + backward as one HIP graph (single process)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -335,4 +350,4 @@ if __name__ == "__main__":
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    train(dev=f"cuda:{local}", iters=a.iters, ns=a.ns, nd=a.nd, width=a.width, height=a.height, log=10)
+    train(dev=f"cuda:{local}", iters=a.iters, ns=a.ns, nd=a.nd, width=a.width, height=a.height, log=10, graph=a.graph)

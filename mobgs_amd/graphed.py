@@ -166,8 +166,9 @@ class GraphedCallable:
     -- captured once into a HIP graph and replayed (round 6, VERDICT r5 item 7: the reference's own 512x288 operating point is
     bound by the host's ~1400 launches per iteration, not by the device).
 
-        fb = GraphedCallable(trainer.forward_backward)   # reads parameters / cameras / targets, writes the gradient buffer
-        loss = fb()                                      # first call: eager warm-up, capture; then: one graph launch
+        trainer.iteration()                              # an ordinary eager iteration first: arenas and hints exist
+        fb = GraphedCallable(trainer.forward_backward, warmup=0)   # reads parameters / cameras / targets, writes the gradients
+        loss = fb()                                      # first call: capture + one replay; then: one graph launch
         fused_adam_step(optimizers)                      # NOT inside: its bias corrections are host scalars of the step count
         fb.check() / fb.recapture()                      # as GraphedRenderStep
 
@@ -200,10 +201,12 @@ class GraphedCallable:
         return self
 
     def __call__(self):
+        """One execution of fn (a capture records, it does not execute: the call that captures replays once as well).  With
+        warmup > 0 that first call ALSO ran fn eagerly `warmup` times -- harmless for a pure function of the parameters, not
+        for one that accumulates (densification statistics): capture with warmup = 0 after an ordinary eager iteration then."""
         if self.graph is None:
             self.capture()
-        else:
-            self.graph.replay()
+        self.graph.replay()
         return self.result
 
     def check(self) -> bool:

@@ -54,7 +54,7 @@ def where(diff):
     return f"words {lo}..{hi} (param floats {tr.bucket.param_floats}): " + ", ".join(names[:8])
 
 
-fb = GraphedCallable(tr.forward_backward)
+fb = GraphedCallable(tr.forward_backward, warmup=0)
 loss = fb()            # warm-up (eager) + capture
 fb()                   # a replay
 torch.cuda.synchronize()

@@ -150,7 +150,7 @@ def test_whole_training_iteration_as_one_graph(hip_device, lambda_flow):
     tr.forward_backward()
     torch.cuda.synchronize()
     ref = tr.bucket.flat.clone()
-    fb = GraphedCallable(tr.forward_backward)
+    fb = GraphedCallable(tr.forward_backward, warmup=0)
     loss0 = fb()                      # eager warm-up + capture
     fb()                              # a replay
     torch.cuda.synchronize()

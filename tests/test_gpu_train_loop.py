@@ -51,6 +51,18 @@ def test_miniature_deblur_training_loop(hip_device):
     assert sum(m > 0 for m in moved) >= 20, "BLCE parameters must receive gradients through the warped cameras"
 
 
+def test_graphed_deblur_training_loop_tracks_the_eager_one(hip_device):
+    """train(graph=True): the loop with forward + backward replayed as ONE HIP graph follows the eager loop's photometric
+    curve (lambda_flow_loss = 0, the shipped configs: every kernel of the iteration is deterministic, so the two loops are the
+    SAME computation -- the curves agree to the last bit) and its arenas fit."""
+    import train_deblur_synth as T
+    kw = dict(dev=str(hip_device), iters=12, ns=3000, nd=1500, width=192, height=144, seed=2, lambda_flow=0.0)
+    eager = T.train(**kw)[0]
+    graphed = T.train(graph=True, **kw)[0]
+    assert eager == graphed, (eager, graphed)
+    assert graphed[-1] < graphed[0]
+
+
 def test_sharded_iteration_with_per_view_gradient_messages_tracks_the_single_process_loop(hip_device):
     """DeblurTrainer._iteration_sharded (per-view loss terms, SubframeShard.backward_by_view: one gradient message per
     view on the communication stream) on a ONE-rank gloo group with MOBGS_FORCE_COLLECTIVES=1 -- every exchange an
