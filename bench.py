@@ -812,7 +812,9 @@ def main():
                 "event_median_ms_per_iteration": round(umed, 2),
                 "what": "the same iteration as train.py:430-807 writes it, after the import swap alone: per view 9 render() "
                         "(train mode) + 9 get_flow() calls, l1_loss + ssim, the flow-consistency term as two F.grid_sample + "
-                        "two masked l1_loss (torch), loss.backward() into ordinary .grad tensors, three torch.optim.Adam steps "
+                        "two masked l1_loss (torch), loss.backward() into ordinary .grad tensors, three optimizer.step() calls "
+                        "(optim.FusedAdam -- the torch.optim.Adam subclass densify.TrainableGaussians.training_setup and "
+                        "blceKernel build: one launch each; a reference GaussianModel kept as is steps torch's Adam) "
                         "(DeblurTrainer.iteration_unchanged)"}
             # the same iteration with its forward + loss + backward recorded ONCE as a HIP graph (graphed.GraphedCallable;
             # the one-launch Adam step outside): at this size the iteration is device-bound -- what a graph removes is gaps

@@ -227,7 +227,8 @@ class DeblurTrainer:
         get_static = get_dynamic = True (train.py:441 and :512), one get_flow() per exposure (:570-579), l1_loss + ssim
         as two calls (:621-628), the flow-consistency term as torch statements (two F.grid_sample + two masked l1_loss,
         :651-671), loss.backward() into ordinary .grad tensors, viewspace_points.grad for the densification statistics
-        (:634-648) and the three torch.optim.Adam steps (:790-807).  None of the opt-in entry points (render_many,
+        (:634-648) and the three optimizer.step() calls (:790-807; the optimisers are optim.FusedAdam, the torch.optim.Adam
+        subclass TrainableGaussians.training_setup / blceKernel build: one launch per step() instead of ~8 per parameter group).  None of the opt-in entry points (render_many,
         get_flow_many, flow_warp_loss, fused_adam_step, LeafGradSink, FlatGradients).  Single process."""
         import torch.nn.functional as F
         from mobgs_amd.gaussian_renderer import get_flow
