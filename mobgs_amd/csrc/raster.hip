@@ -1099,9 +1099,10 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
     // are never staged: their slots get their zeros here (lane = entry; the slot index by the same chain as below)
     const bool cover = !FILTER && cls.cover != 0;
     if (cover && (!HEAVY || quad == 0)) {
-        for (int base = e - 1; base > top; base -= 64) {
+        const int lo = max(top, s - 1);   // (top may lie far below the list when no pixel of the tile is valid: stop at the list)
+        for (int base = e - 1; base > lo; base -= 64) {
             const int idx = base - lane;
-            if (idx > top && idx >= s) {
+            if (idx > lo) {
                 const int g = flatten_ids[idx];
                 const float2 m = *reinterpret_cast<const float2*>(records + (size_t)g * RS);
                 const TileRect tr = tile_rect(m.x, m.y, radii[g], tile_w, tile_h);
