@@ -1099,10 +1099,13 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
     // are never staged: their slots get their zeros here (lane = entry; the slot index by the same chain as below)
     const bool cover = !FILTER && cls.cover != 0;
     if (cover && (!HEAVY || quad == 0)) {
-        const int lo = max(top, s - 1);   // (top may lie far below the list when no pixel of the tile is valid: stop at the list)
-        for (int base = e - 1; base > lo; base -= 64) {
+        // (base >= s: `top` = -1 when no pixel of the tile is valid -- far below a list that starts at s; without the second
+        // condition such a tile walked down to index 0: ~40 us of a launch whose cotangents vanish on a third of the image.
+        // Of five ways to write the bound this one disturbs the allocator's choices in the main loop least: +3 us on the lean
+        // step against +4 .. +7, profiles/r06/ab_cover_preloop_bound.txt)
+        for (int base = e - 1; base > top && base >= s; base -= 64) {
             const int idx = base - lane;
-            if (idx > lo) {
+            if (idx > top && idx >= s) {
                 const int g = flatten_ids[idx];
                 const float2 m = *reinterpret_cast<const float2*>(records + (size_t)g * RS);
                 const TileRect tr = tile_rect(m.x, m.y, radii[g], tile_w, tile_h);
