@@ -1100,7 +1100,8 @@ __device__ __forceinline__ void composite_bwd(int tile, int quad, int wv, int la
     const bool cover = !FILTER && cls.cover != 0;
     if (cover && (!HEAVY || quad == 0)) {
         // (base >= s: `top` = -1 when no pixel of the tile is valid -- far below a list that starts at s; without the second
-        // condition such a tile walked down to index 0: ~40 us of a launch whose cotangents vanish on a third of the image.
+        // condition such a tile walked down to index 0: the whole backward pass 0.50 -> 0.67 ms with a third of the image
+        // without cotangents, 0.43 -> 1.16 ms with two thirds (scripts/r06/dead_tiles_probe.py).
         // Of five ways to write the bound this one disturbs the allocator's choices in the main loop least: +3 us on the lean
         // step against +4 .. +7, profiles/r06/ab_cover_preloop_bound.txt)
         for (int base = e - 1; base > top && base >= s; base -= 64) {
