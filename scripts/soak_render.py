@@ -20,6 +20,7 @@ from mobgs_amd.helper_model import Sandwich  # noqa: E402
 from mobgs_amd.synth import SynthCamera, dynamic_extras, gaussian_cloud  # noqa: E402
 from oracle import render_torch as R  # noqa: E402
 
+MASKED = False   # --masked: cotangents vanish on random bands of the image (tiles without a valid pixel: cover_slots' pre-loop)
 LEAVES = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_t", "_omega", "control_xyz")
 
 
@@ -48,6 +49,12 @@ def run_case(rng, i, dev):
     g = torch.Generator().manual_seed(seed + 5)
     bg0 = torch.rand(9, generator=g) if rng.random() < 0.5 else torch.zeros(9)
     v3, v1 = torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g)
+    if MASKED:   # a masked loss: a band of rows and a band of columns carry no cotangent at all (whole tiles without a valid pixel)
+        r0, r1 = sorted(int(x) for x in rng.integers(0, H + 1, 2))
+        c0, c1 = sorted(int(x) for x in rng.integers(0, W + 1, 2))
+        for v_ in (v3, v1):
+            v_[:, r0:r1] = 0
+            v_[:, :, c0:c1] = 0
     torch.manual_seed(seed)
     dec = Sandwich(9, 3)
     res = {}
@@ -224,6 +231,11 @@ def run_many_case(rng, i, dev):
     bg0 = torch.rand(9, generator=g) if rng.random() < 0.5 else torch.zeros(9)
     v3 = [torch.randn(3, H, W, generator=g) for _ in range(K)]
     v1 = [torch.randn(1, H, W, generator=g) for _ in range(K)]
+    if MASKED:
+        for k in range(K):
+            r0, r1 = sorted(int(x) for x in rng.integers(0, H + 1, 2))
+            for v_ in (v3[k], v1[k]):
+                v_[:, r0:r1] = 0
     torch.manual_seed(seed)
     dec = Sandwich(9, 3)
     res = {}
@@ -308,7 +320,9 @@ if __name__ == "__main__":
     ap.add_argument("--headline", action="store_true",
                     help="the benchmark's kernel selection on these small images: one wave per tile (heavy_tile_len = 0), the "
                          "quadrant backward (bwd_mfma = 0) -- with it the decoder prologue and cover_slots of round 6")
+    ap.add_argument("--masked", action="store_true", help="cotangents that vanish on random bands of the image (masked losses)")
     a = ap.parse_args()
+    MASKED = a.masked
     if a.headline:
         import mobgs_amd.rendering as _R
         _R.tuning.heavy_tile_len = 0
