@@ -629,6 +629,21 @@ def _log_path(direction, D, tl, class_filter=False, tn=None, **extra):
                          heavy_len=bits >> 8, heavy_tiles=heavy, **extra))
 
 
+_path_bits_cache = {}
+
+
+def _raster_path_bits(D: int, nt: int) -> int:
+    """mobgs_raster_path(D, 0, nt, tuning) -- which kernels a plain pass takes -- cached per (D, grid, policy fields): the
+    backward node asks once per call, and a ctypes call + a pointer object cost the host ~5 us each time."""
+    key = (int(D), int(nt), tuning.heavy_tile_len, tuning.bwd_mfma, tuning.bwd_block_walk, tuning.block_walk)
+    bits = _path_bits_cache.get(key)
+    if bits is None:
+        if len(_path_bits_cache) > 256:
+            _path_bits_cache.clear()
+        bits = _path_bits_cache[key] = int(_lib_().mobgs_raster_path(int(D), 0, int(nt), tuning.ref()))
+    return bits
+
+
 def _refuse_token(colors, packed, who):
     """The fused prep path hands a colour TOKEN through render() (SharedProjection.from_raw): never-written storage that
     stands for "the records the projection kernel packed".  A consumer about to read it as an array stops here."""
@@ -786,7 +801,7 @@ class _Rasterize(torch.autograd.Function):
         F = _fast.get()
         gated = bool(ctx.gate) and tuning.bwd_block_walk != 1
         nt = tl.C * tl.tile_w * tl.tile_h
-        quadrant = tuning.bwd_block_walk != 1 and (lib.mobgs_raster_path(D, 0, nt, tuning.ref()) & 3) == 0
+        quadrant = tuning.bwd_block_walk != 1 and (_raster_path_bits(D, nt) & 3) == 0
         cover = COVER_SLOTS and quadrant and not gated   # the kernel writes every slot: no zero fill, no flag
         tn = _tuning_variant(gated, ctx.static_rows, cover)
         g_c2w = g_w1 = g_w2 = None
