@@ -47,7 +47,10 @@ def test_render_without_the_slot_fill_is_bit_identical(hip_device, W, H, ns, nd,
             res[cover] = [stat._xyz.grad.clone(), stat._features_dc.grad.clone(), stat._scaling.grad.clone(),
                           stat._opacity.grad.clone(), dyn.control_xyz.grad.clone(), dyn._opacity.grad.clone(),
                           dyn._features_t.grad.clone(), out["viewspace_points"].grad.clone(),
-                          cam.world_view_transform.grad.clone()]
+                          cam.world_view_transform.grad.clone(),
+                          # (with the decoder prologue these two are sums over the per-tile rows of a torch.empty scratch:
+                          # a row the kernel did not write would be one of the poison's NaNs)
+                          dyn.rgbdecoder.mlp1.weight.grad.clone(), dyn.rgbdecoder.mlp2.weight.grad.clone()]
     finally:
         R.COVER_SLOTS, R.FUSE_DECODER_BWD, R.tuning.heavy_tile_len, R.tuning.bwd_mfma = saved
     for a, b in zip(res[False], res[True]):
