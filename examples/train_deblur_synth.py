@@ -322,7 +322,11 @@ def train(dev="cuda:0", iters=40, ns=4000, nd=2000, width=256, height=192, n_vie
         if fb is not None:
             photo = fb()
             t.optimizer_step()
-            if it % 50 == 0 and not fb.check():   # (a synchronisation; an arena outgrown by the moving scene: record again)
+            # the counts of the replays land in pinned rows; reading them WITHOUT a synchronisation sees the last completed
+            # replay (a lag of one or two iterations): an arena outgrown by the moving scene -- its frame saw empty lists,
+            # i.e. a background image and no splat gradients -- is noticed here and the iteration recorded again
+            if not fb.check():
+                torch.cuda.synchronize()
                 fb.recapture()
             history.append(float(photo))
         else:

@@ -115,8 +115,10 @@ extern "C" {
  *                      zero-fill grad_slots (108 MB at 1352x1014 / 300 k splats: a 15-us fill per render, 9 of them per
  *                      blurry view) -- the kernel writes the slot of EVERY entry of its lists, zeros where no pixel blended
  *                      the splat (entries behind every pixel's last blended one included), so mobgs_raster_bwd_reduce
- *                      sums exactly what it would have; pass any_record = NULL to both stages then (the flag would live in
- *                      unwritten memory).  Honoured only where the quadrant kernel runs ((mobgs_raster_path(D, 0, n_tiles,
+ *                      sums exactly what it would have; stage 1 takes any_record = NULL then (the flag would live in unwritten
+ *                      memory), stage 2 takes as its any_record the address of tile_offsets[n_tiles] -- the lists' total, 0
+ *                      when a speculative binning call overflowed an arena and emptied the lists: without a host in the
+ *                      loop (a HIP-graph replay) keep_scan and the slot ranges of such a frame must not be read.  Honoured only where the quadrant kernel runs ((mobgs_raster_path(D, 0, n_tiles,
  *                      tuning) & 3) == 0; other selections return MOBGS_E_UNSUPPORTED) and not together with
  *                      gate_zero_cotangent (a gated-off pass writes nothing).  Gradients are bit-identical. */
 typedef struct MobgsTuning {

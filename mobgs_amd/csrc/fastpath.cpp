@@ -334,14 +334,16 @@ raster_bwd_decode_finish(int64_t C, int64_t width, int64_t height, const Tensor&
 // -> (v_means2d, v_conics, v_opac, v_colors, v_extra, g_c2w | None, g_w1, g_w2)
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, OptT, Tensor, Tensor>
 raster_bwd_reduce_decode(int64_t C, int64_t N, int64_t width, int64_t height, const Tensor& records, const Tensor& cum_tiles,
-                         const Tensor& keep_scan, const Tensor& slots, const OptT& tiles_per_gauss, bool use_flag,
+                         const Tensor& keep_scan, const Tensor& slots, const OptT& tiles_per_gauss, int64_t flag_ptr,
                          const Tensor& partial, const Tensor& c2w, const Tensor& w1, const Tensor& w2, bool c2w_needs_grad,
                          const OptT& g_w1_in, const OptT& g_w2_in, int64_t accumulate, int64_t stream) {
     const auto f = slots.options();
     Tensor v_means2d = at::empty({C, N, 2}, f), v_conics = at::empty({C, N, 3}, f), v_opac = at::empty({C, N}, f),
            v_colors = at::empty({C, N, 9}, f), v_extra = at::empty({C, N}, f);
-    const int32_t* flag =
-        use_flag ? reinterpret_cast<const int32_t*>(fp(slots) + (slots.size(0) - 1) * slots.size(1)) : nullptr;
+    // flag_ptr: -1 = the first word of the slots' extra row (stage 1 set it), else the address of a device int32 that is 0 when
+    // no slot may be read (the lists' total: cover_slots mode) or 0 = none
+    const int32_t* flag = flag_ptr == -1 ? reinterpret_cast<const int32_t*>(fp(slots) + (slots.size(0) - 1) * slots.size(1))
+                                         : reinterpret_cast<const int32_t*>(static_cast<uintptr_t>(flag_ptr));
     const bool sunk = g_w1_in.has_value() && g_w1_in->defined();
     Tensor g_w1 = sunk ? *g_w1_in : at::empty_like(w1);
     Tensor g_w2 = sunk ? *g_w2_in : at::empty_like(w2);
@@ -361,13 +363,13 @@ raster_bwd_reduce_decode(int64_t C, int64_t N, int64_t width, int64_t height, co
 std::tuple<Tensor, Tensor, Tensor, Tensor, OptT>
 raster_bwd_reduce(int64_t C, int64_t N, int64_t channels, int64_t has_extra, const Tensor& records,
                   const Tensor& cum_tiles, const Tensor& keep_scan, const Tensor& slots, int64_t stream,
-                  const OptT& tiles_per_gauss, bool use_flag) {
+                  const OptT& tiles_per_gauss, int64_t flag_ptr) {
     const auto f = slots.options();
     Tensor v_means2d = at::empty({C, N, 2}, f), v_conics = at::empty({C, N, 3}, f), v_opac = at::empty({C, N}, f),
            v_colors = at::empty({C, N, channels}, f);
     OptT v_extra = has_extra ? OptT(at::empty({C, N}, f)) : OptT();
-    const int32_t* flag =
-        use_flag ? reinterpret_cast<const int32_t*>(fp(slots) + (slots.size(0) - 1) * slots.size(1)) : nullptr;
+    const int32_t* flag = flag_ptr == -1 ? reinterpret_cast<const int32_t*>(fp(slots) + (slots.size(0) - 1) * slots.size(1))
+                                         : reinterpret_cast<const int32_t*>(static_cast<uintptr_t>(flag_ptr));   // (as above)
     check(api.raster_bwd_reduce((int)C, (int)N, (int)channels, (int)has_extra, fp(records), ip(cum_tiles), ip(keep_scan),
                                 fp(slots), flag, fpw(v_means2d), fpw(v_conics), fpw(v_opac), fpw(v_colors), fpw(v_extra),
                                 ip(tiles_per_gauss), sp(stream)),

@@ -466,13 +466,16 @@ layers_slot_reduce_kernel(int n_gauss, int channels, int has_extra, int stride, 
                           const float* __restrict__ grad_xy0, float* __restrict__ v_means2d_l0,
                           float* __restrict__ v_means2d, float* __restrict__ v_conics,
                           float* __restrict__ v_opacities, float* __restrict__ v_colors, float* __restrict__ v_extra,
-                          const int32_t* __restrict__ tiles_per_gauss) {
+                          const int32_t* __restrict__ tiles_per_gauss, const int32_t* __restrict__ lists_total) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / 16;
     const int comp = threadIdx.x % 16;
     if (gid >= n_gauss) return;
     // (with a caller-chosen enumeration order of the intersections only start + count is the end: mobgs_hip.h, enum_order)
     const int end_box = tiles_per_gauss ? cum_tiles[gid] + tiles_per_gauss[gid] : cum_tiles[gid + 1];
-    const int a = 2 * keep_index(keep_scan, cum_tiles[gid]), b = 2 * keep_index(keep_scan, end_box);
+    // lists_total = tile_offsets[n_tiles]: 0 when an arena overflowed and the lists were emptied (speculative binning without
+    // a host in the loop, e.g. a HIP-graph replay) -- keep_scan and the slot ranges are then NOT to be trusted: every sum is 0
+    const bool empty = lists_total && *lists_total == 0;
+    const int a = empty ? 0 : 2 * keep_index(keep_scan, cum_tiles[gid]), b = empty ? 0 : 2 * keep_index(keep_scan, end_box);
     float acc = 0.f;
     if (comp < stride) {
         const float* p = grad_slots + (size_t)a * stride + comp;
@@ -567,7 +570,8 @@ int mobgs_raster_layers_bwd(int C, int N, int Ns, int layer_mask, int channels, 
     if (n > 0)
         hipLaunchKernelGGL(layers_slot_reduce_kernel, dim3((int)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, n,
                            channels, has_extra, record_stride(D), cum_tiles, keep_scan, grad_slots, grad_xy0,
-                           v_means2d_layer0, v_means2d, v_conics, v_opacities, v_colors, v_extra, tiles_per_gauss);
+                           v_means2d_layer0, v_means2d, v_conics, v_opacities, v_colors, v_extra, tiles_per_gauss,
+                           tile_offsets ? tile_offsets + nt : nullptr);
     return check_launch("raster_layers_bwd_kernel");
 }
 

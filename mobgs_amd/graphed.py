@@ -210,7 +210,11 @@ class GraphedCallable:
         return self.result
 
     def check(self) -> bool:
-        """After a synchronisation: True when every arena of the replayed frames fitted."""
+        """True when every arena of the replayed frames fitted.  After a synchronisation: of ALL replays so far; without one:
+        of the replays that have completed (the counts land in pinned host rows -- a training loop can call this every
+        iteration for free and notices an outgrown arena one or two iterations late).  A frame whose arena overflowed saw EMPTY
+        tile lists: a background image, zero splat gradients, no out-of-bounds access (scripts/r06/overflow_probe.py) --
+        recapture() records the function again with the sizes it has learnt."""
         return self.static.check() if self.static is not None else True
 
     def recapture(self):

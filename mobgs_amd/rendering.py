@@ -629,6 +629,15 @@ def _log_path(direction, D, tl, class_filter=False, tn=None, **extra):
                          heavy_len=bits >> 8, heavy_tiles=heavy, **extra))
 
 
+def _lists_total_addr(tl) -> int:
+    """Address of tile_offsets[n_tiles] -- the total number of listed entries, 0 when an arena overflowed and the binning kernels
+    emptied the lists.  Handed to the slot reductions as their `any_record` word wherever stage 1 sets none (cover_slots, the
+    class passes): without a host in the loop (StaticCapacity / a HIP-graph replay) an overflowed frame's keep_scan and slot
+    ranges must not be read (found in round 6: a graphed training loop faulted when the scene outgrew its arenas)."""
+    to = tl.tile_offsets
+    return to.data_ptr() + 4 * (to.numel() - 1)
+
+
 _path_bits_cache = {}
 
 
@@ -852,8 +861,8 @@ class _Rasterize(torch.autograd.Function):
                         "mobgs_raster_bwd_decode_finish")
                 elif F is not None:
                     v_means2d, v_conics, v_opac, v_colors, v_extra, g_c2w, g_w1, g_w2 = F.raster_bwd_reduce_decode(
-                        C, N, width, height, records, tl.cum_tiles, tl.keep_scan, slots, tl.tiles_per_gauss, not cover,
-                        partial, c2w, w1, w2, bool(ctx.dec_c2w_needs_grad), sunk[0] if sunk is not None else None,
+                        C, N, width, height, records, tl.cum_tiles, tl.keep_scan, slots, tl.tiles_per_gauss,
+                        _lists_total_addr(tl) if cover else -1, partial, c2w, w1, w2, bool(ctx.dec_c2w_needs_grad), sunk[0] if sunk is not None else None,
                         sunk[1] if sunk is not None else None, sunk[2] if sunk is not None else 0, stream_int())
                 else:
                     if sunk is not None:
@@ -866,7 +875,7 @@ class _Rasterize(torch.autograd.Function):
                     v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
                     v_colors = torch.empty(C, N, channels, dtype=torch.float32, device=dev)
                     v_extra = torch.empty(C, N, dtype=torch.float32, device=dev)
-                    flag2 = None if cover else ctypes.c_void_p(slots.data_ptr() + 4 * max(tl.n_isects, 1) * stride)
+                    flag2 = ctypes.c_void_p(_lists_total_addr(tl) if cover else slots.data_ptr() + 4 * max(tl.n_isects, 1) * stride)
                     check(lib.mobgs_raster_bwd_reduce_decode(
                         C, N, ptr(records), ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(slots), flag2, ptr(v_means2d),
                         ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra), ptr(tl.tiles_per_gauss), width, height,
@@ -892,10 +901,10 @@ class _Rasterize(torch.autograd.Function):
             if F is not None:
                 v_means2d, v_conics, v_opac, v_colors, v_extra = F.raster_bwd_reduce(
                     C, N, channels, int(has_extra), records, tl.cum_tiles, tl.keep_scan, slots, st, tl.tiles_per_gauss,
-                    not cover)
+                    _lists_total_addr(tl) if cover else -1)
             else:
                 rows = max(tl.n_isects, 1)
-                flag = None if cover else ctypes.c_void_p(slots.data_ptr() + 4 * rows * stride)
+                flag = ctypes.c_void_p(_lists_total_addr(tl) if cover else slots.data_ptr() + 4 * rows * stride)
                 v_means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
                 v_conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
                 v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
@@ -915,7 +924,7 @@ class _Rasterize(torch.autograd.Function):
                                      tl.flatten_ids, alphas, last_ids, v_render, v_alphas, reach, tn.address(), st, cover)
             v_means2d, v_conics, v_opac, v_colors, v_extra = F.raster_bwd_reduce(
                 C, N, channels, int(has_extra), records, tl.cum_tiles, tl.keep_scan, slots, st, tl.tiles_per_gauss,
-                not cover)
+                _lists_total_addr(tl) if cover else -1)
         else:
             v_render = f32c(v_render)
             v_alphas = f32c(v_alphas) if v_alphas is not None else None
@@ -935,7 +944,9 @@ class _Rasterize(torch.autograd.Function):
                                            ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(slots), ptr(reach),
                                            flag, tn.ref(), stream()), "mobgs_raster_bwd")
             check(lib.mobgs_raster_bwd_reduce(C, N, channels, int(has_extra), ptr(records), ptr(tl.cum_tiles),
-                                              ptr(tl.keep_scan), ptr(slots), flag, ptr(v_means2d), ptr(v_conics), ptr(v_opac),
+                                              ptr(tl.keep_scan), ptr(slots),
+                                              ctypes.c_void_p(_lists_total_addr(tl)) if cover else flag, ptr(v_means2d),
+                                              ptr(v_conics), ptr(v_opac),
                                               ptr(v_colors), ptr(v_extra), ptr(tl.tiles_per_gauss), stream()),
                   "mobgs_raster_bwd_reduce")
         if not colors_per_camera:
@@ -1267,7 +1278,9 @@ class _RasterizeClasses(torch.autograd.Function):
         v_opac = torch.empty(C, N, dtype=torch.float32, device=dev)
         v_colors = torch.empty(C, N, channels, dtype=torch.float32, device=dev)
         v_extra = torch.empty(C, N, dtype=torch.float32, device=dev)
-        check(lib.mobgs_raster_bwd_reduce(C, N, channels, 1, ptr(records), ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(slots), None,
+        # (any_record: the lists' total -- zero when an arena overflowed without a host in the loop: no slot is read then)
+        check(lib.mobgs_raster_bwd_reduce(C, N, channels, 1, ptr(records), ptr(tl.cum_tiles), ptr(tl.keep_scan), ptr(slots),
+                                          ctypes.c_void_p(_lists_total_addr(tl)),
                                           ptr(v_means2d), ptr(v_conics), ptr(v_opac), ptr(v_colors), ptr(v_extra),
                                           ptr(tl.tiles_per_gauss), stream()), "mobgs_raster_bwd_reduce")
         if not colors_per_camera:
