@@ -314,7 +314,7 @@ def train(dev="cuda:0", iters=40, ns=4000, nd=2000, width=256, height=192, n_vie
     iteration is ~1400 launches and bound by the host (the reference's own 512x288 / 30 k operating point: 9.5 -> 7.5 ms)."""
     t = DeblurTrainer(dev, ns, nd, width, height, n_views, seed, lambda_flow, shard, iters)
     history = []
-    fb = None
+    fb, pending = None, []
     for it in range(1, iters + 1):
         if graph and it == 2 and not t.shard.collective:   # (iteration 1 ran eagerly: arenas and hints exist)
             from mobgs_amd.graphed import GraphedCallable
@@ -322,9 +322,15 @@ def train(dev="cuda:0", iters=40, ns=4000, nd=2000, width=256, height=192, n_vie
         if fb is not None:
             photo = fb()
             t.optimizer_step()
-            # the counts of the replays land in pinned rows; reading them WITHOUT a synchronisation sees the last completed
-            # replay (a lag of one or two iterations): an arena outgrown by the moving scene -- its frame saw empty lists,
-            # i.e. a background image and no splat gradients -- is noticed here and the iteration recorded again
+            # the counts of the replays land in pinned rows: check() sees the replays that have COMPLETED.  The host enqueues a
+            # replay in a fraction of its run time, so it is kept at most two iterations ahead (an event per iteration) -- an
+            # arena outgrown by the moving scene (its frame saw empty lists: a background image, no splat gradients) is then
+            # noticed two iterations late at most, and the iteration recorded again
+            ev = torch.cuda.Event()
+            ev.record()
+            pending.append(ev)
+            if len(pending) > 2:
+                pending.pop(0).synchronize()
             if not fb.check():
                 torch.cuda.synchronize()
                 fb.recapture()

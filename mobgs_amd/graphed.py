@@ -211,8 +211,9 @@ class GraphedCallable:
 
     def check(self) -> bool:
         """True when every arena of the replayed frames fitted.  After a synchronisation: of ALL replays so far; without one:
-        of the replays that have completed (the counts land in pinned host rows -- a training loop can call this every
-        iteration for free and notices an outgrown arena one or two iterations late).  A frame whose arena overflowed saw EMPTY
+        of the replays that have COMPLETED (the counts land in pinned host rows) -- a training loop can call this every
+        iteration for free; the host enqueues replays far faster than they run, so bound its run-ahead (an event per iteration,
+        wait for the one two iterations back: examples/train_deblur_synth.py) and an outgrown arena is noticed that late.  A frame whose arena overflowed saw EMPTY
         tile lists: a background image, zero splat gradients, no out-of-bounds access (scripts/r06/overflow_probe.py) --
         recapture() records the function again with the sizes it has learnt."""
         return self.static.check() if self.static is not None else True

@@ -48,15 +48,22 @@ for graph in (False, True):
     torch.cuda.synchronize()
     print(f"training loop 512x288 / 30 k ({'graphed' if graph else 'eager'}):", mem())
     losses = []
+    recaptures = [0]
+    pending = []
     for w in range(3):
         t0 = time.perf_counter()
         for _ in range(100):
             if fb is not None:
                 losses.append(fb()); tr.optimizer_step()
+                ev = torch.cuda.Event(); ev.record(); pending.append(ev)
+                if len(pending) > 2:
+                    pending.pop(0).synchronize()   # the host stays at most two iterations ahead
+                if not fb.check():     # (sees the completed replays) an arena outgrown: record again
+                    torch.cuda.synchronize(); fb.recapture(); recaptures[0] += 1
             else:
                 losses.append(tr.iteration())
         torch.cuda.synchronize()
         ok = fb.check() if fb is not None else True
-        print(f"  iterations {100 * w:3d}..{100 * w + 99}: {(time.perf_counter() - t0) / 100 * 1e3:.3f} ms per iteration, loss {float(losses[-1]):.5f}, arenas fitted {ok}")
+        print(f"  iterations {100 * w:3d}..{100 * w + 99}: {(time.perf_counter() - t0) / 100 * 1e3:.3f} ms per iteration, loss {float(losses[-1]):.5f}, arenas fitted {ok}, recaptures so far {recaptures[0]}")
     print("  end:", mem())
     del tr, fb
