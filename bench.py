@@ -811,7 +811,8 @@ def main():
                 "ms_per_iteration_lambda_flow_loss_0": round(uzdt / args.train_steps * 1e3, 2),
                 "event_median_ms_per_iteration": round(umed, 2),
                 "what": "the same iteration as train.py:430-807 writes it, after the import swap alone: per view 9 render() "
-                        "(train mode) + 9 get_flow() calls, l1_loss + ssim, the flow-consistency term as two F.grid_sample + "
+                        "(train mode) + 9 get_flow() calls, l1_loss + ssim as two calls (the fused kernels, reached through the "
+                        "loss_utils shim of INTEGRATION.md), the flow-consistency term as two F.grid_sample + "
                         "two masked l1_loss (torch), loss.backward() into ordinary .grad tensors, three optimizer.step() calls "
                         "(optim.FusedAdam -- the torch.optim.Adam subclass densify.TrainableGaussians.training_setup and "
                         "blceKernel build: one launch each; a reference GaussianModel kept as is steps torch's Adam) "
